@@ -1,0 +1,46 @@
+"""Helpers shared by the golden-vector tests (mirror of tests/golden/make_goldens.py:summarize)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+CASES = {
+    # name: (signal_map, num_classes, B, S, missing, weight seed, input seed) -- as in make_goldens.py
+    'c1_ecg_only': ({'ECG': 'UNI'}, 4, 2, 16, None, 11, 101),
+    'c2_four_mod': ({'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}, 4, 3, 8, {'ABD': [1], 'PPG': [2], 'ECG': [1]}, 12, 102),
+    'c4_eog_pair': ({'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 4, {'EOG-R': [0]}, 14, 104),
+    'c5_shared_enc': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [0]}, 15, 105),
+}
+
+
+def summarize(t: torch.Tensor, k: int = 64) -> np.ndarray:
+    f = t.detach().double().flatten().cpu()
+    n = f.numel()
+    idx = torch.linspace(0, n - 1, k).long()
+    head = f[:k] if n >= k else torch.cat([f, f.new_zeros(k - n)])
+    return torch.cat([torch.stack([f.sum(), f.abs().sum(), f.norm()]), head, f[idx]]).numpy()
+
+
+def checksum(d: dict) -> float:
+    return float(sum(v.double().abs().sum() for v in d.values() if torch.isfinite(v).all()))
+
+
+def load(name: str):
+    return np.load(os.path.join(GOLDEN_DIR, f'{name}.npz'))
+
+
+def assert_summary_close(got: torch.Tensor, want: np.ndarray, rtol: float, atol: float, what: str = ''):
+    """Compare a tensor against either its full golden array or its golden summary vector."""
+    if want.shape == tuple(got.shape):
+        np.testing.assert_allclose(got.detach().cpu().double().numpy(), want, rtol=rtol, atol=atol, err_msg=what)
+        return
+    s = summarize(got)
+    assert s.shape == want.shape, f'{what}: neither full nor summary shape ({got.shape} vs {want.shape})'
+    # sums: scale atol by the abs-sum; pointwise entries: plain tolerances
+    np.testing.assert_allclose(s[3:], want[3:], rtol=rtol, atol=atol, err_msg=what + ' [samples]')
+    scale = max(want[1], 1e-30)
+    assert abs(s[0] - want[0]) <= rtol * scale + atol, f'{what} [sum] {s[0]} vs {want[0]}'
+    assert abs(s[1] - want[1]) <= rtol * scale + atol, f'{what} [abs-sum] {s[1]} vs {want[1]}'
+    assert abs(s[2] - want[2]) <= rtol * max(want[2], 1e-30) + atol, f'{what} [l2] {s[2]} vs {want[2]}'
