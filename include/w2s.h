@@ -1,0 +1,170 @@
+/*
+ * w2s.h -- C ABI of libw2s_hip.so, the MI355X (gfx950) implementation of the wav2sleep hot path.
+ *
+ * The reference (joncarter1/wav2sleep) is 100 % Python on stock PyTorch ATen ops; it has no FFI.  The
+ * boundary this library replaces is therefore "the ATen ops dispatched by Wav2Sleep.forward / the train
+ * step" (SURVEY.md 2.1 + 8a).  Each entry point below names the reference call site(s) it replaces.
+ * The Python host (wav2sleep_amd/lib.py) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; all tensors fp32 device memory owned by the CALLER,
+ *     16-byte aligned, ACTIVATIONS ARE CHANNELS-LAST: [B][L][C] (row = one time position, C contiguous);
+ *   - asynchronous on `stream` (a hipStream_t passed as void*), no internal sync, no allocation, no global
+ *     state => re-entrant across streams/devices and capturable into a hipGraph;
+ *   - return 0 on success, negative W2S_E* on error (never throws, never aborts).
+ */
+#ifndef W2S_H
+#define W2S_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2S_OK 0
+#define W2S_EINVAL (-1)     /* bad argument / unsupported shape */
+#define W2S_ELAUNCH (-2)    /* hipLaunch failure */
+
+/* ---- prologue (transform applied to the input operand while it is staged into LDS) ---- */
+#define W2S_PRO_NONE 0
+#define W2S_PRO_SANITIZE 1  /* inf -> 0                 models/wav2sleep.py:151 */
+#define W2S_PRO_GELU 2      /* GELU(x)                  blocks.py:70 (block output is stored pre-activation) */
+#define W2S_PRO_IN_GELU 3   /* GELU((x-mean)*rstd)      blocks.py:183-184 InstanceNorm1d(eps=1e-2)+GELU */
+#define W2S_PRO_INBWD 4     /* g_y = rstd*(g - s1 - n*s2), n=(x2-mean)*rstd   (instance-norm backward) */
+#define W2S_PRO_INBWD_GP 5  /* as 4 with g := g*GELU'(n) first */
+
+/* ---- epilogue (applied to the accumulator tile before the store) ---- */
+#define W2S_EPI_PLAIN 0
+#define W2S_EPI_STATS 1     /* store + per-(b,c) partial sum / sum-of-squares (instance-norm statistics) */
+#define W2S_EPI_AUX_INGELU_ADD 2 /* v += GELU(IN(aux))    blocks.py:68-69 residual join, stored pre-activation */
+#define W2S_EPI_BIAS 3      /* v += bias[c]; optional y2 = GELU(v) */
+#define W2S_EPI_GP 4        /* v = (v [+ add_even[t/2] if t even]) * GELU'(n(aux)); partial sums of v and v*n */
+
+/* ---- geometry modes ---- */
+#define W2S_MODE_CONTIG 0   /* dilation 1: one staged window serves all taps */
+#define W2S_MODE_DILATED 1  /* one staged window per tap: dilated convs (7,1) and the taps=4/stride=4 linears */
+#define W2S_MODE_UP2 2      /* transposed stride-2, 3 taps, pad 1 (data gradient of conv3) */
+
+/*
+ * Generic channels-last 1-D convolution as an implicit GEMM on the fp32 matrix cores.
+ *   y[b,t,o] = EPI( sum_{j<taps} sum_{c<cin} w[o][j][c] * PRO(x[b, t*stride + roff(j)*dil - pad, c]) )
+ * roff(j) = flip ? taps-1-j : j.  Rows outside [0,L_in) contribute zero (zero padding of the TRANSFORMED
+ * operand, as torch's Conv1d pads the activation).  Weight layout is [cout][taps][cin] (see w2s_repack).
+ * Replaces: F.conv1d in ConvLayer1D.forward (blocks.py:174), ConvBlock1D.downsample (blocks.py:68),
+ * nn.Linear in SignalEncoder.forward (wav2sleep.py:264, as taps=4/stride=4 over the [B,4S,C] map),
+ * the Linear/in_proj/out_proj GEMMs of nn.TransformerEncoderLayer (wav2sleep.py:286-296), the dilated
+ * convs of DilatedConvBlock (blocks.py:95-108) -- and their data gradients (flip / UP2 modes).
+ */
+typedef struct w2s_conv_args {
+  const float* x;          /* [B][L_in][ldx]  staged operand (or gradient g for PRO_INBWD*) */
+  const float* x2;         /* PRO_INBWD*: pre-norm tensor y, same geometry as x */
+  const float* w;          /* [cout][taps][cin] */
+  float* y;                /* [B][L_out][ldy] */
+  float* y2;               /* optional second output (GELU(v)) for EPI_BIAS, [B][L_out][ldy2] */
+  const float* pro_stats;  /* [B][cin][2] (mean, rstd) */
+  const float* pro_bstats; /* [B][cin][2] (s1, s2) */
+  const float* aux;        /* epilogue aux tensor [B][L_out][ld_aux] */
+  const float* aux_stats;  /* [B][cout][2] (mean, rstd) or NULL (then n = aux) */
+  const float* add_even;   /* EPI_GP: [B][L_out/2][cout] added at even t, or NULL */
+  const float* bias;       /* [cout] */
+  const float* rowkeep;    /* [B] multiplier on the stored value (0 for a missing modality) or NULL */
+  float* part;             /* EPI_STATS / EPI_GP: [B][ntiles][2][cout] partial sums, or NULL */
+  int32_t B, L_in, L_out, cin, cout, taps, stride, dil, pad, flip, mode;
+  int32_t ldx, ldy, ldy2, ld_aux;
+  int32_t pro, epi;
+} w2s_conv_args;
+
+/* positions per workgroup tile for (cin,cout); ntiles = ceil(L_out / tile) sizes `part`. */
+int w2s_conv_tile(const w2s_conv_args* a);
+int w2s_conv_forward(const w2s_conv_args* a, void* stream);
+
+/*
+ * Weight gradient: dW[o][j][c] = sum_{b,t} GY(g)[b,t,o] * H(x)[b, t*stride + j*dil - pad, c]
+ * GY/H are the same on-load transforms as above (pro_g on the gradient side, pro_h on the input side).
+ * Writes per-workgroup partial slabs; w2s_wgrad_reduce sums them deterministically into the torch-layout
+ * gradient.  Replaces the weight half of aten::convolution_backward / addmm backward.
+ */
+typedef struct w2s_wgrad_args {
+  const float* g;  const float* g2;        /* gradient side: g (and pre-norm y for INBWD*) [B][L_out][cout] */
+  const float* g_stats; const float* g_bstats;
+  const float* x;                          /* input side [B][L_in][cin] */
+  const float* x_stats;
+  float* slab;                             /* nslab raw-fragment slabs of cout*taps*cin floats */
+  int32_t B, L_in, L_out, cin, cout, taps, stride, dil, pad;
+  int32_t ldg, ldx;
+  int32_t pro_g, pro_h;
+  int32_t nslab;                           /* number of partial slabs = 4 * grid.x (one per wave) */
+} w2s_wgrad_args;
+int w2s_wgrad(const w2s_wgrad_args* a, void* stream);
+int w2s_wgrad_grid_y(int cin, int cout, int taps, int dil); /* grid.y of w2s_wgrad: slab floats = nslab*cout*cin*taps */
+/* grad (+)= sum_s slab[s]; layout 0: grad[o][c][j] (torch Conv1d), 1: grad[o][j][c] (Linear over the flattened taps) */
+int w2s_wgrad_reduce(const float* slab, int nslab, float* grad, int cout, int cin, int taps, int dil, int accumulate, int layout, void* stream);
+
+/* [cout][cin][taps] (torch) -> fwd pack [cout][taps][cin] and/or bwd pack [cin][taps][cout]; either dst may be NULL */
+int w2s_repack(const float* w, float* fwd, float* bwd, int cout, int cin, int taps, void* stream);
+
+/* partial sums [B][ntiles][2][C] -> per-(b,c) pairs [B][C][2]: kind 0 = (mean, rstd) with biased variance + eps
+ * (nn.InstanceNorm1d, models/utils.py:89-92), kind 1 = (sum1, sum2)/count.  fp64 accumulation, fixed order. */
+int w2s_stats_finalize(const float* part, int B, int ntiles, int C, long count, float eps, int kind, float* out, void* stream);
+
+/* First encoder layer, Cin = 1 (blocks.py:46, conv1 of block 0): y[b,t,o] = sum_j w[o][j]*san(x[b,t+j-1]);
+ * part [B][ceil(L/tile)][2][16] = partial sum / sum-of-squares.  w is the torch tensor [16][1][3]. */
+int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, void* stream);
+/* Block-0 residual join (blocks.py:67-69): pre[b,u,o] = GELU(IN(y3[b,u,o])) + wd[o]*san(x[b,2u]) */
+int w2s_enc_first_join(const float* x, const float* wd, const float* y3, const float* stats3, float* pre, int B, int L, int cout, void* stream);
+/* weight grads of block-0 conv1 / downsample; slab[nslab][64] = {dW1[o][j] (48), dWd[o] (16)}; sum with w2s_colsum */
+int w2s_enc_first_bwd(const float* x, const float* gn1, const float* y1, const float* stats1, const float* bstats1,
+                      const float* gpre, float* slab, int nslab, int B, int L, int cout, void* stream);
+/* pre-pass of conv3's backward: part [B][ceil(L/tile)][2][C] = partial sums of g*GELU'(n) and g*GELU'(n)*n, n = IN(y) */
+int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, void* stream);
+
+/* ---- row-wise ops on [rows][C] (nn.LayerNorm of the transformer; ConvLayerNorm models/utils.py:17-23) ---- */
+int w2s_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* rstat, int rows, int C,
+                      float eps, int gelu, void* stream);
+int w2s_layernorm_bwd(const float* g, int ldg, const float* x, int ldx, const float* gamma, const float* beta, const float* rstat,
+                      const float* gadd, float* gx, int ldgx, float* part_gamma, float* part_beta, int rows, int C, int gelu,
+                      int nparts, void* stream);
+int w2s_bias_grad(const float* g, int rows, int C, int ldg, float* part, int nparts, void* stream); /* part[p][c] = block column sums */
+int w2s_colsum(const float* part, int nparts, int C, int ld, float* out, int accumulate, void* stream); /* out[c] (+)= sum_p part[p*ld+c] */
+/* out[row][c] = g[row*ldg+c] * GELU'(pre[row][c]) * keep[row/rows_per_sample]  (encoder-output GELU backward) */
+int w2s_gelu_bwd_rows(const float* g, int ldg, const float* pre, const float* keep, int rows_per_sample, float* out, int rows, int C, void* stream);
+int w2s_fill_rows(float* dst, int ld, const float* src, int rows, int C, void* stream);             /* CLS rows, wav2sleep.py:330 */
+
+/* elementwise on n floats (n % 4 == 0).  Dropout masks are a pure function of (seed, element index). */
+#define W2S_ELT_GELU 0          /* y = GELU(a) */
+#define W2S_ELT_GELU_BWD 1      /* y = b * GELU'(a) */
+#define W2S_ELT_ADD 2           /* y = a + b */
+#define W2S_ELT_ADD_DROP 3      /* y = a + drop(b) */
+#define W2S_ELT_DROP 4          /* y = drop(a) */
+#define W2S_ELT_GELU_DROP 5     /* y = drop(GELU(a)) */
+#define W2S_ELT_GELU_DROP_BWD 6 /* y = drop(b) * GELU'(a) */
+int w2s_eltwise(int op, const float* a, const float* b, float* y, long n, float p_drop, uint64_t seed, void* stream);
+
+/* ---- set-fusion attention core: SDPA inside nn.MultiheadAttention (wav2sleep.py:286-296), D = 1+C tokens (2..7),
+ * head_dim 16, qkv [N*D][3*H*16], keypad [N][D] (1 = missing modality), out [N*D][H*16] ---- */
+int w2s_attn_fwd(const float* qkv, const uint8_t* keypad, float* out, int N, int D, int H, float p_drop, uint64_t seed, void* stream);
+int w2s_attn_bwd(const float* qkv, const uint8_t* keypad, const float* gout, float* gqkv, int N, int D, int H, float p_drop, uint64_t seed, void* stream);
+
+/* ---- classifier (wav2sleep.py:41,66), masked cross-entropy + confusion matrix (trainer/main.py:162-172) ---- */
+int w2s_head_fwd(const float* pre, int ld, const float* w, const float* bias, float* logits, int rows, int F, int nc, int gelu_in, void* stream);
+/* part: [ceil(rows/256)][2] scratch; loss_out[0] = mean NLL over labels != -1, loss_out[1] = count;
+ * glogits (optional) = gscale * dLoss/dlogits; cmat (optional) int64 [nc][nc] += counts (rows = true, cols = argmax) */
+int w2s_ce_fwd_bwd(const float* logits, const float* labels, int rows, int nc, float* part, float* loss_out, float* glogits,
+                   long long* cmat, float gscale, void* stream);
+/* gpre = (glogits . W) * (gelu_in ? GELU'(pre) : 1); part[nparts][nc*F + nc] = block partials of dW, db (sum with w2s_colsum) */
+int w2s_head_bwd(const float* pre, int ld, const float* w, const float* glogits, float* gpre, int ldg, float* part, int nparts,
+                 int rows, int F, int nc, int gelu_in, void* stream);
+
+/* ---- optimiser on the flat buffers: clip_grad_norm_(L2) + AdamW (training/main.yaml:21-22, optimizer/adamw.yaml) ----
+ * hyper (device, 8 floats): lr, weight_decay, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, max_norm (<= 0: no clipping)
+ * normcoef (device, 2 floats): total norm, clip coefficient */
+int w2s_sumsq_partial(const float* g, long n, float* part, int nparts, void* stream);
+int w2s_clip_coef(const float* part, int nparts, const float* hyper, float* normcoef, void* stream);
+int w2s_adamw(float* p, const float* g, float* m, float* v, long n, const float* hyper, const float* normcoef, void* stream);
+
+const char* w2s_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,43 @@
+// C-ABI entry of the channels-last implicit-GEMM convolution; kernels live in conv_cl.inl and are
+// instantiated per geometry in conv_inst_*.hip (split only to parallelise the build).
+#include "w2s_common.h"
+
+static inline int pick_nt(int cout) { return cout >= 128 ? 8 : cout >= 64 ? 4 : cout >= 32 ? 2 : 1; }
+int w2s_conv_dispatch_31(const w2s_conv_args& a, hipStream_t s);
+int w2s_conv_dispatch_32(const w2s_conv_args& a, hipStream_t s);
+int w2s_conv_dispatch_12(const w2s_conv_args& a, hipStream_t s);
+int w2s_conv_dispatch_11(const w2s_conv_args& a, hipStream_t s);
+int w2s_conv_dispatch_71d(const w2s_conv_args& a, hipStream_t s);
+int w2s_conv_dispatch_44d(const w2s_conv_args& a, hipStream_t s);
+int w2s_conv_dispatch_33d(const w2s_conv_args& a, hipStream_t s);
+int w2s_conv_dispatch_up2(const w2s_conv_args& a, hipStream_t s);
+int w2s_conv_tile_impl(int cin, int cout, int taps, int stride, int mode);
+
+extern "C" int w2s_conv_tile(const w2s_conv_args* a) { return w2s_conv_tile_impl(a->cin, a->cout, a->taps, a->stride, a->mode); }
+
+extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
+  if (!ap) return W2S_EINVAL;
+  const w2s_conv_args& a = *ap;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (a.cin < 16 || a.cin > 128 || (a.cin & (a.cin - 1)) || (a.cout & 15) || a.B <= 0 || a.L_out <= 0) return W2S_EINVAL;
+  if ((a.ldx & 3) || (a.ldy & 3) || !a.x || !a.w || !a.y) return W2S_EINVAL;
+  if (a.pro >= W2S_PRO_IN_GELU && !a.pro_stats) return W2S_EINVAL;
+  if (a.pro >= W2S_PRO_INBWD && (!a.pro_bstats || !a.x2)) return W2S_EINVAL;
+  if ((a.epi == W2S_EPI_AUX_INGELU_ADD && (!a.aux || !a.aux_stats)) || (a.epi == W2S_EPI_GP && !a.aux)) return W2S_EINVAL;
+  if (a.mode == W2S_MODE_UP2) {
+    if (a.taps != 3 || a.stride != 2) return W2S_EINVAL;
+    return w2s_conv_dispatch_up2(a, s);
+  }
+  if (a.mode == W2S_MODE_DILATED) {
+    if (a.taps == 7 && a.stride == 1) return w2s_conv_dispatch_71d(a, s);
+    if (a.taps == 4 && a.stride == 4) return w2s_conv_dispatch_44d(a, s);
+    if (a.taps == 3 && a.stride == 3) return w2s_conv_dispatch_33d(a, s);
+    return W2S_EINVAL;
+  }
+  if (a.dil != 1) return W2S_EINVAL;
+  if (a.taps == 3 && a.stride == 1) return w2s_conv_dispatch_31(a, s);
+  if (a.taps == 3 && a.stride == 2) return w2s_conv_dispatch_32(a, s);
+  if (a.taps == 1 && a.stride == 2) return w2s_conv_dispatch_12(a, s);
+  if (a.taps == 1 && a.stride == 1) return w2s_conv_dispatch_11(a, s);
+  return W2S_EINVAL;
+}

@@ -1,0 +1,292 @@
+// Channels-last 1-D convolution as an implicit GEMM on the gfx950 fp32 matrix cores.
+//
+// One workgroup (256 threads = 4 waves) produces a tile of TM = 64*MT consecutive output positions of ONE
+// sample for NT*16 output channels.  The input window is staged ONCE into LDS through registers with the
+// producer's normalisation + activation applied on the way (instance-norm statistics are a global
+// reduction over ~1M positions, so conv -> norm -> GELU cannot be fused forwards; instead the conv writes
+// the PRE-norm tensor + partial statistics and the consumer normalises on load).  Each wave then owns
+// 16*MT positions x all NT*16 channels and walks K = taps*cin in chunks of 16:
+//   B operand (activations): ONE ds_read_b128 per lane feeds 4 MFMAs (the 4 k-slots of an MFMA are the
+//       lane groups l>>4, so K is permuted as k = 16q + 4*(l>>4) + e, e = MFMA index);
+//   A operand (weights [cout][taps][cin]): one global_load_dwordx4 per lane per n-tile, L1/L2 resident;
+//   D fragment: lane (r = l&15, g = l>>4) holds 4 consecutive channels 4g..4g+3 of position r
+//       => one coalesced 16-B store per lane, a wave writes whole rows.
+// Reference ops replaced: see include/w2s.h (w2s_conv_args).
+#pragma once
+#include "w2s_common.h"
+
+struct ConvP {
+  w2s_conv_args a;
+  int ntiles;
+};
+
+// ---- on-load transform of one float4 (4 consecutive channels) --------------------------------------
+__device__ __forceinline__ f32x4 pro_apply(int pro, f32x4 v, f32x4 v2, f32x4 mean, f32x4 rstd, f32x4 s1, f32x4 s2) {
+  switch (pro) {
+    case W2S_PRO_SANITIZE:
+      v.x = sanitize_f(v.x); v.y = sanitize_f(v.y); v.z = sanitize_f(v.z); v.w = sanitize_f(v.w);
+      return v;
+    case W2S_PRO_GELU:
+      return gelu4(v);
+    case W2S_PRO_IN_GELU:
+      return gelu4((v - mean) * rstd);
+    case W2S_PRO_INBWD: {
+      f32x4 n = (v2 - mean) * rstd;
+      return rstd * (v - s1 - n * s2);
+    }
+    case W2S_PRO_INBWD_GP: {
+      f32x4 n = (v2 - mean) * rstd;
+      f32x4 gn = v * gelu_grad4(n);
+      return rstd * (gn - s1 - n * s2);
+    }
+    default:
+      return v;
+  }
+}
+
+template <int NT, int MT, int TAPS, int STRIDE, int MODE>
+__global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
+  extern __shared__ f32x4 smem4[];
+  float* smem = reinterpret_cast<float*>(smem4);
+  const w2s_conv_args& a = P.a;
+  constexpr int TM = 64 * MT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, tile = blockIdx.x, n0 = blockIdx.y * (NT * 16);
+  const int t0 = tile * TM;
+  const int cin = a.cin, RS = cin + 4, c4n = cin >> 2, rstep = 256 / c4n;
+  const int K = TAPS * cin;
+  const int L_in = a.L_in, L_out = a.L_out;
+  const int pro = a.pro;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-thread channel-group parameters for the on-load transform
+  const int myc4 = tid % c4n, row0 = tid / c4n;
+  f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, ps1 = {0, 0, 0, 0}, ps2 = {0, 0, 0, 0};
+  if (pro >= W2S_PRO_IN_GELU) {
+    const float* st = a.pro_stats + ((size_t)b * cin + myc4 * 4) * 2;
+    f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+    pm = (f32x4){s01.x, s01.z, s23.x, s23.z};
+    pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+    if (pro >= W2S_PRO_INBWD) {
+      const float* bs = a.pro_bstats + ((size_t)b * cin + myc4 * 4) * 2;
+      f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
+      ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z};
+      ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
+    }
+  }
+  const float* xb = a.x + (size_t)b * L_in * a.ldx + myc4 * 4;
+  const float* x2b = (pro >= W2S_PRO_INBWD) ? a.x2 + (size_t)b * L_in * a.ldx + myc4 * 4 : nullptr;
+
+  auto stage = [&](int rb, int NR, int rowmul) {
+    constexpr int U = 4;
+    for (int row = row0; row < NR; row += rstep * U) {
+      f32x4 v[U], v2[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rr = row + u * rstep, gr = rb + rr * rowmul;
+        const bool ok = (rr < NR) && (gr >= 0) && (gr < L_in);
+        v[u] = ok ? ld4(xb + (size_t)gr * a.ldx) : (f32x4){0, 0, 0, 0};
+        v2[u] = (ok && x2b) ? ld4(x2b + (size_t)gr * a.ldx) : (f32x4){0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rr = row + u * rstep, gr = rb + rr * rowmul;
+        if (rr < NR) {
+          const bool ok = (gr >= 0) && (gr < L_in);
+          f32x4 t = ok ? pro_apply(pro, v[u], v2[u], pm, pr, ps1, ps2) : (f32x4){0, 0, 0, 0};
+          st4(smem + rr * RS + myc4 * 4, t);
+        }
+      }
+    }
+  };
+
+  const int wm0 = wave * (16 * MT);  // first tile-local output position (or u-row for UP2) of this wave
+
+  auto mma_tap = [&](int jw, int rowoff, int mtmask) {
+    // jw: weight tap index; rowoff: LDS row offset added to the per-position row; mtmask: which m-tiles take part
+    for (int q = 0; q < (cin >> 4); ++q) {
+      f32x4 bf[MT], af[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        int row;
+        if (MODE == W2S_MODE_UP2) row = wave * (8 * MT) + (mt >> 1) * 16 + r + rowoff;
+        else if (MODE == W2S_MODE_DILATED) row = wm0 + mt * 16 + r;
+        else row = (wm0 + mt * 16 + r) * STRIDE + rowoff;
+        bf[mt] = *reinterpret_cast<const f32x4*>(smem + row * RS + q * 16 + 4 * g);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        af[nt] = ld4(a.w + (size_t)(n0 + nt * 16 + r) * K + jw * cin + q * 16 + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          if (mtmask & (1 << mt))
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(af[nt][e], bf[mt][e], acc[mt][nt]);
+    }
+  };
+
+  if (MODE == W2S_MODE_CONTIG) {
+    stage(t0 * STRIDE - a.pad, (TM - 1) * STRIDE + TAPS, 1);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) mma_tap(j, a.flip ? (TAPS - 1 - j) : j, (1 << MT) - 1);
+  } else if (MODE == W2S_MODE_DILATED) {
+    for (int j = 0; j < TAPS; ++j) {
+      const int off = a.flip ? (TAPS - 1 - j) : j;
+      __syncthreads();
+      stage(t0 * STRIDE - a.pad + off * a.dil, TM, STRIDE);
+      __syncthreads();
+      mma_tap(j, 0, (1 << MT) - 1);
+    }
+  } else {  // UP2: output position t' = 2u + phase; phase = mt & 1
+    constexpr int EVEN = 0x55 & ((1 << MT) - 1), ODD = 0xAA & ((1 << MT) - 1);
+    stage(t0 / 2, TM / 2 + 1, 1);
+    __syncthreads();
+    mma_tap(1, 0, EVEN);  // t' = 2u   : W_1^T g[u]
+    mma_tap(2, 0, ODD);   // t' = 2u+1 : W_2^T g[u]
+    mma_tap(0, 1, ODD);   //            + W_0^T g[u+1]
+  }
+
+  // ------------------------------------ epilogue ------------------------------------
+  const int epi = a.epi;
+  const int cout = a.cout;
+  f32x4 sA[NT], sB[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { sA[nt] = (f32x4){0, 0, 0, 0}; sB[nt] = (f32x4){0, 0, 0, 0}; }
+  const float keep = a.rowkeep ? a.rowkeep[b] : 1.0f;
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int pos;
+    if (MODE == W2S_MODE_UP2) pos = t0 + 2 * (wave * (8 * MT) + (mt >> 1) * 16 + r) + (mt & 1);
+    else pos = t0 + wm0 + mt * 16 + r;
+    const bool valid = pos < L_out;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = n0 + nt * 16 + 4 * g;
+      f32x4 v = acc[mt][nt];
+      if (!valid) continue;
+      const size_t orow = (size_t)b * L_out + pos;
+      if (epi == W2S_EPI_BIAS) {
+        if (a.bias) v += ld4(a.bias + ch);
+      } else if (epi == W2S_EPI_AUX_INGELU_ADD) {
+        f32x4 ax = ld4(a.aux + orow * a.ld_aux + ch);
+        const float* st = a.aux_stats + ((size_t)b * cout + ch) * 2;
+        f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+        f32x4 mean = {s01.x, s01.z, s23.x, s23.z}, rstd = {s01.y, s01.w, s23.y, s23.w};
+        v += gelu4((ax - mean) * rstd);
+      } else if (epi == W2S_EPI_GP) {
+        f32x4 n = ld4(a.aux + orow * a.ld_aux + ch);
+        if (a.aux_stats) {
+          const float* st = a.aux_stats + ((size_t)b * cout + ch) * 2;
+          f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+          f32x4 mean = {s01.x, s01.z, s23.x, s23.z}, rstd = {s01.y, s01.w, s23.y, s23.w};
+          n = (n - mean) * rstd;
+        }
+        if (a.add_even && !(pos & 1)) v += ld4(a.add_even + ((size_t)b * (L_out >> 1) + (pos >> 1)) * cout + ch);
+        v = v * gelu_grad4(n);
+        sA[nt] += v;
+        sB[nt] += v * n;
+      } else if (epi == W2S_EPI_STATS) {
+        sA[nt] += v;
+        sB[nt] += v * v;
+      }
+      v = v * keep;
+      st4(a.y + orow * a.ldy + ch, v);
+      if (a.y2) st4(a.y2 + orow * a.ldy2 + ch, gelu4(v));
+    }
+  }
+
+  if ((epi == W2S_EPI_STATS || epi == W2S_EPI_GP) && a.part) {
+    // deterministic two-level reduction: 16 positions (shuffle) -> 4 waves (LDS) -> one partial per tile
+    __syncthreads();  // LDS window no longer needed
+    float* red = smem;  // [wave][nt][g][4][2]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 x1, x2;
+      x1.x = row16_sum(sA[nt].x); x1.y = row16_sum(sA[nt].y); x1.z = row16_sum(sA[nt].z); x1.w = row16_sum(sA[nt].w);
+      x2.x = row16_sum(sB[nt].x); x2.y = row16_sum(sB[nt].y); x2.z = row16_sum(sB[nt].z); x2.w = row16_sum(sB[nt].w);
+      if (r == 0) {
+        float* d = red + ((wave * NT + nt) * 4 + g) * 8;
+        st4(d, x1);
+        st4(d + 4, x2);
+      }
+    }
+    __syncthreads();
+    // NT*16 channels x 2 sums, one thread each
+    if (tid < NT * 32) {
+      const int k = tid / (NT * 16), c = tid % (NT * 16);
+      const int nt = c >> 4, gg = (c >> 2) & 3, e = c & 3;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[((w * NT + nt) * 4 + gg) * 8 + k * 4 + e];
+      a.part[(((size_t)b * P.ntiles + tile) * 2 + k) * cout + n0 + c] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (NT, MT): accumulators MT*NT <= 16 float4 (64 VGPRs) and staged window <= 72 KB (>= 2 workgroups / CU)
+static inline int pick_nt(int cout) { return cout >= 128 ? 8 : cout >= 64 ? 4 : cout >= 32 ? 2 : 1; }
+static inline int window_rows(int mt, int taps, int stride, int mode) {
+  const int tm = 64 * mt;
+  if (mode == W2S_MODE_CONTIG) return (tm - 1) * stride + taps;
+  if (mode == W2S_MODE_DILATED) return tm;
+  return tm / 2 + 1;
+}
+static inline int pick_mt(int cin, int cout, int taps, int stride, int mode) {
+  const int nt = pick_nt(cout);
+  int mt = nt <= 2 ? 4 : nt == 4 ? 2 : 1;
+  const int lo = (mode == W2S_MODE_UP2) ? 2 : (nt <= 2 ? 2 : 1);
+  if (mt < lo) mt = lo;
+  while (mt > lo && (size_t)window_rows(mt, taps, stride, mode) * (cin + 4) * 4 > 72 * 1024) mt >>= 1;
+  return mt;
+}
+
+
+template <int NT, int MT, int TAPS, int STRIDE, int MODE>
+static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
+  constexpr int TM = 64 * MT;
+  ConvP P;
+  P.a = a;
+  P.ntiles = (a.L_out + TM - 1) / TM;
+  const int NR = window_rows(MT, TAPS, STRIDE, MODE);
+  size_t lds = (size_t)NR * (a.cin + 4) * sizeof(float);
+  size_t red = (size_t)4 * NT * 4 * 8 * sizeof(float);
+  if (lds < red) lds = red;
+  dim3 grid(P.ntiles, a.cout / (NT * 16), a.B);
+  auto kern = conv_cl_kernel<NT, MT, TAPS, STRIDE, MODE>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return W2S_ELAUNCH;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+
+template <int TAPS, int STRIDE, int MODE>
+static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
+  const int nt = pick_nt(a.cout), mt = pick_mt(a.cin, a.cout, TAPS, STRIDE, MODE);
+  if (a.cout % (nt * 16)) return W2S_EINVAL;
+  if (nt == 1 && mt == 4) return launch_conv<1, 4, TAPS, STRIDE, MODE>(a, s);
+  if (nt == 1 && mt == 2) return launch_conv<1, 2, TAPS, STRIDE, MODE>(a, s);
+  if (nt == 2 && mt == 4) return launch_conv<2, 4, TAPS, STRIDE, MODE>(a, s);
+  if (nt == 2 && mt == 2) return launch_conv<2, 2, TAPS, STRIDE, MODE>(a, s);
+  if (nt == 4 && mt == 2) return launch_conv<4, 2, TAPS, STRIDE, MODE>(a, s);
+  if (nt == 8 && mt == 2) return launch_conv<8, 2, TAPS, STRIDE, MODE>(a, s);
+  if constexpr (MODE != W2S_MODE_UP2) {
+    if (nt == 4 && mt == 1) return launch_conv<4, 1, TAPS, STRIDE, MODE>(a, s);
+    if (nt == 8 && mt == 1) return launch_conv<8, 1, TAPS, STRIDE, MODE>(a, s);
+  }
+  return W2S_EINVAL;
+}

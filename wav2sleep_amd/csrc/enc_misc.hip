@@ -1,0 +1,258 @@
+// Encoder helper kernels that are not GEMM-shaped: the Cin = 1 first layer (HBM-bound, VALU), the block-0
+// residual join, instance-norm statistics finalisation and the conv3 backward pre-pass.
+// All reductions are two-level and fixed-order (no float atomics) so results are run-to-run identical.
+#include "w2s_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// y1[b,t,o] = sum_j w[o][j] * san(x[b,t+j-1]),  o < 16.  One thread = one position x 4 channels
+// (16-B store; 4 lanes cover a 64-B row; a wave writes 1 KiB contiguous).  blocks.py:46 with Cin = 1.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                            float* __restrict__ part, int L, int tile, int ntiles) {
+  __shared__ float red[4][4][8];
+  const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x;
+  const int og = tid & 3, lane = tid & 63, wave = tid >> 6;
+  float wr[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wr[i][j] = w[(og * 4 + i) * 3 + j];
+  const float* xb = x + (size_t)b * L;
+  float* yb = y + (size_t)b * L * 16;
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  const int t0 = tl * tile;
+  for (int p = tid >> 2; p < tile; p += 64) {
+    const int t = t0 + p;
+    if (t >= L) break;
+    const float xm = (t > 0) ? sanitize_f(xb[t - 1]) : 0.f;
+    const float xc = sanitize_f(xb[t]);
+    const float xp = (t + 1 < L) ? sanitize_f(xb[t + 1]) : 0.f;
+    f32x4 v;
+    v.x = wr[0][0] * xm + wr[0][1] * xc + wr[0][2] * xp;
+    v.y = wr[1][0] * xm + wr[1][1] * xc + wr[1][2] * xp;
+    v.z = wr[2][0] * xm + wr[2][1] * xc + wr[2][2] * xp;
+    v.w = wr[3][0] * xm + wr[3][1] * xc + wr[3][2] * xp;
+    st4(yb + (size_t)t * 16 + og * 4, v);
+    s1 += v;
+    s2 += v * v;
+  }
+  // reduce over lanes with equal og (lane bits 2..5), then over the 4 waves
+  float a[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float v = a[k];
+    v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    a[k] = v;
+  }
+  if (lane < 4) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[wave][lane][k] = a[k];
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int k = tid >> 4, c = tid & 15;  // k: 0 sum, 1 sumsq
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) s += red[wv][c >> 2][k * 4 + (c & 3)];
+    part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + c] = s;
+  }
+}
+
+extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, void* stream) {
+  if (!x || !w || !y || !part || cout != 16 || tile < 64 || (tile & 63)) return W2S_EINVAL;
+  const int ntiles = (L + tile - 1) / tile;
+  hipLaunchKernelGGL(enc_first_fwd_kernel, dim3(ntiles, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, y, part, L, tile,
+                     ntiles);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// pre[b,u,o] = GELU(IN(y3[b,u,o])) + wd[o] * san(x[b,2u])     (blocks.py:67-69, stored pre-activation)
+__global__ __launch_bounds__(256) void enc_first_join_kernel(const float* __restrict__ x, const float* __restrict__ wd,
+                                                             const float* __restrict__ y3, const float* __restrict__ stats3,
+                                                             float* __restrict__ pre, int L, int Lh) {
+  const int b = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // float4 index within the sample
+  if (i >= (size_t)Lh * 4) return;
+  const int u = (int)(i >> 2), og = (int)(i & 3);
+  const float* st = stats3 + ((size_t)b * 16 + og * 4) * 2;
+  f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+  f32x4 mean = {s01.x, s01.z, s23.x, s23.z}, rstd = {s01.y, s01.w, s23.y, s23.w};
+  f32x4 v = ld4(y3 + ((size_t)b * Lh + u) * 16 + og * 4);
+  const float xv = sanitize_f(x[(size_t)b * L + 2 * u]);
+  f32x4 o = gelu4((v - mean) * rstd) + ld4(wd + og * 4) * xv;
+  st4(pre + ((size_t)b * Lh + u) * 16 + og * 4, o);
+}
+
+extern "C" int w2s_enc_first_join(const float* x, const float* wd, const float* y3, const float* stats3, float* pre, int B, int L, int cout,
+                                  void* stream) {
+  if (!x || !wd || !y3 || !stats3 || !pre || cout != 16 || (L & 1)) return W2S_EINVAL;
+  const int Lh = L / 2;
+  hipLaunchKernelGGL(enc_first_join_kernel, dim3((Lh * 4 + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, wd, y3,
+                     stats3, pre, L, Lh);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// Weight gradients of block 0's conv1 (16x1x3) and downsample (16x1x1):
+//   dW1[o][j] = sum_{b,t} gy1[b,t,o] * san(x[b,t+j-1]),  gy1 = IN-backward(gn1; y1)
+//   dWd[o]    = sum_{b,u} gpre[b,u,o] * san(x[b,2u])
+// slab[wg][64]: [0..47] = dW1[o][j], [48..63] = dWd[o].  Sum the slabs with w2s_colsum.
+__global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gn1,
+                                                            const float* __restrict__ y1, const float* __restrict__ stats1,
+                                                            const float* __restrict__ bstats1, const float* __restrict__ gpre,
+                                                            float* __restrict__ slab, int B, int L) {
+  __shared__ float red[4][4][16];
+  const int tid = threadIdx.x, og = tid & 3, lane = tid & 63, wave = tid >> 6;
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  const int chunks = (L + 1023) / 1024;  // 1024 positions per work item
+  for (int item = blockIdx.x; item < B * chunks; item += gridDim.x) {
+    const int b = item / chunks, t0 = (item % chunks) * 1024;
+    const float* st = stats1 + ((size_t)b * 16 + og * 4) * 2;
+    f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+    f32x4 mean = {s01.x, s01.z, s23.x, s23.z}, rstd = {s01.y, s01.w, s23.y, s23.w};
+    const float* bs = bstats1 + ((size_t)b * 16 + og * 4) * 2;
+    f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
+    f32x4 q1 = {b01.x, b01.z, b23.x, b23.z}, q2 = {b01.y, b01.w, b23.y, b23.w};
+    const float* xb = x + (size_t)b * L;
+    for (int p = tid >> 2; p < 1024; p += 64) {
+      const int t = t0 + p;
+      if (t >= L) break;
+      const size_t off = ((size_t)b * L + t) * 16 + og * 4;
+      f32x4 n = (ld4(y1 + off) - mean) * rstd;
+      f32x4 gy = rstd * (ld4(gn1 + off) - q1 - n * q2);
+      const float xm = (t > 0) ? sanitize_f(xb[t - 1]) : 0.f;
+      const float xc = sanitize_f(xb[t]);
+      const float xp = (t + 1 < L) ? sanitize_f(xb[t + 1]) : 0.f;
+      acc[0] += gy.x * xm; acc[1] += gy.x * xc; acc[2] += gy.x * xp;
+      acc[3] += gy.y * xm; acc[4] += gy.y * xc; acc[5] += gy.y * xp;
+      acc[6] += gy.z * xm; acc[7] += gy.z * xc; acc[8] += gy.z * xp;
+      acc[9] += gy.w * xm; acc[10] += gy.w * xc; acc[11] += gy.w * xp;
+      if (!(t & 1)) {
+        f32x4 gp = ld4(gpre + ((size_t)b * (L >> 1) + (t >> 1)) * 16 + og * 4);
+        acc[12] += gp.x * xc; acc[13] += gp.y * xc; acc[14] += gp.z * xc; acc[15] += gp.w * xc;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float v = acc[k];
+    v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    acc[k] = v;
+  }
+  if (lane < 4) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) red[wave][lane][k] = acc[k];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // output index -> (og, k): dW1[o][j]: o = tid/3, j = tid%3 for tid < 48; dWd[o] = tid-48
+    int g4, k;
+    if (tid < 48) { const int o = tid / 3, j = tid % 3; g4 = o >> 2; k = (o & 3) * 3 + j; }
+    else { const int o = tid - 48; g4 = o >> 2; k = 12 + (o & 3); }
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) s += red[wv][g4][k];
+    slab[(size_t)blockIdx.x * 64 + tid] = s;
+  }
+}
+
+extern "C" int w2s_enc_first_bwd(const float* x, const float* gn1, const float* y1, const float* stats1, const float* bstats1,
+                                 const float* gpre, float* slab, int nslab, int B, int L, int cout, void* stream) {
+  if (!x || !gn1 || !y1 || !stats1 || !bstats1 || !gpre || !slab || cout != 16 || nslab <= 0) return W2S_EINVAL;
+  hipLaunchKernelGGL(enc_first_bwd_kernel, dim3(nslab), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gn1, y1, stats1, bstats1,
+                     gpre, slab, B, L);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// partial sums -> per-(b,c) statistics.  kind 0: (mean, rstd) with biased variance + eps
+// (nn.InstanceNorm1d, models/utils.py:89-92);  kind 1: (sum1/count, sum2/count).  fp64 accumulation.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, int ntiles, int C, double inv_count, float eps,
+                                                             int kind, float* __restrict__ out) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int c = tid % C, rl = tid / C, nrl = 256 / C;
+  double s1 = 0.0, s2 = 0.0;
+  if (rl < nrl) {
+    for (int t = rl; t < ntiles; t += nrl) {
+      const float* p = part + (((size_t)b * ntiles + t) * 2) * C;
+      s1 += (double)p[c];
+      s2 += (double)p[C + c];
+    }
+  }
+  red[0][tid] = s1;
+  red[1][tid] = s2;
+  __syncthreads();
+  if (tid < C) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int k = 0; k < nrl; ++k) { a1 += red[0][k * C + tid]; a2 += red[1][k * C + tid]; }
+    float o0, o1;
+    if (kind == 0) {
+      const double mean = a1 * inv_count;
+      double var = a2 * inv_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      o0 = (float)mean;
+      o1 = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+      o0 = (float)(a1 * inv_count);
+      o1 = (float)(a2 * inv_count);
+    }
+    out[((size_t)b * C + tid) * 2] = o0;
+    out[((size_t)b * C + tid) * 2 + 1] = o1;
+  }
+}
+
+extern "C" int w2s_stats_finalize(const float* part, int B, int ntiles, int C, long count, float eps, int kind, float* out, void* stream) {
+  if (!part || !out || C <= 0 || C > 256 || (256 % C) || count <= 0) return W2S_EINVAL;
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, ntiles, C,
+                     1.0 / (double)count, eps, kind, out);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv3 backward pre-pass: gn = g * GELU'(n), n = IN(y);  partial sums of gn and gn*n per (b, tile, c).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_stats_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                       const float* __restrict__ stats, float* __restrict__ part, int L, int C, int tile,
+                                                       int ntiles) {
+  extern __shared__ float sm[];  // [256][8]
+  const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x;
+  const int c4n = C >> 2, myc4 = tid % c4n, row0 = tid / c4n, rstep = 256 / c4n;
+  const float* st = stats + ((size_t)b * C + myc4 * 4) * 2;
+  f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+  f32x4 mean = {s01.x, s01.z, s23.x, s23.z}, rstd = {s01.y, s01.w, s23.y, s23.w};
+  f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+  for (int rr = row0; rr < tile; rr += rstep) {
+    const int t = tl * tile + rr;
+    if (t >= L) break;
+    const size_t off = ((size_t)b * L + t) * C + myc4 * 4;
+    f32x4 n = (ld4(y + off) - mean) * rstd;
+    f32x4 gn = ld4(g + off) * gelu_grad4(n);
+    a1 += gn;
+    a2 += gn * n;
+  }
+  st4(sm + tid * 8, a1);
+  st4(sm + tid * 8 + 4, a2);
+  __syncthreads();
+  if (tid < 2 * C) {
+    const int k = tid / C, c = tid % C;
+    float s = 0.f;
+    for (int rl = 0; rl < rstep; ++rl) s += sm[(rl * c4n + (c >> 2)) * 8 + k * 4 + (c & 3)];
+    part[(((size_t)b * ntiles + tl) * 2 + k) * C + c] = s;
+  }
+}
+
+extern "C" int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, void* stream) {
+  if (!g || !y || !stats || !part || C < 16 || C > 128 || (C & (C - 1)) || tile <= 0) return W2S_EINVAL;
+  const int ntiles = (L + tile - 1) / tile;
+  hipLaunchKernelGGL(gp_stats_kernel, dim3(ntiles, B), dim3(256), 256 * 8 * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y,
+                     stats, part, L, C, tile, ntiles);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}

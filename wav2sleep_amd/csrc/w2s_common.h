@@ -1,0 +1,71 @@
+// Shared device helpers for the wav2sleep gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/w2s.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define W2S_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    if (hipGetLastError() != hipSuccess) return W2S_ELAUNCH; \
+  } while (0)
+
+// D[16x16] += A[16x4] * B[4x16] on the fp32 matrix core.  Lane l supplies A[l&15][l>>4], B[l>>4][l&15];
+// afterwards lane l holds D[4*(l>>4)+reg][l&15] (cdna_hip_programming.md section 3).
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// exact (erf) GELU and its derivative -- models/utils.py:61-74 nn.GELU(approximate='none')
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ f32x4 gelu4(f32x4 v) {
+  f32x4 r; r.x = gelu_f(v.x); r.y = gelu_f(v.y); r.z = gelu_f(v.z); r.w = gelu_f(v.w); return r;
+}
+__device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
+  f32x4 r; r.x = gelu_grad_f(v.x); r.y = gelu_grad_f(v.y); r.z = gelu_grad_f(v.z); r.w = gelu_grad_f(v.w); return r;
+}
+__device__ __forceinline__ float sanitize_f(float x) { return isinf(x) ? 0.0f : x; }
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// counter-based RNG for dropout: splitmix64 of (seed, element index) -> uniform [0,1).  The same
+// (seed, index) regenerates the same mask in the backward pass; nothing is stored.
+__device__ __forceinline__ float w2s_uniform(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float w2s_dropscale(uint64_t seed, uint64_t idx, float p) {
+  return (w2s_uniform(seed, idx) >= p) ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+// sum over the 16 lanes that share (lane >> 4)  [row of the MFMA output fragment]
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}

@@ -1,0 +1,264 @@
+// Weight gradient of the channels-last convolution on the fp32 matrix cores, + slab reduction, + weight repack.
+//
+//   dW[o][j][c] = sum_{b,t} GY[b,t,o] * H[b, t*stride + j*dil - pad, c]
+// is a GEMM with M = cout, N = taps*cin and K = B*L_out (millions).  A workgroup walks position tiles
+// (grid-stride over (b, tile)), stages GY (its 16*NTO output channels) and the H window into LDS with the same
+// on-load transforms as conv_cl (GY = instance-norm backward of the incoming gradient, H = norm+GELU of the
+// stored pre-norm tensor), and each of its 4 waves accumulates the FULL (16*NTO) x (TAPS_T*16*NTC) block over
+// its own quarter of the positions.  Every wave then writes its accumulators as one raw-fragment slab;
+// w2s_wgrad_reduce sums the slabs in a fixed order (deterministic) and scatters to torch layout [o][c][j].
+// blockIdx.y enumerates (output-channel tile, tap group) so accumulators stay <= 32 tiles (128 VGPRs).
+#include "w2s_common.h"
+
+struct WgradP {
+  w2s_wgrad_args a;
+  int TM;      // positions per staged tile
+  int ntiles;  // tiles per sample
+  int ntg;     // tap groups = taps / TAPS_T
+};
+
+__device__ __forceinline__ f32x4 pro4(int pro, f32x4 v, f32x4 v2, f32x4 mean, f32x4 rstd, f32x4 s1, f32x4 s2) {
+  switch (pro) {
+    case W2S_PRO_SANITIZE:
+      v.x = sanitize_f(v.x); v.y = sanitize_f(v.y); v.z = sanitize_f(v.z); v.w = sanitize_f(v.w);
+      return v;
+    case W2S_PRO_GELU: return gelu4(v);
+    case W2S_PRO_IN_GELU: return gelu4((v - mean) * rstd);
+    case W2S_PRO_INBWD: { f32x4 n = (v2 - mean) * rstd; return rstd * (v - s1 - n * s2); }
+    case W2S_PRO_INBWD_GP: { f32x4 n = (v2 - mean) * rstd; f32x4 gn = v * gelu_grad4(n); return rstd * (gn - s1 - n * s2); }
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ void load_chan_params(const float* stats, int b, int C, int ch, f32x4& p0, f32x4& p1) {
+  const float* st = stats + ((size_t)b * C + ch) * 2;
+  f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+  p0 = (f32x4){s01.x, s01.z, s23.x, s23.z};
+  p1 = (f32x4){s01.y, s01.w, s23.y, s23.w};
+}
+
+template <int NTO, int NTC, int TAPS_T, int STRIDE>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradP P) {
+  extern __shared__ f32x4 smem4[];
+  float* smem = reinterpret_cast<float*>(smem4);
+  const w2s_wgrad_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int TM = P.TM;
+  const int cin = a.cin;             // == 16*NTC
+  constexpr int WG = NTO * 16;       // gradient-side width handled here
+  const int oy = blockIdx.y / P.ntg, tg = blockIdx.y % P.ntg;
+  const int o0 = oy * WG, j0 = tg * TAPS_T;
+  const int RSg = WG + 4, RSh = cin + 4;
+  const int NRh = (TAPS_T == 1) ? TM : (TM - 1) * STRIDE + TAPS_T;  // TAPS_T>1 only with dil == 1
+  float* gyL = smem;
+  float* hL = smem + TM * RSg;
+
+  f32x4 acc[NTO][TAPS_T][NTC];
+#pragma unroll
+  for (int i = 0; i < NTO; ++i)
+#pragma unroll
+    for (int j = 0; j < TAPS_T; ++j)
+#pragma unroll
+      for (int c = 0; c < NTC; ++c) acc[i][j][c] = (f32x4){0, 0, 0, 0};
+
+  const int total = a.B * P.ntiles;
+  for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    const int b = tl / P.ntiles, tile = tl % P.ntiles;
+    const int t0 = tile * TM;
+    __syncthreads();
+    {  // ---- stage GY tile: rows t0..t0+TM-1, channels o0..o0+WG-1
+      constexpr int c4n = WG / 4, rstep = 256 / c4n;
+      const int myc4 = tid % c4n, row0 = tid / c4n, ch = o0 + myc4 * 4;
+      f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, ps1 = {0, 0, 0, 0}, ps2 = {0, 0, 0, 0};
+      if (a.pro_g >= W2S_PRO_IN_GELU) {
+        load_chan_params(a.g_stats, b, a.cout, ch, pm, pr);
+        if (a.pro_g >= W2S_PRO_INBWD) load_chan_params(a.g_bstats, b, a.cout, ch, ps1, ps2);
+      }
+      const float* gb = a.g + (size_t)b * a.L_out * a.ldg + ch;
+      const float* g2b = (a.pro_g >= W2S_PRO_INBWD) ? a.g2 + (size_t)b * a.L_out * a.ldg + ch : nullptr;
+      for (int row = row0; row < TM; row += rstep) {
+        const int t = t0 + row;
+        f32x4 v = {0, 0, 0, 0};
+        if (t < a.L_out) {
+          f32x4 x = ld4(gb + (size_t)t * a.ldg);
+          f32x4 x2 = g2b ? ld4(g2b + (size_t)t * a.ldg) : (f32x4){0, 0, 0, 0};
+          v = pro4(a.pro_g, x, x2, pm, pr, ps1, ps2);
+        }
+        st4(gyL + row * RSg + myc4 * 4, v);
+      }
+    }
+    {  // ---- stage H window
+      const int c4n = cin >> 2, rstep = 256 / c4n;
+      const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
+      f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, z = {0, 0, 0, 0};
+      if (a.pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
+      const float* xb = a.x + (size_t)b * a.L_in * a.ldx + ch;
+      const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
+      const int rowmul = (TAPS_T == 1) ? STRIDE : 1;
+      for (int row = row0; row < NRh; row += rstep) {
+        const int gr = rb + row * rowmul;
+        f32x4 v = {0, 0, 0, 0};
+        if (gr >= 0 && gr < a.L_in) v = pro4(a.pro_h, ld4(xb + (size_t)gr * a.ldx), z, pm, pr, z, z);
+        st4(hL + row * RSh + ch, v);
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: this wave's quarter of the positions; k-step = 4 positions (lane group g picks one)
+    const int pw = wave * (TM >> 2);
+    for (int s = 0; s < (TM >> 4); ++s) {
+      const int p = pw + 4 * s + g;
+      float ga[NTO], hb[TAPS_T][NTC];
+#pragma unroll
+      for (int i = 0; i < NTO; ++i) ga[i] = gyL[p * RSg + i * 16 + r];
+#pragma unroll
+      for (int j = 0; j < TAPS_T; ++j) {
+        const int hr = (TAPS_T == 1) ? p : p * STRIDE + j;
+#pragma unroll
+        for (int c = 0; c < NTC; ++c) hb[j][c] = hL[hr * RSh + c * 16 + r];
+      }
+#pragma unroll
+      for (int i = 0; i < NTO; ++i)
+#pragma unroll
+        for (int j = 0; j < TAPS_T; ++j)
+#pragma unroll
+          for (int c = 0; c < NTC; ++c) acc[i][j][c] = mfma16(ga[i], hb[j][c], acc[i][j][c]);
+    }
+  }
+  // ---- raw-fragment slab: slab[(blockIdx.x*4+wave)][blockIdx.y][tile(i,j,c)][lane][4]
+  constexpr int TILES = NTO * TAPS_T * NTC;
+  float* out = a.slab + (((size_t)(blockIdx.x * 4 + wave) * gridDim.y + blockIdx.y) * TILES) * 256 + lane * 4;
+#pragma unroll
+  for (int i = 0; i < NTO; ++i)
+#pragma unroll
+    for (int j = 0; j < TAPS_T; ++j)
+#pragma unroll
+      for (int c = 0; c < NTC; ++c) st4(out + ((i * TAPS_T + j) * NTC + c) * 256, acc[i][j][c]);
+}
+
+// sum slabs in fixed order; decode the fragment index to (o, j, c); write torch layout grad[o][c][j]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, float* __restrict__ grad, int cout, int cin,
+                                    int taps, int NTO, int NTC, int TAPS_T, int accumulate, int layout) {
+  const size_t per = (size_t)cout * cin * taps;  // floats per slab
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * per + idx];
+  // idx = ((y * TILES + tile) * 64 + lane) * 4 + reg
+  const int reg = idx & 3, lane = (idx >> 2) & 63;
+  const int TILES = NTO * TAPS_T * NTC;
+  const int tile = (idx >> 8) % TILES, y = (idx >> 8) / TILES;
+  const int ntg = taps / TAPS_T;
+  const int oy = y / ntg, tg = y % ntg;
+  const int c_t = tile % NTC, j_t = (tile / NTC) % TAPS_T, i_t = tile / (NTC * TAPS_T);
+  const int o = oy * NTO * 16 + i_t * 16 + 4 * (lane >> 4) + reg;
+  const int j = tg * TAPS_T + j_t;
+  const int c = c_t * 16 + (lane & 15);
+  float* d = layout ? grad + ((size_t)o * taps + j) * cin + c : grad + ((size_t)o * cin + c) * taps + j;
+  *d = accumulate ? (*d + s) : s;
+}
+
+struct WgCfg { int nto, ntc, tapst; };
+static inline WgCfg wg_cfg(int cin, int cout, int taps, int dil) {
+  WgCfg c;
+  c.ntc = cin / 16;
+  c.tapst = (taps == 3 && dil == 1 && c.ntc <= 4) ? 3 : 1;
+  const int budget = 32 / (c.ntc * c.tapst);  // accumulator tiles per wave <= 32 (128 VGPRs)
+  int nto = 8;
+  while (nto > 1 && (nto > budget || (cout / 16) % nto)) nto >>= 1;
+  c.nto = nto;
+  return c;
+}
+
+template <int NTO, int NTC, int TAPS_T, int STRIDE>
+static int launch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
+  WgradP P;
+  P.a = a;
+  int TM = 256;
+  auto lds_of = [&](int tm) {
+    const int nrh = (TAPS_T == 1) ? tm : (tm - 1) * STRIDE + TAPS_T;
+    return (size_t)(tm * (NTO * 16 + 4) + nrh * (a.cin + 4)) * sizeof(float);
+  };
+  while (TM > 32 && lds_of(TM) > 76 * 1024) TM >>= 1;
+  while (TM > 32 && TM >= 2 * a.L_out) TM >>= 1;
+  P.TM = TM;
+  P.ntiles = (a.L_out + TM - 1) / TM;
+  P.ntg = a.taps / TAPS_T;
+  const int gy = (a.cout / (NTO * 16)) * P.ntg;
+  int gx = a.nslab / 4;
+  if (gx < 1) return W2S_EINVAL;
+  dim3 grid(gx, gy);
+  size_t lds = lds_of(TM);
+  auto kern = wgrad_kernel<NTO, NTC, TAPS_T, STRIDE>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return W2S_ELAUNCH;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+template <int STRIDE>
+static int dispatch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
+  const WgCfg c = wg_cfg(a.cin, a.cout, a.taps, a.dil);
+#define W2S_WG(NTO_, NTC_, TT_) \
+  if (c.nto == NTO_ && c.ntc == NTC_ && c.tapst == TT_) return launch_wgrad<NTO_, NTC_, TT_, STRIDE>(a, s);
+  if constexpr (STRIDE <= 2) {
+    W2S_WG(1, 1, 3) W2S_WG(2, 1, 3) W2S_WG(2, 2, 3) W2S_WG(4, 2, 3) W2S_WG(2, 4, 3)
+  }
+  W2S_WG(1, 1, 1) W2S_WG(2, 1, 1) W2S_WG(2, 2, 1) W2S_WG(4, 2, 1) W2S_WG(4, 4, 1) W2S_WG(8, 4, 1) W2S_WG(4, 8, 1)
+#undef W2S_WG
+  return W2S_EINVAL;
+}
+
+extern "C" int w2s_wgrad(const w2s_wgrad_args* ap, void* stream) {
+  if (!ap) return W2S_EINVAL;
+  const w2s_wgrad_args& a = *ap;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (a.cin < 16 || a.cin > 128 || (a.cin & (a.cin - 1)) || (a.cout & 15) || !a.g || !a.x || !a.slab) return W2S_EINVAL;
+  if (a.pro_g >= W2S_PRO_IN_GELU && !a.g_stats) return W2S_EINVAL;
+  if (a.pro_g >= W2S_PRO_INBWD && (!a.g_bstats || !a.g2)) return W2S_EINVAL;
+  if (a.pro_h >= W2S_PRO_IN_GELU && !a.x_stats) return W2S_EINVAL;
+  if (a.stride == 1) return dispatch_wgrad<1>(a, s);
+  if (a.stride == 2) return dispatch_wgrad<2>(a, s);
+  if (a.stride == 4) return dispatch_wgrad<4>(a, s);
+  return W2S_EINVAL;
+}
+
+extern "C" int w2s_wgrad_grid_y(int cin, int cout, int taps, int dil) {
+  const WgCfg c = wg_cfg(cin, cout, taps, dil);
+  return (cout / (c.nto * 16)) * (taps / c.tapst);
+}
+
+extern "C" int w2s_wgrad_reduce(const float* slab, int nslab, float* grad, int cout, int cin, int taps, int dil, int accumulate,
+                                int layout, void* stream) {
+  if (!slab || !grad || nslab <= 0) return W2S_EINVAL;
+  const WgCfg c = wg_cfg(cin, cout, taps, dil);
+  const size_t per = (size_t)cout * cin * taps;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab,
+                     nslab, grad, cout, cin, taps, c.nto, c.ntc, c.tapst, accumulate, layout);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// torch [cout][cin][taps] -> fwd [cout][taps][cin] and bwd [cin][taps][cout]
+__global__ void repack_kernel(const float* __restrict__ w, float* __restrict__ fwd, float* __restrict__ bwd, int cout, int cin, int taps) {
+  const size_t n = (size_t)cout * cin * taps;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int j = idx % taps;
+  const int c = (idx / taps) % cin;
+  const int o = idx / ((size_t)taps * cin);
+  const float v = w[idx];
+  if (fwd) fwd[((size_t)o * taps + j) * cin + c] = v;
+  if (bwd) bwd[((size_t)c * taps + j) * cout + o] = v;
+}
+
+extern "C" int w2s_repack(const float* w, float* fwd, float* bwd, int cout, int cin, int taps, void* stream) {
+  if (!w) return W2S_EINVAL;
+  const size_t n = (size_t)cout * cin * taps;
+  hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, fwd, bwd,
+                     cout, cin, taps);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}

@@ -1,0 +1,527 @@
+"""Launch plan of the wav2sleep hot path on MI355X: which C-ABI kernel runs when, on which buffers.
+
+This is host logic only (no arithmetic): every FLOP of the forward/backward is in libw2s_hip.so.
+Activation layout is channels-last [B, L, C]; every tensor between two encoder convs is stored PRE-norm /
+PRE-activation exactly once and the consumer normalises + activates while staging it into LDS, so a
+ConvBlock1D (models/blocks.py:57-71) costs 4 launches forward and reads/writes each tensor once.
+
+Reference call sites mirrored here: Wav2Sleep.forward (models/wav2sleep.py:48-67), SignalEncoders.forward (:146-161),
+SignalEncoder.forward (:235-267), MultiModalAttentionEmbedder.forward (:301-346), SequenceCNN.forward (:379-390),
+DilatedConvBlock.forward (blocks.py:115-126), and autograd's backward of all of them.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+from . import lib
+from .settings import COLS_TO_SAMPLES_PER_EPOCH
+
+FIRST_TILE = 1024  # positions per statistics partial of the Cin=1 layer
+
+
+@dataclass
+class EngineSpec:
+    signal_map: dict
+    feature_dim: int = 128
+    num_classes: int = 4
+    initial_channels: int = 16
+    max_channels: int = 128
+    mixer_layers: int = 2
+    mixer_nhead: int = 8
+    mixer_dim_ff: int = 512
+    mixer_dropout: float = 0.0
+    seq_blocks: int = 2
+    seq_dilations: int = 6
+    seq_kernel: int = 7
+    seq_dropout: float = 0.0
+    instance_eps: float = 1e-2
+    layer_eps: float = 1e-5
+    enc_sig: dict = field(default_factory=dict)  # encoder name -> first signal that created it
+
+    def __post_init__(self):
+        for sig, enc in self.signal_map.items():
+            if sig not in COLS_TO_SAMPLES_PER_EPOCH:
+                raise ValueError(f"Column {sig} unrecognised. Doesn't have a sampling rate.")
+            self.enc_sig.setdefault(enc, sig)
+        if self.feature_dim != 128 or self.mixer_nhead * 16 != self.feature_dim:
+            raise ValueError('kernels are built for feature_dim=128, head_dim=16 (scripts/config/model/wav2sleep.yaml)')
+        if self.mixer_dim_ff % 128 or self.seq_kernel != 7 or self.initial_channels != 16 or self.max_channels not in (16, 32, 64, 128):
+            raise ValueError('unsupported hyper-parameters for the gfx950 kernels')
+
+    def channels(self, enc: str) -> list[int]:
+        """models/wav2sleep.py:198-201"""
+        spe = COLS_TO_SAMPLES_PER_EPOCH[self.enc_sig[enc]]
+        nb = int(math.log2(spe)) - 2
+        return [min(self.initial_channels * 2 ** (i // 2), self.max_channels) for i in range(nb)]
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+class Engine:
+    """Owns nothing but scratch: parameters/gradients are views handed in by the caller (flat buffers)."""
+
+    def __init__(self, spec: EngineSpec, params: dict[str, torch.Tensor], grads: dict[str, torch.Tensor] | None = None):
+        self.spec = spec
+        self.P = params
+        self.G = grads
+        self.PF: dict[str, torch.Tensor] = {}
+        self.PB: dict[str, torch.Tensor] = {}
+        self._pack_key = None
+        self.step_seed = 0
+        self._written: set[str] = set()
+        self.ctx = None
+        lib.load()
+
+    # ------------------------------------------------------------------ weights
+    def _pack_list(self):
+        sp = self.spec
+        out = []  # (name, cout, cin, taps, need_fwd, need_bwd)
+        for enc in dict.fromkeys(sp.signal_map.values()):
+            ch = sp.channels(enc)
+            cin = 1
+            for i, c in enumerate(ch):
+                p = f'signal_encoders.encoders.{enc}.cnn.{i}.'
+                if i > 0:
+                    out.append((p + 'conv1.conv.weight', c, cin, 3, True, True))
+                    out.append((p + 'downsample.weight', c, cin, 1, False, True))
+                out.append((p + 'conv2.conv.weight', c, c, 3, True, True))
+                out.append((p + 'conv3.conv.weight', c, c, 3, True, True))
+                cin = c
+            out.append((f'signal_encoders.encoders.{enc}.linear.weight', sp.feature_dim, 4 * ch[-1], 1, False, True))
+        F = sp.feature_dim
+        for l in range(sp.mixer_layers):
+            p = f'epoch_mixer.transformer_encoder.layers.{l}.'
+            out.append((p + 'self_attn.in_proj_weight', 3 * F, F, 1, False, True))
+            out.append((p + 'self_attn.out_proj.weight', F, F, 1, False, True))
+            out.append((p + 'linear1.weight', sp.mixer_dim_ff, F, 1, False, True))
+            out.append((p + 'linear2.weight', F, sp.mixer_dim_ff, 1, False, True))
+        for b in range(sp.seq_blocks):
+            for j in range(sp.seq_dilations):
+                out.append((f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.conv.weight', F, F, sp.seq_kernel, True, True))
+        return out
+
+    def pack(self, need_bwd: bool = True):
+        """torch-layout weights -> kernel layouts ([cout][taps][cin] forward, [cin][taps][cout] data-gradient)."""
+        for name, cout, cin, taps, nf, nb in self._pack_list():
+            w = self.P[name]
+            if nf and name not in self.PF:
+                self.PF[name] = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+            if nb and need_bwd and name not in self.PB:
+                self.PB[name] = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+            f = self.PF.get(name) if nf else None
+            bw = self.PB.get(name) if (nb and need_bwd) else None
+            if f is not None or bw is not None:
+                lib.repack(w, f, bw, cout, cin, taps)
+
+    def ensure_packed(self, key, need_bwd: bool):
+        key = (key, need_bwd or (self._pack_key is not None and self._pack_key[1]))
+        if self._pack_key != key:
+            self.pack(need_bwd=key[1])
+            self._pack_key = key
+
+    # ------------------------------------------------------------------ helpers
+    def _finalize(self, part, B, ntiles, C, count, kind):
+        out = torch.empty(B, C, 2, device=part.device, dtype=torch.float32)
+        lib.stats_finalize(part, B, ntiles, C, count, self.spec.instance_eps, kind, out)
+        return out
+
+    def _conv(self, **kw):
+        lib.conv_forward(lib.conv_args(**kw))
+
+    def _conv_stats(self, *, x, w, B, L_in, L_out, cin, cout, stride, pro, pro_stats=None):
+        """k=3 encoder conv writing the pre-norm tensor + instance-norm statistics (blocks.py:174-183)."""
+        dev = x.device
+        y = torch.empty(B, L_out, cout, device=dev, dtype=torch.float32)
+        tile = lib.conv_tile(cin, cout, 3, stride, lib.MODE_CONTIG)
+        nt = _cdiv(L_out, tile)
+        part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
+        self._conv(x=x, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=1, pro=pro,
+                   pro_stats=pro_stats, epi=lib.EPI_STATS, part=part)
+        return y, self._finalize(part, B, nt, cout, L_out, 0)
+
+    def _linear(self, x, w, bias, rows, cin, cout, ldx=None, y=None, ldy=None):
+        """y[rows, cout] = x[rows, cin(*k)] @ w^T + bias; cin > 128 runs as k = cin/128 strided taps."""
+        if y is None:
+            y = torch.empty(rows, cout, device=x.device, dtype=torch.float32)
+        if cin <= 128:
+            self._conv(x=x, w=w, y=y, B=1, L_in=rows, L_out=rows, cin=cin, cout=cout, taps=1, stride=1, pad=0, ldx=ldx, ldy=ldy,
+                       epi=lib.EPI_BIAS, bias=bias)
+        else:
+            k = cin // 128
+            assert cin % 128 == 0 and k in (3, 4) and ldx is None
+            self._conv(x=x, w=w, y=y, B=1, L_in=rows * k, L_out=rows, cin=128, cout=cout, taps=k, stride=k, pad=0, mode=lib.MODE_DILATED,
+                       ldy=ldy, epi=lib.EPI_BIAS, bias=bias)
+        return y
+
+    def _slab(self, dev, nslab, n):
+        return torch.empty(nslab * n, device=dev, dtype=torch.float32)
+
+    def _wgrad(self, name, *, g, x, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, layout=0, **kw):
+        """weight gradient -> slabs -> deterministic reduce into G[name] (accumulating if already written)."""
+        gy = lib.wgrad_grid_y(cin, cout, taps, dil)
+        work = _cdiv(B * L_out, 256)
+        gx = max(1, min(work, max(1, 1024 // gy)))
+        nslab = 4 * gx
+        slab = self._slab(g.device, nslab, cout * cin * taps)
+        lib.wgrad(g=g, x=x, slab=slab, nslab=nslab, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad,
+                  dil=dil, **kw)
+        lib.wgrad_reduce(slab, nslab, self.G[name], cout, cin, taps, dil, accumulate=name in self._written, layout=layout)
+        self._written.add(name)
+
+    def _colgrad(self, name, g, rows, C, ldg=None):
+        """G[name][c] = sum_rows g[row, c]  (bias / CLS gradients)."""
+        nparts = max(1, min(256, _cdiv(rows, 64)))
+        part = torch.empty(nparts, C, device=g.device, dtype=torch.float32)
+        lib.bias_grad(g, rows, C, C if ldg is None else ldg, part, nparts)
+        lib.colsum(part, nparts, C, self.G[name], accumulate=name in self._written)
+        self._written.add(name)
+
+    def _seed(self, site: int) -> int:
+        return ((self.step_seed & 0xFFFFFFFF) << 16) ^ (site * 0x9E3779B1 & 0xFFFFFFFF)
+
+    # ------------------------------------------------------------------ encoder forward
+    def _encoder_forward(self, sig, x, keep, tok_slice, ldtok, save):
+        sp, P, PF = self.spec, self.P, self.PF
+        enc = sp.signal_map[sig]
+        ch = sp.channels(enc)
+        spe = COLS_TO_SAMPLES_PER_EPOCH[sig]
+        B, T = x.shape
+        if T % spe:
+            raise ValueError(f'Input length {T} must be divisible by samples_per_epoch={spe}.')
+        S = T // spe
+        dev = x.device
+        pfx = f'signal_encoders.encoders.{enc}.'
+        blocks = []
+        # ---- block 0 (Cin = 1)
+        c, L = ch[0], T
+        y1 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
+        nt = _cdiv(L, FIRST_TILE)
+        part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
+        lib.enc_first_fwd(x, P[pfx + 'cnn.0.conv1.conv.weight'], y1, part, B, L, c, FIRST_TILE)
+        st1 = self._finalize(part, B, nt, c, L, 0)
+        y2, st2 = self._conv_stats(x=y1, w=PF[pfx + 'cnn.0.conv2.conv.weight'], B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1,
+                                   pro=lib.PRO_IN_GELU, pro_stats=st1)
+        y3, st3 = self._conv_stats(x=y2, w=PF[pfx + 'cnn.0.conv3.conv.weight'], B=B, L_in=L, L_out=L // 2, cin=c, cout=c, stride=2,
+                                   pro=lib.PRO_IN_GELU, pro_stats=st2)
+        pre = torch.empty(B, L // 2, c, device=dev, dtype=torch.float32)
+        lib.enc_first_join(x, P[pfx + 'cnn.0.downsample.weight'], y3, st3, pre, B, L, c)
+        if save:
+            blocks.append(dict(y1=y1, st1=st1, y2=y2, st2=st2, y3=y3, st3=st3, pin=None, L=L, cin=1, c=c))
+        pin, cin, L = pre, c, L // 2
+        # ---- blocks 1..
+        for i in range(1, len(ch)):
+            c = ch[i]
+            p = f'{pfx}cnn.{i}.'
+            y1, st1 = self._conv_stats(x=pin, w=PF[p + 'conv1.conv.weight'], B=B, L_in=L, L_out=L, cin=cin, cout=c, stride=1, pro=lib.PRO_GELU)
+            y2, st2 = self._conv_stats(x=y1, w=PF[p + 'conv2.conv.weight'], B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1,
+                                       pro=lib.PRO_IN_GELU, pro_stats=st1)
+            y3, st3 = self._conv_stats(x=y2, w=PF[p + 'conv3.conv.weight'], B=B, L_in=L, L_out=L // 2, cin=c, cout=c, stride=2,
+                                       pro=lib.PRO_IN_GELU, pro_stats=st2)
+            pre = torch.empty(B, L // 2, c, device=dev, dtype=torch.float32)
+            self._conv(x=pin, w=P[p + 'downsample.weight'], y=pre, B=B, L_in=L, L_out=L // 2, cin=cin, cout=c, taps=1, stride=2, pad=0,
+                       pro=lib.PRO_GELU, epi=lib.EPI_AUX_INGELU_ADD, aux=y3, aux_stats=st3)
+            if save:
+                blocks.append(dict(y1=y1, st1=st1, y2=y2, st2=st2, y3=y3, st3=st3, pin=pin, L=L, cin=cin, c=c))
+            pin, cin, L = pre, c, L // 2
+        # ---- time-distributed dense + GELU (wav2sleep.py:261-265): taps=4/stride=4 over the [B,4S,C] map
+        F = sp.feature_dim
+        zpre = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+        self._conv(x=pin, w=P[pfx + 'linear.weight'], y=zpre, B=B, L_in=4 * S, L_out=S, cin=cin, cout=F, taps=4, stride=4, pad=0,
+                   mode=lib.MODE_DILATED, pro=lib.PRO_GELU, epi=lib.EPI_BIAS, bias=P[pfx + 'linear.bias'], rowkeep=keep,
+                   y2=tok_slice, ldy2=ldtok)
+        return dict(sig=sig, enc=enc, x=x, keep=keep, blocks=blocks, plast=pin, zpre=zpre, S=S, B=B) if save else None
+
+    # ------------------------------------------------------------------ full forward
+    def forward(self, x: dict[str, torch.Tensor], train: bool = False, save: bool = False, pack_key=None) -> torch.Tensor:
+        sp, P = self.spec, self.P
+        if len(x) == 0:
+            raise ValueError('No signals provided to MultiModalAttentionEmbedder.')
+        for s in x:
+            if s not in sp.signal_map:
+                raise ValueError(f'Unknown signal {s}')
+        self.ensure_packed(pack_key, need_bwd=save)
+        sigs = sorted(x.keys())  # wav2sleep.py:311
+        first = x[sigs[0]]
+        dev = first.device
+        B = first.shape[0]
+        S = first.shape[1] // COLS_TO_SAMPLES_PER_EPOCH[sigs[0]]
+        F, D, N = sp.feature_dim, len(sigs) + 1, B * S
+        pm = sp.mixer_dropout if train else 0.0
+        ps = sp.seq_dropout if train else 0.0
+
+        tokens = torch.empty(N, D, F, device=dev, dtype=torch.float32)
+        lib.fill_rows(tokens, D * F, P['epoch_mixer.register_tokens'], N, F)
+        keeps, enc_ctx = [], []
+        for m, s in enumerate(sigs):
+            xs = x[s]
+            if xs.dtype != torch.float32 or not xs.is_contiguous():
+                xs = xs.float().contiguous()
+            keep = (~torch.isinf(xs[:, 0])).float()  # wav2sleep.py:150 (plumbing on B scalars)
+            keeps.append(keep)
+            enc_ctx.append(self._encoder_forward(s, xs, keep, tokens.view(-1)[(1 + m) * F:], D * F, save))
+        keep_BD = torch.stack([torch.ones_like(keeps[0])] + keeps, dim=1)  # [B, D]
+        keypad = (keep_BD == 0).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
+
+        # ---- set-fusion transformer (nn.TransformerEncoderLayer norm_first, wav2sleep.py:286-296)
+        R = N * D
+        X = tokens.view(R, F)
+        layers = []
+        for l in range(sp.mixer_layers):
+            p = f'epoch_mixer.transformer_encoder.layers.{l}.'
+            h = torch.empty(R, F, device=dev, dtype=torch.float32)
+            rs1 = torch.empty(R, 2, device=dev, dtype=torch.float32)
+            lib.layernorm_fwd(X, F, P[p + 'norm1.weight'], P[p + 'norm1.bias'], h, F, rs1, R, F, sp.layer_eps)
+            qkv = self._linear(h, P[p + 'self_attn.in_proj_weight'], P[p + 'self_attn.in_proj_bias'], R, F, 3 * F)
+            ao = torch.empty(R, F, device=dev, dtype=torch.float32)
+            lib.attn_fwd(qkv, keypad, ao, N, D, sp.mixer_nhead, pm, self._seed(10 * l + 1))
+            proj = self._linear(ao, P[p + 'self_attn.out_proj.weight'], P[p + 'self_attn.out_proj.bias'], R, F, F)
+            X1 = torch.empty(R, F, device=dev, dtype=torch.float32)
+            lib.eltwise(lib.ELT_ADD_DROP, X, proj, X1, R * F, pm, self._seed(10 * l + 2))
+            h2 = torch.empty(R, F, device=dev, dtype=torch.float32)
+            rs2 = torch.empty(R, 2, device=dev, dtype=torch.float32)
+            lib.layernorm_fwd(X1, F, P[p + 'norm2.weight'], P[p + 'norm2.bias'], h2, F, rs2, R, F, sp.layer_eps)
+            FF = sp.mixer_dim_ff
+            f1 = self._linear(h2, P[p + 'linear1.weight'], P[p + 'linear1.bias'], R, F, FF)
+            a1 = torch.empty(R, FF, device=dev, dtype=torch.float32)
+            lib.eltwise(lib.ELT_GELU_DROP, f1, None, a1, R * FF, pm, self._seed(10 * l + 3))
+            f2 = self._linear(a1, P[p + 'linear2.weight'], P[p + 'linear2.bias'], R, FF, F)
+            X2 = torch.empty(R, F, device=dev, dtype=torch.float32)
+            lib.eltwise(lib.ELT_ADD_DROP, X1, f2, X2, R * F, pm, self._seed(10 * l + 4))
+            if save:
+                layers.append(dict(X=X, rs1=rs1, h=h, qkv=qkv, ao=ao, X1=X1, rs2=rs2, h2=h2, f1=f1, a1=a1))
+            X = X2
+
+        # ---- SequenceCNN over the CLS rows (row n*D of X; ld = D*F) -- wav2sleep.py:345, 379-390
+        xin, ldin = X, D * F
+        seq = []
+        pre_out = None
+        for b in range(sp.seq_blocks):
+            hcur, ldh = xin, ldin
+            convs = []
+            for j in range(sp.seq_dilations):
+                d = 2 ** j
+                p = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.'
+                y = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                self._conv(x=hcur, w=self.PF[p + 'conv.weight'], y=y, B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1,
+                           dil=d, pad=(sp.seq_kernel // 2) * d, mode=lib.MODE_DILATED, ldx=ldh)
+                hn = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                rs = torch.empty(B * S, 2, device=dev, dtype=torch.float32)
+                lib.layernorm_fwd(y, F, P[p + 'norm.weight'], P[p + 'norm.bias'], hn, F, rs, B * S, F, sp.layer_eps, gelu=True)
+                if save:
+                    convs.append(dict(hin=hcur, ldh=ldh, y=y, rs=rs))
+                hcur, ldh = hn, F
+            pre_out = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+            if ldin == F:
+                lib.eltwise(lib.ELT_ADD_DROP, xin, hcur, pre_out, B * S * F, ps, self._seed(100 + b))
+            else:  # block 0 reads the strided CLS rows: gather them once (small)
+                xg = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                xg.view(N, F).copy_(xin.view(N, D * F)[:, :F])  # strided device copy (plumbing)
+                lib.eltwise(lib.ELT_ADD_DROP, xg, hcur, pre_out, B * S * F, ps, self._seed(100 + b))
+            if save:
+                seq.append(dict(convs=convs, pre_out=pre_out))
+            if b + 1 < sp.seq_blocks:
+                act = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                lib.eltwise(lib.ELT_GELU, pre_out, None, act, B * S * F)
+                xin, ldin = act, F
+
+        logits = torch.empty(B, S, sp.num_classes, device=dev, dtype=torch.float32)
+        lib.head_fwd(pre_out, F, P['classifier.weight'], P['classifier.bias'], logits, B * S, F, sp.num_classes, True)
+        if save:
+            self.ctx = dict(B=B, S=S, D=D, N=N, sigs=sigs, enc=enc_ctx, keypad=keypad, layers=layers, seq=seq, pre_out=pre_out, pm=pm,
+                            ps=ps, tokens=tokens)
+        return logits
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, glogits: torch.Tensor, accumulate: bool = False):
+        """Gradients of everything saved by forward(save=True) into self.G (overwrite unless accumulate)."""
+        sp, P, PB, c = self.spec, self.P, self.PB, self.ctx
+        if c is None:
+            raise RuntimeError('backward() needs forward(save=True) first')
+        if self.G is None:
+            raise RuntimeError('engine was built without gradient buffers')
+        self._written = set(self.G.keys()) if accumulate else set()
+        B, S, D, N, F = c['B'], c['S'], c['D'], c['N'], sp.feature_dim
+        dev = glogits.device
+        nc = sp.num_classes
+        rows = B * S
+        pm, ps = c['pm'], c['ps']
+        glogits = glogits.reshape(rows, nc).contiguous()
+
+        # ---- classifier
+        g_pre = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+        nparts = max(1, min(256, _cdiv(rows, 64)))
+        part = torch.empty(nparts, nc * F + nc, device=dev, dtype=torch.float32)
+        lib.head_bwd(c['pre_out'], F, P['classifier.weight'], glogits, g_pre, F, part, nparts, rows, F, nc, True)
+        lib.colsum(part, nparts, nc * F, self.G['classifier.weight'], accumulate='classifier.weight' in self._written, ld=nc * F + nc)
+        lib.colsum(part.view(-1)[nc * F:], nparts, nc, self.G['classifier.bias'], accumulate='classifier.bias' in self._written, ld=nc * F + nc)
+        self._written.update(('classifier.weight', 'classifier.bias'))
+
+        # ---- SequenceCNN
+        for b in reversed(range(sp.seq_blocks)):
+            blk = c['seq'][b]
+            gh = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+            lib.eltwise(lib.ELT_DROP, g_pre, None, gh, rows * F, ps, self._seed(100 + b))
+            for j in reversed(range(sp.seq_dilations)):
+                d = 2 ** j
+                cv = blk['convs'][j]
+                p = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.'
+                gy = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                npl = max(1, min(128, _cdiv(rows, 16)))
+                pg = torch.empty(npl, F, device=dev, dtype=torch.float32)
+                pb = torch.empty(npl, F, device=dev, dtype=torch.float32)
+                lib.layernorm_bwd(gh, F, cv['y'], F, P[p + 'norm.weight'], P[p + 'norm.bias'], cv['rs'], None, gy, F, pg, pb, rows, F, True, npl)
+                lib.colsum(pg, npl, F, self.G[p + 'norm.weight'], accumulate=(p + 'norm.weight') in self._written)
+                lib.colsum(pb, npl, F, self.G[p + 'norm.bias'], accumulate=(p + 'norm.bias') in self._written)
+                self._written.update((p + 'norm.weight', p + 'norm.bias'))
+                pad = (sp.seq_kernel // 2) * d
+                self._wgrad(p + 'conv.weight', g=gy, x=cv['hin'], ldx=cv['ldh'], B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel,
+                            stride=1, pad=pad, dil=d)
+                gh = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                self._conv(x=gy, w=PB[p + 'conv.weight'], y=gh, B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1, dil=d,
+                           pad=pad, flip=1, mode=lib.MODE_DILATED)
+            gx = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+            lib.eltwise(lib.ELT_ADD, g_pre, gh, gx, rows * F)
+            if b > 0:
+                g_pre = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                lib.eltwise(lib.ELT_GELU_BWD, c['seq'][b - 1]['pre_out'], gx, g_pre, rows * F)
+            else:
+                g_pre = gx  # gradient w.r.t. the CLS rows of the transformer output
+
+        # ---- set-fusion transformer
+        R = N * D
+        gX = torch.zeros(N, D, F, device=dev, dtype=torch.float32)
+        gX[:, 0, :].copy_(g_pre.view(N, F))  # only token 0 is returned (wav2sleep.py:345)
+        gX = gX.view(R, F)
+        FF = sp.mixer_dim_ff
+        for l in reversed(range(sp.mixer_layers)):
+            L = c['layers'][l]
+            p = f'epoch_mixer.transformer_encoder.layers.{l}.'
+            gf2 = torch.empty(R, F, device=dev, dtype=torch.float32)
+            lib.eltwise(lib.ELT_DROP, gX, None, gf2, R * F, pm, self._seed(10 * l + 4))
+            self._colgrad(p + 'linear2.bias', gf2, R, F)
+            self._wgrad(p + 'linear2.weight', g=gf2, x=L['a1'], B=1, L_in=R * (FF // 128), L_out=R, cin=128, cout=F, taps=FF // 128,
+                        stride=FF // 128, pad=0, layout=1)
+            ga1 = self._linear(gf2, PB[p + 'linear2.weight'], None, R, F, FF)
+            gf1 = torch.empty(R, FF, device=dev, dtype=torch.float32)
+            lib.eltwise(lib.ELT_GELU_DROP_BWD, L['f1'], ga1, gf1, R * FF, pm, self._seed(10 * l + 3))
+            self._colgrad(p + 'linear1.bias', gf1, R, FF)
+            self._wgrad(p + 'linear1.weight', g=gf1, x=L['h2'], B=1, L_in=R, L_out=R, cin=F, cout=FF, taps=1, stride=1, pad=0)
+            gh2 = self._linear(gf1, PB[p + 'linear1.weight'], None, R, FF, F)
+            gX1 = torch.empty(R, F, device=dev, dtype=torch.float32)
+            self._ln_bwd(p + 'norm2', gh2, L['X1'], L['rs2'], gX, gX1, R)
+            gproj = torch.empty(R, F, device=dev, dtype=torch.float32)
+            lib.eltwise(lib.ELT_DROP, gX1, None, gproj, R * F, pm, self._seed(10 * l + 2))
+            self._colgrad(p + 'self_attn.out_proj.bias', gproj, R, F)
+            self._wgrad(p + 'self_attn.out_proj.weight', g=gproj, x=L['ao'], B=1, L_in=R, L_out=R, cin=F, cout=F, taps=1, stride=1, pad=0)
+            gao = self._linear(gproj, PB[p + 'self_attn.out_proj.weight'], None, R, F, F)
+            gqkv = torch.empty(R, 3 * F, device=dev, dtype=torch.float32)
+            lib.attn_bwd(L['qkv'], c['keypad'], gao, gqkv, N, D, sp.mixer_nhead, pm, self._seed(10 * l + 1))
+            self._colgrad(p + 'self_attn.in_proj_bias', gqkv, R, 3 * F)
+            self._wgrad(p + 'self_attn.in_proj_weight', g=gqkv, x=L['h'], B=1, L_in=R, L_out=R, cin=F, cout=3 * F, taps=1, stride=1, pad=0)
+            gh = self._linear(gqkv, PB[p + 'self_attn.in_proj_weight'], None, R, 3 * F, F)
+            gXn = torch.empty(R, F, device=dev, dtype=torch.float32)
+            self._ln_bwd(p + 'norm1', gh, L['X'], L['rs1'], gX1, gXn, R)
+            gX = gXn
+        # CLS parameter: sum of the token-0 rows' gradients
+        self._colgrad('epoch_mixer.register_tokens', gX, N, F, ldg=D * F)
+
+        # ---- encoders
+        for m, ec in enumerate(c['enc']):
+            self._encoder_backward(ec, gX.view(-1)[(1 + m) * F:], D * F)
+
+        if not accumulate:
+            for name, g in self.G.items():
+                if name not in self._written:
+                    g.zero_()
+        self.ctx = None
+
+    def _ln_bwd(self, pfx, g, x, rstat, gadd, gx, rows):
+        F = self.spec.feature_dim
+        npl = max(1, min(256, _cdiv(rows, 16)))
+        pg = torch.empty(npl, F, device=g.device, dtype=torch.float32)
+        pb = torch.empty(npl, F, device=g.device, dtype=torch.float32)
+        lib.layernorm_bwd(g, F, x, F, self.P[pfx + '.weight'], self.P[pfx + '.bias'], rstat, gadd, gx, F, pg, pb, rows, F, False, npl)
+        lib.colsum(pg, npl, F, self.G[pfx + '.weight'], accumulate=(pfx + '.weight') in self._written)
+        lib.colsum(pb, npl, F, self.G[pfx + '.bias'], accumulate=(pfx + '.bias') in self._written)
+        self._written.update((pfx + '.weight', pfx + '.bias'))
+
+    def _bstats(self, part, B, nt, C, count):
+        return self._finalize(part, B, nt, C, count, 1)
+
+    def _encoder_backward(self, ec, gtok, ldtok):
+        sp, P, PB = self.spec, self.P, self.PB
+        enc, B, S, F = ec['enc'], ec['B'], ec['S'], sp.feature_dim
+        dev = gtok.device
+        pfx = f'signal_encoders.encoders.{enc}.'
+        ch = sp.channels(enc)
+        cl = ch[-1]
+        # z = keep * GELU(zpre): g_zpre
+        gz = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+        lib.gelu_bwd_rows(gtok, ldtok, ec['zpre'], ec['keep'], S, gz, B * S, F)
+        self._colgrad(pfx + 'linear.bias', gz, B * S, F)
+        self._wgrad(pfx + 'linear.weight', g=gz, x=ec['plast'], B=B, L_in=4 * S, L_out=S, cin=cl, cout=F, taps=4, stride=4, pad=0,
+                    pro_h=lib.PRO_GELU, layout=1)
+        # data gradient through the dense layer, times GELU'(plast): rows = B*S, cout' = 4*cl
+        gpre = torch.empty(B, 2 * 2 * S, cl, device=dev, dtype=torch.float32)
+        self._conv(x=gz, w=PB[pfx + 'linear.weight'], y=gpre, B=1, L_in=B * S, L_out=B * S, cin=F, cout=4 * cl, taps=1, stride=1, pad=0,
+                   epi=lib.EPI_GP, aux=ec['plast'], ld_aux=4 * cl)
+        for i in reversed(range(len(ch))):
+            blk = ec['blocks'][i]
+            p = f'{pfx}cnn.{i}.'
+            c, cin, L = blk['c'], blk['cin'], blk['L']
+            Lh = L // 2
+            # conv3 (stride 2): pre-pass for the instance-norm backward sums, then data + weight gradient
+            tile = 512
+            nt = _cdiv(Lh, tile)
+            part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
+            lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile)
+            bs3 = self._bstats(part, B, nt, c, Lh)
+            gn2 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
+            tile = lib.conv_tile(c, c, 3, 2, lib.MODE_UP2)
+            nt = _cdiv(L, tile)
+            part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
+            self._conv(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
+                       pad=1, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP, aux=blk['y2'],
+                       aux_stats=blk['st2'], part=part)
+            bs2 = self._bstats(part, B, nt, c, L)
+            self._wgrad(p + 'conv3.conv.weight', g=gpre, g2=blk['y3'], g_stats=blk['st3'], g_bstats=bs3, pro_g=lib.PRO_INBWD_GP, x=blk['y2'],
+                        x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=1)
+            # conv2
+            gn1 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
+            tile = lib.conv_tile(c, c, 3, 1, lib.MODE_CONTIG)
+            nt = _cdiv(L, tile)
+            part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
+            self._conv(x=gn2, x2=blk['y2'], w=PB[p + 'conv2.conv.weight'], y=gn1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1,
+                       pad=1, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st2'], pro_bstats=bs2, epi=lib.EPI_GP, aux=blk['y1'],
+                       aux_stats=blk['st1'], part=part)
+            bs1 = self._bstats(part, B, nt, c, L)
+            self._wgrad(p + 'conv2.conv.weight', g=gn2, g2=blk['y2'], g_stats=blk['st2'], g_bstats=bs2, pro_g=lib.PRO_INBWD, x=blk['y1'],
+                        x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=1)
+            del gn2
+            if i > 0:
+                # residual 1x1/stride-2 branch: R = Wd^T gpre, added at even positions inside conv1's data-gradient epilogue
+                Rr = torch.empty(B, Lh, cin, device=dev, dtype=torch.float32)
+                self._conv(x=gpre, w=PB[p + 'downsample.weight'], y=Rr, B=B, L_in=Lh, L_out=Lh, cin=c, cout=cin, taps=1, stride=1, pad=0)
+                gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
+                self._conv(x=gn1, x2=blk['y1'], w=PB[p + 'conv1.conv.weight'], y=gprev, B=B, L_in=L, L_out=L, cin=c, cout=cin, taps=3,
+                           stride=1, pad=1, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st1'], pro_bstats=bs1, epi=lib.EPI_GP, aux=blk['pin'],
+                           add_even=Rr)
+                self._wgrad(p + 'conv1.conv.weight', g=gn1, g2=blk['y1'], g_stats=blk['st1'], g_bstats=bs1, pro_g=lib.PRO_INBWD,
+                            x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=L, cin=cin, cout=c, taps=3, stride=1, pad=1)
+                self._wgrad(p + 'downsample.weight', g=gpre, x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=Lh, cin=cin, cout=c,
+                            taps=1, stride=2, pad=0)
+                gpre = gprev
+            else:
+                nslab = max(1, min(1024, _cdiv(B * L, 4096)))
+                slab = torch.empty(nslab, 64, device=dev, dtype=torch.float32)
+                lib.enc_first_bwd(ec['x'], gn1, blk['y1'], blk['st1'], bs1, gpre, slab, nslab, B, L, c)
+                n1, nd = p + 'conv1.conv.weight', p + 'downsample.weight'
+                lib.colsum(slab, nslab, 48, self.G[n1], accumulate=n1 in self._written, ld=64)
+                lib.colsum(slab.view(-1)[48:], nslab, 16, self.G[nd], accumulate=nd in self._written, ld=64)
+                self._written.update((n1, nd))

@@ -1,0 +1,238 @@
+"""ctypes binding of libw2s_hip.so (include/w2s.h).  PyTorch only supplies device memory and the stream.
+
+There is NO fallback: if the shared library is missing or a kernel returns an error, this raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libw2s_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+# enums (include/w2s.h)
+PRO_NONE, PRO_SANITIZE, PRO_GELU, PRO_IN_GELU, PRO_INBWD, PRO_INBWD_GP = range(6)
+EPI_PLAIN, EPI_STATS, EPI_AUX_INGELU_ADD, EPI_BIAS, EPI_GP = range(5)
+MODE_CONTIG, MODE_DILATED, MODE_UP2 = range(3)
+ELT_GELU, ELT_GELU_BWD, ELT_ADD, ELT_ADD_DROP, ELT_DROP, ELT_GELU_DROP, ELT_GELU_DROP_BWD = range(7)
+
+_fp = C.c_void_p
+_i32 = C.c_int32
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [(n, _fp) for n in ('x', 'x2', 'w', 'y', 'y2', 'pro_stats', 'pro_bstats', 'aux', 'aux_stats', 'add_even', 'bias',
+                                   'rowkeep', 'part')] + \
+               [(n, _i32) for n in ('B', 'L_in', 'L_out', 'cin', 'cout', 'taps', 'stride', 'dil', 'pad', 'flip', 'mode',
+                                    'ldx', 'ldy', 'ldy2', 'ld_aux', 'pro', 'epi')]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [(n, _fp) for n in ('g', 'g2', 'g_stats', 'g_bstats', 'x', 'x_stats', 'slab')] + \
+               [(n, _i32) for n in ('B', 'L_in', 'L_out', 'cin', 'cout', 'taps', 'stride', 'dil', 'pad', 'ldg', 'ldx',
+                                    'pro_g', 'pro_h', 'nslab')]
+
+
+EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_reduce', 'w2s_repack',
+           'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
+           'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_eltwise',
+           'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
+           'w2s_clip_coef', 'w2s_adamw', 'w2s_version']
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libw2s_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(['make', '-C', CSRC, '-j8'], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('building libw2s_hip.so failed:\n' + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+def load():
+    """Load the HIP library; raise loudly if it is not there (no CPU path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                               f'(or `make -C wav2sleep_amd/csrc`). wav2sleep_amd has no CPU fallback.')
+        lib = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                raise RuntimeError(f'{LIB_PATH} does not export {name}')
+        lib.w2s_version.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+class W2SError(RuntimeError):
+    pass
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise W2SError(f'{what} failed with code {rc} ({ {-1: "EINVAL", -2: "ELAUNCH"}.get(rc, "?")})')
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise W2SError('wav2sleep_amd kernels need device tensors (no CPU path)')
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f(t):
+    assert t is None or (t.dtype == torch.float32), 'fp32 tensors only'
+    return _p(t)
+
+
+# ------------------------------------------------------------------------------------------------
+def conv_args(*, x, w, y, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, flip=0, mode=MODE_CONTIG, ldx=None, ldy=None,
+              pro=PRO_NONE, epi=EPI_PLAIN, x2=None, pro_stats=None, pro_bstats=None, aux=None, aux_stats=None, add_even=None,
+              bias=None, rowkeep=None, part=None, y2=None, ldy2=0, ld_aux=0) -> ConvArgs:
+    a = ConvArgs()
+    a.x, a.x2, a.w, a.y, a.y2 = _f(x), _f(x2), _f(w), _f(y), _f(y2)
+    a.pro_stats, a.pro_bstats, a.aux, a.aux_stats = _f(pro_stats), _f(pro_bstats), _f(aux), _f(aux_stats)
+    a.add_even, a.bias, a.rowkeep, a.part = _f(add_even), _f(bias), _f(rowkeep), _f(part)
+    a.B, a.L_in, a.L_out, a.cin, a.cout, a.taps, a.stride, a.dil, a.pad, a.flip, a.mode = B, L_in, L_out, cin, cout, taps, stride, dil, pad, flip, mode
+    a.ldx = cin if ldx is None else ldx
+    a.ldy = cout if ldy is None else ldy
+    a.ldy2 = ldy2 or cout
+    a.ld_aux = ld_aux or cout
+    a.pro, a.epi = pro, epi
+    return a
+
+
+def conv_tile(cin, cout, taps, stride, mode=MODE_CONTIG) -> int:
+    a = ConvArgs()
+    a.cin, a.cout, a.taps, a.stride, a.mode = cin, cout, taps, stride, mode
+    return load().w2s_conv_tile(C.byref(a))
+
+
+def conv_forward(a: ConvArgs):
+    _chk(load().w2s_conv_forward(C.byref(a), _stream()), f'w2s_conv_forward(cin={a.cin},cout={a.cout},taps={a.taps},stride={a.stride},mode={a.mode})')
+
+
+def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, ldg=None, ldx=None, pro_g=PRO_NONE,
+          pro_h=PRO_NONE, g2=None, g_stats=None, g_bstats=None, x_stats=None):
+    a = WgradArgs()
+    a.g, a.g2, a.g_stats, a.g_bstats, a.x, a.x_stats, a.slab = _f(g), _f(g2), _f(g_stats), _f(g_bstats), _f(x), _f(x_stats), _f(slab)
+    a.B, a.L_in, a.L_out, a.cin, a.cout, a.taps, a.stride, a.dil, a.pad = B, L_in, L_out, cin, cout, taps, stride, dil, pad
+    a.ldg = cout if ldg is None else ldg
+    a.ldx = cin if ldx is None else ldx
+    a.pro_g, a.pro_h, a.nslab = pro_g, pro_h, nslab
+    _chk(load().w2s_wgrad(C.byref(a), _stream()), f'w2s_wgrad(cin={cin},cout={cout},taps={taps},stride={stride})')
+
+
+def wgrad_grid_y(cin, cout, taps, dil=1) -> int:
+    return load().w2s_wgrad_grid_y(cin, cout, taps, dil)
+
+
+def wgrad_reduce(slab, nslab, grad, cout, cin, taps, dil=1, accumulate=False, layout=0):
+    _chk(load().w2s_wgrad_reduce(_f(slab), nslab, _f(grad), cout, cin, taps, dil, int(accumulate), layout, _stream()), 'w2s_wgrad_reduce')
+
+
+def repack(w, fwd, bwd, cout, cin, taps):
+    _chk(load().w2s_repack(_f(w), _f(fwd), _f(bwd), cout, cin, taps, _stream()), 'w2s_repack')
+
+
+def stats_finalize(part, B, ntiles, Cc, count, eps, kind, out):
+    _chk(load().w2s_stats_finalize(_f(part), B, ntiles, Cc, C.c_long(count), C.c_float(eps), kind, _f(out), _stream()), 'w2s_stats_finalize')
+
+
+def enc_first_fwd(x, w, y, part, B, L, cout, tile):
+    _chk(load().w2s_enc_first_fwd(_f(x), _f(w), _f(y), _f(part), B, L, cout, tile, _stream()), 'w2s_enc_first_fwd')
+
+
+def enc_first_join(x, wd, y3, stats3, pre, B, L, cout):
+    _chk(load().w2s_enc_first_join(_f(x), _f(wd), _f(y3), _f(stats3), _f(pre), B, L, cout, _stream()), 'w2s_enc_first_join')
+
+
+def enc_first_bwd(x, gn1, y1, stats1, bstats1, gpre, slab, nslab, B, L, cout):
+    _chk(load().w2s_enc_first_bwd(_f(x), _f(gn1), _f(y1), _f(stats1), _f(bstats1), _f(gpre), _f(slab), nslab, B, L, cout, _stream()),
+         'w2s_enc_first_bwd')
+
+
+def gp_stats(g, y, stats, part, B, L, Cc, tile):
+    _chk(load().w2s_gp_stats(_f(g), _f(y), _f(stats), _f(part), B, L, Cc, tile, _stream()), 'w2s_gp_stats')
+
+
+def layernorm_fwd(x, ldx, gamma, beta, y, ldy, rstat, rows, Cc, eps, gelu=False):
+    _chk(load().w2s_layernorm_fwd(_f(x), ldx, _f(gamma), _f(beta), _f(y), ldy, _f(rstat), rows, Cc, C.c_float(eps), int(gelu), _stream()),
+         'w2s_layernorm_fwd')
+
+
+def layernorm_bwd(g, ldg, x, ldx, gamma, beta, rstat, gadd, gx, ldgx, part_gamma, part_beta, rows, Cc, gelu, nparts):
+    _chk(load().w2s_layernorm_bwd(_f(g), ldg, _f(x), ldx, _f(gamma), _f(beta), _f(rstat), _f(gadd), _f(gx), ldgx, _f(part_gamma),
+                                  _f(part_beta), rows, Cc, int(gelu), nparts, _stream()), 'w2s_layernorm_bwd')
+
+
+def bias_grad(g, rows, Cc, ldg, part, nparts):
+    _chk(load().w2s_bias_grad(_f(g), rows, Cc, ldg, _f(part), nparts, _stream()), 'w2s_bias_grad')
+
+
+def colsum(part, nparts, Cc, out, accumulate=False, ld=None):
+    _chk(load().w2s_colsum(_f(part), nparts, Cc, Cc if ld is None else ld, _f(out), int(accumulate), _stream()), 'w2s_colsum')
+
+
+def gelu_bwd_rows(g, ldg, pre, keep, rows_per_sample, out, rows, Cc):
+    _chk(load().w2s_gelu_bwd_rows(_f(g), ldg, _f(pre), _f(keep), rows_per_sample, _f(out), rows, Cc, _stream()), 'w2s_gelu_bwd_rows')
+
+
+def fill_rows(dst, ld, src, rows, Cc):
+    _chk(load().w2s_fill_rows(_f(dst), ld, _f(src), rows, Cc, _stream()), 'w2s_fill_rows')
+
+
+def eltwise(op, a, b, y, n, p=0.0, seed=0):
+    _chk(load().w2s_eltwise(op, _f(a), _f(b), _f(y), C.c_long(n), C.c_float(p), C.c_uint64(seed), _stream()), 'w2s_eltwise')
+
+
+def attn_fwd(qkv, keypad, out, N, D, H, p=0.0, seed=0):
+    _chk(load().w2s_attn_fwd(_f(qkv), _p(keypad), _f(out), N, D, H, C.c_float(p), C.c_uint64(seed), _stream()), 'w2s_attn_fwd')
+
+
+def attn_bwd(qkv, keypad, gout, gqkv, N, D, H, p=0.0, seed=0):
+    _chk(load().w2s_attn_bwd(_f(qkv), _p(keypad), _f(gout), _f(gqkv), N, D, H, C.c_float(p), C.c_uint64(seed), _stream()), 'w2s_attn_bwd')
+
+
+def head_fwd(pre, ld, w, bias, logits, rows, F, nc, gelu_in):
+    _chk(load().w2s_head_fwd(_f(pre), ld, _f(w), _f(bias), _f(logits), rows, F, nc, int(gelu_in), _stream()), 'w2s_head_fwd')
+
+
+def ce_fwd_bwd(logits, labels, rows, nc, part, loss_out, glogits, cmat, gscale=1.0):
+    _chk(load().w2s_ce_fwd_bwd(_f(logits), _f(labels), rows, nc, _f(part), _f(loss_out), _f(glogits), _p(cmat), C.c_float(gscale), _stream()),
+         'w2s_ce_fwd_bwd')
+
+
+def head_bwd(pre, ld, w, glogits, gpre, ldg, part, nparts, rows, F, nc, gelu_in):
+    _chk(load().w2s_head_bwd(_f(pre), ld, _f(w), _f(glogits), _f(gpre), ldg, _f(part), nparts, rows, F, nc, int(gelu_in), _stream()),
+         'w2s_head_bwd')
+
+
+def sumsq_partial(g, n, part, nparts):
+    _chk(load().w2s_sumsq_partial(_f(g), C.c_long(n), _f(part), nparts, _stream()), 'w2s_sumsq_partial')
+
+
+def clip_coef(part, nparts, hyper, normcoef):
+    _chk(load().w2s_clip_coef(_f(part), nparts, _f(hyper), _f(normcoef), _stream()), 'w2s_clip_coef')
+
+
+def adamw(p, g, m, v, n, hyper, normcoef):
+    _chk(load().w2s_adamw(_f(p), _f(g), _f(m), _f(v), C.c_long(n), _f(hyper), _f(normcoef), _stream()), 'w2s_adamw')
+
+
+def version() -> str:
+    return load().w2s_version().decode()

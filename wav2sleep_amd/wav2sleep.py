@@ -1,0 +1,330 @@
+"""Host-side mirror of the reference's model surface (src/wav2sleep/models/{wav2sleep,blocks,utils}.py).
+
+Same class names, constructor arguments, attribute names and `state_dict` keys/shapes as the reference, so
+`load_model()` / Hydra `_target_` configs / reference checkpoints are drop-in.  The sub-modules below are
+PARAMETER CONTAINERS built from the same torch.nn classes the reference uses (identical default init under
+the same seed); none of their `forward`s run.  `Wav2Sleep.forward` hands the whole computation to the HIP
+engine (wav2sleep_amd/engine.py -> libw2s_hip.so) and plugs into autograd as ONE node.
+
+There is no CPU path: CPU tensors raise (lib.W2SError).
+"""
+
+from __future__ import annotations
+
+import logging
+import math
+
+import torch
+from torch import Tensor, nn
+
+from .engine import Engine, EngineSpec
+from .settings import COLS_TO_SAMPLES_PER_EPOCH
+
+logger = logging.getLogger(__name__)
+
+_NO_FORWARD = ('{} is a parameter container in wav2sleep_amd; run it through Wav2Sleep.forward '
+               '(the HIP engine fuses across module boundaries).')
+
+
+def _check_activation(name: str):
+    """models/utils.py:61-74 (only GELU has gfx950 kernels)."""
+    if name not in ('relu', 'leaky', 'gelu', 'silu', 'swish', 'linear'):
+        raise ValueError(f'{name=} is unsupported.')
+    if name != 'gelu':
+        raise NotImplementedError(f"activation '{name}' has no gfx950 kernel yet (production config uses 'gelu')")
+
+
+class ConvLayerNorm(nn.Module):
+    """models/utils.py:9-23 (weights [1, C, 1])."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(1, num_features, 1))
+        self.bias = nn.Parameter(torch.zeros(1, num_features, 1))
+        self.eps = eps
+
+
+class ConvLayer1D(nn.Module):
+    """models/blocks.py:129-186: holds `.conv` (+ `.norm` parameters for norm='layer')."""
+
+    def __init__(self, input_dim, output_dim, kernel_size=3, stride=1, padding=1, dilation=1, norm='instance'):
+        super().__init__()
+        self.conv = nn.Conv1d(input_dim, output_dim, kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation, bias=False)
+        if norm == 'layer':
+            self.norm = ConvLayerNorm(output_dim)
+        elif norm == 'instance':
+            self.norm = nn.Identity()  # InstanceNorm1d(affine=False) contributes no keys
+        else:
+            raise NotImplementedError(f"norm '{norm}' has no gfx950 kernel yet (production config: instance / layer)")
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(_NO_FORWARD.format('ConvLayer1D'))
+
+
+class ConvBlock1D(nn.Module):
+    """models/blocks.py:8-71."""
+
+    def __init__(self, input_dim, output_dim, norm='instance', use_residual=True):
+        super().__init__()
+        if not use_residual:
+            raise NotImplementedError('use_residual=False has no gfx950 kernel yet')
+        self.use_residual = use_residual
+        self.conv1 = ConvLayer1D(input_dim, output_dim, norm=norm)
+        self.conv2 = ConvLayer1D(output_dim, output_dim, norm=norm)
+        self.conv3 = ConvLayer1D(output_dim, output_dim, stride=2, norm=norm)
+        self.downsample = nn.Conv1d(input_dim, output_dim, kernel_size=1, stride=2, padding=0, bias=False)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(_NO_FORWARD.format('ConvBlock1D'))
+
+
+class DilatedConvBlock(nn.Module):
+    """models/blocks.py:74-126."""
+
+    def __init__(self, feature_dim=128, dropout=0.2, norm='layer', kernel_size=7, num_dilations=6):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.dilations = [2 ** i for i in range(num_dilations)]
+        blocks = []
+        for d in self.dilations:
+            k_eff = kernel_size + (kernel_size - 1) * (d - 1)
+            blocks.append(ConvLayer1D(feature_dim, feature_dim, kernel_size=kernel_size, dilation=d, padding=k_eff // 2, norm=norm))
+        self.conv_layers = nn.Sequential(*blocks)
+        self.dropout = nn.Dropout(p=dropout)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(_NO_FORWARD.format('DilatedConvBlock'))
+
+
+class SignalEncoder(nn.Module):
+    """models/wav2sleep.py:164-267 (non-causal path)."""
+
+    def __init__(self, input_dim=1, feature_dim=256, activation='gelu', samples_per_epoch=1024, norm='instance', initial_channels=16,
+                 max_channels=128, causal=False, chunk_causal=True, output_norm=False, use_residual=True):
+        super().__init__()
+        _check_activation(activation)
+        if causal or output_norm or norm != 'instance':
+            raise NotImplementedError('causal / output_norm / non-instance encoder norms have no gfx950 kernels yet')
+        self.feature_dim = feature_dim
+        self.samples_per_epoch = samples_per_epoch
+        self.causal = causal
+        self.chunk_causal = chunk_causal
+        if samples_per_epoch & (samples_per_epoch - 1) != 0:
+            raise ValueError(f'samples_per_epoch must be a power of 2, got {samples_per_epoch}')
+        num_blocks = int(math.log2(samples_per_epoch)) - 2
+        channels = [min(initial_channels * 2 ** (i // 2), max_channels) for i in range(num_blocks)]
+        blocks = []
+        for c in channels:
+            blocks.append(ConvBlock1D(input_dim, c, norm=norm, use_residual=use_residual))
+            input_dim = c
+        self.cnn = nn.Sequential(*blocks)
+        self.epoch_dim = channels[-1] * 4
+        self.linear = nn.Linear(self.epoch_dim, feature_dim)
+        self.output_norm = nn.Identity()
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(_NO_FORWARD.format('SignalEncoder'))
+
+
+class SignalEncoders(nn.Module):
+    """models/wav2sleep.py:83-161."""
+
+    def __init__(self, signal_map: dict[str, str], feature_dim: int, activation: str, norm: str = 'instance', causal: bool = False,
+                 chunk_causal: bool = True, embed_signals: bool = False, initial_channels: int = 16, max_channels: int = 128,
+                 output_norm: bool = False, use_residual: bool = True) -> None:
+        super().__init__()
+        if embed_signals:
+            raise NotImplementedError('embed_signals=True has no gfx950 kernel yet (off in every shipped config)')
+        self.feature_dim = feature_dim
+        self.signal_map = dict(signal_map)
+        self.causal = causal
+        self.initial_channels = initial_channels
+        self.max_channels = max_channels
+        encoders = {}
+        for signal_name, encoder_name in self.signal_map.items():
+            if encoder_name in encoders:
+                continue
+            if signal_name not in COLS_TO_SAMPLES_PER_EPOCH:
+                raise ValueError(f"Column {signal_name} unrecognised. Doesn't have a sampling rate.")
+            encoders[encoder_name] = SignalEncoder(input_dim=1, feature_dim=feature_dim, samples_per_epoch=COLS_TO_SAMPLES_PER_EPOCH[signal_name],
+                                                   activation=activation, norm=norm, causal=causal, chunk_causal=chunk_causal,
+                                                   initial_channels=initial_channels, max_channels=max_channels, output_norm=output_norm,
+                                                   use_residual=use_residual)
+        self.encoders = nn.ModuleDict(encoders)
+        self.embed_signals = embed_signals
+        self.sig_to_embedding_idx = {sig: i for i, sig in enumerate(sorted(signal_map.keys()))}
+        self.register_parameter('embedder', None)
+
+    def __len__(self) -> int:
+        return len(self.encoders)
+
+    def get_encoder(self, signal_name: str) -> SignalEncoder:
+        return self.encoders[self.signal_map[signal_name]]  # type: ignore
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(_NO_FORWARD.format('SignalEncoders'))
+
+
+class MultiModalAttentionEmbedder(nn.Module):
+    """models/wav2sleep.py:270-346."""
+
+    def __init__(self, feature_dim: int, layers: int = 4, dropout: float = 0.0, dim_ff: int = 512, activation: str = 'gelu',
+                 norm_first: bool = True, nhead: int = 4, register_tokens: int = 0):
+        super().__init__()
+        _check_activation(activation)
+        if not norm_first or register_tokens != 0:
+            raise NotImplementedError('post-norm / register tokens have no gfx950 kernels yet')
+        self.feature_dim = feature_dim
+        self.dropout_p = dropout
+        self.nhead = nhead
+        self.dim_ff = dim_ff
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            encoder_layer = nn.TransformerEncoderLayer(d_model=feature_dim, dim_feedforward=dim_ff, activation=nn.GELU(), nhead=nhead,
+                                                       batch_first=True, dropout=dropout, norm_first=norm_first)
+            self.num_layers = layers
+            self.transformer_encoder = nn.TransformerEncoder(encoder_layer, num_layers=layers)
+        self.num_register_tokens = register_tokens
+        self.register_tokens = nn.Parameter(torch.randn(1, 1, feature_dim, register_tokens + 1))
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(_NO_FORWARD.format('MultiModalAttentionEmbedder'))
+
+
+class SequenceCNN(nn.Module):
+    """models/wav2sleep.py:349-390."""
+
+    def __init__(self, feature_dim: int = 128, dropout: float = 0.2, num_layers: int = 2, activation: str = 'gelu', norm: str = 'batch',
+                 causal: bool = False, num_dilations: int = 6, kernel_size: int = 7) -> None:
+        super().__init__()
+        _check_activation(activation)
+        if causal or norm != 'layer':
+            raise NotImplementedError("SequenceCNN kernels cover the production config (norm='layer', causal=False)")
+        self.dropout_p = dropout
+        self.num_layers = num_layers
+        self.num_dilations = num_dilations
+        self.kernel_size = kernel_size
+        self.dilated_convs = nn.Sequential(*[DilatedConvBlock(feature_dim=feature_dim, dropout=dropout, norm=norm, kernel_size=kernel_size,
+                                                              num_dilations=num_dilations) for _ in range(num_layers)])
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(_NO_FORWARD.format('SequenceCNN'))
+
+
+class _W2SFunction(torch.autograd.Function):
+    """The whole forward/backward as one autograd node (inputs: the parameters, in named_parameters order)."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        eng = model._engine
+        eng.step_seed = model._next_seed() if model.training else 0
+        logits = eng.forward(x, train=model.training, save=save, pack_key=model.param_version())
+        ctx.model = model
+        ctx.saved = eng.ctx
+        eng.ctx = None
+        return logits
+
+    @staticmethod
+    def backward(ctx, glogits):
+        model = ctx.model
+        eng = model._engine
+        eng.ctx = ctx.saved
+        eng.backward(glogits.contiguous().float())
+        gflat = model._flat_grad.clone()  # fresh storage per backward: autograd may keep or accumulate these views
+        grads = tuple(gflat[o:o + n].view(shape) for (o, n, shape) in model._layout)
+        return (None, None) + grads
+
+
+class Wav2Sleep(nn.Module):
+    """models/wav2sleep.py:16-80 -- same constructor, attributes and state_dict; compute on libw2s_hip.so."""
+
+    def __init__(self, signal_encoders: SignalEncoders, epoch_mixer: MultiModalAttentionEmbedder, sequence_mixer: SequenceCNN,
+                 num_classes: int):
+        super().__init__()
+        self.signal_encoders = signal_encoders
+        self.epoch_mixer = epoch_mixer
+        self.sequence_mixer = sequence_mixer
+        self.feature_dim = self.epoch_mixer.feature_dim
+        self.num_classes = num_classes
+        self.classifier = nn.Linear(in_features=self.feature_dim, out_features=num_classes)
+        self._flat = None
+        self._flat_grad = None
+        self._engine: Engine | None = None
+        self._layout = []
+        self._seed_base = 0x5eed
+        self._seed_ctr = 0
+        self._param_epoch = 0
+
+    # ---------------------------------------------------------------- reference API
+    @property
+    def valid_signals(self) -> list[str]:
+        return list(self.signal_encoders.signal_map.keys())
+
+    def forward(self, x: dict[str, Tensor]) -> Tensor:
+        """dict[str -> [B, T_sig]] -> logits [B, S, num_classes]."""
+        self._ensure_flat()
+        params = [p for _, p in self.named_parameters()]
+        return _W2SFunction.apply(self, x, *params)
+
+    def predict(self, x: dict[str, Tensor]) -> Tensor:
+        return self(x).argmax(axis=2)
+
+    # ---------------------------------------------------------------- engine plumbing
+    def spec(self) -> EngineSpec:
+        se, em, sm = self.signal_encoders, self.epoch_mixer, self.sequence_mixer
+        return EngineSpec(signal_map=dict(se.signal_map), feature_dim=self.feature_dim, num_classes=self.num_classes,
+                          initial_channels=se.initial_channels, max_channels=se.max_channels, mixer_layers=em.num_layers,
+                          mixer_nhead=em.nhead, mixer_dim_ff=em.dim_ff, mixer_dropout=em.dropout_p, seq_blocks=sm.num_layers,
+                          seq_dilations=sm.num_dilations, seq_kernel=sm.kernel_size, seq_dropout=sm.dropout_p)
+
+    def param_version(self) -> int:
+        """Changes whenever any parameter was written (torch in-place ops bump `_version`; the fused AdamW kernel
+        writes through raw pointers, so the trainer calls `mark_params_dirty()`).  Keys the packed-weight cache."""
+        return self._param_epoch * (1 << 40) + sum(p._version for p in self.parameters())
+
+    def mark_params_dirty(self):
+        self._param_epoch += 1
+
+    def _next_seed(self) -> int:
+        self._seed_ctr += 1
+        return (self._seed_base * 1000003 + self._seed_ctr) & 0x7FFFFFFF
+
+    def _ensure_flat(self):
+        """Move all parameters into ONE fp32 device buffer (16-B aligned slices); params become views of it.
+
+        One buffer => one clip-norm reduction, one AdamW launch, one RCCL all-reduce for all 183 tensors.
+        Re-done automatically if `.to()` / `load_state_dict(assign=True)` replaced the storage.
+        """
+        named = list(self.named_parameters())
+        dev = named[0][1].device
+        if dev.type != 'cuda':
+            from .lib import W2SError
+            raise W2SError('wav2sleep_amd runs on MI355X only: move the model to a cuda device (there is no CPU fallback)')
+        ok = self._flat is not None and self._flat.device == dev
+        if ok:
+            base = self._flat.data_ptr()
+            for (o, n, _), (_, p) in zip(self._layout, named):
+                if p.data_ptr() != base + 4 * o or p.dtype != torch.float32:
+                    ok = False
+                    break
+        if ok:
+            return
+        layout, off = [], 0
+        for _, p in named:
+            n = p.numel()
+            layout.append((off, n, tuple(p.shape)))
+            off += (n + 3) // 4 * 4
+        flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        gflat = torch.zeros(off, device=dev, dtype=torch.float32)
+        P, G = {}, {}
+        with torch.no_grad():
+            for (o, n, shape), (name, p) in zip(layout, named):
+                v = flat[o:o + n].view(shape)
+                v.copy_(p.detach().to(torch.float32))
+                p.data = v
+                P[name] = v
+                G[name] = gflat[o:o + n].view(shape)
+        self._flat, self._flat_grad, self._layout = flat, gflat, layout
+        self._engine = Engine(self.spec(), P, G)
