@@ -1,0 +1,235 @@
+"""Progressive GPU check of libw2s_hip.so against CPU torch / the oracle.  Prints a table; never stops early.
+Run on the GPU box:  python tools/gpu_check.py [stage ...]"""
+import os, sys, math, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from wav2sleep_amd import lib
+from oracle import wav2sleep_oracle as O
+
+dev = 'cuda'
+torch.manual_seed(0)
+RES = []
+
+def report(name, got, want, tol=1e-4):
+    got = got.detach().float().cpu(); want = want.detach().float().cpu()
+    err = (got - want).abs().max().item(); scale = want.abs().max().item() + 1e-12
+    ok = err <= tol * max(1.0, scale)
+    RES.append((name, ok))
+    print(f'{"OK  " if ok else "FAIL"} {name:55s} maxerr {err:.3e} (scale {scale:.3e})', flush=True)
+
+def cl(x):  # [B,C,L] -> channels-last [B,L,C]
+    return x.transpose(1, 2).contiguous()
+
+def pack_fwd(w):  # torch [o][c][j] -> [o][j][c]
+    return w.permute(0, 2, 1).contiguous()
+
+def run(fn):
+    try:
+        fn()
+    except Exception as e:
+        traceback.print_exc(); RES.append((fn.__name__, False)); print('FAIL', fn.__name__, 'exception', e, flush=True)
+
+def t_conv_plain():
+    for (cin, cout, taps, stride, L) in [(16, 16, 3, 1, 700), (16, 32, 3, 1, 512), (32, 32, 3, 2, 1000), (64, 64, 3, 1, 300), (64, 128, 3, 1, 260),
+                                         (128, 128, 3, 1, 200), (128, 128, 3, 2, 256), (16, 32, 1, 2, 512), (128, 128, 1, 2, 128), (128, 384, 1, 1, 333), (128, 64, 1, 1, 100)]:
+        B = 2
+        x = torch.randn(B, cin, L); w = torch.randn(cout, cin, taps) / math.sqrt(cin * taps)
+        pad = 1 if taps == 3 else 0
+        want = F.conv1d(x, w, stride=stride, padding=pad)
+        Lo = want.shape[-1]
+        xd, wd = cl(x).to(dev), pack_fwd(w).to(dev)
+        y = torch.zeros(B, Lo, cout, device=dev)
+        lib.conv_forward(lib.conv_args(x=xd, w=wd, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad))
+        report(f'conv {cin}->{cout} k{taps} s{stride} L{L}', y, cl(want))
+
+def t_conv_stats_pro():
+    B, cin, cout, L = 2, 16, 16, 1000
+    x = torch.randn(B, cin, L) * 2 + 0.5; w = torch.randn(cout, cin, 3) / 7
+    mean = x.mean(2); var = x.var(2, unbiased=False); rstd = 1 / torch.sqrt(var + 1e-2)
+    st = torch.stack([mean, rstd], -1).to(dev)
+    h = F.gelu(F.instance_norm(x, eps=1e-2))
+    want = F.conv1d(h, w, padding=1)
+    y = torch.zeros(B, L, cout, device=dev)
+    tile = lib.conv_tile(cin, cout, 3, 1); nt = (L + tile - 1) // tile
+    part = torch.zeros(B, nt, 2, cout, device=dev)
+    lib.conv_forward(lib.conv_args(x=cl(x).to(dev), w=pack_fwd(w).to(dev), y=y, B=B, L_in=L, L_out=L, cin=cin, cout=cout, taps=3, stride=1, pad=1,
+                                   pro=lib.PRO_IN_GELU, pro_stats=st, epi=lib.EPI_STATS, part=part))
+    report('conv IN_GELU prologue', y, cl(want))
+    out = torch.zeros(B, cout, 2, device=dev)
+    lib.stats_finalize(part, B, nt, cout, L, 1e-2, 0, out)
+    report('stats mean', out[..., 0], want.mean(2))
+    report('stats rstd', out[..., 1], 1 / torch.sqrt(want.var(2, unbiased=False) + 1e-2))
+
+def t_conv_dilated():
+    B, C, S = 2, 128, 200
+    for d in (1, 4, 32):
+        x = torch.randn(B, C, S); w = torch.randn(C, C, 7) / 30
+        want = F.conv1d(x, w, padding=3 * d, dilation=d)
+        y = torch.zeros(B, S, C, device=dev)
+        lib.conv_forward(lib.conv_args(x=cl(x).to(dev), w=pack_fwd(w).to(dev), y=y, B=B, L_in=S, L_out=S, cin=C, cout=C, taps=7, stride=1, dil=d,
+                                       pad=3 * d, mode=lib.MODE_DILATED))
+        report(f'dilated conv d={d}', y, cl(want))
+    # taps=4/stride=4 linear over [B,4S,C]
+    Cc = 64
+    x = torch.randn(B, 4 * S, Cc); W = torch.randn(128, 4 * Cc) / 16; bias = torch.randn(128)
+    want = F.linear(x.reshape(B, S, 4 * Cc), W, bias)
+    y = torch.zeros(B, S, 128, device=dev)
+    lib.conv_forward(lib.conv_args(x=x.to(dev), w=W.to(dev), y=y, B=B, L_in=4 * S, L_out=S, cin=Cc, cout=128, taps=4, stride=4, pad=0,
+                                   mode=lib.MODE_DILATED, epi=lib.EPI_BIAS, bias=bias.to(dev)))
+    report('linear as taps4/stride4', y, want)
+
+def t_dgrad():
+    B = 2
+    for (cin, cout, stride, L) in [(16, 16, 1, 600), (32, 64, 1, 300), (16, 16, 2, 600), (128, 128, 2, 256), (64, 64, 2, 520)]:
+        x = torch.randn(B, cin, L, requires_grad=True); w = torch.randn(cout, cin, 3) / 7
+        y = F.conv1d(x, w, stride=stride, padding=1)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        Lo = y.shape[-1]
+        wb = w.permute(1, 2, 0).contiguous().to(dev)  # [cin][taps][cout]
+        gx = torch.zeros(B, L, cin, device=dev)
+        if stride == 1:
+            a = lib.conv_args(x=cl(gy).to(dev), w=wb, y=gx, B=B, L_in=Lo, L_out=L, cin=cout, cout=cin, taps=3, stride=1, pad=1, flip=1)
+        else:
+            a = lib.conv_args(x=cl(gy).to(dev), w=wb, y=gx, B=B, L_in=Lo, L_out=L, cin=cout, cout=cin, taps=3, stride=2, pad=1, mode=lib.MODE_UP2)
+        lib.conv_forward(a)
+        report(f'dgrad {cin}->{cout} s{stride}', gx, cl(x.grad))
+
+def t_wgrad():
+    B = 2
+    for (cin, cout, taps, stride, dil, L) in [(16, 16, 3, 1, 1, 700), (16, 32, 3, 1, 1, 300), (32, 32, 3, 2, 1, 600), (64, 64, 3, 1, 1, 300), (64, 128, 3, 2, 1, 256),
+                                              (128, 128, 3, 1, 1, 200), (128, 128, 7, 1, 4, 200), (16, 32, 1, 2, 1, 512), (128, 384, 1, 1, 1, 300), (64, 128, 1, 2, 1, 256)]:
+        pad = (taps // 2) * dil
+        x = torch.randn(B, cin, L); w = (torch.randn(cout, cin, taps) / 7).requires_grad_(True)
+        y = F.conv1d(x, w, stride=stride, padding=pad, dilation=dil)
+        gy = torch.randn_like(y); y.backward(gy)
+        Lo = y.shape[-1]
+        gyd = lib.wgrad_grid_y(cin, cout, taps, dil)
+        nslab = 4 * 8
+        slab = torch.zeros(nslab * cout * cin * taps, device=dev)
+        lib.wgrad(g=cl(gy).to(dev), x=cl(x).to(dev), slab=slab, nslab=nslab, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
+                  pad=pad, dil=dil)
+        gw = torch.zeros(cout, cin, taps, device=dev)
+        lib.wgrad_reduce(slab, nslab, gw, cout, cin, taps, dil)
+        report(f'wgrad {cin}->{cout} k{taps} s{stride} d{dil}', gw, w.grad, tol=3e-4)
+
+def t_rowops():
+    rows, C = 1000, 128
+    x = torch.randn(rows, C, requires_grad=True); g = torch.randn(C) + 1; b = torch.randn(C)
+    g.requires_grad_(True); b.requires_grad_(True)
+    for gelu in (False, True):
+        x.grad = g.grad = b.grad = None
+        y = F.layer_norm(x, (C,), g, b, 1e-5)
+        if gelu: y = F.gelu(y)
+        go = torch.randn_like(y); y.backward(go)
+        yd = torch.zeros(rows, C, device=dev); rs = torch.zeros(rows, 2, device=dev)
+        lib.layernorm_fwd(x.detach().to(dev), C, g.detach().to(dev), b.detach().to(dev), yd, C, rs, rows, C, 1e-5, gelu)
+        report(f'layernorm fwd gelu={gelu}', yd, y)
+        gx = torch.zeros(rows, C, device=dev); npl = 16
+        pg = torch.zeros(npl, C, device=dev); pb = torch.zeros(npl, C, device=dev)
+        lib.layernorm_bwd(go.to(dev), C, x.detach().to(dev), C, g.detach().to(dev), b.detach().to(dev), rs, None, gx, C, pg, pb, rows, C, gelu, npl)
+        report(f'layernorm bwd gx gelu={gelu}', gx, x.grad)
+        dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+        lib.colsum(pg, npl, C, dg); lib.colsum(pb, npl, C, db)
+        report(f'layernorm bwd dgamma gelu={gelu}', dg, g.grad, tol=3e-4); report(f'layernorm bwd dbeta gelu={gelu}', db, b.grad, tol=3e-4)
+
+def t_attn():
+    N, D, H = 50, 5, 8; Fd = 128
+    qkv = torch.randn(N * D, 3 * Fd, requires_grad=True)
+    pad = torch.zeros(N, D, dtype=torch.bool); pad[::3, 2] = True; pad[1::4, 4] = True
+    q, k, v = qkv.view(N, D, 3, H, 16).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) / 4
+    s = s.masked_fill(pad[:, None, None, :], float('-inf'))
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(N * D, Fd)
+    go = torch.randn_like(o); o.backward(go)
+    od = torch.zeros(N * D, Fd, device=dev)
+    kp = pad.to(torch.uint8).to(dev)
+    lib.attn_fwd(qkv.detach().to(dev), kp, od, N, D, H)
+    report('attn fwd', od, o)
+    gq = torch.zeros(N * D, 3 * Fd, device=dev)
+    lib.attn_bwd(qkv.detach().to(dev), kp, go.to(dev), gq, N, D, H)
+    report('attn bwd', gq, qkv.grad)
+
+def t_head_optim():
+    rows, Fd, nc = 700, 128, 5
+    pre = torch.randn(rows, Fd, requires_grad=True); W = (torch.randn(nc, Fd) / 10).requires_grad_(True); b = torch.randn(nc).requires_grad_(True)
+    y = torch.randint(0, nc, (rows,)).float(); y[::7] = -1
+    logits = F.linear(F.gelu(pre), W, b)
+    loss = F.cross_entropy(logits, y.long(), ignore_index=-1); loss.backward()
+    lg = torch.zeros(rows, nc, device=dev)
+    lib.head_fwd(pre.detach().to(dev), Fd, W.detach().to(dev), b.detach().to(dev), lg, rows, Fd, nc, True)
+    report('head logits', lg, logits)
+    part = torch.zeros((rows + 255) // 256, 2, device=dev); lo = torch.zeros(2, device=dev); gl = torch.zeros(rows, nc, device=dev)
+    cm = torch.zeros(nc, nc, dtype=torch.int64, device=dev)
+    lib.ce_fwd_bwd(lg, y.to(dev), rows, nc, part, lo, gl, cm, 1.0)
+    report('ce loss', lo[0], loss); 
+    report('cmat', cm.float(), O.confusion_matrix(logits.argmax(-1), y, nc).float())
+    gp = torch.zeros(rows, Fd, device=dev); npart = 8; pp = torch.zeros(npart, nc * Fd + nc, device=dev)
+    lib.head_bwd(pre.detach().to(dev), Fd, W.detach().to(dev), gl, gp, Fd, pp, npart, rows, Fd, nc, True)
+    report('head gpre', gp, pre.grad, tol=1e-5)
+    gw = torch.zeros(nc, Fd, device=dev); gb = torch.zeros(nc, device=dev)
+    lib.colsum(pp, npart, nc * Fd, gw, ld=nc * Fd + nc); lib.colsum(pp.view(-1)[nc * Fd:], npart, nc, gb, ld=nc * Fd + nc)
+    report('head dW', gw, W.grad, tol=1e-5); report('head db', gb, b.grad, tol=1e-5)
+    # adamw + clip
+    n = 10007
+    p = torch.randn(n); g = torch.randn(n) * 3
+    sd = {'p': p.clone()}; st = {}
+    gg = {'p': g.clone()}; gn = O.clip_grad_norm(gg, 1.0); O.adamw_step(sd, gg, st, 5e-7)
+    pd, gd, m, v = p.to(dev), g.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    parts = torch.zeros(64, device=dev); lib.sumsq_partial(gd, n, parts, 64)
+    hyper = torch.tensor([5e-7, 1e-4, 0.9, 0.999, 1e-8, 1 - 0.9, 1 - 0.999, 1.0], device=dev); nc2 = torch.zeros(2, device=dev)
+    lib.clip_coef(parts, 64, hyper, nc2); lib.adamw(pd, gd, m, v, n, hyper, nc2)
+    report('grad norm', nc2[0], torch.tensor(gn)); report('adamw param', pd, sd['p'], tol=1e-6)
+
+def model_case(name, signal_map, nc, B, S, missing):
+    from wav2sleep_amd.wav2sleep import Wav2Sleep, SignalEncoders, MultiModalAttentionEmbedder, SequenceCNN
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc)
+    sd = O.make_state_dict(cfg, seed=3)
+    x, y = O.make_inputs(cfg, B, S, seed=5, missing=missing)
+    model = Wav2Sleep(SignalEncoders(signal_map, 128, 'gelu', chunk_causal=False), MultiModalAttentionEmbedder(128, layers=2, dropout=0.0, nhead=8),
+                      SequenceCNN(128, dropout=0.0, norm='layer'), nc)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).train()
+    model._ensure_flat(); model._engine.taps = {}
+    xd = {k: v.to(dev) for k, v in x.items()}
+    logits = model(xd)
+    taps = {}
+    want = O.forward(sd, cfg, x, taps)
+    T = model._engine.taps
+    for sig in signal_map:
+        enc = signal_map[sig]
+        for i in range(len(cfg.encoder_channels(sig))):
+            k = f'signal_encoders.encoders.{enc}.cnn.{i}.out'
+            if sum(1 for s2 in signal_map if signal_map[s2] == enc) == 1:
+                report(f'{name} {sig} block{i}', F.gelu(T[f'{sig}.pre.{i}']), cl(taps[k]), tol=2e-4)
+    report(f'{name} mixer', T['mixer'], taps['mixer'], tol=2e-4)
+    report(f'{name} seq', F.gelu(T['seq_pre']), taps['seq'], tol=2e-4)
+    report(f'{name} logits', logits, want, tol=2e-4)
+    agree = (logits.argmax(-1).cpu() == want.argmax(-1)).float().mean().item()
+    print(f'     argmax agreement {agree:.4f}')
+    loss = F.cross_entropy(logits.view(-1, nc), y.to(dev).view(-1).long(), ignore_index=-1)
+    loss.backward()
+    l0, _, grads = O.loss_and_grads(sd, cfg, x, y)
+    report(f'{name} loss', loss, torch.tensor(l0), tol=1e-5)
+    worst = 0
+    for k, p in model.named_parameters():
+        g = p.grad.cpu(); w = grads[k]
+        rel = ((g - w).norm() / (w.norm() + 1e-12)).item()
+        worst = max(worst, rel)
+        if rel > 2e-3:
+            print(f'     grad mismatch {k}: rel {rel:.3e} |want| {w.norm():.3e} |got| {g.norm():.3e}')
+    RES.append((f'{name} grads', worst <= 2e-3)); print(f'{"OK  " if worst <= 2e-3 else "FAIL"} {name} grads worst rel-L2 {worst:.3e}', flush=True)
+
+def t_model_c1(): model_case('c1', {'ECG': 'UNI'}, 4, 2, 4, None)
+def t_model_c2(): model_case('c2', {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}, 4, 3, 4, {'ABD': [1], 'PPG': [2]})
+def t_model_c4(): model_case('c4', {'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 2, {'EOG-R': [0]})
+
+STAGES = dict(conv=t_conv_plain, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+              head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
+if __name__ == '__main__':
+    print(lib.version(), torch.cuda.get_device_name(0))
+    for s in (sys.argv[1:] or list(STAGES)):
+        run(STAGES[s]); torch.cuda.synchronize()
+    bad = [n for n, ok in RES if not ok]
+    print(f'SUMMARY: {len(RES) - len(bad)}/{len(RES)} ok; failed: {bad}')

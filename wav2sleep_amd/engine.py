@@ -76,6 +76,7 @@ class Engine:
         self.step_seed = 0
         self._written: set[str] = set()
         self.ctx = None
+        self.taps = None  # set to {} to collect per-stage tensors (tests / debugging)
         lib.load()
 
     # ------------------------------------------------------------------ weights
@@ -211,6 +212,8 @@ class Engine:
                                    pro=lib.PRO_IN_GELU, pro_stats=st2)
         pre = torch.empty(B, L // 2, c, device=dev, dtype=torch.float32)
         lib.enc_first_join(x, P[pfx + 'cnn.0.downsample.weight'], y3, st3, pre, B, L, c)
+        if self.taps is not None:
+            self.taps.update({f'{sig}.y1.0': y1, f'{sig}.st1.0': st1, f'{sig}.y2.0': y2, f'{sig}.y3.0': y3, f'{sig}.pre.0': pre})
         if save:
             blocks.append(dict(y1=y1, st1=st1, y2=y2, st2=st2, y3=y3, st3=st3, pin=None, L=L, cin=1, c=c))
         pin, cin, L = pre, c, L // 2
@@ -228,6 +231,8 @@ class Engine:
                        pro=lib.PRO_GELU, epi=lib.EPI_AUX_INGELU_ADD, aux=y3, aux_stats=st3)
             if save:
                 blocks.append(dict(y1=y1, st1=st1, y2=y2, st2=st2, y3=y3, st3=st3, pin=pin, L=L, cin=cin, c=c))
+            if self.taps is not None:
+                self.taps[f'{sig}.pre.{i}'] = pre
             pin, cin, L = pre, c, L // 2
         # ---- time-distributed dense + GELU (wav2sleep.py:261-265): taps=4/stride=4 over the [B,4S,C] map
         F = sp.feature_dim
@@ -235,6 +240,8 @@ class Engine:
         self._conv(x=pin, w=P[pfx + 'linear.weight'], y=zpre, B=B, L_in=4 * S, L_out=S, cin=cin, cout=F, taps=4, stride=4, pad=0,
                    mode=lib.MODE_DILATED, pro=lib.PRO_GELU, epi=lib.EPI_BIAS, bias=P[pfx + 'linear.bias'], rowkeep=keep,
                    y2=tok_slice, ldy2=ldtok)
+        if self.taps is not None:
+            self.taps[f'{sig}.zpre'] = zpre
         return dict(sig=sig, enc=enc, x=x, keep=keep, blocks=blocks, plast=pin, zpre=zpre, S=S, B=B) if save else None
 
     # ------------------------------------------------------------------ full forward
@@ -297,6 +304,9 @@ class Engine:
                 layers.append(dict(X=X, rs1=rs1, h=h, qkv=qkv, ao=ao, X1=X1, rs2=rs2, h2=h2, f1=f1, a1=a1))
             X = X2
 
+        if self.taps is not None:
+            self.taps['tokens'] = tokens
+            self.taps['mixer'] = X.view(N, D * F)[:, :F].reshape(B, S, F)
         # ---- SequenceCNN over the CLS rows (row n*D of X; ld = D*F) -- wav2sleep.py:345, 379-390
         xin, ldin = X, D * F
         seq = []
@@ -330,6 +340,8 @@ class Engine:
                 lib.eltwise(lib.ELT_GELU, pre_out, None, act, B * S * F)
                 xin, ldin = act, F
 
+        if self.taps is not None:
+            self.taps['seq_pre'] = pre_out
         logits = torch.empty(B, S, sp.num_classes, device=dev, dtype=torch.float32)
         lib.head_fwd(pre_out, F, P['classifier.weight'], P['classifier.bias'], logits, B * S, F, sp.num_classes, True)
         if save:

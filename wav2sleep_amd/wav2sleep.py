@@ -217,7 +217,7 @@ class _W2SFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, *params):
-        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        save = any(ctx.needs_input_grad[2:])  # (grad mode is off inside Function.forward)
         eng = model._engine
         eng.step_seed = model._next_seed() if model.training else 0
         logits = eng.forward(x, train=model.training, save=save, pack_key=model.param_version())
