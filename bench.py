@@ -1,0 +1,157 @@
+"""Headline benchmark: overnight-recordings/sec for a full train step (fwd + masked CE + bwd + clip + AdamW
+[+ RCCL all-reduce]) at per-GPU batch 16 -- BASELINE.json `metric`, workload = configs[1] (4-modality
+ABD+THX+ECG+PPG, 8 h = 960 epochs, 4 classes, batch 16), synthetic z-scored-like inputs resident in HBM,
+reference weights initialisation (random), fp32 end to end (the reference trains `32-true`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  Extra legs, outside the timed region: `roofline` (per-launch HIP-event timing of
+the dominant kernel in one extra step) and `cpu_baseline` (the CPU oracle = the stock-ATen path the reference runs,
+timed on this box's host cores on a bounded sample: the same workload at micro-batch 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+SIGNAL_MAP = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
+SPE = {'ABD': 256, 'THX': 256, 'ECG': 1024, 'PPG': 1024}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak
+
+
+def make_batch(batch, epochs, num_classes, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = {s: torch.randn(batch, epochs * SPE[s], device=device, generator=g) for s in SIGNAL_MAP}
+    y = torch.randint(0, num_classes, (batch, epochs), device=device, generator=g).float()
+    y[torch.rand(batch, epochs, device=device, generator=g) < 0.1] = -1.0
+    return x, y
+
+
+def cpu_baseline(epochs, num_classes, budget_s=30.0):
+    """CPU 'port' baseline: oracle train step (stock ATen CPU kernels, fp32) at micro-batch 1 of the same workload."""
+    from oracle import wav2sleep_oracle as O
+    cfg = O.ModelConfig(signal_map=SIGNAL_MAP, num_classes=num_classes)
+    sd = O.make_state_dict(cfg, seed=42)
+    x, y = O.make_inputs(cfg, 1, epochs, seed=1234)
+    state = {}
+    t0 = time.time()
+    O.train_step(sd, cfg, x, y, state)  # warm-up (oneDNN primitive caching)
+    times = []
+    while len(times) < 2 or (time.time() - t0 < budget_s and len(times) < 5):
+        t1 = time.time()
+        O.train_step(sd, cfg, x, y, state)
+        times.append(time.time() - t1)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': round(1.0 / med, 4), 'unit': 'recordings/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'full train step, same 4-modality {epochs}-epoch workload at micro-batch 1, median of {len(times)} steps after 1 warm-up '
+                      f'({med:.2f} s/step); oracle/wav2sleep_oracle.py on stock torch CPU ops'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--epochs', type=int, default=960)
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    import wav2sleep_amd as W
+    from wav2sleep_amd import lib
+    torch.manual_seed(42)  # scripts/config/main.yaml:35
+    nc = 4
+    model = W.Wav2Sleep(W.SignalEncoders(SIGNAL_MAP, 128, 'gelu', norm='instance', chunk_causal=False),
+                        W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.1, dim_ff=512, nhead=8),
+                        W.SequenceCNN(128, dropout=0.1, norm='layer', num_layers=2, kernel_size=7, num_dilations=6), nc).to(dev).train()
+    if world > 1:  # DDP init: broadcast rank 0's parameters
+        model._ensure_flat()
+        dist.broadcast(model._flat, src=0)
+    trainer = W.FusedTrainStep(model)
+    x, y = make_batch(args.batch, args.epochs, nc, dev, 1234 + rank)
+
+    for _ in range(args.warmup):
+        trainer.step(x, y)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(x, y)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(out['loss'])
+
+    line = {'metric': 'overnight-recordings/sec (train step, bs=16)', 'value': round(args.batch * world * args.steps / dt, 3), 'unit': 'recordings/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'4-modality (ABD+THX+ECG+PPG) {args.epochs}-epoch ({args.epochs // 120} h) synthetic, 4-class, per-GPU batch {args.batch}, '
+                                   f'full train step fwd+CE+bwd+clip+AdamW', 'global_batch': args.batch * world, 'epochs': args.epochs,
+                       'parallelism': f'dp{world}', 'final_loss': round(loss, 5)}}
+
+    if rank == 0 and not args.no_roofline:
+        # one extra, untimed step with a HIP event pair around every GEMM-shaped launch
+        lib.TIMER = lib.LaunchTimer()
+        trainer.step(x, y)
+        agg = lib.TIMER.summary()
+        lib.TIMER = None
+        total_ms = sum(d['ms'] for d in agg.values())
+        key, d = max(agg.items(), key=lambda kv: kv[1]['ms'])
+        avg_s = d['ms'] / d['launches'] / 1e3
+        b_per, f_per = d['bytes'] / d['launches'], d['flops'] / d['launches']
+        ai = f_per / b_per
+        if ai > MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9):
+            ach = f_per / avg_s / 1e12
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TF, 4)}
+        else:
+            ach = b_per / avg_s / 1e9
+            roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
+        roof.update({'traffic': None, 'kernel': key, 'launches_per_step': d['launches'], 'avg_us': round(avg_s * 1e6, 1),
+                     'share_of_gemm_kernel_time': round(d['ms'] / total_ms, 3), 'algorithmic_bytes_per_launch': int(b_per),
+                     'flops_per_launch': int(f_per)})
+        # whole-step view against the SURVEY 8d convention (3x forward algorithmic bytes, fp32 storage)
+        elems_fwd = {'ABD': 62.2e6, 'THX': 62.2e6, 'ECG': 266.4e6, 'PPG': 266.4e6}
+        step_bytes = 3 * 4 * sum(elems_fwd.values()) * (args.epochs / 960) * args.batch
+        roof['step_algorithmic_GBps'] = round(step_bytes / (dt / args.steps) / 1e9, 1)
+        roof['step_frac_of_hbm_peak'] = round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
+        line['roofline'] = roof
+        top = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])[:12]
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'bench_launch_breakdown.json'), 'w') as f:
+            json.dump({k: v for k, v in top}, f, indent=1)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        line['cpu_baseline'] = cpu_baseline(args.epochs, nc)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

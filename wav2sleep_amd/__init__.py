@@ -1,0 +1,11 @@
+"""wav2sleep hot path (train step / inference forward) on AMD Instinct MI355X -- hand-written HIP kernels
+(wav2sleep_amd/csrc -> libw2s_hip.so, C ABI in include/w2s.h) behind the reference's own module surface."""
+from .api import load_model, predict  # noqa: F401
+from .stats import cohens_kappa, confusion_accuracy  # noqa: F401
+from .trainer import (ExpWarmUpScheduler, FusedTrainStep, SignalMasker, SleepLightningModule, SleepModule,  # noqa: F401
+                      exp_warmup_lr, invert_signals)
+from .wav2sleep import MultiModalAttentionEmbedder, SequenceCNN, SignalEncoders, Wav2Sleep  # noqa: F401
+
+__all__ = ['Wav2Sleep', 'SignalEncoders', 'MultiModalAttentionEmbedder', 'SequenceCNN', 'load_model', 'predict', 'FusedTrainStep',
+           'SleepModule', 'SleepLightningModule', 'SignalMasker', 'invert_signals', 'ExpWarmUpScheduler', 'exp_warmup_lr',
+           'cohens_kappa', 'confusion_accuracy']

@@ -350,7 +350,7 @@ class Engine:
         return logits
 
     # ------------------------------------------------------------------ backward
-    def backward(self, glogits: torch.Tensor, accumulate: bool = False):
+    def backward(self, glogits: torch.Tensor, accumulate: bool = False, hook=None):
         """Gradients of everything saved by forward(save=True) into self.G (overwrite unless accumulate)."""
         sp, P, PB, c = self.spec, self.P, self.PB, self.ctx
         if c is None:
@@ -443,9 +443,15 @@ class Engine:
         # CLS parameter: sum of the token-0 rows' gradients
         self._colgrad('epoch_mixer.register_tokens', gX, N, F, ldg=D * F)
 
+        if hook is not None:
+            hook('_tail')  # mixer + sequence CNN + classifier gradients are final: their all-reduce can start
+
         # ---- encoders
+        encs = [ec['enc'] for ec in c['enc']]
         for m, ec in enumerate(c['enc']):
             self._encoder_backward(ec, gX.view(-1)[(1 + m) * F:], D * F)
+            if hook is not None and ec['enc'] not in encs[m + 1:]:
+                hook(ec['enc'])
 
         if not accumulate:
             for name, g in self.G.items():

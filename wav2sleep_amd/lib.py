@@ -122,8 +122,48 @@ def conv_tile(cin, cout, taps, stride, mode=MODE_CONTIG) -> int:
     return load().w2s_conv_tile(C.byref(a))
 
 
+class LaunchTimer:
+    """Optional per-launch HIP-event timing of the two GEMM-shaped kernels (bench.py roofline leg).  Events are
+    recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []  # (key, algorithmic bytes, flops, start event, end event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, nbytes, flops, e0, e1 in self.records:
+            d = agg.setdefault(key, dict(launches=0, ms=0.0, bytes=0, flops=0))
+            d['launches'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['bytes'] += nbytes
+            d['flops'] += flops
+        return agg
+
+
+TIMER: LaunchTimer | None = None
+
+
+def _timed(key, nbytes, flops, fn):
+    if TIMER is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    TIMER.records.append((key, nbytes, flops, e0, e1))
+
+
 def conv_forward(a: ConvArgs):
-    _chk(load().w2s_conv_forward(C.byref(a), _stream()), f'w2s_conv_forward(cin={a.cin},cout={a.cout},taps={a.taps},stride={a.stride},mode={a.mode})')
+    def run():
+        _chk(load().w2s_conv_forward(C.byref(a), _stream()), f'w2s_conv_forward(cin={a.cin},cout={a.cout},taps={a.taps},stride={a.stride},mode={a.mode})')
+    if TIMER is None:
+        return run()
+    out_el = a.B * a.L_out * a.cout
+    nbytes = 4 * (a.B * a.L_in * a.cin * (2 if a.x2 else 1) + out_el * (2 if a.y2 else 1) + (out_el if a.aux else 0) + (out_el // 2 if a.add_even else 0))
+    taps_eff = 1.5 if a.mode == MODE_UP2 else a.taps
+    flops = int(2 * out_el * a.cin * taps_eff)
+    _timed(f'conv_cl {a.cin}->{a.cout} k{a.taps} s{a.stride} mode{a.mode} pro{a.pro} epi{a.epi} L{a.L_out}', nbytes, flops, run)
 
 
 def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, ldg=None, ldx=None, pro_g=PRO_NONE,
@@ -134,7 +174,11 @@ def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, di
     a.ldg = cout if ldg is None else ldg
     a.ldx = cin if ldx is None else ldx
     a.pro_g, a.pro_h, a.nslab = pro_g, pro_h, nslab
-    _chk(load().w2s_wgrad(C.byref(a), _stream()), f'w2s_wgrad(cin={cin},cout={cout},taps={taps},stride={stride})')
+
+    def run():
+        _chk(load().w2s_wgrad(C.byref(a), _stream()), f'w2s_wgrad(cin={cin},cout={cout},taps={taps},stride={stride})')
+    nbytes = 4 * (B * L_out * cout * (2 if g2 is not None else 1) + B * L_in * cin)
+    _timed(f'wgrad {cin}->{cout} k{taps} s{stride} d{dil} L{L_out}', nbytes, 2 * B * L_out * cout * cin * taps, run)
 
 
 def wgrad_grid_y(cin, cout, taps, dil=1) -> int:

@@ -1,0 +1,267 @@
+"""Callers of the hot path, mirrored from the reference's trainer package (src/wav2sleep/trainer/*.py).
+
+* `exp_warmup_lr` / `ExpWarmUpScheduler`  -- trainer/scheduler.py:7-32
+* `invert_signals`, `SignalMasker`         -- trainer/main.py:342-353, trainer/masker.py:6-51 (device-side augmentations)
+* `FusedTrainStep`                         -- what Lightning's loop does around `SleepLightningModule._step`
+  (trainer/main.py:140-183 + clip 1.0 + AdamW + scheduler, scripts/config/training/main.yaml) as ONE launch sequence:
+  forward -> masked CE + confusion matrix -> backward -> [bucketed RCCL all-reduce] -> global-norm clip + AdamW,
+  all on flat buffers, no host synchronisation inside the step.
+* `SleepModule` (alias `SleepLightningModule`) -- same constructor / `_step` semantics without the Lightning dependency.
+"""
+
+from __future__ import annotations
+
+import math
+from collections import defaultdict
+
+import torch
+from torch.distributions.one_hot_categorical import OneHotCategorical
+from torch.optim import Optimizer
+from torch.optim.lr_scheduler import LRScheduler
+
+from . import lib
+from .ddp import FlatGradReducer, reduce_metrics
+from .wav2sleep import Wav2Sleep
+
+
+def exp_warmup_lr(step: int, lr_max: float = 1e-3, warmup_steps: int = 2000, tau: float = 10000.0) -> float:
+    """LR used by optimiser step `step` (1-based): linear warm-up then exponential decay (scheduler.py:23-32)."""
+    if step <= warmup_steps:
+        return lr_max * (step / warmup_steps)
+    return lr_max * math.exp(-(step - warmup_steps) / tau)
+
+
+class ExpWarmUpScheduler(LRScheduler):
+    """trainer/scheduler.py:7-32 (for callers that drive a torch optimiser themselves)."""
+
+    def __init__(self, optimizer: Optimizer, lr_max: float, warmup_steps: int, tau: float) -> None:
+        self.lr_max = lr_max
+        self.warmup_steps = warmup_steps
+        self.tau = tau
+        self.num_param_groups = len(optimizer.param_groups)
+        super().__init__(optimizer, last_epoch=-1)
+
+    def get_lr(self):
+        return [exp_warmup_lr(self.last_epoch + 1, self.lr_max, self.warmup_steps, self.tau)] * self.num_param_groups
+
+
+def invert_signals(signals: dict[str, torch.Tensor]):
+    """Random polarity flip per (sample, signal), in place (trainer/main.py:342-353)."""
+    for name, x_BT in signals.items():
+        B = x_BT.shape[0]
+        flip = 2 * torch.randint(0, 2, (B, 1), dtype=torch.float, device=x_BT.device) - 1
+        signals[name] *= flip
+    return signals
+
+
+class SignalMasker:
+    """Stochastic modality dropout with backup channel; writes -inf rows (trainer/masker.py:6-51)."""
+
+    def __init__(self, dropouts: dict[str, float], backups: list[str] | None = None):
+        self.channel_dropouts = dropouts
+        self.backup_channels = backups
+
+    def draw(self, signals):
+        """-> (names, keep mask [B, C] bool) following the reference's sampling rule."""
+        probs, onehot, unavailable = [], [], []
+        x_BT = None
+        for name, x_BT in signals.items():
+            z_B = torch.isinf(x_BT[:, 0])
+            p = self.channel_dropouts.get(name, 0.0)
+            if p < 0.0 or p > 1:
+                raise ValueError(f'channel_dropout={p} is not a valid probability.')
+            probs.append(p)
+            if self.backup_channels is not None:
+                onehot.append(~z_B if name in self.backup_channels else torch.zeros_like(z_B))
+            else:
+                onehot.append(~z_B * (1 - p))
+            unavailable.append(z_B)
+        z_BC = torch.stack(unavailable, dim=-1)
+        if z_BC.all(dim=-1).any():
+            raise ValueError('Found batch element with all signals unavailable.')
+        B = z_BC.size(0)
+        p_BC = torch.tensor(probs, dtype=torch.float32, device=x_BT.device)[None, :].repeat(B, 1)
+        if (p_BC == 1).all(dim=-1).any():
+            raise ValueError('Dropout probability equal to 1 for all channels.')
+        p_min = torch.stack(onehot, dim=-1).to(x_BT.device).float()
+        if (p_min == 0).all(dim=-1).any():
+            raise ValueError('No backup channels for stochastic sampling were available')
+        min_m = OneHotCategorical(p_min).sample().bool()
+        m_BC = (1 - p_BC).bernoulli().bool()
+        all_zero = torch.logical_or(z_BC, ~m_BC).all(dim=-1)
+        m_BC[all_zero] = min_m[all_zero]
+        if torch.logical_or(z_BC, ~m_BC).all(dim=-1).any():
+            raise ValueError('Masking will result in no available channels for a batch element.')
+        return list(signals.keys()), m_BC
+
+    def __call__(self, signals):
+        names, m_BC = self.draw(signals)
+        for name, m_B in zip(names, m_BC.T):
+            signals[name][~m_B] = float('-inf')
+        return signals
+
+
+class FusedTrainStep:
+    """One optimiser step of the reference's recipe on the HIP engine (fp32, deterministic reductions).
+
+    loss = CrossEntropy(mean over labels != -1) per rank; DDP = mean of per-rank gradients;
+    clip_grad_norm_(max_norm) on the reduced gradient; AdamW(lr_k, wd); lr_k from ExpWarmUp at step k.
+    """
+
+    def __init__(self, model: Wav2Sleep, lr: float = 1e-3, weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_norm: float = 1.0, warmup_steps: int = 2000, tau: float = 10000.0, process_group=None, scheduler: bool = True):
+        self.model = model
+        model._ensure_flat()
+        self.eng = model._engine
+        flat = model._flat
+        self.n = flat.numel()
+        dev = flat.device
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.lr_max, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.warmup_steps, self.tau, self.use_sched = warmup_steps, tau, scheduler
+        self.step_count = 0
+        self.nparts = 256
+        self.sumsq = torch.empty(self.nparts, device=dev, dtype=torch.float32)
+        self.hyper = torch.zeros(8, device=dev, dtype=torch.float32)
+        self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+        self.normcoef = torch.zeros(2, device=dev, dtype=torch.float32)
+        self.loss_out = torch.zeros(2, device=dev, dtype=torch.float32)
+        nc = model.num_classes
+        self.cmat = torch.zeros(nc, nc, device=dev, dtype=torch.int64)
+        self.reducer = FlatGradReducer(model._flat_grad, group=process_group)
+        # contiguous flat ranges in the order backward completes them: [mixer..classifier], then encoders as visited
+        names = [n for n, _ in model.named_parameters()]
+        self._range = {}
+        for (o, n, _), name in zip(model._layout, names):
+            key = name.split('.')[2] if name.startswith('signal_encoders.encoders.') else '_tail'
+            lo, hi = self._range.get(key, (o, o))
+            self._range[key] = (min(lo, o), max(hi, o + (n + 3) // 4 * 4))
+
+    def lr_at(self, step: int) -> float:
+        return exp_warmup_lr(step, self.lr_max, self.warmup_steps, self.tau) if self.use_sched else self.lr_max
+
+    def step(self, x: dict[str, torch.Tensor], y: torch.Tensor) -> dict:
+        """x: dict signal -> [B, T] (device, fp32, -inf rows = missing modality); y: [B, S] float labels, -1 = ignore."""
+        model, eng = self.model, self.eng
+        model._ensure_flat()
+        self.step_count += 1
+        k = self.step_count
+        b1, b2 = self.betas
+        h = self.hyper_host
+        h[0], h[1], h[2], h[3], h[4] = self.lr_at(k), self.wd, b1, b2, self.eps
+        h[5], h[6], h[7] = 1 - b1 ** k, 1 - b2 ** k, self.max_norm if self.max_norm else 0.0
+        self.hyper.copy_(h, non_blocking=True)
+
+        eng.step_seed = model._next_seed()
+        logits = eng.forward(x, train=True, save=True, pack_key=model.param_version())
+        B, S, nc = logits.shape
+        rows = B * S
+        yv = y.reshape(rows)
+        if yv.dtype != torch.float32:
+            yv = yv.float()
+        part = torch.empty((rows + 255) // 256, 2, device=logits.device, dtype=torch.float32)
+        glogits = torch.empty(rows, nc, device=logits.device, dtype=torch.float32)
+        self.cmat.zero_()
+        lib.ce_fwd_bwd(logits, yv.contiguous(), rows, nc, part, self.loss_out, glogits, self.cmat, self.reducer.grad_scale)
+        if self.reducer.world > 1:
+            eng.backward(glogits, hook=self._on_ready)
+            self.reducer.wait()
+        else:
+            eng.backward(glogits)
+        lib.sumsq_partial(model._flat_grad, self.n, self.sumsq, self.nparts)
+        lib.clip_coef(self.sumsq, self.nparts, self.hyper, self.normcoef)
+        lib.adamw(model._flat, model._flat_grad, self.m, self.v, self.n, self.hyper, self.normcoef)
+        model.mark_params_dirty()
+        return dict(loss=self.loss_out[0], count=self.loss_out[1], grad_norm=self.normcoef[0], cmat=self.cmat, logits=logits, lr=float(h[0]))
+
+    def _on_ready(self, stage: str):
+        lo, hi = self._range.get(stage, (0, 0))
+        self.reducer.reduce_range(lo, hi)
+
+    def metrics(self):
+        """(global mean loss, rank-mean loss as the reference logs it, summed confusion matrix) -- one packed all-reduce."""
+        return reduce_metrics(self.loss_out, self.cmat, self.reducer.group)
+
+
+def confusion_matrix_from_logits(logits: torch.Tensor, labels: torch.Tensor, num_classes: int) -> torch.Tensor:
+    """argmax + MulticlassConfusionMatrix(ignore_index=-1) on the device (trainer/main.py:49-59): rows true, cols pred."""
+    rows = logits.numel() // num_classes
+    dev = logits.device
+    part = torch.empty((rows + 255) // 256, 2, device=dev, dtype=torch.float32)
+    out = torch.zeros(2, device=dev, dtype=torch.float32)
+    cm = torch.zeros(num_classes, num_classes, device=dev, dtype=torch.int64)
+    lib.ce_fwd_bwd(logits.reshape(rows, num_classes).contiguous().float(), labels.reshape(rows).float().contiguous(), rows, num_classes, part, out,
+                   None, cm, 1.0)
+    return cm
+
+
+class SleepModule:
+    """Lightning-free mirror of SleepLightningModule (trainer/main.py:62-240): same constructor keywords, `_step`
+    semantics (loss, confusion matrices per mode / signal subset / dataset, cross-rank sums), augmentations on device.
+    `optimizer` / `scheduler` partials are accepted for signature compatibility; the fused AdamW step is used instead.
+    """
+
+    def __init__(self, model: Wav2Sleep, criterion=None, optimizer=None, aux_metrics=None, scheduler=None, debug_level=2,
+                 on_step: bool = False, on_epoch: bool = True, num_classes: int = 4, masker: SignalMasker | None = None,
+                 flip_polarity: bool = True, causal: bool = False, lr: float = 1e-3, weight_decay: float = 1e-4, max_norm: float = 1.0,
+                 process_group=None):
+        self.model = model
+        self.num_classes = num_classes
+        self.masker = masker if isinstance(model, Wav2Sleep) else None
+        self.flip_polarity = flip_polarity
+        self.causal = causal
+        self.unified = len(model.signal_encoders) > 1
+        self.aux_outputs = {mode: defaultdict(lambda: defaultdict(lambda: 0)) for mode in ('train', 'val', 'test')}
+        self.trainer = FusedTrainStep(model, lr=lr, weight_decay=weight_decay, max_norm=max_norm, process_group=process_group)
+
+    def on_after_batch_transfer(self, batch, training: bool = True):
+        x, y = batch
+        if training:
+            if self.flip_polarity:
+                invert_signals(x)
+            if self.unified and self.masker is not None:
+                self.masker(x)
+        return x, y
+
+    def training_step(self, batch, ds_name: str = 'all'):
+        x, y = batch
+        self.model.train()
+        out = self.trainer.step(x, y)
+        _, _, cm = self.trainer.metrics()
+        self.aux_outputs['train'][None][ds_name] += cm
+        return out['loss']
+
+    @torch.no_grad()
+    def eval_step(self, batch, mode: str = 'val', signals: tuple | None = None, ds_name: str = 'all'):
+        x, y = batch
+        if signals is not None:
+            x = {s: x[s] for s in signals}
+        self.model.eval()
+        logits = self.model(x)
+        rows = logits.shape[0] * logits.shape[1]
+        dev = logits.device
+        part = torch.empty((rows + 255) // 256, 2, device=dev, dtype=torch.float32)
+        out = torch.zeros(2, device=dev, dtype=torch.float32)
+        cm = torch.zeros(self.num_classes, self.num_classes, device=dev, dtype=torch.int64)
+        lib.ce_fwd_bwd(logits, y.reshape(rows).float().contiguous(), rows, self.num_classes, part, out, None, cm, 1.0)
+        _, _, cm = reduce_metrics(out, cm, self.trainer.reducer.group)
+        prefix = '_'.join(signals) if signals is not None else (None if self.unified else '_'.join(x.keys()))
+        self.aux_outputs[mode][prefix][ds_name] += cm
+        return out[0]
+
+    @torch.no_grad()
+    def predict_step(self, batch):
+        """trainer/main.py:226-240: predictions from ECG, ECG+THX and all modalities."""
+        x, y = batch
+        self.model.eval()
+        out = {'labels': y}
+        if 'ECG' in x:
+            out['preds_ECG'] = self.model({'ECG': x['ECG']}).argmax(dim=-1)
+        if 'ECG' in x and 'THX' in x:
+            out['preds_ECG_THX'] = self.model({'ECG': x['ECG'], 'THX': x['THX']}).argmax(dim=-1)
+        out['preds'] = self.model(x).argmax(dim=-1)
+        return out
+
+
+SleepLightningModule = SleepModule
