@@ -167,7 +167,7 @@ class Engine:
         """weight gradient -> slabs -> deterministic reduce into G[name] (accumulating if already written)."""
         gy = lib.wgrad_grid_y(cin, cout, taps, dil)
         work = _cdiv(B * L_out, 256)
-        gx = max(1, min(work, max(1, 1024 // gy)))
+        gx = max(1, min(work, max(1, 512 // gy)))
         nslab = 4 * gx
         slab = self._slab(g.device, nslab, cout * cin * taps)
         lib.wgrad(g=g, x=x, slab=slab, nslab=nslab, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad,
