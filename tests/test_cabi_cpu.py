@@ -1,0 +1,69 @@
+"""CPU-only checks of the C-ABI boundary: the library loads, exports every symbol include/w2s.h declares, the header is
+valid C, and the ctypes structs have the C layout.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'w2s.h')
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    from wav2sleep_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        lib.build()
+    return lib
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r'\b(w2s_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    dll = ctypes.CDLL(built_lib.LIB_PATH)
+    missing = [s for s in syms if not hasattr(dll, s)]
+    assert not missing, missing
+    assert set(built_lib.EXPORTS) <= set(syms), set(built_lib.EXPORTS) - set(syms)
+    dll.w2s_version.restype = ctypes.c_char_p
+    assert b'gfx950' in dll.w2s_version()
+
+
+def test_header_is_plain_c_and_struct_layout_matches_ctypes(built_lib, tmp_path):
+    src = tmp_path / 't.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "w2s.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(w2s_conv_args), '
+                   'offsetof(w2s_conv_args, B), offsetof(w2s_conv_args, epi), sizeof(w2s_wgrad_args), offsetof(w2s_wgrad_args, B), '
+                   'offsetof(w2s_wgrad_args, nslab));return 0;}\n')
+    exe = tmp_path / 't'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    L = built_lib
+    want = [ctypes.sizeof(L.ConvArgs), L.ConvArgs.B.offset, L.ConvArgs.epi.offset, ctypes.sizeof(L.WgradArgs), L.WgradArgs.B.offset,
+            L.WgradArgs.nslab.offset]
+    assert [int(v) for v in out] == want
+
+
+def test_argument_validation_without_gpu(built_lib):
+    """Entry points reject bad descriptors before touching the device (EINVAL = -1), so this is safe on CPU."""
+    L = built_lib
+    dll = L.load()
+    a = L.ConvArgs()
+    assert dll.w2s_conv_forward(ctypes.byref(a), None) == -1
+    assert dll.w2s_conv_forward(None, None) == -1
+    w = L.WgradArgs()
+    assert dll.w2s_wgrad(ctypes.byref(w), None) == -1
+    assert dll.w2s_stats_finalize(None, 1, 1, 16, ctypes.c_long(1), ctypes.c_float(0.01), 0, None, None) == -1
+    assert L.conv_tile(16, 16, 3, 1) == 256 and L.conv_tile(128, 128, 3, 1) == 64
+    assert L.wgrad_grid_y(128, 128, 3) == 6 and L.wgrad_grid_y(16, 16, 3) == 1
+
+
+def test_cpu_tensors_are_refused(built_lib):
+    import torch
+    with pytest.raises(built_lib.W2SError):
+        built_lib.eltwise(0, torch.zeros(4), None, torch.zeros(4), 4)

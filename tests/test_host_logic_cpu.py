@@ -1,0 +1,131 @@
+"""CPU-only tests of the host side that mirrors the reference's interface (no kernels run)."""
+import numpy as np
+import pytest
+import torch
+
+import wav2sleep_amd as W
+from oracle import wav2sleep_oracle as O
+from tests.golden_util import load
+from wav2sleep_amd import api
+from wav2sleep_amd.engine import EngineSpec
+from wav2sleep_amd.lib import W2SError
+
+SM4 = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
+
+
+def build(signal_map=SM4, nc=4, dropout=0.1):
+    return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', chunk_causal=False),
+                       W.MultiModalAttentionEmbedder(128, layers=2, dropout=dropout, dim_ff=512, nhead=8),
+                       W.SequenceCNN(128, dropout=dropout, norm='layer', num_layers=2, kernel_size=7, num_dilations=6), nc)
+
+
+@pytest.mark.parametrize('signal_map,nc,count', [(SM4, 4, 2948740), ({'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 3345797), ({'ECG': 'UNI'}, 4, 2233412)])
+def test_state_dict_abi_matches_reference_schema(signal_map, nc, count):
+    """Key names / shapes / parameter counts of SURVEY.md 8b (probed on the reference)."""
+    m = build(signal_map, nc)
+    sd = m.state_dict()
+    want = O.param_shapes(O.ModelConfig(signal_map=signal_map, num_classes=nc))
+    assert set(sd) == set(want)
+    for k, shp in want.items():
+        assert tuple(sd[k].shape) == tuple(shp), k
+    assert sum(p.numel() for p in m.parameters()) == count
+    m.load_state_dict(O.make_state_dict(O.ModelConfig(signal_map=signal_map, num_classes=nc), seed=1), strict=True)
+    assert m.valid_signals == list(signal_map)
+    assert m.signal_encoders.causal is False and m.num_classes == nc and m.feature_dim == 128
+
+
+def test_default_init_is_the_reference_init_under_the_same_seed():
+    """Parameter containers are the same torch.nn classes created in the same order => same RNG stream."""
+    torch.manual_seed(42)
+    a = build().state_dict()
+    torch.manual_seed(42)
+    b = build().state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert float(a['epoch_mixer.transformer_encoder.layers.0.self_attn.in_proj_bias'].abs().max()) == 0.0
+    assert float(a['sequence_mixer.dilated_convs.0.conv_layers.0.norm.weight'].min()) == 1.0
+
+
+def test_no_cpu_fallback():
+    m = build()
+    with pytest.raises(W2SError):
+        m({'ECG': torch.zeros(1, 1024)})
+
+
+def test_error_conventions():
+    with pytest.raises(ValueError):
+        W.SignalEncoders({'XYZ': 'XYZ'}, 128, 'gelu')
+    with pytest.raises(ValueError):
+        W.SignalEncoders({'ECG': 'ECG'}, 128, 'tanh')
+    with pytest.raises(ValueError):
+        EngineSpec(signal_map={'BAD': 'BAD'})
+    with pytest.raises(ValueError):
+        EngineSpec(signal_map={'ECG': 'ECG'}, feature_dim=64, mixer_nhead=4)
+    spec = build({'EOG-L': 'E', 'EOG-R': 'E'}, 5).spec()
+    assert spec.channels('E') == [16, 16, 32, 32, 64, 64, 128, 128, 128, 128]
+    assert build().spec().channels('ABD') == [16, 16, 32, 32, 64, 64]
+
+
+def test_scheduler_and_stats_match_reference_goldens():
+    g = load('misc')
+    for k, v in zip(g['lr_steps'], g['lr_values']):
+        assert W.exp_warmup_lr(int(k)) == pytest.approx(float(v), rel=1e-12)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    sched = W.ExpWarmUpScheduler(opt, lr_max=1e-3, warmup_steps=2000, tau=10000)
+    lrs = []
+    for _ in range(5):
+        lrs.append(opt.param_groups[0]['lr'])
+        opt.step(); sched.step()
+    np.testing.assert_allclose(lrs, g['lr_values'][:5], rtol=1e-12)
+    assert W.cohens_kappa(g['cm'], 4) == pytest.approx(float(g['kappa']), rel=1e-12)
+    assert W.confusion_accuracy(g['cm']) == pytest.approx(float(g['acc']), rel=1e-12)
+
+
+def test_masker_invariants_and_errors():
+    torch.manual_seed(0)
+    B = 256
+    x = {s: torch.randn(B, 8) for s in SM4}
+    x['ECG'][:32] = float('-inf'); x['PPG'][32:64] = float('-inf'); x['ABD'][64:96] = float('-inf')
+    avail = torch.stack([~torch.isinf(v[:, 0]) for v in x.values()], -1)
+    masker = W.SignalMasker({'ABD': 0.7, 'THX': 0.7, 'ECG': 0.5, 'PPG': 0.1}, backups=['ECG', 'PPG'])
+    keeps = []
+    for _ in range(40):
+        xm = masker({k: v.clone() for k, v in x.items()})
+        keep = torch.stack([~torch.isinf(v[:, 0]) for v in xm.values()], -1)
+        assert not (keep & ~avail).any() and keep.any(-1).all()
+        keeps.append(keep.float())
+    rate = torch.stack(keeps).mean((0, 1))  # keep rates ~ (1-p) * availability (+ backups), as the reference's own draws
+    ref = torch.tensor(load('misc')['masker_keep']).float().mean((0, 1))
+    assert torch.allclose(rate, ref, atol=0.08), (rate, ref)
+    bad = {s: torch.full((2, 8), float('-inf')) for s in SM4}
+    with pytest.raises(ValueError):
+        masker(bad)
+    x2 = {k: v[:4].clone() for k, v in x.items()}
+    before = {k: v.clone() for k, v in x2.items()}
+    W.invert_signals(x2)
+    for k in x2:
+        fin = torch.isfinite(before[k])
+        ratio = (x2[k][fin] / before[k][fin])
+        assert torch.all((ratio - 1).abs().lt(1e-6) | (ratio + 1).abs().lt(1e-6))
+
+
+def test_target_instantiation_of_reference_config(tmp_path):
+    cfg = {'_target_': 'wav2sleep.models.wav2sleep.Wav2Sleep', 'num_classes': 4,
+           'signal_encoders': {'_target_': 'wav2sleep.models.wav2sleep.SignalEncoders', 'signal_map': {'ECG': 'ECG', 'THX': 'THX'},
+                               'feature_dim': 128, 'activation': 'gelu', 'norm': 'instance', 'causal': False, 'chunk_causal': False,
+                               'initial_channels': 16, 'max_channels': 128, 'output_norm': False, 'use_residual': True},
+           'epoch_mixer': {'_target_': 'wav2sleep.models.wav2sleep.MultiModalAttentionEmbedder', 'feature_dim': 128, 'dropout': 0.1,
+                           'activation': 'gelu', 'layers': 2, 'dim_ff': 512, 'nhead': 8},
+           'sequence_mixer': {'_target_': 'wav2sleep.models.wav2sleep.SequenceCNN', 'feature_dim': 128, 'dropout': 0.1, 'activation': 'gelu',
+                              'norm': 'layer', 'causal': False, 'num_layers': 2, 'kernel_size': 7, 'num_dilations': 6}}
+    m = api.instantiate(cfg)
+    assert isinstance(m, W.Wav2Sleep) and m.valid_signals == ['ECG', 'THX']
+    import yaml
+    (tmp_path / 'config.yaml').write_text(yaml.safe_dump(cfg))
+    torch.save({'model.' + k: v for k, v in m.state_dict().items()}, tmp_path / 'state_dict.pth')
+    m2 = W.load_model(str(tmp_path), device='cpu')
+    assert not m2.training and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    with pytest.raises(FileNotFoundError):
+        W.load_model(str(tmp_path / 'nope'), device='cpu')
+    with pytest.raises(ValueError):
+        api.instantiate({'_target_': 'os.system'})
