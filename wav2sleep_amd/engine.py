@@ -252,6 +252,12 @@ class Engine:
         for s in x:
             if s not in sp.signal_map:
                 raise ValueError(f'Unknown signal {s}')
+        for s, v in x.items():  # wav2sleep.py:243-244, before anything is launched
+            spe = COLS_TO_SAMPLES_PER_EPOCH[s]
+            if v.dim() != 2 or v.shape[1] == 0 or v.shape[1] % spe:
+                raise ValueError(f'Input length {tuple(v.shape)} of {s} must be [B, T] with T divisible by samples_per_epoch={spe}.')
+        if len({(v.shape[0], v.shape[1] // COLS_TO_SAMPLES_PER_EPOCH[s]) for s, v in x.items()}) != 1:
+            raise ValueError('all signals must share batch size and number of epochs')
         self.ensure_packed(pack_key, need_bwd=save)
         sigs = sorted(x.keys())  # wav2sleep.py:311
         first = x[sigs[0]]
