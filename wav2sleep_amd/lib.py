@@ -163,7 +163,10 @@ def conv_forward(a: ConvArgs):
     nbytes = 4 * (a.B * a.L_in * a.cin * (2 if a.x2 else 1) + out_el * (2 if a.y2 else 1) + (out_el if a.aux else 0) + (out_el // 2 if a.add_even else 0))
     taps_eff = 1.5 if a.mode == MODE_UP2 else a.taps
     flops = int(2 * out_el * a.cin * taps_eff)
-    _timed(f'conv_cl {a.cin}->{a.cout} k{a.taps} s{a.stride} mode{a.mode} pro{a.pro} epi{a.epi} L{a.L_out}', nbytes, flops, run)
+    nt = 8 if a.cout >= 128 else 4 if a.cout >= 64 else 2 if a.cout >= 32 else 1
+    mt = load().w2s_conv_tile(C.byref(a)) // 64
+    # key == the kernel name rocprofv3 reports, so bench.py's average can be checked against profiles/
+    _timed(f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}>', nbytes, flops, run)
 
 
 def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, ldg=None, ldx=None, pro_g=PRO_NONE,
@@ -178,7 +181,12 @@ def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, di
     def run():
         _chk(load().w2s_wgrad(C.byref(a), _stream()), f'w2s_wgrad(cin={cin},cout={cout},taps={taps},stride={stride})')
     nbytes = 4 * (B * L_out * cout * (2 if g2 is not None else 1) + B * L_in * cin)
-    _timed(f'wgrad {cin}->{cout} k{taps} s{stride} d{dil} L{L_out}', nbytes, 2 * B * L_out * cout * cin * taps, run)
+    ntc = cin // 16
+    tapst = 3 if (taps == 3 and dil == 1 and ntc <= 4) else 1
+    nto = 8
+    while nto > 1 and (nto > 32 // (ntc * tapst) or (cout // 16) % nto):
+        nto //= 2
+    _timed(f'wgrad_kernel<{nto}, {ntc}, {tapst}, {stride}>', nbytes, 2 * B * L_out * cout * cin * taps, run)
 
 
 def wgrad_grid_y(cin, cout, taps, dil=1) -> int:
