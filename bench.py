@@ -141,7 +141,7 @@ def main():
         roof['step_algorithmic_GBps'] = round(step_bytes / (dt / args.steps) / 1e9, 1)
         roof['step_frac_of_hbm_peak'] = round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
         line['roofline'] = roof
-        top = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])[:12]
+        top = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(ROOT, 'gpurun_out', 'bench_launch_breakdown.json'), 'w') as f:
             json.dump({k: v for k, v in top}, f, indent=1)

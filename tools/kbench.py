@@ -1,0 +1,78 @@
+"""Single-kernel micro-benchmarks (HIP-event timed) for tuning.  python tools/kbench.py [name ...] [--iters N]"""
+import os, sys, argparse
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from wav2sleep_amd import lib
+
+dev = 'cuda'
+
+def timeit(fn, iters):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+def conv_case(cin, cout, L, stride=1, pro=lib.PRO_IN_GELU, epi=lib.EPI_STATS, B=16, taps=3, mode=lib.MODE_CONTIG, flip=0):
+    Lo = L // stride if mode != lib.MODE_UP2 else L * 2
+    x = torch.randn(B, L, cin, device=dev); x2 = torch.randn(B, L, cin, device=dev)
+    w = torch.randn(cout, taps, cin, device=dev) / (cin * taps) ** 0.5
+    y = torch.empty(B, Lo, cout, device=dev)
+    st = torch.rand(B, cin, 2, device=dev) + 0.5; bst = torch.rand(B, cin, 2, device=dev) * 0.01
+    ost = torch.rand(B, cout, 2, device=dev) + 0.5
+    aux = torch.randn(B, Lo, cout, device=dev) if epi in (lib.EPI_GP, lib.EPI_AUX_INGELU_ADD) else None
+    a0 = lib.ConvArgs(); a0.cin, a0.cout, a0.taps, a0.stride, a0.mode = cin, cout, taps, stride, mode
+    tile = lib.load().w2s_conv_tile(__import__('ctypes').byref(a0))
+    part = torch.empty(B, (Lo + tile - 1) // tile, 2, cout, device=dev)
+    a = lib.conv_args(x=x, x2=x2 if pro >= lib.PRO_INBWD else None, w=w, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
+                      pad=1 if taps == 3 else 0, flip=flip, mode=mode, pro=pro, epi=epi, pro_stats=st, pro_bstats=bst, aux=aux, aux_stats=ost if aux is not None else None,
+                      part=part if epi in (lib.EPI_STATS, lib.EPI_GP) else None)
+    nbytes = 4 * (B * L * cin * (2 if pro >= lib.PRO_INBWD else 1) + B * Lo * cout * (2 if aux is not None else 1))
+    flops = 2 * B * Lo * cout * cin * (1.5 if mode == lib.MODE_UP2 else taps)
+    return (lambda: lib.conv_forward(a)), nbytes, flops
+
+def wgrad_case(cin, cout, L, stride=1, taps=3, B=16, pro_g=lib.PRO_INBWD, pro_h=lib.PRO_IN_GELU):
+    Lo = L // stride
+    g = torch.randn(B, Lo, cout, device=dev); g2 = torch.randn(B, Lo, cout, device=dev); x = torch.randn(B, L, cin, device=dev)
+    st = torch.rand(B, cout, 2, device=dev) + 0.5; bst = torch.rand(B, cout, 2, device=dev) * 0.01; xst = torch.rand(B, cin, 2, device=dev) + 0.5
+    gy = lib.wgrad_grid_y(cin, cout, taps, 1)
+    gx = max(1, min((B * Lo + 255) // 256, max(1, 512 // gy))); nslab = 4 * gx
+    slab = torch.empty(nslab * cout * cin * taps, device=dev)
+    fn = lambda: lib.wgrad(g=g, g2=g2, g_stats=st, g_bstats=bst, x=x, x_stats=xst, slab=slab, nslab=nslab, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout,
+                           taps=taps, stride=stride, pad=1 if taps == 3 else 0, pro_g=pro_g, pro_h=pro_h)
+    return fn, 4 * (B * Lo * cout * 2 + B * L * cin), 2 * B * Lo * cout * cin * taps
+
+def elt_case(op, n=16 * 983040 * 16):
+    a = torch.randn(n, device=dev); b = torch.randn(n, device=dev); y = torch.empty(n, device=dev)
+    nb = 4 * n * (3 if op == lib.ELT_ADD else 2)
+    return (lambda: lib.eltwise(op, a, b if op == lib.ELT_ADD else None, y, n)), nb, n
+
+CASES = {
+    'add': lambda: elt_case(lib.ELT_ADD),
+    'gelu': lambda: elt_case(lib.ELT_GELU),
+    'tcopy': lambda: (lambda a, y: ((lambda: y.copy_(a)), 8 * a.numel(), a.numel()))(torch.randn(16 * 983040 * 16, device=dev), torch.empty(16 * 983040 * 16, device=dev)),
+    'f16': lambda: conv_case(16, 16, 983040),
+    'f16n': lambda: conv_case(16, 16, 983040, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN),
+    'f16s2': lambda: conv_case(16, 16, 983040, stride=2),
+    'd16': lambda: conv_case(16, 16, 983040, pro=lib.PRO_INBWD, epi=lib.EPI_GP, flip=1),
+    'u16': lambda: conv_case(16, 16, 491520, stride=2, pro=lib.PRO_INBWD_GP, epi=lib.EPI_GP, mode=lib.MODE_UP2),
+    'w16': lambda: wgrad_case(16, 16, 983040),
+    'f32': lambda: conv_case(32, 32, 245760),
+    'w32': lambda: wgrad_case(32, 32, 245760),
+    'f64': lambda: conv_case(64, 64, 61440),
+    'd64': lambda: conv_case(64, 64, 61440, pro=lib.PRO_INBWD, epi=lib.EPI_GP, flip=1),
+    'w64': lambda: wgrad_case(64, 64, 61440),
+    'f128': lambda: conv_case(128, 128, 15360),
+    'f128n': lambda: conv_case(128, 128, 15360, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN),
+    'd128': lambda: conv_case(128, 128, 15360, pro=lib.PRO_INBWD, epi=lib.EPI_GP, flip=1),
+    'w128': lambda: wgrad_case(128, 128, 15360),
+}
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser(); ap.add_argument('names', nargs='*'); ap.add_argument('--iters', type=int, default=20)
+    a = ap.parse_args()
+    for n in (a.names or list(CASES)):
+        fn, nb, fl = CASES[n]()
+        ms = timeit(fn, a.iters)
+        print(f'{n:8s} {ms*1e3:9.1f} us  {nb/ms/1e6:8.0f} GB/s  {fl/ms/1e9:7.1f} TF/s', flush=True)

@@ -44,13 +44,17 @@ __device__ __forceinline__ f32x4 pro_apply(int pro, f32x4 v, f32x4 v2, f32x4 mea
   }
 }
 
-template <int NT, int MT, int TAPS, int STRIDE, int MODE>
+// NT: n-tiles (16 channels) per workgroup; MT: m-tiles (16 positions) per WAVE; WN: waves along channels (the 4 waves
+// form a (4/WN) x WN grid, so a wave owns 16*MT positions x 16*NT/WN channels and each weight fragment fetched from
+// L2 feeds MT MFMAs: WN = 2 quarters the L2 weight traffic of the 128-channel layers, which was their limiter).
+template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN>
 __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
   const w2s_conv_args& a = P.a;
-  constexpr int TM = 64 * MT;
+  constexpr int WM = 4 / WN, NTW = NT / WN, TM = 16 * MT * WM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WN, wave_n = wave % WN;
   const int r = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, tile = blockIdx.x, n0 = blockIdx.y * (NT * 16);
   const int t0 = tile * TM;
@@ -59,11 +63,11 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   const int L_in = a.L_in, L_out = a.L_out;
   const int pro = a.pro;
 
-  f32x4 acc[MT][NT];
+  f32x4 acc[MT][NTW];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // per-thread channel-group parameters for the on-load transform
   const int myc4 = tid % c4n, row0 = tid / c4n;
@@ -106,30 +110,31 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
     }
   };
 
-  const int wm0 = wave * (16 * MT);  // first tile-local output position (or u-row for UP2) of this wave
+  const int wm0 = wave_m * (16 * MT);  // first tile-local output position of this wave
+  const int wn0 = wave_n * (NTW * 16);  // first tile-local output channel of this wave
 
   auto mma_tap = [&](int jw, int rowoff, int mtmask) {
     // jw: weight tap index; rowoff: LDS row offset added to the per-position row; mtmask: which m-tiles take part
     for (int q = 0; q < (cin >> 4); ++q) {
-      f32x4 bf[MT], af[NT];
+      f32x4 bf[MT], af[NTW];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         int row;
-        if (MODE == W2S_MODE_UP2) row = wave * (8 * MT) + (mt >> 1) * 16 + r + rowoff;
+        if (MODE == W2S_MODE_UP2) row = wave_m * (8 * MT) + (mt >> 1) * 16 + r + rowoff;
         else if (MODE == W2S_MODE_DILATED) row = wm0 + mt * 16 + r;
         else row = (wm0 + mt * 16 + r) * STRIDE + rowoff;
         bf[mt] = *reinterpret_cast<const f32x4*>(smem + row * RS + q * 16 + 4 * g);
       }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        af[nt] = ld4(a.w + (size_t)(n0 + nt * 16 + r) * K + jw * cin + q * 16 + 4 * g);
+      for (int nt = 0; nt < NTW; ++nt)
+        af[nt] = ld4(a.w + (size_t)(n0 + wn0 + nt * 16 + r) * K + jw * cin + q * 16 + 4 * g);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
           if (mtmask & (1 << mt))
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(af[nt][e], bf[mt][e], acc[mt][nt]);
+            for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = mfma16(af[nt][e], bf[mt][e], acc[mt][nt]);
     }
   };
 
@@ -158,20 +163,20 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   // ------------------------------------ epilogue ------------------------------------
   const int epi = a.epi;
   const int cout = a.cout;
-  f32x4 sA[NT], sB[NT];
+  f32x4 sA[NTW], sB[NTW];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) { sA[nt] = (f32x4){0, 0, 0, 0}; sB[nt] = (f32x4){0, 0, 0, 0}; }
+  for (int nt = 0; nt < NTW; ++nt) { sA[nt] = (f32x4){0, 0, 0, 0}; sB[nt] = (f32x4){0, 0, 0, 0}; }
   const float keep = a.rowkeep ? a.rowkeep[b] : 1.0f;
 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int pos;
-    if (MODE == W2S_MODE_UP2) pos = t0 + 2 * (wave * (8 * MT) + (mt >> 1) * 16 + r) + (mt & 1);
+    if (MODE == W2S_MODE_UP2) pos = t0 + 2 * (wave_m * (8 * MT) + (mt >> 1) * 16 + r) + (mt & 1);
     else pos = t0 + wm0 + mt * 16 + r;
     const bool valid = pos < L_out;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int ch = n0 + nt * 16 + 4 * g;
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int ch = n0 + wn0 + nt * 16 + 4 * g;
       f32x4 v = acc[mt][nt];
       if (!valid) continue;
       const size_t orow = (size_t)b * L_out + pos;
@@ -208,14 +213,14 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   if ((epi == W2S_EPI_STATS || epi == W2S_EPI_GP) && a.part) {
     // deterministic two-level reduction: 16 positions (shuffle) -> 4 waves (LDS) -> one partial per tile
     __syncthreads();  // LDS window no longer needed
-    float* red = smem;  // [wave][nt][g][4][2]
+    float* red = smem;  // [wave][ntw][g][2][4]
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NTW; ++nt) {
       f32x4 x1, x2;
       x1.x = row16_sum(sA[nt].x); x1.y = row16_sum(sA[nt].y); x1.z = row16_sum(sA[nt].z); x1.w = row16_sum(sA[nt].w);
       x2.x = row16_sum(sB[nt].x); x2.y = row16_sum(sB[nt].y); x2.z = row16_sum(sB[nt].z); x2.w = row16_sum(sB[nt].w);
       if (r == 0) {
-        float* d = red + ((wave * NT + nt) * 4 + g) * 8;
+        float* d = red + ((wave * NTW + nt) * 4 + g) * 8;
         st4(d, x1);
         st4(d + 4, x2);
       }
@@ -224,46 +229,48 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
     // NT*16 channels x 2 sums, one thread each
     if (tid < NT * 32) {
       const int k = tid / (NT * 16), c = tid % (NT * 16);
-      const int nt = c >> 4, gg = (c >> 2) & 3, e = c & 3;
+      const int wn = c / (NTW * 16), nt = (c >> 4) % NTW, gg = (c >> 2) & 3, e = c & 3;
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) s += red[((w * NT + nt) * 4 + gg) * 8 + k * 4 + e];
+      for (int wm = 0; wm < WM; ++wm) s += red[(((wm * WN + wn) * NTW + nt) * 4 + gg) * 8 + k * 4 + e];
       a.part[(((size_t)b * P.ntiles + tile) * 2 + k) * cout + n0 + c] = s;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// (NT, MT): accumulators MT*NT <= 16 float4 (64 VGPRs) and staged window <= 72 KB (>= 2 workgroups / CU)
+// tile configuration: (NT n-tiles per workgroup, MT m-tiles per wave, WN waves along channels); TM = 16*MT*(4/WN).
+// accumulators MT*NT/WN <= 16 float4 (64 VGPRs); staged window <= 72 KB so two workgroups share a CU.
 static inline int pick_nt(int cout) { return cout >= 128 ? 8 : cout >= 64 ? 4 : cout >= 32 ? 2 : 1; }
-static inline int window_rows(int mt, int taps, int stride, int mode) {
-  const int tm = 64 * mt;
+static inline int window_rows(int tm, int taps, int stride, int mode) {
   if (mode == W2S_MODE_CONTIG) return (tm - 1) * stride + taps;
   if (mode == W2S_MODE_DILATED) return tm;
   return tm / 2 + 1;
 }
-static inline int pick_mt(int cin, int cout, int taps, int stride, int mode) {
-  const int nt = pick_nt(cout);
-  int mt = nt <= 2 ? 4 : nt == 4 ? 2 : 1;
-  const int lo = (mode == W2S_MODE_UP2) ? 2 : (nt <= 2 ? 2 : 1);
-  if (mt < lo) mt = lo;
-  while (mt > lo && (size_t)window_rows(mt, taps, stride, mode) * (cin + 4) * 4 > 72 * 1024) mt >>= 1;
-  return mt;
+struct TileCfg { int nt, mt, wn; };
+static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode) {
+  TileCfg c;
+  c.nt = pick_nt(cout);
+  c.wn = (c.nt == 8) ? 2 : 1;
+  c.mt = 4;
+  const int wm = 4 / c.wn;
+  if ((size_t)window_rows(16 * c.mt * wm, taps, stride, mode) * (cin + 4) * 4 > 72 * 1024) c.mt = 2;
+  return c;
 }
+static inline int cfg_tm(const TileCfg& c) { return 16 * c.mt * (4 / c.wn); }
 
-
-template <int NT, int MT, int TAPS, int STRIDE, int MODE>
+template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN>
 static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
-  constexpr int TM = 64 * MT;
+  constexpr int TM = 16 * MT * (4 / WN);
   ConvP P;
   P.a = a;
   P.ntiles = (a.L_out + TM - 1) / TM;
-  const int NR = window_rows(MT, TAPS, STRIDE, MODE);
+  const int NR = window_rows(TM, TAPS, STRIDE, MODE);
   size_t lds = (size_t)NR * (a.cin + 4) * sizeof(float);
-  size_t red = (size_t)4 * NT * 4 * 8 * sizeof(float);
+  size_t red = (size_t)4 * (NT / WN) * 4 * 8 * sizeof(float);
   if (lds < red) lds = red;
   dim3 grid(P.ntiles, a.cout / (NT * 16), a.B);
-  auto kern = conv_cl_kernel<NT, MT, TAPS, STRIDE, MODE>;
+  auto kern = conv_cl_kernel<NT, MT, TAPS, STRIDE, MODE, WN>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return W2S_ELAUNCH;
@@ -276,17 +283,10 @@ static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
 
 template <int TAPS, int STRIDE, int MODE>
 static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
-  const int nt = pick_nt(a.cout), mt = pick_mt(a.cin, a.cout, TAPS, STRIDE, MODE);
-  if (a.cout % (nt * 16)) return W2S_EINVAL;
-  if (nt == 1 && mt == 4) return launch_conv<1, 4, TAPS, STRIDE, MODE>(a, s);
-  if (nt == 1 && mt == 2) return launch_conv<1, 2, TAPS, STRIDE, MODE>(a, s);
-  if (nt == 2 && mt == 4) return launch_conv<2, 4, TAPS, STRIDE, MODE>(a, s);
-  if (nt == 2 && mt == 2) return launch_conv<2, 2, TAPS, STRIDE, MODE>(a, s);
-  if (nt == 4 && mt == 2) return launch_conv<4, 2, TAPS, STRIDE, MODE>(a, s);
-  if (nt == 8 && mt == 2) return launch_conv<8, 2, TAPS, STRIDE, MODE>(a, s);
-  if constexpr (MODE != W2S_MODE_UP2) {
-    if (nt == 4 && mt == 1) return launch_conv<4, 1, TAPS, STRIDE, MODE>(a, s);
-    if (nt == 8 && mt == 1) return launch_conv<8, 1, TAPS, STRIDE, MODE>(a, s);
-  }
+  const TileCfg c = pick_cfg(a.cin, a.cout, TAPS, STRIDE, MODE);
+  if (a.cout % (c.nt * 16)) return W2S_EINVAL;
+#define W2S_CFG(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_>(a, s);
+  W2S_CFG(1, 4, 1) W2S_CFG(2, 4, 1) W2S_CFG(2, 2, 1) W2S_CFG(4, 4, 1) W2S_CFG(4, 2, 1) W2S_CFG(8, 4, 2) W2S_CFG(8, 2, 2) W2S_CFG(1, 2, 1)
+#undef W2S_CFG
   return W2S_EINVAL;
 }

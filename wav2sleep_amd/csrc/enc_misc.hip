@@ -172,11 +172,11 @@ extern "C" int w2s_enc_first_bwd(const float* x, const float* gn1, const float* 
 // partial sums -> per-(b,c) statistics.  kind 0: (mean, rstd) with biased variance + eps
 // (nn.InstanceNorm1d, models/utils.py:89-92);  kind 1: (sum1/count, sum2/count).  fp64 accumulation.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, int ntiles, int C, double inv_count, float eps,
-                                                             int kind, float* __restrict__ out) {
-  __shared__ double red[2][256];
+__global__ __launch_bounds__(1024) void stats_finalize_kernel(const float* __restrict__ part, int ntiles, int C, double inv_count, float eps,
+                                                              int kind, float* __restrict__ out) {
+  __shared__ double red[2][1024];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int c = tid % C, rl = tid / C, nrl = 256 / C;
+  const int c = tid % C, rl = tid / C, nrl = 1024 / C;
   double s1 = 0.0, s2 = 0.0;
   if (rl < nrl) {
     for (int t = rl; t < ntiles; t += nrl) {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
 
 extern "C" int w2s_stats_finalize(const float* part, int B, int ntiles, int C, long count, float eps, int kind, float* out, void* stream) {
   if (!part || !out || C <= 0 || C > 256 || (256 % C) || count <= 0) return W2S_EINVAL;
-  hipLaunchKernelGGL(stats_finalize_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, ntiles, C,
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3(B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), part, ntiles, C,
                      1.0 / (double)count, eps, kind, out);
   W2S_CHECK_LAUNCH();
   return W2S_OK;

@@ -112,13 +112,25 @@ extern "C" int w2s_layernorm_bwd(const float* g, int ldg, const float* x, int ld
 // ------------------------------------------------------------------------------------------------
 // column sums: part[blk][c] = sum over the block's rows of g[row][c]; then out[c] (+)= sum_p part[p][c]
 // ------------------------------------------------------------------------------------------------
+// 256 threads = 32 column lanes x 8 row lanes; fixed-order LDS tree
 __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ g, int rows, int C, int ldg, float* __restrict__ part) {
+  __shared__ float red[8][33];
   const int per = (rows + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
-  for (int c = threadIdx.x; c < C; c += 256) {
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    const int c = c0 + cl;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += g[(size_t)r * ldg + c];
-    part[(size_t)blockIdx.x * C + c] = s;
+    if (c < C)
+      for (int r = r0 + rl; r < r1; r += 8) s += g[(size_t)r * ldg + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+      for (int k = 1; k < 8; ++k) s += red[k][cl];
+      part[(size_t)blockIdx.x * C + c] = s;
+    }
+    __syncthreads();
   }
 }
 extern "C" int w2s_bias_grad(const float* g, int rows, int C, int ldg, float* part, int nparts, void* stream) {
@@ -127,16 +139,24 @@ extern "C" int w2s_bias_grad(const float* g, int rows, int C, int ldg, float* pa
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
-__global__ void colsum_kernel(const float* __restrict__ part, int nparts, int C, int ld, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[c] (+)= sum_p part[p*ld + c]: 16 column lanes x 16 part lanes, fp64, fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nparts, int C, int ld, float* __restrict__ out, int accumulate) {
+  __shared__ double red[16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += (double)part[(size_t)p * ld + c];
+  if (c < C)
+    for (int p = pl; p < nparts; p += 16) s += (double)part[(size_t)p * ld + c];
+  red[pl][cl] = s;
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += red[k][cl];
   out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 extern "C" int w2s_colsum(const float* part, int nparts, int C, int ld, float* out, int accumulate, void* stream) {
   if (!part || !out || nparts <= 0 || C <= 0 || ld < C) return W2S_EINVAL;
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, nparts, C, ld, out, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 15) / 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, nparts, C, ld, out, accumulate);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

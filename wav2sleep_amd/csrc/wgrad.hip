@@ -138,20 +138,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP P) {
 
 // sum slabs in a fixed order (16 slab-lanes x sequential chunks, then a fixed LDS tree); decode the fragment
 // index to (o, j, c); write torch layout grad[o][c][j] (layout 0) or [o][j][c] (layout 1).  Deterministic.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, float* __restrict__ grad, int cout,
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, float* __restrict__ grad, int cout,
                                                            int cin, int taps, int NTO, int NTC, int TAPS_T, int accumulate, int layout) {
-  __shared__ float red[16][16];
+  __shared__ float red[64][17];
   const size_t per = (size_t)cout * cin * taps;  // floats per slab
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const size_t idx = (size_t)blockIdx.x * 16 + el;
   float s = 0.f;
   if (idx < per)
-    for (int k = sl; k < nslab; k += 16) s += slab[(size_t)k * per + idx];
+    for (int k = sl; k < nslab; k += 64) s += slab[(size_t)k * per + idx];
   red[sl][el] = s;
   __syncthreads();
   if (sl != 0 || idx >= per) return;
-#pragma unroll
-  for (int k = 1; k < 16; ++k) s += red[k][el];
+#pragma unroll 8
+  for (int k = 1; k < 64; ++k) s += red[k][el];
   // idx = ((y * TILES + tile) * 64 + lane) * 4 + reg
   const int reg = idx & 3, lane = (idx >> 2) & 63;
   const int TILES = NTO * TAPS_T * NTC;
@@ -243,7 +243,7 @@ extern "C" int w2s_wgrad_reduce(const float* slab, int nslab, float* grad, int c
   if (!slab || !grad || nslab <= 0) return W2S_EINVAL;
   const WgCfg c = wg_cfg(cin, cout, taps, dil);
   const size_t per = (size_t)cout * cin * taps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 15) / 16)), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), slab,
                      nslab, grad, cout, cin, taps, c.nto, c.ntc, c.tapst, accumulate, layout);
   W2S_CHECK_LAUNCH();
   return W2S_OK;

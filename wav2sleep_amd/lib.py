@@ -142,6 +142,7 @@ class LaunchTimer:
 
 
 TIMER: LaunchTimer | None = None
+DETAIL = bool(os.environ.get('W2S_TIMER_DETAIL'))
 
 
 def _timed(key, nbytes, flops, fn):
@@ -164,9 +165,13 @@ def conv_forward(a: ConvArgs):
     taps_eff = 1.5 if a.mode == MODE_UP2 else a.taps
     flops = int(2 * out_el * a.cin * taps_eff)
     nt = 8 if a.cout >= 128 else 4 if a.cout >= 64 else 2 if a.cout >= 32 else 1
-    mt = load().w2s_conv_tile(C.byref(a)) // 64
+    wn = 2 if nt == 8 else 1
+    mt = load().w2s_conv_tile(C.byref(a)) // (16 * (4 // wn))
     # key == the kernel name rocprofv3 reports, so bench.py's average can be checked against profiles/
-    _timed(f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}>', nbytes, flops, run)
+    key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}, {wn}>'
+    if DETAIL:
+        key += f' {a.cin}->{a.cout} pro{a.pro} epi{a.epi} L{a.L_out}'
+    _timed(key, nbytes, flops, run)
 
 
 def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, ldg=None, ldx=None, pro_g=PRO_NONE,
@@ -186,7 +191,10 @@ def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, di
     nto = 8
     while nto > 1 and (nto > 32 // (ntc * tapst) or (cout // 16) % nto):
         nto //= 2
-    _timed(f'wgrad_kernel<{nto}, {ntc}, {tapst}, {stride}>', nbytes, 2 * B * L_out * cout * cin * taps, run)
+    key = f'wgrad_kernel<{nto}, {ntc}, {tapst}, {stride}>'
+    if DETAIL:
+        key += f' {cin}->{cout} k{taps} L{L_out}'
+    _timed(key, nbytes, 2 * B * L_out * cout * cin * taps, run)
 
 
 def wgrad_grid_y(cin, cout, taps, dil=1) -> int:
