@@ -251,7 +251,7 @@ struct TileCfg { int nt, mt, wn; };
 static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode) {
   TileCfg c;
   c.nt = pick_nt(cout);
-  c.wn = (c.nt == 8) ? 2 : 1;
+  c.wn = (c.nt >= 4) ? 2 : 1;
   c.mt = 4;
   const int wm = 4 / c.wn;
   if ((size_t)window_rows(16 * c.mt * wm, taps, stride, mode) * (cin + 4) * 4 > 72 * 1024) c.mt = 2;
@@ -286,7 +286,7 @@ static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
   const TileCfg c = pick_cfg(a.cin, a.cout, TAPS, STRIDE, MODE);
   if (a.cout % (c.nt * 16)) return W2S_EINVAL;
 #define W2S_CFG(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_>(a, s);
-  W2S_CFG(1, 4, 1) W2S_CFG(2, 4, 1) W2S_CFG(2, 2, 1) W2S_CFG(4, 4, 1) W2S_CFG(4, 2, 1) W2S_CFG(8, 4, 2) W2S_CFG(8, 2, 2) W2S_CFG(1, 2, 1)
+  W2S_CFG(1, 4, 1) W2S_CFG(2, 4, 1) W2S_CFG(2, 2, 1) W2S_CFG(4, 4, 2) W2S_CFG(4, 2, 2) W2S_CFG(8, 4, 2) W2S_CFG(8, 2, 2) W2S_CFG(1, 2, 1)
 #undef W2S_CFG
   return W2S_EINVAL;
 }

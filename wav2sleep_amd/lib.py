@@ -165,7 +165,7 @@ def conv_forward(a: ConvArgs):
     taps_eff = 1.5 if a.mode == MODE_UP2 else a.taps
     flops = int(2 * out_el * a.cin * taps_eff)
     nt = 8 if a.cout >= 128 else 4 if a.cout >= 64 else 2 if a.cout >= 32 else 1
-    wn = 2 if nt == 8 else 1
+    wn = 2 if nt >= 4 else 1
     mt = load().w2s_conv_tile(C.byref(a)) // (16 * (4 // wn))
     # key == the kernel name rocprofv3 reports, so bench.py's average can be checked against profiles/
     key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}, {wn}>'
