@@ -103,6 +103,19 @@ int w2s_wgrad_reduce(const float* slab, int nslab, float* grad, int cout, int ci
 /* [cout][cin][taps] (torch) -> fwd pack [cout][taps][cin] and/or bwd pack [cin][taps][cout]; either dst may be NULL */
 int w2s_repack(const float* w, float* fwd, float* bwd, int cout, int cin, int taps, void* stream);
 
+/*
+ * Fused backward of one encoder ConvLayer1D (k=3, pad=1, stride 1 or 2) for the bandwidth-bound <=32-channel layers:
+ * data gradient + weight gradient from one pass over (g, y_k, y_{k-1}).  cg = channels of the gradient side (the
+ * forward conv's cout), ch = channels of the input side (its cin); supported (cg,ch): (16,16) (32,16) (32,32).
+ * gout[t][c] = (W^T gy [+ add_even[t/2] at even t]) * GELU'(n_in);  part: [B][ceil(Lh/tile)][2][ch] sums of gout, gout*n_in;
+ * slab: nslab (= grid size) raw-fragment slabs of cg*3*ch floats -> w2s_wgrad_reduce(slab, nslab, grad, cg, ch, 3, 1, ...).
+ * Replaces aten::convolution_backward + native_batch_norm_backward + gelu_backward of blocks.py:173-186.
+ */
+int w2s_bwd_fused_tile(int cg, int ch);
+int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
+                  const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
+                  int B, int Lg, int Lh, int cg, int ch, int stride, void* stream);
+
 /* partial sums [B][ntiles][2][C] -> per-(b,c) pairs [B][C][2]: kind 0 = (mean, rstd) with biased variance + eps
  * (nn.InstanceNorm1d, models/utils.py:89-92), kind 1 = (sum1, sum2)/count.  fp64 accumulation, fixed order. */
 int w2s_stats_finalize(const float* part, int B, int ntiles, int C, long count, float eps, int kind, float* out, void* stream);

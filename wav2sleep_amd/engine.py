@@ -175,6 +175,20 @@ class Engine:
         lib.wgrad_reduce(slab, nslab, self.G[name], cout, cin, taps, dil, accumulate=name in self._written, layout=layout)
         self._written.add(name)
 
+    def _bwd_fused(self, name, *, g, y, st_k, bst_k, pro, xin, st_in, add_even, gout, want_part, B, Lg, Lh, cg, ch, stride):
+        """dgrad + wgrad of one k=3 encoder conv in one pass (<= 32 channels); returns the backward statistics or None."""
+        dev = g.device
+        tile = lib.bwd_fused_tile(cg, ch)
+        nt = _cdiv(Lh, tile)
+        nslab = max(1, min(B * nt, 1024))
+        slab = self._slab(dev, nslab, cg * ch * 3)
+        part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
+        lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
+                      part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride)
+        lib.wgrad_reduce(slab, nslab, self.G[name], cg, ch, 3, 1, accumulate=name in self._written, layout=0)
+        self._written.add(name)
+        return self._bstats(part, B, nt, ch, Lh) if want_part else None
+
     def _colgrad(self, name, g, rows, C, ldg=None):
         """G[name][c] = sum_rows g[row, c]  (bias / CLS gradients)."""
         nparts = max(1, min(256, _cdiv(rows, 64)))
@@ -507,37 +521,46 @@ class Engine:
             lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile)
             bs3 = self._bstats(part, B, nt, c, Lh)
             gn2 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
-            tile = lib.conv_tile(c, c, 3, 2, lib.MODE_UP2)
-            nt = _cdiv(L, tile)
-            part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
-            self._conv(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
-                       pad=1, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP, aux=blk['y2'],
-                       aux_stats=blk['st2'], part=part)
-            bs2 = self._bstats(part, B, nt, c, L)
-            self._wgrad(p + 'conv3.conv.weight', g=gpre, g2=blk['y3'], g_stats=blk['st3'], g_bstats=bs3, pro_g=lib.PRO_INBWD_GP, x=blk['y2'],
-                        x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=1)
-            # conv2
             gn1 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
-            tile = lib.conv_tile(c, c, 3, 1, lib.MODE_CONTIG)
-            nt = _cdiv(L, tile)
-            part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
-            self._conv(x=gn2, x2=blk['y2'], w=PB[p + 'conv2.conv.weight'], y=gn1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1,
-                       pad=1, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st2'], pro_bstats=bs2, epi=lib.EPI_GP, aux=blk['y1'],
-                       aux_stats=blk['st1'], part=part)
-            bs1 = self._bstats(part, B, nt, c, L)
-            self._wgrad(p + 'conv2.conv.weight', g=gn2, g2=blk['y2'], g_stats=blk['st2'], g_bstats=bs2, pro_g=lib.PRO_INBWD, x=blk['y1'],
-                        x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=1)
+            if lib.bwd_fused_supported(c, c):
+                bs2 = self._bwd_fused(p + 'conv3.conv.weight', g=gpre, y=blk['y3'], st_k=blk['st3'], bst_k=bs3, pro=lib.PRO_INBWD_GP,
+                                      xin=blk['y2'], st_in=blk['st2'], add_even=None, gout=gn2, want_part=True, B=B, Lg=Lh, Lh=L, cg=c, ch=c, stride=2)
+                bs1 = self._bwd_fused(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, pro=lib.PRO_INBWD,
+                                      xin=blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B, Lg=L, Lh=L, cg=c, ch=c, stride=1)
+            else:
+                tile = lib.conv_tile(c, c, 3, 2, lib.MODE_UP2)
+                nt = _cdiv(L, tile)
+                part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
+                self._conv(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
+                           pad=1, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP, aux=blk['y2'],
+                           aux_stats=blk['st2'], part=part)
+                bs2 = self._bstats(part, B, nt, c, L)
+                self._wgrad(p + 'conv3.conv.weight', g=gpre, g2=blk['y3'], g_stats=blk['st3'], g_bstats=bs3, pro_g=lib.PRO_INBWD_GP, x=blk['y2'],
+                            x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=1)
+                tile = lib.conv_tile(c, c, 3, 1, lib.MODE_CONTIG)
+                nt = _cdiv(L, tile)
+                part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
+                self._conv(x=gn2, x2=blk['y2'], w=PB[p + 'conv2.conv.weight'], y=gn1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1,
+                           pad=1, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st2'], pro_bstats=bs2, epi=lib.EPI_GP, aux=blk['y1'],
+                           aux_stats=blk['st1'], part=part)
+                bs1 = self._bstats(part, B, nt, c, L)
+                self._wgrad(p + 'conv2.conv.weight', g=gn2, g2=blk['y2'], g_stats=blk['st2'], g_bstats=bs2, pro_g=lib.PRO_INBWD, x=blk['y1'],
+                            x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=1)
             del gn2
             if i > 0:
                 # residual 1x1/stride-2 branch: R = Wd^T gpre, added at even positions inside conv1's data-gradient epilogue
                 Rr = torch.empty(B, Lh, cin, device=dev, dtype=torch.float32)
                 self._conv(x=gpre, w=PB[p + 'downsample.weight'], y=Rr, B=B, L_in=Lh, L_out=Lh, cin=c, cout=cin, taps=1, stride=1, pad=0)
                 gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
-                self._conv(x=gn1, x2=blk['y1'], w=PB[p + 'conv1.conv.weight'], y=gprev, B=B, L_in=L, L_out=L, cin=c, cout=cin, taps=3,
-                           stride=1, pad=1, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st1'], pro_bstats=bs1, epi=lib.EPI_GP, aux=blk['pin'],
-                           add_even=Rr)
-                self._wgrad(p + 'conv1.conv.weight', g=gn1, g2=blk['y1'], g_stats=blk['st1'], g_bstats=bs1, pro_g=lib.PRO_INBWD,
-                            x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=L, cin=cin, cout=c, taps=3, stride=1, pad=1)
+                if lib.bwd_fused_supported(c, cin):
+                    self._bwd_fused(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, pro=lib.PRO_INBWD, xin=blk['pin'],
+                                    st_in=None, add_even=Rr, gout=gprev, want_part=False, B=B, Lg=L, Lh=L, cg=c, ch=cin, stride=1)
+                else:
+                    self._conv(x=gn1, x2=blk['y1'], w=PB[p + 'conv1.conv.weight'], y=gprev, B=B, L_in=L, L_out=L, cin=c, cout=cin, taps=3,
+                               stride=1, pad=1, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st1'], pro_bstats=bs1, epi=lib.EPI_GP, aux=blk['pin'],
+                               add_even=Rr)
+                    self._wgrad(p + 'conv1.conv.weight', g=gn1, g2=blk['y1'], g_stats=blk['st1'], g_bstats=bs1, pro_g=lib.PRO_INBWD,
+                                x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=L, cin=cin, cout=c, taps=3, stride=1, pad=1)
                 self._wgrad(p + 'downsample.weight', g=gpre, x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=Lh, cin=cin, cout=c,
                             taps=1, stride=2, pad=0)
                 gpre = gprev

@@ -39,7 +39,7 @@ class WgradArgs(C.Structure):
 
 
 EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_reduce', 'w2s_repack',
-           'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
+           'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_version']
@@ -195,6 +195,26 @@ def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, di
     if DETAIL:
         key += f' {cin}->{cout} k{taps} L{L_out}'
     _timed(key, nbytes, 2 * B * L_out * cout * cin * taps, run)
+
+
+def bwd_fused_supported(cg, ch) -> bool:
+    return (cg, ch) in ((16, 16), (32, 16), (32, 32))
+
+
+def bwd_fused_tile(cg, ch) -> int:
+    return load().w2s_bwd_fused_tile(cg, ch)
+
+
+def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride):
+    def run():
+        _chk(load().w2s_bwd_fused(_f(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), _f(gout), _f(part),
+                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, _stream()), f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
+    nbytes = 4 * (2 * B * Lg * cg + 2 * B * Lh * ch + (B * Lh * ch // 2 if add_even is not None else 0))
+    flops = 2 * B * Lg * cg * ch * 3 * 2
+    key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}>'
+    if DETAIL:
+        key += f' L{Lh}'
+    _timed(key, nbytes, flops, run)
 
 
 def wgrad_grid_y(cin, cout, taps, dil=1) -> int:
