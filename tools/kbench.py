@@ -49,7 +49,24 @@ def elt_case(op, n=16 * 983040 * 16):
     nb = 4 * n * (3 if op == lib.ELT_ADD else 2)
     return (lambda: lib.eltwise(op, a, b if op == lib.ELT_ADD else None, y, n)), nb, n
 
+def fused_case(cg, ch, L, stride=1, B=16, nslab=None):
+    Lg = L // stride
+    g = torch.randn(B, Lg, cg, device=dev); y = torch.randn(B, Lg, cg, device=dev); xin = torch.randn(B, L, ch, device=dev)
+    st = torch.rand(B, cg, 2, device=dev) + 0.5; bst = torch.rand(B, cg, 2, device=dev) * 0.01; sti = torch.rand(B, ch, 2, device=dev) + 0.5
+    wb = torch.randn(ch, 3, cg, device=dev) / 7; gout = torch.empty(B, L, ch, device=dev)
+    tile = lib.bwd_fused_tile(cg, ch); nt = (L + tile - 1) // tile
+    part = torch.empty(B, nt, 2, ch, device=dev)
+    ns = nslab or int(os.environ.get('NSLAB', 1024))
+    slab = torch.empty(ns * cg * ch * 3, device=dev)
+    fn = lambda: lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=lib.PRO_INBWD if stride == 1 else lib.PRO_INBWD_GP, xin=xin, st_in=sti, add_even=None,
+                               wb=wb, gout=gout, part=part, slab=slab, nslab=ns, B=B, Lg=Lg, Lh=L, cg=cg, ch=ch, stride=stride)
+    return fn, 4 * (2 * B * Lg * cg + 2 * B * L * ch), 2 * B * Lg * cg * ch * 3 * 2
+
 CASES = {
+    'b16': lambda: fused_case(16, 16, 983040),
+    'b16u': lambda: fused_case(16, 16, 983040, stride=2),
+    'b32': lambda: fused_case(32, 32, 245760),
+    'b32u': lambda: fused_case(32, 32, 245760, stride=2),
     'add': lambda: elt_case(lib.ELT_ADD),
     'gelu': lambda: elt_case(lib.ELT_GELU),
     'tcopy': lambda: (lambda a, y: ((lambda: y.copy_(a)), 8 * a.numel(), a.numel()))(torch.randn(16 * 983040 * 16, device=dev), torch.empty(16 * 983040 * 16, device=dev)),

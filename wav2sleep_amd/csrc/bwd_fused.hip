@@ -23,7 +23,7 @@ struct BwdP {
   int B, Lg, Lh, ntiles, pro;
 };
 
-template <int CG, int CH, int MT, int UP2>
+template <int CG, int CH, int MT, int UP2, int PF>
 __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdP P) {
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdP P) {
   constexpr int NRh = UP2 ? TM + 1 : TM + 2;        // h window rows (row 0 = position t0-1)
   float* gyL = smem;
   float* hL = smem + NRg * RSg;
-  float* red = hL + NRh * RSh;                      // [4][CH][4][8] stats scratch, later [4][64][4] slab reduce
+  float* nL = hL + NRh * RSh;                       // normalised input n_in of the TM centre rows (epilogue: GELU'(n), stats)
+  float* red = nL + TM * RSh;                       // [4][CH][4][8] stats scratch, later [4][64][4] slab reduce
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int Lg = P.Lg, Lh = P.Lh;
@@ -47,50 +48,88 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdP P) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) accw[i][j][c] = (f32x4){0, 0, 0, 0};
 
+  // ---- dgrad weights [HC][3][GC] -> LDS once (persistent kernel): the MFMA loops then touch no global memory, so the
+  //      next tile's prefetch (below) is not drained by an in-order vmcnt wait on a weight load.
+  constexpr int WROW = 3 * GC + 4;
+  float* wL = red + 1024;
+  for (int i = tid; i < HC * (3 * GC / 4); i += 256) {
+    const int row = i / (3 * GC / 4), c4 = i % (3 * GC / 4);
+    st4(wL + row * WROW + c4 * 4, ld4(P.wb + (size_t)row * (3 * GC) + c4 * 4));
+  }
+
+  // ---- software pipeline: raw global data of tile i+1 is prefetched into registers while tile i computes
+  constexpr int c4g = GC / 4, rstep_g = 256 / c4g, NG = (NRg + rstep_g - 1) / rstep_g;
+  constexpr int c4h = HC / 4, rstep_h = 256 / c4h, NH = (NRh + rstep_h - 1) / rstep_h;
+  const int gc4 = tid % c4g, grow0 = tid / c4g, gch = gc4 * 4;
+  const int hc4 = tid % c4h, hrow0 = tid / c4h, hch = hc4 * 4;
+  f32x4 rg[NG], ry[NG], rh[NH];
+  auto prefetch = [&](int tl) {
+    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+    const float* gb = P.g + (size_t)b * Lg * GC + gch;
+    const float* yb = P.y + (size_t)b * Lg * GC + gch;
+    const int rb = UP2 ? t0 / 2 : t0 - 1;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int row = grow0 + k * rstep_g, gr = rb + row;
+      const bool ok = row < NRg && gr >= 0 && gr < Lg;
+      rg[k] = ok ? ld4(gb + (size_t)gr * GC) : (f32x4){0, 0, 0, 0};
+      ry[k] = ok ? ld4(yb + (size_t)gr * GC) : (f32x4){0, 0, 0, 0};
+    }
+    const float* xb = P.xin + (size_t)b * Lh * HC + hch;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
+      const bool ok = row < NRh && gr >= 0 && gr < Lh;
+      rh[k] = ok ? ld4(xb + (size_t)gr * HC) : (f32x4){0, 0, 0, 0};
+    }
+  };
+  auto commit = [&](int tl) {  // transform the prefetched registers and write both windows to LDS
+    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+    f32x4 pm, pr, ps1, ps2;
+    {
+      const float* st = P.st_k + ((size_t)b * GC + gch) * 2;
+      f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+      pm = (f32x4){s01.x, s01.z, s23.x, s23.z}; pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+      const float* bs = P.bst_k + ((size_t)b * GC + gch) * 2;
+      f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
+      ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z}; ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
+    }
+    const int rb = UP2 ? t0 / 2 : t0 - 1;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int row = grow0 + k * rstep_g, gr = rb + row;
+      if (row < NRg) {
+        const bool ok = gr >= 0 && gr < Lg;
+        st4(gyL + row * RSg + gch, ok ? pro_apply(P.pro, rg[k], ry[k], pm, pr, ps1, ps2) : (f32x4){0, 0, 0, 0});
+      }
+    }
+    f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
+    if (P.st_in) {
+      const float* st = P.st_in + ((size_t)b * HC + hch) * 2;
+      f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+      hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
+      if (row < NRh) {
+        const bool ok = gr >= 0 && gr < Lh;
+        const f32x4 nv = (rh[k] - hm) * hr;
+        st4(hL + row * RSh + hch, ok ? gelu4(nv) : (f32x4){0, 0, 0, 0});
+        if (row >= 1 && row <= TM) st4(nL + (row - 1) * RSh + hch, nv);
+      }
+    }
+  };
+
   const int total = P.B * P.ntiles;
+  if (PF && (int)blockIdx.x < total) prefetch(blockIdx.x);
   for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
     const int b = tl / P.ntiles, tile = tl % P.ntiles;
     const int t0 = tile * TM;
-    __syncthreads();
-    {  // ---- stage gy window
-      constexpr int c4n = GC / 4, rstep = 256 / c4n;
-      const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
-      f32x4 pm, pr, ps1, ps2;
-      {
-        const float* st = P.st_k + ((size_t)b * GC + ch) * 2;
-        f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-        pm = (f32x4){s01.x, s01.z, s23.x, s23.z}; pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
-        const float* bs = P.bst_k + ((size_t)b * GC + ch) * 2;
-        f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
-        ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z}; ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
-      }
-      const float* gb = P.g + (size_t)b * Lg * GC + ch;
-      const float* yb = P.y + (size_t)b * Lg * GC + ch;
-      const int rb = UP2 ? t0 / 2 : t0 - 1;
-      for (int row = row0; row < NRg; row += rstep) {
-        const int gr = rb + row;
-        f32x4 v = {0, 0, 0, 0};
-        if (gr >= 0 && gr < Lg) v = pro_apply(P.pro, ld4(gb + (size_t)gr * GC), ld4(yb + (size_t)gr * GC), pm, pr, ps1, ps2);
-        st4(gyL + row * RSg + ch, v);
-      }
-    }
-    {  // ---- stage h window (rows t0-1 ...)
-      constexpr int c4n = HC / 4, rstep = 256 / c4n;
-      const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
-      f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1};
-      if (P.st_in) {
-        const float* st = P.st_in + ((size_t)b * HC + ch) * 2;
-        f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-        pm = (f32x4){s01.x, s01.z, s23.x, s23.z}; pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
-      }
-      const float* xb = P.xin + (size_t)b * Lh * HC + ch;
-      for (int row = row0; row < NRh; row += rstep) {
-        const int gr = t0 - 1 + row;
-        f32x4 v = {0, 0, 0, 0};
-        if (gr >= 0 && gr < Lh) v = gelu4((ld4(xb + (size_t)gr * HC) - pm) * pr);
-        st4(hL + row * RSh + ch, v);
-      }
-    }
+    __syncthreads();  // everyone is done reading the previous tile's windows (and wL is written)
+    if (!PF) prefetch(tl);
+    commit(tl);
+    if (PF && tl + (int)gridDim.x < total) prefetch(tl + gridDim.x);
     __syncthreads();
 
     // ---- data gradient: this wave's 16*MT output positions x HC channels
@@ -109,7 +148,7 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdP P) {
           bf[mt] = *reinterpret_cast<const f32x4*>(gyL + row * RSg + q * 16 + 4 * g);
         }
 #pragma unroll
-        for (int nt = 0; nt < CH; ++nt) af[nt] = ld4(P.wb + (size_t)(nt * 16 + r) * (3 * GC) + jw * GC + q * 16 + 4 * g);
+        for (int nt = 0; nt < CH; ++nt) af[nt] = *reinterpret_cast<const f32x4*>(wL + (nt * 16 + r) * WROW + jw * GC + q * 16 + 4 * g);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -141,12 +180,7 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdP P) {
       for (int nt = 0; nt < CH; ++nt) {
         const int ch = nt * 16 + 4 * g;
         const size_t orow = (size_t)b * Lh + pos;
-        f32x4 n = ld4(P.xin + orow * HC + ch);
-        if (P.st_in) {
-          const float* st = P.st_in + ((size_t)b * HC + ch) * 2;
-          f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-          n = (n - (f32x4){s01.x, s01.z, s23.x, s23.z}) * (f32x4){s01.y, s01.w, s23.y, s23.w};
-        }
+        const f32x4 n = *reinterpret_cast<const f32x4*>(nL + (pos - t0) * RSh + ch);
         f32x4 v = acc[mt][nt];
         if (P.add_even && !(pos & 1)) v += ld4(P.add_even + ((size_t)b * (Lh >> 1) + (pos >> 1)) * HC + ch);
         v = v * gelu_grad4(n);
@@ -220,7 +254,7 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdP P) {
       }
 }
 
-template <int CG, int CH, int MT, int UP2>
+template <int CG, int CH, int MT, int UP2, int PF>
 static int launch_bwd(const BwdP& P0, int nslab, hipStream_t s) {
   constexpr int TM = 64 * MT;
   BwdP P = P0;
@@ -228,8 +262,8 @@ static int launch_bwd(const BwdP& P0, int nslab, hipStream_t s) {
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = UP2 ? TM + 1 : TM + 2;
   size_t lds = (size_t)(NRg * (CG * 16 + 4) + NRh * (CH * 16 + 4)) * 4;
   size_t redb = (size_t)((4 * CH * 4 * 8 > 1024) ? 4 * CH * 4 * 8 : 1024) * 4;
-  lds += redb;
-  auto kern = bwd_fused_kernel<CG, CH, MT, UP2>;
+  lds += redb + (size_t)(CH * 16) * (3 * CG * 16 + 4) * 4 + (size_t)TM * (CH * 16 + 4) * 4;
+  auto kern = bwd_fused_kernel<CG, CH, MT, UP2, PF>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -238,7 +272,16 @@ static int launch_bwd(const BwdP& P0, int nslab, hipStream_t s) {
   return W2S_OK;
 }
 
-extern "C" int w2s_bwd_fused_tile(int cg, int ch) { return (cg == 16 && ch == 16) ? 256 : 128; }
+#ifndef W2S_BF_MT11
+#define W2S_BF_MT11 4
+#endif
+#ifndef W2S_BF_MT2
+#define W2S_BF_MT2 2
+#endif
+#ifndef W2S_BF_PF
+#define W2S_BF_PF 1
+#endif
+extern "C" int w2s_bwd_fused_tile(int cg, int ch) { return 64 * ((cg == 16 && ch == 16) ? W2S_BF_MT11 : W2S_BF_MT2); }
 
 // cg = channels of the gradient side (the forward conv's cout), ch = channels of the input side (its cin).
 extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
@@ -251,8 +294,8 @@ extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int up2 = stride == 2;
 #define W2S_BF(CG_, CH_, MT_) \
-  if (cg == 16 * CG_ && ch == 16 * CH_) return up2 ? launch_bwd<CG_, CH_, MT_, 1>(P, nslab, s) : launch_bwd<CG_, CH_, MT_, 0>(P, nslab, s);
-  W2S_BF(1, 1, 4) W2S_BF(2, 1, 2) W2S_BF(2, 2, 2)
+  if (cg == 16 * CG_ && ch == 16 * CH_) return up2 ? launch_bwd<CG_, CH_, MT_, 1, W2S_BF_PF>(P, nslab, s) : launch_bwd<CG_, CH_, MT_, 0, W2S_BF_PF>(P, nslab, s);
+  W2S_BF(1, 1, W2S_BF_MT11) W2S_BF(2, 1, W2S_BF_MT2) W2S_BF(2, 2, W2S_BF_MT2)
 #undef W2S_BF
   return W2S_EINVAL;
 }

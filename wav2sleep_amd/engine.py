@@ -180,7 +180,7 @@ class Engine:
         dev = g.device
         tile = lib.bwd_fused_tile(cg, ch)
         nt = _cdiv(Lh, tile)
-        nslab = max(1, min(B * nt, 1024))
+        nslab = max(1, min(B * nt, 512))
         slab = self._slab(dev, nslab, cg * ch * 3)
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,

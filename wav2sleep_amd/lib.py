@@ -12,7 +12,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libw2s_hip.so')
+LIB_PATH = os.environ.get('W2S_LIB') or os.path.join(_HERE, 'libw2s_hip.so')  # W2S_LIB: tuning builds only
 CSRC = os.path.join(_HERE, 'csrc')
 
 # enums (include/w2s.h)
@@ -211,7 +211,7 @@ def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, s
                                   _f(slab), nslab, B, Lg, Lh, cg, ch, stride, _stream()), f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
     nbytes = 4 * (2 * B * Lg * cg + 2 * B * Lh * ch + (B * Lh * ch // 2 if add_even is not None else 0))
     flops = 2 * B * Lg * cg * ch * 3 * 2
-    key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}>'
+    key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}, 1>'
     if DETAIL:
         key += f' L{Lh}'
     _timed(key, nbytes, flops, run)
