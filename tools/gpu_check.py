@@ -51,7 +51,7 @@ def t_conv_stats_pro():
     h = F.gelu(F.instance_norm(x, eps=1e-2))
     want = F.conv1d(h, w, padding=1)
     y = torch.zeros(B, L, cout, device=dev)
-    tile = lib.conv_tile(cin, cout, 3, 1); nt = (L + tile - 1) // tile
+    tile = lib.conv_tile(cin, cout, 3, 1, lib.MODE_CONTIG, B, L); nt = (L + tile - 1) // tile
     part = torch.zeros(B, nt, 2, cout, device=dev)
     lib.conv_forward(lib.conv_args(x=cl(x).to(dev), w=pack_fwd(w).to(dev), y=y, B=B, L_in=L, L_out=L, cin=cin, cout=cout, taps=3, stride=1, pad=1,
                                    pro=lib.PRO_IN_GELU, pro_stats=st, epi=lib.EPI_STATS, part=part))

@@ -23,7 +23,7 @@ def conv_case(cin, cout, L, stride=1, pro=lib.PRO_IN_GELU, epi=lib.EPI_STATS, B=
     st = torch.rand(B, cin, 2, device=dev) + 0.5; bst = torch.rand(B, cin, 2, device=dev) * 0.01
     ost = torch.rand(B, cout, 2, device=dev) + 0.5
     aux = torch.randn(B, Lo, cout, device=dev) if epi in (lib.EPI_GP, lib.EPI_AUX_INGELU_ADD) else None
-    a0 = lib.ConvArgs(); a0.cin, a0.cout, a0.taps, a0.stride, a0.mode = cin, cout, taps, stride, mode
+    a0 = lib.ConvArgs(); a0.cin, a0.cout, a0.taps, a0.stride, a0.mode, a0.B, a0.L_out = cin, cout, taps, stride, mode, B, Lo
     tile = lib.load().w2s_conv_tile(__import__('ctypes').byref(a0))
     part = torch.empty(B, (Lo + tile - 1) // tile, 2, cout, device=dev)
     a = lib.conv_args(x=x, x2=x2 if pro >= lib.PRO_INBWD else None, w=w, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,

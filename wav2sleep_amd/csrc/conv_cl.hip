@@ -11,9 +11,9 @@ int w2s_conv_dispatch_71d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_44d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_33d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_up2(const w2s_conv_args& a, hipStream_t s);
-int w2s_conv_tile_impl(int cin, int cout, int taps, int stride, int mode);
+int w2s_conv_tile_impl(int cin, int cout, int taps, int stride, int mode, int B, int L_out);
 
-extern "C" int w2s_conv_tile(const w2s_conv_args* a) { return w2s_conv_tile_impl(a->cin, a->cout, a->taps, a->stride, a->mode); }
+extern "C" int w2s_conv_tile(const w2s_conv_args* a) { return w2s_conv_tile_impl(a->cin, a->cout, a->taps, a->stride, a->mode, a->B, a->L_out); }
 
 extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
   if (!ap) return W2S_EINVAL;

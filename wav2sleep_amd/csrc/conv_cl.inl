@@ -248,13 +248,21 @@ static inline int window_rows(int tm, int taps, int stride, int mode) {
   return tm / 2 + 1;
 }
 struct TileCfg { int nt, mt, wn; };
-static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode) {
+static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode, int B, int L_out) {
   TileCfg c;
   c.nt = pick_nt(cout);
   c.wn = (c.nt >= 4) ? 2 : 1;
   c.mt = 4;
-  const int wm = 4 / c.wn;
-  if ((size_t)window_rows(16 * c.mt * wm, taps, stride, mode) * (cin + 4) * 4 > 72 * 1024) c.mt = 2;
+  if ((size_t)window_rows(16 * c.mt * (4 / c.wn), taps, stride, mode) * (cin + 4) * 4 > 72 * 1024) c.mt = 2;
+  // short problems (SequenceCNN: 16 x 960 rows): shrink the tile until the grid covers the 256 CUs about twice
+  auto wgs = [&](const TileCfg& t) {
+    const long tm = 16 * t.mt * (4 / t.wn);
+    return (long)B * ((L_out + tm - 1) / tm) * (cout / (t.nt * 16));
+  };
+  if (B > 0 && L_out > 0) {
+    if (wgs(c) < 512 && c.mt == 4) c.mt = 2;
+    if (wgs(c) < 512 && c.nt == 8) c.nt = 4;
+  }
   return c;
 }
 static inline int cfg_tm(const TileCfg& c) { return 16 * c.mt * (4 / c.wn); }
@@ -283,7 +291,7 @@ static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
 
 template <int TAPS, int STRIDE, int MODE>
 static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
-  const TileCfg c = pick_cfg(a.cin, a.cout, TAPS, STRIDE, MODE);
+  const TileCfg c = pick_cfg(a.cin, a.cout, TAPS, STRIDE, MODE, a.B, a.L_out);
   if (a.cout % (c.nt * 16)) return W2S_EINVAL;
 #define W2S_CFG(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_>(a, s);
   W2S_CFG(1, 4, 1) W2S_CFG(2, 4, 1) W2S_CFG(2, 2, 1) W2S_CFG(4, 4, 2) W2S_CFG(4, 2, 2) W2S_CFG(8, 4, 2) W2S_CFG(8, 2, 2) W2S_CFG(1, 2, 1)

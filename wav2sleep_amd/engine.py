@@ -139,7 +139,7 @@ class Engine:
         """k=3 encoder conv writing the pre-norm tensor + instance-norm statistics (blocks.py:174-183)."""
         dev = x.device
         y = torch.empty(B, L_out, cout, device=dev, dtype=torch.float32)
-        tile = lib.conv_tile(cin, cout, 3, stride, lib.MODE_CONTIG)
+        tile = lib.conv_tile(cin, cout, 3, stride, lib.MODE_CONTIG, B, L_out)
         nt = _cdiv(L_out, tile)
         part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
         self._conv(x=x, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=1, pro=pro,
@@ -528,7 +528,7 @@ class Engine:
                 bs1 = self._bwd_fused(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, pro=lib.PRO_INBWD,
                                       xin=blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B, Lg=L, Lh=L, cg=c, ch=c, stride=1)
             else:
-                tile = lib.conv_tile(c, c, 3, 2, lib.MODE_UP2)
+                tile = lib.conv_tile(c, c, 3, 2, lib.MODE_UP2, B, L)
                 nt = _cdiv(L, tile)
                 part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
                 self._conv(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
@@ -537,7 +537,7 @@ class Engine:
                 bs2 = self._bstats(part, B, nt, c, L)
                 self._wgrad(p + 'conv3.conv.weight', g=gpre, g2=blk['y3'], g_stats=blk['st3'], g_bstats=bs3, pro_g=lib.PRO_INBWD_GP, x=blk['y2'],
                             x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=1)
-                tile = lib.conv_tile(c, c, 3, 1, lib.MODE_CONTIG)
+                tile = lib.conv_tile(c, c, 3, 1, lib.MODE_CONTIG, B, L)
                 nt = _cdiv(L, tile)
                 part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
                 self._conv(x=gn2, x2=blk['y2'], w=PB[p + 'conv2.conv.weight'], y=gn1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1,

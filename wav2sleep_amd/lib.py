@@ -116,9 +116,10 @@ def conv_args(*, x, w, y, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, f
     return a
 
 
-def conv_tile(cin, cout, taps, stride, mode=MODE_CONTIG) -> int:
+def conv_tile(cin, cout, taps, stride, mode=MODE_CONTIG, B=0, L_out=0) -> int:
+    """Positions per workgroup tile (sizes the statistics partials); depends on the problem size for short sequences."""
     a = ConvArgs()
-    a.cin, a.cout, a.taps, a.stride, a.mode = cin, cout, taps, stride, mode
+    a.cin, a.cout, a.taps, a.stride, a.mode, a.B, a.L_out = cin, cout, taps, stride, mode, B, L_out
     return load().w2s_conv_tile(C.byref(a))
 
 
@@ -166,7 +167,10 @@ def conv_forward(a: ConvArgs):
     flops = int(2 * out_el * a.cin * taps_eff)
     nt = 8 if a.cout >= 128 else 4 if a.cout >= 64 else 2 if a.cout >= 32 else 1
     wn = 2 if nt >= 4 else 1
-    mt = load().w2s_conv_tile(C.byref(a)) // (16 * (4 // wn))
+    tm = load().w2s_conv_tile(C.byref(a))
+    mt = tm // (16 * (4 // wn))
+    if nt == 8 and mt == 2 and a.B * ((a.L_out + tm - 1) // tm) * (a.cout // 128) < 512:
+        nt = 4  # short-sequence configuration (pick_cfg in conv_cl.inl)
     # key == the kernel name rocprofv3 reports, so bench.py's average can be checked against profiles/
     key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}, {wn}>'
     if DETAIL:
