@@ -93,9 +93,10 @@ typedef struct w2s_wgrad_args {
   int32_t B, L_in, L_out, cin, cout, taps, stride, dil, pad;
   int32_t ldg, ldx;
   int32_t pro_g, pro_h;
-  int32_t nslab;                           /* number of partial slabs = 4 * grid.x (one per wave) */
+  int32_t nslab;                           /* number of partial slabs = grid.x * w2s_wgrad_slabs_per_block() */
 } w2s_wgrad_args;
 int w2s_wgrad(const w2s_wgrad_args* a, void* stream);
+int w2s_wgrad_slabs_per_block(int cin, int cout, int taps, int dil); /* slabs written per grid.x block: nslab = grid.x * this */
 int w2s_wgrad_grid_y(int cin, int cout, int taps, int dil); /* grid.y of w2s_wgrad: slab floats = nslab*cout*cin*taps */
 /* grad (+)= sum_s slab[s]; layout 0: grad[o][c][j] (torch Conv1d), 1: grad[o][j][c] (Linear over the flattened taps) */
 int w2s_wgrad_reduce(const float* slab, int nslab, float* grad, int cout, int cin, int taps, int dil, int accumulate, int layout, void* stream);

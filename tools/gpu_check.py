@@ -106,7 +106,7 @@ def t_wgrad():
         gy = torch.randn_like(y); y.backward(gy)
         Lo = y.shape[-1]
         gyd = lib.wgrad_grid_y(cin, cout, taps, dil)
-        nslab = 4 * 8
+        nslab = 8 * lib.wgrad_slabs_per_block(cin, cout, taps, dil)
         slab = torch.zeros(nslab * cout * cin * taps, device=dev)
         lib.wgrad(g=cl(gy).to(dev), x=cl(x).to(dev), slab=slab, nslab=nslab, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
                   pad=pad, dil=dil)

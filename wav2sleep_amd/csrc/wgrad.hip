@@ -136,6 +136,116 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP P) {
       for (int c = 0; c < NTC; ++c) st4(out + ((i * TAPS_T + j) * NTC + c) * 256, acc[i][j][c]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Tile-split variant for the matrix-core-bound layers (cin >= 64): ONE workgroup of NW waves covers a whole block of
+// NW*OT*16 output channels x JT taps x all cin channels, wave w owning output-channel tiles [w*OT, (w+1)*OT).  Every wave
+// walks all positions of the staged tile, so GY and H are staged (and GELU'd) once instead of once per output-channel
+// slice (the position-split kernel above re-staged H up to 6x for 128 channels).  One slab per workgroup.
+// ------------------------------------------------------------------------------------------------------------------
+template <int OT, int JT, int CT, int NW, int STRIDE>
+__global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
+  extern __shared__ f32x4 smem4[];
+  float* smem = reinterpret_cast<float*>(smem4);
+  const w2s_wgrad_args& a = P.a;
+  constexpr int NT = NW * 64, WG = NW * OT * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int TM = P.TM;
+  const int cin = a.cin;  // == 16*CT
+  const int oy = blockIdx.y / P.ntg, tg = blockIdx.y % P.ntg;
+  const int o0 = oy * WG, j0 = tg * JT;
+  const int RSg = WG + 4, RSh = cin + 4;
+  const int NRh = (JT == 1) ? TM : (TM - 1) * STRIDE + JT;
+  float* gyL = smem;
+  float* hL = smem + TM * RSg;
+
+  f32x4 acc[OT][JT][CT];
+#pragma unroll
+  for (int i = 0; i < OT; ++i)
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[i][j][c] = (f32x4){0, 0, 0, 0};
+
+  const int total = a.B * P.ntiles;
+  for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    const int b = tl / P.ntiles, tile = tl % P.ntiles;
+    const int t0 = tile * TM;
+    __syncthreads();
+    {  // ---- stage GY tile (channels o0 .. o0+WG-1)
+      constexpr int c4n = WG / 4;
+      const float* gb = a.g + (size_t)b * a.L_out * a.ldg + o0;
+      const float* g2b = (a.pro_g >= W2S_PRO_INBWD) ? a.g2 + (size_t)b * a.L_out * a.ldg + o0 : nullptr;
+      if constexpr (NT % c4n == 0) {
+        constexpr int rstep = NT / c4n;
+        const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
+        f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, ps1 = {0, 0, 0, 0}, ps2 = {0, 0, 0, 0};
+        if (a.pro_g >= W2S_PRO_IN_GELU) {
+          load_chan_params(a.g_stats, b, a.cout, o0 + ch, pm, pr);
+          if (a.pro_g >= W2S_PRO_INBWD) load_chan_params(a.g_bstats, b, a.cout, o0 + ch, ps1, ps2);
+        }
+        for (int row = row0; row < TM; row += rstep) {
+          const int t = t0 + row;
+          f32x4 v = {0, 0, 0, 0};
+          if (t < a.L_out) {
+            f32x4 x = ld4(gb + (size_t)t * a.ldg + ch);
+            f32x4 x2 = g2b ? ld4(g2b + (size_t)t * a.ldg + ch) : (f32x4){0, 0, 0, 0};
+            v = pro4(a.pro_g, x, x2, pm, pr, ps1, ps2);
+          }
+          st4(gyL + row * RSg + ch, v);
+        }
+      } else {  // wide untransformed gradients (transformer linears): launcher guarantees pro_g == NONE
+        for (int f = tid; f < TM * c4n; f += NT) {
+          const int row = f / c4n, ch = (f % c4n) * 4, t = t0 + row;
+          st4(gyL + row * RSg + ch, t < a.L_out ? ld4(gb + (size_t)t * a.ldg + ch) : (f32x4){0, 0, 0, 0});
+        }
+      }
+    }
+    {  // ---- stage H window
+      const int c4n = cin >> 2, rstep = NT / c4n;
+      const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
+      f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, z = {0, 0, 0, 0};
+      if (a.pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
+      const float* xb = a.x + (size_t)b * a.L_in * a.ldx + ch;
+      const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
+      const int rowmul = (JT == 1) ? STRIDE : 1;
+      for (int row = row0; row < NRh; row += rstep) {
+        const int gr = rb + row * rowmul;
+        f32x4 v = {0, 0, 0, 0};
+        if (gr >= 0 && gr < a.L_in) v = pro4(a.pro_h, ld4(xb + (size_t)gr * a.ldx), z, pm, pr, z, z);
+        st4(hL + row * RSh + ch, v);
+      }
+    }
+    __syncthreads();
+    for (int s = 0; s < (TM >> 2); ++s) {
+      const int p = 4 * s + g;
+      float ga[OT], hb[JT][CT];
+#pragma unroll
+      for (int i = 0; i < OT; ++i) ga[i] = gyL[p * RSg + (wave * OT + i) * 16 + r];
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const int hr = (JT == 1) ? p : p * STRIDE + j;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) hb[j][c] = hL[hr * RSh + c * 16 + r];
+      }
+#pragma unroll
+      for (int i = 0; i < OT; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) acc[i][j][c] = mfma16(ga[i], hb[j][c], acc[i][j][c]);
+    }
+  }
+  constexpr int TILES = NW * OT * JT * CT;
+  float* out = a.slab + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * TILES) * 256 + lane * 4;
+#pragma unroll
+  for (int i = 0; i < OT; ++i)
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) st4(out + (((wave * OT + i) * JT + j) * CT + c) * 256, acc[i][j][c]);
+}
+
 // sum slabs in a fixed order (16 slab-lanes x sequential chunks, then a fixed LDS tree); decode the fragment
 // index to (o, j, c); write torch layout grad[o][c][j] (layout 0) or [o][j][c] (layout 1).  Deterministic.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, float* __restrict__ grad, int cout,
@@ -166,16 +276,55 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   *d = accumulate ? (*d + s) : s;
 }
 
-struct WgCfg { int nto, ntc, tapst; };
+struct WgCfg { int nto, ntc, tapst, ts, nw, ot; };
 static inline WgCfg wg_cfg(int cin, int cout, int taps, int dil) {
   WgCfg c;
   c.ntc = cin / 16;
+  c.ts = 0; c.nw = 4; c.ot = 0;
+  if (cin >= 64 && cout >= 64) {  // matrix-core-bound: tile-split kernel, one workgroup per output-channel block
+    c.ts = 1;
+    c.tapst = (taps == 3 && dil == 1) ? 3 : 1;
+    c.nw = (cout >= 128) ? 8 : 4;
+    const int budget = 32 / (c.ntc * c.tapst);  // accumulator tiles per wave <= 32
+    int ot = (cout / 16) / c.nw;
+    while (ot > 1 && (ot > budget || ((cout / 16) / c.nw) % ot)) --ot;
+    c.ot = ot;
+    c.nto = c.nw * ot;
+    return c;
+  }
   c.tapst = (taps == 3 && dil == 1 && c.ntc <= 4) ? 3 : 1;
   const int budget = 32 / (c.ntc * c.tapst);  // accumulator tiles per wave <= 32 (128 VGPRs)
   int nto = 8;
   while (nto > 1 && (nto > budget || (cout / 16) % nto)) nto >>= 1;
   c.nto = nto;
   return c;
+}
+
+template <int OT, int JT, int CT, int NW, int STRIDE>
+static int launch_wgrad_ts(const w2s_wgrad_args& a, hipStream_t s) {
+  WgradP P;
+  P.a = a;
+  constexpr int WG = NW * OT * 16;
+  if ((NW * 64) % (WG / 4) != 0 && a.pro_g != W2S_PRO_NONE) return W2S_EINVAL;
+  int TM = 128;
+  auto lds_of = [&](int tm) {
+    const int nrh = (JT == 1) ? tm : (tm - 1) * STRIDE + JT;
+    return (size_t)(tm * (WG + 4) + nrh * (a.cin + 4)) * sizeof(float);
+  };
+  while (TM > 16 && lds_of(TM) > 76 * 1024) TM >>= 1;
+  while (TM > 16 && TM >= 2 * a.L_out) TM >>= 1;
+  P.TM = TM;
+  P.ntiles = (a.L_out + TM - 1) / TM;
+  P.ntg = a.taps / JT;
+  dim3 grid(a.nslab, (a.cout / WG) * P.ntg);
+  size_t lds = lds_of(TM);
+  auto kern = wgrad_ts_kernel<OT, JT, CT, NW, STRIDE>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return W2S_ELAUNCH;
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, P);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
 }
 
 template <int NTO, int NTC, int TAPS_T, int STRIDE>
@@ -209,6 +358,14 @@ static int launch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
 template <int STRIDE>
 static int dispatch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
   const WgCfg c = wg_cfg(a.cin, a.cout, a.taps, a.dil);
+  if (c.ts) {
+#define W2S_TS(OT_, JT_, CT_, NW_) \
+  if (c.ot == OT_ && c.tapst == JT_ && c.ntc == CT_ && c.nw == NW_) return launch_wgrad_ts<OT_, JT_, CT_, NW_, STRIDE>(a, s);
+    if constexpr (STRIDE <= 2) { W2S_TS(1, 3, 8, 8) W2S_TS(1, 3, 4, 4) W2S_TS(1, 3, 4, 8) }
+    W2S_TS(1, 1, 8, 8) W2S_TS(1, 1, 4, 8) W2S_TS(1, 1, 4, 4) W2S_TS(3, 1, 8, 8) W2S_TS(4, 1, 8, 8) W2S_TS(2, 1, 8, 8) W2S_TS(1, 1, 8, 4)
+#undef W2S_TS
+    return W2S_EINVAL;
+  }
 #define W2S_WG(NTO_, NTC_, TT_) \
   if (c.nto == NTO_ && c.ntc == NTC_ && c.tapst == TT_) return launch_wgrad<NTO_, NTC_, TT_, STRIDE>(a, s);
   if constexpr (STRIDE <= 2) {
@@ -232,6 +389,8 @@ extern "C" int w2s_wgrad(const w2s_wgrad_args* ap, void* stream) {
   if (a.stride == 4) return dispatch_wgrad<4>(a, s);
   return W2S_EINVAL;
 }
+
+extern "C" int w2s_wgrad_slabs_per_block(int cin, int cout, int taps, int dil) { return wg_cfg(cin, cout, taps, dil).ts ? 1 : 4; }
 
 extern "C" int w2s_wgrad_grid_y(int cin, int cout, int taps, int dil) {
   const WgCfg c = wg_cfg(cin, cout, taps, dil);

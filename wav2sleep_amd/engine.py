@@ -168,7 +168,7 @@ class Engine:
         gy = lib.wgrad_grid_y(cin, cout, taps, dil)
         work = _cdiv(B * L_out, 256)
         gx = max(1, min(work, max(1, 512 // gy)))
-        nslab = 4 * gx
+        nslab = gx * lib.wgrad_slabs_per_block(cin, cout, taps, dil)
         slab = self._slab(g.device, nslab, cout * cin * taps)
         lib.wgrad(g=g, x=x, slab=slab, nslab=nslab, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad,
                   dil=dil, **kw)

@@ -38,7 +38,7 @@ class WgradArgs(C.Structure):
                                     'pro_g', 'pro_h', 'nslab')]
 
 
-EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_reduce', 'w2s_repack',
+EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_repack',
            'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
@@ -191,11 +191,19 @@ def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, di
         _chk(load().w2s_wgrad(C.byref(a), _stream()), f'w2s_wgrad(cin={cin},cout={cout},taps={taps},stride={stride})')
     nbytes = 4 * (B * L_out * cout * (2 if g2 is not None else 1) + B * L_in * cin)
     ntc = cin // 16
-    tapst = 3 if (taps == 3 and dil == 1 and ntc <= 4) else 1
-    nto = 8
-    while nto > 1 and (nto > 32 // (ntc * tapst) or (cout // 16) % nto):
-        nto //= 2
-    key = f'wgrad_kernel<{nto}, {ntc}, {tapst}, {stride}>'
+    if cin >= 64 and cout >= 64:  # tile-split kernel (wg_cfg in wgrad.hip)
+        tapst = 3 if (taps == 3 and dil == 1) else 1
+        nw = 8 if cout >= 128 else 4
+        ot = (cout // 16) // nw
+        while ot > 1 and (ot > 32 // (ntc * tapst) or ((cout // 16) // nw) % ot):
+            ot -= 1
+        key = f'wgrad_ts_kernel<{ot}, {tapst}, {ntc}, {nw}, {stride}>'
+    else:
+        tapst = 3 if (taps == 3 and dil == 1 and ntc <= 4) else 1
+        nto = 8
+        while nto > 1 and (nto > 32 // (ntc * tapst) or (cout // 16) % nto):
+            nto //= 2
+        key = f'wgrad_kernel<{nto}, {ntc}, {tapst}, {stride}>'
     if DETAIL:
         key += f' {cin}->{cout} k{taps} L{L_out}'
     _timed(key, nbytes, 2 * B * L_out * cout * cin * taps, run)
@@ -219,6 +227,10 @@ def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, s
     if DETAIL:
         key += f' L{Lh}'
     _timed(key, nbytes, flops, run)
+
+
+def wgrad_slabs_per_block(cin, cout, taps, dil=1) -> int:
+    return load().w2s_wgrad_slabs_per_block(cin, cout, taps, dil)
 
 
 def wgrad_grid_y(cin, cout, taps, dil=1) -> int:
