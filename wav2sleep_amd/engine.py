@@ -13,6 +13,7 @@ DilatedConvBlock.forward (blocks.py:115-126), and autograd's backward of all of 
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -77,6 +78,8 @@ class Engine:
         self._written: set[str] = set()
         self.ctx = None
         self.taps = None  # set to {} to collect per-stage tensors (tests / debugging)
+        self.multi_stream = os.environ.get('W2S_MULTI_STREAM', '1') != '0'
+        self._streams = {}
         lib.load()
 
     # ------------------------------------------------------------------ weights
@@ -127,6 +130,14 @@ class Engine:
             self._pack_key = key
 
     # ------------------------------------------------------------------ helpers
+    def _side_stream(self, enc: str, dev):
+        if not self.multi_stream:
+            return torch.cuda.current_stream(dev)
+        key = (enc, dev.index if dev.index is not None else torch.cuda.current_device())
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=dev)
+        return self._streams[key]
+
     def _finalize(self, part, B, ntiles, C, count, kind):
         out = torch.empty(B, C, 2, device=part.device, dtype=torch.float32)
         lib.stats_finalize(part, B, ntiles, C, count, self.spec.instance_eps, kind, out)
@@ -285,13 +296,22 @@ class Engine:
         tokens = torch.empty(N, D, F, device=dev, dtype=torch.float32)
         lib.fill_rows(tokens, D * F, P['epoch_mixer.register_tokens'], N, F)
         keeps, enc_ctx = [], []
+        # The encoders are independent until the set-fusion transformer: each runs on its own HIP stream, so the
+        # matrix-core-bound 64/128-channel layers of one modality overlap the bandwidth-bound 16/32-channel layers of
+        # another and grid tails are filled (signals sharing an encoder share a stream: their weight gradients accumulate).
+        main = torch.cuda.current_stream(dev)
         for m, s in enumerate(sigs):
             xs = x[s]
             if xs.dtype != torch.float32 or not xs.is_contiguous():
                 xs = xs.float().contiguous()
-            keep = (~torch.isinf(xs[:, 0])).float()  # wav2sleep.py:150 (plumbing on B scalars)
-            keeps.append(keep)
-            enc_ctx.append(self._encoder_forward(s, xs, keep, tokens.view(-1)[(1 + m) * F:], D * F, save))
+            st = self._side_stream(sp.signal_map[s], dev)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                keep = (~torch.isinf(xs[:, 0])).float()  # wav2sleep.py:150 (plumbing on B scalars)
+                keeps.append(keep)
+                enc_ctx.append(self._encoder_forward(s, xs, keep, tokens.view(-1)[(1 + m) * F:], D * F, save))
+        for s in sigs:
+            main.wait_stream(self._side_stream(sp.signal_map[s], dev))
         keep_BD = torch.stack([torch.ones_like(keeps[0])] + keeps, dim=1)  # [B, D]
         keypad = (keep_BD == 0).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
 
@@ -468,10 +488,16 @@ class Engine:
 
         # ---- encoders
         encs = [ec['enc'] for ec in c['enc']]
+        main = torch.cuda.current_stream(dev)
         for m, ec in enumerate(c['enc']):
-            self._encoder_backward(ec, gX.view(-1)[(1 + m) * F:], D * F)
-            if hook is not None and ec['enc'] not in encs[m + 1:]:
-                hook(ec['enc'])
+            st = self._side_stream(ec['enc'], dev)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self._encoder_backward(ec, gX.view(-1)[(1 + m) * F:], D * F)
+                if hook is not None and ec['enc'] not in encs[m + 1:]:
+                    hook(ec['enc'])
+        for e in dict.fromkeys(encs):
+            main.wait_stream(self._side_stream(e, dev))
 
         if not accumulate:
             for name, g in self.G.items():
