@@ -70,8 +70,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or os.environ.get('W2S_FORCE_COLLECTIVES') == '1':
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     dev = torch.device('cuda', local)
@@ -84,7 +86,7 @@ def main():
     model = W.Wav2Sleep(W.SignalEncoders(SIGNAL_MAP, 128, 'gelu', norm='instance', chunk_causal=False),
                         W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.1, dim_ff=512, nhead=8),
                         W.SequenceCNN(128, dropout=0.1, norm='layer', num_layers=2, kernel_size=7, num_dilations=6), nc).to(dev).train()
-    if world > 1:  # DDP init: broadcast rank 0's parameters
+    if dist.is_initialized():  # DDP init: broadcast rank 0's parameters
         model._ensure_flat()
         dist.broadcast(model._flat, src=0)
     trainer = W.FusedTrainStep(model)
@@ -149,7 +151,7 @@ def main():
         line['cpu_baseline'] = cpu_baseline(args.epochs, nc)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

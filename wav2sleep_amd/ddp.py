@@ -11,6 +11,8 @@ Pure torch.distributed (device-agnostic: the gloo/CPU tests exercise exactly thi
 
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -24,9 +26,11 @@ class FlatGradReducer:
         self.flat = flat_grad
         self.group = group
         self.world = world_size(group)
+        # W2S_FORCE_COLLECTIVES=1: issue the collectives even at world size 1 (exercises the RCCL + side-stream path on one GPU)
+        self.force = os.environ.get('W2S_FORCE_COLLECTIVES') == '1' and dist.is_available() and dist.is_initialized()
         self.handles = []
         self.stream = None
-        if self.world > 1 and flat_grad.is_cuda and side_stream:
+        if (self.world > 1 or self.force) and flat_grad.is_cuda and side_stream:
             self.stream = torch.cuda.Stream(device=flat_grad.device)
 
     @property
@@ -36,7 +40,7 @@ class FlatGradReducer:
 
     def reduce_range(self, lo: int, hi: int):
         """All-reduce flat[lo:hi] (SUM).  Called as soon as that range's gradients are final."""
-        if self.world == 1 or hi <= lo:
+        if (self.world == 1 and not self.force) or hi <= lo:
             return
         chunk = self.flat[lo:hi]
         if self.stream is not None:
@@ -48,7 +52,7 @@ class FlatGradReducer:
 
     def wait(self):
         """Make the compute stream wait for every outstanding range."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.stream is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
@@ -67,7 +71,7 @@ def reduce_metrics(loss_count: torch.Tensor, cmat: torch.Tensor, group=None):
     w = world_size(group)
     loss, count = loss_count[0].double(), loss_count[1].double()
     packed = torch.cat([torch.stack([loss * count, count, loss]), cmat.reshape(-1).double()])
-    if w > 1:
+    if w > 1 or (os.environ.get('W2S_FORCE_COLLECTIVES') == '1' and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     cm = packed[3:].round().long().reshape(nc, nc)
     return packed[0] / packed[1], packed[2] / w, cm

@@ -164,7 +164,7 @@ class FusedTrainStep:
         glogits = torch.empty(rows, nc, device=logits.device, dtype=torch.float32)
         self.cmat.zero_()
         lib.ce_fwd_bwd(logits, yv.contiguous(), rows, nc, part, self.loss_out, glogits, self.cmat, self.reducer.grad_scale)
-        if self.reducer.world > 1:
+        if self.reducer.world > 1 or self.reducer.force:
             eng.backward(glogits, hook=self._on_ready)
             self.reducer.wait()
         else:
