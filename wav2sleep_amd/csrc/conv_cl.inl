@@ -13,6 +13,7 @@
 //       => one coalesced 16-B store per lane, a wave writes whole rows.
 // Reference ops replaced: see include/w2s.h (w2s_conv_args).
 #pragma once
+#include <cstdlib>
 #include "w2s_common.h"
 
 struct ConvP {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   const float* x2b = (pro >= W2S_PRO_INBWD) ? a.x2 + (size_t)b * L_in * a.ldx + myc4 * 4 : nullptr;
 
   auto stage = [&](int rb, int NR, int rowmul) {
-    constexpr int U = 4;
+    constexpr int U = (NT >= 8) ? 8 : 4;  // loads in flight per thread per batch (bigger windows: fewer round trips)
     for (int row = row0; row < NR; row += rstep * U) {
       f32x4 v[U], v2[U];
 #pragma unroll
@@ -254,6 +255,7 @@ static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode
   c.wn = (c.nt >= 4) ? 2 : 1;
   c.mt = 4;
   if ((size_t)window_rows(16 * c.mt * (4 / c.wn), taps, stride, mode) * (cin + 4) * 4 > 72 * 1024) c.mt = 2;
+  { static const char* e = getenv("W2S_FORCE_MT"); if (e && c.nt >= 4) c.mt = atoi(e); }  // tuning only
   // short problems (SequenceCNN: 16 x 960 rows): shrink the tile until the grid covers the 256 CUs about twice
   auto wgs = [&](const TileCfg& t) {
     const long tm = 16 * t.mt * (4 / t.wn);
