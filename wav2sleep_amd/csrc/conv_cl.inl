@@ -48,7 +48,9 @@ __device__ __forceinline__ f32x4 pro_apply(int pro, f32x4 v, f32x4 v2, f32x4 mea
 // NT: n-tiles (16 channels) per workgroup; MT: m-tiles (16 positions) per WAVE; WN: waves along channels (the 4 waves
 // form a (4/WN) x WN grid, so a wave owns 16*MT positions x 16*NT/WN channels and each weight fragment fetched from
 // L2 feeds MT MFMAs: WN = 2 quarters the L2 weight traffic of the 128-channel layers, which was their limiter).
-template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN>
+// PRO / EPI >= 0: the prologue / epilogue mode is a compile-time constant (hot encoder paths: dead variants vanish and
+// the kernel needs ~58 instead of ~84 VGPRs => more resident workgroups => more bytes in flight); -1: runtime switch.
+template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN, int PRO, int EPI>
 __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   const int cin = a.cin, RS = cin + 4, c4n = cin >> 2, rstep = 256 / c4n;
   const int K = TAPS * cin;
   const int L_in = a.L_in, L_out = a.L_out;
-  const int pro = a.pro;
+  const int pro = (PRO >= 0) ? PRO : a.pro;
 
   f32x4 acc[MT][NTW];
 #pragma unroll
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   }
 
   // ------------------------------------ epilogue ------------------------------------
-  const int epi = a.epi;
+  const int epi = (EPI >= 0) ? EPI : a.epi;
   const int cout = a.cout;
   f32x4 sA[NTW], sB[NTW];
 #pragma unroll
@@ -269,7 +271,7 @@ static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode
 }
 static inline int cfg_tm(const TileCfg& c) { return 16 * c.mt * (4 / c.wn); }
 
-template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN>
+template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN, int PRO, int EPI>
 static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
   constexpr int TM = 16 * MT * (4 / WN);
   ConvP P;
@@ -280,7 +282,7 @@ static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
   size_t red = (size_t)4 * (NT / WN) * 4 * 8 * sizeof(float);
   if (lds < red) lds = red;
   dim3 grid(P.ntiles, a.cout / (NT * 16), a.B);
-  auto kern = conv_cl_kernel<NT, MT, TAPS, STRIDE, MODE, WN>;
+  auto kern = conv_cl_kernel<NT, MT, TAPS, STRIDE, MODE, WN, PRO, EPI>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return W2S_ELAUNCH;
@@ -291,12 +293,30 @@ static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
 }
 
 
-template <int TAPS, int STRIDE, int MODE>
-static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
+template <int TAPS, int STRIDE, int MODE, int PRO, int EPI>
+static int dispatch_cfg(const w2s_conv_args& a, hipStream_t s) {
   const TileCfg c = pick_cfg(a.cin, a.cout, TAPS, STRIDE, MODE, a.B, a.L_out);
   if (a.cout % (c.nt * 16)) return W2S_EINVAL;
-#define W2S_CFG(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_>(a, s);
+#define W2S_CFG(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_, PRO, EPI>(a, s);
   W2S_CFG(1, 4, 1) W2S_CFG(2, 4, 1) W2S_CFG(2, 2, 1) W2S_CFG(4, 4, 2) W2S_CFG(4, 2, 2) W2S_CFG(8, 4, 2) W2S_CFG(8, 2, 2) W2S_CFG(1, 2, 1)
 #undef W2S_CFG
   return W2S_EINVAL;
+}
+
+// hot (prologue, epilogue) pairs of the encoder get compile-time specialisations; everything else the runtime-switch kernel
+template <int TAPS, int STRIDE, int MODE>
+static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
+  const bool plain_io = !a.y2 && !a.rowkeep;
+  if (plain_io && MODE == W2S_MODE_CONTIG && TAPS == 3 && STRIDE == 1) {
+    if (a.pro == W2S_PRO_GELU && a.epi == W2S_EPI_STATS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_GELU, W2S_EPI_STATS>(a, s);
+    if (a.pro == W2S_PRO_IN_GELU && a.epi == W2S_EPI_STATS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_IN_GELU, W2S_EPI_STATS>(a, s);
+    if (a.pro == W2S_PRO_INBWD && a.epi == W2S_EPI_GP) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_INBWD, W2S_EPI_GP>(a, s);
+  }
+  if (plain_io && MODE == W2S_MODE_CONTIG && TAPS == 3 && STRIDE == 2 && a.pro == W2S_PRO_IN_GELU && a.epi == W2S_EPI_STATS)
+    return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_IN_GELU, W2S_EPI_STATS>(a, s);
+  if (plain_io && MODE == W2S_MODE_CONTIG && TAPS == 1 && STRIDE == 2 && a.pro == W2S_PRO_GELU && a.epi == W2S_EPI_AUX_INGELU_ADD)
+    return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_GELU, W2S_EPI_AUX_INGELU_ADD>(a, s);
+  if (plain_io && MODE == W2S_MODE_UP2 && a.pro == W2S_PRO_INBWD_GP && a.epi == W2S_EPI_GP)
+    return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_INBWD_GP, W2S_EPI_GP>(a, s);
+  return dispatch_cfg<TAPS, STRIDE, MODE, -1, -1>(a, s);
 }

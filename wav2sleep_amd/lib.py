@@ -172,7 +172,12 @@ def conv_forward(a: ConvArgs):
     if nt == 8 and mt == 2 and a.B * ((a.L_out + tm - 1) // tm) * (a.cout // 128) < 512:
         nt = 4  # short-sequence configuration (pick_cfg in conv_cl.inl)
     # key == the kernel name rocprofv3 reports, so bench.py's average can be checked against profiles/
-    key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}, {wn}>'
+    spec = (-1, -1)
+    if not a.y2 and not a.rowkeep:
+        hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)]}
+        if (a.pro, a.epi) in hot.get((a.mode, a.taps, a.stride), []):
+            spec = (a.pro, a.epi)
+    key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}, {wn}, {spec[0]}, {spec[1]}>'
     if DETAIL:
         key += f' {a.cin}->{a.cout} pro{a.pro} epi{a.epi} L{a.L_out}'
     _timed(key, nbytes, flops, run)
