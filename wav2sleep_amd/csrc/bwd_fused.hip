@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdP P) {
       const int row = grow0 + k * rstep_g, gr = rb + row;
       if (row < NRg) {
         const bool ok = gr >= 0 && gr < Lg;
-        st4(gyL + row * RSg + gch, ok ? pro_apply(P.pro, rg[k], ry[k], pm, pr, ps1, ps2) : (f32x4){0, 0, 0, 0});
+        st4(gyL + row * RSg + gch, ok ? pro_apply(UP2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD, rg[k], ry[k], pm, pr, ps1, ps2) : (f32x4){0, 0, 0, 0});
       }
     }
     f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
@@ -290,6 +290,7 @@ extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, 
   if (!g || !y || !st_k || !bst_k || !xin || !wb || !gout || !slab || nslab <= 0) return W2S_EINVAL;
   if (pro != W2S_PRO_INBWD && pro != W2S_PRO_INBWD_GP) return W2S_EINVAL;
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
+  if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in
   BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int up2 = stride == 2;
