@@ -142,11 +142,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP P) {
 // walks all positions of the staged tile, so GY and H are staged (and GELU'd) once instead of once per output-channel
 // slice (the position-split kernel above re-staged H up to 6x for 128 channels).  One slab per workgroup.
 // ------------------------------------------------------------------------------------------------------------------
-template <int OT, int JT, int CT, int NW, int STRIDE>
+// PG / PH >= 0: gradient-side / input-side transform fixed at compile time (encoder k=3 convs; fewer live registers so two
+// 8-wave workgroups fit a CU), -1: runtime switch.
+template <int OT, int JT, int CT, int NW, int STRIDE, int PG, int PH>
 __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
   const w2s_wgrad_args& a = P.a;
+  const int pro_g = (PG >= 0) ? PG : a.pro_g, pro_h = (PH >= 0) ? PH : a.pro_h;
   constexpr int NT = NW * 64, WG = NW * OT * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -175,14 +178,14 @@ __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
     {  // ---- stage GY tile (channels o0 .. o0+WG-1)
       constexpr int c4n = WG / 4;
       const float* gb = a.g + (size_t)b * a.L_out * a.ldg + o0;
-      const float* g2b = (a.pro_g >= W2S_PRO_INBWD) ? a.g2 + (size_t)b * a.L_out * a.ldg + o0 : nullptr;
+      const float* g2b = (pro_g >= W2S_PRO_INBWD) ? a.g2 + (size_t)b * a.L_out * a.ldg + o0 : nullptr;
       if constexpr (NT % c4n == 0) {
         constexpr int rstep = NT / c4n;
         const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
         f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, ps1 = {0, 0, 0, 0}, ps2 = {0, 0, 0, 0};
-        if (a.pro_g >= W2S_PRO_IN_GELU) {
+        if (pro_g >= W2S_PRO_IN_GELU) {
           load_chan_params(a.g_stats, b, a.cout, o0 + ch, pm, pr);
-          if (a.pro_g >= W2S_PRO_INBWD) load_chan_params(a.g_bstats, b, a.cout, o0 + ch, ps1, ps2);
+          if (pro_g >= W2S_PRO_INBWD) load_chan_params(a.g_bstats, b, a.cout, o0 + ch, ps1, ps2);
         }
         for (int row = row0; row < TM; row += rstep) {
           const int t = t0 + row;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
           if (t < a.L_out) {
             f32x4 x = ld4(gb + (size_t)t * a.ldg + ch);
             f32x4 x2 = g2b ? ld4(g2b + (size_t)t * a.ldg + ch) : (f32x4){0, 0, 0, 0};
-            v = pro4(a.pro_g, x, x2, pm, pr, ps1, ps2);
+            v = pro4(pro_g, x, x2, pm, pr, ps1, ps2);
           }
           st4(gyL + row * RSg + ch, v);
         }
@@ -205,14 +208,14 @@ __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
       const int c4n = cin >> 2, rstep = NT / c4n;
       const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
       f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, z = {0, 0, 0, 0};
-      if (a.pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
+      if (pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
       const float* xb = a.x + (size_t)b * a.L_in * a.ldx + ch;
       const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
       const int rowmul = (JT == 1) ? STRIDE : 1;
       for (int row = row0; row < NRh; row += rstep) {
         const int gr = rb + row * rowmul;
         f32x4 v = {0, 0, 0, 0};
-        if (gr >= 0 && gr < a.L_in) v = pro4(a.pro_h, ld4(xb + (size_t)gr * a.ldx), z, pm, pr, z, z);
+        if (gr >= 0 && gr < a.L_in) v = pro4(pro_h, ld4(xb + (size_t)gr * a.ldx), z, pm, pr, z, z);
         st4(hL + row * RSh + ch, v);
       }
     }
@@ -300,7 +303,7 @@ static inline WgCfg wg_cfg(int cin, int cout, int taps, int dil) {
   return c;
 }
 
-template <int OT, int JT, int CT, int NW, int STRIDE>
+template <int OT, int JT, int CT, int NW, int STRIDE, int PG, int PH>
 static int launch_wgrad_ts(const w2s_wgrad_args& a, hipStream_t s) {
   WgradP P;
   P.a = a;
@@ -318,7 +321,7 @@ static int launch_wgrad_ts(const w2s_wgrad_args& a, hipStream_t s) {
   P.ntg = a.taps / JT;
   dim3 grid(a.nslab, (a.cout / WG) * P.ntg);
   size_t lds = lds_of(TM);
-  auto kern = wgrad_ts_kernel<OT, JT, CT, NW, STRIDE>;
+  auto kern = wgrad_ts_kernel<OT, JT, CT, NW, STRIDE, PG, PH>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -359,11 +362,22 @@ template <int STRIDE>
 static int dispatch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
   const WgCfg c = wg_cfg(a.cin, a.cout, a.taps, a.dil);
   if (c.ts) {
+#define W2S_TS3(CT_, NW_, PG_, PH_) \
+  if (c.ot == 1 && c.tapst == 3 && c.ntc == CT_ && c.nw == NW_ && a.pro_g == PG_ && a.pro_h == PH_) \
+    return launch_wgrad_ts<1, 3, CT_, NW_, STRIDE, PG_, PH_>(a, s);
 #define W2S_TS(OT_, JT_, CT_, NW_) \
-  if (c.ot == OT_ && c.tapst == JT_ && c.ntc == CT_ && c.nw == NW_) return launch_wgrad_ts<OT_, JT_, CT_, NW_, STRIDE>(a, s);
+  if (c.ot == OT_ && c.tapst == JT_ && c.ntc == CT_ && c.nw == NW_) return launch_wgrad_ts<OT_, JT_, CT_, NW_, STRIDE, -1, -1>(a, s);
+    if constexpr (STRIDE == 1) {
+      W2S_TS3(8, 8, W2S_PRO_INBWD, W2S_PRO_IN_GELU) W2S_TS3(4, 4, W2S_PRO_INBWD, W2S_PRO_IN_GELU) W2S_TS3(4, 8, W2S_PRO_INBWD, W2S_PRO_IN_GELU)
+      W2S_TS3(8, 8, W2S_PRO_INBWD, W2S_PRO_GELU) W2S_TS3(4, 4, W2S_PRO_INBWD, W2S_PRO_GELU) W2S_TS3(4, 8, W2S_PRO_INBWD, W2S_PRO_GELU)
+    }
+    if constexpr (STRIDE == 2) {
+      W2S_TS3(8, 8, W2S_PRO_INBWD_GP, W2S_PRO_IN_GELU) W2S_TS3(4, 4, W2S_PRO_INBWD_GP, W2S_PRO_IN_GELU)
+    }
     if constexpr (STRIDE <= 2) { W2S_TS(1, 3, 8, 8) W2S_TS(1, 3, 4, 4) W2S_TS(1, 3, 4, 8) }
     W2S_TS(1, 1, 8, 8) W2S_TS(1, 1, 4, 8) W2S_TS(1, 1, 4, 4) W2S_TS(3, 1, 8, 8) W2S_TS(4, 1, 8, 8) W2S_TS(2, 1, 8, 8) W2S_TS(1, 1, 8, 4)
 #undef W2S_TS
+#undef W2S_TS3
     return W2S_EINVAL;
   }
 #define W2S_WG(NTO_, NTC_, TT_) \

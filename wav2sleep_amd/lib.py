@@ -202,7 +202,11 @@ def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, di
         ot = (cout // 16) // nw
         while ot > 1 and (ot > 32 // (ntc * tapst) or ((cout // 16) // nw) % ot):
             ot -= 1
-        key = f'wgrad_ts_kernel<{ot}, {tapst}, {ntc}, {nw}, {stride}>'
+        spec = (-1, -1)
+        if tapst == 3 and ((stride == 1 and pro_g == PRO_INBWD and pro_h in (PRO_IN_GELU, PRO_GELU)) or
+                           (stride == 2 and pro_g == PRO_INBWD_GP and pro_h == PRO_IN_GELU and not (ntc == 4 and nw == 8))):
+            spec = (pro_g, pro_h)
+        key = f'wgrad_ts_kernel<{ot}, {tapst}, {ntc}, {nw}, {stride}, {spec[0]}, {spec[1]}>'
     else:
         tapst = 3 if (taps == 3 and dil == 1 and ntc <= 4) else 1
         nto = 8
