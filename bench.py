@@ -134,7 +134,12 @@ def main():
         else:
             ach = b_per / avg_s / 1e9
             roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
-        roof.update({'traffic': None, 'kernel': key, 'launches_per_step': d['launches'], 'avg_us': round(avg_s * 1e6, 1),
+        traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+        for fn in sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1:]:
+            t = json.load(open(fn)).get(key)
+            if t and args.batch == 16 and args.epochs == 960:
+                traffic = int(t['hbm_bytes_per_launch'])
+        roof.update({'traffic': traffic, 'kernel': key, 'launches_per_step': d['launches'], 'avg_us': round(avg_s * 1e6, 1),
                      'share_of_gemm_kernel_time': round(d['ms'] / total_ms, 3), 'algorithmic_bytes_per_launch': int(b_per),
                      'flops_per_launch': int(f_per)})
         # whole-step view against the SURVEY 8d convention (3x forward algorithmic bytes, fp32 storage)

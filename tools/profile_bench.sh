@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round profile of the headline benchmark (run on the GPU box):  tools/profile_bench.sh <tag>
+#   1. rocprofv3 --kernel-trace --stats      -> gpurun_out/<tag>_stats/
+#   2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, no trace domains) -> per-kernel HBM traffic
+# Summaries are written to gpurun_out/<tag>_kernel_stats.csv and gpurun_out/<tag>_pmc_traffic.json (copy to profiles/).
+set -e
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- $CMD > gpurun_out/${TAG}_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_fetch -- $CMD > gpurun_out/${TAG}_fetch.log 2>&1 || true
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_write -- $CMD > gpurun_out/${TAG}_write.log 2>&1 || true
+python3 - <<PY
+import csv, glob, json, collections
+tag = '$TAG'
+st = glob.glob(f'gpurun_out/{tag}_stats/**/*kernel_stats.csv', recursive=True)[0]
+open(f'gpurun_out/{tag}_kernel_stats.csv', 'w').write('# rocprofv3 --kernel-trace --stats --output-format csv -- $CMD  (3 train steps, batch 16, MI355X)\n' + open(st).read())
+agg = collections.defaultdict(lambda: {'FETCH_SIZE': [], 'WRITE_SIZE': []})
+for kind in ('fetch', 'write'):
+    for f in glob.glob(f'gpurun_out/{tag}_{kind}/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+out = {}
+for k, d in agg.items():
+    if not d['FETCH_SIZE'] or not d['WRITE_SIZE']:
+        continue
+    fetch = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE']) * 1024 * 2   # KB -> B; gfx950: FETCH_SIZE reports 1/2 of a wide coalesced stream (MI355X_MICROARCH.md, HBM)
+    write = sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE']) * 1024
+    name = k.split('(')[0].replace('void ', '')
+    out[name] = {'launches': len(d['FETCH_SIZE']), 'read_bytes_per_launch': fetch, 'write_bytes_per_launch': write, 'hbm_bytes_per_launch': fetch + write}
+json.dump(out, open(f'gpurun_out/{tag}_pmc_traffic.json', 'w'), indent=1)
+print('kernels with traffic:', len(out))
+PY
+grep metric gpurun_out/${TAG}_stats.log | cut -c1-200
