@@ -174,23 +174,29 @@ extern "C" int w2s_enc_first_bwd(const float* x, const float* gn1, const float* 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void stats_finalize_kernel(const float* __restrict__ part, int ntiles, int C, double inv_count, float eps,
                                                               int kind, float* __restrict__ out) {
+  // grid (B, 4): block y owns channels [y*C/4, (y+1)*C/4); 1024 threads = CQ channels x (1024/CQ) tile lanes
   __shared__ double red[2][1024];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int c = tid % C, rl = tid / C, nrl = 1024 / C;
+  const int CQ = C >> 2, c0 = blockIdx.y * CQ;
+  const int c = tid % CQ, rl = tid / CQ, nrl = 1024 / CQ;
   double s1 = 0.0, s2 = 0.0;
-  if (rl < nrl) {
-    for (int t = rl; t < ntiles; t += nrl) {
-      const float* p = part + (((size_t)b * ntiles + t) * 2) * C;
-      s1 += (double)p[c];
-      s2 += (double)p[C + c];
-    }
+  for (int t = rl; t < ntiles; t += nrl) {
+    const float* p = part + (((size_t)b * ntiles + t) * 2) * C + c0;
+    s1 += (double)p[c];
+    s2 += (double)p[C + c];
   }
   red[0][tid] = s1;
   red[1][tid] = s2;
   __syncthreads();
-  if (tid < C) {
-    double a1 = 0.0, a2 = 0.0;
-    for (int k = 0; k < nrl; ++k) { a1 += red[0][k * C + tid]; a2 += red[1][k * C + tid]; }
+  for (int half = nrl >> 1; half > 0; half >>= 1) {  // fixed-order tree over the tile lanes
+    if (rl < half) {
+      red[0][tid] += red[0][tid + half * CQ];
+      red[1][tid] += red[1][tid + half * CQ];
+    }
+    __syncthreads();
+  }
+  if (tid < CQ) {
+    const double a1 = red[0][tid], a2 = red[1][tid];
     float o0, o1;
     if (kind == 0) {
       const double mean = a1 * inv_count;
@@ -202,14 +208,14 @@ __global__ __launch_bounds__(1024) void stats_finalize_kernel(const float* __res
       o0 = (float)(a1 * inv_count);
       o1 = (float)(a2 * inv_count);
     }
-    out[((size_t)b * C + tid) * 2] = o0;
-    out[((size_t)b * C + tid) * 2 + 1] = o1;
+    out[((size_t)b * C + c0 + tid) * 2] = o0;
+    out[((size_t)b * C + c0 + tid) * 2 + 1] = o1;
   }
 }
 
 extern "C" int w2s_stats_finalize(const float* part, int B, int ntiles, int C, long count, float eps, int kind, float* out, void* stream) {
-  if (!part || !out || C <= 0 || C > 256 || (256 % C) || count <= 0) return W2S_EINVAL;
-  hipLaunchKernelGGL(stats_finalize_kernel, dim3(B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), part, ntiles, C,
+  if (!part || !out || C < 16 || C > 256 || (C & (C - 1)) || count <= 0) return W2S_EINVAL;
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3(B, 4), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), part, ntiles, C,
                      1.0 / (double)count, eps, kind, out);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
