@@ -223,3 +223,29 @@ def test_load_model_and_predict_roundtrip(tmp_path):
     cm = W.trainer.confusion_matrix_from_logits(model(to_dev(x)), y.to(DEV), 4).cpu()
     assert torch.equal(cm, O.confusion_matrix(want, y, 4))
     assert W.cohens_kappa(cm.numpy(), 4) == pytest.approx(O.cohens_kappa(cm.numpy(), 4))
+
+
+@pytest.mark.parametrize('name', ['c2_four_mod', 'c4_eog_pair', 'c5_shared_enc'])
+def test_submodule_forwards_match_reference_goldens(name):
+    """SignalEncoders / MultiModalAttentionEmbedder / SequenceCNN called on their own, like the reference modules
+    (wav2sleep.py:146-161, 301-346, 379-390), against the per-stage outputs recorded from the reference."""
+    signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
+    g = load(name)
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc)
+    model = build(signal_map, nc)
+    model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
+    model.to(DEV).eval()
+    x, _ = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
+    z = model.signal_encoders(to_dev(x))
+    assert list(z) == list(x)
+    for s in signal_map:
+        got, want = z[s].cpu().numpy(), g[f'z.{s}']
+        assert np.array_equal(np.isinf(got), np.isinf(want))
+        fin = np.isfinite(want)
+        np.testing.assert_allclose(got[fin], want[fin], rtol=1e-3, atol=1e-4)
+    mixed = model.epoch_mixer(z)
+    np.testing.assert_allclose(mixed.cpu().numpy(), g['mixer'], rtol=1e-3, atol=1e-4)
+    seq = model.sequence_mixer(mixed)
+    np.testing.assert_allclose(seq.cpu().numpy(), g['seq'], rtol=1e-3, atol=1e-4)
+    with pytest.raises(ValueError):
+        model.epoch_mixer({})

@@ -113,6 +113,8 @@ class Engine:
     def pack(self, need_bwd: bool = True):
         """torch-layout weights -> kernel layouts ([cout][taps][cin] forward, [cin][taps][cout] data-gradient)."""
         for name, cout, cin, taps, nf, nb in self._pack_list():
+            if name not in self.P:  # stand-alone sub-module engines hold only their own parameters
+                continue
             w = self.P[name]
             if nf and name not in self.PF:
                 self.PF[name] = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
@@ -270,7 +272,10 @@ class Engine:
         return dict(sig=sig, enc=enc, x=x, keep=keep, blocks=blocks, plast=pin, zpre=zpre, S=S, B=B) if save else None
 
     # ------------------------------------------------------------------ full forward
-    def forward(self, x: dict[str, torch.Tensor], train: bool = False, save: bool = False, pack_key=None) -> torch.Tensor:
+    def encode(self, x: dict[str, torch.Tensor], save: bool = False, pack_key=None, cls: bool = True):
+        """SignalEncoders.forward (models/wav2sleep.py:146-161) + token assembly (:319-330): returns the set-fusion input
+        tokens [N, D, F] (token 0 = CLS, tokens 1.. = modalities in sorted order, zero rows for missing ones), the per-signal
+        keep masks [B] and, if `save`, what backward needs."""
         sp, P = self.spec, self.P
         if len(x) == 0:
             raise ValueError('No signals provided to MultiModalAttentionEmbedder.')
@@ -290,11 +295,10 @@ class Engine:
         B = first.shape[0]
         S = first.shape[1] // COLS_TO_SAMPLES_PER_EPOCH[sigs[0]]
         F, D, N = sp.feature_dim, len(sigs) + 1, B * S
-        pm = sp.mixer_dropout if train else 0.0
-        ps = sp.seq_dropout if train else 0.0
 
         tokens = torch.empty(N, D, F, device=dev, dtype=torch.float32)
-        lib.fill_rows(tokens, D * F, P['epoch_mixer.register_tokens'], N, F)
+        if cls:
+            lib.fill_rows(tokens, D * F, P['epoch_mixer.register_tokens'], N, F)
         keeps, enc_ctx = [], []
         # The encoders are independent until the set-fusion transformer: each runs on its own HIP stream, so the
         # matrix-core-bound 64/128-channel layers of one modality overlap the bandwidth-bound 16/32-channel layers of
@@ -315,6 +319,14 @@ class Engine:
         keep_BD = torch.stack([torch.ones_like(keeps[0])] + keeps, dim=1)  # [B, D]
         keypad = (keep_BD == 0).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
 
+        return dict(tokens=tokens, keeps=keeps, keypad=keypad, enc=enc_ctx, sigs=sigs, B=B, S=S, D=D, N=N)
+
+    def mix(self, tokens: torch.Tensor, keypad: torch.Tensor, pm: float = 0.0, save: bool = False):
+        """MultiModalAttentionEmbedder's transformer (models/wav2sleep.py:341-345) on tokens [N, D, F]; returns the final
+        token tensor [N*D, F] (row n*D is the CLS output) and the per-layer tensors backward needs."""
+        sp, P = self.spec, self.P
+        N, D, F = tokens.shape
+        dev = tokens.device
         # ---- set-fusion transformer (nn.TransformerEncoderLayer norm_first, wav2sleep.py:286-296)
         R = N * D
         X = tokens.view(R, F)
@@ -344,10 +356,16 @@ class Engine:
                 layers.append(dict(X=X, rs1=rs1, h=h, qkv=qkv, ao=ao, X1=X1, rs2=rs2, h2=h2, f1=f1, a1=a1))
             X = X2
 
-        if self.taps is not None:
-            self.taps['tokens'] = tokens
-            self.taps['mixer'] = X.view(N, D * F)[:, :F].reshape(B, S, F)
-        # ---- SequenceCNN over the CLS rows (row n*D of X; ld = D*F) -- wav2sleep.py:345, 379-390
+        return X, layers
+
+    def seq(self, xin: torch.Tensor, ldin: int, B: int, S: int, ps: float = 0.0, save: bool = False):
+        """SequenceCNN.forward (models/wav2sleep.py:379-390) on rows [B*S] of `xin` (row stride ldin); returns the last block's
+        PRE-activation output [B, S, F] (the module output is GELU of it) and the saved tensors."""
+        sp, P = self.spec, self.P
+        F = sp.feature_dim
+        N, D = B * S, ldin // F
+        dev = xin.device
+        X = xin
         xin, ldin = X, D * F
         seq = []
         pre_out = None
@@ -380,12 +398,27 @@ class Engine:
                 lib.eltwise(lib.ELT_GELU, pre_out, None, act, B * S * F)
                 xin, ldin = act, F
 
+        return pre_out, seq
+
+    def forward(self, x: dict[str, torch.Tensor], train: bool = False, save: bool = False, pack_key=None) -> torch.Tensor:
+        sp, P = self.spec, self.P
+        F = sp.feature_dim
+        pm = sp.mixer_dropout if train else 0.0
+        ps = sp.seq_dropout if train else 0.0
+        e = self.encode(x, save=save, pack_key=pack_key)
+        tokens, keypad, B, S, D, N = e['tokens'], e['keypad'], e['B'], e['S'], e['D'], e['N']
+        dev = tokens.device
+        X, layers = self.mix(tokens, keypad, pm, save)
+        if self.taps is not None:
+            self.taps['tokens'] = tokens
+            self.taps['mixer'] = X.view(N, D * F)[:, :F].reshape(B, S, F)
+        pre_out, seq = self.seq(X, D * F, B, S, ps, save)
         if self.taps is not None:
             self.taps['seq_pre'] = pre_out
         logits = torch.empty(B, S, sp.num_classes, device=dev, dtype=torch.float32)
         lib.head_fwd(pre_out, F, P['classifier.weight'], P['classifier.bias'], logits, B * S, F, sp.num_classes, True)
         if save:
-            self.ctx = dict(B=B, S=S, D=D, N=N, sigs=sigs, enc=enc_ctx, keypad=keypad, layers=layers, seq=seq, pre_out=pre_out, pm=pm,
+            self.ctx = dict(B=B, S=S, D=D, N=N, sigs=e['sigs'], enc=e['enc'], keypad=keypad, layers=layers, seq=seq, pre_out=pre_out, pm=pm,
                             ps=ps, tokens=tokens)
         return logits
 

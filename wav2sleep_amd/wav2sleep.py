@@ -34,6 +34,22 @@ def _check_activation(name: str):
         raise NotImplementedError(f"activation '{name}' has no gfx950 kernel yet (production config uses 'gelu')")
 
 
+def _standalone_engine(module: nn.Module, prefix: str, spec: EngineSpec) -> Engine:
+    """Engine over ONE sub-module's own parameters (inference only: the fused autograd path lives in Wav2Sleep)."""
+    params = {prefix + k: p.detach() for k, p in module.named_parameters()}
+    for k, p in params.items():
+        if p.device.type != 'cuda':
+            from .lib import W2SError
+            raise W2SError('wav2sleep_amd runs on MI355X only: move the module to a cuda device (there is no CPU fallback)')
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            raise ValueError(f'{k}: fp32 contiguous parameters required')
+    key = tuple((p.data_ptr(), p._version) for p in module.parameters())
+    cached = getattr(module, '_w2s_engine', None)
+    if cached is None or cached[0] != tuple(k[0] for k in key):
+        module._w2s_engine = (tuple(k[0] for k in key), Engine(spec, params, None))
+    return module._w2s_engine[1], hash(key)
+
+
 class ConvLayerNorm(nn.Module):
     """models/utils.py:9-23 (weights [1, C, 1])."""
 
@@ -161,8 +177,20 @@ class SignalEncoders(nn.Module):
     def get_encoder(self, signal_name: str) -> SignalEncoder:
         return self.encoders[self.signal_map[signal_name]]  # type: ignore
 
-    def forward(self, *a, **k):
-        raise NotImplementedError(_NO_FORWARD.format('SignalEncoders'))
+    @torch.no_grad()
+    def forward(self, x: dict[str, Tensor]) -> dict[str, Tensor]:
+        """models/wav2sleep.py:146-161, inference only (training goes through Wav2Sleep.forward, one fused autograd node):
+        dict signal -> [B, T]  ->  dict signal -> [B, S, feature_dim]; samples whose input row is -inf come back as -inf."""
+        spec = EngineSpec(signal_map=dict(self.signal_map), feature_dim=self.feature_dim, initial_channels=self.initial_channels,
+                          max_channels=self.max_channels)
+        eng, ver = _standalone_engine(self, 'signal_encoders.', spec)
+        e = eng.encode(x, save=False, pack_key=ver, cls=False)
+        B, S, F = e['B'], e['S'], self.feature_dim
+        out = {}
+        for m, sig in enumerate(e['sigs']):
+            z = e['tokens'][:, 1 + m, :].reshape(B, S, F).clone()
+            out[sig] = torch.where(e['keeps'][m][:, None, None] == 0, float('-inf'), z)
+        return {k: out[k] for k in x}
 
 
 class MultiModalAttentionEmbedder(nn.Module):
@@ -188,8 +216,32 @@ class MultiModalAttentionEmbedder(nn.Module):
         self.num_register_tokens = register_tokens
         self.register_tokens = nn.Parameter(torch.randn(1, 1, feature_dim, register_tokens + 1))
 
-    def forward(self, *a, **k):
-        raise NotImplementedError(_NO_FORWARD.format('MultiModalAttentionEmbedder'))
+    @torch.no_grad()
+    def forward(self, z_dict: dict[str, Tensor]) -> Tensor:
+        """models/wav2sleep.py:301-346, inference only: dict signal -> [B, S, F] (-inf rows = missing) -> CLS features [B, S, F]."""
+        signals = sorted(z_dict.keys())
+        if len(signals) == 0:
+            raise ValueError('No signals provided to MultiModalAttentionEmbedder.')
+        first = z_dict[signals[0]]
+        B, S, F = first.shape
+        if F != self.feature_dim:
+            raise ValueError(f'Feature dimension {F} does not match {self.feature_dim=}.')
+        spec = EngineSpec(signal_map={'ECG': 'ECG'}, feature_dim=self.feature_dim, mixer_layers=self.num_layers, mixer_nhead=self.nhead,
+                          mixer_dim_ff=self.dim_ff, mixer_dropout=self.dropout_p)
+        eng, ver = _standalone_engine(self, 'epoch_mixer.', spec)
+        from . import lib
+        N, D = B * S, len(signals) + 1
+        tokens = torch.empty(N, D, F, device=first.device, dtype=torch.float32)
+        lib.fill_rows(tokens, D * F, eng.P['epoch_mixer.register_tokens'], N, F)
+        pads = [torch.zeros(B, dtype=torch.bool, device=first.device)]
+        for m, sig in enumerate(signals):  # host-side plumbing of [B,S,F] tensors: mask detection, zero fill, token slot copy
+            z = z_dict[sig].float()
+            m_B = torch.isinf(z).any(dim=2).any(dim=1)
+            tokens[:, 1 + m, :] = torch.where(m_B[:, None, None], 0.0, z).reshape(N, F)
+            pads.append(m_B)
+        keypad = torch.stack(pads, dim=1).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
+        X, _ = eng.mix(tokens, keypad, self.dropout_p if self.training else 0.0, save=False)
+        return X.view(N, D * F)[:, :F].reshape(B, S, F).clone()
 
 
 class SequenceCNN(nn.Module):
@@ -208,8 +260,19 @@ class SequenceCNN(nn.Module):
         self.dilated_convs = nn.Sequential(*[DilatedConvBlock(feature_dim=feature_dim, dropout=dropout, norm=norm, kernel_size=kernel_size,
                                                               num_dilations=num_dilations) for _ in range(num_layers)])
 
-    def forward(self, *a, **k):
-        raise NotImplementedError(_NO_FORWARD.format('SequenceCNN'))
+    @torch.no_grad()
+    def forward(self, x_BSF: Tensor) -> Tensor:
+        """models/wav2sleep.py:379-390, inference only: [B, S, F] -> [B, S, F]."""
+        B, S, F = x_BSF.shape
+        spec = EngineSpec(signal_map={'ECG': 'ECG'}, feature_dim=F, seq_blocks=self.num_layers, seq_dilations=self.num_dilations,
+                          seq_kernel=self.kernel_size, seq_dropout=self.dropout_p)
+        eng, ver = _standalone_engine(self, 'sequence_mixer.', spec)
+        from . import lib
+        eng.ensure_packed(ver, need_bwd=False)
+        pre, _ = eng.seq(x_BSF.float().contiguous(), F, B, S, self.dropout_p if self.training else 0.0, save=False)
+        out = torch.empty_like(pre)
+        lib.eltwise(lib.ELT_GELU, pre, None, out, pre.numel())
+        return out
 
 
 class _W2SFunction(torch.autograd.Function):
