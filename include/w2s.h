@@ -176,6 +176,14 @@ int w2s_sumsq_partial(const float* g, long n, float* part, int nparts, void* str
 int w2s_clip_coef(const float* part, int nparts, const float* hyper, float* normcoef, void* stream);
 int w2s_adamw(float* p, const float* g, float* m, float* v, long n, const float* hyper, const float* normcoef, void* stream);
 
+/* ---- device-side input pipeline (data/dataset.py:76-87,174-182, trainer/main.py:342-353, masker.py:49-50) ----
+ * w2s_zscore: y[row] = (x[row]-mean)/max(std_unbiased, eps) per row of T samples (rows with a non-finite value are copied);
+ *   part: rows*nblk*3 doubles of scratch; stats_out (optional): [rows][2] = mean, std used.
+ * w2s_augment: in place x[b,:] = keep[b] ? x[b,:]*sign[b] : -inf.   w2s_map_labels: AASM stages 0..4 -> 4/5 classes, else -1. */
+int w2s_zscore(const float* x, float* y, int rows, long T, double* part, int nblk, float eps, float* stats_out, void* stream);
+int w2s_augment(float* x, int B, long T, const float* sign, const uint8_t* keep, void* stream);
+int w2s_map_labels(const float* src, float* dst, long n, int num_classes, void* stream);
+
 const char* w2s_version(void);
 
 #ifdef __cplusplus

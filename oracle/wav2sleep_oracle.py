@@ -399,6 +399,26 @@ def train_step(sd: dict, cfg: ModelConfig, x: dict, y: Tensor, opt_state: dict, 
     return loss, logits, gn, lr
 
 
+def zscore_normalize(x_T: Tensor, eps: float = 1e-6) -> Tensor:
+    """ParquetDataset._zscore_normalize for one recording -- data/dataset.py:76-87.
+    PARITY UNPINNED: data/dataset.py cannot be imported here (it pulls numba); restated from the source text."""
+    if x_T.numel() == 0 or not torch.isfinite(x_T).all():
+        return x_T
+    mu = torch.mean(x_T)
+    std = torch.std(x_T)
+    std = std if std > eps else torch.tensor(eps, dtype=x_T.dtype)
+    return (x_T - mu) / std
+
+
+def map_labels(stages: Tensor, num_classes: int) -> Tensor:
+    """df[LABEL].map(INTEGER_LABEL_MAPS[nc]).fillna(-1) -- data/dataset.py:174-182, settings.py:52-56."""
+    m = INTEGER_LABEL_MAPS[num_classes]
+    out = torch.full_like(stages, -1.0)
+    for k, v in m.items():
+        out[stages == k] = float(v)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # Augmentations (explicit-draw restatements; the reference samples with torch RNG on device)
 # ----------------------------------------------------------------------------------------------

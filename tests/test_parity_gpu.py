@@ -249,3 +249,63 @@ def test_submodule_forwards_match_reference_goldens(name):
     np.testing.assert_allclose(seq.cpu().numpy(), g['seq'], rtol=1e-3, atol=1e-4)
     with pytest.raises(ValueError):
         model.epoch_mixer({})
+
+
+def test_full_size_eog_variant_matches_oracle():
+    """BASELINE configs[3] shapes: EOG-L + EOG-R, 8 h @ 4096 samples/epoch (T = 3 932 160), 5 classes -- one recording
+    forward against the CPU oracle (the longest sequences and deepest encoders: 10 blocks), then a batch-2 train step."""
+    signal_map = {'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=5)
+    sd = O.make_state_dict(cfg, seed=31)
+    x, y = O.make_inputs(cfg, 1, 960, seed=32)
+    model = build(signal_map, 5)
+    model.load_state_dict(sd)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        got = model(to_dev(x)).cpu()
+        want = O.forward(sd, cfg, x)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-3, atol=2e-4)
+    assert float((got.argmax(-1) == want.argmax(-1)).float().mean()) == 1.0
+    model.train()
+    tr = W.FusedTrainStep(model)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    xb = {s: torch.randn(2, 960 * 4096, device=DEV, generator=g) for s in signal_map}
+    yb = torch.randint(0, 5, (2, 960), device=DEV, generator=g).float()
+    out = tr.step(xb, yb)
+    assert torch.isfinite(out['loss']) and torch.isfinite(out['grad_norm']) and torch.isfinite(model._flat).all()
+
+
+def test_device_input_pipeline_matches_oracle():
+    """z-score, -inf passthrough, label map and augmentation kernels vs the oracle restatement."""
+    from wav2sleep_amd import inputs
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 120 * 1024, generator=g) * 37.5 + 12.0
+    x[1] = float('-inf')                      # missing modality: passes through
+    x[2] = 3.25                               # constant row: std clamps to eps
+    x[3, :1000] += 500.0
+    got = inputs.zscore_normalize({'ECG': x.to(DEV)})['ECG'].cpu()
+    for r in range(5):
+        want = O.zscore_normalize(x[r])
+        if torch.isfinite(want).all():
+            np.testing.assert_allclose(got[r].numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+        else:
+            assert torch.equal(got[r], want)
+    st = torch.tensor([0, 1, 2, 3, 4, float('nan'), 2, 0, -1, 7]).float()
+    for nc in (4, 5):
+        want = O.map_labels(torch.nan_to_num(st, nan=-5.0), nc)
+        assert torch.equal(inputs.map_labels(st.to(DEV), nc).cpu(), want)
+    padded = inputs.pad_missing({'ECG': x[:, :8192].to(DEV)}, ['ABD', 'ECG'], epochs=8, batch=5, device=DEV)
+    assert list(padded) == ['ABD', 'ECG'] and torch.isinf(padded['ABD']).all() and padded['ABD'].shape == (5, 2048)
+    torch.manual_seed(1)
+    sig = {s: torch.randn(64, 4096, device=DEV) for s in SM4}
+    sig['ECG'][:8] = float('-inf')
+    before = {k: v.clone() for k, v in sig.items()}
+    inputs.augment_(sig, flip_polarity=True, masker=W.SignalMasker({'ABD': 0.7, 'THX': 0.7, 'ECG': 0.5, 'PPG': 0.1}, backups=['ECG', 'PPG']))
+    kept = torch.stack([~torch.isinf(v[:, 0]) for v in sig.values()], -1)
+    avail = torch.stack([~torch.isinf(v[:, 0]) for v in before.values()], -1)
+    assert kept.any(-1).all() and not (kept & ~avail).any() and (~kept & avail).any()
+    for k in sig:
+        m = ~torch.isinf(sig[k][:, 0])
+        ratio = sig[k][m] / before[k][m]
+        assert torch.all(((ratio - 1).abs() < 1e-6) | ((ratio + 1).abs() < 1e-6))
+        assert torch.isinf(sig[k][~m]).all()

@@ -1,6 +1,6 @@
 """wav2sleep hot path (train step / inference forward) on AMD Instinct MI355X -- hand-written HIP kernels
 (wav2sleep_amd/csrc -> libw2s_hip.so, C ABI in include/w2s.h) behind the reference's own module surface."""
-from . import settings, trainer  # noqa: F401
+from . import inputs, settings, trainer  # noqa: F401
 from .api import load_model, predict  # noqa: F401
 from .stats import cohens_kappa, confusion_accuracy  # noqa: F401
 from .trainer import (ExpWarmUpScheduler, FusedTrainStep, SignalMasker, SleepLightningModule, SleepModule,  # noqa: F401

@@ -42,7 +42,7 @@ EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y',
            'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
-           'w2s_clip_coef', 'w2s_adamw', 'w2s_version']
+           'w2s_clip_coef', 'w2s_adamw', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_version']
 
 _lib = None
 
@@ -337,6 +337,19 @@ def clip_coef(part, nparts, hyper, normcoef):
 
 def adamw(p, g, m, v, n, hyper, normcoef):
     _chk(load().w2s_adamw(_f(p), _f(g), _f(m), _f(v), C.c_long(n), _f(hyper), _f(normcoef), _stream()), 'w2s_adamw')
+
+
+def zscore(x, y, rows, T, part, nblk, eps, stats_out=None):
+    assert part.dtype == torch.float64
+    _chk(load().w2s_zscore(_f(x), _f(y), rows, C.c_long(T), _p(part), nblk, C.c_float(eps), _f(stats_out), _stream()), 'w2s_zscore')
+
+
+def augment(x, B, T, sign, keep):
+    _chk(load().w2s_augment(_f(x), B, C.c_long(T), _f(sign), _p(keep), _stream()), 'w2s_augment')
+
+
+def map_labels(src, dst, n, num_classes):
+    _chk(load().w2s_map_labels(_f(src), _f(dst), C.c_long(n), num_classes, _stream()), 'w2s_map_labels')
 
 
 def version() -> str:

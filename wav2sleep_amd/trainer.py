@@ -217,11 +217,9 @@ class SleepModule:
 
     def on_after_batch_transfer(self, batch, training: bool = True):
         x, y = batch
-        if training:
-            if self.flip_polarity:
-                invert_signals(x)
-            if self.unified and self.masker is not None:
-                self.masker(x)
+        if training:  # one fused pass per signal (csrc/input_pipe.hip) instead of torch indexing; same sampling rule
+            from .inputs import augment_
+            augment_(x, flip_polarity=self.flip_polarity, masker=self.masker if self.unified else None)
         return x, y
 
     def training_step(self, batch, ds_name: str = 'all'):
