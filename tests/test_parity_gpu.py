@@ -309,3 +309,23 @@ def test_device_input_pipeline_matches_oracle():
         ratio = sig[k][m] / before[k][m]
         assert torch.all(((ratio - 1).abs() < 1e-6) | ((ratio + 1).abs() < 1e-6))
         assert torch.isinf(sig[k][~m]).all()
+
+
+def test_subset_evaluation_reuses_encoders_exactly():
+    """forward_subsets == separate model({subset}) calls (trainer/main.py:188-224 semantics), bit for bit."""
+    cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
+    model = build(SM4, 4)
+    model.load_state_dict(O.make_state_dict(cfg, seed=13))
+    model.to(DEV).eval()
+    x, y = O.make_inputs(cfg, 3, 6, seed=14, missing={'THX': [1]})
+    xd = to_dev(x)
+    subs = [None, ('ECG',), ('ECG', 'THX'), ('PPG',), ('PPG', 'THX')]
+    got = model.forward_subsets(xd, subs)
+    with torch.no_grad():
+        for sub in subs:
+            want = model(xd if sub is None else {k: xd[k] for k in sub})
+            assert torch.equal(got[sub], want), sub
+    mod = W.SleepModule(model, num_classes=4)
+    losses = mod.validation_step((xd, y.to(DEV)), ds_name='mesa')
+    assert set(losses) == set(subs) and all(torch.isfinite(v) for v in losses.values())
+    assert int(mod.aux_outputs['val']['ECG_THX']['mesa'].sum()) == int((y != -1).sum())

@@ -249,6 +249,37 @@ class SleepModule:
         return out[0]
 
     @torch.no_grad()
+    def validation_step(self, batch, ds_name: str = 'all', mode: str = 'val', combined: bool = False):
+        """trainer/main.py:188-224: all-signal evaluation plus the ECG / ECG+THX / PPG / PPG+THX subset evaluations the
+        reference runs per dataset -- here from ONE pass over the encoders (Wav2Sleep.forward_subsets)."""
+        x, y = batch
+        self.model.eval()
+        subsets = [None]
+        valid = self.model.valid_signals
+        if self.unified and not combined:
+            if 'ECG' in x and 'ECG' in valid:
+                subsets.append(('ECG',))
+                if 'THX' in x and 'THX' in valid and (mode == 'test' or ds_name in ('shhs', 'mesa')):
+                    subsets.append(('ECG', 'THX'))
+            if 'PPG' in x and 'PPG' in valid and ds_name in ('mesa', 'cfs', 'ccshs', 'chat'):
+                subsets.append(('PPG',))
+                if 'THX' in x and 'THX' in valid and ds_name in ('mesa',):
+                    subsets.append(('PPG', 'THX'))
+        logits = self.model.forward_subsets(x, subsets)
+        losses = {}
+        for sub, lg in logits.items():
+            rows = lg.shape[0] * lg.shape[1]
+            part = torch.empty((rows + 255) // 256, 2, device=lg.device, dtype=torch.float32)
+            out = torch.zeros(2, device=lg.device, dtype=torch.float32)
+            cm = torch.zeros(self.num_classes, self.num_classes, device=lg.device, dtype=torch.int64)
+            lib.ce_fwd_bwd(lg, y.reshape(rows).float().contiguous(), rows, self.num_classes, part, out, None, cm, 1.0)
+            _, _, cm = reduce_metrics(out, cm, self.trainer.reducer.group)
+            prefix = '_'.join(sub) if sub is not None else (None if self.unified else '_'.join(x.keys()))
+            self.aux_outputs[mode][prefix][ds_name] += cm
+            losses[sub] = out[0]
+        return losses
+
+    @torch.no_grad()
     def predict_step(self, batch):
         """trainer/main.py:226-240: predictions from ECG, ECG+THX and all modalities."""
         x, y = batch

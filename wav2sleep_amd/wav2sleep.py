@@ -3,8 +3,9 @@
 Same class names, constructor arguments, attribute names and `state_dict` keys/shapes as the reference, so
 `load_model()` / Hydra `_target_` configs / reference checkpoints are drop-in.  The sub-modules below are
 PARAMETER CONTAINERS built from the same torch.nn classes the reference uses (identical default init under
-the same seed); none of their `forward`s run.  `Wav2Sleep.forward` hands the whole computation to the HIP
-engine (wav2sleep_amd/engine.py -> libw2s_hip.so) and plugs into autograd as ONE node.
+the same seed); torch's own forwards never run.  `Wav2Sleep.forward` hands the whole computation to the HIP
+engine (wav2sleep_amd/engine.py -> libw2s_hip.so) and plugs into autograd as ONE node; `SignalEncoders`,
+`MultiModalAttentionEmbedder` and `SequenceCNN` can also be called on their own (inference, same kernels).
 
 There is no CPU path: CPU tensors raise (lib.W2SError).
 """
@@ -333,6 +334,38 @@ class Wav2Sleep(nn.Module):
 
     def predict(self, x: dict[str, Tensor]) -> Tensor:
         return self(x).argmax(axis=2)
+
+    @torch.no_grad()
+    def forward_subsets(self, x: dict[str, Tensor], subsets) -> dict:
+        """Logits for several signal subsets of ONE batch with every encoder run once (inference).
+
+        The reference's validation / test / predict steps re-run the whole model per subset (trainer/main.py:188-240:
+        all signals, ECG, ECG+THX, PPG, PPG+THX); the encoders are >95 % of the forward, and a subset only changes which
+        tokens enter the set-fusion transformer, so the encoder outputs are computed once and re-used.
+        subsets: iterable of tuples of signal names (None = all signals of `x`).  -> {subset: logits [B, S, nc]}"""
+        from . import lib
+        self._ensure_flat()
+        eng = self._engine
+        e = eng.encode(x, save=False, pack_key=self.param_version())
+        tokens, B, S, F = e['tokens'], e['B'], e['S'], self.feature_dim
+        N, sigs = B * S, e['sigs']
+        out = {}
+        for sub in subsets:
+            names = sorted(sub) if sub is not None else sigs
+            for n in names:
+                if n not in sigs:
+                    raise ValueError(f'signal {n} is not in the batch')
+            cols = [0] + [1 + sigs.index(n) for n in names]
+            D = len(cols)
+            tok = tokens[:, cols, :].contiguous()  # [N, D, F] token gather (host-side plumbing on the small tensor)
+            keep = torch.stack([torch.ones(B, device=tok.device)] + [e['keeps'][sigs.index(n)] for n in names], dim=1)
+            keypad = (keep == 0).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
+            X, _ = eng.mix(tok, keypad, 0.0, save=False)
+            pre, _ = eng.seq(X, D * F, B, S, 0.0, save=False)
+            logits = torch.empty(B, S, self.num_classes, device=tok.device, dtype=torch.float32)
+            lib.head_fwd(pre, F, eng.P['classifier.weight'], eng.P['classifier.bias'], logits, N, F, self.num_classes, True)
+            out[tuple(sub) if sub is not None else None] = logits
+        return out
 
     # ---------------------------------------------------------------- engine plumbing
     def spec(self) -> EngineSpec:
