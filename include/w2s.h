@@ -69,6 +69,8 @@ typedef struct w2s_conv_args {
   const float* bias;       /* [cout] */
   const float* rowkeep;    /* [B] multiplier on the stored value (0 for a missing modality) or NULL */
   float* part;             /* EPI_STATS / EPI_GP: [B][ntiles][2][cout] partial sums, or NULL */
+  const void* w_hi;        /* optional bf16 planes of w (w = hi + lo, layout as w; see w2s_repack_bf16): enables the split-  */
+  const void* w_lo;        /* precision matrix-core path for cin >= 32 and cout >= 64; NULL = exact fp32 MFMA               */
   int32_t B, L_in, L_out, cin, cout, taps, stride, dil, pad, flip, mode;
   int32_t ldx, ldy, ldy2, ld_aux;
   int32_t pro, epi;
@@ -103,6 +105,8 @@ int w2s_wgrad_reduce(const float* slab, int nslab, float* grad, int cout, int ci
 
 /* [cout][cin][taps] (torch) -> fwd pack [cout][taps][cin] and/or bwd pack [cin][taps][cout]; either dst may be NULL */
 int w2s_repack(const float* w, float* fwd, float* bwd, int cout, int cin, int taps, void* stream);
+/* same layouts as bf16 (hi, lo) planes with w = hi + lo: operands of the split-precision ("bf16x3") path; planes may be NULL in pairs */
+int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, void* bwd_lo, int cout, int cin, int taps, void* stream);
 
 /*
  * Fused backward of one encoder ConvLayer1D (k=3, pad=1, stride 1 or 2) for the bandwidth-bound <=32-channel layers:

@@ -61,6 +61,30 @@ def t_conv_stats_pro():
     report('stats mean', out[..., 0], want.mean(2))
     report('stats rstd', out[..., 1], 1 / torch.sqrt(want.var(2, unbiased=False) + 1e-2))
 
+def t_conv_split_precision():
+    """bf16x3 matrix-core path (w = hi + lo planes): same contract as fp32, error <= ~2^-16 per product."""
+    B = 2
+    for (cin, cout, taps, stride, L, mode, dil) in [(64, 64, 3, 1, 300, 0, 1), (32, 64, 3, 1, 300, 0, 1), (128, 128, 3, 2, 256, 0, 1), (128, 384, 1, 1, 333, 0, 1),
+                                                   (128, 128, 7, 1, 200, 1, 4), (64, 128, 1, 2, 256, 0, 1)]:
+        pad = (taps // 2) * dil
+        x = torch.randn(B, cin, L); w = torch.randn(cout, cin, taps) / math.sqrt(cin * taps)
+        want = F.conv1d(x.double(), w.double(), stride=stride, padding=pad, dilation=dil).float()
+        Lo = want.shape[-1]
+        wp = pack_fwd(w).to(dev); wh = wp.bfloat16(); wl = (wp - wh.float()).bfloat16()
+        y = torch.zeros(B, Lo, cout, device=dev)
+        lib.conv_forward(lib.conv_args(x=cl(x).to(dev), w=wp, w_hi=wh, w_lo=wl, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
+                                       pad=pad, dil=dil, mode=mode))
+        report(f'bf16x3 conv {cin}->{cout} k{taps} s{stride} d{dil}', y, cl(want), tol=5e-5)
+    # data gradient through the transposed stride-2 mode
+    cin, cout, L = 128, 128, 256
+    x = torch.randn(B, cin, L, requires_grad=True); w = torch.randn(cout, cin, 3) / 20
+    yv = F.conv1d(x, w, stride=2, padding=1); gy = torch.randn_like(yv); yv.backward(gy)
+    wb = w.permute(1, 2, 0).contiguous().to(dev); wh = wb.bfloat16(); wl = (wb - wh.float()).bfloat16()
+    gx = torch.zeros(B, L, cin, device=dev)
+    lib.conv_forward(lib.conv_args(x=cl(gy).to(dev), w=wb, w_hi=wh, w_lo=wl, y=gx, B=B, L_in=L // 2, L_out=L, cin=cout, cout=cin, taps=3, stride=2, pad=1,
+                                   mode=lib.MODE_UP2))
+    report('bf16x3 dgrad 128 s2', gx, cl(x.grad), tol=5e-5)
+
 def t_conv_dilated():
     B, C, S = 2, 128, 200
     for d in (1, 4, 32):
@@ -211,7 +235,7 @@ def model_case(name, signal_map, nc, B, S, missing):
     loss = F.cross_entropy(logits.view(-1, nc), y.to(dev).view(-1).long(), ignore_index=-1)
     loss.backward()
     l0, _, grads = O.loss_and_grads(sd, cfg, x, y)
-    report(f'{name} loss', loss, torch.tensor(l0), tol=1e-5)
+    report(f'{name} loss', loss, torch.tensor(l0), tol=1e-4)
     worst = 0
     for k, p in model.named_parameters():
         g = p.grad.cpu(); w = grads[k]
@@ -225,7 +249,7 @@ def t_model_c1(): model_case('c1', {'ECG': 'UNI'}, 4, 2, 4, None)
 def t_model_c2(): model_case('c2', {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}, 4, 3, 4, {'ABD': [1], 'PPG': [2]})
 def t_model_c4(): model_case('c4', {'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 2, {'EOG-R': [0]})
 
-STAGES = dict(conv=t_conv_plain, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

@@ -26,7 +26,10 @@ def conv_case(cin, cout, L, stride=1, pro=lib.PRO_IN_GELU, epi=lib.EPI_STATS, B=
     a0 = lib.ConvArgs(); a0.cin, a0.cout, a0.taps, a0.stride, a0.mode, a0.B, a0.L_out = cin, cout, taps, stride, mode, B, Lo
     tile = lib.load().w2s_conv_tile(__import__('ctypes').byref(a0))
     part = torch.empty(B, (Lo + tile - 1) // tile, 2, cout, device=dev)
-    a = lib.conv_args(x=x, x2=x2 if pro >= lib.PRO_INBWD else None, w=w, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
+    wh = wl = None
+    if os.environ.get('BF') == '1':
+        wh = w.bfloat16(); wl = (w - wh.float()).bfloat16()
+    a = lib.conv_args(w_hi=wh, w_lo=wl, x=x, x2=x2 if pro >= lib.PRO_INBWD else None, w=w, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
                       pad=1 if taps == 3 else 0, flip=flip, mode=mode, pro=pro, epi=epi, pro_stats=st, pro_bstats=bst, aux=aux, aux_stats=ost if aux is not None else None,
                       part=part if epi in (lib.EPI_STATS, lib.EPI_GP) else None)
     nbytes = 4 * (B * L * cin * (2 if pro >= lib.PRO_INBWD else 1) + B * Lo * cout * (2 if aux is not None else 1))

@@ -19,6 +19,7 @@
 struct ConvP {
   w2s_conv_args a;
   int ntiles;
+  int nr_lds;  // rows of the staged window (BF: offset of the lo plane)
 };
 
 // ---- on-load transform of one float4 (4 consecutive channels) --------------------------------------
@@ -50,7 +51,12 @@ __device__ __forceinline__ f32x4 pro_apply(int pro, f32x4 v, f32x4 v2, f32x4 mea
 // L2 feeds MT MFMAs: WN = 2 quarters the L2 weight traffic of the 128-channel layers, which was their limiter).
 // PRO / EPI >= 0: the prologue / epilogue mode is a compile-time constant (hot encoder paths: dead variants vanish and
 // the kernel needs ~58 instead of ~84 VGPRs => more resident workgroups => more bytes in flight); -1: runtime switch.
-template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN, int PRO, int EPI>
+// BF = 1: split-precision matrix cores ("bf16x3") for the MFMA-bound layers.  Every fp32 operand is split on the way into
+// LDS as x = hi + lo (two bf16 planes, together the size of the fp32 window), weights arrive pre-split, and each
+// 16x16x32 product runs as three bf16 MFMAs  hi*hi + hi*lo + lo*hi  with fp32 accumulation: 3 x 16 cycles per 32 channels
+// instead of 8 x 32 cycles of fp32 MFMA (5.3x), relative error per product <= 2^-16.  This is the arithmetic class the
+// reference itself trains with (torch.set_float32_matmul_precision('high') = TF32 / bf16_3x, scripts/train.py:117).
+template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN, int PRO, int EPI, int BF>
 __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
@@ -62,6 +68,9 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   const int b = blockIdx.z, tile = blockIdx.x, n0 = blockIdx.y * (NT * 16);
   const int t0 = tile * TM;
   const int cin = a.cin, RS = cin + 4, c4n = cin >> 2, rstep = 256 / c4n;
+  const int RSE = cin + 8;  // BF: bf16 elements per LDS row (16 B pad)
+  __bf16* hiL = reinterpret_cast<__bf16*>(smem);
+  __bf16* loL = hiL + P.nr_lds * RSE;
   const int K = TAPS * cin;
   const int L_in = a.L_in, L_out = a.L_out;
   const int pro = (PRO >= 0) ? PRO : a.pro;
@@ -107,7 +116,14 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
         if (rr < NR) {
           const bool ok = (gr >= 0) && (gr < L_in);
           f32x4 t = ok ? pro_apply(pro, v[u], v2[u], pm, pr, ps1, ps2) : (f32x4){0, 0, 0, 0};
-          st4(smem + rr * RS + myc4 * 4, t);
+          if constexpr (BF) {
+            bf16x4 h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
+            bf16x4 l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
+            *reinterpret_cast<bf16x4*>(hiL + rr * RSE + myc4 * 4) = h;
+            *reinterpret_cast<bf16x4*>(loL + rr * RSE + myc4 * 4) = l;
+          } else {
+            st4(smem + rr * RS + myc4 * 4, t);
+          }
         }
       }
     }
@@ -118,6 +134,38 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
 
   auto mma_tap = [&](int jw, int rowoff, int mtmask) {
     // jw: weight tap index; rowoff: LDS row offset added to the per-position row; mtmask: which m-tiles take part
+    if constexpr (BF) {
+      // chunks of 32 input channels; lane (r, g) holds 8 consecutive channels 8g..8g+7 of its row (A: weights of output
+      // channel r, B: activations of position r) -- the 16x16x32 bf16 operand layout
+      for (int q = 0; q < (cin >> 5); ++q) {
+        bf16x8 bh[MT], bl[MT], ah[NTW], al[NTW];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          int row;
+          if (MODE == W2S_MODE_UP2) row = wave_m * (8 * MT) + (mt >> 1) * 16 + r + rowoff;
+          else if (MODE == W2S_MODE_DILATED) row = wm0 + mt * 16 + r;
+          else row = (wm0 + mt * 16 + r) * STRIDE + rowoff;
+          bh[mt] = *reinterpret_cast<const bf16x8*>(hiL + row * RSE + q * 32 + 8 * g);
+          bl[mt] = *reinterpret_cast<const bf16x8*>(loL + row * RSE + q * 32 + 8 * g);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const size_t wo = (size_t)(n0 + wn0 + nt * 16 + r) * K + jw * cin + q * 32 + 8 * g;
+          ah[nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_hi) + wo);
+          al[nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_lo) + wo);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          if (mtmask & (1 << mt))
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl[mt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+            }
+      }
+      return;
+    }
     for (int q = 0; q < (cin >> 4); ++q) {
       f32x4 bf[MT], af[NTW];
 #pragma unroll
@@ -271,18 +319,19 @@ static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode
 }
 static inline int cfg_tm(const TileCfg& c) { return 16 * c.mt * (4 / c.wn); }
 
-template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN, int PRO, int EPI>
+template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN, int PRO, int EPI, int BF>
 static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
   constexpr int TM = 16 * MT * (4 / WN);
   ConvP P;
   P.a = a;
   P.ntiles = (a.L_out + TM - 1) / TM;
   const int NR = window_rows(TM, TAPS, STRIDE, MODE);
-  size_t lds = (size_t)NR * (a.cin + 4) * sizeof(float);
+  P.nr_lds = NR;
+  size_t lds = BF ? (size_t)2 * NR * (a.cin + 8) * 2 : (size_t)NR * (a.cin + 4) * sizeof(float);
   size_t red = (size_t)4 * (NT / WN) * 4 * 8 * sizeof(float);
   if (lds < red) lds = red;
   dim3 grid(P.ntiles, a.cout / (NT * 16), a.B);
-  auto kern = conv_cl_kernel<NT, MT, TAPS, STRIDE, MODE, WN, PRO, EPI>;
+  auto kern = conv_cl_kernel<NT, MT, TAPS, STRIDE, MODE, WN, PRO, EPI, BF>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return W2S_ELAUNCH;
@@ -297,9 +346,14 @@ template <int TAPS, int STRIDE, int MODE, int PRO, int EPI>
 static int dispatch_cfg(const w2s_conv_args& a, hipStream_t s) {
   const TileCfg c = pick_cfg(a.cin, a.cout, TAPS, STRIDE, MODE, a.B, a.L_out);
   if (a.cout % (c.nt * 16)) return W2S_EINVAL;
-#define W2S_CFG(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_, PRO, EPI>(a, s);
+  // split-precision path: caller supplied bf16 weight planes and the layer is matrix-core bound (>= 64 output channels)
+  const bool bf = a.w_hi && a.w_lo && a.cin >= 32 && c.nt >= 4;
+#define W2S_CFG(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_ && !bf) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_, PRO, EPI, 0>(a, s);
+#define W2S_CFGB(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_ && bf) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_, PRO, EPI, 1>(a, s);
   W2S_CFG(1, 4, 1) W2S_CFG(2, 4, 1) W2S_CFG(2, 2, 1) W2S_CFG(4, 4, 2) W2S_CFG(4, 2, 2) W2S_CFG(8, 4, 2) W2S_CFG(8, 2, 2) W2S_CFG(1, 2, 1)
+  W2S_CFGB(4, 4, 2) W2S_CFGB(4, 2, 2) W2S_CFGB(8, 4, 2) W2S_CFGB(8, 2, 2)
 #undef W2S_CFG
+#undef W2S_CFGB
   return W2S_EINVAL;
 }
 

@@ -5,6 +5,8 @@
 #include "../../include/w2s.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define W2S_CHECK_LAUNCH()                                   \
   do {                                                       \

@@ -435,6 +435,34 @@ __global__ void repack_kernel(const float* __restrict__ w, float* __restrict__ f
   if (bwd) bwd[((size_t)c * taps + j) * cout + o] = v;
 }
 
+// torch [cout][cin][taps] fp32 -> bf16 hi/lo planes (w = hi + lo up to 2^-17 relative) in the forward [cout][taps][cin]
+// and data-gradient [cin][taps][cout] layouts, for the split-precision matrix-core path of conv_cl.
+__global__ void repack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ fh, __bf16* __restrict__ fl, __bf16* __restrict__ bh,
+                                   __bf16* __restrict__ bl, int cout, int cin, int taps) {
+  const size_t n = (size_t)cout * cin * taps;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int j = idx % taps;
+  const int c = (idx / taps) % cin;
+  const int o = idx / ((size_t)taps * cin);
+  const float v = w[idx];
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  if (fh) { const size_t d = ((size_t)o * taps + j) * cin + c; fh[d] = h; fl[d] = l; }
+  if (bh) { const size_t d = ((size_t)c * taps + j) * cout + o; bh[d] = h; bl[d] = l; }
+}
+
+extern "C" int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, void* bwd_lo, int cout, int cin, int taps,
+                               void* stream) {
+  if (!w || (fwd_hi && !fwd_lo) || (bwd_hi && !bwd_lo)) return W2S_EINVAL;
+  const size_t n = (size_t)cout * cin * taps;
+  hipLaunchKernelGGL(repack_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+                     static_cast<__bf16*>(fwd_hi), static_cast<__bf16*>(fwd_lo), static_cast<__bf16*>(bwd_hi), static_cast<__bf16*>(bwd_lo),
+                     cout, cin, taps);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
 extern "C" int w2s_repack(const float* w, float* fwd, float* bwd, int cout, int cin, int taps, void* stream) {
   if (!w) return W2S_EINVAL;
   const size_t n = (size_t)cout * cin * taps;

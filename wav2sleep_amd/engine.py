@@ -79,6 +79,10 @@ class Engine:
         self.ctx = None
         self.taps = None  # set to {} to collect per-stage tensors (tests / debugging)
         self.multi_stream = os.environ.get('W2S_MULTI_STREAM', '1') != '0'
+        # split-precision (bf16x3) matrix-core path for the >=64-channel GEMM-shaped layers; W2S_EXACT_FP32=1 keeps fp32 MFMA
+        self.split_precision = os.environ.get('W2S_EXACT_FP32', '0') != '1'
+        self._bf = {}  # data_ptr of a weight operand -> (hi plane, lo plane)
+        self._bfbuf = {}
         self._streams = {}
         lib.load()
 
@@ -124,6 +128,24 @@ class Engine:
             bw = self.PB.get(name) if (nb and need_bwd) else None
             if f is not None or bw is not None:
                 lib.repack(w, f, bw, cout, cin, taps)
+            if self.split_precision:
+                # forward operand (packed copy, or the torch tensor itself when taps == 1) and data-gradient operand
+                fop = f if f is not None else w
+                want_f = cin >= 32 and cout >= 64
+                want_b = bw is not None and cout >= 32 and cin >= 64
+                planes = self._bfbuf.setdefault(name, {})
+                for kind, want in (('f', want_f), ('b', want_b)):
+                    if want and kind not in planes:
+                        planes[kind] = (torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16),
+                                        torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16))
+                fh, fl = planes['f'] if want_f else (None, None)
+                bh, bl = planes['b'] if want_b else (None, None)
+                if want_f or want_b:
+                    lib.repack_bf16(w, fh, fl, bh, bl, cout, cin, taps)
+                if want_f:
+                    self._bf[fop.data_ptr()] = (fh, fl)
+                if want_b:
+                    self._bf[bw.data_ptr()] = (bh, bl)
 
     def ensure_packed(self, key, need_bwd: bool):
         key = (key, need_bwd or (self._pack_key is not None and self._pack_key[1]))
@@ -146,6 +168,9 @@ class Engine:
         return out
 
     def _conv(self, **kw):
+        planes = self._bf.get(kw['w'].data_ptr()) if self.split_precision else None
+        if planes is not None:
+            kw['w_hi'], kw['w_lo'] = planes
         lib.conv_forward(lib.conv_args(**kw))
 
     def _conv_stats(self, *, x, w, B, L_in, L_out, cin, cout, stride, pro, pro_stats=None):

@@ -27,7 +27,7 @@ _i32 = C.c_int32
 
 class ConvArgs(C.Structure):
     _fields_ = [(n, _fp) for n in ('x', 'x2', 'w', 'y', 'y2', 'pro_stats', 'pro_bstats', 'aux', 'aux_stats', 'add_even', 'bias',
-                                   'rowkeep', 'part')] + \
+                                   'rowkeep', 'part', 'w_hi', 'w_lo')] + \
                [(n, _i32) for n in ('B', 'L_in', 'L_out', 'cin', 'cout', 'taps', 'stride', 'dil', 'pad', 'flip', 'mode',
                                     'ldx', 'ldy', 'ldy2', 'ld_aux', 'pro', 'epi')]
 
@@ -38,7 +38,7 @@ class WgradArgs(C.Structure):
                                     'pro_g', 'pro_h', 'nslab')]
 
 
-EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_repack',
+EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_repack', 'w2s_repack_bf16',
            'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
@@ -102,8 +102,9 @@ def _f(t):
 # ------------------------------------------------------------------------------------------------
 def conv_args(*, x, w, y, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, flip=0, mode=MODE_CONTIG, ldx=None, ldy=None,
               pro=PRO_NONE, epi=EPI_PLAIN, x2=None, pro_stats=None, pro_bstats=None, aux=None, aux_stats=None, add_even=None,
-              bias=None, rowkeep=None, part=None, y2=None, ldy2=0, ld_aux=0) -> ConvArgs:
+              bias=None, rowkeep=None, part=None, y2=None, ldy2=0, ld_aux=0, w_hi=None, w_lo=None) -> ConvArgs:
     a = ConvArgs()
+    a.w_hi, a.w_lo = _p(w_hi), _p(w_lo)
     a.x, a.x2, a.w, a.y, a.y2 = _f(x), _f(x2), _f(w), _f(y), _f(y2)
     a.pro_stats, a.pro_bstats, a.aux, a.aux_stats = _f(pro_stats), _f(pro_bstats), _f(aux), _f(aux_stats)
     a.add_even, a.bias, a.rowkeep, a.part = _f(add_even), _f(bias), _f(rowkeep), _f(part)
@@ -177,7 +178,8 @@ def conv_forward(a: ConvArgs):
         hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)]}
         if (a.pro, a.epi) in hot.get((a.mode, a.taps, a.stride), []):
             spec = (a.pro, a.epi)
-    key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}, {wn}, {spec[0]}, {spec[1]}>'
+    bf = 1 if (a.w_hi and a.w_lo and a.cin >= 32 and nt >= 4) else 0
+    key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}, {wn}, {spec[0]}, {spec[1]}, {bf}>'
     if DETAIL:
         key += f' {a.cin}->{a.cout} pro{a.pro} epi{a.epi} L{a.L_out}'
     _timed(key, nbytes, flops, run)
@@ -252,6 +254,10 @@ def wgrad_reduce(slab, nslab, grad, cout, cin, taps, dil=1, accumulate=False, la
 
 def repack(w, fwd, bwd, cout, cin, taps):
     _chk(load().w2s_repack(_f(w), _f(fwd), _f(bwd), cout, cin, taps, _stream()), 'w2s_repack')
+
+
+def repack_bf16(w, fwd_hi, fwd_lo, bwd_hi, bwd_lo, cout, cin, taps):
+    _chk(load().w2s_repack_bf16(_f(w), _p(fwd_hi), _p(fwd_lo), _p(bwd_hi), _p(bwd_lo), cout, cin, taps, _stream()), 'w2s_repack_bf16')
 
 
 def stats_finalize(part, B, ntiles, Cc, count, eps, kind, out):
