@@ -96,6 +96,7 @@ typedef struct w2s_wgrad_args {
   int32_t ldg, ldx;
   int32_t pro_g, pro_h;
   int32_t nslab;                           /* number of partial slabs = grid.x * w2s_wgrad_slabs_per_block() */
+  int32_t split_precision;                 /* != 0: bf16x3 matrix-core path where available (cin, cout >= 64) */
 } w2s_wgrad_args;
 int w2s_wgrad(const w2s_wgrad_args* a, void* stream);
 int w2s_wgrad_slabs_per_block(int cin, int cout, int taps, int dil); /* slabs written per grid.x block: nslab = grid.x * this */

@@ -137,6 +137,12 @@ def t_wgrad():
         gw = torch.zeros(cout, cin, taps, device=dev)
         lib.wgrad_reduce(slab, nslab, gw, cout, cin, taps, dil)
         report(f'wgrad {cin}->{cout} k{taps} s{stride} d{dil}', gw, w.grad, tol=3e-4)
+        if cin >= 64 and cout >= 64:  # split-precision (bf16x3) variant of the tile-split kernel
+            slab.zero_(); gw.zero_()
+            lib.wgrad(g=cl(gy).to(dev), x=cl(x).to(dev), slab=slab, nslab=nslab, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
+                      pad=pad, dil=dil, split_precision=True)
+            lib.wgrad_reduce(slab, nslab, gw, cout, cin, taps, dil)
+            report(f'wgrad bf16x3 {cin}->{cout} k{taps} s{stride} d{dil}', gw, w.grad, tol=3e-4)
 
 def t_rowops():
     rows, C = 1000, 128

@@ -44,7 +44,7 @@ def wgrad_case(cin, cout, L, stride=1, taps=3, B=16, pro_g=lib.PRO_INBWD, pro_h=
     gx = max(1, min((B * Lo + 255) // 256, max(1, 512 // gy))); nslab = gx * lib.wgrad_slabs_per_block(cin, cout, taps, 1)
     slab = torch.empty(nslab * cout * cin * taps, device=dev)
     fn = lambda: lib.wgrad(g=g, g2=g2, g_stats=st, g_bstats=bst, x=x, x_stats=xst, slab=slab, nslab=nslab, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout,
-                           taps=taps, stride=stride, pad=1 if taps == 3 else 0, pro_g=pro_g, pro_h=pro_h)
+                           taps=taps, stride=stride, pad=1 if taps == 3 else 0, pro_g=pro_g, pro_h=pro_h, split_precision=os.environ.get('BF') == '1')
     return fn, 4 * (B * Lo * cout * 2 + B * L * cin), 2 * B * Lo * cout * cin * taps
 
 def elt_case(op, n=16 * 983040 * 16):

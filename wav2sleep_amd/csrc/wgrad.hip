@@ -249,6 +249,140 @@ __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
       for (int c = 0; c < CT; ++c) st4(out + (((wave * OT + i) * JT + j) * CT + c) * 256, acc[i][j][c]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Split-precision ("bf16x3") tile-split weight gradient.  GY and H are staged as bf16 hi/lo planes in plain row-major
+// [position][channel] LDS tiles; both MFMA operands need 8 CONSECUTIVE POSITIONS per lane (the contraction index), which
+// is a column of those tiles, so they are fetched with the CDNA4 transposing LDS read ds_read_b64_tr_b16 (4 positions x
+// 16 channels per 16-lane group, delivered position-major) -- two per operand, any tap shift is just a row offset.
+// Wave w owns input-channel tile (w % CT) and output-channel tiles [(w / CT) * OW, +OW): the H fragments (3 taps) are
+// read once per wave and the GY fragments are shared through LDS broadcast-free reads; 3 bf16 MFMAs (16 cycles each,
+// K = 32 positions) replace 8 fp32 MFMAs (32 cycles each, K = 4).  Slab layout identical to wgrad_ts_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4v __attribute__((__vector_size__(4 * sizeof(__bf16))));
+__device__ __forceinline__ bf16x8 tr_read8(const __bf16* p0, const __bf16* p1) {
+  typedef __attribute__((address_space(3))) bf16x4v* lds_p;
+  bf16x4v a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p0));
+  bf16x4v b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p1));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int OW, int JT, int CT, int NW, int STRIDE, int PG, int PH>
+__global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
+  extern __shared__ f32x4 smem4[];
+  const w2s_wgrad_args& a = P.a;
+  const int pro_g = (PG >= 0) ? PG : a.pro_g, pro_h = (PH >= 0) ? PH : a.pro_h;
+  constexpr int NT = NW * 64, OGR = NW / CT, WG = OGR * OW * 16;  // WG = output channels of this block
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+  const int TM = P.TM;
+  const int cin = a.cin;  // == 16*CT
+  const int oy = blockIdx.y / P.ntg, tg = blockIdx.y % P.ntg;
+  const int o0 = oy * WG, j0 = tg * JT;
+  const int RSg = WG + 8, RSh = cin + 8;  // bf16 elements per row
+  const int NRh = (JT == 1) ? TM : (TM - 1) * STRIDE + JT;
+  __bf16* gH = reinterpret_cast<__bf16*>(smem4);
+  __bf16* gL = gH + TM * RSg;
+  __bf16* hH = gL + TM * RSg;
+  __bf16* hL = hH + NRh * RSh;
+  const int ctile = wave % CT, ogrp = wave / CT;
+
+  f32x4 acc[OW][JT];
+#pragma unroll
+  for (int i = 0; i < OW; ++i)
+#pragma unroll
+    for (int j = 0; j < JT; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+
+  auto split_store = [&](__bf16* hi, __bf16* lo, int off, f32x4 t) {
+    bf16x4 h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
+    bf16x4 l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
+    *reinterpret_cast<bf16x4*>(hi + off) = h;
+    *reinterpret_cast<bf16x4*>(lo + off) = l;
+  };
+
+  const int total = a.B * P.ntiles;
+  for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    const int b = tl / P.ntiles, tile = tl % P.ntiles;
+    const int t0 = tile * TM;
+    __syncthreads();
+    {  // ---- stage GY tile (channels o0 .. o0+WG-1) as bf16 hi/lo planes
+      constexpr int c4n = WG / 4;
+      const float* gb = a.g + (size_t)b * a.L_out * a.ldg + o0;
+      const float* g2b = (pro_g >= W2S_PRO_INBWD) ? a.g2 + (size_t)b * a.L_out * a.ldg + o0 : nullptr;
+      if constexpr (NT % c4n == 0) {
+        constexpr int rstep = NT / c4n;
+        const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
+        f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, ps1 = {0, 0, 0, 0}, ps2 = {0, 0, 0, 0};
+        if (pro_g >= W2S_PRO_IN_GELU) {
+          load_chan_params(a.g_stats, b, a.cout, o0 + ch, pm, pr);
+          if (pro_g >= W2S_PRO_INBWD) load_chan_params(a.g_bstats, b, a.cout, o0 + ch, ps1, ps2);
+        }
+        for (int row = row0; row < TM; row += rstep) {
+          const int t = t0 + row;
+          f32x4 v = {0, 0, 0, 0};
+          if (t < a.L_out) {
+            f32x4 x = ld4(gb + (size_t)t * a.ldg + ch);
+            f32x4 x2 = g2b ? ld4(g2b + (size_t)t * a.ldg + ch) : (f32x4){0, 0, 0, 0};
+            v = pro4(pro_g, x, x2, pm, pr, ps1, ps2);
+          }
+          split_store(gH, gL, row * RSg + ch, v);
+        }
+      } else {
+        for (int f = tid; f < TM * c4n; f += NT) {
+          const int row = f / c4n, ch = (f % c4n) * 4, t = t0 + row;
+          split_store(gH, gL, row * RSg + ch, t < a.L_out ? ld4(gb + (size_t)t * a.ldg + ch) : (f32x4){0, 0, 0, 0});
+        }
+      }
+    }
+    {  // ---- stage H window
+      const int c4n = cin >> 2, rstep = NT / c4n;
+      const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
+      f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, z = {0, 0, 0, 0};
+      if (pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
+      const float* xb = a.x + (size_t)b * a.L_in * a.ldx + ch;
+      const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
+      const int rowmul = (JT == 1) ? STRIDE : 1;
+      for (int row = row0; row < NRh; row += rstep) {
+        const int gr = rb + row * rowmul;
+        f32x4 v = {0, 0, 0, 0};
+        if (gr >= 0 && gr < a.L_in) v = pro4(pro_h, ld4(xb + (size_t)gr * a.ldx), z, pm, pr, z, z);
+        split_store(hH, hL, row * RSh + ch, v);
+      }
+    }
+    __syncthreads();
+    // ---- k-steps of 32 positions; lane group g covers positions 8g..8g+7 of the step (two 4-row transposed reads)
+    for (int s = 0; s < (TM >> 5); ++s) {
+      const int p0 = 32 * s + 8 * g + q4;  // this lane's address row for the first 4-position block
+      bf16x8 bh[JT], bl[JT];
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const int r0 = (JT == 1) ? p0 : p0 * STRIDE + j;
+        const int r1 = (JT == 1) ? p0 + 4 : (p0 + 4) * STRIDE + j;
+        const int col = ctile * 16 + 4 * p4;
+        bh[j] = tr_read8(hH + r0 * RSh + col, hH + r1 * RSh + col);
+        bl[j] = tr_read8(hL + r0 * RSh + col, hL + r1 * RSh + col);
+      }
+#pragma unroll
+      for (int i = 0; i < OW; ++i) {
+        const int col = (ogrp * OW + i) * 16 + 4 * p4;
+        const bf16x8 ah = tr_read8(gH + p0 * RSg + col, gH + (p0 + 4) * RSg + col);
+        const bf16x8 al = tr_read8(gL + p0 * RSg + col, gL + (p0 + 4) * RSg + col);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  constexpr int TILES = OGR * OW * JT * CT;
+  float* out = a.slab + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * TILES) * 256 + lane * 4;
+#pragma unroll
+  for (int i = 0; i < OW; ++i)
+#pragma unroll
+    for (int j = 0; j < JT; ++j) st4(out + (((ogrp * OW + i) * JT + j) * CT + ctile) * 256, acc[i][j]);
+}
+
 // sum slabs in a fixed order (16 slab-lanes x sequential chunks, then a fixed LDS tree); decode the fragment
 // index to (o, j, c); write torch layout grad[o][c][j] (layout 0) or [o][j][c] (layout 1).  Deterministic.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, float* __restrict__ grad, int cout,
@@ -330,6 +464,33 @@ static int launch_wgrad_ts(const w2s_wgrad_args& a, hipStream_t s) {
   return W2S_OK;
 }
 
+template <int OW, int JT, int CT, int NW, int STRIDE, int PG, int PH>
+static int launch_wgrad_bf(const w2s_wgrad_args& a, hipStream_t s) {
+  WgradP P;
+  P.a = a;
+  constexpr int WG = (NW / CT) * OW * 16;
+  if ((NW * 64) % (WG / 4) != 0 && a.pro_g != W2S_PRO_NONE) return W2S_EINVAL;
+  int TM = 128;
+  auto lds_of = [&](int tm) {
+    const int nrh = (JT == 1) ? tm : (tm - 1) * STRIDE + JT;
+    return (size_t)(tm * (WG + 8) + nrh * (a.cin + 8)) * 4;  // two bf16 planes each
+  };
+  while (TM > 32 && lds_of(TM) > 76 * 1024) TM >>= 1;
+  while (TM > 32 && TM >= 2 * a.L_out) TM >>= 1;
+  P.TM = TM;
+  P.ntiles = (a.L_out + TM - 1) / TM;
+  P.ntg = a.taps / JT;
+  dim3 grid(a.nslab, (a.cout / WG) * P.ntg);
+  size_t lds = lds_of(TM);
+  auto kern = wgrad_bf_kernel<OW, JT, CT, NW, STRIDE, PG, PH>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return W2S_ELAUNCH;
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, P);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
 template <int NTO, int NTC, int TAPS_T, int STRIDE>
 static int launch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
   WgradP P;
@@ -361,6 +522,24 @@ static int launch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
 template <int STRIDE>
 static int dispatch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
   const WgCfg c = wg_cfg(a.cin, a.cout, a.taps, a.dil);
+  if (c.ts && a.split_precision && c.nw >= c.ntc && c.nw % c.ntc == 0) {
+    // (OW = o-tiles per wave) = nto / (nw / ntc);  same slab layout / reduce as the fp32 tile-split kernel
+    const int ow = c.nto / (c.nw / c.ntc);
+#define W2S_BF(OW_, JT_, CT_, NW_, PG_, PH_) \
+  if (ow == OW_ && c.tapst == JT_ && c.ntc == CT_ && c.nw == NW_ && (PG_ < 0 || (a.pro_g == PG_ && a.pro_h == PH_))) \
+    return launch_wgrad_bf<OW_, JT_, CT_, NW_, STRIDE, PG_, PH_>(a, s);
+    if constexpr (STRIDE == 1) {
+      W2S_BF(8, 3, 8, 8, W2S_PRO_INBWD, W2S_PRO_IN_GELU) W2S_BF(4, 3, 4, 4, W2S_PRO_INBWD, W2S_PRO_IN_GELU) W2S_BF(4, 3, 4, 8, W2S_PRO_INBWD, W2S_PRO_IN_GELU)
+      W2S_BF(8, 3, 8, 8, W2S_PRO_INBWD, W2S_PRO_GELU) W2S_BF(4, 3, 4, 4, W2S_PRO_INBWD, W2S_PRO_GELU) W2S_BF(4, 3, 4, 8, W2S_PRO_INBWD, W2S_PRO_GELU)
+    }
+    if constexpr (STRIDE == 2) {
+      W2S_BF(8, 3, 8, 8, W2S_PRO_INBWD_GP, W2S_PRO_IN_GELU) W2S_BF(4, 3, 4, 4, W2S_PRO_INBWD_GP, W2S_PRO_IN_GELU)
+    }
+    if constexpr (STRIDE <= 2) { W2S_BF(8, 3, 8, 8, -1, -1) W2S_BF(4, 3, 4, 4, -1, -1) W2S_BF(4, 3, 4, 8, -1, -1) }
+    W2S_BF(8, 1, 8, 8, -1, -1) W2S_BF(4, 1, 4, 8, -1, -1) W2S_BF(4, 1, 4, 4, -1, -1) W2S_BF(24, 1, 8, 8, -1, -1) W2S_BF(32, 1, 8, 8, -1, -1)
+    W2S_BF(16, 1, 8, 8, -1, -1)
+#undef W2S_BF
+  }
   if (c.ts) {
 #define W2S_TS3(CT_, NW_, PG_, PH_) \
   if (c.ot == 1 && c.tapst == 3 && c.ntc == CT_ && c.nw == NW_ && a.pro_g == PG_ && a.pro_h == PH_) \

@@ -209,7 +209,7 @@ class Engine:
         nslab = gx * lib.wgrad_slabs_per_block(cin, cout, taps, dil)
         slab = self._slab(g.device, nslab, cout * cin * taps)
         lib.wgrad(g=g, x=x, slab=slab, nslab=nslab, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad,
-                  dil=dil, **kw)
+                  dil=dil, split_precision=self.split_precision, **kw)
         lib.wgrad_reduce(slab, nslab, self.G[name], cout, cin, taps, dil, accumulate=name in self._written, layout=layout)
         self._written.add(name)
 

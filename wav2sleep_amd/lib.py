@@ -35,7 +35,7 @@ class ConvArgs(C.Structure):
 class WgradArgs(C.Structure):
     _fields_ = [(n, _fp) for n in ('g', 'g2', 'g_stats', 'g_bstats', 'x', 'x_stats', 'slab')] + \
                [(n, _i32) for n in ('B', 'L_in', 'L_out', 'cin', 'cout', 'taps', 'stride', 'dil', 'pad', 'ldg', 'ldx',
-                                    'pro_g', 'pro_h', 'nslab')]
+                                    'pro_g', 'pro_h', 'nslab', 'split_precision')]
 
 
 EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_repack', 'w2s_repack_bf16',
@@ -186,13 +186,14 @@ def conv_forward(a: ConvArgs):
 
 
 def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, ldg=None, ldx=None, pro_g=PRO_NONE,
-          pro_h=PRO_NONE, g2=None, g_stats=None, g_bstats=None, x_stats=None):
+          pro_h=PRO_NONE, g2=None, g_stats=None, g_bstats=None, x_stats=None, split_precision=False):
     a = WgradArgs()
     a.g, a.g2, a.g_stats, a.g_bstats, a.x, a.x_stats, a.slab = _f(g), _f(g2), _f(g_stats), _f(g_bstats), _f(x), _f(x_stats), _f(slab)
     a.B, a.L_in, a.L_out, a.cin, a.cout, a.taps, a.stride, a.dil, a.pad = B, L_in, L_out, cin, cout, taps, stride, dil, pad
     a.ldg = cout if ldg is None else ldg
     a.ldx = cin if ldx is None else ldx
     a.pro_g, a.pro_h, a.nslab = pro_g, pro_h, nslab
+    a.split_precision = int(bool(split_precision))
 
     def run():
         _chk(load().w2s_wgrad(C.byref(a), _stream()), f'w2s_wgrad(cin={cin},cout={cout},taps={taps},stride={stride})')
@@ -208,7 +209,10 @@ def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, di
         if tapst == 3 and ((stride == 1 and pro_g == PRO_INBWD and pro_h in (PRO_IN_GELU, PRO_GELU)) or
                            (stride == 2 and pro_g == PRO_INBWD_GP and pro_h == PRO_IN_GELU and not (ntc == 4 and nw == 8))):
             spec = (pro_g, pro_h)
-        key = f'wgrad_ts_kernel<{ot}, {tapst}, {ntc}, {nw}, {stride}, {spec[0]}, {spec[1]}>'
+        if split_precision and nw >= ntc and nw % ntc == 0:
+            key = f'wgrad_bf_kernel<{(nw * ot) // (nw // ntc)}, {tapst}, {ntc}, {nw}, {stride}, {spec[0]}, {spec[1]}>'
+        else:
+            key = f'wgrad_ts_kernel<{ot}, {tapst}, {ntc}, {nw}, {stride}, {spec[0]}, {spec[1]}>'
     else:
         tapst = 3 if (taps == 3 and dil == 1 and ntc <= 4) else 1
         nto = 8
