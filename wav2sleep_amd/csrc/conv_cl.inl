@@ -346,12 +346,12 @@ template <int TAPS, int STRIDE, int MODE, int PRO, int EPI>
 static int dispatch_cfg(const w2s_conv_args& a, hipStream_t s) {
   const TileCfg c = pick_cfg(a.cin, a.cout, TAPS, STRIDE, MODE, a.B, a.L_out);
   if (a.cout % (c.nt * 16)) return W2S_EINVAL;
-  // split-precision path: caller supplied bf16 weight planes and the layer is matrix-core bound (>= 64 output channels)
-  const bool bf = a.w_hi && a.w_lo && a.cin >= 32 && c.nt >= 4;
+  // split-precision path: caller supplied bf16 weight planes (>= 32 input and output channels)
+  const bool bf = a.w_hi && a.w_lo && a.cin >= 32 && c.nt >= 2;
 #define W2S_CFG(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_ && !bf) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_, PRO, EPI, 0>(a, s);
 #define W2S_CFGB(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_ && bf) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_, PRO, EPI, 1>(a, s);
   W2S_CFG(1, 4, 1) W2S_CFG(2, 4, 1) W2S_CFG(2, 2, 1) W2S_CFG(4, 4, 2) W2S_CFG(4, 2, 2) W2S_CFG(8, 4, 2) W2S_CFG(8, 2, 2) W2S_CFG(1, 2, 1)
-  W2S_CFGB(4, 4, 2) W2S_CFGB(4, 2, 2) W2S_CFGB(8, 4, 2) W2S_CFGB(8, 2, 2)
+  W2S_CFGB(2, 4, 1) W2S_CFGB(2, 2, 1) W2S_CFGB(4, 4, 2) W2S_CFGB(4, 2, 2) W2S_CFGB(8, 4, 2) W2S_CFGB(8, 2, 2)
 #undef W2S_CFG
 #undef W2S_CFGB
   return W2S_EINVAL;

@@ -131,8 +131,8 @@ class Engine:
             if self.split_precision:
                 # forward operand (packed copy, or the torch tensor itself when taps == 1) and data-gradient operand
                 fop = f if f is not None else w
-                want_f = cin >= 32 and cout >= 64
-                want_b = bw is not None and cout >= 32 and cin >= 64
+                want_f = cin >= 32 and cout >= 32
+                want_b = bw is not None and cout >= 32 and cin >= 32
                 planes = self._bfbuf.setdefault(name, {})
                 for kind, want in (('f', want_f), ('b', want_b)):
                     if want and kind not in planes:

@@ -178,7 +178,7 @@ def conv_forward(a: ConvArgs):
         hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)]}
         if (a.pro, a.epi) in hot.get((a.mode, a.taps, a.stride), []):
             spec = (a.pro, a.epi)
-    bf = 1 if (a.w_hi and a.w_lo and a.cin >= 32 and nt >= 4) else 0
+    bf = 1 if (a.w_hi and a.w_lo and a.cin >= 32 and nt >= 2) else 0
     key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}, {wn}, {spec[0]}, {spec[1]}, {bf}>'
     if DETAIL:
         key += f' {a.cin}->{a.cout} pro{a.pro} epi{a.epi} L{a.L_out}'
