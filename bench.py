@@ -115,14 +115,23 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'4-modality (ABD+THX+ECG+PPG) {args.epochs}-epoch ({args.epochs // 120} h) synthetic, 4-class, per-GPU batch {args.batch}, '
                                    f'full train step fwd+CE+bwd+clip+AdamW', 'global_batch': args.batch * world, 'epochs': args.epochs,
-                       'parallelism': f'dp{world}', 'final_loss': round(loss, 5)}}
+                       'parallelism': f'dp{world}', 'final_loss': round(loss, 5),
+                       'precision': "fp32 storage + fp32 accumulate; >=32-channel GEMMs as bf16x3 split products on the matrix cores "
+                                    "(= the reference's float32_matmul_precision('high')); W2S_EXACT_FP32=1 for fp32 MFMA throughout"}}
 
     if rank == 0 and not args.no_roofline:
         # one extra, untimed step with a HIP event pair around every GEMM-shaped launch
+        # (single stream for this step: the timed steps overlap the four encoders on separate HIP streams, which inflates
+        #  every kernel's own duration; isolated durations are what a roofline fraction is about.  profiles/ holds the
+        #  rocprofv3 summaries of both: `bench.py` as is, and with W2S_MULTI_STREAM=0 which this leg agrees with.)
+        ms_flag = trainer.eng.multi_stream
+        trainer.eng.multi_stream = False
+        trainer.step(x, y)  # settle allocator / packs in single-stream mode
         lib.TIMER = lib.LaunchTimer()
         trainer.step(x, y)
         agg = lib.TIMER.summary()
         lib.TIMER = None
+        trainer.eng.multi_stream = ms_flag
         total_ms = sum(d['ms'] for d in agg.values())
         key, d = max(agg.items(), key=lambda kv: kv[1]['ms'])
         avg_s = d['ms'] / d['launches'] / 1e3
@@ -139,7 +148,7 @@ def main():
             t = json.load(open(fn)).get(key)
             if t and args.batch == 16 and args.epochs == 960:
                 traffic = int(t['hbm_bytes_per_launch'])
-        roof.update({'traffic': traffic, 'kernel': key, 'launches_per_step': d['launches'], 'avg_us': round(avg_s * 1e6, 1),
+        roof.update({'traffic': traffic, 'kernel': key, 'measured': 'HIP events, one extra single-stream step', 'launches_per_step': d['launches'], 'avg_us': round(avg_s * 1e6, 1),
                      'share_of_gemm_kernel_time': round(d['ms'] / total_ms, 3), 'algorithmic_bytes_per_launch': int(b_per),
                      'flops_per_launch': int(f_per)})
         # whole-step view against the SURVEY 8d convention (3x forward algorithmic bytes, fp32 storage)

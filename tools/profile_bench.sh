@@ -8,13 +8,17 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- $CMD > gpurun_out/${TAG}_stats.log 2>&1
+export W2S_MULTI_STREAM=0   # isolated per-kernel durations / traffic: one stream (the roofline leg of bench.py runs like this)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats1s -- $CMD > gpurun_out/${TAG}_stats1s.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_fetch -- $CMD > gpurun_out/${TAG}_fetch.log 2>&1 || true
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_write -- $CMD > gpurun_out/${TAG}_write.log 2>&1 || true
 python3 - <<PY
 import csv, glob, json, collections
 tag = '$TAG'
 st = glob.glob(f'gpurun_out/{tag}_stats/**/*kernel_stats.csv', recursive=True)[0]
-open(f'gpurun_out/{tag}_kernel_stats.csv', 'w').write('# rocprofv3 --kernel-trace --stats --output-format csv -- $CMD  (3 train steps, batch 16, MI355X)\n' + open(st).read())
+open(f'gpurun_out/{tag}_kernel_stats.csv', 'w').write('# rocprofv3 --kernel-trace --stats --output-format csv -- $CMD  (3 train steps, batch 16, MI355X; encoders on 4 HIP streams)\n' + open(st).read())
+st1 = glob.glob(f'gpurun_out/{tag}_stats1s/**/*kernel_stats.csv', recursive=True)[0]
+open(f'gpurun_out/{tag}_kernel_stats_single_stream.csv', 'w').write('# W2S_MULTI_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -- $CMD  (3 train steps, batch 16, MI355X; one stream)\n' + open(st1).read())
 agg = collections.defaultdict(lambda: {'FETCH_SIZE': [], 'WRITE_SIZE': []})
 for kind in ('fetch', 'write'):
     for f in glob.glob(f'gpurun_out/{tag}_{kind}/**/*counter_collection.csv', recursive=True):
