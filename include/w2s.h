@@ -115,12 +115,13 @@ int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, vo
  * forward conv's cout), ch = channels of the input side (its cin); supported (cg,ch): (16,16) (32,16) (32,32).
  * gout[t][c] = (W^T gy [+ add_even[t/2] at even t]) * GELU'(n_in);  part: [B][ceil(Lh/tile)][2][ch] sums of gout, gout*n_in;
  * slab: nslab (= grid size) raw-fragment slabs of cg*3*ch floats -> w2s_wgrad_reduce(slab, nslab, grad, cg, ch, 3, 1, ...).
+ * split_precision != 0: both products run as bf16x3 (hi/lo planes in LDS, fp32 accumulate).
  * Replaces aten::convolution_backward + native_batch_norm_backward + gelu_backward of blocks.py:173-186.
  */
 int w2s_bwd_fused_tile(int cg, int ch);
 int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                   const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
-                  int B, int Lg, int Lh, int cg, int ch, int stride, void* stream);
+                  int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, void* stream);
 
 /* partial sums [B][ntiles][2][C] -> per-(b,c) pairs [B][C][2]: kind 0 = (mean, rstd) with biased variance + eps
  * (nn.InstanceNorm1d, models/utils.py:89-92), kind 1 = (sum1, sum2)/count.  fp64 accumulation, fixed order. */

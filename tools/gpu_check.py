@@ -255,7 +255,30 @@ def t_model_c1(): model_case('c1', {'ECG': 'UNI'}, 4, 2, 4, None)
 def t_model_c2(): model_case('c2', {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}, 4, 3, 4, {'ABD': [1], 'PPG': [2]})
 def t_model_c4(): model_case('c4', {'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 2, {'EOG-R': [0]})
 
-STAGES = dict(conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+def t_fused_split_precision():
+    """bf16x3 fused backward (32 gradient channels) vs the fp32 fused kernel on the same tensors, ragged lengths."""
+    for cg, ch in ((16, 16), (32, 32), (32, 16)):
+        for stride, Lh in ((1, 1000), (2, 1322), (1, 128), (2, 4096)):
+            B, Lg = 3, Lh // stride
+            g = torch.randn(B, Lg, cg, device=dev); y = torch.randn(B, Lg, cg, device=dev); xin = torch.randn(B, Lh, ch, device=dev)
+            st = torch.rand(B, cg, 2, device=dev) + 0.5; bst = torch.rand(B, cg, 2, device=dev) * 0.01; sti = torch.rand(B, ch, 2, device=dev) + 0.5
+            add_even = torch.randn(B, Lh // 2, ch, device=dev)
+            wb = torch.randn(ch, 3, cg, device=dev) / 7
+            tile = lib.bwd_fused_tile(cg, ch); nt = (Lh + tile - 1) // tile
+            outs = []
+            for sp in (False, True):
+                gout = torch.zeros(B, Lh, ch, device=dev); part = torch.zeros(B, nt, 2, ch, device=dev)
+                ns = min(B * nt, 5)
+                slab = torch.zeros(ns * cg * ch * 3, device=dev); grad = torch.zeros(cg, ch, 3, device=dev)
+                lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=lib.PRO_INBWD if stride == 1 else lib.PRO_INBWD_GP, xin=xin, st_in=sti,
+                              add_even=add_even, wb=wb, gout=gout, part=part, slab=slab, nslab=ns, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch,
+                              stride=stride, split_precision=sp)
+                lib.wgrad_reduce(slab, ns, grad, cg, ch, 3, 1, accumulate=False, layout=0)
+                outs.append((gout, part, grad))
+            for nm, a, b in zip(('gout', 'part', 'wgrad'), outs[1], outs[0]):
+                report(f'fused bf16x3 {cg}->{ch} s{stride} L{Lh} {nm}', a, b, tol=2e-4)
+
+STAGES = dict(fusedbf=t_fused_split_precision, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

@@ -15,7 +15,7 @@ def timeit(fn, iters):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 
-def conv_case(cin, cout, L, stride=1, pro=lib.PRO_IN_GELU, epi=lib.EPI_STATS, B=16, taps=3, mode=lib.MODE_CONTIG, flip=0):
+def conv_case(cin, cout, L, stride=1, pro=lib.PRO_IN_GELU, epi=lib.EPI_STATS, B=16, taps=3, mode=lib.MODE_CONTIG, flip=0, dil=1, pad=None):
     Lo = L // stride if mode != lib.MODE_UP2 else L * 2
     x = torch.randn(B, L, cin, device=dev); x2 = torch.randn(B, L, cin, device=dev)
     w = torch.randn(cout, taps, cin, device=dev) / (cin * taps) ** 0.5
@@ -30,7 +30,7 @@ def conv_case(cin, cout, L, stride=1, pro=lib.PRO_IN_GELU, epi=lib.EPI_STATS, B=
     if os.environ.get('BF') == '1':
         wh = w.bfloat16(); wl = (w - wh.float()).bfloat16()
     a = lib.conv_args(w_hi=wh, w_lo=wl, x=x, x2=x2 if pro >= lib.PRO_INBWD else None, w=w, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
-                      pad=1 if taps == 3 else 0, flip=flip, mode=mode, pro=pro, epi=epi, pro_stats=st, pro_bstats=bst, aux=aux, aux_stats=ost if aux is not None else None,
+                      pad=(1 if taps == 3 else 0) if pad is None else pad, dil=dil, bias=torch.randn(cout, device=dev) if epi == lib.EPI_BIAS else None, flip=flip, mode=mode, pro=pro, epi=epi, pro_stats=st, pro_bstats=bst, aux=aux, aux_stats=ost if aux is not None else None,
                       part=part if epi in (lib.EPI_STATS, lib.EPI_GP) else None)
     nbytes = 4 * (B * L * cin * (2 if pro >= lib.PRO_INBWD else 1) + B * Lo * cout * (2 if aux is not None else 1))
     flops = 2 * B * Lo * cout * cin * (1.5 if mode == lib.MODE_UP2 else taps)
@@ -62,7 +62,7 @@ def fused_case(cg, ch, L, stride=1, B=16, nslab=None):
     ns = nslab or int(os.environ.get('NSLAB', 1024))
     slab = torch.empty(ns * cg * ch * 3, device=dev)
     fn = lambda: lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=lib.PRO_INBWD if stride == 1 else lib.PRO_INBWD_GP, xin=xin, st_in=sti, add_even=None,
-                               wb=wb, gout=gout, part=part, slab=slab, nslab=ns, B=B, Lg=Lg, Lh=L, cg=cg, ch=ch, stride=stride)
+                               wb=wb, gout=gout, part=part, slab=slab, nslab=ns, B=B, Lg=Lg, Lh=L, cg=cg, ch=ch, stride=stride, split_precision=os.environ.get('BF') == '1')
     return fn, 4 * (2 * B * Lg * cg + 2 * B * L * ch), 2 * B * Lg * cg * ch * 3 * 2
 
 CASES = {
@@ -70,6 +70,7 @@ CASES = {
     'b16u': lambda: fused_case(16, 16, 983040, stride=2),
     'b32': lambda: fused_case(32, 32, 245760),
     'b32u': lambda: fused_case(32, 32, 245760, stride=2),
+    'b21': lambda: fused_case(32, 16, 245760),
     'add': lambda: elt_case(lib.ELT_ADD),
     'gelu': lambda: elt_case(lib.ELT_GELU),
     'tcopy': lambda: (lambda a, y: ((lambda: y.copy_(a)), 8 * a.numel(), a.numel()))(torch.randn(16 * 983040 * 16, device=dev), torch.empty(16 * 983040 * 16, device=dev)),
@@ -88,6 +89,12 @@ CASES = {
     'f128n': lambda: conv_case(128, 128, 15360, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN),
     'd128': lambda: conv_case(128, 128, 15360, pro=lib.PRO_INBWD, epi=lib.EPI_GP, flip=1),
     'w128': lambda: wgrad_case(128, 128, 15360),
+    'qkv': lambda: conv_case(128, 384, 76800, B=1, taps=1, pro=lib.PRO_NONE, epi=lib.EPI_BIAS),
+    'ff1': lambda: conv_case(128, 512, 76800, B=1, taps=1, pro=lib.PRO_NONE, epi=lib.EPI_BIAS),
+    'proj': lambda: conv_case(128, 128, 76800, B=1, taps=1, pro=lib.PRO_NONE, epi=lib.EPI_BIAS),
+    'ff2': lambda: conv_case(128, 128, 76800 * 4, stride=4, B=1, taps=4, pro=lib.PRO_NONE, epi=lib.EPI_BIAS, mode=lib.MODE_DILATED),
+    'seq1': lambda: conv_case(128, 128, 960, B=16, taps=7, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN, mode=lib.MODE_DILATED, dil=1, pad=3),
+    'seq32': lambda: conv_case(128, 128, 960, B=16, taps=7, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN, mode=lib.MODE_DILATED, dil=32, pad=96),
 }
 if __name__ == '__main__':
     ap = argparse.ArgumentParser(); ap.add_argument('names', nargs='*'); ap.add_argument('--iters', type=int, default=20)

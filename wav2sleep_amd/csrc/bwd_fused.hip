@@ -23,19 +23,28 @@ struct BwdP {
   int B, Lg, Lh, ntiles, pro;
 };
 
+// LDS row strides: 16-channel rows stay unpadded (64-B rows: the three windows + weights of the 16x16 kernel then fit
+// three workgroups per CU = 50 % more loads in flight); wider rows get 4 floats of padding against bank conflicts.
+#ifndef W2S_BF_OCC3
+#define W2S_BF_OCC3 1
+#endif
+__host__ __device__ constexpr int bwd_rs(int c) { return (c > 16 || !W2S_BF_OCC3) ? c + 4 : c; }
+__host__ __device__ constexpr int bwd_redn(int ch) { return 4 * ch * 4 * 8; }  // floats of the statistics scratch
+
 template <int CG, int CH, int MT, int UP2, int PF>
-__global__ __launch_bounds__(256) void bwd_fused_kernel(BwdP P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CG == 1 && CH == 1 && W2S_BF_OCC3) ? 3 : 2)))
+void bwd_fused_kernel(BwdP P) {
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
   constexpr int TM = 64 * MT;                       // output (h-side) positions per tile
   constexpr int GC = CG * 16, HC = CH * 16;         // channels on the gradient / input side
-  constexpr int RSg = GC + 4, RSh = HC + 4;
+  constexpr int RSg = bwd_rs(GC), RSh = bwd_rs(HC);
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2;    // gy window rows
   constexpr int NRh = UP2 ? TM + 1 : TM + 2;        // h window rows (row 0 = position t0-1)
   float* gyL = smem;
   float* hL = smem + NRg * RSg;
   float* nL = hL + NRh * RSh;                       // normalised input n_in of the TM centre rows (epilogue: GELU'(n), stats)
-  float* red = nL + TM * RSh;                       // [4][CH][4][8] stats scratch, later [4][64][4] slab reduce
+  float* red = nL + TM * RSh;                       // [4][CH][4][8] stats scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int Lg = P.Lg, Lh = P.Lh;
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdP P) {
   // ---- dgrad weights [HC][3][GC] -> LDS once (persistent kernel): the MFMA loops then touch no global memory, so the
   //      next tile's prefetch (below) is not drained by an in-order vmcnt wait on a weight load.
   constexpr int WROW = 3 * GC + 4;
-  float* wL = red + 1024;
+  float* wL = red + bwd_redn(CH);
   for (int i = tid; i < HC * (3 * GC / 4); i += 256) {
     const int row = i / (3 * GC / 4), c4 = i % (3 * GC / 4);
     st4(wL + row * WROW + c4 * 4, ld4(P.wb + (size_t)row * (3 * GC) + c4 * 4));
@@ -244,11 +253,11 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdP P) {
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        __syncthreads();
-        st4(red + (wave * 64 + lane) * 4, accw[i][j][c]);
+        __syncthreads();  // (first pass: every wave is done with the windows; the scratch aliases them)
+        st4(smem + (wave * 64 + lane) * 4, accw[i][j][c]);
         __syncthreads();
         if (wave == 0) {
-          f32x4 v = ld4(red + lane * 4) + ld4(red + (64 + lane) * 4) + ld4(red + (128 + lane) * 4) + ld4(red + (192 + lane) * 4);
+          f32x4 v = ld4(smem + lane * 4) + ld4(smem + (64 + lane) * 4) + ld4(smem + (128 + lane) * 4) + ld4(smem + (192 + lane) * 4);
           st4(out + ((i * 3 + j) * CH + c) * 256 + lane * 4, v);
         }
       }
@@ -260,10 +269,335 @@ static int launch_bwd(const BwdP& P0, int nslab, hipStream_t s) {
   BwdP P = P0;
   P.ntiles = (P.Lh + TM - 1) / TM;
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = UP2 ? TM + 1 : TM + 2;
-  size_t lds = (size_t)(NRg * (CG * 16 + 4) + NRh * (CH * 16 + 4)) * 4;
-  size_t redb = (size_t)((4 * CH * 4 * 8 > 1024) ? 4 * CH * 4 * 8 : 1024) * 4;
-  lds += redb + (size_t)(CH * 16) * (3 * CG * 16 + 4) * 4 + (size_t)TM * (CH * 16 + 4) * 4;
+  size_t lds = (size_t)(NRg * bwd_rs(CG * 16) + NRh * bwd_rs(CH * 16) + TM * bwd_rs(CH * 16)) * 4;
+  lds += (size_t)bwd_redn(CH) * 4 + (size_t)(CH * 16) * (3 * CG * 16 + 4) * 4;
   auto kern = bwd_fused_kernel<CG, CH, MT, UP2, PF>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return W2S_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(nslab), dim3(256), lds, s, P);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Split-precision ("bf16x3") form for 32 gradient-side channels: the fp32 kernel above spends ~70 % of a tile's time
+// budget in the matrix pipe at 32x32 channels (2.7 TB/s); with both windows staged as bf16 (hi, lo) planes every product
+// is 3 x v_mfma_f32_16x16x32_bf16 (hh + hl + lh, fp32 accumulate; K = 32 = the gradient channels for the data gradient,
+// = 32 positions for the weight gradient, whose operands are columns of the row-major tiles => ds_read_b64_tr_b16).
+// Weight-gradient tiles are split over waves by (cout tile, cin tile) so each wave owns its 3 tap accumulators: no
+// cross-wave reduction at the end.  Staging, prefetch, epilogue and slab layout are those of bwd_fused_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4t __attribute__((__vector_size__(4 * sizeof(__bf16))));
+__device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
+  typedef __attribute__((address_space(3))) bf16x4t* lds_p;
+  bf16x4t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p0));
+  bf16x4t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p1));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void split_store4(__bf16* hi, __bf16* lo, int off, f32x4 t) {
+  bf16x4 h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
+  bf16x4 l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
+  *reinterpret_cast<bf16x4*>(hi + off) = h;
+  *reinterpret_cast<bf16x4*>(lo + off) = l;
+}
+__device__ __forceinline__ f32x4 mfma_bf3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  return c;
+}
+
+template <int CG, int CH, int MT, int UP2>
+__global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
+  extern __shared__ f32x4 smem4[];
+  constexpr int TM = 64 * MT;
+  constexpr int GC = CG * 16, HC = CH * 16;
+  constexpr int RSg = GC + 8, RSh = HC + 8, RSn = bwd_rs(HC);   // bf16 / bf16 / float elements per row
+  constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2;
+  constexpr int NRh = UP2 ? TM + 1 : TM + 2;
+  // data-gradient K axis of the LDS weight image.  32 gradient channels: k = tap*32 + o (one tap per MFMA).
+  // 16 gradient channels: two taps share one K = 32 step: stride 1: [tap0 | tap1] [tap2 | 0];
+  // stride 2 (even outputs use tap 1, odd outputs taps 2 and 0): [tap1 | 0] [tap2 | tap0].
+  constexpr int KD = (GC == 32) ? 96 : 64;
+  constexpr int WROW = KD + 8;
+  float* nL = reinterpret_cast<float*>(smem4);              // [TM][RSn] normalised input of the centre rows
+  float* red = nL + TM * RSn;                               // [4][CH][4][8] stats scratch
+  __bf16* gyH = reinterpret_cast<__bf16*>(red + bwd_redn(CH));
+  __bf16* gyLo = gyH + NRg * RSg;
+  __bf16* hH = gyLo + NRg * RSg;
+  __bf16* hLo = hH + NRh * RSh;
+  __bf16* wH = hLo + NRh * RSh;                             // [HC][WROW]
+  __bf16* wLo = wH + HC * WROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4, q4 = r >> 2, p4 = r & 3;
+  const int Lg = P.Lg, Lh = P.Lh;
+
+  // weight-gradient ownership: the CG*CH (cout tile, cin tile) pairs are spread over the 4 waves; KW waves share a
+  // pair and take every KW-th k-step (summed through LDS at the end, fixed order)
+  constexpr int NWT = CG * CH, KW = 4 / NWT;
+  const int wt = wave / KW, wk = wave % KW, wi = wt / CH, wc = wt % CH;
+  f32x4 accw[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) accw[j] = (f32x4){0, 0, 0, 0};
+
+  for (int i = tid; i < HC * (KD / 4); i += 256) {
+    const int row = i / (KD / 4), k = (i % (KD / 4)) * 4;
+    const float* wr = P.wb + (size_t)row * (3 * GC);
+    f32x4 v = {0, 0, 0, 0};
+    if (GC == 32) v = ld4(wr + k);
+    else if (!UP2) { if (k < 48) v = ld4(wr + k); }
+    else {
+      const int seg = k >> 4, o = k & 15;
+      if (seg == 0) v = ld4(wr + 16 + o);
+      else if (seg == 2) v = ld4(wr + 32 + o);
+      else if (seg == 3) v = ld4(wr + o);
+    }
+    split_store4(wH, wLo, row * WROW + k, v);
+  }
+
+  constexpr int c4g = GC / 4, rstep_g = 256 / c4g, NG = (NRg + rstep_g - 1) / rstep_g;
+  constexpr int c4h = HC / 4, rstep_h = 256 / c4h, NH = (NRh + rstep_h - 1) / rstep_h;
+  const int gc4 = tid % c4g, grow0 = tid / c4g, gch = gc4 * 4;
+  const int hc4 = tid % c4h, hrow0 = tid / c4h, hch = hc4 * 4;
+  f32x4 rg[NG], ry[NG], rh[NH];
+  auto prefetch = [&](int tl) {
+    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+    const float* gb = P.g + (size_t)b * Lg * GC + gch;
+    const float* yb = P.y + (size_t)b * Lg * GC + gch;
+    const int rb = UP2 ? t0 / 2 : t0 - 1;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int row = grow0 + k * rstep_g, gr = rb + row;
+      const bool ok = row < NRg && gr >= 0 && gr < Lg;
+      rg[k] = ok ? ld4(gb + (size_t)gr * GC) : (f32x4){0, 0, 0, 0};
+      ry[k] = ok ? ld4(yb + (size_t)gr * GC) : (f32x4){0, 0, 0, 0};
+    }
+    const float* xb = P.xin + (size_t)b * Lh * HC + hch;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
+      const bool ok = row < NRh && gr >= 0 && gr < Lh;
+      rh[k] = ok ? ld4(xb + (size_t)gr * HC) : (f32x4){0, 0, 0, 0};
+    }
+  };
+  auto commit = [&](int tl) {
+    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+    f32x4 pm, pr, ps1, ps2;
+    {
+      const float* st = P.st_k + ((size_t)b * GC + gch) * 2;
+      f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+      pm = (f32x4){s01.x, s01.z, s23.x, s23.z}; pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+      const float* bs = P.bst_k + ((size_t)b * GC + gch) * 2;
+      f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
+      ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z}; ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
+    }
+    const int rb = UP2 ? t0 / 2 : t0 - 1;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int row = grow0 + k * rstep_g, gr = rb + row;
+      if (row < NRg) {
+        const bool ok = gr >= 0 && gr < Lg;
+        split_store4(gyH, gyLo, row * RSg + gch,
+                     ok ? pro_apply(UP2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD, rg[k], ry[k], pm, pr, ps1, ps2) : (f32x4){0, 0, 0, 0});
+      }
+    }
+    f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
+    if (P.st_in) {
+      const float* st = P.st_in + ((size_t)b * HC + hch) * 2;
+      f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+      hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
+      if (row < NRh) {
+        const bool ok = gr >= 0 && gr < Lh;
+        const f32x4 nv = (rh[k] - hm) * hr;
+        split_store4(hH, hLo, row * RSh + hch, ok ? gelu4(nv) : (f32x4){0, 0, 0, 0});
+        if (row >= 1 && row <= TM) st4(nL + (row - 1) * RSn + hch, nv);
+      }
+    }
+  };
+
+  const int total = P.B * P.ntiles;
+  if ((int)blockIdx.x < total) prefetch(blockIdx.x);
+  for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    const int b = tl / P.ntiles, tile = tl % P.ntiles;
+    const int t0 = tile * TM;
+    __syncthreads();
+    commit(tl);
+    if (tl + (int)gridDim.x < total) prefetch(tl + gridDim.x);
+    __syncthreads();
+
+    // ---- data gradient
+    f32x4 acc[MT][CH];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < CH; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
+    if constexpr (GC == 32) {  // K = the 32 gradient channels of one tap
+      auto mma_tap = [&](int jw, int rowoff, int mtmask) {
+        bf16x8 ah[CH], al[CH];
+#pragma unroll
+        for (int nt = 0; nt < CH; ++nt) {
+          ah[nt] = *reinterpret_cast<const bf16x8*>(wH + (nt * 16 + r) * WROW + jw * GC + 8 * g);
+          al[nt] = *reinterpret_cast<const bf16x8*>(wLo + (nt * 16 + r) * WROW + jw * GC + 8 * g);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (!(mtmask & (1 << mt))) continue;
+          const int row = UP2 ? wave * (8 * MT) + (mt >> 1) * 16 + r + rowoff : wave * (16 * MT) + mt * 16 + r + rowoff;
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(gyH + row * RSg + 8 * g);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(gyLo + row * RSg + 8 * g);
+#pragma unroll
+          for (int nt = 0; nt < CH; ++nt) acc[mt][nt] = mfma_bf3(ah[nt], al[nt], bh, bl, acc[mt][nt]);
+        }
+      };
+      if (UP2) {
+        constexpr int EVEN = 0x55 & ((1 << MT) - 1), ODD = 0xAA & ((1 << MT) - 1);
+        mma_tap(1, 0, EVEN);
+        mma_tap(2, 0, ODD);
+        mma_tap(0, 1, ODD);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mma_tap(j, 2 - j, (1 << MT) - 1);
+      }
+    } else {  // 16 gradient channels: lane groups g = 0,1 carry the first tap of a K step, g = 2,3 the second
+      bf16x8 ah[2][CH], al[2][CH];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < CH; ++nt) {
+          ah[ks][nt] = *reinterpret_cast<const bf16x8*>(wH + (nt * 16 + r) * WROW + ks * 32 + 8 * g);
+          al[ks][nt] = *reinterpret_cast<const bf16x8*>(wLo + (nt * 16 + r) * WROW + ks * 32 + 8 * g);
+        }
+      const int col = 8 * (g & 1), second = g >> 1;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (UP2) {
+          const int m = wave * (8 * MT) + (mt >> 1) * 16 + r;
+          const int ks = mt & 1;                         // even outputs: [tap1 | 0]; odd outputs: [tap2 (row m) | tap0 (row m+1)]
+          const int row = m + ((ks && second) ? 1 : 0);
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(gyH + row * RSg + col);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(gyLo + row * RSg + col);
+#pragma unroll
+          for (int nt = 0; nt < CH; ++nt) acc[mt][nt] = mfma_bf3(ah[ks][nt], al[ks][nt], bh, bl, acc[mt][nt]);
+        } else {
+          const int m = wave * (16 * MT) + mt * 16 + r;  // window row of gy[t'+1-j] is m + (2 - j)
+          const int row0 = m + 2 - second;               // K step 0: taps 0 | 1
+          const int row1 = m;                            // K step 1: tap 2 | zero weights
+          const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(gyH + row0 * RSg + col);
+          const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(gyLo + row0 * RSg + col);
+          const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(gyH + row1 * RSg + col);
+          const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(gyLo + row1 * RSg + col);
+#pragma unroll
+          for (int nt = 0; nt < CH; ++nt) {
+            acc[mt][nt] = mfma_bf3(ah[0][nt], al[0][nt], b0h, b0l, acc[mt][nt]);
+            acc[mt][nt] = mfma_bf3(ah[1][nt], al[1][nt], b1h, b1l, acc[mt][nt]);
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: * GELU'(n_in), statistics, store
+    f32x4 sA[CH], sB[CH];
+#pragma unroll
+    for (int nt = 0; nt < CH; ++nt) { sA[nt] = (f32x4){0, 0, 0, 0}; sB[nt] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int pos = UP2 ? t0 + 2 * (wave * (8 * MT) + (mt >> 1) * 16 + r) + (mt & 1) : t0 + wave * (16 * MT) + mt * 16 + r;
+      if (pos >= Lh) continue;
+#pragma unroll
+      for (int nt = 0; nt < CH; ++nt) {
+        const int ch = nt * 16 + 4 * g;
+        const size_t orow = (size_t)b * Lh + pos;
+        const f32x4 n = *reinterpret_cast<const f32x4*>(nL + (pos - t0) * RSn + ch);
+        f32x4 v = acc[mt][nt];
+        if (P.add_even && !(pos & 1)) v += ld4(P.add_even + ((size_t)b * (Lh >> 1) + (pos >> 1)) * HC + ch);
+        v = v * gelu_grad4(n);
+        sA[nt] += v;
+        sB[nt] += v * n;
+        st4(P.gout + orow * HC + ch, v);
+      }
+    }
+    if (P.part) {
+#pragma unroll
+      for (int nt = 0; nt < CH; ++nt) {
+        f32x4 x1, x2;
+        x1.x = row16_sum(sA[nt].x); x1.y = row16_sum(sA[nt].y); x1.z = row16_sum(sA[nt].z); x1.w = row16_sum(sA[nt].w);
+        x2.x = row16_sum(sB[nt].x); x2.y = row16_sum(sB[nt].y); x2.z = row16_sum(sB[nt].z); x2.w = row16_sum(sB[nt].w);
+        if (r == 0) {
+          float* d = red + ((wave * CH + nt) * 4 + g) * 8;
+          st4(d, x1);
+          st4(d + 4, x2);
+        }
+      }
+      __syncthreads();
+      if (tid < CH * 32) {
+        const int k = tid / HC, c = tid % HC;
+        const int nt = c >> 4, gg = (c >> 2) & 3, e = c & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
+        P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c] = s;
+      }
+    }
+
+    // ---- weight gradient: k-step = 32 gradient-side positions; lane group g covers positions 8g..8g+7 of the step
+    constexpr int KS = (UP2 ? TM / 2 : TM) / 32;
+#pragma unroll
+    for (int s0 = 0; s0 < KS; s0 += KW) {
+      const int s = s0 + wk;
+      const int p0 = 32 * s + 8 * g + q4;         // this lane's address row (gradient-side position) of the first 4-block
+      const int gr0 = UP2 ? p0 : p0 + 1;
+      const int gcol = wi * 16 + 4 * p4;
+      const bf16x8 ah = lds_tr8(gyH + gr0 * RSg + gcol, gyH + (gr0 + 4) * RSg + gcol);
+      const bf16x8 al = lds_tr8(gyLo + gr0 * RSg + gcol, gyLo + (gr0 + 4) * RSg + gcol);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int h0 = UP2 ? 2 * p0 + j : p0 + j, h1 = UP2 ? 2 * (p0 + 4) + j : p0 + 4 + j;
+        const int hcol = wc * 16 + 4 * p4;
+        const bf16x8 bh = lds_tr8(hH + h0 * RSh + hcol, hH + h1 * RSh + hcol);
+        const bf16x8 bl = lds_tr8(hLo + h0 * RSh + hcol, hLo + h1 * RSh + hcol);
+        accw[j] = mfma_bf3(ah, al, bh, bl, accw[j]);
+      }
+    }
+  }
+
+  // ---- one slab per workgroup, raw-fragment layout [tile(i,j,c)][lane][4]; waves sharing a tile pair sum in wave order
+  float* out = P.slab + (size_t)blockIdx.x * (CG * 3 * CH) * 256;
+  if (KW == 1) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) st4(out + ((wi * 3 + j) * CH + wc) * 256 + lane * 4, accw[j]);
+  } else {
+    __syncthreads();
+    float* sc = reinterpret_cast<float*>(smem4);  // the windows are free now: [wave][3][64][4]
+    if (wk != 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) st4(sc + ((wave * 3 + j) * 64 + lane) * 4, accw[j]);
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        f32x4 v = accw[j];
+#pragma unroll
+        for (int k = 1; k < KW; ++k) v += ld4(sc + (((wave + k) * 3 + j) * 64 + lane) * 4);
+        st4(out + ((wi * 3 + j) * CH + wc) * 256 + lane * 4, v);
+      }
+    }
+  }
+}
+
+template <int CG, int CH, int MT, int UP2>
+static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
+  constexpr int TM = 64 * MT, GC = CG * 16, HC = CH * 16, KD = (GC == 32) ? 96 : 64;
+  BwdP P = P0;
+  P.ntiles = (P.Lh + TM - 1) / TM;
+  constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = UP2 ? TM + 1 : TM + 2;
+  size_t lds = (size_t)TM * bwd_rs(HC) * 4 + (size_t)bwd_redn(CH) * 4 + (size_t)2 * 2 * (NRg * (GC + 8) + NRh * (HC + 8) + HC * (KD + 8));
+  auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -286,7 +620,7 @@ extern "C" int w2s_bwd_fused_tile(int cg, int ch) { return 64 * ((cg == 16 && ch
 // cg = channels of the gradient side (the forward conv's cout), ch = channels of the input side (its cin).
 extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                              const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
-                             int B, int Lg, int Lh, int cg, int ch, int stride, void* stream) {
+                             int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, void* stream) {
   if (!g || !y || !st_k || !bst_k || !xin || !wb || !gout || !slab || nslab <= 0) return W2S_EINVAL;
   if (pro != W2S_PRO_INBWD && pro != W2S_PRO_INBWD_GP) return W2S_EINVAL;
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
@@ -294,6 +628,11 @@ extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, 
   BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int up2 = stride == 2;
+#define W2S_BFS(CG_, CH_, MT_) \
+  if (split_precision && cg == 16 * CG_ && ch == 16 * CH_) \
+    return up2 ? launch_bwd_bf<CG_, CH_, MT_, 1>(P, nslab, s) : launch_bwd_bf<CG_, CH_, MT_, 0>(P, nslab, s);
+  W2S_BFS(1, 1, W2S_BF_MT11) W2S_BFS(2, 1, W2S_BF_MT2) W2S_BFS(2, 2, W2S_BF_MT2)
+#undef W2S_BFS
 #define W2S_BF(CG_, CH_, MT_) \
   if (cg == 16 * CG_ && ch == 16 * CH_) return up2 ? launch_bwd<CG_, CH_, MT_, 1, W2S_BF_PF>(P, nslab, s) : launch_bwd<CG_, CH_, MT_, 0, W2S_BF_PF>(P, nslab, s);
   W2S_BF(1, 1, W2S_BF_MT11) W2S_BF(2, 1, W2S_BF_MT2) W2S_BF(2, 2, W2S_BF_MT2)

@@ -306,6 +306,8 @@ static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode
   c.mt = 4;
   if ((size_t)window_rows(16 * c.mt * (4 / c.wn), taps, stride, mode) * (cin + 4) * 4 > 72 * 1024) c.mt = 2;
   { static const char* e = getenv("W2S_FORCE_MT"); if (e && c.nt >= 4) c.mt = atoi(e); }  // tuning only
+  { static const char* e = getenv("W2S_FORCE_NT"); if (e && c.nt >= 8) c.nt = atoi(e); }  // tuning only
+  { static const char* e = getenv("W2S_NO_SHRINK"); if (e) return c; }                    // tuning only
   // short problems (SequenceCNN: 16 x 960 rows): shrink the tile until the grid covers the 256 CUs about twice
   auto wgs = [&](const TileCfg& t) {
     const long tm = 16 * t.mt * (4 / t.wn);

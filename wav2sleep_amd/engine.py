@@ -222,7 +222,7 @@ class Engine:
         slab = self._slab(dev, nslab, cg * ch * 3)
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
-                      part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride)
+                      part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, split_precision=self.split_precision)
         lib.wgrad_reduce(slab, nslab, self.G[name], cg, ch, 3, 1, accumulate=name in self._written, layout=0)
         self._written.add(name)
         return self._bstats(part, B, nt, ch, Lh) if want_part else None

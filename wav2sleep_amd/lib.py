@@ -232,13 +232,16 @@ def bwd_fused_tile(cg, ch) -> int:
     return load().w2s_bwd_fused_tile(cg, ch)
 
 
-def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride):
+def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False):
     def run():
         _chk(load().w2s_bwd_fused(_f(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), _f(gout), _f(part),
-                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, _stream()), f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
+                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, int(bool(split_precision)), _stream()), f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
     nbytes = 4 * (2 * B * Lg * cg + 2 * B * Lh * ch + (B * Lh * ch // 2 if add_even is not None else 0))
     flops = 2 * B * Lg * cg * ch * 3 * 2
-    key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}, 1>'
+    if split_precision:
+        key = f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}>'
+    else:
+        key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}, 1>'
     if DETAIL:
         key += f' L{Lh}'
     _timed(key, nbytes, flops, run)
