@@ -103,9 +103,22 @@ int w2s_wgrad_slabs_per_block(int cin, int cout, int taps, int dil); /* slabs wr
 int w2s_wgrad_grid_y(int cin, int cout, int taps, int dil); /* grid.y of w2s_wgrad: slab floats = nslab*cout*cin*taps */
 /* grad (+)= sum_s slab[s]; layout 0: grad[o][c][j] (torch Conv1d), 1: grad[o][j][c] (Linear over the flattened taps) */
 int w2s_wgrad_reduce(const float* slab, int nslab, float* grad, int cout, int cin, int taps, int dil, int accumulate, int layout, void* stream);
+/* the reductions of many layers in one launch per 48 jobs (jobs: HOST array); jobs of one call must target distinct grads */
+typedef struct w2s_reduce_job {
+  const float* slab; float* grad;
+  int32_t nslab, cout, cin, taps, dil, accumulate, layout, reserved;
+} w2s_reduce_job;
+int w2s_wgrad_reduce_batch(const w2s_reduce_job* jobs, int njobs, void* stream);
 
 /* [cout][cin][taps] (torch) -> fwd pack [cout][taps][cin] and/or bwd pack [cin][taps][cout]; either dst may be NULL */
 int w2s_repack(const float* w, float* fwd, float* bwd, int cout, int cin, int taps, void* stream);
+/* the same for many layers at once (jobs: HOST array; any of the output pointers may be NULL, bf16 planes in pairs): the
+ * ~130 per-layer repacks after an optimiser step become 3 launches */
+typedef struct w2s_repack_job {
+  const float* w; float* fwd; float* bwd; void* fwd_hi; void* fwd_lo; void* bwd_hi; void* bwd_lo;
+  int32_t cout, cin, taps, reserved;
+} w2s_repack_job;
+int w2s_repack_batch(const w2s_repack_job* jobs, int njobs, void* stream);
 /* same layouts as bf16 (hi, lo) planes with w = hi + lo: operands of the split-precision ("bf16x3") path; planes may be NULL in pairs */
 int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, void* bwd_lo, int cout, int cin, int taps, void* stream);
 

@@ -10,6 +10,7 @@ P4="WRITE_SIZE"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
+  if [ -n "$PMC_PASSES" ] && [ $i -gt $PMC_PASSES ]; then break; fi
   rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 tools/kbench.py $CASE --iters 3 > $OUT.p$i.log 2>&1 || true
 done
 python3 - <<PY
@@ -18,7 +19,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('$OUT/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name'][:60]
-        if 'conv_cl' in k or 'wgrad_kernel' in k or 'bwd_fused' in k:
+        if 'conv_cl' in k or 'wgrad_' in k or 'bwd_fused' in k:
             agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,d in agg.items():
     print(k)

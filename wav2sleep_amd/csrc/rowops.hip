@@ -96,12 +96,70 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// C = 128: 32 lanes x float4 per row; a wave covers 2 rows per step and keeps U = 4 steps (8 rows) of loads in flight
+// (the one-row-per-wave form above is latency-bound: 75 dependent row round trips per wave on the 76 800-token tensors).
+__global__ __launch_bounds__(256) void layernorm_bwd128_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ rstat, const float* __restrict__ gadd,
+                                                               float* __restrict__ gx, int ldgx, float* __restrict__ part_gamma,
+                                                               float* __restrict__ part_beta, int rows, int gelu) {
+  constexpr int C = 128, U = 4;
+  __shared__ float red[2][8][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 5, c0 = (lane & 31) * 4;
+  const f32x4 gm = ld4(gamma + c0), bt = ld4(beta + c0);
+  f32x4 dg = {0, 0, 0, 0}, db = {0, 0, 0, 0};
+  for (int base = blockIdx.x * (8 * U); base < rows; base += gridDim.x * (8 * U)) {
+    f32x4 xv[U], gv[U], ga[U];
+    float mean[U], rstd[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = base + (u * 4 + wave) * 2 + sub;
+      const bool ok = row < rows;
+      xv[u] = ok ? ld4(x + (size_t)row * ldx + c0) : (f32x4){0, 0, 0, 0};
+      gv[u] = ok ? ld4(g + (size_t)row * ldg + c0) : (f32x4){0, 0, 0, 0};
+      ga[u] = (ok && gadd) ? ld4(gadd + (size_t)row * ldgx + c0) : (f32x4){0, 0, 0, 0};
+      mean[u] = ok ? rstat[2 * (size_t)row] : 0.f;
+      rstd[u] = ok ? rstat[2 * (size_t)row + 1] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = base + (u * 4 + wave) * 2 + sub;
+      const f32x4 xh = (xv[u] - mean[u]) * rstd[u];
+      f32x4 gn = gv[u];
+      if (gelu) gn = gn * gelu_grad4(gm * xh + bt);
+      dg += gn * xh;
+      db += gn;
+      const f32x4 t = gm * gn, tx = t * xh;
+      float a = (t.x + t.y) + (t.z + t.w), bs = (tx.x + tx.y) + (tx.z + tx.w);
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); bs += __shfl_xor(bs, m); }
+      a *= (1.0f / C); bs *= (1.0f / C);
+      const f32x4 o = rstd[u] * (t - a - xh * bs) + ga[u];
+      if (row < rows) st4(gx + (size_t)row * ldgx + c0, o);
+    }
+  }
+  st4(&red[0][wave * 2 + sub][c0], dg);
+  st4(&red[1][wave * 2 + sub][c0], db);
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    float s0 = red[0][0][c], s1 = red[1][0][c];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { s0 += red[0][k][c]; s1 += red[1][k][c]; }
+    part_gamma[(size_t)blockIdx.x * C + c] = s0;
+    part_beta[(size_t)blockIdx.x * C + c] = s1;
+  }
+}
+
 extern "C" int w2s_layernorm_bwd(const float* g, int ldg, const float* x, int ldx, const float* gamma, const float* beta, const float* rstat,
                                  const float* gadd, float* gx, int ldgx, float* part_gamma, float* part_beta, int rows, int C, int gelu,
                                  int nparts, void* stream) {
   if (!g || !x || !gamma || !beta || !rstat || !gx || !part_gamma || !part_beta || nparts <= 0) return W2S_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (C == 128) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nparts), dim3(256), 0, s, g, ldg, x, ldx, gamma, beta, rstat, gadd, gx, ldgx, part_gamma, part_beta, rows, gelu);
+  const bool vec = !((ldg | ldx | ldgx) & 3) && !(((uintptr_t)g | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)gadd | (uintptr_t)gamma | (uintptr_t)beta) & 15);
+  if (C == 128 && vec) hipLaunchKernelGGL(layernorm_bwd128_kernel, dim3(nparts), dim3(256), 0, s, g, ldg, x, ldx, gamma, beta, rstat, gadd, gx, ldgx, part_gamma, part_beta, rows, gelu);
+  else if (C == 128) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nparts), dim3(256), 0, s, g, ldg, x, ldx, gamma, beta, rstat, gadd, gx, ldgx, part_gamma, part_beta, rows, gelu);
   else if (C == 64) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nparts), dim3(256), 0, s, g, ldg, x, ldx, gamma, beta, rstat, gadd, gx, ldgx, part_gamma, part_beta, rows, gelu);
   else if (C == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nparts), dim3(256), 0, s, g, ldg, x, ldx, gamma, beta, rstat, gadd, gx, ldgx, part_gamma, part_beta, rows, gelu);
   else return W2S_EINVAL;
@@ -133,8 +191,42 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
     __syncthreads();
   }
 }
+// float4 form: 16 column lanes (64 columns) x 16 row lanes per pass, 4 rows of loads in flight per thread
+__global__ __launch_bounds__(256) void colsum_rows4_kernel(const float* __restrict__ g, int rows, int C, int ldg, float* __restrict__ part) {
+  __shared__ float red[16][68];
+  const int per = (rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + cl * 4;
+    f32x4 s = {0, 0, 0, 0};
+    if (c < C) {
+      int r = r0 + rl;
+      for (; r + 48 < r1; r += 64) {
+        const f32x4 a0 = ld4(g + (size_t)r * ldg + c), a1 = ld4(g + (size_t)(r + 16) * ldg + c);
+        const f32x4 a2 = ld4(g + (size_t)(r + 32) * ldg + c), a3 = ld4(g + (size_t)(r + 48) * ldg + c);
+        s += (a0 + a1) + (a2 + a3);
+      }
+      for (; r < r1; r += 16) s += ld4(g + (size_t)r * ldg + c);
+    }
+    st4(&red[rl][cl * 4], s);
+    __syncthreads();
+    if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+      float t = red[0][threadIdx.x];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) t += red[k][threadIdx.x];
+      part[(size_t)blockIdx.x * C + c0 + threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+}
 extern "C" int w2s_bias_grad(const float* g, int rows, int C, int ldg, float* part, int nparts, void* stream) {
   if (!g || !part || nparts <= 0) return W2S_EINVAL;
+  if (!(C & 3) && !(ldg & 3) && !((uintptr_t)g & 15)) {
+    hipLaunchKernelGGL(colsum_rows4_kernel, dim3(nparts), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, rows, C, ldg, part);
+    W2S_CHECK_LAUNCH();
+    return W2S_OK;
+  }
   hipLaunchKernelGGL(colsum_rows_kernel, dim3(nparts), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, rows, C, ldg, part);
   W2S_CHECK_LAUNCH();
   return W2S_OK;

@@ -385,12 +385,11 @@ __global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
 
 // sum slabs in a fixed order (16 slab-lanes x sequential chunks, then a fixed LDS tree); decode the fragment
 // index to (o, j, c); write torch layout grad[o][c][j] (layout 0) or [o][j][c] (layout 1).  Deterministic.
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, float* __restrict__ grad, int cout,
-                                                           int cin, int taps, int NTO, int NTC, int TAPS_T, int accumulate, int layout) {
-  __shared__ float red[64][17];
+__device__ __forceinline__ void wgrad_reduce_block(float (*red)[17], int blk, const float* __restrict__ slab, int nslab, float* __restrict__ grad,
+                                                   int cout, int cin, int taps, int NTO, int NTC, int TAPS_T, int accumulate, int layout) {
   const size_t per = (size_t)cout * cin * taps;  // floats per slab
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const size_t idx = (size_t)blockIdx.x * 16 + el;
+  const size_t idx = (size_t)blk * 16 + el;
   float s = 0.f;
   if (idx < per)
     for (int k = sl; k < nslab; k += 64) s += slab[(size_t)k * per + idx];
@@ -411,6 +410,24 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   const int c = c_t * 16 + (lane & 15);
   float* d = layout ? grad + ((size_t)o * taps + j) * cin + c : grad + ((size_t)o * cin + c) * taps + j;
   *d = accumulate ? (*d + s) : s;
+}
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, float* __restrict__ grad, int cout,
+                                                           int cin, int taps, int NTO, int NTC, int TAPS_T, int accumulate, int layout) {
+  __shared__ float red[64][17];
+  wgrad_reduce_block(red, blockIdx.x, slab, nslab, grad, cout, cin, taps, NTO, NTC, TAPS_T, accumulate, layout);
+}
+
+// Several layers' slab reductions in ONE launch (a backward pass has ~130 of them, most a few microseconds long):
+// the job table travels by value in the kernel arguments; block -> job through the running block counts.
+#define W2S_REDUCE_BATCH 48
+struct ReduceJobD { const float* slab; float* grad; int nslab, cout, cin, taps, nto, ntc, tapst, flags, blk0; };
+struct ReduceBatch { ReduceJobD j[W2S_REDUCE_BATCH]; int njobs; };
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(ReduceBatch T) {
+  __shared__ float red[64][17];
+  int k = 0;
+  while (k + 1 < T.njobs && (int)blockIdx.x >= T.j[k + 1].blk0) ++k;
+  const ReduceJobD& J = T.j[k];
+  wgrad_reduce_block(red, blockIdx.x - J.blk0, J.slab, J.nslab, J.grad, J.cout, J.cin, J.taps, J.nto, J.ntc, J.tapst, J.flags & 1, (J.flags >> 1) & 1);
 }
 
 struct WgCfg { int nto, ntc, tapst, ts, nw, ot; };
@@ -598,6 +615,70 @@ extern "C" int w2s_wgrad_reduce(const float* slab, int nslab, float* grad, int c
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 15) / 16)), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), slab,
                      nslab, grad, cout, cin, taps, c.nto, c.ntc, c.tapst, accumulate, layout);
   W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+extern "C" int w2s_wgrad_reduce_batch(const w2s_reduce_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs <= 0) return W2S_EINVAL;
+  for (int base = 0; base < njobs; base += W2S_REDUCE_BATCH) {
+    ReduceBatch T;
+    T.njobs = (njobs - base < W2S_REDUCE_BATCH) ? njobs - base : W2S_REDUCE_BATCH;
+    int blocks = 0;
+    for (int i = 0; i < T.njobs; ++i) {
+      const w2s_reduce_job& q = jobs[base + i];
+      if (!q.slab || !q.grad || q.nslab <= 0) return W2S_EINVAL;
+      const WgCfg c = wg_cfg(q.cin, q.cout, q.taps, q.dil);
+      const size_t per = (size_t)q.cout * q.cin * q.taps;
+      T.j[i] = ReduceJobD{q.slab, q.grad, q.nslab, q.cout, q.cin, q.taps, c.nto, c.ntc, c.tapst, (q.accumulate ? 1 : 0) | (q.layout ? 2 : 0), blocks};
+      blocks += (int)((per + 15) / 16);
+    }
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), T);
+    W2S_CHECK_LAUNCH();
+  }
+  return W2S_OK;
+}
+
+// all layers' repacks (fp32 kernel layouts + bf16 hi/lo planes) of one optimiser step in a few launches
+#define W2S_REPACK_BATCH 48
+struct RepackJobD { const float* w; float* fwd; float* bwd; __bf16* fh; __bf16* fl; __bf16* bh; __bf16* bl; int cout, cin, taps, blk0; };
+struct RepackBatch { RepackJobD j[W2S_REPACK_BATCH]; int njobs; };
+__global__ __launch_bounds__(256) void repack_batch_kernel(RepackBatch T) {
+  int k = 0;
+  while (k + 1 < T.njobs && (int)blockIdx.x >= T.j[k + 1].blk0) ++k;
+  const RepackJobD& J = T.j[k];
+  const size_t n = (size_t)J.cout * J.cin * J.taps;
+  const size_t idx = (size_t)(blockIdx.x - J.blk0) * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int j = idx % J.taps;
+  const int c = (idx / J.taps) % J.cin;
+  const int o = idx / ((size_t)J.taps * J.cin);
+  const float v = J.w[idx];
+  const size_t df = ((size_t)o * J.taps + j) * J.cin + c, db = ((size_t)c * J.taps + j) * J.cout + o;
+  if (J.fwd) J.fwd[df] = v;
+  if (J.bwd) J.bwd[db] = v;
+  if (J.fh || J.bh) {
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    if (J.fh) { J.fh[df] = h; J.fl[df] = l; }
+    if (J.bh) { J.bh[db] = h; J.bl[db] = l; }
+  }
+}
+extern "C" int w2s_repack_batch(const w2s_repack_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs <= 0) return W2S_EINVAL;
+  for (int base = 0; base < njobs; base += W2S_REPACK_BATCH) {
+    RepackBatch T;
+    T.njobs = (njobs - base < W2S_REPACK_BATCH) ? njobs - base : W2S_REPACK_BATCH;
+    int blocks = 0;
+    for (int i = 0; i < T.njobs; ++i) {
+      const w2s_repack_job& q = jobs[base + i];
+      if (!q.w || (q.fwd_hi && !q.fwd_lo) || (q.bwd_hi && !q.bwd_lo)) return W2S_EINVAL;
+      T.j[i] = RepackJobD{q.w, q.fwd, q.bwd, static_cast<__bf16*>(q.fwd_hi), static_cast<__bf16*>(q.fwd_lo), static_cast<__bf16*>(q.bwd_hi),
+                          static_cast<__bf16*>(q.bwd_lo), q.cout, q.cin, q.taps, blocks};
+      blocks += (int)(((size_t)q.cout * q.cin * q.taps + 255) / 256);
+    }
+    hipLaunchKernelGGL(repack_batch_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T);
+    W2S_CHECK_LAUNCH();
+  }
   return W2S_OK;
 }
 

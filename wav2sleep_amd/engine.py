@@ -84,6 +84,7 @@ class Engine:
         self._bf = {}  # data_ptr of a weight operand -> (hi plane, lo plane)
         self._bfbuf = {}
         self._streams = {}
+        self._rjobs = []
         lib.load()
 
     # ------------------------------------------------------------------ weights
@@ -116,6 +117,7 @@ class Engine:
 
     def pack(self, need_bwd: bool = True):
         """torch-layout weights -> kernel layouts ([cout][taps][cin] forward, [cin][taps][cout] data-gradient)."""
+        jobs = []
         for name, cout, cin, taps, nf, nb in self._pack_list():
             if name not in self.P:  # stand-alone sub-module engines hold only their own parameters
                 continue
@@ -126,8 +128,7 @@ class Engine:
                 self.PB[name] = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
             f = self.PF.get(name) if nf else None
             bw = self.PB.get(name) if (nb and need_bwd) else None
-            if f is not None or bw is not None:
-                lib.repack(w, f, bw, cout, cin, taps)
+            fh = fl = bh = bl = None
             if self.split_precision:
                 # forward operand (packed copy, or the torch tensor itself when taps == 1) and data-gradient operand
                 fop = f if f is not None else w
@@ -140,12 +141,13 @@ class Engine:
                                         torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16))
                 fh, fl = planes['f'] if want_f else (None, None)
                 bh, bl = planes['b'] if want_b else (None, None)
-                if want_f or want_b:
-                    lib.repack_bf16(w, fh, fl, bh, bl, cout, cin, taps)
                 if want_f:
                     self._bf[fop.data_ptr()] = (fh, fl)
                 if want_b:
                     self._bf[bw.data_ptr()] = (bh, bl)
+            if f is not None or bw is not None or fh is not None or bh is not None:
+                jobs.append((w, f, bw, fh, fl, bh, bl, cout, cin, taps))
+        lib.repack_batch(jobs)  # every layer of the model in ceil(n / 48) launches
 
     def ensure_packed(self, key, need_bwd: bool):
         key = (key, need_bwd or (self._pack_key is not None and self._pack_key[1]))
@@ -210,7 +212,7 @@ class Engine:
         slab = self._slab(g.device, nslab, cout * cin * taps)
         lib.wgrad(g=g, x=x, slab=slab, nslab=nslab, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad,
                   dil=dil, split_precision=self.split_precision, **kw)
-        lib.wgrad_reduce(slab, nslab, self.G[name], cout, cin, taps, dil, accumulate=name in self._written, layout=layout)
+        self._rjobs.append((slab, nslab, self.G[name], cout, cin, taps, dil, name in self._written, layout))
         self._written.add(name)
 
     def _bwd_fused(self, name, *, g, y, st_k, bst_k, pro, xin, st_in, add_even, gout, want_part, B, Lg, Lh, cg, ch, stride):
@@ -223,13 +225,19 @@ class Engine:
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
                       part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, split_precision=self.split_precision)
-        lib.wgrad_reduce(slab, nslab, self.G[name], cg, ch, 3, 1, accumulate=name in self._written, layout=0)
+        self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         return self._bstats(part, B, nt, ch, Lh) if want_part else None
 
+    def _flush_reduce(self):
+        """Deterministic slab sums of every weight gradient queued since the last flush, in one launch per 48 layers
+        (on the current stream; a weight appears at most once per flush)."""
+        jobs, self._rjobs = self._rjobs, []
+        lib.wgrad_reduce_batch(jobs)
+
     def _colgrad(self, name, g, rows, C, ldg=None):
         """G[name][c] = sum_rows g[row, c]  (bias / CLS gradients)."""
-        nparts = max(1, min(256, _cdiv(rows, 64)))
+        nparts = max(1, min(1024, _cdiv(rows, 64)))
         part = torch.empty(nparts, C, device=g.device, dtype=torch.float32)
         lib.bias_grad(g, rows, C, C if ldg is None else ldg, part, nparts)
         lib.colsum(part, nparts, C, self.G[name], accumulate=name in self._written)
@@ -456,6 +464,7 @@ class Engine:
         if self.G is None:
             raise RuntimeError('engine was built without gradient buffers')
         self._written = set(self.G.keys()) if accumulate else set()
+        self._rjobs = []
         B, S, D, N, F = c['B'], c['S'], c['D'], c['N'], sp.feature_dim
         dev = glogits.device
         nc = sp.num_classes
@@ -482,7 +491,7 @@ class Engine:
                 cv = blk['convs'][j]
                 p = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.'
                 gy = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-                npl = max(1, min(128, _cdiv(rows, 16)))
+                npl = max(1, min(1024, _cdiv(rows, 32)))
                 pg = torch.empty(npl, F, device=dev, dtype=torch.float32)
                 pb = torch.empty(npl, F, device=dev, dtype=torch.float32)
                 lib.layernorm_bwd(gh, F, cv['y'], F, P[p + 'norm.weight'], P[p + 'norm.bias'], cv['rs'], None, gy, F, pg, pb, rows, F, True, npl)
@@ -540,6 +549,7 @@ class Engine:
             gX = gXn
         # CLS parameter: sum of the token-0 rows' gradients
         self._colgrad('epoch_mixer.register_tokens', gX, N, F, ldg=D * F)
+        self._flush_reduce()
 
         if hook is not None:
             hook('_tail')  # mixer + sequence CNN + classifier gradients are final: their all-reduce can start
@@ -552,6 +562,7 @@ class Engine:
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 self._encoder_backward(ec, gX.view(-1)[(1 + m) * F:], D * F)
+                self._flush_reduce()
                 if hook is not None and ec['enc'] not in encs[m + 1:]:
                     hook(ec['enc'])
         for e in dict.fromkeys(encs):
@@ -565,7 +576,7 @@ class Engine:
 
     def _ln_bwd(self, pfx, g, x, rstat, gadd, gx, rows):
         F = self.spec.feature_dim
-        npl = max(1, min(256, _cdiv(rows, 16)))
+        npl = max(1, min(1024, _cdiv(rows, 32)))
         pg = torch.empty(npl, F, device=g.device, dtype=torch.float32)
         pb = torch.empty(npl, F, device=g.device, dtype=torch.float32)
         lib.layernorm_bwd(g, F, x, F, self.P[pfx + '.weight'], self.P[pfx + '.bias'], rstat, gadd, gx, F, pg, pb, rows, F, False, npl)

@@ -32,13 +32,21 @@ class ConvArgs(C.Structure):
                                     'ldx', 'ldy', 'ldy2', 'ld_aux', 'pro', 'epi')]
 
 
+class ReduceJob(C.Structure):
+    _fields_ = [('slab', _fp), ('grad', _fp)] + [(n, _i32) for n in ('nslab', 'cout', 'cin', 'taps', 'dil', 'accumulate', 'layout', 'reserved')]
+
+
+class RepackJob(C.Structure):
+    _fields_ = [(n, _fp) for n in ('w', 'fwd', 'bwd', 'fwd_hi', 'fwd_lo', 'bwd_hi', 'bwd_lo')] + [(n, _i32) for n in ('cout', 'cin', 'taps', 'reserved')]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [(n, _fp) for n in ('g', 'g2', 'g_stats', 'g_bstats', 'x', 'x_stats', 'slab')] + \
                [(n, _i32) for n in ('B', 'L_in', 'L_out', 'cin', 'cout', 'taps', 'stride', 'dil', 'pad', 'ldg', 'ldx',
                                     'pro_g', 'pro_h', 'nslab', 'split_precision')]
 
 
-EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_repack', 'w2s_repack_bf16',
+EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
            'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
@@ -253,6 +261,29 @@ def wgrad_slabs_per_block(cin, cout, taps, dil=1) -> int:
 
 def wgrad_grid_y(cin, cout, taps, dil=1) -> int:
     return load().w2s_wgrad_grid_y(cin, cout, taps, dil)
+
+
+def wgrad_reduce_batch(jobs):
+    """jobs: list of (slab, nslab, grad, cout, cin, taps, dil, accumulate, layout); one launch per 48 jobs."""
+    if not jobs:
+        return
+    arr = (ReduceJob * len(jobs))()
+    for q, (slab, nslab, grad, cout, cin, taps, dil, accumulate, layout) in zip(arr, jobs):
+        q.slab, q.grad = _f(slab), _f(grad)
+        q.nslab, q.cout, q.cin, q.taps, q.dil, q.accumulate, q.layout = nslab, cout, cin, taps, dil, int(accumulate), layout
+    _chk(load().w2s_wgrad_reduce_batch(arr, len(jobs), _stream()), 'w2s_wgrad_reduce_batch')
+
+
+def repack_batch(jobs):
+    """jobs: list of (w, fwd, bwd, fwd_hi, fwd_lo, bwd_hi, bwd_lo, cout, cin, taps); tensors or None."""
+    if not jobs:
+        return
+    arr = (RepackJob * len(jobs))()
+    for q, (w, fwd, bwd, fh, fl, bh, bl, cout, cin, taps) in zip(arr, jobs):
+        q.w, q.fwd, q.bwd = _f(w), _f(fwd), _f(bwd)
+        q.fwd_hi, q.fwd_lo, q.bwd_hi, q.bwd_lo = _p(fh), _p(fl), _p(bh), _p(bl)
+        q.cout, q.cin, q.taps = cout, cin, taps
+    _chk(load().w2s_repack_batch(arr, len(jobs), _stream()), 'w2s_repack_batch')
 
 
 def wgrad_reduce(slab, nslab, grad, cout, cin, taps, dil=1, accumulate=False, layout=0):
