@@ -194,6 +194,10 @@ int w2s_head_bwd(const float* pre, int ld, const float* w, const float* glogits,
 int w2s_sumsq_partial(const float* g, long n, float* part, int nparts, void* stream);
 int w2s_clip_coef(const float* part, int nparts, const float* hyper, float* normcoef, void* stream);
 int w2s_adamw(float* p, const float* g, float* m, float* v, long n, const float* hyper, const float* normcoef, void* stream);
+/* EMACallback on the flat parameter buffer (trainer/callbacks.py:55-64): ema = decay*ema + (1-decay)*p, evaluated as the
+ * reference's mul_ then add_(alpha) (two roundings); w2s_swap exchanges two buffers in place (callbacks.py:84-98). */
+int w2s_ema_update(float* ema, const float* p, long n, float decay, void* stream);
+int w2s_swap(float* a, float* b, long n, void* stream);
 
 /* ---- device-side input pipeline (data/dataset.py:76-87,174-182, trainer/main.py:342-353, masker.py:49-50) ----
  * w2s_zscore: y[row] = (x[row]-mean)/max(std_unbiased, eps) per row of T samples (rows with a non-finite value are copied);

@@ -129,3 +129,19 @@ def test_target_instantiation_of_reference_config(tmp_path):
         W.load_model(str(tmp_path / 'nope'), device='cpu')
     with pytest.raises(ValueError):
         api.instantiate({'_target_': 'os.system'})
+
+
+def test_ema_callback_and_checkpoint_api_surface():
+    """trainer/callbacks.py:33-34 argument check, hook names and state-dict schema (no device work on CPU)."""
+    import inspect
+    import wav2sleep_amd as W
+    with pytest.raises(ValueError):
+        W.EMACallback(decay=1.5)
+    cb = W.EMACallback(decay=0.999, start_step=10, device='cpu')
+    for hook in ('setup', 'on_train_batch_end', 'on_validation_epoch_start', 'on_validation_epoch_end', 'on_test_epoch_start',
+                 'on_test_epoch_end', 'on_train_end', 'state_dict', 'load_state_dict'):
+        assert callable(getattr(cb, hook))
+    assert cb.state_dict() == {'ema_state_dict': None, 'step_count': 0}
+    cb.on_train_batch_end(None, None, None, None, 0)          # before setup(): counts the step, touches nothing
+    assert cb.state_dict()['step_count'] == 1 and not cb._should_update()
+    assert list(inspect.signature(W.EMACallback.__init__).parameters) == ['self', 'decay', 'start_step', 'device']

@@ -39,7 +39,7 @@ def to_dev(x):
     return {k: v.to(DEV) for k, v in x.items()}
 
 
-@pytest.mark.parametrize('stage', ['conv', 'split', 'stats', 'dil', 'dgrad', 'wgrad', 'rowops', 'attn', 'head'])
+@pytest.mark.parametrize('stage', ['conv', 'split', 'fusedbf', 'stats', 'dil', 'dgrad', 'wgrad', 'rowops', 'attn', 'head'])
 def test_kernels_against_cpu_torch(stage):
     """Every C-ABI kernel family against the stock CPU op it replaces (tools/gpu_check.py)."""
     from tools import gpu_check as G
@@ -337,3 +337,115 @@ def test_subset_evaluation_reuses_encoders_exactly():
     losses = mod.validation_step((xd, y.to(DEV)), ds_name='mesa')
     assert set(losses) == set(subs) and all(torch.isfinite(v) for v in losses.values())
     assert int(mod.aux_outputs['val']['ECG_THX']['mesa'].sum()) == int((y != -1).sum())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# EMA of the weights and Lightning checkpoint interop (trainer/callbacks.py:12-128, trainer/main.py:299-334)
+# ------------------------------------------------------------------------------------------------------------------
+def _small_module(seed=3, sm=None, **kw):
+    sm = sm or {'ECG': 'ECG', 'THX': 'THX'}
+    cfg = O.ModelConfig(signal_map=sm, num_classes=4)
+    model = build(sm, 4, dropout=0.0)
+    model.load_state_dict(O.make_state_dict(cfg, seed=seed))
+    model.to(DEV)
+    return cfg, W.SleepModule(model, num_classes=4, flip_polarity=False, **kw)
+
+
+def test_ema_callback_follows_the_reference_update_rule_and_swaps_exactly():
+    cfg, mod = _small_module()
+    x, y = O.make_inputs(cfg, 2, 4, seed=21)
+    batch = (to_dev(x), y.to(DEV))
+    cb = W.EMACallback(decay=0.9, start_step=2)
+    cb.setup(None, mod, 'fit')
+    want = {k: v.detach().cpu().clone() for k, v in mod.model.state_dict().items()}   # reference: clone of the state dict at setup
+    for k in range(4):
+        mod.training_step(batch)
+        cb.on_train_batch_end(None, mod, None, batch, k)
+        if k + 1 >= 2:                                                                 # callbacks.py:51-64
+            for name, p in mod.model.state_dict().items():
+                want[name].mul_(0.9).add_(p.detach().cpu(), alpha=1 - 0.9)
+    got = cb.state_dict()
+    assert got['step_count'] == 4 and list(got['ema_state_dict']) == ['model.' + k for k in want]
+    for k, v in want.items():
+        torch.testing.assert_close(got['ema_state_dict']['model.' + k].cpu(), v, rtol=1e-6, atol=1e-7)
+    # swap in for validation, swap back: bit-exact both ways; forward uses the swapped-in weights
+    orig = {k: v.detach().clone() for k, v in mod.model.state_dict().items()}
+    cb.on_validation_epoch_start(None, mod)
+    for k, v in mod.model.state_dict().items():
+        assert torch.equal(v, got['ema_state_dict']['model.' + k].to(DEV))
+    mod.model.eval()
+    lg_ema = mod.model(batch[0])
+    assert_logits_close(lg_ema.detach().cpu(), O.forward({k: v.detach().cpu() for k, v in mod.model.state_dict().items()}, cfg, x))
+    cb.on_validation_epoch_end(None, mod)
+    for k, v in mod.model.state_dict().items():
+        assert torch.equal(v, orig[k])
+    # checkpoint round trip of the callback state, then adoption at train end
+    cb2 = W.EMACallback(decay=0.9, start_step=2)
+    cb2.load_state_dict(got, pl_module=mod)
+    assert cb2._step_count == 4
+    cb2.on_train_end(None, mod)
+    for k, v in mod.model.state_dict().items():
+        assert torch.equal(v, got['ema_state_dict']['model.' + k].to(DEV))
+
+
+def test_lightning_checkpoint_roundtrip_resumes_bit_exactly(tmp_path):
+    cfg, a = _small_module(seed=3)
+    x, y = O.make_inputs(cfg, 2, 4, seed=22)
+    batch = (to_dev(x), y.to(DEV))
+    for _ in range(2):
+        a.training_step(batch)
+    path = W.save_lightning_checkpoint(str(tmp_path / 'checkpoints' / 'last' / 'last.ckpt'), a, epoch=1)
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    names = list(a.model.state_dict())
+    assert list(ck['state_dict']) == ['model.' + n for n in names] and ck['global_step'] == 2 and ck['gradient_clip_val'] == 1.0
+    # the optimiser section is a valid torch.optim.AdamW state dict for the same parameter list
+    ref_params = [torch.nn.Parameter(v.clone()) for v in ck['state_dict'].values()]
+    opt = torch.optim.AdamW(ref_params, lr=1e-3, weight_decay=1e-4)
+    opt.load_state_dict(ck['optimizer_states'][0])
+    assert int(opt.state[ref_params[0]]['step']) == 2
+    # reference-side restore (log.py:50-60): state_dict -> module.load_state_dict with the `model.` prefix
+    _, b = _small_module(seed=77)
+    W.load_lightning_checkpoint(path, b)
+    la, lb = a.training_step(batch), b.training_step(batch)
+    assert float(la) == float(lb) and b.trainer.step_count == 3
+    for (k, va), vb in zip(a.model.state_dict().items(), b.model.state_dict().values()):
+        assert torch.equal(va, vb), k
+    assert torch.equal(a.trainer.m, b.trainer.m) and torch.equal(a.trainer.v, b.trainer.v)
+
+
+def test_resume_from_a_torch_adamw_checkpoint_matches_the_oracle_continuation():
+    """A checkpoint as the REFERENCE stack writes it (torch.optim.AdamW.state_dict(), `model.`-prefixed weights):
+    loading it and taking one more step must land where the CPU oracle lands when it continues from the same state."""
+    sm = {'ECG': 'ECG', 'THX': 'THX'}
+    cfg = O.ModelConfig(signal_map=sm, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=5)
+    x, y = O.make_inputs(cfg, 2, 4, seed=23)
+    st = {}
+    for _ in range(2):
+        O.train_step(sd, cfg, x, y, st)
+    names = [n for n, _ in build(sm, 4).named_parameters()]   # torch.optim state is indexed in model.parameters() order
+    assert sorted(names) == sorted(sd)
+    opt_state = {'state': {i: {'step': torch.tensor(2.0), 'exp_avg': st['m.' + n].clone(), 'exp_avg_sq': st['v.' + n].clone()}
+                           for i, n in enumerate(names)},
+                 'param_groups': [{'lr': O.exp_warmup_lr(2), 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 1e-4, 'amsgrad': False,
+                                   'initial_lr': 1e-3, 'params': list(range(len(names)))}]}
+    ck = {'state_dict': {'model.' + k: v.clone() for k, v in sd.items()}, 'optimizer_states': [opt_state], 'global_step': 2, 'epoch': 0,
+          'gradient_clip_val': 1.0, 'gradient_clip_algorithm': 'norm'}
+    _, mod = _small_module(seed=99)
+    W.load_lightning_checkpoint(ck, mod, restore_rng=False)
+    loss_o, _, gn_o, lr_o = O.train_step(sd, cfg, x, y, st)
+    out = mod.trainer.step(to_dev(x), y.to(DEV))
+    assert out['lr'] == pytest.approx(lr_o) and float(out['loss']) == pytest.approx(float(loss_o), rel=1e-4)
+    assert float(out['grad_norm']) == pytest.approx(gn_o, rel=2e-3)
+    for k, v in mod.model.state_dict().items():
+        torch.testing.assert_close(v.cpu(), sd[k], rtol=0, atol=2e-6)
+
+
+def test_save_model_folder_is_what_load_model_reads(tmp_path):
+    cfg, mod = _small_module(seed=8)
+    W.save_model(str(tmp_path / 'model'), mod.model)
+    again = W.load_model(str(tmp_path / 'model'), device='cuda')
+    x, _ = O.make_inputs(cfg, 2, 4, seed=24)
+    mod.model.eval()
+    assert torch.equal(again(to_dev(x)), mod.model(to_dev(x)))
+    assert again.config_dict() == mod.model.config_dict()

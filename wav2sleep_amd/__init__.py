@@ -2,6 +2,8 @@
 (wav2sleep_amd/csrc -> libw2s_hip.so, C ABI in include/w2s.h) behind the reference's own module surface."""
 from . import inputs, settings, trainer  # noqa: F401
 from .api import load_model, predict  # noqa: F401
+from .checkpoint import (EMACallback, lightning_checkpoint, load_lightning_checkpoint, save_lightning_checkpoint,  # noqa: F401
+                         save_model)
 from .stats import cohens_kappa, confusion_accuracy  # noqa: F401
 from .trainer import (ExpWarmUpScheduler, FusedTrainStep, SignalMasker, SleepLightningModule, SleepModule,  # noqa: F401
                       exp_warmup_lr, invert_signals)
@@ -9,4 +11,5 @@ from .wav2sleep import MultiModalAttentionEmbedder, SequenceCNN, SignalEncoders,
 
 __all__ = ['Wav2Sleep', 'SignalEncoders', 'MultiModalAttentionEmbedder', 'SequenceCNN', 'load_model', 'predict', 'FusedTrainStep',
            'SleepModule', 'SleepLightningModule', 'SignalMasker', 'invert_signals', 'ExpWarmUpScheduler', 'exp_warmup_lr',
-           'cohens_kappa', 'confusion_accuracy']
+           'cohens_kappa', 'confusion_accuracy', 'EMACallback', 'lightning_checkpoint', 'save_lightning_checkpoint',
+           'load_lightning_checkpoint', 'save_model']

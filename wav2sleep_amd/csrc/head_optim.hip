@@ -229,4 +229,38 @@ extern "C" int w2s_adamw(float* p, const float* g, float* m, float* v, long n, c
   return W2S_OK;
 }
 
+// ---- exponential moving average of the weights on the flat buffer (trainer/callbacks.py:61-64) and the in-place exchange
+//      used to evaluate with the averaged weights (callbacks.py:84-98): one launch each for all 183 tensors
+__global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ ema, const float* __restrict__ p, size_t n, float decay) {
+  const float a = 1.0f - decay;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float e = ema[i] * decay;   // ema.mul_(decay).add_(p, alpha=1-decay): two rounded steps, like the reference
+    e = e + a * p[i];
+    ema[i] = e;
+  }
+}
+__global__ __launch_bounds__(256) void swap_kernel(float* __restrict__ a, float* __restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float t = a[i];
+    a[i] = b[i];
+    b[i] = t;
+  }
+}
+extern "C" int w2s_ema_update(float* ema, const float* p, long n, float decay, void* stream) {
+  if (!ema || !p || n <= 0 || !(decay >= 0.0f && decay <= 1.0f)) return W2S_EINVAL;
+  size_t blocks = ((size_t)n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ema, p, (size_t)n, decay);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+extern "C" int w2s_swap(float* a, float* b, long n, void* stream) {
+  if (!a || !b || n <= 0) return W2S_EINVAL;
+  size_t blocks = ((size_t)n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(swap_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b, (size_t)n);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
 extern "C" const char* w2s_version(void) { return "w2s-hip 0.1 (gfx950, fp32 MFMA)"; }

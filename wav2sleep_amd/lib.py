@@ -50,7 +50,7 @@ EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y',
            'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
-           'w2s_clip_coef', 'w2s_adamw', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_version']
+           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_version']
 
 _lib = None
 
@@ -381,6 +381,14 @@ def clip_coef(part, nparts, hyper, normcoef):
 
 def adamw(p, g, m, v, n, hyper, normcoef):
     _chk(load().w2s_adamw(_f(p), _f(g), _f(m), _f(v), C.c_long(n), _f(hyper), _f(normcoef), _stream()), 'w2s_adamw')
+
+
+def ema_update(ema, p, n, decay):
+    _chk(load().w2s_ema_update(_f(ema), _f(p), C.c_long(n), C.c_float(decay), _stream()), 'w2s_ema_update')
+
+
+def swap(a, b, n):
+    _chk(load().w2s_swap(_f(a), _f(b), C.c_long(n), _stream()), 'w2s_swap')
 
 
 def zscore(x, y, rows, T, part, nblk, eps, stats_out=None):

@@ -335,6 +335,24 @@ class Wav2Sleep(nn.Module):
     def predict(self, x: dict[str, Tensor]) -> Tensor:
         return self(x).argmax(axis=2)
 
+    def config_dict(self) -> dict:
+        """The resolved `model/wav2sleep.yaml` tree (Hydra `_target_` keys of the REFERENCE package) that rebuilds this
+        model: what log.py:75-83 stores as `config.yaml` next to `state_dict.pth`."""
+        se, em, sm = self.signal_encoders, self.epoch_mixer, self.sequence_mixer
+        t = 'wav2sleep.models.wav2sleep.'
+        return {
+            '_target_': t + 'Wav2Sleep', 'num_classes': self.num_classes,
+            'signal_encoders': {'_target_': t + 'SignalEncoders', 'signal_map': dict(se.signal_map), 'feature_dim': se.feature_dim,
+                                'activation': 'gelu', 'norm': 'instance', 'causal': False, 'chunk_causal': False,
+                                'initial_channels': se.initial_channels, 'max_channels': se.max_channels, 'output_norm': False,
+                                'use_residual': True},
+            'epoch_mixer': {'_target_': t + 'MultiModalAttentionEmbedder', 'feature_dim': em.feature_dim, 'dropout': em.dropout_p,
+                            'activation': 'gelu', 'layers': em.num_layers, 'dim_ff': em.dim_ff, 'nhead': em.nhead},
+            'sequence_mixer': {'_target_': t + 'SequenceCNN', 'feature_dim': self.feature_dim, 'dropout': sm.dropout_p, 'activation': 'gelu',
+                               'norm': 'layer', 'causal': False, 'num_layers': sm.num_layers, 'kernel_size': sm.kernel_size,
+                               'num_dilations': sm.num_dilations},
+        }
+
     @torch.no_grad()
     def forward_subsets(self, x: dict[str, Tensor], subsets) -> dict:
         """Logits for several signal subsets of ONE batch with every encoder run once (inference).
