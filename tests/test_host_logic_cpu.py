@@ -1,4 +1,6 @@
 """CPU-only tests of the host side that mirrors the reference's interface (no kernels run)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -145,3 +147,80 @@ def test_ema_callback_and_checkpoint_api_surface():
     cb.on_train_batch_end(None, None, None, None, 0)          # before setup(): counts the step, touches nothing
     assert cb.state_dict()['step_count'] == 1 and not cb._should_update()
     assert list(inspect.signature(W.EMACallback.__init__).parameters) == ['self', 'decay', 'start_step', 'device']
+
+
+# ---- parquet in -> .preds.csv out (data/dataset.py:132-183, api.py:193-222); host logic only ------------
+def _write_recording(path, epochs, cols=('ECG', 'THX'), labels=True, datetime_index=False, seed=0):
+    """A model-ready parquet file as preprocessing.py leaves it: one row per timestamp of the fastest signal, slower
+    signals and the 30-s stage labels NaN elsewhere."""
+    import pandas as pd
+    from wav2sleep_amd.settings import COLS_TO_SAMPLES_PER_EPOCH as SPE
+    rng = np.random.default_rng(seed)
+    frames = []
+    for c in cols:
+        n = epochs * SPE[c]
+        t = np.arange(n) * (30.0 / SPE[c])
+        frames.append(pd.Series(rng.standard_normal(n).astype(np.float32) * 3 + 1, index=t, name=c))
+    if labels:
+        st = rng.integers(0, 5, epochs).astype(np.float64)
+        st[1] = np.nan                                       # an unscored epoch: dropna() would shorten the column ...
+        frames.append(pd.Series(st, index=np.arange(epochs) * 30.0 + 1e-3, name='Stage').fillna(7.0))   # ... so mark it out-of-map
+    df = pd.concat(frames, axis=1).sort_index()
+    df.index.name = 'Timestamp'
+    if datetime_index:
+        df.index = pd.Timestamp('2024-01-01 22:00:00') + pd.to_timedelta(df.index, unit='s')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    df.to_parquet(path)
+    return df
+
+
+def test_parquet_dataset_matches_reference_contract(tmp_path):
+    import os as _os
+    fp = str(tmp_path / 'site' / 'rec1.parquet')
+    df = _write_recording(fp, epochs=5)
+    ds = W.ParquetDataset([fp], columns=['ECG', 'PPG', 'THX'], num_classes=4, require_labels=True, max_length_hours=None)
+    x, y = ds[0]
+    assert list(x) == ['ECG', 'THX', 'PPG'] and x['ECG'].shape == (5 * 1024,) and x['THX'].shape == (5 * 256,)
+    assert torch.isinf(x['PPG']).all() and x['PPG'].shape == (5 * 1024,)                       # absent column: -inf (dataset.py:170-173)
+    ecg = torch.from_numpy(df['ECG'].dropna().values).float()
+    torch.testing.assert_close(x['ECG'], O.zscore_normalize(ecg))                               # host z-score == oracle restatement
+    stages = df['Stage'].dropna().values
+    want = torch.tensor([{0: 0, 1: 1, 2: 1, 3: 2, 4: 3}.get(int(s), -1) for s in stages]).float()
+    assert torch.equal(y, want) and y[1] == -1
+    raw = W.ParquetDataset([fp], columns=['ECG', 'THX'], normalize_on_device=True)[0][0]
+    assert torch.equal(raw['ECG'], ecg)                                                         # device mode hands over raw samples
+    short = W.ParquetDataset([fp], columns=['ECG'], max_length_hours=0)                         # truncation to max_length_epochs
+    assert short[0][0]['ECG'].numel() == 0 and short[0][1].numel() == 0
+    with pytest.raises(ValueError):
+        W.ParquetDataset([fp], columns=['EEG'])
+    with pytest.raises(ValueError):
+        W.ParquetDataset([fp], columns=['PPG'])[0]                                              # no relevant column in the file
+    with pytest.raises(ValueError):
+        W.load_dataset(str(tmp_path / 'empty'), ['ECG'])
+    with pytest.raises(NotImplementedError):
+        W.ParquetDataset([fp], columns=['ECG'], causal=True)
+
+
+def test_save_predictions_tree_timestamps_and_overwrite(tmp_path):
+    import pandas as pd
+    src, out = tmp_path / 'pq', tmp_path / 'out'
+    _write_recording(str(src / 'a' / 'r1.parquet'), epochs=4, seed=1)
+    _write_recording(str(src / 'b' / 'c' / 'r2.parquet'), epochs=4, labels=False, datetime_index=True, seed=2)
+    ds = W.load_dataset(str(src), ['ECG', 'THX'], num_classes=4, max_length_hours=10)
+    assert sorted(ds.files) == sorted([str(src / 'a' / 'r1.parquet'), str(src / 'b' / 'c' / 'r2.parquet')]) and ds.normalize_on_device
+    preds = torch.tensor([[0, 1, 2, 3], [3, 2, 1, 0]])
+    labels = torch.tensor([[0., 1., -1., 2.], [1., 1., 1., 1.]])
+    W.save_predictions(preds, str(src), str(out), ds, labels=labels)
+    i1 = ds.files.index(str(src / 'a' / 'r1.parquet'))
+    t1 = pd.read_csv(out / 'a' / 'r1.preds.csv')
+    assert list(t1.columns) == ['Timestamp', 'Pred', 'Stage'] and list(t1['Timestamp']) == [30.0, 60.0, 90.0, 120.0]   # api.py:212
+    assert list(t1['Pred']) == preds[i1].tolist() and list(t1['Stage']) == labels[i1].tolist()
+    t2 = pd.read_csv(out / 'b' / 'c' / 'r2.preds.csv', index_col=0, parse_dates=True)
+    assert t2.index[0] == pd.Timestamp('2024-01-01 22:00:30') and t2.index[-1] == pd.Timestamp('2024-01-01 22:02:00')
+    W.save_predictions(preds + 1, str(src), str(out), ds, labels=None)                           # existing files are kept ...
+    assert list(pd.read_csv(out / 'a' / 'r1.preds.csv')['Pred']) == preds[i1].tolist()
+    W.save_predictions((preds + 1) % 4, str(src), str(out), ds, labels=None, overwrite=True)     # ... unless overwrite
+    t1 = pd.read_csv(out / 'a' / 'r1.preds.csv')
+    assert list(t1.columns) == ['Timestamp', 'Pred'] and list(t1['Pred']) == ((preds[i1] + 1) % 4).tolist()
+    with pytest.raises(ValueError):
+        W.predict_on_folder(str(src), str(out))                                                  # neither model nor model_folder

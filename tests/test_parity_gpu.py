@@ -8,6 +8,8 @@ Tolerances (north_star asks logits within 1e-3 rtol and identical arg-max stage 
            W2S_EXACT_FP32=1 everything is fp32 MFMA and the error is ~2e-5);  arg-max labels: exactly equal
   gradients: relative L2 error per parameter tensor <= 2e-3 (observed ~3e-4)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -449,3 +451,61 @@ def test_save_model_folder_is_what_load_model_reads(tmp_path):
     mod.model.eval()
     assert torch.equal(again(to_dev(x)), mod.model(to_dev(x)))
     assert again.config_dict() == mod.model.config_dict()
+
+
+def _have_parquet():
+    try:
+        import pyarrow  # noqa: F401
+        return True
+    except Exception:  # noqa: BLE001
+        return False
+
+
+def test_predict_with_device_side_normalisation_matches_host_order_of_operations():
+    """api.predict on a dataset that hands over RAW recordings (normalize_on_device=True): z-score as one kernel per signal
+    after the transfer == the reference's per-file host z-score followed by the forward (dataset.py:76-87, api.py:163-190)."""
+    sm = {'ECG': 'ECG', 'THX': 'THX', 'PPG': 'PPG'}
+    cfg = O.ModelConfig(signal_map=sm, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=31)
+    model = build(sm, 4)
+    model.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    raw = [{'ECG': torch.randn(6 * 1024, generator=g) * 40 + 7, 'THX': torch.randn(6 * 256, generator=g) * 0.01 - 3,
+            'PPG': torch.full((6 * 1024,), float('-inf'))} for _ in range(3)]
+    ys = [torch.randint(-1, 4, (6,), generator=g).float() for _ in range(3)]
+
+    class Raw(list):
+        normalize_on_device = True
+    preds, labels = W.predict(model.to(DEV).eval(), Raw(zip(raw, ys)), device='cuda', batch_size=2, num_workers=0)
+    for i in range(3):
+        x = {k: (O.zscore_normalize(v) if torch.isfinite(v).all() else v)[None] for k, v in raw[i].items()}
+        assert torch.equal(preds[i], O.predict(sd, cfg, x)[0]) and torch.equal(labels[i], ys[i])
+
+
+@pytest.mark.skipif(not _have_parquet(), reason='pyarrow not importable on this box (parquet I/O is host-side plumbing; covered on CPU)')
+def test_predict_on_folder_parquet_to_csv_matches_oracle(tmp_path):
+    """SURVEY 8 f-2 (api.py:225-301): parquet tree -> device z-score -> forward -> arg-max -> `.preds.csv` tree."""
+    import pandas as pd
+    from tests.test_host_logic_cpu import _write_recording
+    sm = {'ECG': 'ECG', 'THX': 'THX', 'PPG': 'PPG'}
+    cfg = O.ModelConfig(signal_map=sm, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=31)
+    model = build(sm, 4)
+    model.load_state_dict(sd)
+    src, out = tmp_path / 'pq', tmp_path / 'out'
+    for i, sub in enumerate(['n1/a.parquet', 'n1/b.parquet', 'n2/c.parquet']):
+        _write_recording(str(src / sub), epochs=6, cols=('ECG', 'THX'), seed=40 + i)           # PPG absent -> -inf rows
+    preds, labels = W.predict_on_folder(str(src), str(out), model=model, device='cuda', batch_size=2, num_workers=0, preprocess=True,
+                                        max_length_hours=10, return_tensors=True)
+    assert preds.shape == (3, 6) and labels is not None and labels.shape == (3, 6)
+    host = W.ParquetDataset(W.load_dataset(str(src), list(sm)).files, columns=list(sm), require_labels=False)   # reference order of operations
+    for i in range(3):
+        x, y = host[i]
+        want = O.predict(sd, cfg, {k: v[None] for k, v in x.items()})[0]
+        assert torch.equal(preds[i], want) and torch.equal(labels[i], y)
+        rel = os.path.relpath(host.files[i], str(src))
+        t = pd.read_csv(str(out / rel).replace('.parquet', '.preds.csv'))
+        assert list(t['Pred']) == want.tolist() and list(t['Timestamp']) == [30.0 * (k + 1) for k in range(6)]
+        assert list(t['Stage']) == y.tolist()
+    with pytest.raises(ValueError):
+        W.predict_on_folder(str(src), str(out), model=model, signals=['EEG'], preprocess=False)

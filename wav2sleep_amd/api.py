@@ -76,6 +76,9 @@ def predict(model, dataset, device: str = 'auto', batch_size: int = 4, num_worke
     preds, labels = [], []
     for x, yb in loader:
         x = {k: v.to(device) for k, v in x.items()}
+        if getattr(dataset, 'normalize_on_device', False):  # raw samples: per-recording z-score as one kernel per signal
+            from .inputs import zscore_normalize
+            x = zscore_normalize(x)
         preds.append(model(x).argmax(dim=-1))
         labels.append(yb)
     preds = torch.cat(preds, dim=0).cpu()
