@@ -1,5 +1,6 @@
 // C-ABI entry of the channels-last implicit-GEMM convolution; kernels live in conv_cl.inl and are
 // instantiated per geometry in conv_inst_*.hip (split only to parallelise the build).
+#include <cstdlib>
 #include "w2s_common.h"
 
 static inline int pick_nt(int cout) { return cout >= 128 ? 8 : cout >= 64 ? 4 : cout >= 32 ? 2 : 1; }
@@ -8,6 +9,7 @@ int w2s_conv_dispatch_32(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_12(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_11(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_71d(const w2s_conv_args& a, hipStream_t s);
+int w2s_conv_dispatch_71(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_44d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_33d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_up2(const w2s_conv_args& a, hipStream_t s);
@@ -29,7 +31,15 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
     return w2s_conv_dispatch_up2(a, s);
   }
   if (a.mode == W2S_MODE_DILATED) {
-    if (a.taps == 7 && a.stride == 1) return w2s_conv_dispatch_71d(a, s);
+    if (a.taps == 7 && a.stride == 1) {
+      // whole dilated window (64-position tile + 6*dil halo rows, hi/lo planes or fp32) in LDS: single staging
+      if (a.dil >= 1 && (size_t)(64 + 6 * a.dil) * (a.cin + 8) * 4 <= 150 * 1024 && !getenv("W2S_SEQ_PER_TAP")) {
+        w2s_conv_args b = a;
+        b.mode = W2S_MODE_CONTIG;
+        return w2s_conv_dispatch_71(b, s);
+      }
+      return w2s_conv_dispatch_71d(a, s);
+    }
     if (a.taps == 4 && a.stride == 4) return w2s_conv_dispatch_44d(a, s);
     if (a.taps == 3 && a.stride == 3) return w2s_conv_dispatch_33d(a, s);
     return W2S_EINVAL;

@@ -190,10 +190,13 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   };
 
   if (MODE == W2S_MODE_CONTIG) {
-    stage(t0 * STRIDE - a.pad, (TM - 1) * STRIDE + TAPS, 1);
+    // one staged window serves every tap (dilated taps included: rows j*dil apart -- the SequenceCNN convs up to
+    // dilation 32 fit the 160 KB LDS and run with ONE global->LDS round trip instead of one per tap)
+    const int dil = (TAPS > 1 && a.dil > 1) ? a.dil : 1;
+    stage(t0 * STRIDE - a.pad, (TM - 1) * STRIDE + (TAPS - 1) * dil + 1, 1);
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < TAPS; ++j) mma_tap(j, a.flip ? (TAPS - 1 - j) : j, (1 << MT) - 1);
+    for (int j = 0; j < TAPS; ++j) mma_tap(j, (a.flip ? (TAPS - 1 - j) : j) * dil, (1 << MT) - 1);
   } else if (MODE == W2S_MODE_DILATED) {
     for (int j = 0; j < TAPS; ++j) {
       const int off = a.flip ? (TAPS - 1 - j) : j;
@@ -293,18 +296,18 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
 // tile configuration: (NT n-tiles per workgroup, MT m-tiles per wave, WN waves along channels); TM = 16*MT*(4/WN).
 // accumulators MT*NT/WN <= 16 float4 (64 VGPRs); staged window <= 72 KB so two workgroups share a CU.
 static inline int pick_nt(int cout) { return cout >= 128 ? 8 : cout >= 64 ? 4 : cout >= 32 ? 2 : 1; }
-static inline int window_rows(int tm, int taps, int stride, int mode) {
-  if (mode == W2S_MODE_CONTIG) return (tm - 1) * stride + taps;
+static inline int window_rows(int tm, int taps, int stride, int mode, int dil = 1) {
+  if (mode == W2S_MODE_CONTIG) return (tm - 1) * stride + (taps - 1) * dil + 1;
   if (mode == W2S_MODE_DILATED) return tm;
   return tm / 2 + 1;
 }
 struct TileCfg { int nt, mt, wn; };
-static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode, int B, int L_out) {
+static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode, int B, int L_out, int dil = 1) {
   TileCfg c;
   c.nt = pick_nt(cout);
   c.wn = (c.nt >= 4) ? 2 : 1;
   c.mt = 4;
-  if ((size_t)window_rows(16 * c.mt * (4 / c.wn), taps, stride, mode) * (cin + 4) * 4 > 72 * 1024) c.mt = 2;
+  if ((size_t)window_rows(16 * c.mt * (4 / c.wn), taps, stride, mode, dil) * (cin + 4) * 4 > 72 * 1024) c.mt = 2;
   { static const char* e = getenv("W2S_FORCE_MT"); if (e && c.nt >= 4) c.mt = atoi(e); }  // tuning only
   { static const char* e = getenv("W2S_FORCE_NT"); if (e && c.nt >= 8) c.nt = atoi(e); }  // tuning only
   { static const char* e = getenv("W2S_NO_SHRINK"); if (e) return c; }                    // tuning only
@@ -327,7 +330,7 @@ static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
   ConvP P;
   P.a = a;
   P.ntiles = (a.L_out + TM - 1) / TM;
-  const int NR = window_rows(TM, TAPS, STRIDE, MODE);
+  const int NR = window_rows(TM, TAPS, STRIDE, MODE, a.dil > 0 ? a.dil : 1);
   P.nr_lds = NR;
   size_t lds = BF ? (size_t)2 * NR * (a.cin + 8) * 2 : (size_t)NR * (a.cin + 4) * sizeof(float);
   size_t red = (size_t)4 * (NT / WN) * 4 * 8 * sizeof(float);
@@ -346,7 +349,7 @@ static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
 
 template <int TAPS, int STRIDE, int MODE, int PRO, int EPI>
 static int dispatch_cfg(const w2s_conv_args& a, hipStream_t s) {
-  const TileCfg c = pick_cfg(a.cin, a.cout, TAPS, STRIDE, MODE, a.B, a.L_out);
+  const TileCfg c = pick_cfg(a.cin, a.cout, TAPS, STRIDE, MODE, a.B, a.L_out, a.dil > 0 ? a.dil : 1);
   if (a.cout % (c.nt * 16)) return W2S_EINVAL;
   // split-precision path: caller supplied bf16 weight planes (>= 32 input and output channels)
   const bool bf = a.w_hi && a.w_lo && a.cin >= 32 && c.nt >= 2;
