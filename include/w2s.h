@@ -119,7 +119,9 @@ typedef struct w2s_repack_job {
   int32_t cout, cin, taps, reserved;
 } w2s_repack_job;
 int w2s_repack_batch(const w2s_repack_job* jobs, int njobs, void* stream);
-/* same layouts as bf16 (hi, lo) planes with w = hi + lo: operands of the split-precision ("bf16x3") path; planes may be NULL in pairs */
+/* the same two GEMM operands (rows o x K = taps*cin, rows c x K = taps*cout) as bf16 (hi, lo) planes with w = hi + lo, stored
+ * fragment-major: element (row, k) at (((row/16)*(K/32) + k/32)*64 + ((k%32)/8)*16 + row%16)*8 + k%8, so that one wave fetch of a
+ * 16x32 MFMA operand is a contiguous 1 KB run; operands of the split-precision ("bf16x3") path; planes may be NULL in pairs */
 int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, void* bwd_lo, int cout, int cin, int taps, void* stream);
 
 /*

@@ -70,7 +70,7 @@ def t_conv_split_precision():
         x = torch.randn(B, cin, L); w = torch.randn(cout, cin, taps) / math.sqrt(cin * taps)
         want = F.conv1d(x.double(), w.double(), stride=stride, padding=pad, dilation=dil).float()
         Lo = want.shape[-1]
-        wp = pack_fwd(w).to(dev); wh = wp.bfloat16(); wl = (wp - wh.float()).bfloat16()
+        wp = pack_fwd(w).to(dev); wh, wl = lib.frag_major_planes(wp.view(cout, taps * cin))
         y = torch.zeros(B, Lo, cout, device=dev)
         lib.conv_forward(lib.conv_args(x=cl(x).to(dev), w=wp, w_hi=wh, w_lo=wl, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
                                        pad=pad, dil=dil, mode=mode))
@@ -79,7 +79,7 @@ def t_conv_split_precision():
     cin, cout, L = 128, 128, 256
     x = torch.randn(B, cin, L, requires_grad=True); w = torch.randn(cout, cin, 3) / 20
     yv = F.conv1d(x, w, stride=2, padding=1); gy = torch.randn_like(yv); yv.backward(gy)
-    wb = w.permute(1, 2, 0).contiguous().to(dev); wh = wb.bfloat16(); wl = (wb - wh.float()).bfloat16()
+    wb = w.permute(1, 2, 0).contiguous().to(dev); wh, wl = lib.frag_major_planes(wb.view(cin, 3 * cout))
     gx = torch.zeros(B, L, cin, device=dev)
     lib.conv_forward(lib.conv_args(x=cl(gy).to(dev), w=wb, w_hi=wh, w_lo=wl, y=gx, B=B, L_in=L // 2, L_out=L, cin=cout, cout=cin, taps=3, stride=2, pad=1,
                                    mode=lib.MODE_UP2))

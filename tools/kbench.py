@@ -28,7 +28,7 @@ def conv_case(cin, cout, L, stride=1, pro=lib.PRO_IN_GELU, epi=lib.EPI_STATS, B=
     part = torch.empty(B, (Lo + tile - 1) // tile, 2, cout, device=dev)
     wh = wl = None
     if os.environ.get('BF') == '1':
-        wh = w.bfloat16(); wl = (w - wh.float()).bfloat16()
+        wh, wl = lib.frag_major_planes(w.view(cout, taps * cin))
     a = lib.conv_args(w_hi=wh, w_lo=wl, x=x, x2=x2 if pro >= lib.PRO_INBWD else None, w=w, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
                       pad=(1 if taps == 3 else 0) if pad is None else pad, dil=dil, bias=torch.randn(cout, device=dev) if epi == lib.EPI_BIAS else None, flip=flip, mode=mode, pro=pro, epi=epi, pro_stats=st, pro_bstats=bst, aux=aux, aux_stats=ost if aux is not None else None,
                       part=part if epi in (lib.EPI_STATS, lib.EPI_GP) else None)
@@ -87,6 +87,9 @@ CASES = {
     'w64': lambda: wgrad_case(64, 64, 61440),
     'f128': lambda: conv_case(128, 128, 15360),
     'f128n': lambda: conv_case(128, 128, 15360, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN),
+    'f64n': lambda: conv_case(64, 64, 61440, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN),
+    'f128g': lambda: conv_case(128, 128, 15360, pro=lib.PRO_GELU, epi=lib.EPI_PLAIN),
+    'f128s': lambda: conv_case(128, 128, 15360, pro=lib.PRO_NONE, epi=lib.EPI_STATS),
     'd128': lambda: conv_case(128, 128, 15360, pro=lib.PRO_INBWD, epi=lib.EPI_GP, flip=1),
     'w128': lambda: wgrad_case(128, 128, 15360),
     'qkv': lambda: conv_case(128, 384, 76800, B=1, taps=1, pro=lib.PRO_NONE, epi=lib.EPI_BIAS),

@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
         }
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-          const size_t wo = (size_t)(n0 + wn0 + nt * 16 + r) * K + jw * cin + q * 32 + 8 * g;
+          // fragment-major planes [cout/16][K/32][lane][8] (w2s_frag_index): the wave's 64 x 16 B are ONE contiguous 1 KB run
+          // (8 full cache lines) -- row-major weights made every fetch 16 separate 64-B segments, and the texture-address
+          // path (~40 cycles per such instruction), not the matrix pipe, set the pace of the >= 64-channel layers.
+          const size_t wo = ((size_t)((n0 + wn0) / 16 + nt) * (K >> 5) + (size_t)(jw * cin + q * 32) / 32) * 512 + lane * 8;
           ah[nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_hi) + wo);
           al[nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_lo) + wo);
         }

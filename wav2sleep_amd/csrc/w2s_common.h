@@ -8,6 +8,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// Element index of A[row][k] (row = output channel of the GEMM, k in [0, K), K % 32 == 0, rows % 16 == 0) in the
+// fragment-major bf16 weight planes of the split-precision conv: [row/16][k/32][lane = ((k%32)/8)*16 + row%16][k%8], i.e. the
+// 16 B a lane feeds to v_mfma_f32_16x16x32_bf16 are contiguous and a wave's fetch of one fragment is one 1 KB run.
+__host__ __device__ inline size_t w2s_frag_index(int row, int k, int K) {
+  return (((size_t)(row >> 4) * (K >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (row & 15)) * 8 + (k & 7);
+}
+
 #define W2S_CHECK_LAUNCH()                                   \
   do {                                                       \
     if (hipGetLastError() != hipSuccess) return W2S_ELAUNCH; \

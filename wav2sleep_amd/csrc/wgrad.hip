@@ -659,8 +659,8 @@ __global__ __launch_bounds__(256) void repack_batch_kernel(RepackBatch T) {
   if (J.fh || J.bh) {
     const __bf16 h = (__bf16)v;
     const __bf16 l = (__bf16)(v - (float)h);
-    if (J.fh) { J.fh[df] = h; J.fl[df] = l; }
-    if (J.bh) { J.bh[db] = h; J.bl[db] = l; }
+    if (J.fh) { const size_t d = w2s_frag_index(o, j * J.cin + c, J.taps * J.cin); J.fh[d] = h; J.fl[d] = l; }
+    if (J.bh) { const size_t d = w2s_frag_index(c, j * J.cout + o, J.taps * J.cout); J.bh[d] = h; J.bl[d] = l; }
   }
 }
 extern "C" int w2s_repack_batch(const w2s_repack_job* jobs, int njobs, void* stream) {
@@ -695,8 +695,9 @@ __global__ void repack_kernel(const float* __restrict__ w, float* __restrict__ f
   if (bwd) bwd[((size_t)c * taps + j) * cout + o] = v;
 }
 
-// torch [cout][cin][taps] fp32 -> bf16 hi/lo planes (w = hi + lo up to 2^-17 relative) in the forward [cout][taps][cin]
-// and data-gradient [cin][taps][cout] layouts, for the split-precision matrix-core path of conv_cl.
+// torch [cout][cin][taps] fp32 -> bf16 hi/lo planes (w = hi + lo up to 2^-17 relative) of the forward GEMM operand
+// A_f[o][j*cin + c] and the data-gradient operand A_b[c][j*cout + o], both in the fragment-major order of w2s_frag_index
+// (needs cin, cout multiples of 32 / 16 as the split-precision path does), for conv_cl.
 __global__ void repack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ fh, __bf16* __restrict__ fl, __bf16* __restrict__ bh,
                                    __bf16* __restrict__ bl, int cout, int cin, int taps) {
   const size_t n = (size_t)cout * cin * taps;
@@ -708,8 +709,8 @@ __global__ void repack_bf16_kernel(const float* __restrict__ w, __bf16* __restri
   const float v = w[idx];
   const __bf16 h = (__bf16)v;
   const __bf16 l = (__bf16)(v - (float)h);
-  if (fh) { const size_t d = ((size_t)o * taps + j) * cin + c; fh[d] = h; fl[d] = l; }
-  if (bh) { const size_t d = ((size_t)c * taps + j) * cout + o; bh[d] = h; bl[d] = l; }
+  if (fh) { const size_t d = w2s_frag_index(o, j * cin + c, taps * cin); fh[d] = h; fl[d] = l; }
+  if (bh) { const size_t d = w2s_frag_index(c, j * cout + o, taps * cout); bh[d] = h; bl[d] = l; }
 }
 
 extern "C" int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, void* bwd_lo, int cout, int cin, int taps,

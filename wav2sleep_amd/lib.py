@@ -263,6 +263,16 @@ def wgrad_grid_y(cin, cout, taps, dil=1) -> int:
     return load().w2s_wgrad_grid_y(cin, cout, taps, dil)
 
 
+def frag_major_planes(a_RK: torch.Tensor):
+    """[rows, K] fp32 GEMM operand -> (hi, lo) bf16 planes in the fragment-major order the split-precision conv reads
+    (include/w2s.h, w2s_repack_bf16); rows % 16 == 0, K % 32 == 0.  Tooling / tests; the engine uses w2s_repack_batch."""
+    R, K = a_RK.shape
+    hi = a_RK.bfloat16()
+    lo = (a_RK - hi.float()).bfloat16()
+    f = lambda t: t.view(R // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+    return f(hi), f(lo)
+
+
 def wgrad_reduce_batch(jobs):
     """jobs: list of (slab, nslab, grad, cout, cin, taps, dil, accumulate, layout); one launch per 48 jobs."""
     if not jobs:
