@@ -136,7 +136,13 @@ int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, vo
 int w2s_bwd_fused_tile(int cg, int ch);
 int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                   const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
-                  int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, void* stream);
+                  int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
+                  void* stream);
+/* gpre != NULL (conv1 of a residual block; stride 1, split_precision, add_even NULL, w2s_bwd_fused_folds_residual(cg, ch)): the
+ * block's 1x1/stride-2 residual branch (blocks.py:44-47,68) is folded in -- gout additionally receives Wd^T gpre[t/2] at even t
+ * before the GELU' factor (gpre: [B][Lh/2][cg] = dL/d(block pre-activation), wd: [ch][cg]) and slab_d receives nslab raw-fragment
+ * slabs of the downsample weight gradient -> w2s_wgrad_reduce(slab_d, nslab, grad_wd, cg, ch, 1, 1, ...). */
+int w2s_bwd_fused_folds_residual(int cg, int ch);
 
 /* partial sums [B][ntiles][2][C] -> per-(b,c) pairs [B][C][2]: kind 0 = (mean, rstd) with biased variance + eps
  * (nn.InstanceNorm1d, models/utils.py:89-92), kind 1 = (sum1, sum2)/count.  fp64 accumulation, fixed order. */

@@ -278,7 +278,38 @@ def t_fused_split_precision():
             for nm, a, b in zip(('gout', 'part', 'wgrad'), outs[1], outs[0]):
                 report(f'fused bf16x3 {cg}->{ch} s{stride} L{Lh} {nm}', a, b, tol=2e-4)
 
-STAGES = dict(fusedbf=t_fused_split_precision, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+def t_fused_residual_fold():
+    """conv1 fused backward with the residual branch folded in vs (1x1 conv + add_even) and the separate downsample wgrad."""
+    for cg, ch in ((16, 16), (32, 16)):
+        for Lh in (1000, 256, 4098):
+            B, Lg = 3, Lh
+            g = torch.randn(B, Lg, cg, device=dev); y = torch.randn(B, Lg, cg, device=dev); xin = torch.randn(B, Lh, ch, device=dev)
+            st = torch.rand(B, cg, 2, device=dev) + 0.5; bst = torch.rand(B, cg, 2, device=dev) * 0.01
+            gpre = torch.randn(B, Lh // 2, cg, device=dev)
+            wb = torch.randn(ch, 3, cg, device=dev) / 7; wd = torch.randn(ch, 1, cg, device=dev) / 5
+            tile = lib.bwd_fused_tile(cg, ch); nt = (Lh + tile - 1) // tile; ns = min(B * nt, 5)
+            # reference arm: R = Wd^T gpre via a 1x1 conv, then add_even; downsample wgrad via w2s_wgrad on GELU(xin)
+            Rr = torch.zeros(B, Lh // 2, ch, device=dev)
+            lib.conv_forward(lib.conv_args(x=gpre, w=wd.view(ch, cg), y=Rr, B=B, L_in=Lh // 2, L_out=Lh // 2, cin=cg, cout=ch, taps=1, stride=1, pad=0))
+            outs = []
+            for fold in (False, True):
+                gout = torch.zeros(B, Lh, ch, device=dev); slab = torch.zeros(ns * cg * ch * 3, device=dev); grad = torch.zeros(cg, ch, 3, device=dev)
+                slab_d = torch.zeros(ns * cg * ch, device=dev) if fold else None
+                lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=lib.PRO_INBWD, xin=xin, st_in=None, add_even=None if fold else Rr, wb=wb, gout=gout,
+                              part=None, slab=slab, nslab=ns, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=1, split_precision=True,
+                              gpre=gpre if fold else None, wd=wd.view(ch, cg) if fold else None, slab_d=slab_d)
+                lib.wgrad_reduce(slab, ns, grad, cg, ch, 3, 1, accumulate=False, layout=0)
+                gd = torch.zeros(cg, ch, 1, device=dev)
+                if fold:
+                    lib.wgrad_reduce(slab_d, ns, gd, cg, ch, 1, 1, accumulate=False, layout=0)
+                outs.append((gout, grad, gd))
+            h = F.gelu(xin)[:, 0:2 * (Lh // 2):2, :]                                  # h[2u]
+            want_gd = torch.einsum('buo,buc->oc', gpre.double().cpu(), h.double().cpu()).float().view(cg, ch, 1)
+            report(f'fold {cg}->{ch} L{Lh} gout', outs[1][0], outs[0][0], tol=2e-4)
+            report(f'fold {cg}->{ch} L{Lh} wgrad', outs[1][1], outs[0][1], tol=2e-4)
+            report(f'fold {cg}->{ch} L{Lh} downsample wgrad', outs[1][2], want_gd, tol=2e-4)
+
+STAGES = dict(fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

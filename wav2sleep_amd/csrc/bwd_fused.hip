@@ -21,6 +21,9 @@ struct BwdP {
   const float* xin; const float* st_in; const float* add_even; const float* wb;
   float* gout; float* part; float* slab;
   int B, Lg, Lh, ntiles, pro;
+  // residual fold (conv1 of a block, split-precision kernel only): gpre = dL/d(block pre-activation) [B][Lh/2][GC],
+  // wd = 1x1/stride-2 downsample weight as [HC][GC], slab_d = its weight-gradient slabs (one per workgroup)
+  const float* gpre; const float* wd; float* slab_d;
 };
 
 // LDS row strides: 16-channel rows stay unpadded (64-B rows: the three windows + weights of the 16x16 kernel then fit
@@ -308,18 +311,25 @@ __device__ __forceinline__ f32x4 mfma_bf3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x
   return c;
 }
 
-template <int CG, int CH, int MT, int UP2>
+// RD = 1 (conv1 of a residual block, stride 1): the block's 1x1/stride-2 residual branch is folded in -- its data gradient
+// Wd^T gpre[t/2] (even t) rides in the K axis of the conv's own data gradient (16 channels: the unused half of the second
+// K step; 32 channels: one more K step), and its weight gradient sum_u gpre[u] x h[2u] comes from the h window that is
+// already staged.  Replaces a 1x1 conv launch (+ its output tensor, written and re-read) and a weight-gradient launch that
+// re-read both gpre and the block input.
+__host__ __device__ constexpr int bf_rs(int c) { return c == 16 ? 16 : c + 8; }  // 32-B rows are conflict-free as they are
+template <int CG, int CH, int MT, int UP2, int RD>
 __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 64 * MT;
   constexpr int GC = CG * 16, HC = CH * 16;
-  constexpr int RSg = GC + 8, RSh = HC + 8, RSn = bwd_rs(HC);   // bf16 / bf16 / float elements per row
+  constexpr int RSg = bf_rs(GC), RSh = bf_rs(HC), RSn = bwd_rs(HC);   // bf16 / bf16 / float elements per row
+  static_assert(!(RD && UP2), "the residual fold belongs to the stride-1 conv1");
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2;
   constexpr int NRh = UP2 ? TM + 1 : TM + 2;
   // data-gradient K axis of the LDS weight image.  32 gradient channels: k = tap*32 + o (one tap per MFMA).
   // 16 gradient channels: two taps share one K = 32 step: stride 1: [tap0 | tap1] [tap2 | 0];
   // stride 2 (even outputs use tap 1, odd outputs taps 2 and 0): [tap1 | 0] [tap2 | tap0].
-  constexpr int KD = (GC == 32) ? 96 : 64;
+  constexpr int KD = (GC == 32) ? (RD ? 128 : 96) : 64;   // RD: [tap2 | Wd] (16 ch) / a fourth K step = Wd (32 ch)
   constexpr int WROW = KD + 8;
   float* nL = reinterpret_cast<float*>(smem4);              // [TM][RSn] normalised input of the centre rows
   float* red = nL + TM * RSn;                               // [4][CH][4][8] stats scratch
@@ -329,6 +339,9 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   __bf16* hLo = hH + NRh * RSh;
   __bf16* wH = hLo + NRh * RSh;                             // [HC][WROW]
   __bf16* wLo = wH + HC * WROW;
+  constexpr int NRp = RD ? TM / 2 + 1 : 0;                  // gpre rows of the tile + one all-zero row (odd output positions)
+  __bf16* pH = wLo + HC * WROW;
+  __bf16* pLo = pH + NRp * RSg;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4, q4 = r >> 2, p4 = r & 3;
   const int Lg = P.Lg, Lh = P.Lh;
@@ -337,16 +350,19 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   // pair and take every KW-th k-step (summed through LDS at the end, fixed order)
   constexpr int NWT = CG * CH, KW = 4 / NWT;
   const int wt = wave / KW, wk = wave % KW, wi = wt / CH, wc = wt % CH;
-  f32x4 accw[3];
+  f32x4 accw[3], accd = {0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < 3; ++j) accw[j] = (f32x4){0, 0, 0, 0};
+  if (RD) {  // the zero row of the gpre planes
+    for (int i = tid; i < RSg / 4; i += 256) split_store4(pH, pLo, (TM / 2) * RSg + i * 4, (f32x4){0, 0, 0, 0});
+  }
 
   for (int i = tid; i < HC * (KD / 4); i += 256) {
     const int row = i / (KD / 4), k = (i % (KD / 4)) * 4;
     const float* wr = P.wb + (size_t)row * (3 * GC);
     f32x4 v = {0, 0, 0, 0};
-    if (GC == 32) v = ld4(wr + k);
-    else if (!UP2) { if (k < 48) v = ld4(wr + k); }
+    if (GC == 32) v = (k < 96) ? ld4(wr + k) : ld4(P.wd + (size_t)row * GC + (k - 96));
+    else if (!UP2) { if (k < 48) v = ld4(wr + k); else if (RD) v = ld4(P.wd + (size_t)row * GC + (k - 48)); }
     else {
       const int seg = k >> 4, o = k & 15;
       if (seg == 0) v = ld4(wr + 16 + o);
@@ -360,7 +376,8 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   constexpr int c4h = HC / 4, rstep_h = 256 / c4h, NH = (NRh + rstep_h - 1) / rstep_h;
   const int gc4 = tid % c4g, grow0 = tid / c4g, gch = gc4 * 4;
   const int hc4 = tid % c4h, hrow0 = tid / c4h, hch = hc4 * 4;
-  f32x4 rg[NG], ry[NG], rh[NH];
+  constexpr int NP = RD ? (TM / 2 + rstep_g - 1) / rstep_g : 1;
+  f32x4 rg[NG], ry[NG], rh[NH], rp[NP];
   auto prefetch = [&](int tl) {
     const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
     const float* gb = P.g + (size_t)b * Lg * GC + gch;
@@ -379,6 +396,14 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
       const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
       const bool ok = row < NRh && gr >= 0 && gr < Lh;
       rh[k] = ok ? ld4(xb + (size_t)gr * HC) : (f32x4){0, 0, 0, 0};
+    }
+    if (RD) {
+      const float* pb = P.gpre + (size_t)b * (Lh >> 1) * GC + gch;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int row = grow0 + k * rstep_g, gr = t0 / 2 + row;
+        rp[k] = (row < TM / 2 && gr < (Lh >> 1)) ? ld4(pb + (size_t)gr * GC) : (f32x4){0, 0, 0, 0};
+      }
     }
   };
   auto commit = [&](int tl) {
@@ -416,6 +441,13 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
         const f32x4 nv = (rh[k] - hm) * hr;
         split_store4(hH, hLo, row * RSh + hch, ok ? gelu4(nv) : (f32x4){0, 0, 0, 0});
         if (row >= 1 && row <= TM) st4(nL + (row - 1) * RSn + hch, nv);
+      }
+    }
+    if (RD) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int row = grow0 + k * rstep_g;
+        if (row < TM / 2) split_store4(pH, pLo, row * RSg + gch, rp[k]);
       }
     }
   };
@@ -462,6 +494,23 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
       } else {
 #pragma unroll
         for (int j = 0; j < 3; ++j) mma_tap(j, 2 - j, (1 << MT) - 1);
+        if (RD) {  // + Wd^T gpre[t'/2] at even t' (odd rows read the zero row)
+          bf16x8 ah[CH], al[CH];
+#pragma unroll
+          for (int nt = 0; nt < CH; ++nt) {
+            ah[nt] = *reinterpret_cast<const bf16x8*>(wH + (nt * 16 + r) * WROW + 96 + 8 * g);
+            al[nt] = *reinterpret_cast<const bf16x8*>(wLo + (nt * 16 + r) * WROW + 96 + 8 * g);
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const int m = wave * (16 * MT) + mt * 16 + r;
+            const int prow = (m & 1) ? TM / 2 : (m >> 1);
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pH + prow * RSg + 8 * g);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pLo + prow * RSg + 8 * g);
+#pragma unroll
+            for (int nt = 0; nt < CH; ++nt) acc[mt][nt] = mfma_bf3(ah[nt], al[nt], bh, bl, acc[mt][nt]);
+          }
+        }
       }
     } else {  // 16 gradient channels: lane groups g = 0,1 carry the first tap of a K step, g = 2,3 the second
       bf16x8 ah[2][CH], al[2][CH];
@@ -489,8 +538,11 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
           const int row1 = m;                            // K step 1: tap 2 | zero weights
           const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(gyH + row0 * RSg + col);
           const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(gyLo + row0 * RSg + col);
-          const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(gyH + row1 * RSg + col);
-          const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(gyLo + row1 * RSg + col);
+          const int prow = (m & 1) ? TM / 2 : (m >> 1);  // RD: lane groups 2,3 of K step 1 carry Wd x gpre[t'/2] (zero row at odd t')
+          const __bf16* s1h = (RD && second) ? pH + prow * RSg : gyH + row1 * RSg;
+          const __bf16* s1l = (RD && second) ? pLo + prow * RSg : gyLo + row1 * RSg;
+          const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(s1h + col);
+          const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(s1l + col);
 #pragma unroll
           for (int nt = 0; nt < CH; ++nt) {
             acc[mt][nt] = mfma_bf3(ah[0][nt], al[0][nt], b0h, b0l, acc[mt][nt]);
@@ -563,19 +615,37 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
         accw[j] = mfma_bf3(ah, al, bh, bl, accw[j]);
       }
     }
+    if (RD) {  // dWd[o][c] += sum_u gpre[u][o] * h[2u][c]   (window row of position t0 + 2u is 2u + 1)
+      constexpr int KSD = (TM / 2) / 32;
+#pragma unroll
+      for (int s0 = 0; s0 < KSD; s0 += KW) {
+        const int s = s0 + wk;
+        if (KSD % KW != 0 && s >= KSD) break;
+        const int p0 = 32 * s + 8 * g + q4;
+        const int gcol = wi * 16 + 4 * p4, hcol = wc * 16 + 4 * p4;
+        const bf16x8 ah = lds_tr8(pH + p0 * RSg + gcol, pH + (p0 + 4) * RSg + gcol);
+        const bf16x8 al = lds_tr8(pLo + p0 * RSg + gcol, pLo + (p0 + 4) * RSg + gcol);
+        const bf16x8 bh = lds_tr8(hH + (2 * p0 + 1) * RSh + hcol, hH + (2 * (p0 + 4) + 1) * RSh + hcol);
+        const bf16x8 bl = lds_tr8(hLo + (2 * p0 + 1) * RSh + hcol, hLo + (2 * (p0 + 4) + 1) * RSh + hcol);
+        accd = mfma_bf3(ah, al, bh, bl, accd);
+      }
+    }
   }
 
   // ---- one slab per workgroup, raw-fragment layout [tile(i,j,c)][lane][4]; waves sharing a tile pair sum in wave order
   float* out = P.slab + (size_t)blockIdx.x * (CG * 3 * CH) * 256;
+  float* outd = RD ? P.slab_d + (size_t)blockIdx.x * (CG * CH) * 256 : nullptr;
   if (KW == 1) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) st4(out + ((wi * 3 + j) * CH + wc) * 256 + lane * 4, accw[j]);
+    if (RD) st4(outd + (wi * CH + wc) * 256 + lane * 4, accd);
   } else {
     __syncthreads();
-    float* sc = reinterpret_cast<float*>(smem4);  // the windows are free now: [wave][3][64][4]
+    float* sc = reinterpret_cast<float*>(smem4);  // the windows are free now: [wave][4][64][4]
     if (wk != 0) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) st4(sc + ((wave * 3 + j) * 64 + lane) * 4, accw[j]);
+      for (int j = 0; j < 3; ++j) st4(sc + ((wave * 4 + j) * 64 + lane) * 4, accw[j]);
+      if (RD) st4(sc + ((wave * 4 + 3) * 64 + lane) * 4, accd);
     }
     __syncthreads();
     if (wk == 0) {
@@ -583,21 +653,29 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
       for (int j = 0; j < 3; ++j) {
         f32x4 v = accw[j];
 #pragma unroll
-        for (int k = 1; k < KW; ++k) v += ld4(sc + (((wave + k) * 3 + j) * 64 + lane) * 4);
+        for (int k = 1; k < KW; ++k) v += ld4(sc + (((wave + k) * 4 + j) * 64 + lane) * 4);
         st4(out + ((wi * 3 + j) * CH + wc) * 256 + lane * 4, v);
+      }
+      if (RD) {
+        f32x4 v = accd;
+#pragma unroll
+        for (int k = 1; k < KW; ++k) v += ld4(sc + (((wave + k) * 4 + 3) * 64 + lane) * 4);
+        st4(outd + (wi * CH + wc) * 256 + lane * 4, v);
       }
     }
   }
 }
 
-template <int CG, int CH, int MT, int UP2>
+template <int CG, int CH, int MT, int UP2, int RD>
 static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
-  constexpr int TM = 64 * MT, GC = CG * 16, HC = CH * 16, KD = (GC == 32) ? 96 : 64;
+  constexpr int TM = 64 * MT, GC = CG * 16, HC = CH * 16, KD = (GC == 32) ? (RD ? 128 : 96) : 64;
   BwdP P = P0;
   P.ntiles = (P.Lh + TM - 1) / TM;
-  constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = UP2 ? TM + 1 : TM + 2;
-  size_t lds = (size_t)TM * bwd_rs(HC) * 4 + (size_t)bwd_redn(CH) * 4 + (size_t)2 * 2 * (NRg * (GC + 8) + NRh * (HC + 8) + HC * (KD + 8));
-  auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2>;
+  constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = UP2 ? TM + 1 : TM + 2, NRp = RD ? TM / 2 + 1 : 0;
+  size_t lds = (size_t)TM * bwd_rs(HC) * 4 + (size_t)bwd_redn(CH) * 4 +
+               (size_t)2 * 2 * ((NRg + NRp) * bf_rs(GC) + NRh * bf_rs(HC) + HC * (KD + 8));
+  if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4]
+  auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2, RD>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -615,22 +693,29 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
 #ifndef W2S_BF_PF
 #define W2S_BF_PF 1
 #endif
+// (cg, ch) pairs whose conv1 kernel can fold the residual branch (LDS budget: two workgroups per CU)
+extern "C" int w2s_bwd_fused_folds_residual(int cg, int ch) { return (cg == 16 && ch == 16) || (cg == 32 && ch == 16); }
 extern "C" int w2s_bwd_fused_tile(int cg, int ch) { return 64 * ((cg == 16 && ch == 16) ? W2S_BF_MT11 : W2S_BF_MT2); }
 
 // cg = channels of the gradient side (the forward conv's cout), ch = channels of the input side (its cin).
 extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                              const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
-                             int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, void* stream) {
+                             int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
+                             void* stream) {
   if (!g || !y || !st_k || !bst_k || !xin || !wb || !gout || !slab || nslab <= 0) return W2S_EINVAL;
   if (pro != W2S_PRO_INBWD && pro != W2S_PRO_INBWD_GP) return W2S_EINVAL;
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
   if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in
-  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro};
+  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, gpre, wd, slab_d};
+  const bool rd = gpre != nullptr;
+  if (rd && (!wd || !slab_d || add_even || stride != 1 || !split_precision || !w2s_bwd_fused_folds_residual(cg, ch) || (Lh & 1))) return W2S_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int up2 = stride == 2;
+  if (rd && cg == 16 && ch == 16) return launch_bwd_bf<1, 1, W2S_BF_MT11, 0, 1>(P, nslab, s);
+  if (rd && cg == 32 && ch == 16) return launch_bwd_bf<2, 1, W2S_BF_MT2, 0, 1>(P, nslab, s);
 #define W2S_BFS(CG_, CH_, MT_) \
   if (split_precision && cg == 16 * CG_ && ch == 16 * CH_) \
-    return up2 ? launch_bwd_bf<CG_, CH_, MT_, 1>(P, nslab, s) : launch_bwd_bf<CG_, CH_, MT_, 0>(P, nslab, s);
+    return up2 ? launch_bwd_bf<CG_, CH_, MT_, 1, 0>(P, nslab, s) : launch_bwd_bf<CG_, CH_, MT_, 0, 0>(P, nslab, s);
   W2S_BFS(1, 1, W2S_BF_MT11) W2S_BFS(2, 1, W2S_BF_MT2) W2S_BFS(2, 2, W2S_BF_MT2)
 #undef W2S_BFS
 #define W2S_BF(CG_, CH_, MT_) \

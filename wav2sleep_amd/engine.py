@@ -215,18 +215,25 @@ class Engine:
         self._rjobs.append((slab, nslab, self.G[name], cout, cin, taps, dil, name in self._written, layout))
         self._written.add(name)
 
-    def _bwd_fused(self, name, *, g, y, st_k, bst_k, pro, xin, st_in, add_even, gout, want_part, B, Lg, Lh, cg, ch, stride):
-        """dgrad + wgrad of one k=3 encoder conv in one pass (<= 32 channels); returns the backward statistics or None."""
+    def _bwd_fused(self, name, *, g, y, st_k, bst_k, pro, xin, st_in, add_even, gout, want_part, B, Lg, Lh, cg, ch, stride,
+                   gpre=None, down=None):
+        """dgrad + wgrad of one k=3 encoder conv in one pass (<= 32 channels); returns the backward statistics or None.
+        gpre / down (conv1 of a residual block): fold the 1x1/stride-2 residual branch `down` in as well."""
         dev = g.device
         tile = lib.bwd_fused_tile(cg, ch)
         nt = _cdiv(Lh, tile)
         nslab = max(1, min(B * nt, 512))
         slab = self._slab(dev, nslab, cg * ch * 3)
+        slab_d = self._slab(dev, nslab, cg * ch) if gpre is not None else None
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
-                      part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, split_precision=self.split_precision)
+                      part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, split_precision=self.split_precision,
+                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
+        if gpre is not None:
+            self._rjobs.append((slab_d, nslab, self.G[down], cg, ch, 1, 1, down in self._written, 0))
+            self._written.add(down)
         return self._bstats(part, B, nt, ch, Lh) if want_part else None
 
     def _flush_reduce(self):
@@ -642,7 +649,14 @@ class Engine:
                 self._wgrad(p + 'conv2.conv.weight', g=gn2, g2=blk['y2'], g_stats=blk['st2'], g_bstats=bs2, pro_g=lib.PRO_INBWD, x=blk['y1'],
                             x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=1)
             del gn2
-            if i > 0:
+            if i > 0 and self.split_precision and lib.bwd_fused_supported(c, cin) and lib.bwd_fused_folds_residual(c, cin) and not (L & 1):
+                # conv1 + the whole residual branch (its data gradient AND its weight gradient) in one pass over the tensors
+                gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
+                self._bwd_fused(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, pro=lib.PRO_INBWD, xin=blk['pin'],
+                                st_in=None, add_even=None, gout=gprev, want_part=False, B=B, Lg=L, Lh=L, cg=c, ch=cin, stride=1,
+                                gpre=gpre, down=p + 'downsample.weight')
+                gpre = gprev
+            elif i > 0:
                 # residual 1x1/stride-2 branch: R = Wd^T gpre, added at even positions inside conv1's data-gradient epilogue
                 Rr = torch.empty(B, Lh, cin, device=dev, dtype=torch.float32)
                 self._conv(x=gpre, w=PB[p + 'downsample.weight'], y=Rr, B=B, L_in=Lh, L_out=Lh, cin=c, cout=cin, taps=1, stride=1, pad=0)

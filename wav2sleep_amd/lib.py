@@ -47,7 +47,7 @@ class WgradArgs(C.Structure):
 
 
 EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
-           'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
+           'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_version']
@@ -240,14 +240,20 @@ def bwd_fused_tile(cg, ch) -> int:
     return load().w2s_bwd_fused_tile(cg, ch)
 
 
-def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False):
+def bwd_fused_folds_residual(cg, ch) -> bool:
+    return bool(load().w2s_bwd_fused_folds_residual(cg, ch))
+
+
+def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False,
+              gpre=None, wd=None, slab_d=None):
     def run():
         _chk(load().w2s_bwd_fused(_f(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), _f(gout), _f(part),
-                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, int(bool(split_precision)), _stream()), f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
-    nbytes = 4 * (2 * B * Lg * cg + 2 * B * Lh * ch + (B * Lh * ch // 2 if add_even is not None else 0))
+                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _stream()),
+             f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
+    nbytes = 4 * (2 * B * Lg * cg + 2 * B * Lh * ch + (B * Lh * ch // 2 if add_even is not None else 0) + (B * Lh * cg // 2 if gpre is not None else 0))
     flops = 2 * B * Lg * cg * ch * 3 * 2
     if split_precision:
-        key = f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}>'
+        key = f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}, {1 if gpre is not None else 0}>'
     else:
         key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}, 1>'
     if DETAIL:
