@@ -166,7 +166,10 @@ int w2s_layernorm_bwd(const float* g, int ldg, const float* x, int ldx, const fl
                       const float* gadd, float* gx, int ldgx, float* part_gamma, float* part_beta, int rows, int C, int gelu,
                       int nparts, void* stream);
 int w2s_bias_grad(const float* g, int rows, int C, int ldg, float* part, int nparts, void* stream); /* part[p][c] = block column sums */
-int w2s_colsum(const float* part, int nparts, int C, int ld, float* out, int accumulate, void* stream); /* out[c] (+)= sum_p part[p*ld+c] */
+int w2s_colsum(const float* part, int nparts, int C, int ld, float* out, int accumulate, void* stream);
+/* many of them in one launch (jobs: HOST array, distinct outputs): the ~55 bias / gamma / beta / first-layer reductions of a backward pass */
+typedef struct w2s_colsum_job { const float* part; float* out; int32_t nparts, C, ld, accumulate; } w2s_colsum_job;
+int w2s_colsum_batch(const w2s_colsum_job* jobs, int njobs, void* stream); /* out[c] (+)= sum_p part[p*ld+c] */
 /* out[row][c] = g[row*ldg+c] * GELU'(pre[row][c]) * keep[row/rows_per_sample]  (encoder-output GELU backward) */
 int w2s_gelu_bwd_rows(const float* g, int ldg, const float* pre, const float* keep, int rows_per_sample, float* out, int rows, int C, void* stream);
 int w2s_fill_rows(float* dst, int ld, const float* src, int rows, int C, void* stream);             /* CLS rows, wav2sleep.py:330 */

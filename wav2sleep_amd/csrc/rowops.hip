@@ -246,6 +246,45 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
   for (int k = 1; k < 16; ++k) s += red[k][cl];
   out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
+// many column sums in one launch (a backward pass has ~55 of them, each a few microseconds): job table by value
+#define W2S_COLSUM_BATCH 64
+struct ColsumJobD { const float* part; float* out; int nparts, C, ld, accumulate, blk0; };
+struct ColsumBatch { ColsumJobD j[W2S_COLSUM_BATCH]; int njobs; };
+__global__ __launch_bounds__(256) void colsum_batch_kernel(ColsumBatch T) {
+  __shared__ double red[16][17];
+  int k = 0;
+  while (k + 1 < T.njobs && (int)blockIdx.x >= T.j[k + 1].blk0) ++k;
+  const ColsumJobD& J = T.j[k];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = ((int)blockIdx.x - J.blk0) * 16 + cl;
+  double s = 0.0;
+  if (c < J.C)
+    for (int p = pl; p < J.nparts; p += 16) s += (double)J.part[(size_t)p * J.ld + c];
+  red[pl][cl] = s;
+  __syncthreads();
+  if (pl != 0 || c >= J.C) return;
+#pragma unroll
+  for (int q = 1; q < 16; ++q) s += red[q][cl];
+  J.out[c] = J.accumulate ? J.out[c] + (float)s : (float)s;
+}
+extern "C" int w2s_colsum_batch(const w2s_colsum_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs <= 0) return W2S_EINVAL;
+  for (int base = 0; base < njobs; base += W2S_COLSUM_BATCH) {
+    ColsumBatch T;
+    T.njobs = (njobs - base < W2S_COLSUM_BATCH) ? njobs - base : W2S_COLSUM_BATCH;
+    int blocks = 0;
+    for (int i = 0; i < T.njobs; ++i) {
+      const w2s_colsum_job& q = jobs[base + i];
+      if (!q.part || !q.out || q.nparts <= 0 || q.C <= 0 || q.ld < q.C) return W2S_EINVAL;
+      T.j[i] = ColsumJobD{q.part, q.out, q.nparts, q.C, q.ld, q.accumulate, blocks};
+      blocks += (q.C + 15) / 16;
+    }
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T);
+    W2S_CHECK_LAUNCH();
+  }
+  return W2S_OK;
+}
+
 extern "C" int w2s_colsum(const float* part, int nparts, int C, int ld, float* out, int accumulate, void* stream) {
   if (!part || !out || nparts <= 0 || C <= 0 || ld < C) return W2S_EINVAL;
   hipLaunchKernelGGL(colsum_kernel, dim3((C + 15) / 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, nparts, C, ld, out, accumulate);

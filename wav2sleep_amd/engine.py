@@ -85,6 +85,7 @@ class Engine:
         self._bfbuf = {}
         self._streams = {}
         self._rjobs = []
+        self._cjobs = []
         lib.load()
 
     # ------------------------------------------------------------------ weights
@@ -236,18 +237,24 @@ class Engine:
             self._written.add(down)
         return self._bstats(part, B, nt, ch, Lh) if want_part else None
 
+    def _colsum(self, part, nparts, C, out, accumulate=False, ld=None):
+        """queued column sum (flushed with the slab reductions): out[c] (+)= sum_p part[p*ld + c]"""
+        self._cjobs.append((part, nparts, C, out, accumulate, ld))
+
     def _flush_reduce(self):
         """Deterministic slab sums of every weight gradient queued since the last flush, in one launch per 48 layers
         (on the current stream; a weight appears at most once per flush)."""
         jobs, self._rjobs = self._rjobs, []
         lib.wgrad_reduce_batch(jobs)
+        cjobs, self._cjobs = self._cjobs, []
+        lib.colsum_batch(cjobs)
 
     def _colgrad(self, name, g, rows, C, ldg=None):
         """G[name][c] = sum_rows g[row, c]  (bias / CLS gradients)."""
         nparts = max(1, min(1024, _cdiv(rows, 64)))
         part = torch.empty(nparts, C, device=g.device, dtype=torch.float32)
         lib.bias_grad(g, rows, C, C if ldg is None else ldg, part, nparts)
-        lib.colsum(part, nparts, C, self.G[name], accumulate=name in self._written)
+        self._colsum(part, nparts, C, self.G[name], accumulate=name in self._written)
         self._written.add(name)
 
     def _seed(self, site: int) -> int:
@@ -472,6 +479,7 @@ class Engine:
             raise RuntimeError('engine was built without gradient buffers')
         self._written = set(self.G.keys()) if accumulate else set()
         self._rjobs = []
+        self._cjobs = []
         B, S, D, N, F = c['B'], c['S'], c['D'], c['N'], sp.feature_dim
         dev = glogits.device
         nc = sp.num_classes
@@ -484,8 +492,8 @@ class Engine:
         nparts = max(1, min(256, _cdiv(rows, 64)))
         part = torch.empty(nparts, nc * F + nc, device=dev, dtype=torch.float32)
         lib.head_bwd(c['pre_out'], F, P['classifier.weight'], glogits, g_pre, F, part, nparts, rows, F, nc, True)
-        lib.colsum(part, nparts, nc * F, self.G['classifier.weight'], accumulate='classifier.weight' in self._written, ld=nc * F + nc)
-        lib.colsum(part.view(-1)[nc * F:], nparts, nc, self.G['classifier.bias'], accumulate='classifier.bias' in self._written, ld=nc * F + nc)
+        self._colsum(part, nparts, nc * F, self.G['classifier.weight'], accumulate='classifier.weight' in self._written, ld=nc * F + nc)
+        self._colsum(part.view(-1)[nc * F:], nparts, nc, self.G['classifier.bias'], accumulate='classifier.bias' in self._written, ld=nc * F + nc)
         self._written.update(('classifier.weight', 'classifier.bias'))
 
         # ---- SequenceCNN
@@ -502,8 +510,8 @@ class Engine:
                 pg = torch.empty(npl, F, device=dev, dtype=torch.float32)
                 pb = torch.empty(npl, F, device=dev, dtype=torch.float32)
                 lib.layernorm_bwd(gh, F, cv['y'], F, P[p + 'norm.weight'], P[p + 'norm.bias'], cv['rs'], None, gy, F, pg, pb, rows, F, True, npl)
-                lib.colsum(pg, npl, F, self.G[p + 'norm.weight'], accumulate=(p + 'norm.weight') in self._written)
-                lib.colsum(pb, npl, F, self.G[p + 'norm.bias'], accumulate=(p + 'norm.bias') in self._written)
+                self._colsum(pg, npl, F, self.G[p + 'norm.weight'], accumulate=(p + 'norm.weight') in self._written)
+                self._colsum(pb, npl, F, self.G[p + 'norm.bias'], accumulate=(p + 'norm.bias') in self._written)
                 self._written.update((p + 'norm.weight', p + 'norm.bias'))
                 pad = (sp.seq_kernel // 2) * d
                 self._wgrad(p + 'conv.weight', g=gy, x=cv['hin'], ldx=cv['ldh'], B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel,
@@ -587,8 +595,8 @@ class Engine:
         pg = torch.empty(npl, F, device=g.device, dtype=torch.float32)
         pb = torch.empty(npl, F, device=g.device, dtype=torch.float32)
         lib.layernorm_bwd(g, F, x, F, self.P[pfx + '.weight'], self.P[pfx + '.bias'], rstat, gadd, gx, F, pg, pb, rows, F, False, npl)
-        lib.colsum(pg, npl, F, self.G[pfx + '.weight'], accumulate=(pfx + '.weight') in self._written)
-        lib.colsum(pb, npl, F, self.G[pfx + '.bias'], accumulate=(pfx + '.bias') in self._written)
+        self._colsum(pg, npl, F, self.G[pfx + '.weight'], accumulate=(pfx + '.weight') in self._written)
+        self._colsum(pb, npl, F, self.G[pfx + '.bias'], accumulate=(pfx + '.bias') in self._written)
         self._written.update((pfx + '.weight', pfx + '.bias'))
 
     def _bstats(self, part, B, nt, C, count):
@@ -678,6 +686,6 @@ class Engine:
                 slab = torch.empty(nslab, 64, device=dev, dtype=torch.float32)
                 lib.enc_first_bwd(ec['x'], gn1, blk['y1'], blk['st1'], bs1, gpre, slab, nslab, B, L, c)
                 n1, nd = p + 'conv1.conv.weight', p + 'downsample.weight'
-                lib.colsum(slab, nslab, 48, self.G[n1], accumulate=n1 in self._written, ld=64)
-                lib.colsum(slab.view(-1)[48:], nslab, 16, self.G[nd], accumulate=nd in self._written, ld=64)
+                self._colsum(slab, nslab, 48, self.G[n1], accumulate=n1 in self._written, ld=64)
+                self._colsum(slab.view(-1)[48:], nslab, 16, self.G[nd], accumulate=nd in self._written, ld=64)
                 self._written.update((n1, nd))

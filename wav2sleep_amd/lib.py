@@ -36,6 +36,10 @@ class ReduceJob(C.Structure):
     _fields_ = [('slab', _fp), ('grad', _fp)] + [(n, _i32) for n in ('nslab', 'cout', 'cin', 'taps', 'dil', 'accumulate', 'layout', 'reserved')]
 
 
+class ColsumJob(C.Structure):
+    _fields_ = [('part', _fp), ('out', _fp)] + [(n, _i32) for n in ('nparts', 'C', 'ld', 'accumulate')]
+
+
 class RepackJob(C.Structure):
     _fields_ = [(n, _fp) for n in ('w', 'fwd', 'bwd', 'fwd_hi', 'fwd_lo', 'bwd_hi', 'bwd_lo')] + [(n, _i32) for n in ('cout', 'cin', 'taps', 'reserved')]
 
@@ -48,7 +52,7 @@ class WgradArgs(C.Structure):
 
 EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
            'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
-           'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_eltwise',
+           'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_version']
 
@@ -347,6 +351,17 @@ def layernorm_bwd(g, ldg, x, ldx, gamma, beta, rstat, gadd, gx, ldgx, part_gamma
 
 def bias_grad(g, rows, Cc, ldg, part, nparts):
     _chk(load().w2s_bias_grad(_f(g), rows, Cc, ldg, _f(part), nparts, _stream()), 'w2s_bias_grad')
+
+
+def colsum_batch(jobs):
+    """jobs: list of (part, nparts, C, out, accumulate, ld); one launch per 64 jobs."""
+    if not jobs:
+        return
+    arr = (ColsumJob * len(jobs))()
+    for q, (part, nparts, Cc, out, accumulate, ld) in zip(arr, jobs):
+        q.part, q.out = _f(part), _f(out)
+        q.nparts, q.C, q.ld, q.accumulate = nparts, Cc, Cc if ld is None else ld, int(accumulate)
+    _chk(load().w2s_colsum_batch(arr, len(jobs), _stream()), 'w2s_colsum_batch')
 
 
 def colsum(part, nparts, Cc, out, accumulate=False, ld=None):
