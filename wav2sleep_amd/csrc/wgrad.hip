@@ -385,35 +385,47 @@ __global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
 
 // sum slabs in a fixed order (16 slab-lanes x sequential chunks, then a fixed LDS tree); decode the fragment
 // index to (o, j, c); write torch layout grad[o][c][j] (layout 0) or [o][j][c] (layout 1).  Deterministic.
-__device__ __forceinline__ void wgrad_reduce_block(float (*red)[17], int blk, const float* __restrict__ slab, int nslab, float* __restrict__ grad,
+// One block = 256 consecutive slab elements (64 lanes x float4: a wave reads 1 KB contiguous runs of ONE slab; the earlier
+// 16-element x 64-slab-lane form fetched 64-B segments of four different slabs per instruction and ran at 1.3 TB/s).
+// 16 waves walk the slabs k = wave, wave + 16, ... with four loads in flight, then a fixed-order LDS tree.
+__device__ __forceinline__ void wgrad_reduce_block(float (*red)[260], int blk, const float* __restrict__ slab, int nslab, float* __restrict__ grad,
                                                    int cout, int cin, int taps, int NTO, int NTC, int TAPS_T, int accumulate, int layout) {
-  const size_t per = (size_t)cout * cin * taps;  // floats per slab
-  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const size_t idx = (size_t)blk * 16 + el;
-  float s = 0.f;
-  if (idx < per)
-    for (int k = sl; k < nslab; k += 64) s += slab[(size_t)k * per + idx];
-  red[sl][el] = s;
+  const size_t per = (size_t)cout * cin * taps;  // floats per slab (a multiple of 256: whole raw fragments)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t e0 = (size_t)blk * 256 + lane * 4;
+  f32x4 s = {0, 0, 0, 0};
+  const float* src = slab + e0;
+  int k = wave;
+  for (; k + 48 < nslab; k += 64) {
+    const f32x4 a0 = ld4(src + (size_t)k * per), a1 = ld4(src + (size_t)(k + 16) * per);
+    const f32x4 a2 = ld4(src + (size_t)(k + 32) * per), a3 = ld4(src + (size_t)(k + 48) * per);
+    s += (a0 + a1) + (a2 + a3);
+  }
+  for (; k < nslab; k += 16) s += ld4(src + (size_t)k * per);
+  st4(&red[wave][lane * 4], s);
   __syncthreads();
-  if (sl != 0 || idx >= per) return;
-#pragma unroll 8
-  for (int k = 1; k < 64; ++k) s += red[k][el];
+  if (threadIdx.x >= 256) return;
+  const int el = threadIdx.x;
+  float v = red[0][el];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) v += red[w][el];
+  const size_t idx = (size_t)blk * 256 + el;
   // idx = ((y * TILES + tile) * 64 + lane) * 4 + reg
-  const int reg = idx & 3, lane = (idx >> 2) & 63;
+  const int reg = idx & 3, fl = (idx >> 2) & 63;
   const int TILES = NTO * TAPS_T * NTC;
   const int tile = (idx >> 8) % TILES, y = (idx >> 8) / TILES;
   const int ntg = taps / TAPS_T;
   const int oy = y / ntg, tg = y % ntg;
   const int c_t = tile % NTC, j_t = (tile / NTC) % TAPS_T, i_t = tile / (NTC * TAPS_T);
-  const int o = oy * NTO * 16 + i_t * 16 + 4 * (lane >> 4) + reg;
+  const int o = oy * NTO * 16 + i_t * 16 + 4 * (fl >> 4) + reg;
   const int j = tg * TAPS_T + j_t;
-  const int c = c_t * 16 + (lane & 15);
+  const int c = c_t * 16 + (fl & 15);
   float* d = layout ? grad + ((size_t)o * taps + j) * cin + c : grad + ((size_t)o * cin + c) * taps + j;
-  *d = accumulate ? (*d + s) : s;
+  *d = accumulate ? (*d + v) : v;
 }
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, float* __restrict__ grad, int cout,
                                                            int cin, int taps, int NTO, int NTC, int TAPS_T, int accumulate, int layout) {
-  __shared__ float red[64][17];
+  __shared__ float red[16][260];
   wgrad_reduce_block(red, blockIdx.x, slab, nslab, grad, cout, cin, taps, NTO, NTC, TAPS_T, accumulate, layout);
 }
 
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 struct ReduceJobD { const float* slab; float* grad; int nslab, cout, cin, taps, nto, ntc, tapst, flags, blk0; };
 struct ReduceBatch { ReduceJobD j[W2S_REDUCE_BATCH]; int njobs; };
 __global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(ReduceBatch T) {
-  __shared__ float red[64][17];
+  __shared__ float red[16][260];
   int k = 0;
   while (k + 1 < T.njobs && (int)blockIdx.x >= T.j[k + 1].blk0) ++k;
   const ReduceJobD& J = T.j[k];
@@ -612,7 +624,8 @@ extern "C" int w2s_wgrad_reduce(const float* slab, int nslab, float* grad, int c
   if (!slab || !grad || nslab <= 0) return W2S_EINVAL;
   const WgCfg c = wg_cfg(cin, cout, taps, dil);
   const size_t per = (size_t)cout * cin * taps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 15) / 16)), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), slab,
+  if (per % 256) return W2S_EINVAL;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(per / 256)), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), slab,
                      nslab, grad, cout, cin, taps, c.nto, c.ntc, c.tapst, accumulate, layout);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
@@ -630,7 +643,8 @@ extern "C" int w2s_wgrad_reduce_batch(const w2s_reduce_job* jobs, int njobs, voi
       const WgCfg c = wg_cfg(q.cin, q.cout, q.taps, q.dil);
       const size_t per = (size_t)q.cout * q.cin * q.taps;
       T.j[i] = ReduceJobD{q.slab, q.grad, q.nslab, q.cout, q.cin, q.taps, c.nto, c.ntc, c.tapst, (q.accumulate ? 1 : 0) | (q.layout ? 2 : 0), blocks};
-      blocks += (int)((per + 15) / 16);
+      if (per % 256) return W2S_EINVAL;
+      blocks += (int)(per / 256);
     }
     hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), T);
     W2S_CHECK_LAUNCH();
