@@ -32,6 +32,9 @@ extern "C" {
 #define W2S_PRO_IN_GELU 3   /* GELU((x-mean)*rstd)      blocks.py:183-184 InstanceNorm1d(eps=1e-2)+GELU */
 #define W2S_PRO_INBWD 4     /* g_y = rstd*(g - s1 - n*s2), n=(x2-mean)*rstd   (instance-norm backward) */
 #define W2S_PRO_INBWD_GP 5  /* as 4 with g := g*GELU'(n) first */
+#define W2S_PRO_FIRST 6     /* x = the raw 1-channel signal [B][L_in], x2 = block 0's conv1 weight [16][3]: the 16-channel conv1 output is
+                              * RE-COMPUTED on load (3 FMAs / element; inf -> 0 as W2S_PRO_SANITIZE) and then normalised + GELU'd as mode 3.
+                              * The largest tensor of the model (16 x T per recording) is then never written or read.  cin must be 16. */
 
 /* ---- epilogue (applied to the accumulator tile before the store) ---- */
 #define W2S_EPI_PLAIN 0
@@ -137,12 +140,14 @@ int w2s_bwd_fused_tile(int cg, int ch);
 int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                   const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
                   int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
-                  void* stream);
+                  const float* w1, void* stream);
 /* gpre != NULL (conv1 of a residual block; stride 1, split_precision, add_even NULL, w2s_bwd_fused_folds_residual(cg, ch)): the
  * block's 1x1/stride-2 residual branch (blocks.py:44-47,68) is folded in -- gout additionally receives Wd^T gpre[t/2] at even t
  * before the GELU' factor (gpre: [B][Lh/2][cg] = dL/d(block pre-activation), wd: [ch][cg]) and slab_d receives nslab raw-fragment
  * slabs of the downsample weight gradient -> w2s_wgrad_reduce(slab_d, nslab, grad_wd, cg, ch, 1, 1, ...). */
 int w2s_bwd_fused_folds_residual(int cg, int ch);
+/* w1 != NULL (conv2 of block 0; cg = ch = 16, stride 1, split_precision, st_in given): xin is the RAW 1-channel signal [B][Lh] and
+ * the conv's input (block 0's conv1 output) is recomputed from it with w1 = conv1 weight [16][3] (the W2S_PRO_FIRST flow). */
 
 /* partial sums [B][ntiles][2][C] -> per-(b,c) pairs [B][C][2]: kind 0 = (mean, rstd) with biased variance + eps
  * (nn.InstanceNorm1d, models/utils.py:89-92), kind 1 = (sum1, sum2)/count.  fp64 accumulation, fixed order. */
@@ -150,12 +155,14 @@ int w2s_stats_finalize(const float* part, int B, int ntiles, int C, long count, 
 
 /* First encoder layer, Cin = 1 (blocks.py:46, conv1 of block 0): y[b,t,o] = sum_j w[o][j]*san(x[b,t+j-1]);
  * part [B][ceil(L/tile)][2][16] = partial sum / sum-of-squares.  w is the torch tensor [16][1][3]. */
+/* y may be NULL (statistics only: the W2S_PRO_FIRST consumers recompute the values) */
 int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, void* stream);
 /* Block-0 residual join (blocks.py:67-69): pre[b,u,o] = GELU(IN(y3[b,u,o])) + wd[o]*san(x[b,2u]) */
 int w2s_enc_first_join(const float* x, const float* wd, const float* y3, const float* stats3, float* pre, int B, int L, int cout, void* stream);
 /* weight grads of block-0 conv1 / downsample; slab[nslab][64] = {dW1[o][j] (48), dWd[o] (16)}; sum with w2s_colsum */
 int w2s_enc_first_bwd(const float* x, const float* gn1, const float* y1, const float* stats1, const float* bstats1,
-                      const float* gpre, float* slab, int nslab, int B, int L, int cout, void* stream);
+                      const float* gpre, float* slab, int nslab, int B, int L, int cout, const float* w1, void* stream);
+/* y1 == NULL: the conv1 output is recomputed from x and w1 = conv1 weight [16][3] (the W2S_PRO_FIRST flow) */
 /* pre-pass of conv3's backward: part [B][ceil(L/tile)][2][C] = partial sums of g*GELU'(n) and g*GELU'(n)*n, n = IN(y) */
 int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, void* stream);
 

@@ -24,6 +24,8 @@ struct BwdP {
   // residual fold (conv1 of a block, split-precision kernel only): gpre = dL/d(block pre-activation) [B][Lh/2][GC],
   // wd = 1x1/stride-2 downsample weight as [HC][GC], slab_d = its weight-gradient slabs (one per workgroup)
   const float* gpre; const float* wd; float* slab_d;
+  // first-layer recompute (conv2 of block 0, split-precision kernel only): xin = the raw signal [B][Lh], w1 = conv1 weight [16][3]
+  const float* w1;
 };
 
 // LDS row strides: 16-channel rows stay unpadded (64-B rows: the three windows + weights of the 16x16 kernel then fit
@@ -317,13 +319,16 @@ __device__ __forceinline__ f32x4 mfma_bf3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x
 // already staged.  Replaces a 1x1 conv launch (+ its output tensor, written and re-read) and a weight-gradient launch that
 // re-read both gpre and the block input.
 __host__ __device__ constexpr int bf_rs(int c) { return c == 16 ? 16 : c + 8; }  // 32-B rows are conflict-free as they are
-template <int CG, int CH, int MT, int UP2, int RD>
+// FIRST = 1 (conv2 of block 0): the input side is block 0's conv1 output, which is never stored -- it is recomputed from
+// the raw 1-channel signal while the window is staged (3 FMAs per element instead of a 64-B row per position).
+template <int CG, int CH, int MT, int UP2, int RD, int FIRST>
 __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 64 * MT;
   constexpr int GC = CG * 16, HC = CH * 16;
   constexpr int RSg = bf_rs(GC), RSh = bf_rs(HC), RSn = bwd_rs(HC);   // bf16 / bf16 / float elements per row
   static_assert(!(RD && UP2), "the residual fold belongs to the stride-1 conv1");
+  static_assert(!FIRST || (HC == 16 && !UP2 && !RD), "first-layer recompute: conv2 of block 0");
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2;
   constexpr int NRh = UP2 ? TM + 1 : TM + 2;
   // data-gradient K axis of the LDS weight image.  32 gradient channels: k = tap*32 + o (one tap per MFMA).
@@ -342,6 +347,7 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   constexpr int NRp = RD ? TM / 2 + 1 : 0;                  // gpre rows of the tile + one all-zero row (odd output positions)
   __bf16* pH = wLo + HC * WROW;
   __bf16* pLo = pH + NRp * RSg;
+  float* xsL = reinterpret_cast<float*>(pLo + NRp * RSg);   // FIRST: TM + 4 signal samples
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4, q4 = r >> 2, p4 = r & 3;
   const int Lg = P.Lg, Lh = P.Lh;
@@ -377,7 +383,14 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   const int gc4 = tid % c4g, grow0 = tid / c4g, gch = gc4 * 4;
   const int hc4 = tid % c4h, hrow0 = tid / c4h, hch = hc4 * 4;
   constexpr int NP = RD ? (TM / 2 + rstep_g - 1) / rstep_g : 1;
-  f32x4 rg[NG], ry[NG], rh[NH], rp[NP];
+  f32x4 rg[NG], ry[NG], rh[FIRST ? 1 : NH], rp[NP];
+  float rxs[2], w1r[4][3];
+  if (FIRST) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w1r[i][j] = P.w1[(hch + i) * 3 + j];
+  }
   auto prefetch = [&](int tl) {
     const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
     const float* gb = P.g + (size_t)b * Lg * GC + gch;
@@ -390,12 +403,22 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
       rg[k] = ok ? ld4(gb + (size_t)gr * GC) : (f32x4){0, 0, 0, 0};
       ry[k] = ok ? ld4(yb + (size_t)gr * GC) : (f32x4){0, 0, 0, 0};
     }
-    const float* xb = P.xin + (size_t)b * Lh * HC + hch;
+    if (FIRST) {  // TM + 4 signal samples t0-2 .. t0+TM+1: one per thread (+4), exchanged through LDS at commit time
+      const float* xs = P.xin + (size_t)b * Lh;
 #pragma unroll
-    for (int k = 0; k < NH; ++k) {
-      const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
-      const bool ok = row < NRh && gr >= 0 && gr < Lh;
-      rh[k] = ok ? ld4(xb + (size_t)gr * HC) : (f32x4){0, 0, 0, 0};
+      for (int k = 0; k < 2; ++k) {
+        const int i = tid + 256 * k, gr = t0 - 2 + i;
+        const float xv = xs[min(max(gr, 0), Lh - 1)];
+        rxs[k] = (i < TM + 4 && gr >= 0 && gr < Lh && !isinf(xv)) ? xv : 0.f;
+      }
+    } else {
+      const float* xb = P.xin + (size_t)b * Lh * HC + hch;
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
+        const bool ok = row < NRh && gr >= 0 && gr < Lh;
+        rh[k] = ok ? ld4(xb + (size_t)gr * HC) : (f32x4){0, 0, 0, 0};
+      }
     }
     if (RD) {
       const float* pb = P.gpre + (size_t)b * (Lh >> 1) * GC + gch;
@@ -433,12 +456,27 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
       f32x4 s01 = ld4(st), s23 = ld4(st + 4);
       hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
     }
+    if (FIRST) {
+      xsL[tid] = rxs[0];
+      if (tid < TM + 4 - 256) xsL[256 + tid] = rxs[1];
+      __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
       const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
       if (row < NRh) {
         const bool ok = gr >= 0 && gr < Lh;
-        const f32x4 nv = (rh[k] - hm) * hr;
+        f32x4 xv;
+        if (FIRST) {  // window row <-> position t0-1+row; xsL[i] <-> position t0-2+i
+          const float xm = xsL[row], xc = xsL[row + 1], xp = xsL[row + 2];
+          xv.x = w1r[0][0] * xm + w1r[0][1] * xc + w1r[0][2] * xp;
+          xv.y = w1r[1][0] * xm + w1r[1][1] * xc + w1r[1][2] * xp;
+          xv.z = w1r[2][0] * xm + w1r[2][1] * xc + w1r[2][2] * xp;
+          xv.w = w1r[3][0] * xm + w1r[3][1] * xc + w1r[3][2] * xp;
+        } else {
+          xv = rh[k];
+        }
+        const f32x4 nv = (xv - hm) * hr;
         split_store4(hH, hLo, row * RSh + hch, ok ? gelu4(nv) : (f32x4){0, 0, 0, 0});
         if (row >= 1 && row <= TM) st4(nL + (row - 1) * RSn + hch, nv);
       }
@@ -666,7 +704,7 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   }
 }
 
-template <int CG, int CH, int MT, int UP2, int RD>
+template <int CG, int CH, int MT, int UP2, int RD, int FIRST = 0>
 static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   constexpr int TM = 64 * MT, GC = CG * 16, HC = CH * 16, KD = (GC == 32) ? (RD ? 128 : 96) : 64;
   BwdP P = P0;
@@ -674,8 +712,9 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = UP2 ? TM + 1 : TM + 2, NRp = RD ? TM / 2 + 1 : 0;
   size_t lds = (size_t)TM * bwd_rs(HC) * 4 + (size_t)bwd_redn(CH) * 4 +
                (size_t)2 * 2 * ((NRg + NRp) * bf_rs(GC) + NRh * bf_rs(HC) + HC * (KD + 8));
+  if (FIRST) lds += (size_t)(TM + 4) * 4;
   if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4]
-  auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2, RD>;
+  auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -701,16 +740,20 @@ extern "C" int w2s_bwd_fused_tile(int cg, int ch) { return 64 * ((cg == 16 && ch
 extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                              const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
                              int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
-                             void* stream) {
+                             const float* w1, void* stream) {
   if (!g || !y || !st_k || !bst_k || !xin || !wb || !gout || !slab || nslab <= 0) return W2S_EINVAL;
   if (pro != W2S_PRO_INBWD && pro != W2S_PRO_INBWD_GP) return W2S_EINVAL;
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
   if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in
-  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, gpre, wd, slab_d};
+  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, gpre, wd, slab_d, w1};
   const bool rd = gpre != nullptr;
   if (rd && (!wd || !slab_d || add_even || stride != 1 || !split_precision || !w2s_bwd_fused_folds_residual(cg, ch) || (Lh & 1))) return W2S_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int up2 = stride == 2;
+  if (w1) {  // xin is the raw signal: conv2 of block 0
+    if (rd || !st_in || stride != 1 || !split_precision || cg != 16 || ch != 16) return W2S_EINVAL;
+    return launch_bwd_bf<1, 1, W2S_BF_MT11, 0, 0, 1>(P, nslab, s);
+  }
   if (rd && cg == 16 && ch == 16) return launch_bwd_bf<1, 1, W2S_BF_MT11, 0, 1>(P, nslab, s);
   if (rd && cg == 32 && ch == 16) return launch_bwd_bf<2, 1, W2S_BF_MT2, 0, 1>(P, nslab, s);
 #define W2S_BFS(CG_, CH_, MT_) \

@@ -22,9 +22,10 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
   const w2s_conv_args& a = *ap;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a.cin < 16 || a.cin > 128 || (a.cin & (a.cin - 1)) || (a.cout & 15) || a.B <= 0 || a.L_out <= 0) return W2S_EINVAL;
-  if ((a.ldx & 3) || (a.ldy & 3) || !a.x || !a.w || !a.y) return W2S_EINVAL;
+  if (((a.ldx & 3) && a.pro != W2S_PRO_FIRST) || (a.ldy & 3) || !a.x || !a.w || !a.y) return W2S_EINVAL;
   if (a.pro >= W2S_PRO_IN_GELU && !a.pro_stats) return W2S_EINVAL;
-  if (a.pro >= W2S_PRO_INBWD && (!a.pro_bstats || !a.x2)) return W2S_EINVAL;
+  if ((a.pro == W2S_PRO_INBWD || a.pro == W2S_PRO_INBWD_GP) && (!a.pro_bstats || !a.x2)) return W2S_EINVAL;
+  if (a.pro == W2S_PRO_FIRST && (!a.x2 || a.cin != 16 || a.taps != 3 || a.stride != 1 || a.mode != W2S_MODE_CONTIG)) return W2S_EINVAL;
   if ((a.epi == W2S_EPI_AUX_INGELU_ADD && (!a.aux || !a.aux_stats)) || (a.epi == W2S_EPI_GP && !a.aux)) return W2S_EINVAL;
   if (a.mode == W2S_MODE_UP2) {
     if (a.taps != 3 || a.stride != 2) return W2S_EINVAL;

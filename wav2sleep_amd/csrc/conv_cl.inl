@@ -31,6 +31,7 @@ __device__ __forceinline__ f32x4 pro_apply(int pro, f32x4 v, f32x4 v2, f32x4 mea
     case W2S_PRO_GELU:
       return gelu4(v);
     case W2S_PRO_IN_GELU:
+    case W2S_PRO_FIRST:  // v = the recomputed first-layer output
       return gelu4((v - mean) * rstd);
     case W2S_PRO_INBWD: {
       f32x4 n = (v2 - mean) * rstd;
@@ -89,24 +90,50 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
     f32x4 s01 = ld4(st), s23 = ld4(st + 4);
     pm = (f32x4){s01.x, s01.z, s23.x, s23.z};
     pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
-    if (pro >= W2S_PRO_INBWD) {
+    if (pro == W2S_PRO_INBWD || pro == W2S_PRO_INBWD_GP) {
       const float* bs = a.pro_bstats + ((size_t)b * cin + myc4 * 4) * 2;
       f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
       ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z};
       ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
     }
   }
-  const float* xb = a.x + (size_t)b * L_in * a.ldx + myc4 * 4;
-  const float* x2b = (pro >= W2S_PRO_INBWD) ? a.x2 + (size_t)b * L_in * a.ldx + myc4 * 4 : nullptr;
+  const float* xb = (pro == W2S_PRO_FIRST) ? a.x + (size_t)b * L_in : a.x + (size_t)b * L_in * a.ldx + myc4 * 4;
+  const float* x2b = (pro == W2S_PRO_INBWD || pro == W2S_PRO_INBWD_GP) ? a.x2 + (size_t)b * L_in * a.ldx + myc4 * 4 : nullptr;
+  float w1r[4][3];  // W2S_PRO_FIRST: this thread's 4 output channels of block 0's conv1 (a.x2 = its weight [16][3])
+  if (pro == W2S_PRO_FIRST) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w1r[i][j] = a.x2[(myc4 * 4 + i) * 3 + j];
+  }
 
+  float* xsL = smem + P.nr_lds * RS;  // W2S_PRO_FIRST: sanitised signal samples rb-1 .. rb+NR (zero outside the recording)
   auto stage = [&](int rb, int NR, int rowmul) {
     constexpr int U = (NT >= 8) ? 8 : 4;  // loads in flight per thread per batch (bigger windows: fewer round trips)
+    if (pro == W2S_PRO_FIRST) {
+      for (int i = tid; i < NR + 2; i += 256) {
+        const int gr = rb - 1 + i;
+        const float xv = xb[min(max(gr, 0), L_in - 1)];
+        xsL[i] = (gr >= 0 && gr < L_in && !isinf(xv)) ? xv : 0.f;
+      }
+      __syncthreads();
+    }
     for (int row = row0; row < NR; row += rstep * U) {
       f32x4 v[U], v2[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int rr = row + u * rstep, gr = rb + rr * rowmul;
         const bool ok = (rr < NR) && (gr >= 0) && (gr < L_in);
+        if (pro == W2S_PRO_FIRST) {  // conv1 (Cin = 1, k = 3, zero padding) recomputed from the raw signal window in LDS
+          const int xi = (rr < NR) ? rr : 0;
+          const float xm = xsL[xi], xc = xsL[xi + 1], xp = xsL[xi + 2];
+          v[u].x = w1r[0][0] * xm + w1r[0][1] * xc + w1r[0][2] * xp;
+          v[u].y = w1r[1][0] * xm + w1r[1][1] * xc + w1r[1][2] * xp;
+          v[u].z = w1r[2][0] * xm + w1r[2][1] * xc + w1r[2][2] * xp;
+          v[u].w = w1r[3][0] * xm + w1r[3][1] * xc + w1r[3][2] * xp;
+          v2[u] = (f32x4){0, 0, 0, 0};
+          continue;
+        }
         v[u] = ok ? ld4(xb + (size_t)gr * a.ldx) : (f32x4){0, 0, 0, 0};
         v2[u] = (ok && x2b) ? ld4(x2b + (size_t)gr * a.ldx) : (f32x4){0, 0, 0, 0};
       }
@@ -336,6 +363,7 @@ static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
   const int NR = window_rows(TM, TAPS, STRIDE, MODE, a.dil > 0 ? a.dil : 1);
   P.nr_lds = NR;
   size_t lds = BF ? (size_t)2 * NR * (a.cin + 8) * 2 : (size_t)NR * (a.cin + 4) * sizeof(float);
+  if (a.pro == W2S_PRO_FIRST) lds += (size_t)(NR + 2) * sizeof(float);
   size_t red = (size_t)4 * (NT / WN) * 4 * 8 * sizeof(float);
   if (lds < red) lds = red;
   dim3 grid(P.ntiles, a.cout / (NT * 16), a.B);
@@ -373,6 +401,8 @@ static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
     if (a.pro == W2S_PRO_GELU && a.epi == W2S_EPI_STATS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_GELU, W2S_EPI_STATS>(a, s);
     if (a.pro == W2S_PRO_IN_GELU && a.epi == W2S_EPI_STATS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_IN_GELU, W2S_EPI_STATS>(a, s);
     if (a.pro == W2S_PRO_INBWD && a.epi == W2S_EPI_GP) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_INBWD, W2S_EPI_GP>(a, s);
+    if (a.pro == W2S_PRO_FIRST && a.epi == W2S_EPI_STATS && a.cin == 16)
+      return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_FIRST, W2S_EPI_STATS>(a, s);
   }
   if (plain_io && MODE == W2S_MODE_CONTIG && TAPS == 3 && STRIDE == 2 && a.pro == W2S_PRO_IN_GELU && a.epi == W2S_EPI_STATS)
     return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_IN_GELU, W2S_EPI_STATS>(a, s);

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restr
     v.y = wr[1][0] * xm + wr[1][1] * xc + wr[1][2] * xp;
     v.z = wr[2][0] * xm + wr[2][1] * xc + wr[2][2] * xp;
     v.w = wr[3][0] * xm + wr[3][1] * xc + wr[3][2] * xp;
-    st4(yb + (size_t)t * 16 + og * 4, v);
+    if (y) st4(yb + (size_t)t * 16 + og * 4, v);
     s1 += v;
     s2 += v * v;
   }
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restr
 }
 
 extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, void* stream) {
-  if (!x || !w || !y || !part || cout != 16 || tile < 64 || (tile & 63)) return W2S_EINVAL;
+  if (!x || !w || !part || cout != 16 || tile < 64 || (tile & 63)) return W2S_EINVAL;  // y == NULL: statistics only
   const int ntiles = (L + tile - 1) / tile;
   hipLaunchKernelGGL(enc_first_fwd_kernel, dim3(ntiles, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, y, part, L, tile,
                      ntiles);
@@ -101,9 +101,14 @@ extern "C" int w2s_enc_first_join(const float* x, const float* wd, const float* 
 __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gn1,
                                                             const float* __restrict__ y1, const float* __restrict__ stats1,
                                                             const float* __restrict__ bstats1, const float* __restrict__ gpre,
-                                                            float* __restrict__ slab, int B, int L) {
+                                                            float* __restrict__ slab, int B, int L, const float* __restrict__ w1) {
   __shared__ float red[4][4][16];
   const int tid = threadIdx.x, og = tid & 3, lane = tid & 63, wave = tid >> 6;
+  float wr[4][3];  // y1 == NULL: the conv1 output is recomputed from x (never stored)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wr[i][j] = w1 ? w1[(og * 4 + i) * 3 + j] : 0.f;
   float acc[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.f;
@@ -117,15 +122,24 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
     f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
     f32x4 q1 = {b01.x, b01.z, b23.x, b23.z}, q2 = {b01.y, b01.w, b23.y, b23.w};
     const float* xb = x + (size_t)b * L;
+#pragma unroll 4
     for (int p = tid >> 2; p < 1024; p += 64) {
       const int t = t0 + p;
       if (t >= L) break;
       const size_t off = ((size_t)b * L + t) * 16 + og * 4;
-      f32x4 n = (ld4(y1 + off) - mean) * rstd;
-      f32x4 gy = rstd * (ld4(gn1 + off) - q1 - n * q2);
       const float xm = (t > 0) ? sanitize_f(xb[t - 1]) : 0.f;
       const float xc = sanitize_f(xb[t]);
       const float xp = (t + 1 < L) ? sanitize_f(xb[t + 1]) : 0.f;
+      f32x4 yv;
+      if (y1) yv = ld4(y1 + off);
+      else {
+        yv.x = wr[0][0] * xm + wr[0][1] * xc + wr[0][2] * xp;
+        yv.y = wr[1][0] * xm + wr[1][1] * xc + wr[1][2] * xp;
+        yv.z = wr[2][0] * xm + wr[2][1] * xc + wr[2][2] * xp;
+        yv.w = wr[3][0] * xm + wr[3][1] * xc + wr[3][2] * xp;
+      }
+      f32x4 n = (yv - mean) * rstd;
+      f32x4 gy = rstd * (ld4(gn1 + off) - q1 - n * q2);
       acc[0] += gy.x * xm; acc[1] += gy.x * xc; acc[2] += gy.x * xp;
       acc[3] += gy.y * xm; acc[4] += gy.y * xc; acc[5] += gy.y * xp;
       acc[6] += gy.z * xm; acc[7] += gy.z * xc; acc[8] += gy.z * xp;
@@ -160,10 +174,10 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
 }
 
 extern "C" int w2s_enc_first_bwd(const float* x, const float* gn1, const float* y1, const float* stats1, const float* bstats1,
-                                 const float* gpre, float* slab, int nslab, int B, int L, int cout, void* stream) {
-  if (!x || !gn1 || !y1 || !stats1 || !bstats1 || !gpre || !slab || cout != 16 || nslab <= 0) return W2S_EINVAL;
+                                 const float* gpre, float* slab, int nslab, int B, int L, int cout, const float* w1, void* stream) {
+  if (!x || !gn1 || (!y1 && !w1) || !stats1 || !bstats1 || !gpre || !slab || cout != 16 || nslab <= 0) return W2S_EINVAL;
   hipLaunchKernelGGL(enc_first_bwd_kernel, dim3(nslab), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gn1, y1, stats1, bstats1,
-                     gpre, slab, B, L);
+                     gpre, slab, B, L, y1 ? nullptr : w1);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

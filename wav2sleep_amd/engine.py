@@ -176,15 +176,15 @@ class Engine:
             kw['w_hi'], kw['w_lo'] = planes
         lib.conv_forward(lib.conv_args(**kw))
 
-    def _conv_stats(self, *, x, w, B, L_in, L_out, cin, cout, stride, pro, pro_stats=None):
+    def _conv_stats(self, *, x, w, B, L_in, L_out, cin, cout, stride, pro, pro_stats=None, x2=None):
         """k=3 encoder conv writing the pre-norm tensor + instance-norm statistics (blocks.py:174-183)."""
         dev = x.device
         y = torch.empty(B, L_out, cout, device=dev, dtype=torch.float32)
         tile = lib.conv_tile(cin, cout, 3, stride, lib.MODE_CONTIG, B, L_out)
         nt = _cdiv(L_out, tile)
         part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
-        self._conv(x=x, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=1, pro=pro,
-                   pro_stats=pro_stats, epi=lib.EPI_STATS, part=part)
+        self._conv(x=x, x2=x2, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=1, pro=pro,
+                   pro_stats=pro_stats, epi=lib.EPI_STATS, part=part, **({'ldx': 4} if pro == lib.PRO_FIRST else {}))
         return y, self._finalize(part, B, nt, cout, L_out, 0)
 
     def _linear(self, x, w, bias, rows, cin, cout, ldx=None, y=None, ldy=None):
@@ -217,7 +217,7 @@ class Engine:
         self._written.add(name)
 
     def _bwd_fused(self, name, *, g, y, st_k, bst_k, pro, xin, st_in, add_even, gout, want_part, B, Lg, Lh, cg, ch, stride,
-                   gpre=None, down=None):
+                   gpre=None, down=None, w1=None):
         """dgrad + wgrad of one k=3 encoder conv in one pass (<= 32 channels); returns the backward statistics or None.
         gpre / down (conv1 of a residual block): fold the 1x1/stride-2 residual branch `down` in as well."""
         dev = g.device
@@ -229,7 +229,7 @@ class Engine:
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
                       part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, split_precision=self.split_precision,
-                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d)
+                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         if gpre is not None:
@@ -275,13 +275,22 @@ class Engine:
         blocks = []
         # ---- block 0 (Cin = 1)
         c, L = ch[0], T
-        y1 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
+        # The Cin = 1 conv1 output (16 x T per recording: the largest tensor of the model) is only materialised when someone
+        # needs it (debug taps, the exact-fp32 backward kernels); otherwise its consumers recompute it from the raw signal
+        # (W2S_PRO_FIRST: 3 FMAs per element) and only its instance-norm statistics are computed here.
+        recompute = self.split_precision and self.taps is None and c == 16
+        w1 = P[pfx + 'cnn.0.conv1.conv.weight']
+        y1 = None if recompute else torch.empty(B, L, c, device=dev, dtype=torch.float32)
         nt = _cdiv(L, FIRST_TILE)
         part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
-        lib.enc_first_fwd(x, P[pfx + 'cnn.0.conv1.conv.weight'], y1, part, B, L, c, FIRST_TILE)
+        lib.enc_first_fwd(x, w1, y1, part, B, L, c, FIRST_TILE)
         st1 = self._finalize(part, B, nt, c, L, 0)
-        y2, st2 = self._conv_stats(x=y1, w=PF[pfx + 'cnn.0.conv2.conv.weight'], B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1,
-                                   pro=lib.PRO_IN_GELU, pro_stats=st1)
+        if recompute:
+            y2, st2 = self._conv_stats(x=x, x2=w1, w=PF[pfx + 'cnn.0.conv2.conv.weight'], B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1,
+                                       pro=lib.PRO_FIRST, pro_stats=st1)
+        else:
+            y2, st2 = self._conv_stats(x=y1, w=PF[pfx + 'cnn.0.conv2.conv.weight'], B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1,
+                                       pro=lib.PRO_IN_GELU, pro_stats=st1)
         y3, st3 = self._conv_stats(x=y2, w=PF[pfx + 'cnn.0.conv3.conv.weight'], B=B, L_in=L, L_out=L // 2, cin=c, cout=c, stride=2,
                                    pro=lib.PRO_IN_GELU, pro_stats=st2)
         pre = torch.empty(B, L // 2, c, device=dev, dtype=torch.float32)
@@ -635,8 +644,10 @@ class Engine:
             if lib.bwd_fused_supported(c, c):
                 bs2 = self._bwd_fused(p + 'conv3.conv.weight', g=gpre, y=blk['y3'], st_k=blk['st3'], bst_k=bs3, pro=lib.PRO_INBWD_GP,
                                       xin=blk['y2'], st_in=blk['st2'], add_even=None, gout=gn2, want_part=True, B=B, Lg=Lh, Lh=L, cg=c, ch=c, stride=2)
+                first = i == 0 and blk['y1'] is None   # block 0's conv1 output is recomputed from the raw signal
                 bs1 = self._bwd_fused(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, pro=lib.PRO_INBWD,
-                                      xin=blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B, Lg=L, Lh=L, cg=c, ch=c, stride=1)
+                                      xin=ec['x'] if first else blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B,
+                                      Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None)
             else:
                 tile = lib.conv_tile(c, c, 3, 2, lib.MODE_UP2, B, L)
                 nt = _cdiv(L, tile)
@@ -684,7 +695,7 @@ class Engine:
             else:
                 nslab = max(1, min(1024, _cdiv(B * L, 4096)))
                 slab = torch.empty(nslab, 64, device=dev, dtype=torch.float32)
-                lib.enc_first_bwd(ec['x'], gn1, blk['y1'], blk['st1'], bs1, gpre, slab, nslab, B, L, c)
+                lib.enc_first_bwd(ec['x'], gn1, blk['y1'], blk['st1'], bs1, gpre, slab, nslab, B, L, c, w1=P[p + 'conv1.conv.weight'])
                 n1, nd = p + 'conv1.conv.weight', p + 'downsample.weight'
                 self._colsum(slab, nslab, 48, self.G[n1], accumulate=n1 in self._written, ld=64)
                 self._colsum(slab.view(-1)[48:], nslab, 16, self.G[nd], accumulate=nd in self._written, ld=64)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('W2S_LIB') or os.path.join(_HERE, 'libw2s_hip.so')  # 
 CSRC = os.path.join(_HERE, 'csrc')
 
 # enums (include/w2s.h)
-PRO_NONE, PRO_SANITIZE, PRO_GELU, PRO_IN_GELU, PRO_INBWD, PRO_INBWD_GP = range(6)
+PRO_NONE, PRO_SANITIZE, PRO_GELU, PRO_IN_GELU, PRO_INBWD, PRO_INBWD_GP, PRO_FIRST = range(7)
 EPI_PLAIN, EPI_STATS, EPI_AUX_INGELU_ADD, EPI_BIAS, EPI_GP = range(5)
 MODE_CONTIG, MODE_DILATED, MODE_UP2 = range(3)
 ELT_GELU, ELT_GELU_BWD, ELT_ADD, ELT_ADD_DROP, ELT_DROP, ELT_GELU_DROP, ELT_GELU_DROP_BWD = range(7)
@@ -175,7 +175,8 @@ def conv_forward(a: ConvArgs):
     if TIMER is None:
         return run()
     out_el = a.B * a.L_out * a.cout
-    nbytes = 4 * (a.B * a.L_in * a.cin * (2 if a.x2 else 1) + out_el * (2 if a.y2 else 1) + (out_el if a.aux else 0) + (out_el // 2 if a.add_even else 0))
+    in_el = a.B * a.L_in if a.pro == PRO_FIRST else a.B * a.L_in * a.cin * (2 if a.x2 else 1)
+    nbytes = 4 * (in_el + out_el * (2 if a.y2 else 1) + (out_el if a.aux else 0) + (out_el // 2 if a.add_even else 0))
     taps_eff = 1.5 if a.mode == MODE_UP2 else a.taps
     flops = int(2 * out_el * a.cin * taps_eff)
     nt = 8 if a.cout >= 128 else 4 if a.cout >= 64 else 2 if a.cout >= 32 else 1
@@ -187,7 +188,7 @@ def conv_forward(a: ConvArgs):
     # key == the kernel name rocprofv3 reports, so bench.py's average can be checked against profiles/
     spec = (-1, -1)
     if not a.y2 and not a.rowkeep:
-        hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)]}
+        hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4), (6, 1)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)]}
         if (a.pro, a.epi) in hot.get((a.mode, a.taps, a.stride), []):
             spec = (a.pro, a.epi)
     bf = 1 if (a.w_hi and a.w_lo and a.cin >= 32 and nt >= 2) else 0
@@ -249,15 +250,16 @@ def bwd_fused_folds_residual(cg, ch) -> bool:
 
 
 def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False,
-              gpre=None, wd=None, slab_d=None):
+              gpre=None, wd=None, slab_d=None, w1=None):
     def run():
         _chk(load().w2s_bwd_fused(_f(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), _f(gout), _f(part),
-                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _stream()),
+                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _stream()),
              f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
-    nbytes = 4 * (2 * B * Lg * cg + 2 * B * Lh * ch + (B * Lh * ch // 2 if add_even is not None else 0) + (B * Lh * cg // 2 if gpre is not None else 0))
+    nbytes = 4 * (2 * B * Lg * cg + (B * Lh * (ch + 1) if w1 is not None else 2 * B * Lh * ch) + (B * Lh * ch // 2 if add_even is not None else 0)
+                  + (B * Lh * cg // 2 if gpre is not None else 0))
     flops = 2 * B * Lg * cg * ch * 3 * 2
     if split_precision:
-        key = f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}, {1 if gpre is not None else 0}>'
+        key = f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}, {1 if gpre is not None else 0}, {1 if w1 is not None else 0}>'
     else:
         key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}, 1>'
     if DETAIL:
@@ -330,8 +332,8 @@ def enc_first_join(x, wd, y3, stats3, pre, B, L, cout):
     _chk(load().w2s_enc_first_join(_f(x), _f(wd), _f(y3), _f(stats3), _f(pre), B, L, cout, _stream()), 'w2s_enc_first_join')
 
 
-def enc_first_bwd(x, gn1, y1, stats1, bstats1, gpre, slab, nslab, B, L, cout):
-    _chk(load().w2s_enc_first_bwd(_f(x), _f(gn1), _f(y1), _f(stats1), _f(bstats1), _f(gpre), _f(slab), nslab, B, L, cout, _stream()),
+def enc_first_bwd(x, gn1, y1, stats1, bstats1, gpre, slab, nslab, B, L, cout, w1=None):
+    _chk(load().w2s_enc_first_bwd(_f(x), _f(gn1), _f(y1), _f(stats1), _f(bstats1), _f(gpre), _f(slab), nslab, B, L, cout, _f(w1), _stream()),
          'w2s_enc_first_bwd')
 
 
