@@ -50,11 +50,42 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);  // exp(-x^2/2)
   return cdf + x * pdf;
 }
+// 4-wide forms written on the vector type: every polynomial step is one float4 fma (two v_pk_fma_f32), and the four
+// divisions of the rational erf share ONE v_rcp_f32 (quarter-rate) through r = 1/(q0 q1 q2 q3); |q| is in [0.014, 2.4], so
+// the product cannot over/underflow.  The 16/32-channel kernels are VALU-co-limited (profiles/: VALU ~55 % busy at 4 TB/s), so
+// instruction count here is throughput.
+__device__ __forceinline__ f32x4 splat4(float c) { return (f32x4){c, c, c, c}; }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x4 erf4(f32x4 x) {
+  x.x = __builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f); x.y = __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f);
+  x.z = __builtin_amdgcn_fmed3f(x.z, -4.0f, 4.0f); x.w = __builtin_amdgcn_fmed3f(x.w, -4.0f, 4.0f);
+  const f32x4 x2 = x * x;
+  f32x4 p = fma4(x2, splat4(-2.72614225801306e-10f), splat4(2.77068142495902e-08f));
+  p = fma4(x2, p, splat4(-2.10102402082508e-06f));
+  p = fma4(x2, p, splat4(-5.69250639462346e-05f));
+  p = fma4(x2, p, splat4(-7.34990630326855e-04f));
+  p = fma4(x2, p, splat4(-2.95459980854025e-03f));
+  p = fma4(x2, p, splat4(-1.60960333262415e-02f));
+  f32x4 q = fma4(x2, splat4(-1.45660718464996e-05f), splat4(-2.13374055278905e-04f));
+  q = fma4(x2, q, splat4(-1.68282697438203e-03f));
+  q = fma4(x2, q, splat4(-7.37332916720468e-03f));
+  q = fma4(x2, q, splat4(-1.42647390514189e-02f));
+  // 1/q for the four lanes from one reciprocal
+  const float q01 = q.x * q.y, q23 = q.z * q.w;
+  const float r = __builtin_amdgcn_rcpf(q01 * q23);
+  const float r01 = r * q23, r23 = r * q01;
+  const f32x4 inv = {r01 * q.y, r01 * q.x, r23 * q.w, r23 * q.z};
+  return (x * p) * inv;
+}
 __device__ __forceinline__ f32x4 gelu4(f32x4 v) {
-  f32x4 r; r.x = gelu_f(v.x); r.y = gelu_f(v.y); r.z = gelu_f(v.z); r.w = gelu_f(v.w); return r;
+  const f32x4 e = erf4(v * 0.70710678118654752440f);
+  return (v * 0.5f) * (e + 1.0f);
 }
 __device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
-  f32x4 r; r.x = gelu_grad_f(v.x); r.y = gelu_grad_f(v.y); r.z = gelu_grad_f(v.z); r.w = gelu_grad_f(v.w); return r;
+  const f32x4 cdf = fma4(erf4(v * 0.70710678118654752440f), splat4(0.5f), splat4(0.5f));
+  const f32x4 t = v * v * -0.72134752044448170368f;  // exp(-x^2/2) = 2^t
+  const f32x4 pdf = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y), __builtin_amdgcn_exp2f(t.z), __builtin_amdgcn_exp2f(t.w)};
+  return fma4(v * 0.39894228040143267794f, pdf, cdf);
 }
 __device__ __forceinline__ float sanitize_f(float x) { return isinf(x) ? 0.0f : x; }
 

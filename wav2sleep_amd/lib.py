@@ -279,6 +279,8 @@ def frag_major_planes(a_RK: torch.Tensor):
     """[rows, K] fp32 GEMM operand -> (hi, lo) bf16 planes in the fragment-major order the split-precision conv reads
     (include/w2s.h, w2s_repack_bf16); rows % 16 == 0, K % 32 == 0.  Tooling / tests; the engine uses w2s_repack_batch."""
     R, K = a_RK.shape
+    if K % 32 or R % 16:   # layers below 32 input channels run fp32 MFMA: no planes
+        return None, None
     hi = a_RK.bfloat16()
     lo = (a_RK - hi.float()).bfloat16()
     f = lambda t: t.view(R // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
