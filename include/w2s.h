@@ -124,7 +124,8 @@ typedef struct w2s_repack_job {
 int w2s_repack_batch(const w2s_repack_job* jobs, int njobs, void* stream);
 /* the same two GEMM operands (rows o x K = taps*cin, rows c x K = taps*cout) as bf16 (hi, lo) planes with w = hi + lo, stored
  * fragment-major: element (row, k) at (((row/16)*(K/32) + k/32)*64 + ((k%32)/8)*16 + row%16)*8 + k%8, so that one wave fetch of a
- * 16x32 MFMA operand is a contiguous 1 KB run; operands of the split-precision ("bf16x3") path; planes may be NULL in pairs */
+ * 16x32 MFMA operand is a contiguous 1 KB run (cin == 16, forward planes only: K is padded to 32*ceil(taps/2) and the caller
+ * zero-fills the planes once -- two taps share one K step); operands of the split-precision ("bf16x3") path; planes may be NULL in pairs */
 int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, void* bwd_lo, int cout, int cin, int taps, void* stream);
 
 /*

@@ -6,7 +6,7 @@ Tolerances (north_star asks logits within 1e-3 rtol and identical arg-max stage 
   logits   max |delta| <= 1e-3 * max |logit|  (observed 2e-5 .. 3e-4 abs on logits of magnitude ~4: the >= 64-channel GEMMs run
            split-precision "bf16x3" on the matrix cores = the reference's own float32_matmul_precision('high') class; with
            W2S_EXACT_FP32=1 everything is fp32 MFMA and the error is ~2e-5);  arg-max labels: exactly equal
-  gradients: relative L2 error per parameter tensor <= 2e-3 (observed ~3e-4)
+  gradients: relative L2 error per parameter tensor <= 2e-3 and no element off by more than 2e-3 of the tensor scale (observed rel-L2 <= 5e-4)
 """
 import os
 
@@ -87,8 +87,14 @@ def test_train_steps_match_reference_goldens(name):
         assert out['lr'] == pytest.approx(float(g[f'lr{step}']), rel=1e-6)
         if step == 0:
             for k, p in model._engine.G.items():
-                assert_summary_close(p, g[f'grad0.{k}'], rtol=2e-3, atol=3e-4 * max(1.0, float(np.abs(g[f'grad0.{k}']).max()) if g[f'grad0.{k}'].shape == tuple(p.shape) else 1.0),
-                                     what=f'grad0.{k}')
+                want = g[f'grad0.{k}']
+                if want.shape == tuple(p.shape):   # full tensor stored: the documented bar -- relative L2 <= 2e-3, and no element
+                    got = p.detach().cpu().double().numpy()                          # further off than 2e-3 of the tensor's scale
+                    rel = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+                    assert rel <= 2e-3, (k, rel)
+                    assert np.abs(got - want).max() <= 2e-3 * max(np.abs(want).max(), 1e-6) + 1e-7, (k, np.abs(got - want).max(), np.abs(want).max())
+                else:
+                    assert_summary_close(p, want, rtol=2e-3, atol=3e-4, what=f'grad0.{k}')
     sd = model.state_dict()
     for k in sd:
         assert_summary_close(sd[k], g[f'param2.{k}'], rtol=1e-5, atol=1.1e-6, what=f'param2.{k}')

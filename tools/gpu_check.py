@@ -65,7 +65,8 @@ def t_conv_split_precision():
     """bf16x3 matrix-core path (w = hi + lo planes): same contract as fp32, error <= ~2^-16 per product."""
     B = 2
     for (cin, cout, taps, stride, L, mode, dil) in [(64, 64, 3, 1, 300, 0, 1), (32, 64, 3, 1, 300, 0, 1), (128, 128, 3, 2, 256, 0, 1), (128, 384, 1, 1, 333, 0, 1),
-                                                   (128, 128, 7, 1, 200, 1, 4), (64, 128, 1, 2, 256, 0, 1)]:
+                                                   (128, 128, 7, 1, 200, 1, 4), (64, 128, 1, 2, 256, 0, 1), (16, 16, 3, 1, 300, 0, 1), (16, 32, 3, 2, 256, 0, 1), (16, 16, 1, 2, 256, 0, 1),
+                                                   (16, 32, 1, 2, 512, 0, 1)]:
         pad = (taps // 2) * dil
         x = torch.randn(B, cin, L); w = torch.randn(cout, cin, taps) / math.sqrt(cin * taps)
         want = F.conv1d(x.double(), w.double(), stride=stride, padding=pad, dilation=dil).float()
@@ -232,7 +233,8 @@ def model_case(name, signal_map, nc, B, S, missing):
         for i in range(len(cfg.encoder_channels(sig))):
             k = f'signal_encoders.encoders.{enc}.cnn.{i}.out'
             if sum(1 for s2 in signal_map if signal_map[s2] == enc) == 1:
-                report(f'{name} {sig} block{i}', F.gelu(T[f'{sig}.pre.{i}']), cl(taps[k]), tol=2e-4)
+                # split-precision products: ~1e-5 relative per conv layer, 30 layers deep for the 10-block EOG encoders
+                report(f'{name} {sig} block{i}', F.gelu(T[f'{sig}.pre.{i}']), cl(taps[k]), tol=4e-4)
     report(f'{name} mixer', T['mixer'], taps['mixer'], tol=2e-4)
     report(f'{name} seq', F.gelu(T['seq_pre']), taps['seq'], tol=2e-4)
     report(f'{name} logits', logits, want, tol=2e-4)

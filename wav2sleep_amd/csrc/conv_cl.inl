@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
       for (int j = 0; j < 3; ++j) w1r[i][j] = a.x2[(myc4 * 4 + i) * 3 + j];
   }
 
-  float* xsL = smem + P.nr_lds * RS;  // W2S_PRO_FIRST: sanitised signal samples rb-1 .. rb+NR (zero outside the recording)
+  float* xsL = BF ? reinterpret_cast<float*>(loL + P.nr_lds * RSE) : smem + P.nr_lds * RS;  // W2S_PRO_FIRST: sanitised signal samples rb-1 .. rb+NR (zero outside the recording)
   auto stage = [&](int rb, int NR, int rowmul) {
     constexpr int U = (NT >= 8) ? 8 : 4;  // loads in flight per thread per batch (bigger windows: fewer round trips)
     if (pro == W2S_PRO_FIRST) {
@@ -225,8 +225,42 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
     const int dil = (TAPS > 1 && a.dil > 1) ? a.dil : 1;
     stage(t0 * STRIDE - a.pad, (TM - 1) * STRIDE + (TAPS - 1) * dil + 1, 1);
     __syncthreads();
+    if (BF && cin == 16) {
+      // 16 input channels: two taps share one K = 32 step (lane groups 0,1 carry tap 2*ks, groups 2,3 tap 2*ks+1; the weight
+      // planes are zero beyond the last tap).  The fp32-MFMA form of these layers spends 31 % of the issue time in the
+      // matrix pipe on top of 43 % VALU (profiles/: both compete for issue); this one needs a quarter of the MFMA cycles.
+      constexpr int KSP = (TAPS + 1) / 2;
+      const int half = g >> 1, col = 8 * (g & 1);
 #pragma unroll
-    for (int j = 0; j < TAPS; ++j) mma_tap(j, (a.flip ? (TAPS - 1 - j) : j) * dil, (1 << MT) - 1);
+      for (int ks = 0; ks < KSP; ++ks) {
+        const int j = (2 * ks + half < TAPS) ? 2 * ks + half : TAPS - 1;
+        const int rowoff = (a.flip ? (TAPS - 1 - j) : j) * dil;
+        bf16x8 bh[MT], bl[MT], ah[NTW], al[NTW];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int row = (wm0 + mt * 16 + r) * STRIDE + rowoff;
+          bh[mt] = *reinterpret_cast<const bf16x8*>(hiL + row * RSE + col);
+          bl[mt] = *reinterpret_cast<const bf16x8*>(loL + row * RSE + col);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const size_t wo = ((size_t)((n0 + wn0) / 16 + nt) * KSP + ks) * 512 + lane * 8;
+          ah[nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_hi) + wo);
+          al[nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_lo) + wo);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl[mt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TAPS; ++j) mma_tap(j, (a.flip ? (TAPS - 1 - j) : j) * dil, (1 << MT) - 1);
+    }
   } else if (MODE == W2S_MODE_DILATED) {
     for (int j = 0; j < TAPS; ++j) {
       const int off = a.flip ? (TAPS - 1 - j) : j;
@@ -383,11 +417,11 @@ static int dispatch_cfg(const w2s_conv_args& a, hipStream_t s) {
   const TileCfg c = pick_cfg(a.cin, a.cout, TAPS, STRIDE, MODE, a.B, a.L_out, a.dil > 0 ? a.dil : 1);
   if (a.cout % (c.nt * 16)) return W2S_EINVAL;
   // split-precision path: caller supplied bf16 weight planes (>= 32 input and output channels)
-  const bool bf = a.w_hi && a.w_lo && a.cin >= 32 && c.nt >= 2;
+  const bool bf = a.w_hi && a.w_lo && ((a.cin >= 32 && c.nt >= 2) || (a.cin == 16 && MODE == W2S_MODE_CONTIG && (TAPS == 1 || TAPS == 3) && a.dil <= 1));
 #define W2S_CFG(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_ && !bf) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_, PRO, EPI, 0>(a, s);
 #define W2S_CFGB(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_ && bf) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_, PRO, EPI, 1>(a, s);
   W2S_CFG(1, 4, 1) W2S_CFG(2, 4, 1) W2S_CFG(2, 2, 1) W2S_CFG(4, 4, 2) W2S_CFG(4, 2, 2) W2S_CFG(8, 4, 2) W2S_CFG(8, 2, 2) W2S_CFG(1, 2, 1)
-  W2S_CFGB(2, 4, 1) W2S_CFGB(2, 2, 1) W2S_CFGB(4, 4, 2) W2S_CFGB(4, 2, 2) W2S_CFGB(8, 4, 2) W2S_CFGB(8, 2, 2)
+  W2S_CFGB(1, 4, 1) W2S_CFGB(1, 2, 1) W2S_CFGB(2, 4, 1) W2S_CFGB(2, 2, 1) W2S_CFGB(4, 4, 2) W2S_CFGB(4, 2, 2) W2S_CFGB(8, 4, 2) W2S_CFGB(8, 2, 2)
 #undef W2S_CFG
 #undef W2S_CFGB
   return W2S_EINVAL;

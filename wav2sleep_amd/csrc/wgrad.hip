@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void repack_batch_kernel(RepackBatch T) {
   if (J.fh || J.bh) {
     const __bf16 h = (__bf16)v;
     const __bf16 l = (__bf16)(v - (float)h);
-    if (J.fh) { const size_t d = w2s_frag_index(o, j * J.cin + c, J.taps * J.cin); J.fh[d] = h; J.fl[d] = l; }
+    if (J.fh) { const size_t d = w2s_frag_index(o, j * J.cin + c, J.cin == 16 ? ((J.taps + 1) / 2) * 32 : J.taps * J.cin); J.fh[d] = h; J.fl[d] = l; }
     if (J.bh) { const size_t d = w2s_frag_index(c, j * J.cout + o, J.taps * J.cout); J.bh[d] = h; J.bl[d] = l; }
   }
 }
@@ -723,7 +723,7 @@ __global__ void repack_bf16_kernel(const float* __restrict__ w, __bf16* __restri
   const float v = w[idx];
   const __bf16 h = (__bf16)v;
   const __bf16 l = (__bf16)(v - (float)h);
-  if (fh) { const size_t d = w2s_frag_index(o, j * cin + c, taps * cin); fh[d] = h; fl[d] = l; }
+  if (fh) { const size_t d = w2s_frag_index(o, j * cin + c, cin == 16 ? ((taps + 1) / 2) * 32 : taps * cin); fh[d] = h; fl[d] = l; }
   if (bh) { const size_t d = w2s_frag_index(c, j * cout + o, taps * cout); bh[d] = h; bl[d] = l; }
 }
 

@@ -133,13 +133,14 @@ class Engine:
             if self.split_precision:
                 # forward operand (packed copy, or the torch tensor itself when taps == 1) and data-gradient operand
                 fop = f if f is not None else w
-                want_f = cin >= 32 and cout >= 32
+                want_f = (cin >= 32 and cout >= 32) or (cin == 16 and taps in (1, 3))   # 16 channels: two taps per K step
                 want_b = bw is not None and cout >= 32 and cin >= 32
                 planes = self._bfbuf.setdefault(name, {})
                 for kind, want in (('f', want_f), ('b', want_b)):
                     if want and kind not in planes:
-                        planes[kind] = (torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16),
-                                        torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16))
+                        n = cout * 32 * ((taps + 1) // 2) if (kind == 'f' and cin == 16) else w.numel()   # padded K, zero tail
+                        planes[kind] = (torch.zeros(n, device=w.device, dtype=torch.bfloat16),
+                                        torch.zeros(n, device=w.device, dtype=torch.bfloat16))
                 fh, fl = planes['f'] if want_f else (None, None)
                 bh, bl = planes['b'] if want_b else (None, None)
                 if want_f:

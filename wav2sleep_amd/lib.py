@@ -191,7 +191,7 @@ def conv_forward(a: ConvArgs):
         hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4), (6, 1)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)]}
         if (a.pro, a.epi) in hot.get((a.mode, a.taps, a.stride), []):
             spec = (a.pro, a.epi)
-    bf = 1 if (a.w_hi and a.w_lo and a.cin >= 32 and nt >= 2) else 0
+    bf = 1 if (a.w_hi and a.w_lo and ((a.cin >= 32 and nt >= 2) or (a.cin == 16 and a.mode == MODE_CONTIG and a.taps in (1, 3) and a.dil <= 1))) else 0
     key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}, {wn}, {spec[0]}, {spec[1]}, {bf}>'
     if DETAIL:
         key += f' {a.cin}->{a.cout} pro{a.pro} epi{a.epi} L{a.L_out}'
@@ -279,7 +279,10 @@ def frag_major_planes(a_RK: torch.Tensor):
     """[rows, K] fp32 GEMM operand -> (hi, lo) bf16 planes in the fragment-major order the split-precision conv reads
     (include/w2s.h, w2s_repack_bf16); rows % 16 == 0, K % 32 == 0.  Tooling / tests; the engine uses w2s_repack_batch."""
     R, K = a_RK.shape
-    if K % 32 or R % 16:   # layers below 32 input channels run fp32 MFMA: no planes
+    if K % 32 and K % 16 == 0:   # 16 input channels: K padded with zeros to a multiple of 32 (two taps per K step)
+        a_RK = torch.cat([a_RK, a_RK.new_zeros(R, 32 - K % 32)], dim=1)
+        K = a_RK.shape[1]
+    if K % 32 or R % 16:
         return None, None
     hi = a_RK.bfloat16()
     lo = (a_RK - hi.float()).bfloat16()
