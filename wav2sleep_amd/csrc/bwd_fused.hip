@@ -393,15 +393,18 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   }
   auto prefetch = [&](int tl) {
     const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
-    const float* gb = P.g + (size_t)b * Lg * GC + gch;
-    const float* yb = P.y + (size_t)b * Lg * GC + gch;
+    // wave-uniform 64-bit base per sample + 32-bit per-lane offsets (a sample's tensor is < 4 GB): scalar-base addressing,
+    // no 64-bit VALU address arithmetic per load
+    const float* gb = P.g + (size_t)b * Lg * GC;
+    const float* yb = P.y + (size_t)b * Lg * GC;
     const int rb = UP2 ? t0 / 2 : t0 - 1;
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
       const int row = grow0 + k * rstep_g, gr = rb + row;
       const bool ok = row < NRg && gr >= 0 && gr < Lg;
-      rg[k] = ok ? ld4(gb + (size_t)gr * GC) : (f32x4){0, 0, 0, 0};
-      ry[k] = ok ? ld4(yb + (size_t)gr * GC) : (f32x4){0, 0, 0, 0};
+      const unsigned off = (unsigned)gr * GC + gch;
+      rg[k] = ok ? ld4o(gb, off) : (f32x4){0, 0, 0, 0};
+      ry[k] = ok ? ld4o(yb, off) : (f32x4){0, 0, 0, 0};
     }
     if (FIRST) {  // TM + 4 signal samples t0-2 .. t0+TM+1: one per thread (+4), exchanged through LDS at commit time
       const float* xs = P.xin + (size_t)b * Lh;
@@ -412,20 +415,20 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
         rxs[k] = (i < TM + 4 && gr >= 0 && gr < Lh && !isinf(xv)) ? xv : 0.f;
       }
     } else {
-      const float* xb = P.xin + (size_t)b * Lh * HC + hch;
+      const float* xb = P.xin + (size_t)b * Lh * HC;
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
         const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
         const bool ok = row < NRh && gr >= 0 && gr < Lh;
-        rh[k] = ok ? ld4(xb + (size_t)gr * HC) : (f32x4){0, 0, 0, 0};
+        rh[k] = ok ? ld4o(xb, (unsigned)gr * HC + hch) : (f32x4){0, 0, 0, 0};
       }
     }
     if (RD) {
-      const float* pb = P.gpre + (size_t)b * (Lh >> 1) * GC + gch;
+      const float* pb = P.gpre + (size_t)b * (Lh >> 1) * GC;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const int row = grow0 + k * rstep_g, gr = t0 / 2 + row;
-        rp[k] = (row < TM / 2 && gr < (Lh >> 1)) ? ld4(pb + (size_t)gr * GC) : (f32x4){0, 0, 0, 0};
+        rp[k] = (row < TM / 2 && gr < (Lh >> 1)) ? ld4o(pb, (unsigned)gr * GC + gch) : (f32x4){0, 0, 0, 0};
       }
     }
   };
@@ -601,14 +604,13 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
       for (int nt = 0; nt < CH; ++nt) {
         const int ch = nt * 16 + 4 * g;
-        const size_t orow = (size_t)b * Lh + pos;
         const f32x4 n = *reinterpret_cast<const f32x4*>(nL + (pos - t0) * RSn + ch);
         f32x4 v = acc[mt][nt];
-        if (P.add_even && !(pos & 1)) v += ld4(P.add_even + ((size_t)b * (Lh >> 1) + (pos >> 1)) * HC + ch);
+        if (P.add_even && !(pos & 1)) v += ld4o(P.add_even + (size_t)b * (Lh >> 1) * HC, (unsigned)(pos >> 1) * HC + ch);
         v = v * gelu_grad4(n);
         sA[nt] += v;
         sB[nt] += v * n;
-        st4(P.gout + orow * HC + ch, v);
+        st4o(P.gout + (size_t)b * Lh * HC, (unsigned)pos * HC + ch, v);
       }
     }
     if (P.part) {

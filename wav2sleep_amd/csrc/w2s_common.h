@@ -91,6 +91,13 @@ __device__ __forceinline__ float sanitize_f(float x) { return isinf(x) ? 0.0f : 
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// wave-uniform base + 32-bit BYTE offset per lane: selects the scalar-base addressing mode (no 64-bit VALU address arithmetic)
+__device__ __forceinline__ f32x4 ld4o(const float* base, unsigned elem_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + (elem_off << 2));
+}
+__device__ __forceinline__ void st4o(float* base, unsigned elem_off, f32x4 v) {
+  *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + (elem_off << 2)) = v;
+}
 
 // counter-based RNG for dropout: splitmix64 of (seed, element index) -> uniform [0,1).  The same
 // (seed, index) regenerates the same mask in the backward pass; nothing is stored.
@@ -106,11 +113,22 @@ __device__ __forceinline__ float w2s_dropscale(uint64_t seed, uint64_t idx, floa
 }
 
 // sum over the 16 lanes that share (lane >> 4)  [row of the MFMA output fragment]
+// DPP lane permutes inside a 16-lane row (no LDS traffic, unlike the ds_bpermute behind __shfl_xor): pair swap, quad-pair
+// swap, then the 8-lane and 16-lane mirrors -- after the quad steps every lane of a quad holds the quad sum, so a mirror
+// partner always contributes the other half.  Fixed order => deterministic.
+__device__ __forceinline__ float dpp_f(float v, const int ctrl) {
+  switch (ctrl) {  // the control must be an immediate
+    case 0: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    case 1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    case 2: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false)); // row_mirror
+  }
+}
 __device__ __forceinline__ float row16_sum(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
+  v += dpp_f(v, 0);
+  v += dpp_f(v, 1);
+  v += dpp_f(v, 2);
+  v += dpp_f(v, 3);
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
