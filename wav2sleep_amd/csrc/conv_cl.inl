@@ -97,8 +97,9 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
       ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
     }
   }
-  const float* xb = (pro == W2S_PRO_FIRST) ? a.x + (size_t)b * L_in : a.x + (size_t)b * L_in * a.ldx + myc4 * 4;
-  const float* x2b = (pro == W2S_PRO_INBWD || pro == W2S_PRO_INBWD_GP) ? a.x2 + (size_t)b * L_in * a.ldx + myc4 * 4 : nullptr;
+  // wave-uniform per-sample bases + 32-bit lane offsets: scalar-base addressing (a sample's tensor is < 4 GB)
+  const float* xb = (pro == W2S_PRO_FIRST) ? a.x + (size_t)b * L_in : a.x + (size_t)b * L_in * a.ldx;
+  const float* x2b = (pro == W2S_PRO_INBWD || pro == W2S_PRO_INBWD_GP) ? a.x2 + (size_t)b * L_in * a.ldx : nullptr;
   float w1r[4][3];  // W2S_PRO_FIRST: this thread's 4 output channels of block 0's conv1 (a.x2 = its weight [16][3])
   if (pro == W2S_PRO_FIRST) {
 #pragma unroll
@@ -134,8 +135,9 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
           v2[u] = (f32x4){0, 0, 0, 0};
           continue;
         }
-        v[u] = ok ? ld4(xb + (size_t)gr * a.ldx) : (f32x4){0, 0, 0, 0};
-        v2[u] = (ok && x2b) ? ld4(x2b + (size_t)gr * a.ldx) : (f32x4){0, 0, 0, 0};
+        const unsigned xo = (unsigned)gr * (unsigned)a.ldx + myc4 * 4;
+        v[u] = ok ? ld4o(xb, xo) : (f32x4){0, 0, 0, 0};
+        v2[u] = (ok && x2b) ? ld4o(x2b, xo) : (f32x4){0, 0, 0, 0};
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -297,24 +299,24 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
       const int ch = n0 + wn0 + nt * 16 + 4 * g;
       f32x4 v = acc[mt][nt];
       if (!valid) continue;
-      const size_t orow = (size_t)b * L_out + pos;
+      const size_t ob = (size_t)b * L_out;   // uniform row base; per-lane parts stay 32-bit
       if (epi == W2S_EPI_BIAS) {
         if (a.bias) v += ld4(a.bias + ch);
       } else if (epi == W2S_EPI_AUX_INGELU_ADD) {
-        f32x4 ax = ld4(a.aux + orow * a.ld_aux + ch);
+        f32x4 ax = ld4o(a.aux + ob * a.ld_aux, (unsigned)pos * (unsigned)a.ld_aux + ch);
         const float* st = a.aux_stats + ((size_t)b * cout + ch) * 2;
         f32x4 s01 = ld4(st), s23 = ld4(st + 4);
         f32x4 mean = {s01.x, s01.z, s23.x, s23.z}, rstd = {s01.y, s01.w, s23.y, s23.w};
         v += gelu4((ax - mean) * rstd);
       } else if (epi == W2S_EPI_GP) {
-        f32x4 n = ld4(a.aux + orow * a.ld_aux + ch);
+        f32x4 n = ld4o(a.aux + ob * a.ld_aux, (unsigned)pos * (unsigned)a.ld_aux + ch);
         if (a.aux_stats) {
           const float* st = a.aux_stats + ((size_t)b * cout + ch) * 2;
           f32x4 s01 = ld4(st), s23 = ld4(st + 4);
           f32x4 mean = {s01.x, s01.z, s23.x, s23.z}, rstd = {s01.y, s01.w, s23.y, s23.w};
           n = (n - mean) * rstd;
         }
-        if (a.add_even && !(pos & 1)) v += ld4(a.add_even + ((size_t)b * (L_out >> 1) + (pos >> 1)) * cout + ch);
+        if (a.add_even && !(pos & 1)) v += ld4o(a.add_even + (size_t)b * (L_out >> 1) * cout, (unsigned)(pos >> 1) * (unsigned)cout + ch);
         v = v * gelu_grad4(n);
         sA[nt] += v;
         sB[nt] += v * n;
@@ -323,8 +325,8 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
         sB[nt] += v * v;
       }
       v = v * keep;
-      st4(a.y + orow * a.ldy + ch, v);
-      if (a.y2) st4(a.y2 + orow * a.ldy2 + ch, gelu4(v));
+      st4o(a.y + ob * a.ldy, (unsigned)pos * (unsigned)a.ldy + ch, v);
+      if (a.y2) st4o(a.y2 + ob * a.ldy2, (unsigned)pos * (unsigned)a.ldy2 + ch, gelu4(v));
     }
   }
 
