@@ -75,14 +75,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP P) {
         load_chan_params(a.g_stats, b, a.cout, ch, pm, pr);
         if (a.pro_g >= W2S_PRO_INBWD) load_chan_params(a.g_bstats, b, a.cout, ch, ps1, ps2);
       }
-      const float* gb = a.g + (size_t)b * a.L_out * a.ldg + ch;
-      const float* g2b = (a.pro_g >= W2S_PRO_INBWD) ? a.g2 + (size_t)b * a.L_out * a.ldg + ch : nullptr;
+      const float* gb = a.g + (size_t)b * a.L_out * a.ldg;   // uniform base, 32-bit lane offsets (scalar-base addressing)
+      const float* g2b = (a.pro_g >= W2S_PRO_INBWD) ? a.g2 + (size_t)b * a.L_out * a.ldg : nullptr;
       for (int row = row0; row < TM; row += rstep) {
         const int t = t0 + row;
         f32x4 v = {0, 0, 0, 0};
         if (t < a.L_out) {
-          f32x4 x = ld4(gb + (size_t)t * a.ldg);
-          f32x4 x2 = g2b ? ld4(g2b + (size_t)t * a.ldg) : (f32x4){0, 0, 0, 0};
+          const unsigned go = (unsigned)t * (unsigned)a.ldg + ch;
+          f32x4 x = ld4o(gb, go);
+          f32x4 x2 = g2b ? ld4o(g2b, go) : (f32x4){0, 0, 0, 0};
           v = pro4(a.pro_g, x, x2, pm, pr, ps1, ps2);
         }
         st4(gyL + row * RSg + myc4 * 4, v);
@@ -93,13 +94,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP P) {
       const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
       f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, z = {0, 0, 0, 0};
       if (a.pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
-      const float* xb = a.x + (size_t)b * a.L_in * a.ldx + ch;
+      const float* xb = a.x + (size_t)b * a.L_in * a.ldx;
       const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
       const int rowmul = (TAPS_T == 1) ? STRIDE : 1;
       for (int row = row0; row < NRh; row += rstep) {
         const int gr = rb + row * rowmul;
         f32x4 v = {0, 0, 0, 0};
-        if (gr >= 0 && gr < a.L_in) v = pro4(a.pro_h, ld4(xb + (size_t)gr * a.ldx), z, pm, pr, z, z);
+        if (gr >= 0 && gr < a.L_in) v = pro4(a.pro_h, ld4o(xb, (unsigned)gr * (unsigned)a.ldx + ch), z, pm, pr, z, z);
         st4(hL + row * RSh + ch, v);
       }
     }
@@ -191,8 +192,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
           const int t = t0 + row;
           f32x4 v = {0, 0, 0, 0};
           if (t < a.L_out) {
-            f32x4 x = ld4(gb + (size_t)t * a.ldg + ch);
-            f32x4 x2 = g2b ? ld4(g2b + (size_t)t * a.ldg + ch) : (f32x4){0, 0, 0, 0};
+            const unsigned go = (unsigned)t * (unsigned)a.ldg + ch;
+            f32x4 x = ld4o(gb, go);
+            f32x4 x2 = g2b ? ld4o(g2b, go) : (f32x4){0, 0, 0, 0};
             v = pro4(pro_g, x, x2, pm, pr, ps1, ps2);
           }
           st4(gyL + row * RSg + ch, v);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
       } else {  // wide untransformed gradients (transformer linears): launcher guarantees pro_g == NONE
         for (int f = tid; f < TM * c4n; f += NT) {
           const int row = f / c4n, ch = (f % c4n) * 4, t = t0 + row;
-          st4(gyL + row * RSg + ch, t < a.L_out ? ld4(gb + (size_t)t * a.ldg + ch) : (f32x4){0, 0, 0, 0});
+          st4(gyL + row * RSg + ch, t < a.L_out ? ld4o(gb, (unsigned)t * (unsigned)a.ldg + ch) : (f32x4){0, 0, 0, 0});
         }
       }
     }
@@ -209,13 +211,13 @@ __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
       const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
       f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, z = {0, 0, 0, 0};
       if (pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
-      const float* xb = a.x + (size_t)b * a.L_in * a.ldx + ch;
+      const float* xb = a.x + (size_t)b * a.L_in * a.ldx;
       const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
       const int rowmul = (JT == 1) ? STRIDE : 1;
       for (int row = row0; row < NRh; row += rstep) {
         const int gr = rb + row * rowmul;
         f32x4 v = {0, 0, 0, 0};
-        if (gr >= 0 && gr < a.L_in) v = pro4(pro_h, ld4(xb + (size_t)gr * a.ldx), z, pm, pr, z, z);
+        if (gr >= 0 && gr < a.L_in) v = pro4(pro_h, ld4o(xb, (unsigned)gr * (unsigned)a.ldx + ch), z, pm, pr, z, z);
         st4(hL + row * RSh + ch, v);
       }
     }
@@ -320,8 +322,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
           const int t = t0 + row;
           f32x4 v = {0, 0, 0, 0};
           if (t < a.L_out) {
-            f32x4 x = ld4(gb + (size_t)t * a.ldg + ch);
-            f32x4 x2 = g2b ? ld4(g2b + (size_t)t * a.ldg + ch) : (f32x4){0, 0, 0, 0};
+            const unsigned go = (unsigned)t * (unsigned)a.ldg + ch;
+            f32x4 x = ld4o(gb, go);
+            f32x4 x2 = g2b ? ld4o(g2b, go) : (f32x4){0, 0, 0, 0};
             v = pro4(pro_g, x, x2, pm, pr, ps1, ps2);
           }
           split_store(gH, gL, row * RSg + ch, v);
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
       } else {
         for (int f = tid; f < TM * c4n; f += NT) {
           const int row = f / c4n, ch = (f % c4n) * 4, t = t0 + row;
-          split_store(gH, gL, row * RSg + ch, t < a.L_out ? ld4(gb + (size_t)t * a.ldg + ch) : (f32x4){0, 0, 0, 0});
+          split_store(gH, gL, row * RSg + ch, t < a.L_out ? ld4o(gb, (unsigned)t * (unsigned)a.ldg + ch) : (f32x4){0, 0, 0, 0});
         }
       }
     }
@@ -338,13 +341,13 @@ __global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
       const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
       f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, z = {0, 0, 0, 0};
       if (pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
-      const float* xb = a.x + (size_t)b * a.L_in * a.ldx + ch;
+      const float* xb = a.x + (size_t)b * a.L_in * a.ldx;
       const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
       const int rowmul = (JT == 1) ? STRIDE : 1;
       for (int row = row0; row < NRh; row += rstep) {
         const int gr = rb + row * rowmul;
         f32x4 v = {0, 0, 0, 0};
-        if (gr >= 0 && gr < a.L_in) v = pro4(pro_h, ld4(xb + (size_t)gr * a.ldx), z, pm, pr, z, z);
+        if (gr >= 0 && gr < a.L_in) v = pro4(pro_h, ld4o(xb, (unsigned)gr * (unsigned)a.ldx + ch), z, pm, pr, z, z);
         split_store(hH, hL, row * RSh + ch, v);
       }
     }
