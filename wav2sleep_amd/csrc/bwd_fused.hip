@@ -336,8 +336,12 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   // stride 2 (even outputs use tap 1, odd outputs taps 2 and 0): [tap1 | 0] [tap2 | tap0].
   constexpr int KD = (GC == 32) ? (RD ? 128 : 96) : 64;   // RD: [tap2 | Wd] (16 ch) / a fourth K step = Wd (32 ch)
   constexpr int WROW = KD + 8;
+  // GPS (16 input-side channels: the LDS budget allows it): GELU'(n) of the centre rows is computed once, together with
+  // GELU(n), while the window is staged, instead of a second erf evaluation in the epilogue
+  constexpr int GPS = (HC == 16) ? 1 : 0;
   float* nL = reinterpret_cast<float*>(smem4);              // [TM][RSn] normalised input of the centre rows
-  float* red = nL + TM * RSn;                               // [4][CH][4][8] stats scratch
+  float* gpL = nL + TM * RSn;                               // [TM][RSn] GELU'(n) of the centre rows (GPS)
+  float* red = gpL + (GPS ? TM * RSn : 0);                  // [4][CH][4][8] stats scratch
   __bf16* gyH = reinterpret_cast<__bf16*>(red + bwd_redn(CH));
   __bf16* gyLo = gyH + NRg * RSg;
   __bf16* hH = gyLo + NRg * RSg;
@@ -480,8 +484,15 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
           xv = rh[k];
         }
         const f32x4 nv = (xv - hm) * hr;
-        split_store4(hH, hLo, row * RSh + hch, ok ? gelu4(nv) : (f32x4){0, 0, 0, 0});
-        if (row >= 1 && row <= TM) st4(nL + (row - 1) * RSn + hch, nv);
+        if (GPS) {
+          f32x4 hv, gpv;
+          gelu_both4(nv, hv, gpv);
+          split_store4(hH, hLo, row * RSh + hch, ok ? hv : (f32x4){0, 0, 0, 0});
+          if (row >= 1 && row <= TM) { st4(nL + (row - 1) * RSn + hch, nv); st4(gpL + (row - 1) * RSn + hch, gpv); }
+        } else {
+          split_store4(hH, hLo, row * RSh + hch, ok ? gelu4(nv) : (f32x4){0, 0, 0, 0});
+          if (row >= 1 && row <= TM) st4(nL + (row - 1) * RSn + hch, nv);
+        }
       }
     }
     if (RD) {
@@ -607,7 +618,7 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
         const f32x4 n = *reinterpret_cast<const f32x4*>(nL + (pos - t0) * RSn + ch);
         f32x4 v = acc[mt][nt];
         if (P.add_even && !(pos & 1)) v += ld4o(P.add_even + (size_t)b * (Lh >> 1) * HC, (unsigned)(pos >> 1) * HC + ch);
-        v = v * gelu_grad4(n);
+        v = v * (GPS ? *reinterpret_cast<const f32x4*>(gpL + (pos - t0) * RSn + ch) : gelu_grad4(n));
         sA[nt] += v;
         sB[nt] += v * n;
         st4o(P.gout + (size_t)b * Lh * HC, (unsigned)pos * HC + ch, v);
@@ -712,7 +723,7 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   BwdP P = P0;
   P.ntiles = (P.Lh + TM - 1) / TM;
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = UP2 ? TM + 1 : TM + 2, NRp = RD ? TM / 2 + 1 : 0;
-  size_t lds = (size_t)TM * bwd_rs(HC) * 4 + (size_t)bwd_redn(CH) * 4 +
+  size_t lds = (size_t)TM * bwd_rs(HC) * 4 * (HC == 16 ? 2 : 1) + (size_t)bwd_redn(CH) * 4 +
                (size_t)2 * 2 * ((NRg + NRp) * bf_rs(GC) + NRh * bf_rs(HC) + HC * (KD + 8));
   if (FIRST) lds += (size_t)(TM + 4) * 4;
   if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4]

@@ -87,6 +87,14 @@ __device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
   const f32x4 pdf = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y), __builtin_amdgcn_exp2f(t.z), __builtin_amdgcn_exp2f(t.w)};
   return fma4(v * 0.39894228040143267794f, pdf, cdf);
 }
+// GELU and GELU' of the same argument from ONE erf evaluation (the fused backward needs both for the tile's centre rows)
+__device__ __forceinline__ void gelu_both4(f32x4 v, f32x4& h, f32x4& gp) {
+  const f32x4 cdf = fma4(erf4(v * 0.70710678118654752440f), splat4(0.5f), splat4(0.5f));
+  const f32x4 t = v * v * -0.72134752044448170368f;
+  const f32x4 pdf = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y), __builtin_amdgcn_exp2f(t.z), __builtin_amdgcn_exp2f(t.w)};
+  h = v * cdf;
+  gp = fma4(v * 0.39894228040143267794f, pdf, cdf);
+}
 __device__ __forceinline__ float sanitize_f(float x) { return isinf(x) ? 0.0f : x; }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
