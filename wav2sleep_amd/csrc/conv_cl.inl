@@ -57,8 +57,10 @@ __device__ __forceinline__ f32x4 pro_apply(int pro, f32x4 v, f32x4 v2, f32x4 mea
 // 16x16x32 product runs as three bf16 MFMAs  hi*hi + hi*lo + lo*hi  with fp32 accumulation: 3 x 16 cycles per 32 channels
 // instead of 8 x 32 cycles of fp32 MFMA (5.3x), relative error per product <= 2^-16.  This is the arithmetic class the
 // reference itself trains with (torch.set_float32_matmul_precision('high') = TF32 / bf16_3x, scripts/train.py:117).
+// 128-wide tiles are LDS-limited to two workgroups per CU anyway: cap the allocator at two waves per SIMD's worth of registers
+// (the generic split-precision instance landed on 257 registers = one wave per SIMD, -35 % on the transformer GEMMs)
 template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN, int PRO, int EPI, int BF>
-__global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2 : 1))) void conv_cl_kernel(ConvP P) {
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
   const w2s_conv_args& a = P.a;
@@ -98,10 +100,10 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
     }
   }
   // wave-uniform per-sample bases + 32-bit lane offsets: scalar-base addressing (a sample's tensor is < 4 GB)
-  const float* xb = (pro == W2S_PRO_FIRST) ? a.x + (size_t)b * L_in : a.x + (size_t)b * L_in * a.ldx;
+  const float* xb = ((PRO == W2S_PRO_FIRST)) ? a.x + (size_t)b * L_in : a.x + (size_t)b * L_in * a.ldx;
   const float* x2b = (pro == W2S_PRO_INBWD || pro == W2S_PRO_INBWD_GP) ? a.x2 + (size_t)b * L_in * a.ldx : nullptr;
   float w1r[4][3];  // W2S_PRO_FIRST: this thread's 4 output channels of block 0's conv1 (a.x2 = its weight [16][3])
-  if (pro == W2S_PRO_FIRST) {
+  if ((PRO == W2S_PRO_FIRST)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
   float* xsL = BF ? reinterpret_cast<float*>(loL + P.nr_lds * RSE) : smem + P.nr_lds * RS;  // W2S_PRO_FIRST: sanitised signal samples rb-1 .. rb+NR (zero outside the recording)
   auto stage = [&](int rb, int NR, int rowmul) {
     constexpr int U = (NT >= 8) ? 8 : 4;  // loads in flight per thread per batch (bigger windows: fewer round trips)
-    if (pro == W2S_PRO_FIRST) {
+    if ((PRO == W2S_PRO_FIRST)) {
       for (int i = tid; i < NR + 2; i += 256) {
         const int gr = rb - 1 + i;
         const float xv = xb[min(max(gr, 0), L_in - 1)];
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvP P) {
       for (int u = 0; u < U; ++u) {
         const int rr = row + u * rstep, gr = rb + rr * rowmul;
         const bool ok = (rr < NR) && (gr >= 0) && (gr < L_in);
-        if (pro == W2S_PRO_FIRST) {  // conv1 (Cin = 1, k = 3, zero padding) recomputed from the raw signal window in LDS
+        if ((PRO == W2S_PRO_FIRST)) {  // conv1 (Cin = 1, k = 3, zero padding) recomputed from the raw signal window in LDS
           const int xi = (rr < NR) ? rr : 0;
           const float xm = xsL[xi], xc = xsL[xi + 1], xp = xsL[xi + 2];
           v[u].x = w1r[0][0] * xm + w1r[0][1] * xc + w1r[0][2] * xp;
@@ -433,18 +435,26 @@ static int dispatch_cfg(const w2s_conv_args& a, hipStream_t s) {
 template <int TAPS, int STRIDE, int MODE>
 static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
   const bool plain_io = !a.y2 && !a.rowkeep;
-  if (plain_io && MODE == W2S_MODE_CONTIG && TAPS == 3 && STRIDE == 1) {
+  if constexpr (MODE == W2S_MODE_CONTIG && TAPS == 3 && STRIDE == 1) if (plain_io) {
     if (a.pro == W2S_PRO_GELU && a.epi == W2S_EPI_STATS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_GELU, W2S_EPI_STATS>(a, s);
     if (a.pro == W2S_PRO_IN_GELU && a.epi == W2S_EPI_STATS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_IN_GELU, W2S_EPI_STATS>(a, s);
     if (a.pro == W2S_PRO_INBWD && a.epi == W2S_EPI_GP) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_INBWD, W2S_EPI_GP>(a, s);
     if (a.pro == W2S_PRO_FIRST && a.epi == W2S_EPI_STATS && a.cin == 16)
       return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_FIRST, W2S_EPI_STATS>(a, s);
   }
-  if (plain_io && MODE == W2S_MODE_CONTIG && TAPS == 3 && STRIDE == 2 && a.pro == W2S_PRO_IN_GELU && a.epi == W2S_EPI_STATS)
-    return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_IN_GELU, W2S_EPI_STATS>(a, s);
-  if (plain_io && MODE == W2S_MODE_CONTIG && TAPS == 1 && STRIDE == 2 && a.pro == W2S_PRO_GELU && a.epi == W2S_EPI_AUX_INGELU_ADD)
-    return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_GELU, W2S_EPI_AUX_INGELU_ADD>(a, s);
-  if (plain_io && MODE == W2S_MODE_UP2 && a.pro == W2S_PRO_INBWD_GP && a.epi == W2S_EPI_GP)
-    return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_INBWD_GP, W2S_EPI_GP>(a, s);
+  if constexpr (MODE == W2S_MODE_CONTIG && TAPS == 3 && STRIDE == 2)
+    if (plain_io && a.pro == W2S_PRO_IN_GELU && a.epi == W2S_EPI_STATS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_IN_GELU, W2S_EPI_STATS>(a, s);
+  if constexpr (MODE == W2S_MODE_CONTIG && TAPS == 1 && STRIDE == 2)
+    if (plain_io && a.pro == W2S_PRO_GELU && a.epi == W2S_EPI_AUX_INGELU_ADD)
+      return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_GELU, W2S_EPI_AUX_INGELU_ADD>(a, s);
+  // transformer / SequenceCNN GEMMs (no on-load transform): without the prologue variants the 128-wide instance keeps its
+  // accumulators in AGPRs and two waves per SIMD
+  if constexpr ((MODE == W2S_MODE_CONTIG && TAPS == 1 && STRIDE == 1) || (MODE == W2S_MODE_DILATED && TAPS == STRIDE))
+    if (plain_io && a.pro == W2S_PRO_NONE && a.epi == W2S_EPI_BIAS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_NONE, W2S_EPI_BIAS>(a, s);
+  if constexpr (TAPS == 7 && STRIDE == 1)
+    if (plain_io && a.pro == W2S_PRO_NONE && a.epi == W2S_EPI_PLAIN) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_NONE, W2S_EPI_PLAIN>(a, s);
+  if constexpr (MODE == W2S_MODE_UP2)
+    if (plain_io && a.pro == W2S_PRO_INBWD_GP && a.epi == W2S_EPI_GP) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_INBWD_GP, W2S_EPI_GP>(a, s);
+  if (a.pro == W2S_PRO_FIRST) return W2S_EINVAL;  // only the specialised (FIRST, STATS) k=3/stride-1 instance implements it
   return dispatch_cfg<TAPS, STRIDE, MODE, -1, -1>(a, s);
 }
