@@ -451,6 +451,8 @@ static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
   // accumulators in AGPRs and two waves per SIMD
   if constexpr ((MODE == W2S_MODE_CONTIG && TAPS == 1 && STRIDE == 1) || (MODE == W2S_MODE_DILATED && TAPS == STRIDE))
     if (plain_io && a.pro == W2S_PRO_NONE && a.epi == W2S_EPI_BIAS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_NONE, W2S_EPI_BIAS>(a, s);
+  if constexpr (MODE == W2S_MODE_CONTIG && TAPS == 1 && STRIDE == 1)
+    if (plain_io && a.pro == W2S_PRO_NONE && a.epi == W2S_EPI_PLAIN) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_NONE, W2S_EPI_PLAIN>(a, s);
   if constexpr (TAPS == 7 && STRIDE == 1)
     if (plain_io && a.pro == W2S_PRO_NONE && a.epi == W2S_EPI_PLAIN) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_NONE, W2S_EPI_PLAIN>(a, s);
   if constexpr (MODE == W2S_MODE_UP2)

@@ -189,7 +189,7 @@ def conv_forward(a: ConvArgs):
     spec = (-1, -1)
     if not a.y2 and not a.rowkeep:
         hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4), (6, 1)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)],
-               (0, 1, 1): [(0, 3)], (1, 4, 4): [(0, 3)], (1, 3, 3): [(0, 3)], (0, 7, 1): [(0, 0)], (1, 7, 1): [(0, 0)]}
+               (0, 1, 1): [(0, 3), (0, 0)], (1, 4, 4): [(0, 3)], (1, 3, 3): [(0, 3)], (0, 7, 1): [(0, 0)], (1, 7, 1): [(0, 0)]}
         if (a.pro, a.epi) in hot.get((a.mode, a.taps, a.stride), []):
             spec = (a.pro, a.epi)
     bf = 1 if (a.w_hi and a.w_lo and ((a.cin >= 32 and nt >= 2) or (a.cin == 16 and a.mode == MODE_CONTIG and a.taps in (1, 3) and a.dil <= 1))) else 0
