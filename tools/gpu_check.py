@@ -311,7 +311,108 @@ def t_fused_residual_fold():
             report(f'fold {cg}->{ch} L{Lh} wgrad', outs[1][1], outs[0][1], tol=2e-4)
             report(f'fold {cg}->{ch} L{Lh} downsample wgrad', outs[1][2], want_gd, tol=2e-4)
 
-STAGES = dict(fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+def t_first_layer_recompute():
+    """W2S_PRO_FIRST flow: the consumers of block 0's conv1 output recompute it from the raw signal -- against the same
+    kernels fed with the stored tensor (bit-level arithmetic differs only in the 3-FMA conv itself)."""
+    B, L, c = 2, 1500, 16
+    x = torch.randn(B, L, device=dev); x[0, 7] = float('inf')
+    w1 = torch.randn(16, 1, 3, device=dev) / 2
+    w2 = torch.randn(16, 16, 3, device=dev) / 7
+    tile = 1024
+    nt = (L + tile - 1) // tile
+    y1 = torch.zeros(B, L, c, device=dev); part = torch.zeros(B, nt, 2, c, device=dev)
+    lib.enc_first_fwd(x, w1, y1, part, B, L, c, tile)
+    part2 = torch.zeros_like(part)
+    lib.enc_first_fwd(x, w1, None, part2, B, L, c, tile)                       # statistics only
+    report('first: stats-only partials', part2, part, tol=1e-6)
+    st1 = torch.zeros(B, c, 2, device=dev)
+    lib.stats_finalize(part, B, nt, c, L, 1e-2, 0, st1)
+    wp = pack_fwd(w2).to(dev)
+    outs = []
+    for first in (False, True):
+        for planes in (None, lib.frag_major_planes(wp.view(c, 3 * c))):
+            y2 = torch.zeros(B, L, c, device=dev)
+            t2 = lib.conv_tile(c, c, 3, 1, lib.MODE_CONTIG, B, L)
+            p2 = torch.zeros(B, (L + t2 - 1) // t2, 2, c, device=dev)
+            kw = dict(w_hi=planes[0], w_lo=planes[1]) if planes else {}
+            lib.conv_forward(lib.conv_args(x=x if first else y1, x2=w1 if first else None, w=wp, y=y2, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3,
+                                           stride=1, pad=1, pro=lib.PRO_FIRST if first else lib.PRO_IN_GELU, pro_stats=st1, epi=lib.EPI_STATS,
+                                           part=p2, ldx=4 if first else None, **kw))
+            outs.append((y2, p2))
+    report('first: conv2 fp32 recompute vs stored', outs[2][0], outs[0][0], tol=2e-5)
+    report('first: conv2 bf16x3 recompute vs stored', outs[3][0], outs[1][0], tol=2e-5)
+    report('first: conv2 bf16x3 vs fp32', outs[1][0], outs[0][0], tol=5e-5)
+    report('first: conv2 stats partials', outs[3][1], outs[1][1], tol=1e-4)
+    # fused conv2 backward: xin = stored y1 vs raw signal
+    g = torch.randn(B, L, c, device=dev); y2 = outs[0][0]
+    st2 = torch.rand(B, c, 2, device=dev) + 0.5; bst = torch.rand(B, c, 2, device=dev) * 0.01
+    wb = torch.randn(c, 3, c, device=dev) / 7
+    tilef = lib.bwd_fused_tile(c, c); ntf = (L + tilef - 1) // tilef; ns = min(B * ntf, 5)
+    res = []
+    for first in (False, True):
+        gout = torch.zeros(B, L, c, device=dev); pt = torch.zeros(B, ntf, 2, c, device=dev)
+        slab = torch.zeros(ns * c * c * 3, device=dev); grad = torch.zeros(c, c, 3, device=dev)
+        lib.bwd_fused(g=g, y=y2, st_k=st2, bst_k=bst, pro=lib.PRO_INBWD, xin=x if first else y1, st_in=st1, add_even=None, wb=wb, gout=gout, part=pt,
+                      slab=slab, nslab=ns, B=B, Lg=L, Lh=L, cg=c, ch=c, stride=1, split_precision=True, w1=w1 if first else None)
+        lib.wgrad_reduce(slab, ns, grad, c, c, 3, 1, accumulate=False, layout=0)
+        res.append((gout, pt, grad))
+    for nm, a, b in zip(('gout', 'part', 'wgrad'), res[1], res[0]):
+        report(f'first: fused conv2 backward {nm}', a, b, tol=5e-5)
+    # first-layer weight gradients: stored vs recomputed y1
+    gpre = torch.randn(B, L // 2, c, device=dev); bs1 = torch.rand(B, c, 2, device=dev) * 0.01
+    sl = []
+    for first in (False, True):
+        slab = torch.zeros(8, 64, device=dev)
+        lib.enc_first_bwd(x, g, None if first else y1, st1, bs1, gpre, slab, 8, B, L, c, w1=w1)
+        sl.append(slab.sum(0))
+    report('first: conv1 / downsample weight gradients', sl[1], sl[0], tol=5e-5)
+
+
+def t_batched_entry_points():
+    """w2s_wgrad_reduce_batch / w2s_colsum_batch / w2s_repack_batch against their single-job forms."""
+    jobs, want = [], []
+    for (cout, cin, taps, ns) in ((16, 16, 3, 7), (64, 64, 3, 9), (128, 128, 1, 5), (32, 16, 1, 33), (128, 64, 3, 4)):
+        slab = torch.randn(ns * cout * cin * taps, device=dev)
+        g1 = torch.randn(cout, cin, taps, device=dev); g2 = g1.clone()
+        acc = (cout == 64)
+        lib.wgrad_reduce(slab, ns, g1, cout, cin, taps, 1, accumulate=acc, layout=0)
+        jobs.append((slab, ns, g2, cout, cin, taps, 1, acc, 0)); want.append((g1, g2))
+    lib.wgrad_reduce_batch(jobs)
+    for i, (a, b) in enumerate(want):
+        report(f'batch: slab reduce job {i}', b, a, tol=0)
+    cj, cw = [], []
+    for (nparts, C, ld) in ((40, 128, 128), (7, 4, 516), (300, 512, 512), (64, 48, 64)):
+        part = torch.randn(nparts, ld, device=dev); o1 = torch.randn(C, device=dev); o2 = o1.clone()
+        lib.colsum(part, nparts, C, o1, accumulate=(C == 4), ld=ld)
+        cj.append((part, nparts, C, o2, C == 4, ld)); cw.append((o1, o2))
+    lib.colsum_batch(cj)
+    for i, (a, b) in enumerate(cw):
+        report(f'batch: column sum job {i}', b, a, tol=0)
+    rj, rw = [], []
+    for (cout, cin, taps) in ((64, 32, 3), (128, 128, 7), (32, 16, 3), (16, 16, 1), (128, 64, 1)):
+        w = torch.randn(cout, cin, taps, device=dev)
+        f = torch.zeros(cout * cin * taps, device=dev); bw = torch.zeros_like(f)
+        kf = 32 * ((taps + 1) // 2) if cin == 16 else taps * cin
+        fh = torch.zeros(cout * kf, device=dev, dtype=torch.bfloat16); fl = torch.zeros_like(fh)
+        bh = bl = None
+        if cin >= 32 and cout >= 32:
+            bh = torch.zeros(cin * taps * cout, device=dev, dtype=torch.bfloat16); bl = torch.zeros_like(bh)
+        rj.append((w, f, bw, fh, fl, bh, bl, cout, cin, taps)); rw.append(w)
+    lib.repack_batch(rj)
+    for (w, f, bw, fh, fl, bh, bl, cout, cin, taps) in rj:
+        wf = w.permute(0, 2, 1).contiguous()                     # [o][j][c]
+        wb_ = w.permute(1, 2, 0).contiguous()                    # [c][j][o]
+        report(f'batch: repack fwd {cin}->{cout} k{taps}', f.view_as(wf), wf, tol=0)
+        report(f'batch: repack bwd {cin}->{cout} k{taps}', bw.view_as(wb_), wb_, tol=0)
+        h, l = lib.frag_major_planes(wf.view(cout, taps * cin))
+        report(f'batch: fragment-major hi plane {cin}->{cout} k{taps}', fh.float(), h.float(), tol=0)
+        report(f'batch: fragment-major lo plane {cin}->{cout} k{taps}', fl.float(), l.float(), tol=0)
+        if bh is not None:
+            h, l = lib.frag_major_planes(wb_.view(cin, taps * cout))
+            report(f'batch: fragment-major dgrad hi plane {cin}->{cout} k{taps}', bh.float(), h.float(), tol=0)
+
+
+STAGES = dict(first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))
