@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
                                                             const float* __restrict__ bstats1, const float* __restrict__ gpre,
                                                             float* __restrict__ slab, int B, int L, const float* __restrict__ w1) {
   __shared__ float red[4][4][16];
+  __shared__ float xs[1026];
   const int tid = threadIdx.x, og = tid & 3, lane = tid & 63, wave = tid >> 6;
   float wr[4][3];  // y1 == NULL: the conv1 output is recomputed from x (never stored)
 #pragma unroll
@@ -122,16 +123,26 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
     f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
     f32x4 q1 = {b01.x, b01.z, b23.x, b23.z}, q2 = {b01.y, b01.w, b23.y, b23.w};
     const float* xb = x + (size_t)b * L;
+    // the item's 1026 sanitised signal samples t0-1 .. t0+1024 through LDS (one coalesced pass instead of three 4-B loads
+    // per position)
+    __syncthreads();
+    for (int i = tid; i < 1026; i += 256) {
+      const int t = t0 - 1 + i;
+      const float xv = xb[min(max(t, 0), L - 1)];
+      xs[i] = (t >= 0 && t < L && !isinf(xv)) ? xv : 0.f;
+    }
+    __syncthreads();
+    const float* gb = gn1 + (size_t)b * L * 16;
+    const float* yb = y1 ? y1 + (size_t)b * L * 16 : nullptr;
+    const float* pb = gpre + (size_t)b * (L >> 1) * 16;
 #pragma unroll 4
     for (int p = tid >> 2; p < 1024; p += 64) {
       const int t = t0 + p;
       if (t >= L) break;
-      const size_t off = ((size_t)b * L + t) * 16 + og * 4;
-      const float xm = (t > 0) ? sanitize_f(xb[t - 1]) : 0.f;
-      const float xc = sanitize_f(xb[t]);
-      const float xp = (t + 1 < L) ? sanitize_f(xb[t + 1]) : 0.f;
+      const unsigned off = (unsigned)t * 16 + og * 4;
+      const float xm = xs[p], xc = xs[p + 1], xp = xs[p + 2];
       f32x4 yv;
-      if (y1) yv = ld4(y1 + off);
+      if (yb) yv = ld4o(yb, off);
       else {
         yv.x = wr[0][0] * xm + wr[0][1] * xc + wr[0][2] * xp;
         yv.y = wr[1][0] * xm + wr[1][1] * xc + wr[1][2] * xp;
@@ -139,13 +150,13 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
         yv.w = wr[3][0] * xm + wr[3][1] * xc + wr[3][2] * xp;
       }
       f32x4 n = (yv - mean) * rstd;
-      f32x4 gy = rstd * (ld4(gn1 + off) - q1 - n * q2);
+      f32x4 gy = rstd * (ld4o(gb, off) - q1 - n * q2);
       acc[0] += gy.x * xm; acc[1] += gy.x * xc; acc[2] += gy.x * xp;
       acc[3] += gy.y * xm; acc[4] += gy.y * xc; acc[5] += gy.y * xp;
       acc[6] += gy.z * xm; acc[7] += gy.z * xc; acc[8] += gy.z * xp;
       acc[9] += gy.w * xm; acc[10] += gy.w * xc; acc[11] += gy.w * xp;
       if (!(t & 1)) {
-        f32x4 gp = ld4(gpre + ((size_t)b * (L >> 1) + (t >> 1)) * 16 + og * 4);
+        f32x4 gp = ld4o(pb, (unsigned)(t >> 1) * 16 + og * 4);
         acc[12] += gp.x * xc; acc[13] += gp.y * xc; acc[14] += gp.z * xc; acc[15] += gp.w * xc;
       }
     }
