@@ -59,7 +59,7 @@ def test_argument_validation_without_gpu(built_lib):
     w = L.WgradArgs()
     assert dll.w2s_wgrad(ctypes.byref(w), None) == -1
     assert dll.w2s_stats_finalize(None, 1, 1, 16, ctypes.c_long(1), ctypes.c_float(0.01), 0, None, None) == -1
-    assert L.conv_tile(16, 16, 3, 1) == 256 and L.conv_tile(128, 128, 3, 1) == 128
+    assert L.conv_tile(16, 16, 3, 1) == 256 and L.conv_tile(128, 128, 3, 1) == 64
     assert L.wgrad_grid_y(128, 128, 3) == 1 and L.wgrad_grid_y(128, 128, 7, 2) == 7 and L.wgrad_grid_y(16, 16, 3) == 1
     assert L.wgrad_slabs_per_block(128, 128, 3) == 1 and L.wgrad_slabs_per_block(16, 16, 3) == 4 and L.bwd_fused_tile(16, 16) == 256
 
