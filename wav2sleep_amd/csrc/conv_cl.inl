@@ -378,6 +378,7 @@ static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode
   if ((size_t)window_rows(16 * c.mt * (4 / c.wn), taps, stride, mode, dil) * (cin + 4) * 4 > 72 * 1024) c.mt = 2;
   if (c.nt >= 8) c.mt = 2;  // 128-wide tiles: 64 positions (four workgroups per CU) beat 128 now that a weight fragment is one 1 KB fetch
   { static const char* e = getenv("W2S_FORCE_MT"); if (e && c.nt >= 4) c.mt = atoi(e); }  // tuning only
+  { static const char* e = getenv("W2S_FORCE_MT8"); if (e && c.nt >= 8) c.mt = atoi(e); }  // tuning only
   { static const char* e = getenv("W2S_FORCE_NT"); if (e && c.nt >= 8) c.nt = atoi(e); }  // tuning only
   { static const char* e = getenv("W2S_NO_SHRINK"); if (e) return c; }                    // tuning only
   // short problems (SequenceCNN: 16 x 960 rows): shrink the tile until the grid covers the 256 CUs about twice
