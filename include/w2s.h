@@ -11,7 +11,9 @@
  *     16-byte aligned, ACTIVATIONS ARE CHANNELS-LAST: [B][L][C] (row = one time position, C contiguous);
  *   - asynchronous on `stream` (a hipStream_t passed as void*), no internal sync, no allocation, no global
  *     state => re-entrant across streams/devices and capturable into a hipGraph;
- *   - return 0 on success, negative W2S_E* on error (never throws, never aborts).
+ *   - return 0 on success, negative W2S_E* on error (never throws, never aborts);
+ *   - ONE SAMPLE's tensor (L * ld * 4 bytes) must stay below 4 GiB: lanes address inside a sample with 32-bit byte offsets from a
+ *     wave-uniform 64-bit base (W2S_EINVAL otherwise).  An 8-h recording at 128 Hz x 16 channels is 252 MB.
  */
 #ifndef W2S_H
 #define W2S_H

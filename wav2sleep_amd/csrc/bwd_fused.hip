@@ -755,6 +755,7 @@ extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, 
                              int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
                              const float* w1, void* stream) {
   if (!g || !y || !st_k || !bst_k || !xin || !wb || !gout || !slab || nslab <= 0) return W2S_EINVAL;
+  if ((size_t)Lh * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;  // 32-bit lane offsets inside one sample
   if (pro != W2S_PRO_INBWD && pro != W2S_PRO_INBWD_GP) return W2S_EINVAL;
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
   if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in

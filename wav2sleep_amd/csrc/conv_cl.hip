@@ -23,6 +23,14 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a.cin < 16 || a.cin > 128 || (a.cin & (a.cin - 1)) || (a.cout & 15) || a.B <= 0 || a.L_out <= 0) return W2S_EINVAL;
   if (((a.ldx & 3) && a.pro != W2S_PRO_FIRST) || (a.ldy & 3) || !a.x || !a.w || !a.y) return W2S_EINVAL;
+  // lane offsets inside one sample are 32-bit byte offsets (scalar-base addressing): refuse tensors that do not fit
+  {
+    const size_t lim = (size_t)1 << 32;
+    const size_t ldx = a.pro == W2S_PRO_FIRST ? 1 : (size_t)a.ldx;
+    if ((size_t)a.L_in * ldx * 4 >= lim || (size_t)a.L_out * (size_t)a.ldy * 4 >= lim) return W2S_EINVAL;
+    if (a.y2 && (size_t)a.L_out * (size_t)(a.ldy2 ? a.ldy2 : a.cout) * 4 >= lim) return W2S_EINVAL;
+    if (a.aux && (size_t)a.L_out * (size_t)(a.ld_aux ? a.ld_aux : a.cout) * 4 >= lim) return W2S_EINVAL;
+  }
   if (a.pro >= W2S_PRO_IN_GELU && !a.pro_stats) return W2S_EINVAL;
   if ((a.pro == W2S_PRO_INBWD || a.pro == W2S_PRO_INBWD_GP) && (!a.pro_bstats || !a.x2)) return W2S_EINVAL;
   if (a.pro == W2S_PRO_FIRST && (!a.x2 || a.cin != 16 || a.taps != 3 || a.stride != 1 || a.mode != W2S_MODE_CONTIG)) return W2S_EINVAL;

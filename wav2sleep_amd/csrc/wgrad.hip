@@ -606,6 +606,7 @@ extern "C" int w2s_wgrad(const w2s_wgrad_args* ap, void* stream) {
   const w2s_wgrad_args& a = *ap;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a.cin < 16 || a.cin > 128 || (a.cin & (a.cin - 1)) || (a.cout & 15) || !a.g || !a.x || !a.slab) return W2S_EINVAL;
+  if ((size_t)a.L_out * (size_t)a.ldg * 4 >= ((size_t)1 << 32) || (size_t)a.L_in * (size_t)a.ldx * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;  // 32-bit lane offsets
   if (a.pro_g >= W2S_PRO_IN_GELU && !a.g_stats) return W2S_EINVAL;
   if (a.pro_g >= W2S_PRO_INBWD && (!a.g_bstats || !a.g2)) return W2S_EINVAL;
   if (a.pro_h >= W2S_PRO_IN_GELU && !a.x_stats) return W2S_EINVAL;
