@@ -131,6 +131,19 @@ int w2s_repack_batch(const w2s_repack_job* jobs, int njobs, void* stream);
 int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, void* bwd_lo, int cout, int cin, int taps, void* stream);
 
 /*
+ * Forward k=3 (pad 1, stride 1 or 2) encoder conv + instance-norm statistics partials for the <= 32-channel layers as a persistent
+ * split-precision kernel (next tile prefetched into registers, weights LDS-resident): same result contract as w2s_conv_forward with
+ * pro in {W2S_PRO_GELU, W2S_PRO_IN_GELU, W2S_PRO_FIRST} and W2S_EPI_STATS.  x: [B][L_in][cin] (pro FIRST: the raw signal [B][L_in],
+ * w1 = block 0's conv1 weight), w: [cout][3][cin] (w2s_repack forward layout), st_in: [B][cin][2] (mean, rstd) unless pro == GELU,
+ * y: [B][L_out][cout], part: [B][ceil(L_out/tile)][2][cout] with tile = w2s_conv_fwd_fused_tile (0 = combination not covered),
+ * nwg = workgroups to launch (grid-stride over tiles).  Replaces aten::convolution + the statistics half of native_batch_norm
+ * (blocks.py:173-186).
+ */
+int w2s_conv_fwd_fused_tile(int cin, int cout, int stride);
+int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const float* w1, float* y, float* part, int B, int L_in,
+                       int L_out, int cin, int cout, int stride, int pro, int nwg, void* stream);
+
+/*
  * Fused backward of one encoder ConvLayer1D (k=3, pad=1, stride 1 or 2) for the bandwidth-bound <=32-channel layers:
  * data gradient + weight gradient from one pass over (g, y_k, y_{k-1}).  cg = channels of the gradient side (the
  * forward conv's cout), ch = channels of the input side (its cin); supported (cg,ch): (16,16) (32,16) (32,32).

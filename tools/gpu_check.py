@@ -412,7 +412,44 @@ def t_batched_entry_points():
             report(f'batch: fragment-major dgrad hi plane {cin}->{cout} k{taps}', bh.float(), h.float(), tol=0)
 
 
-STAGES = dict(first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+def t_fwd_fused():
+    """persistent split-precision forward conv (<= 32 channels) vs w2s_conv_forward with the same prologue / EPI_STATS."""
+    B = 3
+    for (cin, cout, stride, L) in ((16, 16, 1, 1000), (16, 16, 2, 1322), (16, 32, 1, 700), (32, 32, 1, 515), (32, 32, 2, 1026), (16, 16, 1, 64)):
+        Lo = L // stride
+        x = torch.randn(B, L, cin, device=dev)
+        w = torch.randn(cout, cin, 3, device=dev) / math.sqrt(3 * cin)
+        st = torch.stack([torch.randn(B, cin, device=dev) * 0.1, torch.rand(B, cin, device=dev) + 0.5], dim=-1).contiguous()
+        wp = pack_fwd(w).to(dev)
+        for pro in (lib.PRO_GELU, lib.PRO_IN_GELU):
+            t1 = lib.conv_tile(cin, cout, 3, stride, lib.MODE_CONTIG, B, Lo)
+            y1 = torch.zeros(B, Lo, cout, device=dev); p1 = torch.zeros(B, (Lo + t1 - 1) // t1, 2, cout, device=dev)
+            lib.conv_forward(lib.conv_args(x=x, w=wp, y=y1, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=3, stride=stride, pad=1, pro=pro,
+                                           pro_stats=st, epi=lib.EPI_STATS, part=p1))
+            t2 = lib.conv_fwd_fused_tile(cin, cout, stride)
+            y2 = torch.zeros(B, Lo, cout, device=dev); p2 = torch.zeros(B, (Lo + t2 - 1) // t2, 2, cout, device=dev)
+            lib.conv_fwd_fused(x=x, w=wp, st_in=st if pro != lib.PRO_GELU else None, w1=None, y=y2, part=p2, B=B, L_in=L, L_out=Lo, cin=cin,
+                               cout=cout, stride=stride, pro=pro, nwg=5)
+            report(f'fwd fused {cin}->{cout} s{stride} L{L} pro{pro}', y2, y1, tol=5e-5)
+            report(f'fwd fused {cin}->{cout} s{stride} L{L} pro{pro} stats', p2.sum(1), p1.sum(1), tol=2e-4)
+    # first-layer recompute flavour
+    L, c = 1500, 16
+    xs = torch.randn(B, L, device=dev); xs[1, 3] = float('-inf')
+    w1 = torch.randn(16, 1, 3, device=dev) / 2; w2 = torch.randn(16, 16, 3, device=dev) / 7
+    st = torch.stack([torch.randn(B, c, device=dev) * 0.1, torch.rand(B, c, device=dev) + 0.5], dim=-1).contiguous()
+    wp = pack_fwd(w2).to(dev)
+    t1 = lib.conv_tile(c, c, 3, 1, lib.MODE_CONTIG, B, L)
+    y1 = torch.zeros(B, L, c, device=dev); p1 = torch.zeros(B, (L + t1 - 1) // t1, 2, c, device=dev)
+    lib.conv_forward(lib.conv_args(x=xs, x2=w1, w=wp, y=y1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=1, pro=lib.PRO_FIRST,
+                                   pro_stats=st, epi=lib.EPI_STATS, part=p1, ldx=4))
+    t2 = lib.conv_fwd_fused_tile(c, c, 1)
+    y2 = torch.zeros(B, L, c, device=dev); p2 = torch.zeros(B, (L + t2 - 1) // t2, 2, c, device=dev)
+    lib.conv_fwd_fused(x=xs, w=wp, st_in=st, w1=w1, y=y2, part=p2, B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1, pro=lib.PRO_FIRST, nwg=7)
+    report('fwd fused first-layer recompute', y2, y1, tol=5e-5)
+    report('fwd fused first-layer recompute stats', p2.sum(1), p1.sum(1), tol=2e-4)
+
+
+STAGES = dict(fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

@@ -65,7 +65,22 @@ def fused_case(cg, ch, L, stride=1, B=16, nslab=None):
                                wb=wb, gout=gout, part=part, slab=slab, nslab=ns, B=B, Lg=Lg, Lh=L, cg=cg, ch=ch, stride=stride, split_precision=os.environ.get('BF') == '1')
     return fn, 4 * (2 * B * Lg * cg + 2 * B * L * ch), 2 * B * Lg * cg * ch * 3 * 2
 
+def ffwd_case(cin, cout, L, stride=1, B=16, pro=lib.PRO_IN_GELU):
+    Lo = L // stride
+    x = torch.randn(B, L, cin, device=dev); w = torch.randn(cout, 3, cin, device=dev) / (3 * cin) ** 0.5
+    st = torch.rand(B, cin, 2, device=dev) + 0.5
+    t = lib.conv_fwd_fused_tile(cin, cout, stride)
+    y = torch.empty(B, Lo, cout, device=dev); part = torch.empty(B, (Lo + t - 1) // t, 2, cout, device=dev)
+    nwg = int(os.environ.get('NWG', 1024 if cin == 16 else 512))
+    fn = lambda: lib.conv_fwd_fused(x=x, w=w, st_in=st, w1=None, y=y, part=part, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, stride=stride, pro=pro, nwg=nwg)
+    return fn, 4 * (B * L * cin + B * Lo * cout), 2 * B * Lo * cout * cin * 3
+
 CASES = {
+    'ff16': lambda: ffwd_case(16, 16, 983040),
+    'ff16s2': lambda: ffwd_case(16, 16, 983040, stride=2),
+    'ff1632': lambda: ffwd_case(16, 32, 245760),
+    'ff32': lambda: ffwd_case(32, 32, 245760),
+    'ff32s2': lambda: ffwd_case(32, 32, 245760, stride=2),
     'b16': lambda: fused_case(16, 16, 983040),
     'b16u': lambda: fused_case(16, 16, 983040, stride=2),
     'b32': lambda: fused_case(32, 32, 245760),
@@ -81,6 +96,8 @@ CASES = {
     'u16': lambda: conv_case(16, 16, 491520, stride=2, pro=lib.PRO_INBWD_GP, epi=lib.EPI_GP, mode=lib.MODE_UP2),
     'w16': lambda: wgrad_case(16, 16, 983040),
     'f32': lambda: conv_case(32, 32, 245760),
+    'f32s2': lambda: conv_case(32, 32, 245760, stride=2),
+    'f1632': lambda: conv_case(16, 32, 245760, pro=lib.PRO_GELU),
     'w32': lambda: wgrad_case(32, 32, 245760),
     'f64': lambda: conv_case(64, 64, 61440),
     'd64': lambda: conv_case(64, 64, 61440, pro=lib.PRO_INBWD, epi=lib.EPI_GP, flip=1),

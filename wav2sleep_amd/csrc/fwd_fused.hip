@@ -1,0 +1,249 @@
+// Forward k=3 encoder conv for the HBM-heavy <= 32-channel layers as a PERSISTENT kernel (split precision):
+//
+//   y[b,t,o] = sum_{j,c} W[o][c][j] * h[b, t*stride + j - 1, c],    h = GELU(x) | GELU(IN(x)) | GELU(IN(conv1(signal)))
+//   part[b][tile][2][CO] = per-tile sums of y and y^2   (instance-norm statistics of the NEXT layer, blocks.py:173-186)
+//
+// Same contract as conv_cl_kernel with EPI_STATS, different execution shape: workgroups walk the (sample, tile) list with a
+// grid stride, the NEXT tile's window is prefetched into registers while the current tile runs through the matrix cores
+// (conv_cl's one-tile workgroups serialise load latency, prologue arithmetic, MFMA and store drain), the weights live in
+// LDS as bf16 hi/lo planes for the whole launch, and every product is 3 x v_mfma_f32_16x16x32_bf16 (16 input channels: two
+// taps share one K = 32 step).  Replaces aten::convolution + native_batch_norm(statistics) of ConvLayer1D.forward.
+#include "conv_cl.inl"
+
+struct FwdP {
+  const float* x; const float* w; const float* st_in; const float* w1;
+  float* y; float* part;
+  int B, L_in, L_out, ntiles, pro;
+};
+
+typedef __bf16 bf16x4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fsplit_store4(__bf16* hi, __bf16* lo, int off, f32x4 t) {
+  bf16x4f h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
+  bf16x4f l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
+  *reinterpret_cast<bf16x4f*>(hi + off) = h;
+  *reinterpret_cast<bf16x4f*>(lo + off) = l;
+}
+__host__ __device__ constexpr int ff_rs(int c) { return c == 16 ? 16 : c + 8; }  // 32-B rows are conflict-free as they are
+
+// CI / CO: input / output channel tiles (16 each); MT: 16-position m-tiles per wave (TM = 64*MT outputs per tile);
+// PRO: W2S_PRO_GELU, W2S_PRO_IN_GELU or W2S_PRO_FIRST (x = raw signal, w1 = block 0's conv1 weight)
+template <int CI, int CO, int MT, int STRIDE, int PRO>
+__global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
+  extern __shared__ f32x4 smem4[];
+  constexpr int TM = 64 * MT;
+  constexpr int HC = CI * 16, OC = CO * 16;
+  constexpr int RSh = ff_rs(HC);
+  constexpr int NRh = (TM - 1) * STRIDE + 3;             // window rows; row 0 = input position t0*STRIDE - 1
+  constexpr int KSP = (HC == 16) ? 2 : 3;                // K = 32 steps: [tap0|tap1] [tap2|0]  or one tap each
+  constexpr int KD = KSP * 32, WROW = KD + 8;
+  float* red = reinterpret_cast<float*>(smem4);          // [4][CO][4][8] statistics scratch
+  __bf16* hH = reinterpret_cast<__bf16*>(red + 4 * CO * 4 * 8);
+  __bf16* hLo = hH + NRh * RSh;
+  __bf16* wH = hLo + NRh * RSh;                          // [OC][WROW]
+  __bf16* wLo = wH + OC * WROW;
+  float* xsL = reinterpret_cast<float*>(wLo + OC * WROW);  // FIRST: NRh + 2 signal samples
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int L_in = P.L_in, L_out = P.L_out;
+
+  // ---- weights [OC][3][HC] (forward packing) -> LDS planes once per launch; 16 channels: k = tap*16 + c, zero tail
+  for (int i = tid; i < OC * (KD / 4); i += 256) {
+    const int row = i / (KD / 4), k = (i % (KD / 4)) * 4;
+    f32x4 v = {0, 0, 0, 0};
+    if (k < 3 * HC) v = ld4(P.w + (size_t)row * (3 * HC) + k);
+    fsplit_store4(wH, wLo, row * WROW + k, v);
+  }
+
+  constexpr int c4h = HC / 4, rstep = 256 / c4h, NH = (NRh + rstep - 1) / rstep;
+  const int hc4 = tid % c4h, hrow0 = tid / c4h, hch = hc4 * 4;
+  constexpr bool FIRST = PRO == W2S_PRO_FIRST;
+  constexpr int NXS = FIRST ? (NRh + 2 + 255) / 256 : 1;
+  f32x4 rh[FIRST ? 1 : NH];
+  float rxs[NXS], w1r[4][3];
+  if (FIRST) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w1r[i][j] = P.w1[(hch + i) * 3 + j];
+  }
+  auto prefetch = [&](int tl) {
+    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+    const int rb = t0 * STRIDE - 1;
+    if (FIRST) {  // signal samples rb-1 .. rb+NRh
+      const float* xs = P.x + (size_t)b * L_in;
+#pragma unroll
+      for (int k = 0; k < NXS; ++k) {
+        const int i = tid + 256 * k, gr = rb - 1 + i;
+        const float xv = xs[min(max(gr, 0), L_in - 1)];
+        rxs[k] = (i < NRh + 2 && gr >= 0 && gr < L_in && !isinf(xv)) ? xv : 0.f;
+      }
+    } else {
+      const float* xb = P.x + (size_t)b * L_in * HC;
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const int row = hrow0 + k * rstep, gr = rb + row;
+        const bool ok = row < NRh && gr >= 0 && gr < L_in;
+        rh[k] = ok ? ld4o(xb, (unsigned)gr * HC + hch) : (f32x4){0, 0, 0, 0};
+      }
+    }
+  };
+  auto commit = [&](int tl) {
+    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+    const int rb = t0 * STRIDE - 1;
+    f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
+    if (PRO != W2S_PRO_GELU) {
+      const float* st = P.st_in + ((size_t)b * HC + hch) * 2;
+      f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+      hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+    }
+    if (FIRST) {
+#pragma unroll
+      for (int k = 0; k < NXS; ++k)
+        if (tid + 256 * k < NRh + 2) xsL[tid + 256 * k] = rxs[k];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int row = hrow0 + k * rstep, gr = rb + row;
+      if (row < NRh) {
+        const bool ok = gr >= 0 && gr < L_in;
+        f32x4 xv;
+        if (FIRST) {  // window row <-> position rb+row; xsL[i] <-> position rb-1+i
+          const float xm = xsL[row], xc = xsL[row + 1], xp = xsL[row + 2];
+          xv.x = w1r[0][0] * xm + w1r[0][1] * xc + w1r[0][2] * xp;
+          xv.y = w1r[1][0] * xm + w1r[1][1] * xc + w1r[1][2] * xp;
+          xv.z = w1r[2][0] * xm + w1r[2][1] * xc + w1r[2][2] * xp;
+          xv.w = w1r[3][0] * xm + w1r[3][1] * xc + w1r[3][2] * xp;
+        } else {
+          xv = rh[k];
+        }
+        fsplit_store4(hH, hLo, row * RSh + hch, ok ? gelu4((xv - hm) * hr) : (f32x4){0, 0, 0, 0});
+      }
+    }
+  };
+
+  const int total = P.B * P.ntiles;
+  if ((int)blockIdx.x < total) prefetch(blockIdx.x);
+  for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    const int b = tl / P.ntiles, tile = tl % P.ntiles;
+    const int t0 = tile * TM;
+    __syncthreads();  // previous tile's LDS reads (and its statistics scratch) are done; weights are written
+    commit(tl);
+    if (tl + (int)gridDim.x < total) prefetch(tl + gridDim.x);
+    __syncthreads();
+
+    f32x4 acc[MT][CO];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < CO; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KSP; ++ks) {
+      bf16x8 ah[CO], al[CO];
+#pragma unroll
+      for (int nt = 0; nt < CO; ++nt) {
+        ah[nt] = *reinterpret_cast<const bf16x8*>(wH + (nt * 16 + r) * WROW + ks * 32 + 8 * g);
+        al[nt] = *reinterpret_cast<const bf16x8*>(wLo + (nt * 16 + r) * WROW + ks * 32 + 8 * g);
+      }
+      // tap and column of this lane's 8 K slots
+      int j, col;
+      if (HC == 16) { j = 2 * ks + (g >> 1); if (j > 2) j = 2; col = 8 * (g & 1); }   // (the 4th half-step meets zero weights)
+      else { j = ks; col = 8 * g; }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = (wave * (16 * MT) + mt * 16 + r) * STRIDE + j;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hH + row * RSh + col);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(hLo + row * RSh + col);
+#pragma unroll
+        for (int nt = 0; nt < CO; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh, acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue: store the pre-norm tensor + statistics partials
+    f32x4 sA[CO], sB[CO];
+#pragma unroll
+    for (int nt = 0; nt < CO; ++nt) { sA[nt] = (f32x4){0, 0, 0, 0}; sB[nt] = (f32x4){0, 0, 0, 0}; }
+    float* yb = P.y + (size_t)b * L_out * OC;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int pos = t0 + wave * (16 * MT) + mt * 16 + r;
+      if (pos >= L_out) continue;
+#pragma unroll
+      for (int nt = 0; nt < CO; ++nt) {
+        const f32x4 v = acc[mt][nt];
+        sA[nt] += v;
+        sB[nt] += v * v;
+        st4o(yb, (unsigned)pos * OC + nt * 16 + 4 * g, v);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < CO; ++nt) {
+      f32x4 x1, x2;
+      x1.x = row16_sum(sA[nt].x); x1.y = row16_sum(sA[nt].y); x1.z = row16_sum(sA[nt].z); x1.w = row16_sum(sA[nt].w);
+      x2.x = row16_sum(sB[nt].x); x2.y = row16_sum(sB[nt].y); x2.z = row16_sum(sB[nt].z); x2.w = row16_sum(sB[nt].w);
+      if (r == 0) {
+        float* d = red + ((wave * CO + nt) * 4 + g) * 8;
+        st4(d, x1);
+        st4(d + 4, x2);
+      }
+    }
+    __syncthreads();
+    if (tid < CO * 32) {
+      const int k = tid / OC, c = tid % OC;
+      const int nt = c >> 4, gg = (c >> 2) & 3, e = c & 3;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[((w * CO + nt) * 4 + gg) * 8 + k * 4 + e];
+      P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c] = s;
+    }
+  }
+}
+
+template <int CI, int CO, int MT, int STRIDE, int PRO>
+static int launch_fwd(const FwdP& P0, int nwg, hipStream_t s) {
+  constexpr int TM = 64 * MT, HC = CI * 16, OC = CO * 16, NRh = (TM - 1) * STRIDE + 3, KD = (HC == 16 ? 2 : 3) * 32;
+  FwdP P = P0;
+  P.ntiles = (P.L_out + TM - 1) / TM;
+  size_t lds = (size_t)4 * CO * 4 * 8 * 4 + (size_t)2 * 2 * (NRh * ff_rs(HC) + OC * (KD + 8));
+  if (PRO == W2S_PRO_FIRST) lds += (size_t)(NRh + 2) * 4;
+  auto kern = conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return W2S_ELAUNCH;
+  const int total = P.B * P.ntiles;
+  hipLaunchKernelGGL(kern, dim3(nwg < total ? nwg : total), dim3(256), lds, s, P);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+static inline int fwd_mt(int cin, int cout, int stride) { return (cin == 32 && stride == 2) ? 2 : 4; }
+// positions per tile (sizes the statistics partials: [B][ceil(L_out/tile)][2][cout]); 0 = combination not covered
+extern "C" int w2s_conv_fwd_fused_tile(int cin, int cout, int stride) {
+  const bool ok = (cin == 16 || cin == 32) && (cout == 16 || cout == 32) && cout >= cin && (stride == 1 || stride == 2);
+  return ok ? 64 * fwd_mt(cin, cout, stride) : 0;
+}
+
+extern "C" int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const float* w1, float* y, float* part, int B,
+                                  int L_in, int L_out, int cin, int cout, int stride, int pro, int nwg, void* stream) {
+  if (!x || !w || !y || !part || B <= 0 || L_out <= 0 || nwg <= 0) return W2S_EINVAL;
+  if (!w2s_conv_fwd_fused_tile(cin, cout, stride)) return W2S_EINVAL;
+  if (pro != W2S_PRO_GELU && pro != W2S_PRO_IN_GELU && pro != W2S_PRO_FIRST) return W2S_EINVAL;
+  if ((pro != W2S_PRO_GELU && !st_in) || (pro == W2S_PRO_FIRST && (!w1 || cin != 16 || stride != 1))) return W2S_EINVAL;
+  if ((stride == 1 && L_out != L_in) || (stride == 2 && 2 * L_out != L_in)) return W2S_EINVAL;
+  if ((size_t)L_in * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;
+  FwdP P{x, w, st_in, w1, y, part, B, L_in, L_out, 0, pro};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define W2S_FF(CI_, CO_, MT_, ST_) \
+  if (cin == 16 * CI_ && cout == 16 * CO_ && stride == ST_) { \
+    if (pro == W2S_PRO_GELU) return launch_fwd<CI_, CO_, MT_, ST_, W2S_PRO_GELU>(P, nwg, s); \
+    if (pro == W2S_PRO_IN_GELU) return launch_fwd<CI_, CO_, MT_, ST_, W2S_PRO_IN_GELU>(P, nwg, s); \
+  }
+  if (pro == W2S_PRO_FIRST) return launch_fwd<1, 1, 4, 1, W2S_PRO_FIRST>(P, nwg, s);
+  W2S_FF(1, 1, 4, 1) W2S_FF(1, 1, 4, 2) W2S_FF(1, 2, 4, 1) W2S_FF(2, 2, 4, 1) W2S_FF(2, 2, 2, 2)
+#undef W2S_FF
+  return W2S_EINVAL;
+}

@@ -85,6 +85,7 @@ class Engine:
         self._bfbuf = {}
         self._streams = {}
         self._rjobs = []
+        self.fused_forward = os.environ.get('W2S_FUSED_FORWARD', '1') != '0'
         self._cjobs = []
         lib.load()
 
@@ -181,6 +182,14 @@ class Engine:
         """k=3 encoder conv writing the pre-norm tensor + instance-norm statistics (blocks.py:174-183)."""
         dev = x.device
         y = torch.empty(B, L_out, cout, device=dev, dtype=torch.float32)
+        ftile = lib.conv_fwd_fused_tile(cin, cout, stride) if (self.split_precision and self.fused_forward) else 0
+        if ftile and pro in (lib.PRO_GELU, lib.PRO_IN_GELU, lib.PRO_FIRST):
+            # <= 32 channels: persistent split-precision forward kernel (prefetch + LDS-resident weights)
+            nt = _cdiv(L_out, ftile)
+            part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
+            lib.conv_fwd_fused(x=x, w=w, st_in=pro_stats, w1=x2, y=y, part=part, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, stride=stride,
+                               pro=pro, nwg=1024 if cin == 16 else 512)
+            return y, self._finalize(part, B, nt, cout, L_out, 0)
         tile = lib.conv_tile(cin, cout, 3, stride, lib.MODE_CONTIG, B, L_out)
         nt = _cdiv(L_out, tile)
         part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
