@@ -156,12 +156,15 @@ int w2s_bwd_fused_tile(int cg, int ch);
 int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                   const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
                   int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
-                  const float* w1, void* stream);
+                  const float* w1, const float* y3p, const float* st3p, void* stream);
 /* gpre != NULL (conv1 of a residual block; stride 1, split_precision, add_even NULL, w2s_bwd_fused_folds_residual(cg, ch)): the
  * block's 1x1/stride-2 residual branch (blocks.py:44-47,68) is folded in -- gout additionally receives Wd^T gpre[t/2] at even t
  * before the GELU' factor (gpre: [B][Lh/2][cg] = dL/d(block pre-activation), wd: [ch][cg]) and slab_d receives nslab raw-fragment
  * slabs of the downsample weight gradient -> w2s_wgrad_reduce(slab_d, nslab, grad_wd, cg, ch, 1, 1, ...). */
 int w2s_bwd_fused_folds_residual(int cg, int ch);
+/* y3p != NULL (only with gpre): additionally fold the PREVIOUS block's conv3-backward pre-pass (w2s_gp_stats) in: y3p = that block's
+ * pre-norm conv3 output [B][Lh][ch], st3p = its (mean, rstd) [B][ch][2]; `part` then holds the partial sums of gout*GELU'(n3) and
+ * gout*GELU'(n3)*n3, n3 = IN(y3p) -- the tensor gout is read by w2s_gp_stats otherwise. */
 /* w1 != NULL (conv2 of block 0; cg = ch = 16, stride 1, split_precision, st_in given): xin is the RAW 1-channel signal [B][Lh] and
  * the conv's input (block 0's conv1 output) is recomputed from it with w1 = conv1 weight [16][3] (the W2S_PRO_FIRST flow). */
 

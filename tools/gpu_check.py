@@ -310,6 +310,19 @@ def t_fused_residual_fold():
             report(f'fold {cg}->{ch} L{Lh} gout', outs[1][0], outs[0][0], tol=2e-4)
             report(f'fold {cg}->{ch} L{Lh} wgrad', outs[1][1], outs[0][1], tol=2e-4)
             report(f'fold {cg}->{ch} L{Lh} downsample wgrad', outs[1][2], want_gd, tol=2e-4)
+            # ... and the previous block's conv3-backward statistics folded into the same kernel vs the w2s_gp_stats pre-pass
+            y3p = torch.randn(B, Lh, ch, device=dev)
+            st3 = torch.stack([torch.randn(B, ch, device=dev) * 0.1, torch.rand(B, ch, device=dev) + 0.5], dim=-1).contiguous()
+            gout2 = torch.zeros(B, Lh, ch, device=dev); pt = torch.zeros(B, nt, 2, ch, device=dev)
+            slab = torch.zeros(ns * cg * ch * 3, device=dev); slab_d = torch.zeros(ns * cg * ch, device=dev)
+            lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=lib.PRO_INBWD, xin=xin, st_in=None, add_even=None, wb=wb, gout=gout2, part=pt, slab=slab,
+                          nslab=ns, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=1, split_precision=True, gpre=gpre, wd=wd.view(ch, cg), slab_d=slab_d,
+                          y3p=y3p, st3p=st3)
+            ntg = (Lh + 511) // 512
+            pg = torch.zeros(B, ntg, 2, ch, device=dev)
+            lib.gp_stats(gout2, y3p, st3, pg, B, Lh, ch, 512)
+            report(f'fold {cg}->{ch} L{Lh} gout (with stats fold)', gout2, outs[1][0], tol=0)
+            report(f'fold {cg}->{ch} L{Lh} conv3 statistics', pt.sum(1), pg.sum(1), tol=2e-4)
 
 def t_first_layer_recompute():
     """W2S_PRO_FIRST flow: the consumers of block 0's conv1 output recompute it from the raw signal -- against the same

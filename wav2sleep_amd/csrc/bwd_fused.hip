@@ -26,6 +26,9 @@ struct BwdP {
   const float* gpre; const float* wd; float* slab_d;
   // first-layer recompute (conv2 of block 0, split-precision kernel only): xin = the raw signal [B][Lh], w1 = conv1 weight [16][3]
   const float* w1;
+  // previous block's conv3 backward statistics folded into this block's conv1 (RD) kernel: y3p = that block's pre-norm conv3
+  // output [B][Lh][HC] (same positions as gout), st3p = its (mean, rstd); part then receives sums of gn = gout*GELU'(n3) and gn*n3
+  const float* y3p; const float* st3p;
 };
 
 // LDS row strides: 16-channel rows stay unpadded (64-B rows: the three windows + weights of the 16x16 kernel then fit
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
   const int gc4 = tid % c4g, grow0 = tid / c4g, gch = gc4 * 4;
   const int hc4 = tid % c4h, hrow0 = tid / c4h, hch = hc4 * 4;
   constexpr int NP = RD ? (TM / 2 + rstep_g - 1) / rstep_g : 1;
-  f32x4 rg[NG], ry[NG], rh[FIRST ? 1 : NH], rp[NP];
+  f32x4 rg[NG], ry[NG], rh[FIRST ? 1 : NH], rp[NP], rq[RD ? MT * CH : 1];  // rq: previous block's y3 in the D-fragment layout
   float rxs[2], w1r[4][3];
   if (FIRST) {
 #pragma unroll
@@ -426,6 +429,16 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
         const bool ok = row < NRh && gr >= 0 && gr < Lh;
         rh[k] = ok ? ld4o(xb, (unsigned)gr * HC + hch) : (f32x4){0, 0, 0, 0};
       }
+    }
+    if (RD && P.y3p) {
+      const float* qb = P.y3p + (size_t)b * Lh * HC;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < CH; ++nt) {
+          const int pos = t0 + wave * (16 * MT) + mt * 16 + r;
+          rq[mt * CH + nt] = (pos < Lh) ? ld4o(qb, (unsigned)pos * HC + nt * 16 + 4 * g) : (f32x4){0, 0, 0, 0};
+        }
     }
     if (RD) {
       const float* pb = P.gpre + (size_t)b * (Lh >> 1) * GC;
@@ -511,6 +524,11 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
     const int t0 = tile * TM;
     __syncthreads();
     commit(tl);
+    f32x4 q3[RD ? MT * CH : 1];  // this tile's y3 fragments (the prefetch below reloads rq for the next tile)
+    if (RD) {
+#pragma unroll
+      for (int i = 0; i < MT * CH; ++i) q3[i] = rq[i];
+    }
     if (tl + (int)gridDim.x < total) prefetch(tl + gridDim.x);
     __syncthreads();
 
@@ -619,8 +637,18 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
         f32x4 v = acc[mt][nt];
         if (P.add_even && !(pos & 1)) v += ld4o(P.add_even + (size_t)b * (Lh >> 1) * HC, (unsigned)(pos >> 1) * HC + ch);
         v = v * (GPS ? *reinterpret_cast<const f32x4*>(gpL + (pos - t0) * RSn + ch) : gelu_grad4(n));
-        sA[nt] += v;
-        sB[nt] += v * n;
+        if (RD && P.y3p) {  // statistics of the previous block's conv3 backward: gn = gout * GELU'(n3), n3 = IN(y3)
+          const float* st = P.st3p + ((size_t)b * HC + ch) * 2;
+          const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+          const f32x4 m3 = {s01.x, s01.z, s23.x, s23.z}, r3 = {s01.y, s01.w, s23.y, s23.w};
+          const f32x4 n3 = (q3[mt * CH + nt] - m3) * r3;
+          const f32x4 gn = v * gelu_grad4(n3);
+          sA[nt] += gn;
+          sB[nt] += gn * n3;
+        } else {
+          sA[nt] += v;
+          sB[nt] += v * n;
+        }
         st4o(P.gout + (size_t)b * Lh * HC, (unsigned)pos * HC + ch, v);
       }
     }
@@ -753,13 +781,14 @@ extern "C" int w2s_bwd_fused_tile(int cg, int ch) { return 64 * ((cg == 16 && ch
 extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                              const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
                              int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
-                             const float* w1, void* stream) {
+                             const float* w1, const float* y3p, const float* st3p, void* stream) {
   if (!g || !y || !st_k || !bst_k || !xin || !wb || !gout || !slab || nslab <= 0) return W2S_EINVAL;
   if ((size_t)Lh * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;  // 32-bit lane offsets inside one sample
   if (pro != W2S_PRO_INBWD && pro != W2S_PRO_INBWD_GP) return W2S_EINVAL;
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
   if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in
-  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, gpre, wd, slab_d, w1};
+  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, gpre, wd, slab_d, w1, y3p, st3p};
+  if (y3p && (!gpre || !st3p || !part)) return W2S_EINVAL;
   const bool rd = gpre != nullptr;
   if (rd && (!wd || !slab_d || add_even || stride != 1 || !split_precision || !w2s_bwd_fused_folds_residual(cg, ch) || (Lh & 1))) return W2S_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -86,6 +86,7 @@ class Engine:
         self._streams = {}
         self._rjobs = []
         self.fused_forward = os.environ.get('W2S_FUSED_FORWARD', '1') != '0'
+        self.fold_gp = os.environ.get('W2S_FOLD_GP', '0') == '1'   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
         lib.load()
 
@@ -227,7 +228,7 @@ class Engine:
         self._written.add(name)
 
     def _bwd_fused(self, name, *, g, y, st_k, bst_k, pro, xin, st_in, add_even, gout, want_part, B, Lg, Lh, cg, ch, stride,
-                   gpre=None, down=None, w1=None):
+                   gpre=None, down=None, w1=None, y3p=None, st3p=None):
         """dgrad + wgrad of one k=3 encoder conv in one pass (<= 32 channels); returns the backward statistics or None.
         gpre / down (conv1 of a residual block): fold the 1x1/stride-2 residual branch `down` in as well."""
         dev = g.device
@@ -239,7 +240,7 @@ class Engine:
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
                       part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, split_precision=self.split_precision,
-                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1)
+                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1, y3p=y3p, st3p=st3p)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         if gpre is not None:
@@ -638,17 +639,21 @@ class Engine:
         gpre = torch.empty(B, 2 * 2 * S, cl, device=dev, dtype=torch.float32)
         self._conv(x=gz, w=PB[pfx + 'linear.weight'], y=gpre, B=1, L_in=B * S, L_out=B * S, cin=F, cout=4 * cl, taps=1, stride=1, pad=0,
                    epi=lib.EPI_GP, aux=ec['plast'], ld_aux=4 * cl)
+        bs3_folded = None   # conv3 backward statistics of block i produced by block i+1's fused conv1 kernel (no gp_stats pre-pass)
         for i in reversed(range(len(ch))):
             blk = ec['blocks'][i]
             p = f'{pfx}cnn.{i}.'
             c, cin, L = blk['c'], blk['cin'], blk['L']
             Lh = L // 2
             # conv3 (stride 2): pre-pass for the instance-norm backward sums, then data + weight gradient
-            tile = 512
-            nt = _cdiv(Lh, tile)
-            part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
-            lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile)
-            bs3 = self._bstats(part, B, nt, c, Lh)
+            if bs3_folded is not None:
+                bs3, bs3_folded = bs3_folded, None
+            else:
+                tile = 512
+                nt = _cdiv(Lh, tile)
+                part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
+                lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile)
+                bs3 = self._bstats(part, B, nt, c, Lh)
             gn2 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
             gn1 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
             if lib.bwd_fused_supported(c, c):
@@ -681,9 +686,12 @@ class Engine:
             if i > 0 and self.split_precision and lib.bwd_fused_supported(c, cin) and lib.bwd_fused_folds_residual(c, cin) and not (L & 1):
                 # conv1 + the whole residual branch (its data gradient AND its weight gradient) in one pass over the tensors
                 gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
-                self._bwd_fused(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, pro=lib.PRO_INBWD, xin=blk['pin'],
-                                st_in=None, add_even=None, gout=gprev, want_part=False, B=B, Lg=L, Lh=L, cg=c, ch=cin, stride=1,
-                                gpre=gpre, down=p + 'downsample.weight')
+                prev = ec['blocks'][i - 1] if self.fold_gp else dict(y3=None, st3=None)   # fold its conv3-backward statistics pre-pass in
+                bs3_folded = self._bwd_fused(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, pro=lib.PRO_INBWD,
+                                             xin=blk['pin'], st_in=None, add_even=None, gout=gprev, want_part=self.fold_gp, B=B, Lg=L, Lh=L, cg=c,
+                                             ch=cin, stride=1, gpre=gpre, down=p + 'downsample.weight', y3p=prev['y3'], st3p=prev['st3'])
+                if not self.fold_gp:
+                    bs3_folded = None
                 gpre = gprev
             elif i > 0:
                 # residual 1x1/stride-2 branch: R = Wd^T gpre, added at even positions inside conv1's data-gradient epilogue

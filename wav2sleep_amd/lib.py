@@ -267,13 +267,13 @@ def bwd_fused_folds_residual(cg, ch) -> bool:
 
 
 def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False,
-              gpre=None, wd=None, slab_d=None, w1=None):
+              gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None):
     def run():
         _chk(load().w2s_bwd_fused(_f(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), _f(gout), _f(part),
-                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _stream()),
+                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p), _stream()),
              f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
     nbytes = 4 * (2 * B * Lg * cg + (B * Lh * (ch + 1) if w1 is not None else 2 * B * Lh * ch) + (B * Lh * ch // 2 if add_even is not None else 0)
-                  + (B * Lh * cg // 2 if gpre is not None else 0))
+                  + (B * Lh * cg // 2 if gpre is not None else 0) + (B * Lh * ch if y3p is not None else 0))
     flops = 2 * B * Lg * cg * ch * 3 * 2
     if split_precision:
         key = f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}, {1 if gpre is not None else 0}, {1 if w1 is not None else 0}>'
