@@ -37,15 +37,18 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 def test_header_is_plain_c_and_struct_layout_matches_ctypes(built_lib, tmp_path):
     src = tmp_path / 't.c'
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "w2s.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(w2s_conv_args), '
-                   'offsetof(w2s_conv_args, B), offsetof(w2s_conv_args, epi), sizeof(w2s_wgrad_args), offsetof(w2s_wgrad_args, B), '
-                   'offsetof(w2s_wgrad_args, nslab));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "w2s.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(w2s_conv_args), offsetof(w2s_conv_args, B), offsetof(w2s_conv_args, epi), sizeof(w2s_wgrad_args), '
+                   'offsetof(w2s_wgrad_args, B), offsetof(w2s_wgrad_args, nslab), sizeof(w2s_reduce_job), offsetof(w2s_reduce_job, layout), '
+                   'sizeof(w2s_repack_job), offsetof(w2s_repack_job, taps), sizeof(w2s_colsum_job), offsetof(w2s_colsum_job, accumulate));'
+                   'return 0;}\n')
     exe = tmp_path / 't'
     subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
     L = built_lib
     want = [ctypes.sizeof(L.ConvArgs), L.ConvArgs.B.offset, L.ConvArgs.epi.offset, ctypes.sizeof(L.WgradArgs), L.WgradArgs.B.offset,
-            L.WgradArgs.nslab.offset]
+            L.WgradArgs.nslab.offset, ctypes.sizeof(L.ReduceJob), L.ReduceJob.layout.offset, ctypes.sizeof(L.RepackJob), L.RepackJob.taps.offset,
+            ctypes.sizeof(L.ColsumJob), L.ColsumJob.accumulate.offset]
     assert [int(v) for v in out] == want
 
 
@@ -62,6 +65,10 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.conv_tile(16, 16, 3, 1) == 256 and L.conv_tile(128, 128, 3, 1) == 64
     assert L.wgrad_grid_y(128, 128, 3) == 1 and L.wgrad_grid_y(128, 128, 7, 2) == 7 and L.wgrad_grid_y(16, 16, 3) == 1
     assert L.wgrad_slabs_per_block(128, 128, 3) == 1 and L.wgrad_slabs_per_block(16, 16, 3) == 4 and L.bwd_fused_tile(16, 16) == 256
+    assert L.conv_fwd_fused_tile(16, 16, 1) == 256 and L.conv_fwd_fused_tile(32, 32, 2) == 128 and L.conv_fwd_fused_tile(64, 64, 1) == 0
+    assert L.bwd_fused_folds_residual(16, 16) and L.bwd_fused_folds_residual(32, 16) and not L.bwd_fused_folds_residual(32, 32)
+    assert dll.w2s_wgrad_reduce_batch(None, 1, None) == -1 and dll.w2s_repack_batch(None, 0, None) == -1 and dll.w2s_colsum_batch(None, 3, None) == -1
+    assert dll.w2s_conv_fwd_fused(None, None, None, None, None, None, 1, 8, 8, 16, 16, 1, 2, 4, None) == -1
 
 
 def test_cpu_tensors_are_refused(built_lib):
