@@ -337,7 +337,7 @@ def t_first_layer_recompute():
     lib.enc_first_fwd(x, w1, y1, part, B, L, c, tile)
     part2 = torch.zeros_like(part)
     lib.enc_first_fwd(x, w1, None, part2, B, L, c, tile)                       # statistics only
-    report('first: stats-only partials', part2, part, tol=1e-6)
+    report('first: stats-only partials (closed form from 9 signal sums)', part2, part, tol=2e-5)
     st1 = torch.zeros(B, c, 2, device=dev)
     lib.stats_finalize(part, B, nt, c, L, 1e-2, 0, st1)
     wp = pack_fwd(w2).to(dev)
