@@ -515,3 +515,30 @@ def test_predict_on_folder_parquet_to_csv_matches_oracle(tmp_path):
         assert list(t['Stage']) == y.tolist()
     with pytest.raises(ValueError):
         W.predict_on_folder(str(src), str(out), model=model, signals=['EEG'], preprocess=False)
+
+
+@pytest.mark.parametrize('signal_map,B,S,missing', [
+    (SM4, 1, 1, None),                                          # one epoch, one recording: every tile is a ragged edge tile
+    (SM4, 5, 3, {'ECG': [0, 4], 'ABD': [2]}),                   # odd batch, missing modalities
+    ({'ECG': 'UNI', 'PPG': 'UNI'}, 3, 2, None),                 # shared encoder: both modalities accumulate into one set of gradients
+    ({'THX': 'THX'}, 2, 9, None),                               # single low-rate modality
+    ({'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 1, 3, {'EOG-L': [0]}),   # 10-block encoders, one side missing
+])
+def test_edge_shapes_match_oracle(signal_map, B, S, missing):
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=3)
+    model = build(signal_map, 4)
+    model.load_state_dict(sd)
+    model.to(DEV).train()
+    x, y = O.make_inputs(cfg, B, S, seed=4, missing=missing)
+    y = y.clamp(min=0)                                           # keep every label valid (B = S = 1 would otherwise be all-ignored)
+    loss_o, logits_o, grads_o = O.loss_and_grads(sd, cfg, x, y)
+    logits = model(to_dev(x))
+    loss = F.cross_entropy(logits.reshape(-1, 4), y.to(DEV).reshape(-1).long(), ignore_index=-1)
+    loss.backward()
+    assert_logits_close(logits.detach().cpu(), logits_o)
+    assert torch.equal(logits.argmax(-1).cpu(), logits_o.argmax(-1))
+    assert float(loss) == pytest.approx(float(loss_o), rel=1e-4)
+    for k, p in model.named_parameters():
+        got, want = p.grad.detach().cpu().double().numpy(), grads_o[k].double().numpy()
+        assert np.linalg.norm(got - want) <= 2e-3 * max(np.linalg.norm(want), 1e-12), k
