@@ -76,9 +76,13 @@ typedef struct w2s_conv_args {
   float* part;             /* EPI_STATS / EPI_GP: [B][ntiles][2][cout] partial sums, or NULL */
   const void* w_hi;        /* optional bf16 planes of w (w = hi + lo, layout as w; see w2s_repack_bf16): enables the split-  */
   const void* w_lo;        /* precision matrix-core path for cin >= 32 and cout >= 64; NULL = exact fp32 MFMA               */
+  float* stat_out;         /* optional, with `part`: [B][cout][2] finalised IN the kernel by the workgroup that writes a sample's  */
+  int32_t* stat_cnt;       /* last partial (EPI_STATS: mean, rstd with stat_eps; EPI_GP: sums / L_out); stat_cnt: [B] zeroed once   */
   int32_t B, L_in, L_out, cin, cout, taps, stride, dil, pad, flip, mode;
   int32_t ldx, ldy, ldy2, ld_aux;
   int32_t pro, epi;
+  float stat_eps;          /* variance epsilon of the in-kernel finalisation (models/wav2sleep.py:213-215: 1e-2) */
+  int32_t reserved;
 } w2s_conv_args;
 
 /* positions per workgroup tile for (cin,cout); ntiles = ceil(L_out / tile) sizes `part`. */
@@ -141,7 +145,7 @@ int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, vo
  */
 int w2s_conv_fwd_fused_tile(int cin, int cout, int stride);
 int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const float* w1, float* y, float* part, int B, int L_in,
-                       int L_out, int cin, int cout, int stride, int pro, int nwg, void* stream);
+                       int L_out, int cin, int cout, int stride, int pro, int nwg, float* stat_out, int32_t* stat_cnt, float eps, void* stream);
 
 /*
  * Fused backward of one encoder ConvLayer1D (k=3, pad=1, stride 1 or 2) for the bandwidth-bound <=32-channel layers:
@@ -156,7 +160,7 @@ int w2s_bwd_fused_tile(int cg, int ch);
 int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                   const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
                   int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
-                  const float* w1, const float* y3p, const float* st3p, void* stream);
+                  const float* w1, const float* y3p, const float* st3p, float* stat_out, int32_t* stat_cnt, void* stream);
 /* gpre != NULL (conv1 of a residual block; stride 1, split_precision, add_even NULL, w2s_bwd_fused_folds_residual(cg, ch)): the
  * block's 1x1/stride-2 residual branch (blocks.py:44-47,68) is folded in -- gout additionally receives Wd^T gpre[t/2] at even t
  * before the GELU' factor (gpre: [B][Lh/2][cg] = dL/d(block pre-activation), wd: [ch][cg]) and slab_d receives nslab raw-fragment
@@ -168,14 +172,18 @@ int w2s_bwd_fused_folds_residual(int cg, int ch);
 /* w1 != NULL (conv2 of block 0; cg = ch = 16, stride 1, split_precision, st_in given): xin is the RAW 1-channel signal [B][Lh] and
  * the conv's input (block 0's conv1 output) is recomputed from it with w1 = conv1 weight [16][3] (the W2S_PRO_FIRST flow). */
 
-/* partial sums [B][ntiles][2][C] -> per-(b,c) pairs [B][C][2]: kind 0 = (mean, rstd) with biased variance + eps
+/* In-kernel finalisation (stat_out / stat_cnt arguments of the producers above): the workgroup that writes the LAST partial of a sample
+ * reduces all of that sample's partials in a fixed order (fp64) -- same result as this call, one launch less per layer.  stat_cnt is a
+ * caller-owned int32 [B] buffer, zero before first use; kernels re-arm it.  One buffer per stream.
+ * partial sums [B][ntiles][2][C] -> per-(b,c) pairs [B][C][2]: kind 0 = (mean, rstd) with biased variance + eps
  * (nn.InstanceNorm1d, models/utils.py:89-92), kind 1 = (sum1, sum2)/count.  fp64 accumulation, fixed order. */
 int w2s_stats_finalize(const float* part, int B, int ntiles, int C, long count, float eps, int kind, float* out, void* stream);
 
 /* First encoder layer, Cin = 1 (blocks.py:46, conv1 of block 0): y[b,t,o] = sum_j w[o][j]*san(x[b,t+j-1]);
  * part [B][ceil(L/tile)][2][16] = partial sum / sum-of-squares.  w is the torch tensor [16][1][3]. */
 /* y may be NULL (statistics only: the W2S_PRO_FIRST consumers recompute the values) */
-int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, void* stream);
+int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, float* stat_out, int32_t* stat_cnt,
+                      float eps, void* stream);
 /* Block-0 residual join (blocks.py:67-69): pre[b,u,o] = GELU(IN(y3[b,u,o])) + wd[o]*san(x[b,2u]) */
 int w2s_enc_first_join(const float* x, const float* wd, const float* y3, const float* stats3, float* pre, int B, int L, int cout, void* stream);
 /* weight grads of block-0 conv1 / downsample; slab[nslab][64] = {dW1[o][j] (48), dWd[o] (16)}; sum with w2s_colsum */
@@ -183,7 +191,8 @@ int w2s_enc_first_bwd(const float* x, const float* gn1, const float* y1, const f
                       const float* gpre, float* slab, int nslab, int B, int L, int cout, const float* w1, void* stream);
 /* y1 == NULL: the conv1 output is recomputed from x and w1 = conv1 weight [16][3] (the W2S_PRO_FIRST flow) */
 /* pre-pass of conv3's backward: part [B][ceil(L/tile)][2][C] = partial sums of g*GELU'(n) and g*GELU'(n)*n, n = IN(y) */
-int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, void* stream);
+int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, float* stat_out, int32_t* stat_cnt,
+                 void* stream);
 
 /* ---- row-wise ops on [rows][C] (nn.LayerNorm of the transformer; ConvLayerNorm models/utils.py:17-23) ---- */
 int w2s_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* rstat, int rows, int C,

@@ -462,7 +462,48 @@ def t_fwd_fused():
     report('fwd fused first-layer recompute stats', p2.sum(1), p1.sum(1), tol=2e-4)
 
 
-STAGES = dict(fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+def t_inkernel_finalize():
+    """statistics finalised by the producer's last workgroup vs the separate w2s_stats_finalize launch (both fp64, fixed order)."""
+    B = 5
+    for (cin, cout, L, stride) in ((16, 16, 5000, 1), (32, 32, 3001, 1), (64, 64, 2000, 1), (128, 128, 777, 2), (32, 32, 4096, 2)):
+        Lo = (L + 2 - 3) // stride + 1
+        x = torch.randn(B, L, cin, device=dev) * 2 + 0.3
+        w = torch.randn(cout, 3, cin, device=dev) / math.sqrt(3 * cin)
+        st = torch.stack([torch.randn(B, cin, device=dev) * 0.1, torch.rand(B, cin, device=dev) + 0.5], dim=-1).contiguous()
+        cnt = torch.zeros(B, device=dev, dtype=torch.int32)
+        for rep in range(2):   # second pass: the counters must have been re-armed by the kernel
+            tile = lib.conv_tile(cin, cout, 3, stride, lib.MODE_CONTIG, B, Lo)
+            nt = (Lo + tile - 1) // tile
+            y = torch.zeros(B, Lo, cout, device=dev); part = torch.zeros(B, nt, 2, cout, device=dev); so = torch.zeros(B, cout, 2, device=dev)
+            lib.conv_forward(lib.conv_args(x=x, w=w, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=3, stride=stride, pad=1, pro=lib.PRO_IN_GELU,
+                                           pro_stats=st, epi=lib.EPI_STATS, part=part, stat_out=so, stat_cnt=cnt, stat_eps=1e-2))
+            ref = torch.zeros(B, cout, 2, device=dev)
+            lib.stats_finalize(part, B, nt, cout, Lo, 1e-2, 0, ref)
+            report(f'in-kernel finalize conv {cin}->{cout} L{L} s{stride} pass {rep}', so, ref, tol=1e-6)
+            want = torch.stack([y.mean(1), 1 / torch.sqrt(y.var(1, unbiased=False) + 1e-2)], dim=-1)
+            report(f'in-kernel finalize conv {cin}->{cout} L{L} s{stride} vs torch', so, want, tol=2e-5)
+        assert int(cnt.abs().sum()) == 0
+        if lib.conv_fwd_fused_tile(cin, cout, stride) and L % stride == 0:
+            tile = lib.conv_fwd_fused_tile(cin, cout, stride); nt = (Lo + tile - 1) // tile
+            y2 = torch.zeros(B, Lo, cout, device=dev); part = torch.zeros(B, nt, 2, cout, device=dev); so = torch.zeros(B, cout, 2, device=dev)
+            lib.conv_fwd_fused(x=x, w=w, st_in=st, w1=None, y=y2, part=part, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, stride=stride,
+                               pro=lib.PRO_IN_GELU, nwg=7, stat_out=so, stat_cnt=cnt, eps=1e-2)
+            want = torch.stack([y2.mean(1), 1 / torch.sqrt(y2.var(1, unbiased=False) + 1e-2)], dim=-1)
+            report(f'in-kernel finalize persistent fwd {cin}->{cout} L{L} s{stride}', so, want, tol=2e-5)
+            assert int(cnt.abs().sum()) == 0
+    # gp_stats (kind 1: plain means)
+    C, L = 32, 3333
+    g = torch.randn(B, L, C, device=dev); yv = torch.randn(B, L, C, device=dev)
+    st = torch.stack([torch.randn(B, C, device=dev) * 0.1, torch.rand(B, C, device=dev) + 0.5], dim=-1).contiguous()
+    nt = (L + 511) // 512
+    part = torch.zeros(B, nt, 2, C, device=dev); so = torch.zeros(B, C, 2, device=dev); cnt = torch.zeros(B, device=dev, dtype=torch.int32)
+    lib.gp_stats(g, yv, st, part, B, L, C, 512, stat_out=so, stat_cnt=cnt)
+    ref = torch.zeros(B, C, 2, device=dev)
+    lib.stats_finalize(part, B, nt, C, L, 0.0, 1, ref)
+    report('in-kernel finalize gp_stats', so, ref, tol=1e-6)
+
+
+STAGES = dict(fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

@@ -29,6 +29,7 @@ struct BwdP {
   // previous block's conv3 backward statistics folded into this block's conv1 (RD) kernel: y3p = that block's pre-norm conv3
   // output [B][Lh][HC] (same positions as gout), st3p = its (mean, rstd); part then receives sums of gn = gout*GELU'(n3) and gn*n3
   const float* y3p; const float* st3p;
+  StatFin fin;   // in-kernel finalisation of `part` into the backward statistics (fin.out == NULL: partials only)
 };
 
 // LDS row strides: 16-channel rows stay unpadded (64-B rows: the three windows + weights of the 16x16 kernel then fit
@@ -225,8 +226,9 @@ void bwd_fused_kernel(BwdP P) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
-        P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c] = s;
+        w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
       }
+      w2s_stat_finish(P.fin, P.part, b, P.ntiles, HC, P.ntiles);
     }
 
     // ---- weight gradient: k-step = 4 positions of the gradient side
@@ -671,8 +673,9 @@ __global__ __launch_bounds__(256) void bwd_fused_bf_kernel(BwdP P) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
-        P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c] = s;
+        w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
       }
+      w2s_stat_finish(P.fin, P.part, b, P.ntiles, HC, P.ntiles);
     }
 
     // ---- weight gradient: k-step = 32 gradient-side positions; lane group g covers positions 8g..8g+7 of the step
@@ -781,13 +784,14 @@ extern "C" int w2s_bwd_fused_tile(int cg, int ch) { return 64 * ((cg == 16 && ch
 extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                              const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
                              int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
-                             const float* w1, const float* y3p, const float* st3p, void* stream) {
+                             const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt, void* stream) {
   if (!g || !y || !st_k || !bst_k || !xin || !wb || !gout || !slab || nslab <= 0) return W2S_EINVAL;
   if ((size_t)Lh * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;  // 32-bit lane offsets inside one sample
   if (pro != W2S_PRO_INBWD && pro != W2S_PRO_INBWD_GP) return W2S_EINVAL;
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
   if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in
-  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, gpre, wd, slab_d, w1, y3p, st3p};
+  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, gpre, wd, slab_d, w1, y3p, st3p, StatFin{stat_out, stat_cnt, 1.0 / (double)Lh, 0.f, 1}};
+  if (stat_out && (!stat_cnt || !part)) return W2S_EINVAL;
   if (y3p && (!gpre || !st3p || !part)) return W2S_EINVAL;
   const bool rd = gpre != nullptr;
   if (rd && (!wd || !slab_d || add_even || stride != 1 || !split_precision || !w2s_bwd_fused_folds_residual(cg, ch) || (Lh & 1))) return W2S_EINVAL;

@@ -31,6 +31,7 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
     if (a.y2 && (size_t)a.L_out * (size_t)(a.ldy2 ? a.ldy2 : a.cout) * 4 >= lim) return W2S_EINVAL;
     if (a.aux && (size_t)a.L_out * (size_t)(a.ld_aux ? a.ld_aux : a.cout) * 4 >= lim) return W2S_EINVAL;
   }
+  if (a.stat_out && (!a.stat_cnt || !a.part || a.cout > 128)) return W2S_EINVAL;
   if (a.pro >= W2S_PRO_IN_GELU && !a.pro_stats) return W2S_EINVAL;
   if ((a.pro == W2S_PRO_INBWD || a.pro == W2S_PRO_INBWD_GP) && (!a.pro_bstats || !a.x2)) return W2S_EINVAL;
   if (a.pro == W2S_PRO_FIRST && (!a.x2 || a.cin != 16 || a.taps != 3 || a.stride != 1 || a.mode != W2S_MODE_CONTIG)) return W2S_EINVAL;

@@ -8,7 +8,7 @@
 // (16-B store; 4 lanes cover a 64-B row; a wave writes 1 KiB contiguous).  blocks.py:46 with Cin = 1.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                                                            float* __restrict__ part, int L, int tile, int ntiles) {
+                                                            float* __restrict__ part, int L, int tile, int ntiles, StatFin fin) {
   __shared__ float red[4][4][8];
   const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x;
   const int og = tid & 3, lane = tid & 63, wave = tid >> 6;
@@ -54,8 +54,9 @@ __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restr
     float s = 0.f;
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv) s += red[wv][c >> 2][k * 4 + (c & 3)];
-    part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + c] = s;
+    w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + c], s);
   }
+  w2s_stat_finish(fin, part, b, ntiles, 16, ntiles);
 }
 
 // Statistics-only form (the W2S_PRO_FIRST flow never materialises y1).  y1 = conv(x) with ONE input channel, so every per-channel
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restr
 // => 6 multiply-adds per sample instead of 16 channels x 5, then a 32-thread expansion per tile.  fp32 partials per tile, fp64 in
 // w2s_stats_finalize as for every other layer.
 __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
-                                                             int L, int tile, int ntiles) {
+                                                             int L, int tile, int ntiles, StatFin fin) {
   __shared__ float red[4][9];
   __shared__ float tot[9];
   const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,20 +96,25 @@ __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __res
     float s;
     if (k == 0) s = w0 * tot[0] + w1 * tot[1] + w2 * tot[2];
     else s = w0 * w0 * tot[3] + w1 * w1 * tot[4] + w2 * w2 * tot[5] + 2.f * (w0 * w1 * tot[6] + w1 * w2 * tot[7] + w0 * w2 * tot[8]);
-    part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + o] = s;
+    w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + o], s);
   }
+  w2s_stat_finish(fin, part, b, ntiles, 16, ntiles);
 }
 
-extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, void* stream) {
+extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, float* stat_out,
+                                 int* stat_cnt, float eps, void* stream) {
   if (!x || !w || !part || cout != 16 || tile < 64 || (tile & 63)) return W2S_EINVAL;  // y == NULL: statistics only
   const int ntiles = (L + tile - 1) / tile;
+  if (stat_out && !stat_cnt) return W2S_EINVAL;
+  const StatFin fin{stat_out, stat_cnt, 1.0 / (double)L, eps, 0};
   if (!y) {
-    hipLaunchKernelGGL(enc_first_stats_kernel, dim3(ntiles, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, part, L, tile, ntiles);
+    hipLaunchKernelGGL(enc_first_stats_kernel, dim3(ntiles, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, part, L, tile, ntiles,
+                       fin);
     W2S_CHECK_LAUNCH();
     return W2S_OK;
   }
   hipLaunchKernelGGL(enc_first_fwd_kernel, dim3(ntiles, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, y, part, L, tile,
-                     ntiles);
+                     ntiles, fin);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
@@ -297,7 +303,7 @@ extern "C" int w2s_stats_finalize(const float* part, int B, int ntiles, int C, l
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gp_stats_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                        const float* __restrict__ stats, float* __restrict__ part, int L, int C, int tile,
-                                                       int ntiles) {
+                                                       int ntiles, StatFin fin) {
   extern __shared__ float sm[];  // [256][8]
   const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x;
   const int c4n = C >> 2, myc4 = tid % c4n, row0 = tid / c4n, rstep = 256 / c4n;
@@ -321,15 +327,19 @@ __global__ __launch_bounds__(256) void gp_stats_kernel(const float* __restrict__
     const int k = tid / C, c = tid % C;
     float s = 0.f;
     for (int rl = 0; rl < rstep; ++rl) s += sm[(rl * c4n + (c >> 2)) * 8 + k * 4 + (c & 3)];
-    part[(((size_t)b * ntiles + tl) * 2 + k) * C + c] = s;
+    w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * C + c], s);
   }
+  w2s_stat_finish(fin, part, b, ntiles, C, ntiles);
 }
 
-extern "C" int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, void* stream) {
+extern "C" int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, float* stat_out,
+                            int* stat_cnt, void* stream) {
   if (!g || !y || !stats || !part || C < 16 || C > 128 || (C & (C - 1)) || tile <= 0) return W2S_EINVAL;
   const int ntiles = (L + tile - 1) / tile;
+  if (stat_out && !stat_cnt) return W2S_EINVAL;
+  const StatFin fin{stat_out, stat_cnt, 1.0 / (double)L, 0.f, 1};
   hipLaunchKernelGGL(gp_stats_kernel, dim3(ntiles, B), dim3(256), 256 * 8 * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y,
-                     stats, part, L, C, tile, ntiles);
+                     stats, part, L, C, tile, ntiles, fin);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

@@ -14,6 +14,7 @@ struct FwdP {
   const float* x; const float* w; const float* st_in; const float* w1;
   float* y; float* part;
   int B, L_in, L_out, ntiles, pro;
+  StatFin fin;   // in-kernel statistics finalisation (fin.out == NULL: partials only)
 };
 
 typedef __bf16 bf16x4f __attribute__((ext_vector_type(4)));
@@ -198,8 +199,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) s += red[((w * CO + nt) * 4 + gg) * 8 + k * 4 + e];
-      P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c] = s;
+      w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c], s);
     }
+    w2s_stat_finish(P.fin, P.part, b, P.ntiles, OC, P.ntiles);
   }
 }
 
@@ -228,14 +230,16 @@ extern "C" int w2s_conv_fwd_fused_tile(int cin, int cout, int stride) {
 }
 
 extern "C" int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const float* w1, float* y, float* part, int B,
-                                  int L_in, int L_out, int cin, int cout, int stride, int pro, int nwg, void* stream) {
+                                  int L_in, int L_out, int cin, int cout, int stride, int pro, int nwg, float* stat_out, int* stat_cnt, float eps,
+                                  void* stream) {
   if (!x || !w || !y || !part || B <= 0 || L_out <= 0 || nwg <= 0) return W2S_EINVAL;
   if (!w2s_conv_fwd_fused_tile(cin, cout, stride)) return W2S_EINVAL;
   if (pro != W2S_PRO_GELU && pro != W2S_PRO_IN_GELU && pro != W2S_PRO_FIRST) return W2S_EINVAL;
   if ((pro != W2S_PRO_GELU && !st_in) || (pro == W2S_PRO_FIRST && (!w1 || cin != 16 || stride != 1))) return W2S_EINVAL;
   if ((stride == 1 && L_out != L_in) || (stride == 2 && 2 * L_out != L_in)) return W2S_EINVAL;
   if ((size_t)L_in * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;
-  FwdP P{x, w, st_in, w1, y, part, B, L_in, L_out, 0, pro};
+  if (stat_out && !stat_cnt) return W2S_EINVAL;
+  FwdP P{x, w, st_in, w1, y, part, B, L_in, L_out, 0, pro, StatFin{stat_out, stat_cnt, 1.0 / (double)L_out, eps, 0}};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define W2S_FF(CI_, CO_, MT_, ST_) \
   if (cin == 16 * CI_ && cout == 16 * CO_ && stride == ST_) { \

@@ -120,6 +120,90 @@ __device__ __forceinline__ float w2s_dropscale(uint64_t seed, uint64_t idx, floa
   return (w2s_uniform(seed, idx) >= p) ? 1.0f / (1.0f - p) : 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Statistics finalisation inside the PRODUCER kernel (replaces a w2s_stats_finalize launch between every two encoder layers:
+// 168 launches and ~1.3 ms per train step on the critical path).  Every workgroup that has written its per-tile partial
+// sums for sample b takes a ticket from counter[b]; the workgroup that draws the last ticket re-reads all of that sample's
+// partials and reduces them in a FIXED order in fp64 -- the result does not depend on which workgroup happens to be last, so
+// runs stay bit-reproducible.  Release/acquire: partial stores -> __threadfence -> ticket (device-scope atomic); last
+// workgroup: ticket -> __threadfence (L1 invalidate) -> loads.  The last workgroup also re-arms the counter.
+// part: [B][ntiles][2][C];  kind 0: out = (mean, rstd = 1/sqrt(biased var + eps));  kind 1: out = (sum1/count, sum2/count).
+// ------------------------------------------------------------------------------------------------------------------
+// per-tile partial sums that another workgroup of the SAME launch may read (w2s_stat_finish): agent-scope relaxed accesses
+__device__ __forceinline__ void w2s_part_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float w2s_part_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+struct StatFin { float* out; int* cnt; double inv_count; float eps; int kind; };
+__device__ __forceinline__ void w2s_stat_finish(const StatFin& F, const float* part, int b, int ntiles, int C, int expected) {
+  __shared__ double fin_red[256];
+  __shared__ double fin_sum[256];
+  __shared__ int fin_last;
+  if (!F.out) return;  // uniform
+  const int tid = threadIdx.x;
+  // The partials were written with agent-scope write-through stores (w2s_part_store); waiting for their acknowledgement is all the
+  // release this needs.  A __threadfence() here would write back / invalidate the whole XCD L2 once per tile (measured: 8x slower step).
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0) fin_last = (__hip_atomic_fetch_add(&F.cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1) ? 1 : 0;
+  __syncthreads();
+  if (!fin_last) return;
+  // one partial row = 2C floats ([2][C]); thread = (4-float slot q of the row, tile lane ln); agent-scope loads (they bypass the
+  // non-coherent L1 / remote-XCD L2 lines), four rows = 16 loads in flight per thread
+  const int qn = (2 * C) >> 2, nl = 256 / qn;   // C = 16: 32 tile lanes ... C = 128: 4
+  const int q = tid % qn, ln = tid / qn;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  {
+    const float* p = part + ((size_t)b * ntiles) * (2 * C) + q * 4;
+    int t = ln;
+    for (; t + 3 * nl < ntiles; t += 4 * nl) {
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[u][e] = w2s_part_load(p + (size_t)(t + u * nl) * (2 * C) + e);
+      s0 += ((double)v[0][0] + (double)v[1][0]) + ((double)v[2][0] + (double)v[3][0]);
+      s1 += ((double)v[0][1] + (double)v[1][1]) + ((double)v[2][1] + (double)v[3][1]);
+      s2 += ((double)v[0][2] + (double)v[1][2]) + ((double)v[2][2] + (double)v[3][2]);
+      s3 += ((double)v[0][3] + (double)v[1][3]) + ((double)v[2][3] + (double)v[3][3]);
+    }
+    for (; t < ntiles; t += nl) {
+      const float* r = p + (size_t)t * (2 * C);
+      s0 += (double)w2s_part_load(r); s1 += (double)w2s_part_load(r + 1); s2 += (double)w2s_part_load(r + 2); s3 += (double)w2s_part_load(r + 3);
+    }
+  }
+  // fixed-order tree over the tile lanes, one float4 component at a time (fin_red holds 256 doubles)
+  double tot[4] = {s0, s1, s2, s3};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    __syncthreads();
+    fin_red[tid] = tot[e];
+    __syncthreads();
+    for (int half = nl >> 1; half > 0; half >>= 1) {
+      if (ln < half) fin_red[tid] += fin_red[tid + half * qn];
+      __syncthreads();
+    }
+    if (ln == 0) fin_sum[q * 4 + e] = fin_red[tid];   // fin_sum[k*C + c]
+  }
+  __syncthreads();
+  if (tid < C) {
+    const double a1 = fin_sum[tid], a2 = fin_sum[C + tid];
+    float o0, o1;
+    if (F.kind == 0) {
+      const double mean = a1 * F.inv_count;
+      double var = a2 * F.inv_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      o0 = (float)mean;
+      o1 = (float)(1.0 / sqrt(var + (double)F.eps));
+    } else {
+      o0 = (float)(a1 * F.inv_count);
+      o1 = (float)(a2 * F.inv_count);
+    }
+    F.out[((size_t)b * C + tid) * 2] = o0;
+    F.out[((size_t)b * C + tid) * 2 + 1] = o1;
+  }
+  if (tid == 0) __hip_atomic_store(&F.cnt[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();  // fin_red / fin_last are reused by the next tile of a persistent workgroup
+}
+
 // sum over the 16 lanes that share (lane >> 4)  [row of the MFMA output fragment]
 // DPP lane permutes inside a 16-lane row (no LDS traffic, unlike the ds_bpermute behind __shfl_xor): pair swap, quad-pair
 // swap, then the 8-lane and 16-lane mirrors -- after the quad steps every lane of a quad holds the quad sum, so a mirror

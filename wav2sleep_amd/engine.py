@@ -86,7 +86,9 @@ class Engine:
         self._streams = {}
         self._rjobs = []
         self.fused_forward = os.environ.get('W2S_FUSED_FORWARD', '1') != '0'
-        self.fold_gp = os.environ.get('W2S_FOLD_GP', '0') == '1'   # measured neutral (its extra read ~ the pre-pass it saves): off
+        self.fold_gp = os.environ.get('W2S_FOLD_GP', '0') == '1'
+        self.fused_finalize = os.environ.get('W2S_FUSED_FINALIZE', '0') != '0'
+        self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
         lib.load()
 
@@ -173,6 +175,17 @@ class Engine:
         lib.stats_finalize(part, B, ntiles, C, count, self.spec.instance_eps, kind, out)
         return out
 
+    def _fin(self, B, C, dev):
+        """(stat_out, stat_cnt) for the in-kernel statistics finalisation: the producer's last workgroup per sample reduces the
+        partials, so no w2s_stats_finalize launch sits between two layers.  One self-re-arming counter buffer per stream."""
+        if not self.fused_finalize:
+            return None, None
+        key = (torch.cuda.current_stream(dev).cuda_stream, B)
+        cnt = self._cnt.get(key)
+        if cnt is None:
+            cnt = self._cnt[key] = torch.zeros(B, device=dev, dtype=torch.int32)
+        return torch.empty(B, C, 2, device=dev, dtype=torch.float32), cnt
+
     def _conv(self, **kw):
         planes = self._bf.get(kw['w'].data_ptr()) if self.split_precision else None
         if planes is not None:
@@ -188,15 +201,18 @@ class Engine:
             # <= 32 channels: persistent split-precision forward kernel (prefetch + LDS-resident weights)
             nt = _cdiv(L_out, ftile)
             part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
+            so, sc = self._fin(B, cout, dev)
             lib.conv_fwd_fused(x=x, w=w, st_in=pro_stats, w1=x2, y=y, part=part, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, stride=stride,
-                               pro=pro, nwg=1024 if cin == 16 else 512)
-            return y, self._finalize(part, B, nt, cout, L_out, 0)
+                               pro=pro, nwg=1024 if cin == 16 else 512, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps)
+            return y, (so if so is not None else self._finalize(part, B, nt, cout, L_out, 0))
         tile = lib.conv_tile(cin, cout, 3, stride, lib.MODE_CONTIG, B, L_out)
         nt = _cdiv(L_out, tile)
         part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
+        so, sc = self._fin(B, cout, dev)
         self._conv(x=x, x2=x2, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=1, pro=pro,
-                   pro_stats=pro_stats, epi=lib.EPI_STATS, part=part, **({'ldx': 4} if pro == lib.PRO_FIRST else {}))
-        return y, self._finalize(part, B, nt, cout, L_out, 0)
+                   pro_stats=pro_stats, epi=lib.EPI_STATS, part=part, stat_out=so, stat_cnt=sc, stat_eps=self.spec.instance_eps,
+                   **({'ldx': 4} if pro == lib.PRO_FIRST else {}))
+        return y, (so if so is not None else self._finalize(part, B, nt, cout, L_out, 0))
 
     def _linear(self, x, w, bias, rows, cin, cout, ldx=None, y=None, ldy=None):
         """y[rows, cout] = x[rows, cin(*k)] @ w^T + bias; cin > 128 runs as k = cin/128 strided taps."""
@@ -238,15 +254,18 @@ class Engine:
         slab = self._slab(dev, nslab, cg * ch * 3)
         slab_d = self._slab(dev, nslab, cg * ch) if gpre is not None else None
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
+        so, sc = self._fin(B, ch, dev) if want_part else (None, None)
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
                       part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, split_precision=self.split_precision,
-                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1, y3p=y3p, st3p=st3p)
+                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1, y3p=y3p, st3p=st3p, stat_out=so, stat_cnt=sc)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         if gpre is not None:
             self._rjobs.append((slab_d, nslab, self.G[down], cg, ch, 1, 1, down in self._written, 0))
             self._written.add(down)
-        return self._bstats(part, B, nt, ch, Lh) if want_part else None
+        if not want_part:
+            return None
+        return so if so is not None else self._bstats(part, B, nt, ch, Lh)
 
     def _colsum(self, part, nparts, C, out, accumulate=False, ld=None):
         """queued column sum (flushed with the slab reductions): out[c] (+)= sum_p part[p*ld + c]"""
@@ -294,8 +313,9 @@ class Engine:
         y1 = None if recompute else torch.empty(B, L, c, device=dev, dtype=torch.float32)
         nt = _cdiv(L, FIRST_TILE)
         part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
-        lib.enc_first_fwd(x, w1, y1, part, B, L, c, FIRST_TILE)
-        st1 = self._finalize(part, B, nt, c, L, 0)
+        so, sc = self._fin(B, c, dev)
+        lib.enc_first_fwd(x, w1, y1, part, B, L, c, FIRST_TILE, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps)
+        st1 = so if so is not None else self._finalize(part, B, nt, c, L, 0)
         if recompute:
             y2, st2 = self._conv_stats(x=x, x2=w1, w=PF[pfx + 'cnn.0.conv2.conv.weight'], B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1,
                                        pro=lib.PRO_FIRST, pro_stats=st1)
@@ -652,8 +672,9 @@ class Engine:
                 tile = 512
                 nt = _cdiv(Lh, tile)
                 part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
-                lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile)
-                bs3 = self._bstats(part, B, nt, c, Lh)
+                so, sc = self._fin(B, c, dev)
+                lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile, stat_out=so, stat_cnt=sc)
+                bs3 = so if so is not None else self._bstats(part, B, nt, c, Lh)
             gn2 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
             gn1 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
             if lib.bwd_fused_supported(c, c):
@@ -669,8 +690,8 @@ class Engine:
                 part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
                 self._conv(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
                            pad=1, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP, aux=blk['y2'],
-                           aux_stats=blk['st2'], part=part)
-                bs2 = self._bstats(part, B, nt, c, L)
+                           aux_stats=blk['st2'], part=part, stat_out=(fin := self._fin(B, c, dev))[0], stat_cnt=fin[1])
+                bs2 = fin[0] if fin[0] is not None else self._bstats(part, B, nt, c, L)
                 self._wgrad(p + 'conv3.conv.weight', g=gpre, g2=blk['y3'], g_stats=blk['st3'], g_bstats=bs3, pro_g=lib.PRO_INBWD_GP, x=blk['y2'],
                             x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=1)
                 tile = lib.conv_tile(c, c, 3, 1, lib.MODE_CONTIG, B, L)
@@ -678,8 +699,8 @@ class Engine:
                 part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
                 self._conv(x=gn2, x2=blk['y2'], w=PB[p + 'conv2.conv.weight'], y=gn1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1,
                            pad=1, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st2'], pro_bstats=bs2, epi=lib.EPI_GP, aux=blk['y1'],
-                           aux_stats=blk['st1'], part=part)
-                bs1 = self._bstats(part, B, nt, c, L)
+                           aux_stats=blk['st1'], part=part, stat_out=(fin := self._fin(B, c, dev))[0], stat_cnt=fin[1])
+                bs1 = fin[0] if fin[0] is not None else self._bstats(part, B, nt, c, L)
                 self._wgrad(p + 'conv2.conv.weight', g=gn2, g2=blk['y2'], g_stats=blk['st2'], g_bstats=bs2, pro_g=lib.PRO_INBWD, x=blk['y1'],
                             x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=1)
             del gn2

@@ -27,9 +27,9 @@ _i32 = C.c_int32
 
 class ConvArgs(C.Structure):
     _fields_ = [(n, _fp) for n in ('x', 'x2', 'w', 'y', 'y2', 'pro_stats', 'pro_bstats', 'aux', 'aux_stats', 'add_even', 'bias',
-                                   'rowkeep', 'part', 'w_hi', 'w_lo')] + \
+                                   'rowkeep', 'part', 'w_hi', 'w_lo', 'stat_out', 'stat_cnt')] + \
                [(n, _i32) for n in ('B', 'L_in', 'L_out', 'cin', 'cout', 'taps', 'stride', 'dil', 'pad', 'flip', 'mode',
-                                    'ldx', 'ldy', 'ldy2', 'ld_aux', 'pro', 'epi')]
+                                    'ldx', 'ldy', 'ldy2', 'ld_aux', 'pro', 'epi')] + [('stat_eps', C.c_float), ('reserved', _i32)]
 
 
 class ReduceJob(C.Structure):
@@ -114,9 +114,11 @@ def _f(t):
 # ------------------------------------------------------------------------------------------------
 def conv_args(*, x, w, y, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, flip=0, mode=MODE_CONTIG, ldx=None, ldy=None,
               pro=PRO_NONE, epi=EPI_PLAIN, x2=None, pro_stats=None, pro_bstats=None, aux=None, aux_stats=None, add_even=None,
-              bias=None, rowkeep=None, part=None, y2=None, ldy2=0, ld_aux=0, w_hi=None, w_lo=None) -> ConvArgs:
+              bias=None, rowkeep=None, part=None, y2=None, ldy2=0, ld_aux=0, w_hi=None, w_lo=None, stat_out=None, stat_cnt=None,
+              stat_eps=1e-2) -> ConvArgs:
     a = ConvArgs()
     a.w_hi, a.w_lo = _p(w_hi), _p(w_lo)
+    a.stat_out, a.stat_cnt, a.stat_eps = _f(stat_out), _p(stat_cnt), stat_eps
     a.x, a.x2, a.w, a.y, a.y2 = _f(x), _f(x2), _f(w), _f(y), _f(y2)
     a.pro_stats, a.pro_bstats, a.aux, a.aux_stats = _f(pro_stats), _f(pro_bstats), _f(aux), _f(aux_stats)
     a.add_even, a.bias, a.rowkeep, a.part = _f(add_even), _f(bias), _f(rowkeep), _f(part)
@@ -242,9 +244,10 @@ def conv_fwd_fused_tile(cin, cout, stride) -> int:
     return load().w2s_conv_fwd_fused_tile(cin, cout, stride)
 
 
-def conv_fwd_fused(*, x, w, st_in, w1, y, part, B, L_in, L_out, cin, cout, stride, pro, nwg):
+def conv_fwd_fused(*, x, w, st_in, w1, y, part, B, L_in, L_out, cin, cout, stride, pro, nwg, stat_out=None, stat_cnt=None, eps=1e-2):
     def run():
-        _chk(load().w2s_conv_fwd_fused(_f(x), _f(w), _f(st_in), _f(w1), _f(y), _f(part), B, L_in, L_out, cin, cout, stride, pro, nwg, _stream()),
+        _chk(load().w2s_conv_fwd_fused(_f(x), _f(w), _f(st_in), _f(w1), _f(y), _f(part), B, L_in, L_out, cin, cout, stride, pro, nwg, _f(stat_out),
+                                       _p(stat_cnt), C.c_float(eps), _stream()),
              f'w2s_conv_fwd_fused(cin={cin},cout={cout},stride={stride},pro={pro})')
     nbytes = 4 * (B * L_in * (1 if pro == PRO_FIRST else cin) + B * L_out * cout)
     mt = conv_fwd_fused_tile(cin, cout, stride) // 64
@@ -267,10 +270,10 @@ def bwd_fused_folds_residual(cg, ch) -> bool:
 
 
 def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False,
-              gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None):
+              gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None, stat_out=None, stat_cnt=None):
     def run():
         _chk(load().w2s_bwd_fused(_f(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), _f(gout), _f(part),
-                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p), _stream()),
+                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p), _f(stat_out), _p(stat_cnt), _stream()),
              f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
     nbytes = 4 * (2 * B * Lg * cg + (B * Lh * (ch + 1) if w1 is not None else 2 * B * Lh * ch) + (B * Lh * ch // 2 if add_even is not None else 0)
                   + (B * Lh * cg // 2 if gpre is not None else 0) + (B * Lh * ch if y3p is not None else 0))
@@ -346,8 +349,9 @@ def stats_finalize(part, B, ntiles, Cc, count, eps, kind, out):
     _chk(load().w2s_stats_finalize(_f(part), B, ntiles, Cc, C.c_long(count), C.c_float(eps), kind, _f(out), _stream()), 'w2s_stats_finalize')
 
 
-def enc_first_fwd(x, w, y, part, B, L, cout, tile):
-    _chk(load().w2s_enc_first_fwd(_f(x), _f(w), _f(y), _f(part), B, L, cout, tile, _stream()), 'w2s_enc_first_fwd')
+def enc_first_fwd(x, w, y, part, B, L, cout, tile, stat_out=None, stat_cnt=None, eps=1e-2):
+    _chk(load().w2s_enc_first_fwd(_f(x), _f(w), _f(y), _f(part), B, L, cout, tile, _f(stat_out), _p(stat_cnt), C.c_float(eps), _stream()),
+         'w2s_enc_first_fwd')
 
 
 def enc_first_join(x, wd, y3, stats3, pre, B, L, cout):
@@ -359,8 +363,8 @@ def enc_first_bwd(x, gn1, y1, stats1, bstats1, gpre, slab, nslab, B, L, cout, w1
          'w2s_enc_first_bwd')
 
 
-def gp_stats(g, y, stats, part, B, L, Cc, tile):
-    _chk(load().w2s_gp_stats(_f(g), _f(y), _f(stats), _f(part), B, L, Cc, tile, _stream()), 'w2s_gp_stats')
+def gp_stats(g, y, stats, part, B, L, Cc, tile, stat_out=None, stat_cnt=None):
+    _chk(load().w2s_gp_stats(_f(g), _f(y), _f(stats), _f(part), B, L, Cc, tile, _f(stat_out), _p(stat_cnt), _stream()), 'w2s_gp_stats')
 
 
 def layernorm_fwd(x, ldx, gamma, beta, y, ldy, rstat, rows, Cc, eps, gelu=False):
