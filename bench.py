@@ -64,6 +64,7 @@ def main():
     ap.add_argument('--epochs', type=int, default=960)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--causal', action='store_true', help="the reference's `causal: True` variant (causal-padded convolutions); not the headline config")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -83,9 +84,9 @@ def main():
     from wav2sleep_amd import lib
     torch.manual_seed(42)  # scripts/config/main.yaml:35
     nc = 4
-    model = W.Wav2Sleep(W.SignalEncoders(SIGNAL_MAP, 128, 'gelu', norm='instance', chunk_causal=False),
+    model = W.Wav2Sleep(W.SignalEncoders(SIGNAL_MAP, 128, 'gelu', norm='instance', causal=args.causal, chunk_causal=False),
                         W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.1, dim_ff=512, nhead=8),
-                        W.SequenceCNN(128, dropout=0.1, norm='layer', num_layers=2, kernel_size=7, num_dilations=6), nc).to(dev).train()
+                        W.SequenceCNN(128, dropout=0.1, norm='layer', causal=args.causal, num_layers=2, kernel_size=7, num_dilations=6), nc).to(dev).train()
     if dist.is_initialized():  # DDP init: broadcast rank 0's parameters
         model._ensure_flat()
         dist.broadcast(model._flat, src=0)
@@ -114,7 +115,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'4-modality (ABD+THX+ECG+PPG) {args.epochs}-epoch ({args.epochs // 120} h) synthetic, 4-class, per-GPU batch {args.batch}, '
-                                   f'full train step fwd+CE+bwd+clip+AdamW', 'global_batch': args.batch * world, 'epochs': args.epochs,
+                                   f'full train step fwd+CE+bwd+clip+AdamW' + (', causal convolutions (causal: True)' if args.causal else ''), 'global_batch': args.batch * world, 'epochs': args.epochs,
                        'parallelism': f'dp{world}', 'final_loss': round(loss, 5),
                        'precision': "fp32 storage + fp32 accumulate; >=32-channel GEMMs as bf16x3 split products on the matrix cores "
                                     "(= the reference's float32_matmul_precision('high')); W2S_EXACT_FP32=1 for fp32 MFMA throughout"}}

@@ -181,14 +181,15 @@ int w2s_stats_finalize(const float* part, int B, int ntiles, int C, long count, 
 
 /* First encoder layer, Cin = 1 (blocks.py:46, conv1 of block 0): y[b,t,o] = sum_j w[o][j]*san(x[b,t+j-1]);
  * part [B][ceil(L/tile)][2][16] = partial sum / sum-of-squares.  w is the torch tensor [16][1][3]. */
-/* y may be NULL (statistics only: the W2S_PRO_FIRST consumers recompute the values) */
+/* y may be NULL (statistics only: the W2S_PRO_FIRST consumers recompute the values).
+ * causal != 0: the causal padding of ConvLayer1D (blocks.py:150-152,178-182), taps x[t-2], x[t-1], x[t]; needs y. */
 int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, float* stat_out, int32_t* stat_cnt,
-                      float eps, void* stream);
+                      float eps, int causal, void* stream);
 /* Block-0 residual join (blocks.py:67-69): pre[b,u,o] = GELU(IN(y3[b,u,o])) + wd[o]*san(x[b,2u]) */
 int w2s_enc_first_join(const float* x, const float* wd, const float* y3, const float* stats3, float* pre, int B, int L, int cout, void* stream);
 /* weight grads of block-0 conv1 / downsample; slab[nslab][64] = {dW1[o][j] (48), dWd[o] (16)}; sum with w2s_colsum */
 int w2s_enc_first_bwd(const float* x, const float* gn1, const float* y1, const float* stats1, const float* bstats1,
-                      const float* gpre, float* slab, int nslab, int B, int L, int cout, const float* w1, void* stream);
+                      const float* gpre, float* slab, int nslab, int B, int L, int cout, const float* w1, int causal, void* stream);
 /* y1 == NULL: the conv1 output is recomputed from x and w1 = conv1 weight [16][3] (the W2S_PRO_FIRST flow) */
 /* pre-pass of conv3's backward: part [B][ceil(L/tile)][2][C] = partial sums of g*GELU'(n) and g*GELU'(n)*n, n = IN(y) */
 int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, float* stat_out, int32_t* stat_cnt,

@@ -48,6 +48,7 @@ class ModelConfig:
     seq_dilations: int = 6
     seq_kernel: int = 7
     instance_eps: float = 1e-2  # models/wav2sleep.py:213-215
+    causal: bool = False  # scripts/config/main.yaml:22 `causal` (with model yaml `chunk_causal: False`): causal-padded convolutions
     layer_eps: float = 1e-5  # nn.LayerNorm default / models/utils.py:12
 
     def encoder_channels(self, signal: str) -> list[int]:
@@ -162,17 +163,26 @@ def instance_norm(x_BCL: Tensor, eps: float) -> Tensor:
     return F.instance_norm(x_BCL, eps=eps)
 
 
-def conv_layer_in(x_BCL: Tensor, w: Tensor, stride: int, eps: float) -> Tensor:
-    """ConvLayer1D (k=3, pad=1, no bias) -> InstanceNorm -> GELU.  models/blocks.py:173-186."""
-    y = F.conv1d(x_BCL, w, None, stride=stride, padding=1)
+def causal_conv1d(x_BCL: Tensor, w: Tensor, stride: int = 1, dilation: int = 1) -> Tensor:
+    """The causal branch of ConvLayer1D (models/blocks.py:150-152,178-182): symmetric padding (k-1)*dil, then the last
+    max(pad-(stride-1), 0) outputs are dropped, i.e. out[j] = sum_k w[k] x[j*stride - (k_size-1-k)*dil] with zeros before the start."""
+    pad = (w.size(-1) - 1) * dilation
+    y = F.conv1d(x_BCL, w, None, stride=stride, padding=pad, dilation=dilation)
+    trim = max(pad - (stride - 1), 0)
+    return y[:, :, :-trim] if trim > 0 else y
+
+
+def conv_layer_in(x_BCL: Tensor, w: Tensor, stride: int, eps: float, causal: bool = False) -> Tensor:
+    """ConvLayer1D (k=3, pad=1 or causal, no bias) -> InstanceNorm -> GELU.  models/blocks.py:173-186."""
+    y = causal_conv1d(x_BCL, w, stride) if causal else F.conv1d(x_BCL, w, None, stride=stride, padding=1)
     return gelu(instance_norm(y, eps))
 
 
-def conv_block(sd: dict, p: str, x_BCL: Tensor, eps: float, taps: dict | None = None) -> Tensor:
-    """ConvBlock1D.forward -- models/blocks.py:57-71."""
-    h1 = conv_layer_in(x_BCL, sd[p + 'conv1.conv.weight'], 1, eps)
-    h2 = conv_layer_in(h1, sd[p + 'conv2.conv.weight'], 1, eps)
-    h3 = conv_layer_in(h2, sd[p + 'conv3.conv.weight'], 2, eps)
+def conv_block(sd: dict, p: str, x_BCL: Tensor, eps: float, taps: dict | None = None, causal: bool = False) -> Tensor:
+    """ConvBlock1D.forward -- models/blocks.py:57-71 (the 1x1/stride-2 residual conv is the same in causal mode)."""
+    h1 = conv_layer_in(x_BCL, sd[p + 'conv1.conv.weight'], 1, eps, causal)
+    h2 = conv_layer_in(h1, sd[p + 'conv2.conv.weight'], 1, eps, causal)
+    h3 = conv_layer_in(h2, sd[p + 'conv3.conv.weight'], 2, eps, causal)
     r = F.conv1d(x_BCL, sd[p + 'downsample.weight'], None, stride=2)
     out = gelu(h3 + r)
     if taps is not None:
@@ -181,7 +191,8 @@ def conv_block(sd: dict, p: str, x_BCL: Tensor, eps: float, taps: dict | None = 
 
 
 def signal_encoder(sd: dict, cfg: ModelConfig, enc: str, sig: str, x_BT: Tensor, taps: dict | None = None) -> Tensor:
-    """SignalEncoder.forward, non-causal path -- models/wav2sleep.py:235-267."""
+    """SignalEncoder.forward -- models/wav2sleep.py:235-267: the whole-sequence path (:256-261), which is also what `causal=True` with
+    `chunk_causal=False` (scripts/config/model/wav2sleep.yaml:10-11) runs, with causal convolutions inside the blocks (:204,220)."""
     spe = SAMPLES_PER_EPOCH[sig]
     if x_BT.size(-1) % spe:
         raise ValueError(f'Input length {x_BT.size(-1)} must be divisible by samples_per_epoch={spe}.')
@@ -189,7 +200,7 @@ def signal_encoder(sd: dict, cfg: ModelConfig, enc: str, sig: str, x_BT: Tensor,
     y = x_BT.unsqueeze(1)
     nb = len(cfg.encoder_channels(sig))
     for i in range(nb):
-        y = conv_block(sd, f'signal_encoders.encoders.{enc}.cnn.{i}.', y, cfg.instance_eps, taps)
+        y = conv_block(sd, f'signal_encoders.encoders.{enc}.cnn.{i}.', y, cfg.instance_eps, taps, cfg.causal)
     epoch_dim = y.size(1) * 4
     y = y.transpose(-1, -2).reshape(B, -1, epoch_dim)
     y = F.linear(y, sd[f'signal_encoders.encoders.{enc}.linear.weight'], sd[f'signal_encoders.encoders.{enc}.linear.bias'])
@@ -278,7 +289,7 @@ def sequence_cnn(sd: dict, cfg: ModelConfig, z_BSF: Tensor) -> Tensor:
             d = 2 ** j
             p = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.'
             pad = (k + (k - 1) * (d - 1)) // 2
-            h = F.conv1d(h, sd[p + 'conv.weight'], None, padding=pad, dilation=d)
+            h = causal_conv1d(h, sd[p + 'conv.weight'], 1, d) if cfg.causal else F.conv1d(h, sd[p + 'conv.weight'], None, padding=pad, dilation=d)
             h = gelu(conv_layer_norm(h, sd[p + 'norm.weight'], sd[p + 'norm.bias'], cfg.layer_eps))
         x = gelu(h + x)
     return x.transpose(-1, -2)

@@ -52,11 +52,11 @@ def checksum(d: dict) -> float:
 
 def build_reference(cfg: O.ModelConfig) -> Wav2Sleep:
     enc = SignalEncoders(signal_map=dict(cfg.signal_map), feature_dim=cfg.feature_dim, activation='gelu', norm='instance',
-                         causal=False, chunk_causal=False, initial_channels=cfg.initial_channels,
+                         causal=cfg.causal, chunk_causal=False, initial_channels=cfg.initial_channels,
                          max_channels=cfg.max_channels, output_norm=False, use_residual=True)
     mix = MultiModalAttentionEmbedder(feature_dim=cfg.feature_dim, dropout=0.0, activation='gelu', layers=cfg.mixer_layers,
                                       dim_ff=cfg.mixer_dim_ff, nhead=cfg.mixer_nhead)
-    seq = SequenceCNN(feature_dim=cfg.feature_dim, dropout=0.0, activation='gelu', norm='layer', causal=False,
+    seq = SequenceCNN(feature_dim=cfg.feature_dim, dropout=0.0, activation='gelu', norm='layer', causal=cfg.causal,
                       num_layers=cfg.seq_blocks, kernel_size=cfg.seq_kernel, num_dilations=cfg.seq_dilations)
     return Wav2Sleep(enc, mix, seq, num_classes=cfg.num_classes)
 
@@ -67,12 +67,15 @@ CASES = {
     'c2_four_mod': ({'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}, 4, 3, 8, {'ABD': [1], 'PPG': [2], 'ECG': [1]}, 12, 102),
     'c4_eog_pair': ({'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 4, {'EOG-R': [0]}, 14, 104),
     'c5_shared_enc': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [0]}, 15, 105),
+    # `causal: True` of scripts/config/main.yaml:22 with the model yaml's `chunk_causal: False`: causal-padded convolutions
+    'c6_causal': ({'ABD': 'ABD', 'ECG': 'ECG'}, 4, 2, 8, {'ABD': [1]}, 16, 106),
 }
+CAUSAL_CASES = {'c6_causal'}
 
 
 def run_case(name: str):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc)
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES)
     sd = O.make_state_dict(cfg, seed=wseed)
     x, y = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
     model = build_reference(cfg)
@@ -174,6 +177,9 @@ def run_misc():
 
 
 if __name__ == '__main__':
+    only = sys.argv[1:]
     for name in CASES:
-        run_case(name)
-    run_misc()
+        if not only or name in only:
+            run_case(name)
+    if not only or 'misc' in only:
+        run_misc()

@@ -12,7 +12,9 @@ CASES = {
     'c2_four_mod': ({'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}, 4, 3, 8, {'ABD': [1], 'PPG': [2], 'ECG': [1]}, 12, 102),
     'c4_eog_pair': ({'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 4, {'EOG-R': [0]}, 14, 104),
     'c5_shared_enc': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [0]}, 15, 105),
+    'c6_causal': ({'ABD': 'ABD', 'ECG': 'ECG'}, 4, 2, 8, {'ABD': [1]}, 16, 106),
 }
+CAUSAL_CASES = {'c6_causal'}  # `causal: True` (scripts/config/main.yaml:22) with `chunk_causal: False` (model/wav2sleep.yaml:11)
 
 
 def summarize(t: torch.Tensor, k: int = 64) -> np.ndarray:

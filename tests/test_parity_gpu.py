@@ -19,16 +19,16 @@ pytestmark = pytest.mark.gpu
 
 import wav2sleep_amd as W  # noqa: E402
 from oracle import wav2sleep_oracle as O  # noqa: E402  (checker only)
-from tests.golden_util import CASES, assert_summary_close, load  # noqa: E402
+from tests.golden_util import CASES, CAUSAL_CASES, assert_summary_close, load  # noqa: E402
 
 DEV = 'cuda'
 SM4 = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
 
 
-def build(signal_map, nc, dropout=0.0):
-    return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', chunk_causal=False),
+def build(signal_map, nc, dropout=0.0, causal=False):
+    return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', causal=causal, chunk_causal=False),
                        W.MultiModalAttentionEmbedder(128, layers=2, dropout=dropout, dim_ff=512, nhead=8),
-                       W.SequenceCNN(128, dropout=dropout, norm='layer', num_layers=2, kernel_size=7, num_dilations=6), nc)
+                       W.SequenceCNN(128, dropout=dropout, norm='layer', causal=causal, num_layers=2, kernel_size=7, num_dilations=6), nc)
 
 
 def assert_logits_close(got, want):
@@ -56,8 +56,8 @@ def test_kernels_against_cpu_torch(stage):
 def test_forward_matches_reference_goldens(name):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
     g = load(name)
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc)
-    model = build(signal_map, nc)
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES)
+    model = build(signal_map, nc, causal=cfg.causal)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).eval()
     x, y = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
@@ -74,8 +74,8 @@ def test_train_steps_match_reference_goldens(name):
     """fwd + CE(ignore -1) + bwd + clip 1.0 + AdamW + ExpWarmUp, two steps, vs the reference's Lightning recipe."""
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
     g = load(name)
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc)
-    model = build(signal_map, nc)
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES)
+    model = build(signal_map, nc, causal=cfg.causal)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).train()
     tr = W.FusedTrainStep(model)
@@ -100,18 +100,20 @@ def test_train_steps_match_reference_goldens(name):
         assert_summary_close(sd[k], g[f'param2.{k}'], rtol=1e-5, atol=1.1e-6, what=f'param2.{k}')
 
 
-@pytest.mark.parametrize('signal_map,nc,B,S,missing', [
-    ({'ECG': 'UNI'}, 4, 2, 120, None),                                   # configs[0]: ECG-only, 1 h, batch 2
-    (SM4, 4, 3, 24, {'ABD': [0], 'ECG': [1], 'PPG': [2]}),               # ragged 4-modality
-    ({'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 6, {'EOG-L': [1]}),     # wav2sleep-eog, 5 classes
-    ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 5, None),       # shared encoder, odd S (partial tiles)
+@pytest.mark.parametrize('signal_map,nc,B,S,missing,causal', [
+    ({'ECG': 'UNI'}, 4, 2, 120, None, False),                                   # configs[0]: ECG-only, 1 h, batch 2
+    (SM4, 4, 3, 24, {'ABD': [0], 'ECG': [1], 'PPG': [2]}, False),               # ragged 4-modality
+    ({'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 6, {'EOG-L': [1]}, False),     # wav2sleep-eog, 5 classes
+    ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 5, None, False),       # shared encoder, odd S (partial tiles)
+    (SM4, 4, 2, 40, {'THX': [1]}, True),                                        # `causal: True`: causal-padded convolutions
+    ({'EOG-L': 'EOG-L', 'ECG': 'UNI'}, 5, 2, 7, None, True),                    # causal, 10-block encoder, odd S
 ])
-def test_autograd_path_matches_oracle(signal_map, nc, B, S, missing):
+def test_autograd_path_matches_oracle(signal_map, nc, B, S, missing, causal):
     """nn.Module surface: logits = model(x); torch CE; loss.backward() fills p.grad like the reference's autograd."""
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc)
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=causal)
     sd = O.make_state_dict(cfg, seed=7)
     x, y = O.make_inputs(cfg, B, S, seed=8, missing=missing)
-    model = build(signal_map, nc)
+    model = build(signal_map, nc, causal=causal)
     model.load_state_dict(sd)
     model.to(DEV).train()
     logits = model(to_dev(x))
@@ -130,6 +132,24 @@ def test_autograd_path_matches_oracle(signal_map, nc, B, S, missing):
     F.cross_entropy(logits.view(-1, nc), y.to(DEV).view(-1).long(), ignore_index=-1).backward()
     for k, p in model.named_parameters():
         assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_causal_sequence_mixer_ignores_the_future():
+    """The property the reference's tests/model/test_causality.py checks (outputs for a prefix do not depend on what follows),
+    on the part of the shipped causal configuration that has it: the causal SequenceCNN (the whole-recording instance norm of the
+    encoders is not prefix-invariant in the reference either).  Bit-exact; the non-causal mixer must differ."""
+    torch.manual_seed(0)
+    z = torch.randn(2, 96, 128, device=DEV)
+    z2 = z.clone()
+    z2[:, 48:] = torch.randn(2, 48, 128, device=DEV)
+    outs = {}
+    for causal in (True, False):
+        seq = W.SequenceCNN(128, dropout=0.0, norm='layer', causal=causal, num_layers=2, kernel_size=7, num_dilations=6).to(DEV).eval()
+        outs[causal] = (seq(z), seq(z2), seq(z[:, :48].contiguous()))
+    a, b, c = outs[True]
+    assert torch.equal(a[:, :48], b[:, :48]) and torch.equal(a[:, :48], c)
+    a, b, _ = outs[False]
+    assert not torch.equal(a[:, :48], b[:, :48])
 
 
 def test_missing_modality_equals_subset_run_and_leaves_other_samples_untouched():

@@ -277,9 +277,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
     constexpr int EVEN = 0x55 & ((1 << MT) - 1), ODD = 0xAA & ((1 << MT) - 1);
     stage(t0 / 2, TM / 2 + 1, 1);
     __syncthreads();
-    mma_tap(1, 0, EVEN);  // t' = 2u   : W_1^T g[u]
-    mma_tap(2, 0, ODD);   // t' = 2u+1 : W_2^T g[u]
-    mma_tap(0, 1, ODD);   //            + W_0^T g[u+1]
+    if (a.pad == 2) {       // causal padding (forward taps 2u'-2+k): the parities swap roles
+      mma_tap(2, 0, EVEN);  // t' = 2u   : W_2^T g[u]
+      mma_tap(0, 1, EVEN);  //            + W_0^T g[u+1]
+      mma_tap(1, 1, ODD);   // t' = 2u+1 : W_1^T g[u+1]
+    } else {
+      mma_tap(1, 0, EVEN);  // t' = 2u   : W_1^T g[u]
+      mma_tap(2, 0, ODD);   // t' = 2u+1 : W_2^T g[u]
+      mma_tap(0, 1, ODD);   //            + W_0^T g[u+1]
+    }
   }
 
   // ------------------------------------ epilogue ------------------------------------

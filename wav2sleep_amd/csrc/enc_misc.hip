@@ -8,7 +8,7 @@
 // (16-B store; 4 lanes cover a 64-B row; a wave writes 1 KiB contiguous).  blocks.py:46 with Cin = 1.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                                                            float* __restrict__ part, int L, int tile, int ntiles, StatFin fin) {
+                                                            float* __restrict__ part, int L, int tile, int ntiles, StatFin fin, int shift) {
   __shared__ float red[4][4][8];
   const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x;
   const int og = tid & 3, lane = tid & 63, wave = tid >> 6;
@@ -24,9 +24,11 @@ __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restr
   for (int p = tid >> 2; p < tile; p += 64) {
     const int t = t0 + p;
     if (t >= L) break;
-    const float xm = (t > 0) ? sanitize_f(xb[t - 1]) : 0.f;
-    const float xc = sanitize_f(xb[t]);
-    const float xp = (t + 1 < L) ? sanitize_f(xb[t + 1]) : 0.f;
+    // shift = 1: causal padding (blocks.py:150-152,178-182) -- the taps read x[t-2], x[t-1], x[t]
+    const int tc = t - shift;
+    const float xm = (tc > 0) ? sanitize_f(xb[tc - 1]) : 0.f;
+    const float xc = (tc >= 0) ? sanitize_f(xb[tc]) : 0.f;
+    const float xp = (tc + 1 < L) ? sanitize_f(xb[tc + 1]) : 0.f;
     f32x4 v;
     v.x = wr[0][0] * xm + wr[0][1] * xc + wr[0][2] * xp;
     v.y = wr[1][0] * xm + wr[1][1] * xc + wr[1][2] * xp;
@@ -102,8 +104,9 @@ __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __res
 }
 
 extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, float* stat_out,
-                                 int* stat_cnt, float eps, void* stream) {
+                                 int* stat_cnt, float eps, int causal, void* stream) {
   if (!x || !w || !part || cout != 16 || tile < 64 || (tile & 63)) return W2S_EINVAL;  // y == NULL: statistics only
+  if (causal && !y) return W2S_EINVAL;  // the closed-form statistics kernel is written for the symmetric padding
   const int ntiles = (L + tile - 1) / tile;
   if (stat_out && !stat_cnt) return W2S_EINVAL;
   const StatFin fin{stat_out, stat_cnt, 1.0 / (double)L, eps, 0};
@@ -114,7 +117,7 @@ extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float
     return W2S_OK;
   }
   hipLaunchKernelGGL(enc_first_fwd_kernel, dim3(ntiles, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, y, part, L, tile,
-                     ntiles, fin);
+                     ntiles, fin, causal ? 1 : 0);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
@@ -153,7 +156,7 @@ extern "C" int w2s_enc_first_join(const float* x, const float* wd, const float* 
 __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gn1,
                                                             const float* __restrict__ y1, const float* __restrict__ stats1,
                                                             const float* __restrict__ bstats1, const float* __restrict__ gpre,
-                                                            float* __restrict__ slab, int B, int L, const float* __restrict__ w1) {
+                                                            float* __restrict__ slab, int B, int L, const float* __restrict__ w1, int shift) {
   __shared__ float red[4][4][16];
   __shared__ float xs[1026];
   const int tid = threadIdx.x, og = tid & 3, lane = tid & 63, wave = tid >> 6;
@@ -175,11 +178,11 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
     f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
     f32x4 q1 = {b01.x, b01.z, b23.x, b23.z}, q2 = {b01.y, b01.w, b23.y, b23.w};
     const float* xb = x + (size_t)b * L;
-    // the item's 1026 sanitised signal samples t0-1 .. t0+1024 through LDS (one coalesced pass instead of three 4-B loads
-    // per position)
+    // the item's 1026 sanitised signal samples t0-1 .. t0+1024 (causal padding, shift = 1: t0-2 .. t0+1023) through LDS (one
+    // coalesced pass instead of three 4-B loads per position)
     __syncthreads();
     for (int i = tid; i < 1026; i += 256) {
-      const int t = t0 - 1 + i;
+      const int t = t0 - 1 - shift + i;
       const float xv = xb[min(max(t, 0), L - 1)];
       xs[i] = (t >= 0 && t < L && !isinf(xv)) ? xv : 0.f;
     }
@@ -209,7 +212,8 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
       acc[9] += gy.w * xm; acc[10] += gy.w * xc; acc[11] += gy.w * xp;
       if (!(t & 1)) {
         f32x4 gp = ld4o(pb, (unsigned)(t >> 1) * 16 + og * 4);
-        acc[12] += gp.x * xc; acc[13] += gp.y * xc; acc[14] += gp.z * xc; acc[15] += gp.w * xc;
+        const float x0 = xs[p + 1 + shift];  // x[t]: the 1x1/stride-2 residual conv has no padding in either mode
+        acc[12] += gp.x * x0; acc[13] += gp.y * x0; acc[14] += gp.z * x0; acc[15] += gp.w * x0;
       }
     }
   }
@@ -237,10 +241,10 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
 }
 
 extern "C" int w2s_enc_first_bwd(const float* x, const float* gn1, const float* y1, const float* stats1, const float* bstats1,
-                                 const float* gpre, float* slab, int nslab, int B, int L, int cout, const float* w1, void* stream) {
+                                 const float* gpre, float* slab, int nslab, int B, int L, int cout, const float* w1, int causal, void* stream) {
   if (!x || !gn1 || (!y1 && !w1) || !stats1 || !bstats1 || !gpre || !slab || cout != 16 || nslab <= 0) return W2S_EINVAL;
   hipLaunchKernelGGL(enc_first_bwd_kernel, dim3(nslab), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gn1, y1, stats1, bstats1,
-                     gpre, slab, B, L, y1 ? nullptr : w1);
+                     gpre, slab, B, L, y1 ? nullptr : w1, causal ? 1 : 0);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

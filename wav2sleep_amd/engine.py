@@ -41,6 +41,8 @@ class EngineSpec:
     seq_dropout: float = 0.0
     instance_eps: float = 1e-2
     layer_eps: float = 1e-5
+    causal: bool = False       # encoders: causal-padded convolutions (blocks.py:150-152,178-182; `chunk_causal: False`)
+    seq_causal: bool = False   # SequenceCNN: causal dilated convolutions (wav2sleep.py:355, blocks.py:150-152)
     enc_sig: dict = field(default_factory=dict)  # encoder name -> first signal that created it
 
     def __post_init__(self):
@@ -90,6 +92,14 @@ class Engine:
         self.fused_finalize = os.environ.get('W2S_FUSED_FINALIZE', '0') != '0'
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
+        # causal padding (scripts/config/main.yaml:22 `causal`): out[j] reads x[j*stride - (k-1-tap)*dil], zeros before the start.  Same
+        # kernels, different pad: forward pad (k-1)*dil, data-gradient (flipped taps) pad 0.  The <= 32-channel fused kernels and
+        # the first-layer recompute are written for the symmetric padding, so the causal model runs on the generic kernels.
+        self.causal = bool(spec.causal)
+        self.seq_causal = bool(spec.seq_causal)
+        self.kpad = 2 if self.causal else 1
+        if self.causal:
+            self.fused_forward = False
         lib.load()
 
     # ------------------------------------------------------------------ weights
@@ -196,7 +206,7 @@ class Engine:
         """k=3 encoder conv writing the pre-norm tensor + instance-norm statistics (blocks.py:174-183)."""
         dev = x.device
         y = torch.empty(B, L_out, cout, device=dev, dtype=torch.float32)
-        ftile = lib.conv_fwd_fused_tile(cin, cout, stride) if (self.split_precision and self.fused_forward) else 0
+        ftile = lib.conv_fwd_fused_tile(cin, cout, stride) if (self.split_precision and self.fused_forward and not self.causal) else 0
         if ftile and pro in (lib.PRO_GELU, lib.PRO_IN_GELU, lib.PRO_FIRST):
             # <= 32 channels: persistent split-precision forward kernel (prefetch + LDS-resident weights)
             nt = _cdiv(L_out, ftile)
@@ -209,7 +219,7 @@ class Engine:
         nt = _cdiv(L_out, tile)
         part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
         so, sc = self._fin(B, cout, dev)
-        self._conv(x=x, x2=x2, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=1, pro=pro,
+        self._conv(x=x, x2=x2, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=self.kpad, pro=pro,
                    pro_stats=pro_stats, epi=lib.EPI_STATS, part=part, stat_out=so, stat_cnt=sc, stat_eps=self.spec.instance_eps,
                    **({'ldx': 4} if pro == lib.PRO_FIRST else {}))
         return y, (so if so is not None else self._finalize(part, B, nt, cout, L_out, 0))
@@ -308,13 +318,13 @@ class Engine:
         # The Cin = 1 conv1 output (16 x T per recording: the largest tensor of the model) is only materialised when someone
         # needs it (debug taps, the exact-fp32 backward kernels); otherwise its consumers recompute it from the raw signal
         # (W2S_PRO_FIRST: 3 FMAs per element) and only its instance-norm statistics are computed here.
-        recompute = self.split_precision and self.taps is None and c == 16
+        recompute = self.split_precision and self.taps is None and c == 16 and not self.causal
         w1 = P[pfx + 'cnn.0.conv1.conv.weight']
         y1 = None if recompute else torch.empty(B, L, c, device=dev, dtype=torch.float32)
         nt = _cdiv(L, FIRST_TILE)
         part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
         so, sc = self._fin(B, c, dev)
-        lib.enc_first_fwd(x, w1, y1, part, B, L, c, FIRST_TILE, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps)
+        lib.enc_first_fwd(x, w1, y1, part, B, L, c, FIRST_TILE, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps, causal=self.causal)
         st1 = so if so is not None else self._finalize(part, B, nt, c, L, 0)
         if recompute:
             y2, st2 = self._conv_stats(x=x, x2=w1, w=PF[pfx + 'cnn.0.conv2.conv.weight'], B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1,
@@ -464,7 +474,7 @@ class Engine:
                 p = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.'
                 y = torch.empty(B, S, F, device=dev, dtype=torch.float32)
                 self._conv(x=hcur, w=self.PF[p + 'conv.weight'], y=y, B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1,
-                           dil=d, pad=(sp.seq_kernel // 2) * d, mode=lib.MODE_DILATED, ldx=ldh)
+                           dil=d, pad=(sp.seq_kernel - 1) * d if self.seq_causal else (sp.seq_kernel // 2) * d, mode=lib.MODE_DILATED, ldx=ldh)
                 hn = torch.empty(B, S, F, device=dev, dtype=torch.float32)
                 rs = torch.empty(B * S, 2, device=dev, dtype=torch.float32)
                 lib.layernorm_fwd(y, F, P[p + 'norm.weight'], P[p + 'norm.bias'], hn, F, rs, B * S, F, sp.layer_eps, gelu=True)
@@ -553,12 +563,12 @@ class Engine:
                 self._colsum(pg, npl, F, self.G[p + 'norm.weight'], accumulate=(p + 'norm.weight') in self._written)
                 self._colsum(pb, npl, F, self.G[p + 'norm.bias'], accumulate=(p + 'norm.bias') in self._written)
                 self._written.update((p + 'norm.weight', p + 'norm.bias'))
-                pad = (sp.seq_kernel // 2) * d
+                pad = (sp.seq_kernel - 1) * d if self.seq_causal else (sp.seq_kernel // 2) * d
                 self._wgrad(p + 'conv.weight', g=gy, x=cv['hin'], ldx=cv['ldh'], B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel,
                             stride=1, pad=pad, dil=d)
                 gh = torch.empty(B, S, F, device=dev, dtype=torch.float32)
                 self._conv(x=gy, w=PB[p + 'conv.weight'], y=gh, B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1, dil=d,
-                           pad=pad, flip=1, mode=lib.MODE_DILATED)
+                           pad=(sp.seq_kernel - 1) * d - pad, flip=1, mode=lib.MODE_DILATED)
             gx = torch.empty(B, S, F, device=dev, dtype=torch.float32)
             lib.eltwise(lib.ELT_ADD, g_pre, gh, gx, rows * F)
             if b > 0:
@@ -677,7 +687,7 @@ class Engine:
                 bs3 = so if so is not None else self._bstats(part, B, nt, c, Lh)
             gn2 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
             gn1 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
-            if lib.bwd_fused_supported(c, c):
+            if lib.bwd_fused_supported(c, c) and not self.causal:
                 bs2 = self._bwd_fused(p + 'conv3.conv.weight', g=gpre, y=blk['y3'], st_k=blk['st3'], bst_k=bs3, pro=lib.PRO_INBWD_GP,
                                       xin=blk['y2'], st_in=blk['st2'], add_even=None, gout=gn2, want_part=True, B=B, Lg=Lh, Lh=L, cg=c, ch=c, stride=2)
                 first = i == 0 and blk['y1'] is None   # block 0's conv1 output is recomputed from the raw signal
@@ -689,22 +699,22 @@ class Engine:
                 nt = _cdiv(L, tile)
                 part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
                 self._conv(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
-                           pad=1, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP, aux=blk['y2'],
+                           pad=self.kpad, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP, aux=blk['y2'],
                            aux_stats=blk['st2'], part=part, stat_out=(fin := self._fin(B, c, dev))[0], stat_cnt=fin[1])
                 bs2 = fin[0] if fin[0] is not None else self._bstats(part, B, nt, c, L)
                 self._wgrad(p + 'conv3.conv.weight', g=gpre, g2=blk['y3'], g_stats=blk['st3'], g_bstats=bs3, pro_g=lib.PRO_INBWD_GP, x=blk['y2'],
-                            x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=1)
+                            x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=self.kpad)
                 tile = lib.conv_tile(c, c, 3, 1, lib.MODE_CONTIG, B, L)
                 nt = _cdiv(L, tile)
                 part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
                 self._conv(x=gn2, x2=blk['y2'], w=PB[p + 'conv2.conv.weight'], y=gn1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1,
-                           pad=1, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st2'], pro_bstats=bs2, epi=lib.EPI_GP, aux=blk['y1'],
+                           pad=2 - self.kpad, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st2'], pro_bstats=bs2, epi=lib.EPI_GP, aux=blk['y1'],
                            aux_stats=blk['st1'], part=part, stat_out=(fin := self._fin(B, c, dev))[0], stat_cnt=fin[1])
                 bs1 = fin[0] if fin[0] is not None else self._bstats(part, B, nt, c, L)
                 self._wgrad(p + 'conv2.conv.weight', g=gn2, g2=blk['y2'], g_stats=blk['st2'], g_bstats=bs2, pro_g=lib.PRO_INBWD, x=blk['y1'],
-                            x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=1)
+                            x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=self.kpad)
             del gn2
-            if i > 0 and self.split_precision and lib.bwd_fused_supported(c, cin) and lib.bwd_fused_folds_residual(c, cin) and not (L & 1):
+            if i > 0 and self.split_precision and not self.causal and lib.bwd_fused_supported(c, cin) and lib.bwd_fused_folds_residual(c, cin) and not (L & 1):
                 # conv1 + the whole residual branch (its data gradient AND its weight gradient) in one pass over the tensors
                 gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
                 prev = ec['blocks'][i - 1] if self.fold_gp else dict(y3=None, st3=None)   # fold its conv3-backward statistics pre-pass in
@@ -719,22 +729,22 @@ class Engine:
                 Rr = torch.empty(B, Lh, cin, device=dev, dtype=torch.float32)
                 self._conv(x=gpre, w=PB[p + 'downsample.weight'], y=Rr, B=B, L_in=Lh, L_out=Lh, cin=c, cout=cin, taps=1, stride=1, pad=0)
                 gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
-                if lib.bwd_fused_supported(c, cin):
+                if lib.bwd_fused_supported(c, cin) and not self.causal:
                     self._bwd_fused(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, pro=lib.PRO_INBWD, xin=blk['pin'],
                                     st_in=None, add_even=Rr, gout=gprev, want_part=False, B=B, Lg=L, Lh=L, cg=c, ch=cin, stride=1)
                 else:
                     self._conv(x=gn1, x2=blk['y1'], w=PB[p + 'conv1.conv.weight'], y=gprev, B=B, L_in=L, L_out=L, cin=c, cout=cin, taps=3,
-                               stride=1, pad=1, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st1'], pro_bstats=bs1, epi=lib.EPI_GP, aux=blk['pin'],
+                               stride=1, pad=2 - self.kpad, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st1'], pro_bstats=bs1, epi=lib.EPI_GP, aux=blk['pin'],
                                add_even=Rr)
                     self._wgrad(p + 'conv1.conv.weight', g=gn1, g2=blk['y1'], g_stats=blk['st1'], g_bstats=bs1, pro_g=lib.PRO_INBWD,
-                                x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=L, cin=cin, cout=c, taps=3, stride=1, pad=1)
+                                x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=L, cin=cin, cout=c, taps=3, stride=1, pad=self.kpad)
                 self._wgrad(p + 'downsample.weight', g=gpre, x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=Lh, cin=cin, cout=c,
                             taps=1, stride=2, pad=0)
                 gpre = gprev
             else:
                 nslab = max(1, min(1024, _cdiv(B * L, 4096)))
                 slab = torch.empty(nslab, 64, device=dev, dtype=torch.float32)
-                lib.enc_first_bwd(ec['x'], gn1, blk['y1'], blk['st1'], bs1, gpre, slab, nslab, B, L, c, w1=P[p + 'conv1.conv.weight'])
+                lib.enc_first_bwd(ec['x'], gn1, blk['y1'], blk['st1'], bs1, gpre, slab, nslab, B, L, c, w1=P[p + 'conv1.conv.weight'], causal=self.causal)
                 n1, nd = p + 'conv1.conv.weight', p + 'downsample.weight'
                 self._colsum(slab, nslab, 48, self.G[n1], accumulate=n1 in self._written, ld=64)
                 self._colsum(slab.view(-1)[48:], nslab, 16, self.G[nd], accumulate=nd in self._written, ld=64)

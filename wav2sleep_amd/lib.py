@@ -349,8 +349,8 @@ def stats_finalize(part, B, ntiles, Cc, count, eps, kind, out):
     _chk(load().w2s_stats_finalize(_f(part), B, ntiles, Cc, C.c_long(count), C.c_float(eps), kind, _f(out), _stream()), 'w2s_stats_finalize')
 
 
-def enc_first_fwd(x, w, y, part, B, L, cout, tile, stat_out=None, stat_cnt=None, eps=1e-2):
-    _chk(load().w2s_enc_first_fwd(_f(x), _f(w), _f(y), _f(part), B, L, cout, tile, _f(stat_out), _p(stat_cnt), C.c_float(eps), _stream()),
+def enc_first_fwd(x, w, y, part, B, L, cout, tile, stat_out=None, stat_cnt=None, eps=1e-2, causal=False):
+    _chk(load().w2s_enc_first_fwd(_f(x), _f(w), _f(y), _f(part), B, L, cout, tile, _f(stat_out), _p(stat_cnt), C.c_float(eps), int(causal), _stream()),
          'w2s_enc_first_fwd')
 
 
@@ -358,8 +358,8 @@ def enc_first_join(x, wd, y3, stats3, pre, B, L, cout):
     _chk(load().w2s_enc_first_join(_f(x), _f(wd), _f(y3), _f(stats3), _f(pre), B, L, cout, _stream()), 'w2s_enc_first_join')
 
 
-def enc_first_bwd(x, gn1, y1, stats1, bstats1, gpre, slab, nslab, B, L, cout, w1=None):
-    _chk(load().w2s_enc_first_bwd(_f(x), _f(gn1), _f(y1), _f(stats1), _f(bstats1), _f(gpre), _f(slab), nslab, B, L, cout, _f(w1), _stream()),
+def enc_first_bwd(x, gn1, y1, stats1, bstats1, gpre, slab, nslab, B, L, cout, w1=None, causal=False):
+    _chk(load().w2s_enc_first_bwd(_f(x), _f(gn1), _f(y1), _f(stats1), _f(bstats1), _f(gpre), _f(slab), nslab, B, L, cout, _f(w1), int(causal), _stream()),
          'w2s_enc_first_bwd')
 
 

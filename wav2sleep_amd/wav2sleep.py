@@ -114,14 +114,18 @@ class DilatedConvBlock(nn.Module):
 
 
 class SignalEncoder(nn.Module):
-    """models/wav2sleep.py:164-267 (non-causal path)."""
+    """models/wav2sleep.py:164-267: the whole-sequence path (:256-261), non-causal or -- `causal=True, chunk_causal=False`, what
+    scripts/config/model/wav2sleep.yaml:10-11 builds for `causal: True` -- with causal-padded convolutions in the blocks."""
 
     def __init__(self, input_dim=1, feature_dim=256, activation='gelu', samples_per_epoch=1024, norm='instance', initial_channels=16,
                  max_channels=128, causal=False, chunk_causal=True, output_norm=False, use_residual=True):
         super().__init__()
         _check_activation(activation)
-        if causal or output_norm or norm != 'instance':
-            raise NotImplementedError('causal / output_norm / non-instance encoder norms have no gfx950 kernels yet')
+        if output_norm or norm != 'instance':
+            raise NotImplementedError('output_norm / non-instance encoder norms have no gfx950 kernels yet')
+        if causal and chunk_causal:
+            raise NotImplementedError('chunk_causal=True (per-epoch [B*S, 1, spe] encoding, wav2sleep.py:248-255) has no gfx950 kernels yet; '
+                                      'the shipped model config uses chunk_causal: False (causal convolutions)')
         self.feature_dim = feature_dim
         self.samples_per_epoch = samples_per_epoch
         self.causal = causal
@@ -183,7 +187,7 @@ class SignalEncoders(nn.Module):
         """models/wav2sleep.py:146-161, inference only (training goes through Wav2Sleep.forward, one fused autograd node):
         dict signal -> [B, T]  ->  dict signal -> [B, S, feature_dim]; samples whose input row is -inf come back as -inf."""
         spec = EngineSpec(signal_map=dict(self.signal_map), feature_dim=self.feature_dim, initial_channels=self.initial_channels,
-                          max_channels=self.max_channels)
+                          max_channels=self.max_channels, causal=self.causal)
         eng, ver = _standalone_engine(self, 'signal_encoders.', spec)
         e = eng.encode(x, save=False, pack_key=ver, cls=False)
         B, S, F = e['B'], e['S'], self.feature_dim
@@ -252,8 +256,9 @@ class SequenceCNN(nn.Module):
                  causal: bool = False, num_dilations: int = 6, kernel_size: int = 7) -> None:
         super().__init__()
         _check_activation(activation)
-        if causal or norm != 'layer':
-            raise NotImplementedError("SequenceCNN kernels cover the production config (norm='layer', causal=False)")
+        if norm != 'layer':
+            raise NotImplementedError("SequenceCNN kernels cover the production config (norm='layer')")
+        self.causal = causal
         self.dropout_p = dropout
         self.num_layers = num_layers
         self.num_dilations = num_dilations
@@ -266,7 +271,7 @@ class SequenceCNN(nn.Module):
         """models/wav2sleep.py:379-390, inference only: [B, S, F] -> [B, S, F]."""
         B, S, F = x_BSF.shape
         spec = EngineSpec(signal_map={'ECG': 'ECG'}, feature_dim=F, seq_blocks=self.num_layers, seq_dilations=self.num_dilations,
-                          seq_kernel=self.kernel_size, seq_dropout=self.dropout_p)
+                          seq_kernel=self.kernel_size, seq_dropout=self.dropout_p, seq_causal=self.causal)
         eng, ver = _standalone_engine(self, 'sequence_mixer.', spec)
         from . import lib
         eng.ensure_packed(ver, need_bwd=False)
@@ -343,13 +348,13 @@ class Wav2Sleep(nn.Module):
         return {
             '_target_': t + 'Wav2Sleep', 'num_classes': self.num_classes,
             'signal_encoders': {'_target_': t + 'SignalEncoders', 'signal_map': dict(se.signal_map), 'feature_dim': se.feature_dim,
-                                'activation': 'gelu', 'norm': 'instance', 'causal': False, 'chunk_causal': False,
+                                'activation': 'gelu', 'norm': 'instance', 'causal': bool(se.causal), 'chunk_causal': False,
                                 'initial_channels': se.initial_channels, 'max_channels': se.max_channels, 'output_norm': False,
                                 'use_residual': True},
             'epoch_mixer': {'_target_': t + 'MultiModalAttentionEmbedder', 'feature_dim': em.feature_dim, 'dropout': em.dropout_p,
                             'activation': 'gelu', 'layers': em.num_layers, 'dim_ff': em.dim_ff, 'nhead': em.nhead},
             'sequence_mixer': {'_target_': t + 'SequenceCNN', 'feature_dim': self.feature_dim, 'dropout': sm.dropout_p, 'activation': 'gelu',
-                               'norm': 'layer', 'causal': False, 'num_layers': sm.num_layers, 'kernel_size': sm.kernel_size,
+                               'norm': 'layer', 'causal': bool(sm.causal), 'num_layers': sm.num_layers, 'kernel_size': sm.kernel_size,
                                'num_dilations': sm.num_dilations},
         }
 
@@ -391,7 +396,8 @@ class Wav2Sleep(nn.Module):
         return EngineSpec(signal_map=dict(se.signal_map), feature_dim=self.feature_dim, num_classes=self.num_classes,
                           initial_channels=se.initial_channels, max_channels=se.max_channels, mixer_layers=em.num_layers,
                           mixer_nhead=em.nhead, mixer_dim_ff=em.dim_ff, mixer_dropout=em.dropout_p, seq_blocks=sm.num_layers,
-                          seq_dilations=sm.num_dilations, seq_kernel=sm.kernel_size, seq_dropout=sm.dropout_p)
+                          seq_dilations=sm.num_dilations, seq_kernel=sm.kernel_size, seq_dropout=sm.dropout_p, causal=se.causal,
+                          seq_causal=sm.causal)
 
     def param_version(self) -> int:
         """Changes whenever any parameter was written (torch in-place ops bump `_version`; the fused AdamW kernel
