@@ -49,6 +49,7 @@ class ModelConfig:
     seq_kernel: int = 7
     instance_eps: float = 1e-2  # models/wav2sleep.py:213-215
     causal: bool = False  # scripts/config/main.yaml:22 `causal` (with model yaml `chunk_causal: False`): causal-padded convolutions
+    chunk_causal: bool = False  # SignalEncoders(chunk_causal=...): with causal=True the encoders see one 30-s epoch at a time instead
     layer_eps: float = 1e-5  # nn.LayerNorm default / models/utils.py:12
 
     def encoder_channels(self, signal: str) -> list[int]:
@@ -197,12 +198,20 @@ def signal_encoder(sd: dict, cfg: ModelConfig, enc: str, sig: str, x_BT: Tensor,
     if x_BT.size(-1) % spe:
         raise ValueError(f'Input length {x_BT.size(-1)} must be divisible by samples_per_epoch={spe}.')
     B = x_BT.size(0)
-    y = x_BT.unsqueeze(1)
+    S = x_BT.size(-1) // spe
     nb = len(cfg.encoder_channels(sig))
-    for i in range(nb):
-        y = conv_block(sd, f'signal_encoders.encoders.{enc}.cnn.{i}.', y, cfg.instance_eps, taps, cfg.causal)
-    epoch_dim = y.size(1) * 4
-    y = y.transpose(-1, -2).reshape(B, -1, epoch_dim)
+    if cfg.causal and cfg.chunk_causal:
+        # quasi-causal: every epoch is encoded on its own with the ordinary (symmetric) padding -- models/wav2sleep.py:204,248-255
+        y = x_BT.reshape(B * S, 1, spe)
+        for i in range(nb):
+            y = conv_block(sd, f'signal_encoders.encoders.{enc}.cnn.{i}.', y, cfg.instance_eps, taps, False)
+        y = y.transpose(-1, -2).reshape(B, S, y.size(1) * 4)
+    else:
+        y = x_BT.unsqueeze(1)
+        for i in range(nb):
+            y = conv_block(sd, f'signal_encoders.encoders.{enc}.cnn.{i}.', y, cfg.instance_eps, taps, cfg.causal)
+        epoch_dim = y.size(1) * 4
+        y = y.transpose(-1, -2).reshape(B, -1, epoch_dim)
     y = F.linear(y, sd[f'signal_encoders.encoders.{enc}.linear.weight'], sd[f'signal_encoders.encoders.{enc}.linear.bias'])
     return gelu(y)
 

@@ -52,7 +52,7 @@ def checksum(d: dict) -> float:
 
 def build_reference(cfg: O.ModelConfig) -> Wav2Sleep:
     enc = SignalEncoders(signal_map=dict(cfg.signal_map), feature_dim=cfg.feature_dim, activation='gelu', norm='instance',
-                         causal=cfg.causal, chunk_causal=False, initial_channels=cfg.initial_channels,
+                         causal=cfg.causal, chunk_causal=cfg.chunk_causal, initial_channels=cfg.initial_channels,
                          max_channels=cfg.max_channels, output_norm=False, use_residual=True)
     mix = MultiModalAttentionEmbedder(feature_dim=cfg.feature_dim, dropout=0.0, activation='gelu', layers=cfg.mixer_layers,
                                       dim_ff=cfg.mixer_dim_ff, nhead=cfg.mixer_nhead)
@@ -69,13 +69,16 @@ CASES = {
     'c5_shared_enc': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [0]}, 15, 105),
     # `causal: True` of scripts/config/main.yaml:22 with the model yaml's `chunk_causal: False`: causal-padded convolutions
     'c6_causal': ({'ABD': 'ABD', 'ECG': 'ECG'}, 4, 2, 8, {'ABD': [1]}, 16, 106),
+    # SignalEncoders' own default for causal models: chunk_causal=True (per-epoch encoding, wav2sleep.py:248-255)
+    'c7_chunk_causal': ({'THX': 'THX', 'PPG': 'PPG'}, 4, 2, 6, {'THX': [0]}, 17, 107),
 }
-CAUSAL_CASES = {'c6_causal'}
+CAUSAL_CASES = {'c6_causal', 'c7_chunk_causal'}
+CHUNK_CASES = {'c7_chunk_causal'}
 
 
 def run_case(name: str):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES)
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES, chunk_causal=name in CHUNK_CASES)
     sd = O.make_state_dict(cfg, seed=wseed)
     x, y = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
     model = build_reference(cfg)

@@ -13,8 +13,17 @@ CASES = {
     'c4_eog_pair': ({'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 4, {'EOG-R': [0]}, 14, 104),
     'c5_shared_enc': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [0]}, 15, 105),
     'c6_causal': ({'ABD': 'ABD', 'ECG': 'ECG'}, 4, 2, 8, {'ABD': [1]}, 16, 106),
+    'c7_chunk_causal': ({'THX': 'THX', 'PPG': 'PPG'}, 4, 2, 6, {'THX': [0]}, 17, 107),
 }
-CAUSAL_CASES = {'c6_causal'}  # `causal: True` (scripts/config/main.yaml:22) with `chunk_causal: False` (model/wav2sleep.yaml:11)
+CAUSAL_CASES = {'c6_causal', 'c7_chunk_causal'}  # `causal: True` (scripts/config/main.yaml:22)
+CHUNK_CASES = {'c7_chunk_causal'}  # chunk_causal=True (SignalEncoders' default) instead of the model yaml's `chunk_causal: False`
+
+
+def case_config(name: str):
+    """oracle ModelConfig of a golden case."""
+    from oracle import wav2sleep_oracle as O
+    signal_map, nc = CASES[name][:2]
+    return O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES, chunk_causal=name in CHUNK_CASES)
 
 
 def summarize(t: torch.Tensor, k: int = 64) -> np.ndarray:

@@ -8,12 +8,12 @@ import pytest
 import torch
 
 from oracle import wav2sleep_oracle as O
-from tests.golden_util import CASES, CAUSAL_CASES, assert_summary_close, checksum, load
+from tests.golden_util import CASES, assert_summary_close, case_config, checksum, load
 
 
 def _setup(name):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES)
+    cfg = case_config(name)
     sd = O.make_state_dict(cfg, seed=wseed)
     x, y = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
     return cfg, sd, x, y, (B, S, missing, iseed)
@@ -45,7 +45,7 @@ def test_forward_matches_reference(name):
         np.testing.assert_allclose(got[fin], want[fin], rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize('name', ['c1_ecg_only', 'c2_four_mod', 'c4_eog_pair', 'c6_causal'])
+@pytest.mark.parametrize('name', ['c1_ecg_only', 'c2_four_mod', 'c4_eog_pair', 'c6_causal', 'c7_chunk_causal'])
 def test_block_taps_match_reference(name):
     g = load(name)
     cfg, sd, x, y, _ = _setup(name)

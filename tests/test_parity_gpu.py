@@ -19,14 +19,14 @@ pytestmark = pytest.mark.gpu
 
 import wav2sleep_amd as W  # noqa: E402
 from oracle import wav2sleep_oracle as O  # noqa: E402  (checker only)
-from tests.golden_util import CASES, CAUSAL_CASES, assert_summary_close, load  # noqa: E402
+from tests.golden_util import CASES, assert_summary_close, case_config, load  # noqa: E402
 
 DEV = 'cuda'
 SM4 = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
 
 
-def build(signal_map, nc, dropout=0.0, causal=False):
-    return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', causal=causal, chunk_causal=False),
+def build(signal_map, nc, dropout=0.0, causal=False, chunk_causal=False):
+    return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', causal=causal, chunk_causal=chunk_causal),
                        W.MultiModalAttentionEmbedder(128, layers=2, dropout=dropout, dim_ff=512, nhead=8),
                        W.SequenceCNN(128, dropout=dropout, norm='layer', causal=causal, num_layers=2, kernel_size=7, num_dilations=6), nc)
 
@@ -56,8 +56,8 @@ def test_kernels_against_cpu_torch(stage):
 def test_forward_matches_reference_goldens(name):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
     g = load(name)
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES)
-    model = build(signal_map, nc, causal=cfg.causal)
+    cfg = case_config(name)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).eval()
     x, y = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
@@ -74,8 +74,8 @@ def test_train_steps_match_reference_goldens(name):
     """fwd + CE(ignore -1) + bwd + clip 1.0 + AdamW + ExpWarmUp, two steps, vs the reference's Lightning recipe."""
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
     g = load(name)
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES)
-    model = build(signal_map, nc, causal=cfg.causal)
+    cfg = case_config(name)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).train()
     tr = W.FusedTrainStep(model)
@@ -107,13 +107,15 @@ def test_train_steps_match_reference_goldens(name):
     ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 5, None, False),       # shared encoder, odd S (partial tiles)
     (SM4, 4, 2, 40, {'THX': [1]}, True),                                        # `causal: True`: causal-padded convolutions
     ({'EOG-L': 'EOG-L', 'ECG': 'UNI'}, 5, 2, 7, None, True),                    # causal, 10-block encoder, odd S
+    (SM4, 4, 2, 20, {'PPG': [0]}, 'chunk'),                                     # causal, chunk_causal=True: per-epoch encoders
+    ({'EOG-R': 'EOG-R', 'ABD': 'ABD'}, 5, 3, 5, None, 'chunk'),
 ])
 def test_autograd_path_matches_oracle(signal_map, nc, B, S, missing, causal):
     """nn.Module surface: logits = model(x); torch CE; loss.backward() fills p.grad like the reference's autograd."""
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=causal)
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=bool(causal), chunk_causal=causal == 'chunk')
     sd = O.make_state_dict(cfg, seed=7)
     x, y = O.make_inputs(cfg, B, S, seed=8, missing=missing)
-    model = build(signal_map, nc, causal=causal)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal)
     model.load_state_dict(sd)
     model.to(DEV).train()
     logits = model(to_dev(x))
@@ -132,6 +134,27 @@ def test_autograd_path_matches_oracle(signal_map, nc, B, S, missing, causal):
     F.cross_entropy(logits.view(-1, nc), y.to(DEV).view(-1).long(), ignore_index=-1).backward()
     for k, p in model.named_parameters():
         assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_chunk_causal_model_ignores_the_future():
+    """tests/model/test_causality.py of the reference, on the GELU / instance-norm / layer-norm modules this build has kernels for:
+    with per-epoch encoders and a causal sequence mixer the logits of a prefix do not depend on what follows (the reference runs it
+    at 20 h of ECG+PPG with batch norm in eval mode; 40 epochs already cross every receptive field boundary that matters here... the
+    causal mixer looks back 2*6*63 = 756 epochs, so S=40 vs S=20 exercises it fully)."""
+    sm = {'ECG': 'ECG', 'PPG': 'PPG'}
+    cfg = O.ModelConfig(signal_map=sm, num_classes=4, causal=True, chunk_causal=True)
+    model = build(sm, 4, causal=True, chunk_causal=True)
+    model.load_state_dict(O.make_state_dict(cfg, seed=5))
+    model.to(DEV).eval()
+    torch.manual_seed(1)
+    x = torch.randn(1, 40 * 1024, device=DEV)
+    x2 = x[:, :20 * 1024].contiguous()
+    with torch.no_grad():
+        y = model({'ECG': x, 'PPG': x})
+        y2 = model({'ECG': x2, 'PPG': x2})
+    assert y2.shape[1] == 20
+    assert torch.allclose(y[:, :20], y2, rtol=1e-5, atol=1e-6)   # the reference asserts torch.allclose with default tolerances
+    assert torch.equal(y[:, :20], y2)                            # here it is bit-exact: fixed-order reductions, per-epoch statistics
 
 
 def test_causal_sequence_mixer_ignores_the_future():

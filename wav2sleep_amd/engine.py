@@ -42,6 +42,7 @@ class EngineSpec:
     instance_eps: float = 1e-2
     layer_eps: float = 1e-5
     causal: bool = False       # encoders: causal-padded convolutions (blocks.py:150-152,178-182; `chunk_causal: False`)
+    chunk_causal: bool = False  # with causal: encode every 30-s epoch on its own ([B*S, 1, spe], wav2sleep.py:248-255), symmetric padding
     seq_causal: bool = False   # SequenceCNN: causal dilated convolutions (wav2sleep.py:355, blocks.py:150-152)
     enc_sig: dict = field(default_factory=dict)  # encoder name -> first signal that created it
 
@@ -95,7 +96,8 @@ class Engine:
         # causal padding (scripts/config/main.yaml:22 `causal`): out[j] reads x[j*stride - (k-1-tap)*dil], zeros before the start.  Same
         # kernels, different pad: forward pad (k-1)*dil, data-gradient (flipped taps) pad 0.  The <= 32-channel fused kernels and
         # the first-layer recompute are written for the symmetric padding, so the causal model runs on the generic kernels.
-        self.causal = bool(spec.causal)
+        self.chunk = bool(spec.causal and spec.chunk_causal)
+        self.causal = bool(spec.causal) and not self.chunk   # = `_causal_conv_mode`, wav2sleep.py:204
         self.seq_causal = bool(spec.seq_causal)
         self.kpad = 2 if self.causal else 1
         if self.causal:
@@ -311,6 +313,12 @@ class Engine:
             raise ValueError(f'Input length {T} must be divisible by samples_per_epoch={spe}.')
         S = T // spe
         dev = x.device
+        Bfull = B
+        if self.chunk:   # every epoch is its own sample for the conv stack; the [B*S, 4, C] result IS the [B, 4S, C] map the dense layer reads
+            if B * S > 65535:
+                raise ValueError(f'chunk-causal encoding launches one grid row per epoch: batch*epochs = {B * S} exceeds 65535')
+            x = x.contiguous().view(B * S, spe)
+            B, T = B * S, spe
         pfx = f'signal_encoders.encoders.{enc}.'
         blocks = []
         # ---- block 0 (Cin = 1)
@@ -360,13 +368,13 @@ class Engine:
             pin, cin, L = pre, c, L // 2
         # ---- time-distributed dense + GELU (wav2sleep.py:261-265): taps=4/stride=4 over the [B,4S,C] map
         F = sp.feature_dim
-        zpre = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-        self._conv(x=pin, w=P[pfx + 'linear.weight'], y=zpre, B=B, L_in=4 * S, L_out=S, cin=cin, cout=F, taps=4, stride=4, pad=0,
+        zpre = torch.empty(Bfull, S, F, device=dev, dtype=torch.float32)
+        self._conv(x=pin, w=P[pfx + 'linear.weight'], y=zpre, B=Bfull, L_in=4 * S, L_out=S, cin=cin, cout=F, taps=4, stride=4, pad=0,
                    mode=lib.MODE_DILATED, pro=lib.PRO_GELU, epi=lib.EPI_BIAS, bias=P[pfx + 'linear.bias'], rowkeep=keep,
                    y2=tok_slice, ldy2=ldtok)
         if self.taps is not None:
             self.taps[f'{sig}.zpre'] = zpre
-        return dict(sig=sig, enc=enc, x=x, keep=keep, blocks=blocks, plast=pin, zpre=zpre, S=S, B=B) if save else None
+        return dict(sig=sig, enc=enc, x=x, keep=keep, blocks=blocks, plast=pin, zpre=zpre, S=S, B=Bfull, Bc=B) if save else None
 
     # ------------------------------------------------------------------ full forward
     def encode(self, x: dict[str, torch.Tensor], save: bool = False, pack_key=None, cls: bool = True):
@@ -669,6 +677,7 @@ class Engine:
         gpre = torch.empty(B, 2 * 2 * S, cl, device=dev, dtype=torch.float32)
         self._conv(x=gz, w=PB[pfx + 'linear.weight'], y=gpre, B=1, L_in=B * S, L_out=B * S, cin=F, cout=4 * cl, taps=1, stride=1, pad=0,
                    epi=lib.EPI_GP, aux=ec['plast'], ld_aux=4 * cl)
+        B = ec['Bc']   # chunk-causal: the conv stack ran on B*S one-epoch samples; gpre [B, 4S, C] is its [B*S, 4, C] gradient
         bs3_folded = None   # conv3 backward statistics of block i produced by block i+1's fused conv1 kernel (no gp_stats pre-pass)
         for i in reversed(range(len(ch))):
             blk = ec['blocks'][i]

@@ -123,9 +123,6 @@ class SignalEncoder(nn.Module):
         _check_activation(activation)
         if output_norm or norm != 'instance':
             raise NotImplementedError('output_norm / non-instance encoder norms have no gfx950 kernels yet')
-        if causal and chunk_causal:
-            raise NotImplementedError('chunk_causal=True (per-epoch [B*S, 1, spe] encoding, wav2sleep.py:248-255) has no gfx950 kernels yet; '
-                                      'the shipped model config uses chunk_causal: False (causal convolutions)')
         self.feature_dim = feature_dim
         self.samples_per_epoch = samples_per_epoch
         self.causal = causal
@@ -159,6 +156,7 @@ class SignalEncoders(nn.Module):
         self.feature_dim = feature_dim
         self.signal_map = dict(signal_map)
         self.causal = causal
+        self.chunk_causal = chunk_causal
         self.initial_channels = initial_channels
         self.max_channels = max_channels
         encoders = {}
@@ -187,7 +185,7 @@ class SignalEncoders(nn.Module):
         """models/wav2sleep.py:146-161, inference only (training goes through Wav2Sleep.forward, one fused autograd node):
         dict signal -> [B, T]  ->  dict signal -> [B, S, feature_dim]; samples whose input row is -inf come back as -inf."""
         spec = EngineSpec(signal_map=dict(self.signal_map), feature_dim=self.feature_dim, initial_channels=self.initial_channels,
-                          max_channels=self.max_channels, causal=self.causal)
+                          max_channels=self.max_channels, causal=self.causal, chunk_causal=self.chunk_causal)
         eng, ver = _standalone_engine(self, 'signal_encoders.', spec)
         e = eng.encode(x, save=False, pack_key=ver, cls=False)
         B, S, F = e['B'], e['S'], self.feature_dim
@@ -348,7 +346,7 @@ class Wav2Sleep(nn.Module):
         return {
             '_target_': t + 'Wav2Sleep', 'num_classes': self.num_classes,
             'signal_encoders': {'_target_': t + 'SignalEncoders', 'signal_map': dict(se.signal_map), 'feature_dim': se.feature_dim,
-                                'activation': 'gelu', 'norm': 'instance', 'causal': bool(se.causal), 'chunk_causal': False,
+                                'activation': 'gelu', 'norm': 'instance', 'causal': bool(se.causal), 'chunk_causal': bool(se.chunk_causal),
                                 'initial_channels': se.initial_channels, 'max_channels': se.max_channels, 'output_norm': False,
                                 'use_residual': True},
             'epoch_mixer': {'_target_': t + 'MultiModalAttentionEmbedder', 'feature_dim': em.feature_dim, 'dropout': em.dropout_p,
@@ -397,7 +395,7 @@ class Wav2Sleep(nn.Module):
                           initial_channels=se.initial_channels, max_channels=se.max_channels, mixer_layers=em.num_layers,
                           mixer_nhead=em.nhead, mixer_dim_ff=em.dim_ff, mixer_dropout=em.dropout_p, seq_blocks=sm.num_layers,
                           seq_dilations=sm.num_dilations, seq_kernel=sm.kernel_size, seq_dropout=sm.dropout_p, causal=se.causal,
-                          seq_causal=sm.causal)
+                          chunk_causal=se.chunk_causal, seq_causal=sm.causal)
 
     def param_version(self) -> int:
         """Changes whenever any parameter was written (torch in-place ops bump `_version`; the fused AdamW kernel
