@@ -384,9 +384,13 @@ static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode
   c.wn = (c.nt >= 4) ? 2 : 1;
   c.mt = 4;
   if ((size_t)window_rows(16 * c.mt * (4 / c.wn), taps, stride, mode, dil) * (cin + 4) * 4 > 72 * 1024) c.mt = 2;
-  if (c.nt >= 8) c.mt = 2;  // 128-wide tiles: 64 positions (four workgroups per CU) beat 128 now that a weight fragment is one 1 KB fetch
+  // 128-wide tiles: 64 positions (four workgroups per CU) beat 128 now that a weight fragment is one 1 KB fetch, as a 1 x 4 wave grid:
+  // every wave owns 32 output channels for all 64 positions, so each weight fragment is fetched ONCE per workgroup (the 2 x 2 grid
+  // fetched it from both position halves: the K loop of these layers waits on L2 weight fetches, 12 TB/s aggregate)  -9 ... -14 %
+  if (c.nt >= 8) { c.mt = 4; c.wn = 4; }
+  { static const char* e = getenv("W2S_WN2"); if (e && c.nt >= 8) { c.mt = 2; c.wn = 2; } }  // tuning only: the 2 x 2 grid
+  { static const char* e = getenv("W2S_WN4"); if (e && c.nt >= atoi(e)) { c.wn = 4; c.mt = 4; } }  // tuning only: 1 x 4 wave grid
   { static const char* e = getenv("W2S_FORCE_MT"); if (e && c.nt >= 4) c.mt = atoi(e); }  // tuning only
-  { static const char* e = getenv("W2S_FORCE_MT8"); if (e && c.nt >= 8) c.mt = atoi(e); }  // tuning only
   { static const char* e = getenv("W2S_FORCE_NT"); if (e && c.nt >= 8) c.nt = atoi(e); }  // tuning only
   { static const char* e = getenv("W2S_NO_SHRINK"); if (e) return c; }                    // tuning only
   // short problems (SequenceCNN: 16 x 960 rows): shrink the tile until the grid covers the 256 CUs about twice
@@ -395,8 +399,8 @@ static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode
     return (long)B * ((L_out + tm - 1) / tm) * (cout / (t.nt * 16));
   };
   if (B > 0 && L_out > 0) {
-    if (wgs(c) < 512 && c.mt == 4) c.mt = 2;
-    if (wgs(c) < 512 && c.nt == 8) c.nt = 4;
+    if (wgs(c) < 512 && c.mt == 4 && c.wn != 4) c.mt = 2;
+    if (wgs(c) < 512 && c.nt == 8) { c.nt = 4; if (c.wn == 4) { c.wn = 2; c.mt = 2; } }
   }
   return c;
 }
@@ -434,8 +438,8 @@ static int dispatch_cfg(const w2s_conv_args& a, hipStream_t s) {
   const bool bf = a.w_hi && a.w_lo && ((a.cin >= 32 && c.nt >= 2) || (a.cin == 16 && MODE == W2S_MODE_CONTIG && (TAPS == 1 || TAPS == 3) && a.dil <= 1));
 #define W2S_CFG(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_ && !bf) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_, PRO, EPI, 0>(a, s);
 #define W2S_CFGB(NT_, MT_, WN_) if (c.nt == NT_ && c.mt == MT_ && c.wn == WN_ && bf) return launch_conv<NT_, MT_, TAPS, STRIDE, MODE, WN_, PRO, EPI, 1>(a, s);
-  W2S_CFG(1, 4, 1) W2S_CFG(2, 4, 1) W2S_CFG(2, 2, 1) W2S_CFG(4, 4, 2) W2S_CFG(4, 2, 2) W2S_CFG(8, 4, 2) W2S_CFG(8, 2, 2) W2S_CFG(1, 2, 1)
-  W2S_CFGB(1, 4, 1) W2S_CFGB(1, 2, 1) W2S_CFGB(2, 4, 1) W2S_CFGB(2, 2, 1) W2S_CFGB(4, 4, 2) W2S_CFGB(4, 2, 2) W2S_CFGB(8, 4, 2) W2S_CFGB(8, 2, 2)
+  W2S_CFG(1, 4, 1) W2S_CFG(2, 4, 1) W2S_CFG(2, 2, 1) W2S_CFG(4, 4, 2) W2S_CFG(4, 2, 2) W2S_CFG(8, 4, 2) W2S_CFG(8, 2, 2) W2S_CFG(1, 2, 1) W2S_CFG(8, 4, 4) W2S_CFG(4, 4, 4)
+  W2S_CFGB(1, 4, 1) W2S_CFGB(1, 2, 1) W2S_CFGB(2, 4, 1) W2S_CFGB(2, 2, 1) W2S_CFGB(4, 4, 2) W2S_CFGB(4, 2, 2) W2S_CFGB(8, 4, 2) W2S_CFGB(8, 2, 2) W2S_CFGB(8, 4, 4) W2S_CFGB(4, 4, 4)
 #undef W2S_CFG
 #undef W2S_CFGB
   return W2S_EINVAL;
