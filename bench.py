@@ -64,6 +64,8 @@ def main():
     ap.add_argument('--epochs', type=int, default=960)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--variant', choices=['cardio', 'eog'], default='cardio',
+                    help="'eog': BASELINE.json configs[3] (EOG-L+EOG-R @256 Hz, 5 classes); a parity-test configuration, not the headline line")
     ap.add_argument('--causal', action='store_true', help="the reference's `causal: True` variant (causal-padded convolutions); not the headline config")
     args = ap.parse_args()
 
@@ -84,6 +86,10 @@ def main():
     from wav2sleep_amd import lib
     torch.manual_seed(42)  # scripts/config/main.yaml:35
     nc = 4
+    if args.variant == 'eog':   # wav2sleep-eog (hub.py:17-22)
+        SIGNAL_MAP.clear(); SIGNAL_MAP.update({'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'})
+        SPE.clear(); SPE.update({'EOG-L': 4096, 'EOG-R': 4096})
+        nc = 5
     model = W.Wav2Sleep(W.SignalEncoders(SIGNAL_MAP, 128, 'gelu', norm='instance', causal=args.causal, chunk_causal=False),
                         W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.1, dim_ff=512, nhead=8),
                         W.SequenceCNN(128, dropout=0.1, norm='layer', causal=args.causal, num_layers=2, kernel_size=7, num_dilations=6), nc).to(dev).train()
@@ -114,7 +120,7 @@ def main():
     line = {'metric': 'overnight-recordings/sec (train step, bs=16)', 'value': round(args.batch * world * args.steps / dt, 3), 'unit': 'recordings/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'4-modality (ABD+THX+ECG+PPG) {args.epochs}-epoch ({args.epochs // 120} h) synthetic, 4-class, per-GPU batch {args.batch}, '
+            'config': {'workload': f'{len(SIGNAL_MAP)}-modality ({"+".join(SIGNAL_MAP)}) {args.epochs}-epoch ({args.epochs // 120} h) synthetic, {nc}-class, per-GPU batch {args.batch}, '
                                    f'full train step fwd+CE+bwd+clip+AdamW' + (', causal convolutions (causal: True)' if args.causal else ''), 'global_batch': args.batch * world, 'epochs': args.epochs,
                        'parallelism': f'dp{world}', 'final_loss': round(loss, 5),
                        'precision': "fp32 storage + fp32 accumulate; >=32-channel GEMMs as bf16x3 split products on the matrix cores "
@@ -147,14 +153,14 @@ def main():
         traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
         for fn in sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1:]:
             t = json.load(open(fn)).get(key)
-            if t and args.batch == 16 and args.epochs == 960:
+            if t and args.batch == 16 and args.epochs == 960 and args.variant == 'cardio' and not args.causal:
                 traffic = int(t['hbm_bytes_per_launch'])
         roof.update({'traffic': traffic, 'kernel': key, 'measured': 'HIP events, one extra single-stream step', 'launches_per_step': d['launches'], 'avg_us': round(avg_s * 1e6, 1),
                      'share_of_gemm_kernel_time': round(d['ms'] / total_ms, 3), 'algorithmic_bytes_per_launch': int(b_per),
                      'flops_per_launch': int(f_per)})
         # whole-step view against the SURVEY 8d convention (3x forward algorithmic bytes, fp32 storage)
-        elems_fwd = {'ABD': 62.2e6, 'THX': 62.2e6, 'ECG': 266.4e6, 'PPG': 266.4e6}
-        step_bytes = 3 * 4 * sum(elems_fwd.values()) * (args.epochs / 960) * args.batch
+        elems_fwd = {'ABD': 62.2e6, 'THX': 62.2e6, 'ECG': 266.4e6, 'PPG': 266.4e6, 'EOG-L': 1083.3e6, 'EOG-R': 1083.3e6}
+        step_bytes = 3 * 4 * sum(elems_fwd[s] for s in SIGNAL_MAP) * (args.epochs / 960) * args.batch
         roof['step_algorithmic_GBps'] = round(step_bytes / (dt / args.steps) / 1e9, 1)
         roof['step_frac_of_hbm_peak'] = round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
         line['roofline'] = roof
