@@ -1,5 +1,5 @@
 """Progressive GPU check of libw2s_hip.so against CPU torch / the oracle.  Prints a table; never stops early.
-Run on the GPU box:  python tools/gpu_check.py [stage ...]"""
+Run on the GPU box:  python tests/gpu_check.py [stage ...]"""
 import os, sys, math, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -43,8 +43,8 @@ def to_dev(x):
 
 @pytest.mark.parametrize('stage', ['conv', 'split', 'fin', 'fwdfused', 'fusedbf', 'fold', 'first', 'batch', 'stats', 'dil', 'dgrad', 'wgrad', 'rowops', 'attn', 'head'])
 def test_kernels_against_cpu_torch(stage):
-    """Every C-ABI kernel family against the stock CPU op it replaces (tools/gpu_check.py)."""
-    from tools import gpu_check as G
+    """Every C-ABI kernel family against the stock CPU op it replaces (tests/gpu_check.py)."""
+    from tests import gpu_check as G
     G.RES.clear()
     G.STAGES[stage]()
     torch.cuda.synchronize()
