@@ -145,6 +145,62 @@ def t_wgrad():
             lib.wgrad_reduce(slab, nslab, gw, cout, cin, taps, dil)
             report(f'wgrad bf16x3 {cin}->{cout} k{taps} s{stride} d{dil}', gw, w.grad, tol=3e-4)
 
+def t_causal():
+    """Causal padding (blocks.py:150-152,178-182) through the C-ABI: forward pad (k-1)*dil, flipped-tap data gradient pad 0, the
+    transposed stride-2 kernel with pad 2, weight gradient pad (k-1)*dil, and the Cin = 1 first layer with its `causal` shift."""
+    B = 2
+    for (cin, cout, taps, stride, dil, L) in [(16, 16, 3, 1, 1, 700), (32, 32, 3, 2, 1, 600), (64, 64, 3, 1, 1, 300), (128, 128, 3, 2, 1, 256),
+                                              (64, 64, 3, 2, 1, 258), (128, 128, 7, 1, 1, 200), (128, 128, 7, 1, 8, 200), (128, 128, 7, 1, 32, 300)]:
+        x = torch.randn(B, cin, L, requires_grad=True); w = (torch.randn(cout, cin, taps) / math.sqrt(cin * taps)).requires_grad_(True)
+        y = O.causal_conv1d(x, w, stride, dil)
+        gy = torch.randn_like(y); y.backward(gy)
+        Lo, pad = y.shape[-1], (taps - 1) * dil
+        mode = lib.MODE_DILATED if taps == 7 else lib.MODE_CONTIG
+        yd = torch.zeros(B, Lo, cout, device=dev)
+        lib.conv_forward(lib.conv_args(x=cl(x.detach()).to(dev), w=pack_fwd(w.detach()).to(dev), y=yd, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps,
+                                       stride=stride, pad=pad, dil=dil, mode=mode))
+        report(f'causal conv {cin}->{cout} k{taps} s{stride} d{dil}', yd, cl(y))
+        wb = w.detach().permute(1, 2, 0).contiguous().to(dev)
+        gx = torch.zeros(B, L, cin, device=dev)
+        if stride == 1:
+            a = lib.conv_args(x=cl(gy).to(dev), w=wb, y=gx, B=B, L_in=Lo, L_out=L, cin=cout, cout=cin, taps=taps, stride=1, pad=0, dil=dil, flip=1, mode=mode)
+        else:
+            a = lib.conv_args(x=cl(gy).to(dev), w=wb, y=gx, B=B, L_in=Lo, L_out=L, cin=cout, cout=cin, taps=3, stride=2, pad=2, mode=lib.MODE_UP2)
+        lib.conv_forward(a)
+        report(f'causal dgrad {cin}->{cout} k{taps} s{stride} d{dil}', gx, cl(x.grad))
+        nslab = 8 * lib.wgrad_slabs_per_block(cin, cout, taps, dil)
+        slab = torch.zeros(nslab * cout * cin * taps, device=dev)
+        lib.wgrad(g=cl(gy).to(dev), x=cl(x.detach()).to(dev), slab=slab, nslab=nslab, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
+                  pad=pad, dil=dil)
+        gw = torch.zeros(cout, cin, taps, device=dev)
+        lib.wgrad_reduce(slab, nslab, gw, cout, cin, taps, dil)
+        report(f'causal wgrad {cin}->{cout} k{taps} s{stride} d{dil}', gw, w.grad, tol=3e-4)
+    # first layer (Cin = 1): values + statistics partials, and its weight gradients
+    L, c, tile = 3000, 16, 1024
+    x = torch.randn(B, L); x[1, 100:130] = float('inf')
+    xs = torch.where(torch.isinf(x), 0.0, x)
+    w1 = (torch.randn(c, 1, 3) / 2).requires_grad_(True)
+    y1 = O.causal_conv1d(xs[:, None, :], w1)
+    nt = (L + tile - 1) // tile
+    yd = torch.zeros(B, L, c, device=dev); part = torch.zeros(B, nt, 2, c, device=dev)
+    lib.enc_first_fwd(x.to(dev), w1.detach().to(dev), yd, part, B, L, c, tile, causal=True)
+    report('causal first layer values', yd, cl(y1))
+    report('causal first layer sum', part[:, :, 0].sum(1), y1.sum(2), tol=1e-4)
+    report('causal first layer sumsq', part[:, :, 1].sum(1), (y1 * y1).sum(2), tol=1e-4)
+    mean = y1.detach().mean(2); rstd = 1 / torch.sqrt(y1.detach().var(2, unbiased=False) + 1e-2)
+    n = (y1 - mean[:, :, None].detach()) * rstd[:, :, None].detach()   # gy1 = rstd * (g - q1 - n q2): the instance-norm backward with given sums
+    g = torch.randn(B, c, L); q1 = torch.randn(B, c) * 0.01; q2 = torch.randn(B, c) * 0.01
+    gy1 = rstd[:, :, None] * (g - q1[:, :, None] - n.detach() * q2[:, :, None])
+    (y1 * gy1).sum().backward()
+    gpre = torch.randn(B, c, L // 2)
+    want_d = torch.einsum('bou,bu->o', gpre, xs[:, 0::2])
+    slab = torch.zeros(8, 64, device=dev)
+    lib.enc_first_bwd(x.to(dev), cl(g).to(dev), yd, torch.stack([mean, rstd], -1).to(dev), torch.stack([q1, q2], -1).to(dev), cl(gpre).to(dev), slab, 8, B, L, c,
+                      causal=True)
+    tot = slab.sum(0)
+    report('causal first layer dW1', tot[:48].view(c, 3), w1.grad.view(c, 3), tol=3e-4)
+    report('causal first layer dWd', tot[48:], want_d, tol=3e-4)
+
 def t_rowops():
     rows, C = 1000, 128
     x = torch.randn(rows, C, requires_grad=True); g = torch.randn(C) + 1; b = torch.randn(C)
@@ -503,7 +559,7 @@ def t_inkernel_finalize():
     report('in-kernel finalize gp_stats', so, ref, tol=1e-6)
 
 
-STAGES = dict(fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))
