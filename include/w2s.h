@@ -209,6 +209,10 @@ int w2s_colsum_batch(const w2s_colsum_job* jobs, int njobs, void* stream); /* ou
 /* out[row][c] = g[row*ldg+c] * GELU'(pre[row][c]) * keep[row/rows_per_sample]  (encoder-output GELU backward) */
 int w2s_gelu_bwd_rows(const float* g, int ldg, const float* pre, const float* keep, int rows_per_sample, float* out, int rows, int C, void* stream);
 int w2s_fill_rows(float* dst, int ld, const float* src, int rows, int C, void* stream);             /* CLS rows, wav2sleep.py:330 */
+/* dst[row][c] (+)= keep[row / rows_per_sample] * src[c * src_stride] (keep may be NULL): register tokens r > 0 of the [1,1,F,R+1]
+ * parameter (wav2sleep.py:299,330) and the signal-source embedding nn.Embedding row added to an encoder's output (wav2sleep.py:155-159) */
+int w2s_add_rows(float* dst, int ld, const float* src, int src_stride, const float* keep, int rows_per_sample, int rows, int C, int accumulate,
+                 void* stream);
 
 /* elementwise on n floats (n % 4 == 0).  Dropout masks are a pure function of (seed, element index). */
 #define W2S_ELT_GELU 0          /* y = GELU(a) */

@@ -49,6 +49,8 @@ class ModelConfig:
     seq_kernel: int = 7
     instance_eps: float = 1e-2  # models/wav2sleep.py:213-215
     causal: bool = False  # scripts/config/main.yaml:22 `causal` (with model yaml `chunk_causal: False`): causal-padded convolutions
+    embed_signals: bool = False  # SignalEncoders(embed_signals=...): nn.Embedding row per signal added to its encoder output
+    register_tokens: int = 0  # MultiModalAttentionEmbedder(register_tokens=R): R learnable tokens next to the CLS token
     chunk_causal: bool = False  # SignalEncoders(chunk_causal=...): with causal=True the encoders see one 30-s epoch at a time instead
     layer_eps: float = 1e-5  # nn.LayerNorm default / models/utils.py:12
 
@@ -96,7 +98,9 @@ def param_shapes(cfg: ModelConfig) -> dict[str, tuple]:
         shapes[p + 'norm1.bias'] = (Fd,)
         shapes[p + 'norm2.weight'] = (Fd,)
         shapes[p + 'norm2.bias'] = (Fd,)
-    shapes['epoch_mixer.register_tokens'] = (1, 1, Fd, 1)
+    shapes['epoch_mixer.register_tokens'] = (1, 1, Fd, cfg.register_tokens + 1)
+    if cfg.embed_signals:
+        shapes['signal_encoders.embedder.weight'] = (len(cfg.signal_map), Fd)  # models/wav2sleep.py:130-131
     for b in range(cfg.seq_blocks):
         for j in range(cfg.seq_dilations):
             p = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.'
@@ -122,7 +126,7 @@ def make_state_dict(cfg: ModelConfig, seed: int = 0, scale: float = 1.0) -> dict
             t = 1.0 + 0.1 * torch.randn(shp, generator=g)
         elif k.endswith('bias'):
             t = 0.05 * torch.randn(shp, generator=g)
-        elif k.endswith('register_tokens'):
+        elif k.endswith('register_tokens') or k.endswith('embedder.weight'):
             t = torch.randn(shp, generator=g)
         else:
             fan_in = int(np.prod(shp[1:]))
@@ -226,6 +230,8 @@ def signal_encoders(sd: dict, cfg: ModelConfig, x: dict[str, Tensor], taps: dict
         x_BT = torch.where(torch.isinf(x_BT), 0.0, x_BT)
         z_BSF = signal_encoder(sd, cfg, cfg.signal_map[sig], sig, x_BT, taps)
         z[sig] = torch.where(mask_B[:, None, None], float('-inf'), z_BSF)
+        if cfg.embed_signals:  # wav2sleep.py:155-159: index = position of the signal among the sorted signal_map keys (:129)
+            z[sig] = z[sig] + sd['signal_encoders.embedder.weight'][sorted(cfg.signal_map).index(sig)][None, None, :]
     return z
 
 
@@ -255,7 +261,7 @@ def encoder_layer(sd: dict, p: str, x_NDF: Tensor, pad_ND: Tensor, nhead: int, e
 
 
 def epoch_mixer(sd: dict, cfg: ModelConfig, z: dict[str, Tensor]) -> Tensor:
-    """MultiModalAttentionEmbedder.forward -- models/wav2sleep.py:301-346 (register_tokens=0)."""
+    """MultiModalAttentionEmbedder.forward -- models/wav2sleep.py:301-346."""
     signals = sorted(z.keys())
     if len(signals) == 0:
         raise ValueError('No signals provided to MultiModalAttentionEmbedder.')
@@ -272,8 +278,9 @@ def epoch_mixer(sd: dict, cfg: ModelConfig, z: dict[str, Tensor]) -> Tensor:
         raise ValueError(f'Feature dimension {Fd} does not match {cfg.feature_dim}.')
     cls = sd['epoch_mixer.register_tokens']
     z_BSFD = torch.cat([cls.repeat(B, S, 1, 1), z_BSFC], dim=-1)
-    D = C + 1
-    m_BD = torch.cat([torch.zeros(B, 1, dtype=torch.bool), m_BC], dim=-1)
+    R1 = cls.size(-1)  # CLS + register tokens, always attendable (wav2sleep.py:334-337)
+    D = C + R1
+    m_BD = torch.cat([torch.zeros(B, R1, dtype=torch.bool), m_BC], dim=-1)
     x = z_BSFD.flatten(0, 1).permute(0, 2, 1)  # [N, D, F]
     pad = m_BD[:, None, :].repeat(1, S, 1).flatten(0, 1)  # [N, D]
     for l in range(cfg.mixer_layers):

@@ -52,10 +52,10 @@ def checksum(d: dict) -> float:
 
 def build_reference(cfg: O.ModelConfig) -> Wav2Sleep:
     enc = SignalEncoders(signal_map=dict(cfg.signal_map), feature_dim=cfg.feature_dim, activation='gelu', norm='instance',
-                         causal=cfg.causal, chunk_causal=cfg.chunk_causal, initial_channels=cfg.initial_channels,
+                         causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, initial_channels=cfg.initial_channels,
                          max_channels=cfg.max_channels, output_norm=False, use_residual=True)
     mix = MultiModalAttentionEmbedder(feature_dim=cfg.feature_dim, dropout=0.0, activation='gelu', layers=cfg.mixer_layers,
-                                      dim_ff=cfg.mixer_dim_ff, nhead=cfg.mixer_nhead)
+                                      dim_ff=cfg.mixer_dim_ff, nhead=cfg.mixer_nhead, register_tokens=cfg.register_tokens)
     seq = SequenceCNN(feature_dim=cfg.feature_dim, dropout=0.0, activation='gelu', norm='layer', causal=cfg.causal,
                       num_layers=cfg.seq_blocks, kernel_size=cfg.seq_kernel, num_dilations=cfg.seq_dilations)
     return Wav2Sleep(enc, mix, seq, num_classes=cfg.num_classes)
@@ -71,14 +71,17 @@ CASES = {
     'c6_causal': ({'ABD': 'ABD', 'ECG': 'ECG'}, 4, 2, 8, {'ABD': [1]}, 16, 106),
     # SignalEncoders' own default for causal models: chunk_causal=True (per-epoch encoding, wav2sleep.py:248-255)
     'c7_chunk_causal': ({'THX': 'THX', 'PPG': 'PPG'}, 4, 2, 6, {'THX': [0]}, 17, 107),
+    # shared encoder told apart by signal embeddings (embed_signals=True) + two register tokens next to CLS
+    'c8_embed_reg': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [1]}, 18, 108),
 }
 CAUSAL_CASES = {'c6_causal', 'c7_chunk_causal'}
 CHUNK_CASES = {'c7_chunk_causal'}
+EXTRA = {'c8_embed_reg': dict(embed_signals=True, register_tokens=2)}
 
 
 def run_case(name: str):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES, chunk_causal=name in CHUNK_CASES)
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES, chunk_causal=name in CHUNK_CASES, **EXTRA.get(name, {}))
     sd = O.make_state_dict(cfg, seed=wseed)
     x, y = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
     model = build_reference(cfg)

@@ -14,8 +14,10 @@ CASES = {
     'c5_shared_enc': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [0]}, 15, 105),
     'c6_causal': ({'ABD': 'ABD', 'ECG': 'ECG'}, 4, 2, 8, {'ABD': [1]}, 16, 106),
     'c7_chunk_causal': ({'THX': 'THX', 'PPG': 'PPG'}, 4, 2, 6, {'THX': [0]}, 17, 107),
+    'c8_embed_reg': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [1]}, 18, 108),
 }
 CAUSAL_CASES = {'c6_causal', 'c7_chunk_causal'}  # `causal: True` (scripts/config/main.yaml:22)
+EXTRA = {'c8_embed_reg': dict(embed_signals=True, register_tokens=2)}  # SignalEncoders(embed_signals=True), MultiModalAttentionEmbedder(register_tokens=2)
 CHUNK_CASES = {'c7_chunk_causal'}  # chunk_causal=True (SignalEncoders' default) instead of the model yaml's `chunk_causal: False`
 
 
@@ -23,7 +25,7 @@ def case_config(name: str):
     """oracle ModelConfig of a golden case."""
     from oracle import wav2sleep_oracle as O
     signal_map, nc = CASES[name][:2]
-    return O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES, chunk_causal=name in CHUNK_CASES)
+    return O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=name in CAUSAL_CASES, chunk_causal=name in CHUNK_CASES, **EXTRA.get(name, {}))
 
 
 def summarize(t: torch.Tensor, k: int = 64) -> np.ndarray:

@@ -25,9 +25,9 @@ DEV = 'cuda'
 SM4 = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
 
 
-def build(signal_map, nc, dropout=0.0, causal=False, chunk_causal=False):
-    return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', causal=causal, chunk_causal=chunk_causal),
-                       W.MultiModalAttentionEmbedder(128, layers=2, dropout=dropout, dim_ff=512, nhead=8),
+def build(signal_map, nc, dropout=0.0, causal=False, chunk_causal=False, embed_signals=False, register_tokens=0):
+    return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', causal=causal, chunk_causal=chunk_causal, embed_signals=embed_signals),
+                       W.MultiModalAttentionEmbedder(128, layers=2, dropout=dropout, dim_ff=512, nhead=8, register_tokens=register_tokens),
                        W.SequenceCNN(128, dropout=dropout, norm='layer', causal=causal, num_layers=2, kernel_size=7, num_dilations=6), nc)
 
 
@@ -57,7 +57,7 @@ def test_forward_matches_reference_goldens(name):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
     g = load(name)
     cfg = case_config(name)
-    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).eval()
     x, y = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
@@ -75,7 +75,7 @@ def test_train_steps_match_reference_goldens(name):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
     g = load(name)
     cfg = case_config(name)
-    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).train()
     tr = W.FusedTrainStep(model)
@@ -109,13 +109,17 @@ def test_train_steps_match_reference_goldens(name):
     ({'EOG-L': 'EOG-L', 'ECG': 'UNI'}, 5, 2, 7, None, True),                    # causal, 10-block encoder, odd S
     (SM4, 4, 2, 20, {'PPG': [0]}, 'chunk'),                                     # causal, chunk_causal=True: per-epoch encoders
     ({'EOG-R': 'EOG-R', 'ABD': 'ABD'}, 5, 3, 5, None, 'chunk'),
+    (SM4, 4, 2, 12, {'ECG': [0]}, 'embed'),                                     # embed_signals + 2 register tokens: D = 7 tokens
 ])
 def test_autograd_path_matches_oracle(signal_map, nc, B, S, missing, causal):
     """nn.Module surface: logits = model(x); torch CE; loss.backward() fills p.grad like the reference's autograd."""
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=bool(causal), chunk_causal=causal == 'chunk')
+    if causal == 'embed':
+        cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, embed_signals=True, register_tokens=2)
+    else:
+        cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=bool(causal), chunk_causal=causal == 'chunk')
     sd = O.make_state_dict(cfg, seed=7)
     x, y = O.make_inputs(cfg, B, S, seed=8, missing=missing)
-    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens)
     model.load_state_dict(sd)
     model.to(DEV).train()
     logits = model(to_dev(x))
@@ -284,14 +288,14 @@ def test_load_model_and_predict_roundtrip(tmp_path):
     assert W.cohens_kappa(cm.numpy(), 4) == pytest.approx(O.cohens_kappa(cm.numpy(), 4))
 
 
-@pytest.mark.parametrize('name', ['c2_four_mod', 'c4_eog_pair', 'c5_shared_enc'])
+@pytest.mark.parametrize('name', ['c2_four_mod', 'c4_eog_pair', 'c5_shared_enc', 'c6_causal', 'c7_chunk_causal', 'c8_embed_reg'])
 def test_submodule_forwards_match_reference_goldens(name):
     """SignalEncoders / MultiModalAttentionEmbedder / SequenceCNN called on their own, like the reference modules
     (wav2sleep.py:146-161, 301-346, 379-390), against the per-stage outputs recorded from the reference."""
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
     g = load(name)
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc)
-    model = build(signal_map, nc)
+    cfg = case_config(name)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).eval()
     x, _ = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
@@ -370,10 +374,11 @@ def test_device_input_pipeline_matches_oracle():
         assert torch.isinf(sig[k][~m]).all()
 
 
-def test_subset_evaluation_reuses_encoders_exactly():
+@pytest.mark.parametrize('extra', [{}, dict(embed_signals=True, register_tokens=1)])
+def test_subset_evaluation_reuses_encoders_exactly(extra):
     """forward_subsets == separate model({subset}) calls (trainer/main.py:188-224 semantics), bit for bit."""
-    cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
-    model = build(SM4, 4)
+    cfg = O.ModelConfig(signal_map=SM4, num_classes=4, **extra)
+    model = build(SM4, 4, **extra)
     model.load_state_dict(O.make_state_dict(cfg, seed=13))
     model.to(DEV).eval()
     x, y = O.make_inputs(cfg, 3, 6, seed=14, missing={'THX': [1]})

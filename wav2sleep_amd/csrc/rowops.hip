@@ -307,6 +307,30 @@ extern "C" int w2s_fill_rows(float* dst, int ld, const float* src, int rows, int
   return W2S_OK;
 }
 
+// dst[row][c] (+)= keep[row / rows_per_sample] * src[c * src_stride]: register tokens beyond the CLS column of the [1,1,F,R+1]
+// parameter (wav2sleep.py:299,330; accumulate = 0, src_stride = R+1) and the signal-source embedding added to an encoder's
+// output rows (wav2sleep.py:155-159; accumulate = 1; missing samples keep their zero rows)
+__global__ void add_rows_kernel(float* __restrict__ dst, int ld, const float* __restrict__ src, int src_stride, const float* __restrict__ keep,
+                                int rows_per_sample, int rows, int C, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * C) return;
+  const int c = (int)(i % C);
+  const size_t row = i / C;
+  const float k = keep ? keep[row / rows_per_sample] : 1.f;
+  const float v = k * src[(size_t)c * src_stride];
+  float* d = dst + row * ld + c;
+  *d = accumulate ? *d + v : v;
+}
+extern "C" int w2s_add_rows(float* dst, int ld, const float* src, int src_stride, const float* keep, int rows_per_sample, int rows, int C,
+                            int accumulate, void* stream) {
+  if (!dst || !src || rows <= 0 || C <= 0 || src_stride <= 0 || (keep && rows_per_sample <= 0)) return W2S_EINVAL;
+  const size_t n = (size_t)rows * C;
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dst, ld, src, src_stride,
+                     keep, rows_per_sample > 0 ? rows_per_sample : 1, rows, C, accumulate);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
 // out[row][c] = g[row*ldg + c] * GELU'(pre[row][c]) * keep[row / rows_per_sample]   (encoder output GELU backward,
 // reading the modality's column block of the token-gradient tensor; wav2sleep.py:154,265)
 __global__ __launch_bounds__(256) void gelu_bwd_rows_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ pre,

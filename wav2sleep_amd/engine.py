@@ -42,6 +42,8 @@ class EngineSpec:
     instance_eps: float = 1e-2
     layer_eps: float = 1e-5
     causal: bool = False       # encoders: causal-padded convolutions (blocks.py:150-152,178-182; `chunk_causal: False`)
+    embed_signals: bool = False  # nn.Embedding row per signal added to its encoder output (wav2sleep.py:127-133,155-159)
+    register_tokens: int = 0    # R learnable tokens next to CLS (wav2sleep.py:299,330): D = R + 1 + C tokens per epoch
     chunk_causal: bool = False  # with causal: encode every 30-s epoch on its own ([B*S, 1, spe], wav2sleep.py:248-255), symmetric padding
     seq_causal: bool = False   # SequenceCNN: causal dilated convolutions (wav2sleep.py:355, blocks.py:150-152)
     enc_sig: dict = field(default_factory=dict)  # encoder name -> first signal that created it
@@ -53,6 +55,8 @@ class EngineSpec:
             self.enc_sig.setdefault(enc, sig)
         if self.feature_dim != 128 or self.mixer_nhead * 16 != self.feature_dim:
             raise ValueError('kernels are built for feature_dim=128, head_dim=16 (scripts/config/model/wav2sleep.yaml)')
+        if not 0 <= self.register_tokens <= 5:
+            raise ValueError('register_tokens must be in 0..5 (the attention kernels hold up to 7 tokens per epoch)')
         if self.mixer_dim_ff % 128 or self.seq_kernel != 7 or self.initial_channels != 16 or self.max_channels not in (16, 32, 64, 128):
             raise ValueError('unsupported hyper-parameters for the gfx950 kernels')
 
@@ -399,11 +403,15 @@ class Engine:
         dev = first.device
         B = first.shape[0]
         S = first.shape[1] // COLS_TO_SAMPLES_PER_EPOCH[sigs[0]]
-        F, D, N = sp.feature_dim, len(sigs) + 1, B * S
+        R1 = sp.register_tokens + 1   # CLS + register tokens occupy token slots 0..R
+        F, D, N = sp.feature_dim, len(sigs) + R1, B * S
+        if D > 7:
+            raise ValueError(f'{len(sigs)} signals + {R1} CLS/register tokens: the attention kernels hold at most 7 tokens per epoch')
 
         tokens = torch.empty(N, D, F, device=dev, dtype=torch.float32)
         if cls:
-            lib.fill_rows(tokens, D * F, P['epoch_mixer.register_tokens'], N, F)
+            for r in range(R1):   # column r of the [1, 1, F, R+1] parameter
+                lib.add_rows(tokens.view(-1)[r * F:], D * F, P['epoch_mixer.register_tokens'].view(-1)[r:], R1, None, 1, N, F, False)
         keeps, enc_ctx = [], []
         # The encoders are independent until the set-fusion transformer: each runs on its own HIP stream, so the
         # matrix-core-bound 64/128-channel layers of one modality overlap the bandwidth-bound 16/32-channel layers of
@@ -418,13 +426,16 @@ class Engine:
             with torch.cuda.stream(st):
                 keep = (~torch.isinf(xs[:, 0])).float()  # wav2sleep.py:150 (plumbing on B scalars)
                 keeps.append(keep)
-                enc_ctx.append(self._encoder_forward(s, xs, keep, tokens.view(-1)[(1 + m) * F:], D * F, save))
+                slot = tokens.view(-1)[(R1 + m) * F:]
+                enc_ctx.append(self._encoder_forward(s, xs, keep, slot, D * F, save))
+                if sp.embed_signals:   # + embedding row of this signal on the samples that have it (wav2sleep.py:155-159)
+                    lib.add_rows(slot, D * F, P['signal_encoders.embedder.weight'][sorted(sp.signal_map).index(s)], 1, keep, S, N, F, True)
         for s in sigs:
             main.wait_stream(self._side_stream(sp.signal_map[s], dev))
-        keep_BD = torch.stack([torch.ones_like(keeps[0])] + keeps, dim=1)  # [B, D]
+        keep_BD = torch.stack([torch.ones_like(keeps[0])] * R1 + keeps, dim=1)  # [B, D]
         keypad = (keep_BD == 0).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
 
-        return dict(tokens=tokens, keeps=keeps, keypad=keypad, enc=enc_ctx, sigs=sigs, B=B, S=S, D=D, N=N)
+        return dict(tokens=tokens, keeps=keeps, keypad=keypad, enc=enc_ctx, sigs=sigs, B=B, S=S, D=D, N=N, R1=R1)
 
     def mix(self, tokens: torch.Tensor, keypad: torch.Tensor, pm: float = 0.0, save: bool = False):
         """MultiModalAttentionEmbedder's transformer (models/wav2sleep.py:341-345) on tokens [N, D, F]; returns the final
@@ -620,9 +631,36 @@ class Engine:
             gXn = torch.empty(R, F, device=dev, dtype=torch.float32)
             self._ln_bwd(p + 'norm1', gh, L['X'], L['rs1'], gX1, gXn, R)
             gX = gXn
-        # CLS parameter: sum of the token-0 rows' gradients
-        self._colgrad('epoch_mixer.register_tokens', gX, N, F, ldg=D * F)
+        # CLS / register-token parameter [1, 1, F, R+1]: column r = sum of the token-r rows' gradients
+        R1 = sp.register_tokens + 1
+        if R1 == 1:
+            self._colgrad('epoch_mixer.register_tokens', gX, N, F, ldg=D * F)
+        else:
+            rt = 'epoch_mixer.register_tokens'
+            tmp = torch.empty(R1, F, device=dev, dtype=torch.float32)
+            for r in range(R1):
+                nparts = max(1, min(1024, _cdiv(N, 64)))
+                part = torch.empty(nparts, F, device=dev, dtype=torch.float32)
+                lib.bias_grad(gX.view(-1)[r * F:], N, F, D * F, part, nparts)
+                self._colsum(part, nparts, F, tmp[r])
+        if sp.embed_signals:
+            # embedding rows: sum over the rows of the samples that have the signal (absent signals and missing samples get zero)
+            ew = 'signal_encoders.embedder.weight'
+            if ew not in self._written:
+                self.G[ew].zero_()
+                self._written.add(ew)
+            order = sorted(sp.signal_map)
+            for m, ec in enumerate(c['enc']):
+                gk = gX.view(N, D, F)[:, R1 + m, :].reshape(B, S, F) * ec['keep'][:, None, None]
+                nparts = max(1, min(1024, _cdiv(N, 64)))
+                part = torch.empty(nparts, F, device=dev, dtype=torch.float32)
+                lib.bias_grad(gk, N, F, F, part, nparts)
+                self._colsum(part, nparts, F, self.G[ew][order.index(ec['sig'])], accumulate=True)
         self._flush_reduce()
+        if R1 > 1:
+            g = self.G[rt].view(F, R1)
+            g.add_(tmp.t()) if rt in self._written else g.copy_(tmp.t())
+            self._written.add(rt)
 
         if hook is not None:
             hook('_tail')  # mixer + sequence CNN + classifier gradients are final: their all-reduce can start
@@ -634,7 +672,7 @@ class Engine:
             st = self._side_stream(ec['enc'], dev)
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                self._encoder_backward(ec, gX.view(-1)[(1 + m) * F:], D * F)
+                self._encoder_backward(ec, gX.view(-1)[(R1 + m) * F:], D * F)
                 self._flush_reduce()
                 if hook is not None and ec['enc'] not in encs[m + 1:]:
                     hook(ec['enc'])

@@ -151,8 +151,6 @@ class SignalEncoders(nn.Module):
                  chunk_causal: bool = True, embed_signals: bool = False, initial_channels: int = 16, max_channels: int = 128,
                  output_norm: bool = False, use_residual: bool = True) -> None:
         super().__init__()
-        if embed_signals:
-            raise NotImplementedError('embed_signals=True has no gfx950 kernel yet (off in every shipped config)')
         self.feature_dim = feature_dim
         self.signal_map = dict(signal_map)
         self.causal = causal
@@ -172,7 +170,10 @@ class SignalEncoders(nn.Module):
         self.encoders = nn.ModuleDict(encoders)
         self.embed_signals = embed_signals
         self.sig_to_embedding_idx = {sig: i for i, sig in enumerate(sorted(signal_map.keys()))}
-        self.register_parameter('embedder', None)
+        if self.embed_signals:   # wav2sleep.py:127-133: one row per signal, added to its encoder's output
+            self.embedder = nn.Embedding(num_embeddings=len(signal_map), embedding_dim=self.feature_dim)
+        else:
+            self.register_parameter('embedder', None)
 
     def __len__(self) -> int:
         return len(self.encoders)
@@ -185,13 +186,13 @@ class SignalEncoders(nn.Module):
         """models/wav2sleep.py:146-161, inference only (training goes through Wav2Sleep.forward, one fused autograd node):
         dict signal -> [B, T]  ->  dict signal -> [B, S, feature_dim]; samples whose input row is -inf come back as -inf."""
         spec = EngineSpec(signal_map=dict(self.signal_map), feature_dim=self.feature_dim, initial_channels=self.initial_channels,
-                          max_channels=self.max_channels, causal=self.causal, chunk_causal=self.chunk_causal)
+                          max_channels=self.max_channels, causal=self.causal, chunk_causal=self.chunk_causal, embed_signals=self.embed_signals)
         eng, ver = _standalone_engine(self, 'signal_encoders.', spec)
         e = eng.encode(x, save=False, pack_key=ver, cls=False)
         B, S, F = e['B'], e['S'], self.feature_dim
         out = {}
         for m, sig in enumerate(e['sigs']):
-            z = e['tokens'][:, 1 + m, :].reshape(B, S, F).clone()
+            z = e['tokens'][:, e['R1'] + m, :].reshape(B, S, F).clone()
             out[sig] = torch.where(e['keeps'][m][:, None, None] == 0, float('-inf'), z)
         return {k: out[k] for k in x}
 
@@ -203,8 +204,10 @@ class MultiModalAttentionEmbedder(nn.Module):
                  norm_first: bool = True, nhead: int = 4, register_tokens: int = 0):
         super().__init__()
         _check_activation(activation)
-        if not norm_first or register_tokens != 0:
-            raise NotImplementedError('post-norm / register tokens have no gfx950 kernels yet')
+        if not norm_first:
+            raise NotImplementedError('the post-norm transformer layer has no gfx950 kernels yet')
+        if not 0 <= register_tokens <= 5:
+            raise ValueError('register_tokens must be in 0..5 (the attention kernels hold up to 7 tokens per epoch)')
         self.feature_dim = feature_dim
         self.dropout_p = dropout
         self.nhead = nhead
@@ -230,17 +233,21 @@ class MultiModalAttentionEmbedder(nn.Module):
         if F != self.feature_dim:
             raise ValueError(f'Feature dimension {F} does not match {self.feature_dim=}.')
         spec = EngineSpec(signal_map={'ECG': 'ECG'}, feature_dim=self.feature_dim, mixer_layers=self.num_layers, mixer_nhead=self.nhead,
-                          mixer_dim_ff=self.dim_ff, mixer_dropout=self.dropout_p)
+                          mixer_dim_ff=self.dim_ff, mixer_dropout=self.dropout_p, register_tokens=self.num_register_tokens)
         eng, ver = _standalone_engine(self, 'epoch_mixer.', spec)
         from . import lib
-        N, D = B * S, len(signals) + 1
+        R1 = self.num_register_tokens + 1
+        N, D = B * S, len(signals) + R1
+        if D > 7:
+            raise ValueError(f'{len(signals)} signals + {R1} CLS/register tokens: the attention kernels hold at most 7 tokens per epoch')
         tokens = torch.empty(N, D, F, device=first.device, dtype=torch.float32)
-        lib.fill_rows(tokens, D * F, eng.P['epoch_mixer.register_tokens'], N, F)
-        pads = [torch.zeros(B, dtype=torch.bool, device=first.device)]
+        for r in range(R1):
+            lib.add_rows(tokens.view(-1)[r * F:], D * F, eng.P['epoch_mixer.register_tokens'].view(-1)[r:], R1, None, 1, N, F, False)
+        pads = [torch.zeros(B, dtype=torch.bool, device=first.device)] * R1
         for m, sig in enumerate(signals):  # host-side plumbing of [B,S,F] tensors: mask detection, zero fill, token slot copy
             z = z_dict[sig].float()
             m_B = torch.isinf(z).any(dim=2).any(dim=1)
-            tokens[:, 1 + m, :] = torch.where(m_B[:, None, None], 0.0, z).reshape(N, F)
+            tokens[:, R1 + m, :] = torch.where(m_B[:, None, None], 0.0, z).reshape(N, F)
             pads.append(m_B)
         keypad = torch.stack(pads, dim=1).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
         X, _ = eng.mix(tokens, keypad, self.dropout_p if self.training else 0.0, save=False)
@@ -346,11 +353,12 @@ class Wav2Sleep(nn.Module):
         return {
             '_target_': t + 'Wav2Sleep', 'num_classes': self.num_classes,
             'signal_encoders': {'_target_': t + 'SignalEncoders', 'signal_map': dict(se.signal_map), 'feature_dim': se.feature_dim,
-                                'activation': 'gelu', 'norm': 'instance', 'causal': bool(se.causal), 'chunk_causal': bool(se.chunk_causal),
+                                'activation': 'gelu', 'norm': 'instance', 'causal': bool(se.causal), 'chunk_causal': bool(se.chunk_causal), 'embed_signals': bool(se.embed_signals),
                                 'initial_channels': se.initial_channels, 'max_channels': se.max_channels, 'output_norm': False,
                                 'use_residual': True},
             'epoch_mixer': {'_target_': t + 'MultiModalAttentionEmbedder', 'feature_dim': em.feature_dim, 'dropout': em.dropout_p,
-                            'activation': 'gelu', 'layers': em.num_layers, 'dim_ff': em.dim_ff, 'nhead': em.nhead},
+                            'activation': 'gelu', 'layers': em.num_layers, 'dim_ff': em.dim_ff, 'nhead': em.nhead,
+                            'register_tokens': em.num_register_tokens},
             'sequence_mixer': {'_target_': t + 'SequenceCNN', 'feature_dim': self.feature_dim, 'dropout': sm.dropout_p, 'activation': 'gelu',
                                'norm': 'layer', 'causal': bool(sm.causal), 'num_layers': sm.num_layers, 'kernel_size': sm.kernel_size,
                                'num_dilations': sm.num_dilations},
@@ -376,10 +384,11 @@ class Wav2Sleep(nn.Module):
             for n in names:
                 if n not in sigs:
                     raise ValueError(f'signal {n} is not in the batch')
-            cols = [0] + [1 + sigs.index(n) for n in names]
+            R1 = e['R1']
+            cols = list(range(R1)) + [R1 + sigs.index(n) for n in names]
             D = len(cols)
             tok = tokens[:, cols, :].contiguous()  # [N, D, F] token gather (host-side plumbing on the small tensor)
-            keep = torch.stack([torch.ones(B, device=tok.device)] + [e['keeps'][sigs.index(n)] for n in names], dim=1)
+            keep = torch.stack([torch.ones(B, device=tok.device)] * R1 + [e['keeps'][sigs.index(n)] for n in names], dim=1)
             keypad = (keep == 0).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
             X, _ = eng.mix(tok, keypad, 0.0, save=False)
             pre, _ = eng.seq(X, D * F, B, S, 0.0, save=False)
@@ -395,7 +404,8 @@ class Wav2Sleep(nn.Module):
                           initial_channels=se.initial_channels, max_channels=se.max_channels, mixer_layers=em.num_layers,
                           mixer_nhead=em.nhead, mixer_dim_ff=em.dim_ff, mixer_dropout=em.dropout_p, seq_blocks=sm.num_layers,
                           seq_dilations=sm.num_dilations, seq_kernel=sm.kernel_size, seq_dropout=sm.dropout_p, causal=se.causal,
-                          chunk_causal=se.chunk_causal, seq_causal=sm.causal)
+                          chunk_causal=se.chunk_causal, seq_causal=sm.causal, embed_signals=se.embed_signals,
+                          register_tokens=em.num_register_tokens)
 
     def param_version(self) -> int:
         """Changes whenever any parameter was written (torch in-place ops bump `_version`; the fused AdamW kernel
