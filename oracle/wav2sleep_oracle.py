@@ -50,6 +50,7 @@ class ModelConfig:
     instance_eps: float = 1e-2  # models/wav2sleep.py:213-215
     causal: bool = False  # scripts/config/main.yaml:22 `causal` (with model yaml `chunk_causal: False`): causal-padded convolutions
     embed_signals: bool = False  # SignalEncoders(embed_signals=...): nn.Embedding row per signal added to its encoder output
+    output_norm: bool = False  # SignalEncoder(output_norm=True): nn.LayerNorm(feature_dim) on the encoder output (wav2sleep.py:232-233,266)
     register_tokens: int = 0  # MultiModalAttentionEmbedder(register_tokens=R): R learnable tokens next to the CLS token
     chunk_causal: bool = False  # SignalEncoders(chunk_causal=...): with causal=True the encoders see one 30-s epoch at a time instead
     layer_eps: float = 1e-5  # nn.LayerNorm default / models/utils.py:12
@@ -84,6 +85,9 @@ def param_shapes(cfg: ModelConfig) -> dict[str, tuple]:
             cin = c
         shapes[f'signal_encoders.encoders.{enc}.linear.weight'] = (Fd, 4 * chans[-1])
         shapes[f'signal_encoders.encoders.{enc}.linear.bias'] = (Fd,)
+        if cfg.output_norm:
+            shapes[f'signal_encoders.encoders.{enc}.output_norm.weight'] = (Fd,)
+            shapes[f'signal_encoders.encoders.{enc}.output_norm.bias'] = (Fd,)
     for l in range(cfg.mixer_layers):
         p = f'epoch_mixer.transformer_encoder.layers.{l}.'
         shapes[p + 'self_attn.in_proj_weight'] = (3 * Fd, Fd)
@@ -122,7 +126,7 @@ def make_state_dict(cfg: ModelConfig, seed: int = 0, scale: float = 1.0) -> dict
     g = torch.Generator().manual_seed(seed)
     sd = {}
     for k, shp in sorted(param_shapes(cfg).items()):
-        if k.endswith('norm.weight') or k.endswith('norm1.weight') or k.endswith('norm2.weight'):
+        if k.endswith('norm.weight') or k.endswith('norm1.weight') or k.endswith('norm2.weight'):  # incl. output_norm.weight
             t = 1.0 + 0.1 * torch.randn(shp, generator=g)
         elif k.endswith('bias'):
             t = 0.05 * torch.randn(shp, generator=g)
@@ -216,8 +220,11 @@ def signal_encoder(sd: dict, cfg: ModelConfig, enc: str, sig: str, x_BT: Tensor,
             y = conv_block(sd, f'signal_encoders.encoders.{enc}.cnn.{i}.', y, cfg.instance_eps, taps, cfg.causal)
         epoch_dim = y.size(1) * 4
         y = y.transpose(-1, -2).reshape(B, -1, epoch_dim)
-    y = F.linear(y, sd[f'signal_encoders.encoders.{enc}.linear.weight'], sd[f'signal_encoders.encoders.{enc}.linear.bias'])
-    return gelu(y)
+    y = gelu(F.linear(y, sd[f'signal_encoders.encoders.{enc}.linear.weight'], sd[f'signal_encoders.encoders.{enc}.linear.bias']))
+    if cfg.output_norm:  # wav2sleep.py:266
+        y = F.layer_norm(y, (y.size(-1),), sd[f'signal_encoders.encoders.{enc}.output_norm.weight'],
+                         sd[f'signal_encoders.encoders.{enc}.output_norm.bias'], cfg.layer_eps)
+    return y
 
 
 def signal_encoders(sd: dict, cfg: ModelConfig, x: dict[str, Tensor], taps: dict | None = None) -> dict[str, Tensor]:

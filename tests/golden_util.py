@@ -17,7 +17,7 @@ CASES = {
     'c8_embed_reg': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [1]}, 18, 108),
 }
 CAUSAL_CASES = {'c6_causal', 'c7_chunk_causal'}  # `causal: True` (scripts/config/main.yaml:22)
-EXTRA = {'c8_embed_reg': dict(embed_signals=True, register_tokens=2)}  # SignalEncoders(embed_signals=True), MultiModalAttentionEmbedder(register_tokens=2)
+EXTRA = {'c8_embed_reg': dict(embed_signals=True, register_tokens=2, output_norm=True)}  # SignalEncoders(embed_signals=True), MultiModalAttentionEmbedder(register_tokens=2)
 CHUNK_CASES = {'c7_chunk_causal'}  # chunk_causal=True (SignalEncoders' default) instead of the model yaml's `chunk_causal: False`
 
 

@@ -25,8 +25,9 @@ DEV = 'cuda'
 SM4 = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
 
 
-def build(signal_map, nc, dropout=0.0, causal=False, chunk_causal=False, embed_signals=False, register_tokens=0):
-    return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', causal=causal, chunk_causal=chunk_causal, embed_signals=embed_signals),
+def build(signal_map, nc, dropout=0.0, causal=False, chunk_causal=False, embed_signals=False, register_tokens=0, output_norm=False):
+    return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', causal=causal, chunk_causal=chunk_causal, embed_signals=embed_signals,
+                                        output_norm=output_norm),
                        W.MultiModalAttentionEmbedder(128, layers=2, dropout=dropout, dim_ff=512, nhead=8, register_tokens=register_tokens),
                        W.SequenceCNN(128, dropout=dropout, norm='layer', causal=causal, num_layers=2, kernel_size=7, num_dilations=6), nc)
 
@@ -57,7 +58,8 @@ def test_forward_matches_reference_goldens(name):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
     g = load(name)
     cfg = case_config(name)
-    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens,
+                  output_norm=cfg.output_norm)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).eval()
     x, y = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
@@ -75,7 +77,8 @@ def test_train_steps_match_reference_goldens(name):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
     g = load(name)
     cfg = case_config(name)
-    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens,
+                  output_norm=cfg.output_norm)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).train()
     tr = W.FusedTrainStep(model)
@@ -114,12 +117,13 @@ def test_train_steps_match_reference_goldens(name):
 def test_autograd_path_matches_oracle(signal_map, nc, B, S, missing, causal):
     """nn.Module surface: logits = model(x); torch CE; loss.backward() fills p.grad like the reference's autograd."""
     if causal == 'embed':
-        cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, embed_signals=True, register_tokens=2)
+        cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, embed_signals=True, register_tokens=2, output_norm=True)
     else:
         cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc, causal=bool(causal), chunk_causal=causal == 'chunk')
     sd = O.make_state_dict(cfg, seed=7)
     x, y = O.make_inputs(cfg, B, S, seed=8, missing=missing)
-    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens,
+                  output_norm=cfg.output_norm)
     model.load_state_dict(sd)
     model.to(DEV).train()
     logits = model(to_dev(x))
@@ -295,7 +299,8 @@ def test_submodule_forwards_match_reference_goldens(name):
     signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
     g = load(name)
     cfg = case_config(name)
-    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens)
+    model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens,
+                  output_norm=cfg.output_norm)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).eval()
     x, _ = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
@@ -374,7 +379,7 @@ def test_device_input_pipeline_matches_oracle():
         assert torch.isinf(sig[k][~m]).all()
 
 
-@pytest.mark.parametrize('extra', [{}, dict(embed_signals=True, register_tokens=1)])
+@pytest.mark.parametrize('extra', [{}, dict(embed_signals=True, register_tokens=1, output_norm=True)])
 def test_subset_evaluation_reuses_encoders_exactly(extra):
     """forward_subsets == separate model({subset}) calls (trainer/main.py:188-224 semantics), bit for bit."""
     cfg = O.ModelConfig(signal_map=SM4, num_classes=4, **extra)

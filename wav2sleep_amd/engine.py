@@ -43,6 +43,7 @@ class EngineSpec:
     layer_eps: float = 1e-5
     causal: bool = False       # encoders: causal-padded convolutions (blocks.py:150-152,178-182; `chunk_causal: False`)
     embed_signals: bool = False  # nn.Embedding row per signal added to its encoder output (wav2sleep.py:127-133,155-159)
+    output_norm: bool = False   # nn.LayerNorm(feature_dim) on every encoder's output (wav2sleep.py:232-233,266)
     register_tokens: int = 0    # R learnable tokens next to CLS (wav2sleep.py:299,330): D = R + 1 + C tokens per epoch
     chunk_causal: bool = False  # with causal: encode every 30-s epoch on its own ([B*S, 1, spe], wav2sleep.py:248-255), symmetric padding
     seq_causal: bool = False   # SequenceCNN: causal dilated convolutions (wav2sleep.py:355, blocks.py:150-152)
@@ -373,12 +374,18 @@ class Engine:
         # ---- time-distributed dense + GELU (wav2sleep.py:261-265): taps=4/stride=4 over the [B,4S,C] map
         F = sp.feature_dim
         zpre = torch.empty(Bfull, S, F, device=dev, dtype=torch.float32)
+        zact = rs_out = None
+        if sp.output_norm:   # GELU output to its own tensor, LayerNorm from there into the token slot (masked samples: LN(0) = beta,
+            zact = torch.empty(Bfull, S, F, device=dev, dtype=torch.float32)   # never read by another token: their keys are padded out)
+            rs_out = torch.empty(Bfull * S, 2, device=dev, dtype=torch.float32)
         self._conv(x=pin, w=P[pfx + 'linear.weight'], y=zpre, B=Bfull, L_in=4 * S, L_out=S, cin=cin, cout=F, taps=4, stride=4, pad=0,
                    mode=lib.MODE_DILATED, pro=lib.PRO_GELU, epi=lib.EPI_BIAS, bias=P[pfx + 'linear.bias'], rowkeep=keep,
-                   y2=tok_slice, ldy2=ldtok)
+                   y2=zact if sp.output_norm else tok_slice, ldy2=F if sp.output_norm else ldtok)
+        if sp.output_norm:
+            lib.layernorm_fwd(zact, F, P[pfx + 'output_norm.weight'], P[pfx + 'output_norm.bias'], tok_slice, ldtok, rs_out, Bfull * S, F, sp.layer_eps)
         if self.taps is not None:
             self.taps[f'{sig}.zpre'] = zpre
-        return dict(sig=sig, enc=enc, x=x, keep=keep, blocks=blocks, plast=pin, zpre=zpre, S=S, B=Bfull, Bc=B) if save else None
+        return dict(sig=sig, enc=enc, x=x, keep=keep, blocks=blocks, plast=pin, zpre=zpre, zact=zact, rs_out=rs_out, S=S, B=Bfull, Bc=B) if save else None
 
     # ------------------------------------------------------------------ full forward
     def encode(self, x: dict[str, torch.Tensor], save: bool = False, pack_key=None, cls: bool = True):
@@ -705,6 +712,17 @@ class Engine:
         pfx = f'signal_encoders.encoders.{enc}.'
         ch = sp.channels(enc)
         cl = ch[-1]
+        if sp.output_norm:   # token = LayerNorm(z): back through it first
+            gact = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+            npl = max(1, min(1024, _cdiv(B * S, 32)))
+            pg = torch.empty(npl, F, device=dev, dtype=torch.float32)
+            pb = torch.empty(npl, F, device=dev, dtype=torch.float32)
+            wn, bn = pfx + 'output_norm.weight', pfx + 'output_norm.bias'
+            lib.layernorm_bwd(gtok, ldtok, ec['zact'], F, P[wn], P[bn], ec['rs_out'], None, gact, F, pg, pb, B * S, F, False, npl)
+            self._colsum(pg, npl, F, self.G[wn], accumulate=wn in self._written)
+            self._colsum(pb, npl, F, self.G[bn], accumulate=bn in self._written)
+            self._written.update((wn, bn))
+            gtok, ldtok = gact, F
         # z = keep * GELU(zpre): g_zpre
         gz = torch.empty(B, S, F, device=dev, dtype=torch.float32)
         lib.gelu_bwd_rows(gtok, ldtok, ec['zpre'], ec['keep'], S, gz, B * S, F)

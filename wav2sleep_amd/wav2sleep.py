@@ -121,8 +121,8 @@ class SignalEncoder(nn.Module):
                  max_channels=128, causal=False, chunk_causal=True, output_norm=False, use_residual=True):
         super().__init__()
         _check_activation(activation)
-        if output_norm or norm != 'instance':
-            raise NotImplementedError('output_norm / non-instance encoder norms have no gfx950 kernels yet')
+        if norm != 'instance':
+            raise NotImplementedError('non-instance encoder norms have no gfx950 kernels yet')
         self.feature_dim = feature_dim
         self.samples_per_epoch = samples_per_epoch
         self.causal = causal
@@ -138,7 +138,7 @@ class SignalEncoder(nn.Module):
         self.cnn = nn.Sequential(*blocks)
         self.epoch_dim = channels[-1] * 4
         self.linear = nn.Linear(self.epoch_dim, feature_dim)
-        self.output_norm = nn.Identity()
+        self.output_norm = nn.LayerNorm(feature_dim) if output_norm else nn.Identity()   # wav2sleep.py:232-233
 
     def forward(self, *a, **k):
         raise NotImplementedError(_NO_FORWARD.format('SignalEncoder'))
@@ -155,6 +155,7 @@ class SignalEncoders(nn.Module):
         self.signal_map = dict(signal_map)
         self.causal = causal
         self.chunk_causal = chunk_causal
+        self.use_output_norm = output_norm
         self.initial_channels = initial_channels
         self.max_channels = max_channels
         encoders = {}
@@ -186,7 +187,8 @@ class SignalEncoders(nn.Module):
         """models/wav2sleep.py:146-161, inference only (training goes through Wav2Sleep.forward, one fused autograd node):
         dict signal -> [B, T]  ->  dict signal -> [B, S, feature_dim]; samples whose input row is -inf come back as -inf."""
         spec = EngineSpec(signal_map=dict(self.signal_map), feature_dim=self.feature_dim, initial_channels=self.initial_channels,
-                          max_channels=self.max_channels, causal=self.causal, chunk_causal=self.chunk_causal, embed_signals=self.embed_signals)
+                          max_channels=self.max_channels, causal=self.causal, chunk_causal=self.chunk_causal, embed_signals=self.embed_signals,
+                          output_norm=self.use_output_norm)
         eng, ver = _standalone_engine(self, 'signal_encoders.', spec)
         e = eng.encode(x, save=False, pack_key=ver, cls=False)
         B, S, F = e['B'], e['S'], self.feature_dim
@@ -354,7 +356,7 @@ class Wav2Sleep(nn.Module):
             '_target_': t + 'Wav2Sleep', 'num_classes': self.num_classes,
             'signal_encoders': {'_target_': t + 'SignalEncoders', 'signal_map': dict(se.signal_map), 'feature_dim': se.feature_dim,
                                 'activation': 'gelu', 'norm': 'instance', 'causal': bool(se.causal), 'chunk_causal': bool(se.chunk_causal), 'embed_signals': bool(se.embed_signals),
-                                'initial_channels': se.initial_channels, 'max_channels': se.max_channels, 'output_norm': False,
+                                'initial_channels': se.initial_channels, 'max_channels': se.max_channels, 'output_norm': bool(se.use_output_norm),
                                 'use_residual': True},
             'epoch_mixer': {'_target_': t + 'MultiModalAttentionEmbedder', 'feature_dim': em.feature_dim, 'dropout': em.dropout_p,
                             'activation': 'gelu', 'layers': em.num_layers, 'dim_ff': em.dim_ff, 'nhead': em.nhead,
@@ -405,7 +407,7 @@ class Wav2Sleep(nn.Module):
                           mixer_nhead=em.nhead, mixer_dim_ff=em.dim_ff, mixer_dropout=em.dropout_p, seq_blocks=sm.num_layers,
                           seq_dilations=sm.num_dilations, seq_kernel=sm.kernel_size, seq_dropout=sm.dropout_p, causal=se.causal,
                           chunk_causal=se.chunk_causal, seq_causal=sm.causal, embed_signals=se.embed_signals,
-                          register_tokens=em.num_register_tokens)
+                          register_tokens=em.num_register_tokens, output_norm=se.use_output_norm)
 
     def param_version(self) -> int:
         """Changes whenever any parameter was written (torch in-place ops bump `_version`; the fused AdamW kernel
