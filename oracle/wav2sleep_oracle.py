@@ -51,6 +51,7 @@ class ModelConfig:
     causal: bool = False  # scripts/config/main.yaml:22 `causal` (with model yaml `chunk_causal: False`): causal-padded convolutions
     embed_signals: bool = False  # SignalEncoders(embed_signals=...): nn.Embedding row per signal added to its encoder output
     output_norm: bool = False  # SignalEncoder(output_norm=True): nn.LayerNorm(feature_dim) on the encoder output (wav2sleep.py:232-233,266)
+    use_residual: bool = True  # ConvBlock1D(use_residual=...): the 1x1/stride-2 branch and its `downsample` weight (blocks.py:49-55,67-68)
     register_tokens: int = 0  # MultiModalAttentionEmbedder(register_tokens=R): R learnable tokens next to the CLS token
     chunk_causal: bool = False  # SignalEncoders(chunk_causal=...): with causal=True the encoders see one 30-s epoch at a time instead
     layer_eps: float = 1e-5  # nn.LayerNorm default / models/utils.py:12
@@ -81,7 +82,8 @@ def param_shapes(cfg: ModelConfig) -> dict[str, tuple]:
             shapes[p + 'conv1.conv.weight'] = (c, cin, 3)
             shapes[p + 'conv2.conv.weight'] = (c, c, 3)
             shapes[p + 'conv3.conv.weight'] = (c, c, 3)
-            shapes[p + 'downsample.weight'] = (c, cin, 1)
+            if cfg.use_residual:
+                shapes[p + 'downsample.weight'] = (c, cin, 1)
             cin = c
         shapes[f'signal_encoders.encoders.{enc}.linear.weight'] = (Fd, 4 * chans[-1])
         shapes[f'signal_encoders.encoders.{enc}.linear.bias'] = (Fd,)
@@ -192,8 +194,7 @@ def conv_block(sd: dict, p: str, x_BCL: Tensor, eps: float, taps: dict | None = 
     h1 = conv_layer_in(x_BCL, sd[p + 'conv1.conv.weight'], 1, eps, causal)
     h2 = conv_layer_in(h1, sd[p + 'conv2.conv.weight'], 1, eps, causal)
     h3 = conv_layer_in(h2, sd[p + 'conv3.conv.weight'], 2, eps, causal)
-    r = F.conv1d(x_BCL, sd[p + 'downsample.weight'], None, stride=2)
-    out = gelu(h3 + r)
+    out = gelu(h3 + F.conv1d(x_BCL, sd[p + 'downsample.weight'], None, stride=2)) if (p + 'downsample.weight') in sd else gelu(h3)
     if taps is not None:
         taps[p + 'out'] = out
     return out

@@ -53,7 +53,7 @@ def checksum(d: dict) -> float:
 def build_reference(cfg: O.ModelConfig) -> Wav2Sleep:
     enc = SignalEncoders(signal_map=dict(cfg.signal_map), feature_dim=cfg.feature_dim, activation='gelu', norm='instance',
                          causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, initial_channels=cfg.initial_channels,
-                         max_channels=cfg.max_channels, output_norm=cfg.output_norm, use_residual=True)
+                         max_channels=cfg.max_channels, output_norm=cfg.output_norm, use_residual=cfg.use_residual)
     mix = MultiModalAttentionEmbedder(feature_dim=cfg.feature_dim, dropout=0.0, activation='gelu', layers=cfg.mixer_layers,
                                       dim_ff=cfg.mixer_dim_ff, nhead=cfg.mixer_nhead, register_tokens=cfg.register_tokens)
     seq = SequenceCNN(feature_dim=cfg.feature_dim, dropout=0.0, activation='gelu', norm='layer', causal=cfg.causal,
@@ -73,10 +73,11 @@ CASES = {
     'c7_chunk_causal': ({'THX': 'THX', 'PPG': 'PPG'}, 4, 2, 6, {'THX': [0]}, 17, 107),
     # shared encoder told apart by signal embeddings (embed_signals=True) + two register tokens next to CLS
     'c8_embed_reg': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [1]}, 18, 108),
+    'c9_no_residual': ({'ABD': 'ABD', 'PPG': 'PPG'}, 4, 2, 4, None, 19, 109),
 }
 CAUSAL_CASES = {'c6_causal', 'c7_chunk_causal'}
 CHUNK_CASES = {'c7_chunk_causal'}
-EXTRA = {'c8_embed_reg': dict(embed_signals=True, register_tokens=2, output_norm=True)}
+EXTRA = {'c8_embed_reg': dict(embed_signals=True, register_tokens=2, output_norm=True), 'c9_no_residual': dict(use_residual=False)}
 
 
 def run_case(name: str):

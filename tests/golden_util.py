@@ -15,9 +15,10 @@ CASES = {
     'c6_causal': ({'ABD': 'ABD', 'ECG': 'ECG'}, 4, 2, 8, {'ABD': [1]}, 16, 106),
     'c7_chunk_causal': ({'THX': 'THX', 'PPG': 'PPG'}, 4, 2, 6, {'THX': [0]}, 17, 107),
     'c8_embed_reg': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [1]}, 18, 108),
+    'c9_no_residual': ({'ABD': 'ABD', 'PPG': 'PPG'}, 4, 2, 4, None, 19, 109),
 }
 CAUSAL_CASES = {'c6_causal', 'c7_chunk_causal'}  # `causal: True` (scripts/config/main.yaml:22)
-EXTRA = {'c8_embed_reg': dict(embed_signals=True, register_tokens=2, output_norm=True)}  # SignalEncoders(embed_signals=True), MultiModalAttentionEmbedder(register_tokens=2)
+EXTRA = {'c8_embed_reg': dict(embed_signals=True, register_tokens=2, output_norm=True), 'c9_no_residual': dict(use_residual=False)}  # SignalEncoders(embed_signals=True), MultiModalAttentionEmbedder(register_tokens=2)
 CHUNK_CASES = {'c7_chunk_causal'}  # chunk_causal=True (SignalEncoders' default) instead of the model yaml's `chunk_causal: False`
 
 

@@ -25,9 +25,10 @@ DEV = 'cuda'
 SM4 = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
 
 
-def build(signal_map, nc, dropout=0.0, causal=False, chunk_causal=False, embed_signals=False, register_tokens=0, output_norm=False):
+def build(signal_map, nc, dropout=0.0, causal=False, chunk_causal=False, embed_signals=False, register_tokens=0, output_norm=False,
+          use_residual=True):
     return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', causal=causal, chunk_causal=chunk_causal, embed_signals=embed_signals,
-                                        output_norm=output_norm),
+                                        output_norm=output_norm, use_residual=use_residual),
                        W.MultiModalAttentionEmbedder(128, layers=2, dropout=dropout, dim_ff=512, nhead=8, register_tokens=register_tokens),
                        W.SequenceCNN(128, dropout=dropout, norm='layer', causal=causal, num_layers=2, kernel_size=7, num_dilations=6), nc)
 
@@ -59,7 +60,7 @@ def test_forward_matches_reference_goldens(name):
     g = load(name)
     cfg = case_config(name)
     model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens,
-                  output_norm=cfg.output_norm)
+                  output_norm=cfg.output_norm, use_residual=cfg.use_residual)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).eval()
     x, y = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)
@@ -78,7 +79,7 @@ def test_train_steps_match_reference_goldens(name):
     g = load(name)
     cfg = case_config(name)
     model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens,
-                  output_norm=cfg.output_norm)
+                  output_norm=cfg.output_norm, use_residual=cfg.use_residual)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).train()
     tr = W.FusedTrainStep(model)
@@ -90,6 +91,8 @@ def test_train_steps_match_reference_goldens(name):
         assert out['lr'] == pytest.approx(float(g[f'lr{step}']), rel=1e-6)
         if step == 0:
             for k, p in model._engine.G.items():
+                if not cfg.use_residual and k.endswith('downsample.weight'):
+                    continue   # the engine's zero stand-in for the absent residual branch: no parameter, no gradient
                 want = g[f'grad0.{k}']
                 if want.shape == tuple(p.shape):   # full tensor stored: the documented bar -- relative L2 <= 2e-3, and no element
                     got = p.detach().cpu().double().numpy()                          # further off than 2e-3 of the tensor's scale
@@ -97,7 +100,8 @@ def test_train_steps_match_reference_goldens(name):
                     assert rel <= 2e-3, (k, rel)
                     assert np.abs(got - want).max() <= 2e-3 * max(np.abs(want).max(), 1e-6) + 1e-7, (k, np.abs(got - want).max(), np.abs(want).max())
                 else:
-                    assert_summary_close(p, want, rtol=2e-3, atol=3e-4, what=f'grad0.{k}')
+                    # summary-stored tensors: the same bar on the stored samples (2e-3 of the tensor's scale, floor 3e-4)
+                    assert_summary_close(p, want, rtol=2e-3, atol=max(3e-4, 2e-3 * float(np.abs(want[3:]).max())), what=f'grad0.{k}')
     sd = model.state_dict()
     for k in sd:
         assert_summary_close(sd[k], g[f'param2.{k}'], rtol=1e-5, atol=1.1e-6, what=f'param2.{k}')
@@ -123,7 +127,7 @@ def test_autograd_path_matches_oracle(signal_map, nc, B, S, missing, causal):
     sd = O.make_state_dict(cfg, seed=7)
     x, y = O.make_inputs(cfg, B, S, seed=8, missing=missing)
     model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens,
-                  output_norm=cfg.output_norm)
+                  output_norm=cfg.output_norm, use_residual=cfg.use_residual)
     model.load_state_dict(sd)
     model.to(DEV).train()
     logits = model(to_dev(x))
@@ -292,7 +296,7 @@ def test_load_model_and_predict_roundtrip(tmp_path):
     assert W.cohens_kappa(cm.numpy(), 4) == pytest.approx(O.cohens_kappa(cm.numpy(), 4))
 
 
-@pytest.mark.parametrize('name', ['c2_four_mod', 'c4_eog_pair', 'c5_shared_enc', 'c6_causal', 'c7_chunk_causal', 'c8_embed_reg'])
+@pytest.mark.parametrize('name', ['c2_four_mod', 'c4_eog_pair', 'c5_shared_enc', 'c6_causal', 'c7_chunk_causal', 'c8_embed_reg', 'c9_no_residual'])
 def test_submodule_forwards_match_reference_goldens(name):
     """SignalEncoders / MultiModalAttentionEmbedder / SequenceCNN called on their own, like the reference modules
     (wav2sleep.py:146-161, 301-346, 379-390), against the per-stage outputs recorded from the reference."""
@@ -300,7 +304,7 @@ def test_submodule_forwards_match_reference_goldens(name):
     g = load(name)
     cfg = case_config(name)
     model = build(signal_map, nc, causal=cfg.causal, chunk_causal=cfg.chunk_causal, embed_signals=cfg.embed_signals, register_tokens=cfg.register_tokens,
-                  output_norm=cfg.output_norm)
+                  output_norm=cfg.output_norm, use_residual=cfg.use_residual)
     model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
     model.to(DEV).eval()
     x, _ = O.make_inputs(cfg, B, S, seed=iseed, missing=missing)

@@ -44,6 +44,7 @@ class EngineSpec:
     causal: bool = False       # encoders: causal-padded convolutions (blocks.py:150-152,178-182; `chunk_causal: False`)
     embed_signals: bool = False  # nn.Embedding row per signal added to its encoder output (wav2sleep.py:127-133,155-159)
     output_norm: bool = False   # nn.LayerNorm(feature_dim) on every encoder's output (wav2sleep.py:232-233,266)
+    use_residual: bool = True   # ConvBlock1D(use_residual=False): no 1x1/stride-2 branch, no `downsample` parameter (blocks.py:49-55,67-68)
     register_tokens: int = 0    # R learnable tokens next to CLS (wav2sleep.py:299,330): D = R + 1 + C tokens per epoch
     chunk_causal: bool = False  # with causal: encode every 30-s epoch on its own ([B*S, 1, spe], wav2sleep.py:248-255), symmetric padding
     seq_causal: bool = False   # SequenceCNN: causal dilated convolutions (wav2sleep.py:355, blocks.py:150-152)
@@ -98,6 +99,18 @@ class Engine:
         self.fused_finalize = os.environ.get('W2S_FUSED_FINALIZE', '0') != '0'
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
+        if not spec.use_residual:
+            # The kernels keep their residual inputs: a zero 1x1 weight that is no parameter (its gradient goes to a scratch buffer that
+            # nothing reads, and the data gradient it contributes, Wd^T g, is exactly zero).
+            for enc in dict.fromkeys(spec.signal_map.values()):
+                cin = 1
+                for i, c in enumerate(spec.channels(enc)):
+                    name = f'signal_encoders.encoders.{enc}.cnn.{i}.downsample.weight'
+                    some = next(iter(params.values()))
+                    self.P[name] = torch.zeros(c, cin, 1, device=some.device, dtype=torch.float32)
+                    if self.G is not None:
+                        self.G[name] = torch.zeros(c, cin, 1, device=some.device, dtype=torch.float32)
+                    cin = c
         # causal padding (scripts/config/main.yaml:22 `causal`): out[j] reads x[j*stride - (k-1-tap)*dil], zeros before the start.  Same
         # kernels, different pad: forward pad (k-1)*dil, data-gradient (flipped taps) pad 0.  The <= 32-channel fused kernels and
         # the first-layer recompute are written for the symmetric padding, so the causal model runs on the generic kernels.

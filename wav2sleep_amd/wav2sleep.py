@@ -83,13 +83,14 @@ class ConvBlock1D(nn.Module):
 
     def __init__(self, input_dim, output_dim, norm='instance', use_residual=True):
         super().__init__()
-        if not use_residual:
-            raise NotImplementedError('use_residual=False has no gfx950 kernel yet')
         self.use_residual = use_residual
         self.conv1 = ConvLayer1D(input_dim, output_dim, norm=norm)
         self.conv2 = ConvLayer1D(output_dim, output_dim, norm=norm)
         self.conv3 = ConvLayer1D(output_dim, output_dim, stride=2, norm=norm)
-        self.downsample = nn.Conv1d(input_dim, output_dim, kernel_size=1, stride=2, padding=0, bias=False)
+        if use_residual:
+            self.downsample = nn.Conv1d(input_dim, output_dim, kernel_size=1, stride=2, padding=0, bias=False)
+        else:
+            self.register_parameter('downsample', None)   # blocks.py:53-55
 
     def forward(self, *a, **k):
         raise NotImplementedError(_NO_FORWARD.format('ConvBlock1D'))
@@ -156,6 +157,7 @@ class SignalEncoders(nn.Module):
         self.causal = causal
         self.chunk_causal = chunk_causal
         self.use_output_norm = output_norm
+        self.use_residual = use_residual
         self.initial_channels = initial_channels
         self.max_channels = max_channels
         encoders = {}
@@ -188,7 +190,7 @@ class SignalEncoders(nn.Module):
         dict signal -> [B, T]  ->  dict signal -> [B, S, feature_dim]; samples whose input row is -inf come back as -inf."""
         spec = EngineSpec(signal_map=dict(self.signal_map), feature_dim=self.feature_dim, initial_channels=self.initial_channels,
                           max_channels=self.max_channels, causal=self.causal, chunk_causal=self.chunk_causal, embed_signals=self.embed_signals,
-                          output_norm=self.use_output_norm)
+                          output_norm=self.use_output_norm, use_residual=self.use_residual)
         eng, ver = _standalone_engine(self, 'signal_encoders.', spec)
         e = eng.encode(x, save=False, pack_key=ver, cls=False)
         B, S, F = e['B'], e['S'], self.feature_dim
@@ -357,7 +359,7 @@ class Wav2Sleep(nn.Module):
             'signal_encoders': {'_target_': t + 'SignalEncoders', 'signal_map': dict(se.signal_map), 'feature_dim': se.feature_dim,
                                 'activation': 'gelu', 'norm': 'instance', 'causal': bool(se.causal), 'chunk_causal': bool(se.chunk_causal), 'embed_signals': bool(se.embed_signals),
                                 'initial_channels': se.initial_channels, 'max_channels': se.max_channels, 'output_norm': bool(se.use_output_norm),
-                                'use_residual': True},
+                                'use_residual': bool(se.use_residual)},
             'epoch_mixer': {'_target_': t + 'MultiModalAttentionEmbedder', 'feature_dim': em.feature_dim, 'dropout': em.dropout_p,
                             'activation': 'gelu', 'layers': em.num_layers, 'dim_ff': em.dim_ff, 'nhead': em.nhead,
                             'register_tokens': em.num_register_tokens},
@@ -407,7 +409,7 @@ class Wav2Sleep(nn.Module):
                           mixer_nhead=em.nhead, mixer_dim_ff=em.dim_ff, mixer_dropout=em.dropout_p, seq_blocks=sm.num_layers,
                           seq_dilations=sm.num_dilations, seq_kernel=sm.kernel_size, seq_dropout=sm.dropout_p, causal=se.causal,
                           chunk_causal=se.chunk_causal, seq_causal=sm.causal, embed_signals=se.embed_signals,
-                          register_tokens=em.num_register_tokens, output_norm=se.use_output_norm)
+                          register_tokens=em.num_register_tokens, output_norm=se.use_output_norm, use_residual=se.use_residual)
 
     def param_version(self) -> int:
         """Changes whenever any parameter was written (torch in-place ops bump `_version`; the fused AdamW kernel
