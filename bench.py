@@ -77,8 +77,14 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        # W2S_DIST_BACKEND=gloo: control-flow test of the multi-rank path with several ranks sharing one GPU (RCCL refuses that)
+        backend = os.environ.get('W2S_DIST_BACKEND', 'nccl')
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
@@ -126,19 +132,25 @@ def main():
                        'precision': "fp32 storage + fp32 accumulate; >=32-channel GEMMs as bf16x3 split products on the matrix cores "
                                     "(= the reference's float32_matmul_precision('high')); W2S_EXACT_FP32=1 for fp32 MFMA throughout"}}
 
-    if rank == 0 and not args.no_roofline:
-        # one extra, untimed step with a HIP event pair around every GEMM-shaped launch
-        # (single stream for this step: the timed steps overlap the four encoders on separate HIP streams, which inflates
+    agg = None
+    if not args.no_roofline:
+        # two extra, untimed steps, the second with a HIP event pair around every GEMM-shaped launch on rank 0.  EVERY rank runs
+        # them: a step contains the gradient all-reduce, so rank 0 stepping alone would leave its collectives unmatched.
+        # (single stream for these steps: the timed steps overlap the four encoders on separate HIP streams, which inflates
         #  every kernel's own duration; isolated durations are what a roofline fraction is about.  profiles/ holds the
         #  rocprofv3 summaries of both: `bench.py` as is, and with W2S_MULTI_STREAM=0 which this leg agrees with.)
         ms_flag = trainer.eng.multi_stream
         trainer.eng.multi_stream = False
         trainer.step(x, y)  # settle allocator / packs in single-stream mode
-        lib.TIMER = lib.LaunchTimer()
+        if rank == 0:
+            lib.TIMER = lib.LaunchTimer()
         trainer.step(x, y)
-        agg = lib.TIMER.summary()
-        lib.TIMER = None
+        if rank == 0:
+            agg = lib.TIMER.summary()
+            lib.TIMER = None
         trainer.eng.multi_stream = ms_flag
+        torch.cuda.synchronize()
+    if rank == 0 and agg is not None:
         total_ms = sum(d['ms'] for d in agg.values())
         key, d = max(agg.items(), key=lambda kv: kv[1]['ms'])
         avg_s = d['ms'] / d['launches'] / 1e3
