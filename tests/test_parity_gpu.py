@@ -187,6 +187,33 @@ def test_causal_sequence_mixer_ignores_the_future():
     assert not torch.equal(a[:, :48], b[:, :48])
 
 
+def test_train_steps_do_not_depend_on_how_far_the_host_runs_ahead():
+    """The per-step hyper-parameters (warm-up lr, bias corrections) travel through a pinned staging buffer with an asynchronous copy:
+    steps enqueued while the GPU is still busy must use their OWN values.  Same init, same batches: once with a sync after every
+    step, once enqueued back to back behind a long-running kernel -- bit-identical parameters."""
+    sm = {'ECG': 'ECG', 'THX': 'THX'}
+    cfg = O.ModelConfig(signal_map=sm, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=21)
+    batches = [O.make_inputs(cfg, 2, 6, seed=30 + i) for i in range(4)]
+    batches = [(to_dev(x), y.to(DEV)) for x, y in batches]
+    finals = []
+    for ahead in (False, True):
+        model = build(sm, 4)
+        model.load_state_dict(sd)
+        model.to(DEV).train()
+        tr = W.FusedTrainStep(model, warmup_steps=5)   # lr changes by 20 % per step during warm-up
+        torch.cuda.synchronize()
+        if ahead:
+            torch.cuda._sleep(int(1.5e9))   # ~0.7 s of GPU time: all four steps are enqueued before the first one starts
+        for x, y in batches:
+            tr.step(x, y)
+            if not ahead:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        finals.append(model._flat.clone())
+    assert torch.equal(finals[0], finals[1])
+
+
 def test_missing_modality_equals_subset_run_and_leaves_other_samples_untouched():
     cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
     model = build(SM4, 4)

@@ -124,7 +124,6 @@ class FusedTrainStep:
         self.nparts = 256
         self.sumsq = torch.empty(self.nparts, device=dev, dtype=torch.float32)
         self.hyper = torch.zeros(8, device=dev, dtype=torch.float32)
-        self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.normcoef = torch.zeros(2, device=dev, dtype=torch.float32)
         self.loss_out = torch.zeros(2, device=dev, dtype=torch.float32)
         nc = model.num_classes
@@ -148,9 +147,11 @@ class FusedTrainStep:
         self.step_count += 1
         k = self.step_count
         b1, b2 = self.betas
-        h = self.hyper_host
-        h[0], h[1], h[2], h[3], h[4] = self.lr_at(k), self.wd, b1, b2, self.eps
-        h[5], h[6], h[7] = 1 - b1 ** k, 1 - b2 ** k, self.max_norm if self.max_norm else 0.0
+        # A fresh pinned staging tensor per step: the host runs several steps ahead of the GPU, so re-using one buffer would let step
+        # k+1's values overwrite step k's before its asynchronous copy has run (the pinned allocator recycles a block only after the
+        # copies that read it have completed).
+        h = torch.tensor([self.lr_at(k), self.wd, b1, b2, self.eps, 1 - b1 ** k, 1 - b2 ** k, self.max_norm if self.max_norm else 0.0],
+                         dtype=torch.float32).pin_memory()
         self.hyper.copy_(h, non_blocking=True)
 
         eng.step_seed = model._next_seed()
