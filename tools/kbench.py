@@ -41,7 +41,7 @@ def wgrad_case(cin, cout, L, stride=1, taps=3, B=16, pro_g=lib.PRO_INBWD, pro_h=
     g = torch.randn(B, Lo, cout, device=dev); g2 = torch.randn(B, Lo, cout, device=dev); x = torch.randn(B, L, cin, device=dev)
     st = torch.rand(B, cout, 2, device=dev) + 0.5; bst = torch.rand(B, cout, 2, device=dev) * 0.01; xst = torch.rand(B, cin, 2, device=dev) + 0.5
     gy = lib.wgrad_grid_y(cin, cout, taps, 1)
-    gx = max(1, min((B * Lo + 255) // 256, max(1, 512 // gy))); nslab = gx * lib.wgrad_slabs_per_block(cin, cout, taps, 1)
+    gx = max(1, min((B * Lo + 255) // 256, max(1, int(os.environ.get('WGCAP', 512)) // gy))); nslab = gx * lib.wgrad_slabs_per_block(cin, cout, taps, 1)
     slab = torch.empty(nslab * cout * cin * taps, device=dev)
     fn = lambda: lib.wgrad(g=g, g2=g2, g_stats=st, g_bstats=bst, x=x, x_stats=xst, slab=slab, nslab=nslab, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout,
                            taps=taps, stride=stride, pad=1 if taps == 3 else 0, pro_g=pro_g, pro_h=pro_h, split_precision=os.environ.get('BF') == '1')
