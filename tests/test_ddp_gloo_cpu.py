@@ -57,3 +57,32 @@ def test_single_process_is_identity():
     assert torch.equal(red.flat, flat) and red.grad_scale == 1.0
     g, r, cm = reduce_metrics(torch.tensor([2.0, 4.0]), torch.eye(2, dtype=torch.long))
     assert float(g) == 2.0 and float(r) == 2.0 and cm.tolist() == [[1, 0], [0, 1]]
+
+
+def test_reduce_ranges_partition_the_flat_buffer():
+    """Every element of the flat gradient is all-reduced exactly once: the '_tail' range plus one range per encoder are disjoint,
+    contiguous and cover the buffer -- for the headline model and for the optional parameters (signal embedding, register tokens,
+    output norms, shared encoders, no residual branch)."""
+    import wav2sleep_amd as W
+    from wav2sleep_amd.ddp import flat_layout, reduce_ranges
+    cases = [
+        (dict(ABD='ABD', THX='THX', ECG='ECG', PPG='PPG'), {}, {}),
+        (dict(ABD='RESP', THX='RESP', ECG='ECG', PPG='PPG'), dict(embed_signals=True, output_norm=True), dict(register_tokens=2)),
+        ({'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, dict(use_residual=False), {}),
+        (dict(ECG='UNI'), dict(causal=True), {}),
+    ]
+    for sm, enc_kw, mix_kw in cases:
+        model = W.Wav2Sleep(W.SignalEncoders(sm, 128, 'gelu', norm='instance', chunk_causal=False, **enc_kw),
+                            W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.1, dim_ff=512, nhead=8, **mix_kw),
+                            W.SequenceCNN(128, dropout=0.1, norm='layer', num_layers=2, kernel_size=7, num_dilations=6), 4)
+        named = list(model.named_parameters())
+        layout, total = flat_layout([p.shape for _, p in named])
+        assert all(o % 4 == 0 for o, _, _ in layout) and total % 4 == 0
+        ranges = reduce_ranges(layout, [n for n, _ in named])
+        assert set(ranges) == {'_tail'} | set(sm.values())
+        cover = torch.zeros(total, dtype=torch.int32)
+        for lo, hi in ranges.values():
+            cover[lo:hi] += 1
+        assert bool((cover == 1).all()), (sm, int((cover == 0).sum()), int((cover > 1).sum()))
+        # the tail (everything outside the encoders) sits behind the encoders: it is final first and reduced first
+        assert ranges['_tail'][1] == total and all(hi <= ranges['_tail'][0] for k, (lo, hi) in ranges.items() if k != '_tail')

@@ -17,6 +17,30 @@ import torch
 import torch.distributed as dist
 
 
+def flat_layout(shapes) -> tuple[list, int]:
+    """(offset, numel, shape) of every parameter in ONE fp32 buffer, each slice starting on a 16-byte boundary; total length."""
+    layout, off = [], 0
+    for shape in shapes:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        layout.append((off, n, tuple(shape)))
+        off += (n + 3) // 4 * 4
+    return layout, off
+
+
+def reduce_ranges(layout, names) -> dict:
+    """Contiguous flat ranges in the order backward completes them: '_tail' = everything that is not inside an encoder (signal
+    embedding, set-fusion transformer, SequenceCNN, classifier -- final first), then one range per encoder as its backward ends.
+    The ranges are disjoint and cover the whole buffer (tests/test_ddp_gloo_cpu.py)."""
+    ranges = {}
+    for (o, n, _), name in zip(layout, names):
+        key = name.split('.')[2] if name.startswith('signal_encoders.encoders.') else '_tail'
+        lo, hi = ranges.get(key, (o, o))
+        ranges[key] = (min(lo, o), max(hi, o + (n + 3) // 4 * 4))
+    return ranges
+
+
 def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 

@@ -20,7 +20,7 @@ from torch.optim import Optimizer
 from torch.optim.lr_scheduler import LRScheduler
 
 from . import lib
-from .ddp import FlatGradReducer, reduce_metrics
+from .ddp import FlatGradReducer, reduce_metrics, reduce_ranges
 from .wav2sleep import Wav2Sleep
 
 
@@ -129,13 +129,7 @@ class FusedTrainStep:
         nc = model.num_classes
         self.cmat = torch.zeros(nc, nc, device=dev, dtype=torch.int64)
         self.reducer = FlatGradReducer(model._flat_grad, group=process_group)
-        # contiguous flat ranges in the order backward completes them: [mixer..classifier], then encoders as visited
-        names = [n for n, _ in model.named_parameters()]
-        self._range = {}
-        for (o, n, _), name in zip(model._layout, names):
-            key = name.split('.')[2] if name.startswith('signal_encoders.encoders.') else '_tail'
-            lo, hi = self._range.get(key, (o, o))
-            self._range[key] = (min(lo, o), max(hi, o + (n + 3) // 4 * 4))
+        self._range = reduce_ranges(model._layout, [n for n, _ in model.named_parameters()])
 
     def lr_at(self, step: int) -> float:
         return exp_warmup_lr(step, self.lr_max, self.warmup_steps, self.tau) if self.use_sched else self.lr_max

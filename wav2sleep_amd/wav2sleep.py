@@ -443,11 +443,8 @@ class Wav2Sleep(nn.Module):
                     break
         if ok:
             return
-        layout, off = [], 0
-        for _, p in named:
-            n = p.numel()
-            layout.append((off, n, tuple(p.shape)))
-            off += (n + 3) // 4 * 4
+        from .ddp import flat_layout
+        layout, off = flat_layout([p.shape for _, p in named])
         flat = torch.zeros(off, device=dev, dtype=torch.float32)
         gflat = torch.zeros(off, device=dev, dtype=torch.float32)
         P, G = {}, {}
