@@ -1,32 +1,20 @@
-"""Constants of the reference's `settings.py` restated (src/wav2sleep/settings.py:1-56)."""
+"""Names and sampling rates the path depends on (values of the reference's `settings.py`; the dataset names are the ones its
+validation loop keys on, `trainer/main.py:188-224`)."""
 
-PPG = 'PPG'
-ECG = 'ECG'
-ABD = 'ABD'
-THX = 'THX'
-EOG_L = 'EOG-L'
-EOG_R = 'EOG-R'
-LABEL = 'Stage'
-TIMESTAMP = 'Timestamp'
-PRED = 'Pred'
+# signal columns, grouped by samples per 30-second epoch (respiratory belts 256, cardiac 1024, EOG 4096)
+_SIGNALS_BY_RATE = {256: ('ABD', 'THX'), 1024: ('ECG', 'PPG'), 4096: ('EOG-L', 'EOG-R')}
+COLS_TO_SAMPLES_PER_EPOCH = {name: rate for rate, names in _SIGNALS_BY_RATE.items() for name in names}
+ABD, THX, ECG, PPG, EOG_L, EOG_R = (n for names in _SIGNALS_BY_RATE.values() for n in names)
+LOW_FREQ_SAMPLES_PER_EPOCH, MEDIUM_FREQ_SAMPLES_PER_EPOCH, HIGH_FREQ_SAMPLES_PER_EPOCH = sorted(_SIGNALS_BY_RATE)
 
-TRAINING_LENGTH_HOURS = 10
+# parquet / csv column names
+LABEL, TIMESTAMP, PRED = 'Stage', 'Timestamp', 'Pred'
 
-LOW_FREQ_SAMPLES_PER_EPOCH = 256
-MEDIUM_FREQ_SAMPLES_PER_EPOCH = 1024
-HIGH_FREQ_SAMPLES_PER_EPOCH = 4096
-COLS_TO_SAMPLES_PER_EPOCH = {
-    ABD: LOW_FREQ_SAMPLES_PER_EPOCH,
-    THX: LOW_FREQ_SAMPLES_PER_EPOCH,
-    ECG: MEDIUM_FREQ_SAMPLES_PER_EPOCH,
-    PPG: MEDIUM_FREQ_SAMPLES_PER_EPOCH,
-    EOG_L: HIGH_FREQ_SAMPLES_PER_EPOCH,
-    EOG_R: HIGH_FREQ_SAMPLES_PER_EPOCH,
-}
-
-INTEGER_LABEL_MAPS = {
-    4: {0: 0, 1: 1, 2: 1, 3: 2, 4: 3},
-    5: {0: 0, 1: 1, 2: 2, 3: 3, 4: 4},
-}
-
+TRAINING_LENGTH_HOURS = 10   # recordings are padded / cropped to this length for training
 TRAIN, VAL, TEST = 'train', 'val', 'test'
+
+# five annotated stages (W, N1, N2, N3, REM) -> class index; the 4-class problem merges N1 and N2 into "light"
+INTEGER_LABEL_MAPS = {
+    5: {stage: stage for stage in range(5)},
+    4: dict(zip(range(5), (0, 1, 1, 2, 3))),
+}
