@@ -367,13 +367,11 @@ def confusion_accuracy(cmat) -> float:
 
 
 def cohens_kappa(cmat, n_classes: int = 4) -> float:
-    """stats.py:14-30."""
-    cmat = np.asarray(cmat).astype(float)
-    sum0 = np.sum(cmat, axis=0)
-    sum1 = np.sum(cmat, axis=1)
-    expected = np.outer(sum0, sum1) / np.sum(sum0)
-    w = np.ones((n_classes, n_classes)) - np.eye(n_classes)
-    return float(1 - np.sum(w * cmat) / np.sum(w * expected))
+    """stats.py:14-30: 1 - (disagreement mass observed) / (disagreement mass of the chance table built from the marginals)."""
+    m = np.asarray(cmat, dtype=np.float64)
+    chance = np.outer(m.sum(axis=0), m.sum(axis=1)) / m.sum()
+    off_diag = 1.0 - np.eye(n_classes)   # every disagreement costs 1
+    return float(1.0 - (off_diag * m).sum() / (off_diag * chance).sum())
 
 
 def exp_warmup_lr(step: int, lr_max: float = 1e-3, warmup_steps: int = 2000, tau: float = 10000.0) -> float:
