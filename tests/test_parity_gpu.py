@@ -299,6 +299,23 @@ def test_full_size_properties_config2():
     assert int(cm.sum()) == B * S
 
 
+def test_ten_hour_recording_matches_oracle():
+    """The longest input `predict_on_folder` feeds by default (max_length_hours=10: 1200 epochs), one recording, all four
+    cardio-respiratory signals with one missing: logits against the CPU oracle, arg-max identical."""
+    cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=23)
+    x, _ = O.make_inputs(cfg, 1, 1200, seed=24, missing={'PPG': [0]})
+    model = build(SM4, 4)
+    model.load_state_dict(sd)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        got = model(to_dev(x)).cpu()
+        want = O.forward(sd, cfg, x)
+    assert got.shape == (1, 1200, 4)
+    assert_logits_close(got.numpy(), want.numpy())
+    assert torch.equal(got.argmax(-1), want.argmax(-1))
+
+
 def test_load_model_and_predict_roundtrip(tmp_path):
     import yaml
     cfg = {'_target_': 'wav2sleep.models.wav2sleep.Wav2Sleep', 'num_classes': 4,
