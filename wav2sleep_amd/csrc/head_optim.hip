@@ -263,4 +263,4 @@ extern "C" int w2s_swap(float* a, float* b, long n, void* stream) {
   return W2S_OK;
 }
 
-extern "C" const char* w2s_version(void) { return "w2s-hip 0.1 (gfx950, fp32 MFMA)"; }
+extern "C" const char* w2s_version(void) { return "w2s-hip 0.1 (gfx950; bf16x3 split-precision and fp32 MFMA)"; }
