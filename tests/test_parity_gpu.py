@@ -149,24 +149,26 @@ def test_autograd_path_matches_oracle(signal_map, nc, B, S, missing, causal):
 
 
 def test_chunk_causal_model_ignores_the_future():
-    """tests/model/test_causality.py of the reference, on the GELU / instance-norm / layer-norm modules this build has kernels for:
-    with per-epoch encoders and a causal sequence mixer the logits of a prefix do not depend on what follows (the reference runs it
-    at 20 h of ECG+PPG with batch norm in eval mode; 40 epochs already cross every receptive field boundary that matters here... the
-    causal mixer looks back 2*6*63 = 756 epochs, so S=40 vs S=20 exercises it fully)."""
+    """tests/model/test_causality.py of the reference at its own size (ECG + PPG, 1 228 800 samples = 1200 epochs against the first
+    half), on the modules this build has kernels for (GELU / instance norm / layer norm, F = 128; the reference instantiates batch
+    norm in eval mode, ReLU and F = 16): with per-epoch encoders and a causal sequence mixer the logits of a prefix do not depend
+    on what follows.  The reference asserts torch.allclose; here the prefix is bit-identical (fixed-order reductions)."""
     sm = {'ECG': 'ECG', 'PPG': 'PPG'}
     cfg = O.ModelConfig(signal_map=sm, num_classes=4, causal=True, chunk_causal=True)
     model = build(sm, 4, causal=True, chunk_causal=True)
     model.load_state_dict(O.make_state_dict(cfg, seed=5))
     model.to(DEV).eval()
     torch.manual_seed(1)
-    x = torch.randn(1, 40 * 1024, device=DEV)
-    x2 = x[:, :20 * 1024].contiguous()
+    L = 1_228_800
+    x = torch.randn(1, L, device=DEV)
+    x2 = x[:, : L // 2].contiguous()
     with torch.no_grad():
         y = model({'ECG': x, 'PPG': x})
         y2 = model({'ECG': x2, 'PPG': x2})
-    assert y2.shape[1] == 20
-    assert torch.allclose(y[:, :20], y2, rtol=1e-5, atol=1e-6)   # the reference asserts torch.allclose with default tolerances
-    assert torch.equal(y[:, :20], y2)                            # here it is bit-exact: fixed-order reductions, per-epoch statistics
+    L_out = y2.shape[1]
+    assert L_out == 600
+    assert torch.allclose(y[:, :L_out], y2[:, :L_out])
+    assert torch.equal(y[:, :L_out], y2)
 
 
 def test_causal_sequence_mixer_ignores_the_future():
