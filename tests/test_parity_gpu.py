@@ -171,6 +171,28 @@ def test_chunk_causal_model_ignores_the_future():
     assert torch.equal(y[:, :L_out], y2)
 
 
+def test_compile_calls_of_the_reference_are_accepted():
+    """tests/model/test_compile.py of the reference: `encoders.compile(fullgraph=True)` and `model.compile(mode='max-autotune',
+    fullgraph=True)` followed by a forward of 1 228 800 samples of ECG + PPG.  Nothing is generated here (the forward is hand-written
+    HIP), so the calls must be accepted and leave the results unchanged."""
+    sm = {'ECG': 'ECG', 'PPG': 'PPG'}
+    cfg = O.ModelConfig(signal_map=sm, num_classes=4)
+    model = build(sm, 4)
+    model.load_state_dict(O.make_state_dict(cfg, seed=6))
+    model.to(DEV).eval()
+    x = torch.randn(1, 1_228_800, device=DEV)
+    with torch.no_grad():
+        before = model({'ECG': x, 'PPG': x})
+    model.signal_encoders.compile(fullgraph=True)
+    model.compile(mode='max-autotune', fullgraph=True)
+    with torch.no_grad():
+        z = model.signal_encoders({'ECG': x, 'PPG': x})
+        after = model({'ECG': x, 'PPG': x})
+    assert set(z) == {'ECG', 'PPG'} and z['ECG'].shape == (1, 1200, 128)
+    assert torch.equal(before, after)
+    assert model.compiled_with['fullgraph'] is True
+
+
 def test_causal_sequence_mixer_ignores_the_future():
     """The property the reference's tests/model/test_causality.py checks (outputs for a prefix do not depend on what follows),
     on the part of the shipped causal configuration that has it: the causal SequenceCNN (the whole-recording instance norm of the

@@ -46,7 +46,8 @@ def _resolve_device(device: str) -> str:
 
 
 def load_model(folder: str, device: str = 'auto', compile: bool = False, revision: str | None = None, cache_dir: str | None = None):
-    """api.py:53-99.  `compile` is accepted and ignored: the hand-written kernels replace Inductor."""
+    """api.py:53-99.  `compile=True` calls `model.compile()` as the reference does (api.py:96-97); on these modules that records the
+    request and changes nothing (the forward already is hand-written gfx950 code)."""
     if str(folder).startswith('hf://'):
         raise NotImplementedError('Hugging Face Hub download needs network; pass a local folder with config.yaml + state_dict.pth')
     device = _resolve_device(device)
@@ -64,6 +65,8 @@ def load_model(folder: str, device: str = 'auto', compile: bool = False, revisio
         sd = {k[len('model.'):]: v for k, v in sd.items()}
     model.load_state_dict(sd)
     model.eval()
+    if compile:
+        model.compile()
     return model.to(device)
 
 

@@ -51,6 +51,18 @@ def _standalone_engine(module: nn.Module, prefix: str, spec: EngineSpec) -> Engi
     return module._w2s_engine[1], hash(key)
 
 
+class _HandWritten:
+    """`nn.Module.compile()` hook for the modules whose forward is a sequence of hand-written HIP launches: the reference calls
+    `model.compile()` / `encoders.compile(fullgraph=True)` (api.py:96-97, tests/model/test_compile.py); there is nothing for
+    Inductor to generate here, so the call is accepted, remembered and leaves the module as it is."""
+
+    compiled_with: dict | None = None
+
+    def compile(self, *args, **kwargs):
+        self.compiled_with = dict(args=args, **kwargs)
+        logger.info('%s.compile(%s): the forward already is hand-written gfx950 code; nothing to compile', type(self).__name__, kwargs)
+
+
 class ConvLayerNorm(nn.Module):
     """models/utils.py:9-23 (weights [1, C, 1])."""
 
@@ -145,7 +157,7 @@ class SignalEncoder(nn.Module):
         raise NotImplementedError(_NO_FORWARD.format('SignalEncoder'))
 
 
-class SignalEncoders(nn.Module):
+class SignalEncoders(_HandWritten, nn.Module):
     """models/wav2sleep.py:83-161."""
 
     def __init__(self, signal_map: dict[str, str], feature_dim: int, activation: str, norm: str = 'instance', causal: bool = False,
@@ -201,7 +213,7 @@ class SignalEncoders(nn.Module):
         return {k: out[k] for k in x}
 
 
-class MultiModalAttentionEmbedder(nn.Module):
+class MultiModalAttentionEmbedder(_HandWritten, nn.Module):
     """models/wav2sleep.py:270-346."""
 
     def __init__(self, feature_dim: int, layers: int = 4, dropout: float = 0.0, dim_ff: int = 512, activation: str = 'gelu',
@@ -258,7 +270,7 @@ class MultiModalAttentionEmbedder(nn.Module):
         return X.view(N, D * F)[:, :F].reshape(B, S, F).clone()
 
 
-class SequenceCNN(nn.Module):
+class SequenceCNN(_HandWritten, nn.Module):
     """models/wav2sleep.py:349-390."""
 
     def __init__(self, feature_dim: int = 128, dropout: float = 0.2, num_layers: int = 2, activation: str = 'gelu', norm: str = 'batch',
@@ -315,7 +327,7 @@ class _W2SFunction(torch.autograd.Function):
         return (None, None) + grads
 
 
-class Wav2Sleep(nn.Module):
+class Wav2Sleep(_HandWritten, nn.Module):
     """models/wav2sleep.py:16-80 -- same constructor, attributes and state_dict; compute on libw2s_hip.so."""
 
     def __init__(self, signal_encoders: SignalEncoders, epoch_mixer: MultiModalAttentionEmbedder, sequence_mixer: SequenceCNN,
