@@ -257,6 +257,10 @@ int w2s_swap(float* a, float* b, long n, void* stream);
 int w2s_zscore(const float* x, float* y, int rows, long T, double* part, int nblk, float eps, float* stats_out, void* stream);
 int w2s_augment(float* x, int B, long T, const float* sign, const uint8_t* keep, void* stream);
 int w2s_map_labels(const float* src, float* dst, long n, int num_classes, void* stream);
+/* HOST function (no GPU, no stream): causal EMA normalisation of one recording, the native counterpart of the reference's numba loop
+ * (data/normalization.py:18-80,106-230), fp64 in and out like that loop.  baseline_tau_seconds <= 0 means "same as tau_seconds"; outlier may be NULL. */
+int w2s_causal_normalize_host(const double* x, long n, double sampling_freq, double tau_seconds, double eps, double outlier_sigma,
+                              double baseline_tau_seconds, double min_sigma, double* out, uint8_t* outlier);
 
 const char* w2s_version(void);
 

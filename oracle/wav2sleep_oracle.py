@@ -485,3 +485,33 @@ def apply_masker(x: dict[str, Tensor], keep_draw: dict[str, Tensor], backup_pick
         v[~m_BC[:, j]] = float('-inf')
         out[s] = v
     return out
+
+
+def causal_rolling_normalize(signal, sampling_freq: float, tau_seconds: float = 900.0, eps: float = 1e-6, outlier_threshold_sigma: float = 4.0,
+                             baseline_tau_seconds: float | None = None, min_sigma: float = 0.1):
+    """data/normalization.py:18-80 (the EMA loop) and :106-230 (alphas, warm-up estimates, final division), as a plain Python loop over
+    a numpy array: -> (normalised fp64 array, outlier mask).  Slow by construction (checker for small inputs)."""
+    x = np.asarray(signal)
+    n = len(x)
+    if n == 0:
+        return x.astype(np.float64), np.zeros(0, dtype=bool)
+    tau_mu = tau_seconds if baseline_tau_seconds is None else baseline_tau_seconds
+    dt = 1.0 / sampling_freq
+    a_mu, a_var = dt / tau_mu, dt / tau_seconds
+    floor2 = min_sigma * min_sigma
+    warm = max(1, min(int(min(tau_mu, tau_seconds) * sampling_freq), n // 10))   # :190-195
+    mu = np.empty(n)
+    var = np.empty(n)
+    hit = np.zeros(n, dtype=bool)
+    mu[0] = float(np.mean(x[:warm]))
+    var[0] = max(max(float(np.var(x[:warm])), floor2), floor2, eps)              # :199 and :54
+    xs = x.astype(np.float64)
+    for t in range(1, n):
+        mu[t] = a_mu * xs[t] + (1.0 - a_mu) * mu[t - 1]
+        r = xs[t] - mu[t]
+        lim = outlier_threshold_sigma * math.sqrt(max(var[t - 1], floor2))
+        if abs(r) > lim:
+            hit[t] = True
+            r = lim if r > lim else -lim
+        var[t] = a_var * r * r + (1.0 - a_var) * var[t - 1]
+    return (x - mu) / np.sqrt(np.maximum(var, floor2)), hit

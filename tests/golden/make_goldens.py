@@ -183,6 +183,44 @@ def run_misc():
     print('misc: kappa', out['kappa'], 'acc', out['acc'], 'lrs', out['lr_values'][:5])
 
 
+def run_causal_norm():
+    """Golden vectors of `causal_rolling_normalize` from the reference module itself.  numba is not installed here; its only use in
+    data/normalization.py is the `@njit(cache=True)` decorator on the loop, so the module is imported with `numba.njit` bound to an
+    identity decorator and the reference's own loop body runs as plain Python (same arithmetic, fp64)."""
+    shim = types.ModuleType('numba')
+    shim.njit = lambda *a, **k: (lambda f: f)
+    sys.modules.setdefault('numba', shim)
+    data = types.ModuleType('wav2sleep.data'); data.__path__ = [REF + '/data']; sys.modules['wav2sleep.data'] = data
+    from wav2sleep.data.normalization import causal_rolling_normalize as ref_norm
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = {
+        # name: (samples per epoch, epochs, dtype, kwargs)
+        'ecg_drift': (1024, 24, np.float32, dict(tau_seconds=900.0, baseline_tau_seconds=120.0, min_sigma=0.1, outlier_threshold_sigma=4.0)),
+        'abd_spikes': (256, 40, np.float32, dict(tau_seconds=900.0, baseline_tau_seconds=120.0, min_sigma=0.1, outlier_threshold_sigma=4.0)),
+        'eog_default': (4096, 6, np.float64, dict()),
+        'flat_then_active': (256, 30, np.float32, dict(tau_seconds=300.0, min_sigma=0.1)),
+    }
+    for name, (spe, epochs, dtype, kw) in cases.items():
+        n = spe * epochs
+        t = np.arange(n) / (spe / 30.0)
+        x = rng.standard_normal(n) * (1.0 + 0.5 * np.sin(2 * np.pi * t / 300.0)) + 0.002 * t
+        if name == 'abd_spikes':
+            x[rng.integers(0, n, 40)] += rng.standard_normal(40) * 25.0
+        if name == 'flat_then_active':
+            x[: n // 3] = 0.25
+        x = x.astype(dtype)
+        y, m = ref_norm(x.copy(), sampling_freq=spe / 30.0, return_outlier_mask=True, **kw)
+        out[f'{name}.x'] = x
+        out[f'{name}.y'] = np.asarray(y)
+        out[f'{name}.mask'] = np.asarray(m)
+        out[f'{name}.spe'] = np.int64(spe)
+        for k, v in kw.items():
+            out[f'{name}.kw.{k}'] = np.float64(v)
+    np.savez_compressed(os.path.join(HERE, 'causal_norm.npz'), **out)
+    print('causal_norm:', {k: int(out[k + '.mask'].sum()) for k in cases})
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     for name in CASES:
@@ -190,3 +228,5 @@ if __name__ == '__main__':
             run_case(name)
     if not only or 'misc' in only:
         run_misc()
+    if not only or 'causal_norm' in only:
+        run_causal_norm()

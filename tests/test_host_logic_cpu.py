@@ -197,8 +197,9 @@ def test_parquet_dataset_matches_reference_contract(tmp_path):
         W.ParquetDataset([fp], columns=['PPG'])[0]                                              # no relevant column in the file
     with pytest.raises(ValueError):
         W.load_dataset(str(tmp_path / 'empty'), ['ECG'])
-    with pytest.raises(NotImplementedError):
-        W.ParquetDataset([fp], columns=['ECG'], causal=True)
+    causal = W.ParquetDataset([fp], columns=['ECG'], require_labels=False, causal=True)[0][0]['ECG']   # online EMA normalisation (dataset.py:165-167)
+    want, _ = O.causal_rolling_normalize(ecg.numpy(), 1024 / 30.0, tau_seconds=900.0, baseline_tau_seconds=120.0, min_sigma=0.1)
+    torch.testing.assert_close(causal, torch.from_numpy(want).float(), rtol=1e-5, atol=1e-6)
 
 
 def test_save_predictions_tree_timestamps_and_overwrite(tmp_path):

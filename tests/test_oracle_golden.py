@@ -118,3 +118,13 @@ def test_scheduler_kappa_confusion_masker():
     assert kept.tolist() == [[False, False, True, False], [False, False, False, True], [True, True, True, True]]
     with pytest.raises(ValueError):
         O.apply_masker(x, draws, backup_pick=torch.tensor([0, 0, 0]), backups=['ECG', 'PPG'])
+
+
+@pytest.mark.parametrize('name', ['ecg_drift', 'abd_spikes', 'eog_default', 'flat_then_active'])
+def test_causal_normalisation_matches_reference(name):
+    """oracle.causal_rolling_normalize against vectors produced by the reference's data/normalization.py (make_goldens.py:run_causal_norm)."""
+    g = load('causal_norm')
+    kw = {k.split('.kw.')[1]: float(g[k]) for k in g.files if k.startswith(name + '.kw.')}
+    y, m = O.causal_rolling_normalize(g[name + '.x'], sampling_freq=int(g[name + '.spe']) / 30.0, **kw)
+    assert np.array_equal(m, g[name + '.mask'])
+    np.testing.assert_allclose(y, g[name + '.y'].astype(np.float64), rtol=1e-5, atol=1e-6)

@@ -110,3 +110,48 @@ extern "C" int w2s_map_labels(const float* src, float* dst, long n, int num_clas
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Causal (online) normalisation of one recording -- HOST code, the native counterpart of the reference's numba loop
+// (data/normalization.py:18-80, 106-230): a running mean and a running variance by exponential moving averages with different
+// time constants, residuals beyond `outlier_sigma` running standard deviations clipped before they enter the variance, a floor
+// on sigma; out[t] = (x[t] - mu[t]) / sqrt(max(sigma2[t], min_sigma^2)).  The variance recurrence depends on its own previous
+// value through the clip, so the scan is sequential per recording; recordings are independent and the dataset workers (one file
+// each, as in the reference's DataLoader) call this through ctypes -- no GPU involved.  fp64 state like the reference's loop.
+// ---------------------------------------------------------------------------------------------------
+extern "C" int w2s_causal_normalize_host(const double* x, long n, double sampling_freq, double tau_seconds, double eps, double outlier_sigma,
+                                         double baseline_tau_seconds, double min_sigma, double* out, uint8_t* outlier) {
+  if (n == 0) return W2S_OK;
+  if (!x || !out || n < 0 || !(sampling_freq > 0.0) || !(tau_seconds > 0.0)) return W2S_EINVAL;
+  const double baseline_tau = baseline_tau_seconds > 0.0 ? baseline_tau_seconds : tau_seconds;
+  const double dt = 1.0 / sampling_freq, a_mu = dt / baseline_tau, a_var = dt / tau_seconds, floor2 = min_sigma * min_sigma;
+  // initial estimates from a warm-up prefix: min(tau) seconds, at most a tenth of the recording, at least one sample
+  long warm = (long)((baseline_tau < tau_seconds ? baseline_tau : tau_seconds) * sampling_freq);
+  if (warm > n / 10) warm = n / 10;
+  if (warm < 1) warm = 1;
+  double s = 0.0;
+  for (long i = 0; i < warm; ++i) s += x[i];
+  double mu = s / (double)warm, q = 0.0;
+  for (long i = 0; i < warm; ++i) { const double d = x[i] - mu; q += d * d; }
+  double var = q / (double)warm;   // population variance, as np.var
+  if (var < floor2) var = floor2;
+  if (var < eps) var = eps;
+  out[0] = (x[0] - mu) / sqrt(var > floor2 ? var : floor2);
+  if (outlier) outlier[0] = 0;
+  // The loop-carried chain is two multiply-adds (mu, var): the clip is decided on squares (|r| > k*sigma <=> r^2 > k^2*sigma^2), so no
+  // square root sits on it; the division by sigma for the output is off the chain and pipelines.
+  const double k2 = outlier_sigma * outlier_sigma;
+  for (long t = 1; t < n; ++t) {
+    const double xt = x[t];
+    mu = a_mu * xt + (1.0 - a_mu) * mu;
+    const double r = xt - mu;
+    double r2 = r * r;
+    const double lim2 = k2 * (var > floor2 ? var : floor2);
+    const bool clip = r2 > lim2;
+    if (clip) r2 = lim2;
+    if (outlier) outlier[t] = clip ? 1 : 0;
+    var = a_var * r2 + (1.0 - a_var) * var;
+    out[t] = r / sqrt(var > floor2 ? var : floor2);
+  }
+  return W2S_OK;
+}

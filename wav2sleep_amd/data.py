@@ -1,6 +1,6 @@
 """Parquet in -> `.preds.csv` out: the callers either side of the inference forward.
 
-Mirrors `ParquetDataset` (reference data/dataset.py:23-183, non-causal normalisation), `load_dataset`,
+Mirrors `ParquetDataset` (reference data/dataset.py:23-183; global z-score or, `causal=True`, the online EMA normalisation), `load_dataset`,
 `save_predictions` and `predict_on_folder` (api.py:141-160,193-301).  File discovery, truncation, the length
 consistency checks, label mapping, `-inf` padding of absent columns, output tree and CSV schema (index `Timestamp`
 = 30 s * k + 30, columns `Pred` [, `Stage`]) follow the reference line by line in behaviour.
@@ -44,12 +44,12 @@ def try_read_parquet(fp: str, columns: list[str] | None = None, max_retries: int
 
 
 class ParquetDataset(torch.utils.data.Dataset):
-    """data/dataset.py:23-186 with `causal=False`."""
+    """data/dataset.py:23-186 (`causal=True`: online EMA normalisation per recording instead of the global z-score, :89-130,165-167)."""
 
     def __init__(self, parquet_fps: list[str], columns: list[str], num_classes: int = 4, require_labels: bool = True,
                  max_length_hours: int | None = None, causal: bool = False, normalize_on_device: bool = False):
-        if causal:
-            raise NotImplementedError('causal rolling normalisation (data/normalization.py, numba) is not part of the hot path')
+        if causal and normalize_on_device:
+            raise ValueError('causal normalisation is a sequential scan per recording and runs in the dataset workers: normalize_on_device=False')
         self.files = parquet_fps
         self.columns = columns
         for col in self.columns:
@@ -74,6 +74,21 @@ class ParquetDataset(torch.utils.data.Dataset):
             std = torch.std(x)
             std = std if std > eps else torch.tensor(eps, dtype=x.dtype)
             out[k] = (x - mu) / std
+        return out
+
+    @staticmethod
+    def _causal_normalize(signals: dict) -> dict:
+        """Online EMA z-score, dataset.py:89-130: per signal with its own sampling rate; missing / non-finite signals pass through."""
+        from .inputs import causal_rolling_normalize
+        from .settings import (CAUSAL_NORM_BASELINE_TAU_SECONDS, CAUSAL_NORM_MIN_SIGMA, CAUSAL_NORM_TAU_SECONDS, NORM_OUTLIER_THRESHOLD)
+        out = {}
+        for k, x in signals.items():
+            if x.numel() == 0 or not torch.isfinite(x).all() or k not in COLS_TO_SAMPLES_PER_EPOCH:
+                out[k] = x
+                continue
+            out[k] = causal_rolling_normalize(x, sampling_freq=COLS_TO_SAMPLES_PER_EPOCH[k] / 30.0, tau_seconds=CAUSAL_NORM_TAU_SECONDS,
+                                              outlier_threshold_sigma=NORM_OUTLIER_THRESHOLD, baseline_tau_seconds=CAUSAL_NORM_BASELINE_TAU_SECONDS,
+                                              min_sigma=CAUSAL_NORM_MIN_SIGMA)
         return out
 
     def _signals(self, df, fp):
@@ -108,7 +123,9 @@ class ParquetDataset(torch.utils.data.Dataset):
         fp = self.files[idx]
         df = try_read_parquet(fp)
         present, n_epochs = self._signals(df, fp)
-        if not self.normalize_on_device:
+        if self.causal:
+            present = self._causal_normalize(present)
+        elif not self.normalize_on_device:
             present = self._zscore_normalize(present)
         kept = min(n_epochs, self.max_length_epochs)
         out = {}

@@ -62,3 +62,37 @@ def augment_(signals: dict[str, torch.Tensor], flip_polarity: bool = True, maske
         keep = keep_BC[:, j].to(torch.uint8).contiguous() if keep_BC is not None else None
         lib.augment(x, B, x.shape[1], sign, keep)
     return signals
+
+
+def causal_rolling_normalize(signal, sampling_freq: float, tau_seconds: float = 900.0, eps: float = 1e-6, outlier_threshold_sigma: float = 4.0,
+                             return_outlier_mask: bool = False, baseline_tau_seconds: float | None = None, min_sigma: float = 0.1):
+    """Causal EMA z-score of ONE recording (reference data/normalization.py:106-230, same arguments): running mean (time constant
+    `baseline_tau_seconds`) and running variance (`tau_seconds`) with residuals clipped at `outlier_threshold_sigma` sigma, sigma floored
+    at `min_sigma`.  numpy array or torch tensor in, the same type / dtype / device out.  The scan is sequential per recording, so it
+    runs on the host inside the dataset workers, as the reference's numba loop does: `w2s_causal_normalize_host` in the native library."""
+    import ctypes as C
+
+    import numpy as np
+    is_torch = isinstance(signal, torch.Tensor)
+    arr = signal.detach().cpu().numpy() if is_torch else np.asarray(signal)
+    n = int(arr.shape[0]) if arr.ndim else 0
+    if arr.ndim != 1:
+        raise ValueError(f'expected a 1-D signal, got shape {arr.shape}')
+    if n == 0:
+        mask = torch.zeros(0, dtype=torch.bool, device=signal.device) if is_torch else np.zeros(0, dtype=bool)
+        return (signal, mask) if return_outlier_mask else signal
+    x64 = np.ascontiguousarray(arr, dtype=np.float64)
+    out = np.empty(n, dtype=np.float64)
+    flags = np.empty(n, dtype=np.uint8)
+    fn = lib.load().w2s_causal_normalize_host
+    fn.argtypes = [C.c_void_p, C.c_long] + [C.c_double] * 6 + [C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+    rc = fn(x64.ctypes.data, n, float(sampling_freq), float(tau_seconds), float(eps), float(outlier_threshold_sigma),
+            float(baseline_tau_seconds) if baseline_tau_seconds is not None else -1.0, float(min_sigma), out.ctypes.data, flags.ctypes.data)
+    if rc != 0:
+        raise lib.W2SError(f'w2s_causal_normalize_host failed with code {rc}')
+    if is_torch:
+        res = torch.from_numpy(out).to(device=signal.device, dtype=signal.dtype)
+        return (res, torch.from_numpy(flags.astype(bool)).to(signal.device)) if return_outlier_mask else res
+    res = out.astype(arr.dtype) if np.issubdtype(arr.dtype, np.floating) else out
+    return (res, flags.astype(bool)) if return_outlier_mask else res

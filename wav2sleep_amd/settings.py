@@ -10,6 +10,12 @@ LOW_FREQ_SAMPLES_PER_EPOCH, MEDIUM_FREQ_SAMPLES_PER_EPOCH, HIGH_FREQ_SAMPLES_PER
 # parquet / csv column names
 LABEL, TIMESTAMP, PRED = 'Stage', 'Timestamp', 'Pred'
 
+# causal (online) normalisation of the dataset, `ParquetDataset(causal=True)`: seconds / sigmas
+CAUSAL_NORM_TAU_SECONDS = 900.0            # variance tracking
+CAUSAL_NORM_BASELINE_TAU_SECONDS = 120.0   # baseline (mean) tracking
+NORM_OUTLIER_THRESHOLD = 4.0               # residuals beyond this many sigma are clipped before they enter the variance
+CAUSAL_NORM_MIN_SIGMA = 0.1                # sigma floor
+
 TRAINING_LENGTH_HOURS = 10   # recordings are padded / cropped to this length for training
 TRAIN, VAL, TEST = 'train', 'val', 'test'
 
