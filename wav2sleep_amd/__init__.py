@@ -5,6 +5,7 @@ from .api import load_model, predict  # noqa: F401
 from .checkpoint import (EMACallback, lightning_checkpoint, load_lightning_checkpoint, save_lightning_checkpoint,  # noqa: F401
                          save_model)
 from .data import ParquetDataset, load_dataset, predict_on_folder, save_predictions  # noqa: F401
+from .inputs import causal_rolling_normalize  # noqa: F401
 from .stats import cohens_kappa, confusion_accuracy  # noqa: F401
 from .trainer import (ExpWarmUpScheduler, FusedTrainStep, SignalMasker, SleepLightningModule, SleepModule,  # noqa: F401
                       exp_warmup_lr, invert_signals)
@@ -13,4 +14,4 @@ from .wav2sleep import MultiModalAttentionEmbedder, SequenceCNN, SignalEncoders,
 __all__ = ['Wav2Sleep', 'SignalEncoders', 'MultiModalAttentionEmbedder', 'SequenceCNN', 'load_model', 'predict', 'FusedTrainStep',
            'SleepModule', 'SleepLightningModule', 'SignalMasker', 'invert_signals', 'ExpWarmUpScheduler', 'exp_warmup_lr',
            'cohens_kappa', 'confusion_accuracy', 'EMACallback', 'lightning_checkpoint', 'save_lightning_checkpoint',
-           'load_lightning_checkpoint', 'save_model', 'ParquetDataset', 'load_dataset', 'save_predictions', 'predict_on_folder']
+           'load_lightning_checkpoint', 'save_model', 'ParquetDataset', 'load_dataset', 'save_predictions', 'predict_on_folder', 'causal_rolling_normalize']
