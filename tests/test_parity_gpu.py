@@ -22,6 +22,7 @@ from oracle import wav2sleep_oracle as O  # noqa: E402  (checker only)
 from tests.golden_util import CASES, assert_summary_close, case_config, load  # noqa: E402
 
 DEV = 'cuda'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SM4 = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
 
 
@@ -640,6 +641,34 @@ def test_predict_on_folder_parquet_to_csv_matches_oracle(tmp_path):
         assert list(t['Stage']) == y.tolist()
     with pytest.raises(ValueError):
         W.predict_on_folder(str(src), str(out), model=model, signals=['EEG'], preprocess=False)
+
+
+@pytest.mark.skipif(not _have_parquet(), reason='pyarrow not importable on this box (parquet I/O is host-side plumbing; covered on CPU)')
+def test_predict_script_end_to_end(tmp_path, caplog):
+    """scripts/predict.py (the reference's CLI flags): exported model folder + parquet tree -> .preds.csv tree, kappa / accuracy logged."""
+    import importlib.util
+    import pandas as pd
+    from tests.test_host_logic_cpu import _write_recording
+    sm = {'ECG': 'ECG', 'THX': 'THX'}
+    cfg = O.ModelConfig(signal_map=sm, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=33)
+    model = build(sm, 4)
+    model.load_state_dict(sd)
+    W.save_model(str(tmp_path / 'model'), model)
+    for i, sub in enumerate(['x/a.parquet', 'y/b.parquet']):
+        _write_recording(str(tmp_path / 'pq' / sub), epochs=5, cols=('ECG', 'THX'), seed=50 + i)
+    spec = importlib.util.spec_from_file_location('w2s_predict_cli', os.path.join(ROOT, 'scripts', 'predict.py'))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    with caplog.at_level('INFO'):
+        rc = cli.main(['--input-folder', str(tmp_path / 'pq'), '--output-folder', str(tmp_path / 'out'), '--model-folder', str(tmp_path / 'model'),
+                       '--signals', 'ECG, THX', '--batch-size', '2', '--num-workers', '0', '--no-preprocess', '--compile'])
+    assert rc == 0 and 'kappa' in caplog.text
+    for sub in ('x/a', 'y/b'):
+        t = pd.read_csv(str(tmp_path / 'out' / (sub + '.preds.csv')))
+        assert list(t.columns) == ['Timestamp', 'Pred', 'Stage'] and len(t) == 5
+    with pytest.raises(SystemExit):
+        cli.main(['--input-folder', str(tmp_path / 'pq'), '--output-folder', str(tmp_path / 'out')])   # no model folder, no network
 
 
 @pytest.mark.parametrize('signal_map,B,S,missing', [
