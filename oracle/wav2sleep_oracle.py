@@ -420,21 +420,22 @@ def loss_and_grads(sd: dict, cfg: ModelConfig, x: dict, y: Tensor):
 
 
 def train_step(sd: dict, cfg: ModelConfig, x: dict, y: Tensor, opt_state: dict, max_norm: float = 1.0,
-               lr_max: float = 1e-3, wd: float = 1e-4):
+               lr_max: float = 1e-3, wd: float = 1e-4, lr: float | None = None):
     """One optimiser step as the Lightning loop runs it: fwd, CE, bwd, clip, AdamW, lr(k).
+    `lr` given: no scheduler (`scheduler: null`), that constant learning rate.
 
     Mutates `sd` and `opt_state` in place; returns (loss, logits, grad_norm, lr).
     """
     loss, logits, grads = loss_and_grads(sd, cfg, x, y)
     gn = clip_grad_norm(grads, max_norm)
-    lr = exp_warmup_lr(opt_state.get('step', 0) + 1, lr_max)
+    lr = exp_warmup_lr(opt_state.get('step', 0) + 1, lr_max) if lr is None else lr
     adamw_step(sd, grads, opt_state, lr, wd)
     return loss, logits, gn, lr
 
 
 def zscore_normalize(x_T: Tensor, eps: float = 1e-6) -> Tensor:
     """ParquetDataset._zscore_normalize for one recording -- data/dataset.py:76-87.
-    PARITY UNPINNED: data/dataset.py cannot be imported here (it pulls numba); restated from the source text."""
+    Pinned by tests/golden/dataset.npz (the reference's own function run by tests/golden/make_goldens_r2.py)."""
     if x_T.numel() == 0 or not torch.isfinite(x_T).all():
         return x_T
     mu = torch.mean(x_T)

@@ -58,3 +58,16 @@ def assert_summary_close(got: torch.Tensor, want: np.ndarray, rtol: float, atol:
     assert abs(s[0] - want[0]) <= rtol * scale + atol, f'{what} [sum] {s[0]} vs {want[0]}'
     assert abs(s[1] - want[1]) <= rtol * scale + atol, f'{what} [abs-sum] {s[1]} vs {want[1]}'
     assert abs(s[2] - want[2]) <= rtol * max(want[2], 1e-30) + atol, f'{what} [l2] {s[2]} vs {want[2]}'
+
+
+# ---- seeded gradient sequence of the optimiser golden (tests/golden/optim.npz): shared by the generator script and the GPU test ----
+OPT_SHAPES = [(16, 1, 3), (32, 16, 3), (48, 96), (128,), (1, 1, 128, 1), (4, 128), (4,), (1, 37, 1)]
+
+
+def grad_sequence(shapes, steps, seed):
+    g = torch.Generator().manual_seed(seed)
+    seq = []
+    for k in range(steps):
+        scale = [3.0, 0.02, 1.0, 0.3, 5.0, 0.05, 0.7, 1.5, 0.01, 2.0][k % 10]   # global norms above and below the clip threshold
+        seq.append([scale * torch.randn(s, generator=g) / (float(np.prod(s)) ** 0.5) for s in shapes])
+    return seq

@@ -86,6 +86,71 @@ def t_conv_split_precision():
                                    mode=lib.MODE_UP2))
     report('bf16x3 dgrad 128 s2', gx, cl(x.grad), tol=5e-5)
 
+def t_conv_wide():
+    """conv_wide_kernel (>= 64-channel k=3 layers, persistent, weights in registers) against the CPU ops it replaces: forward with the
+    GELU / IN+GELU prologues + statistics partials (stride 1 and 2), and the stride-1 data gradient with the instance-norm-backward
+    prologue, GELU' epilogue, residual add at even positions and backward statistics.  Lengths that are no multiple of the 64-position tile."""
+    B = 3
+    for (cin, cout, stride, pro, L) in [(32, 64, 1, lib.PRO_GELU, 1000), (64, 64, 1, lib.PRO_IN_GELU, 777), (64, 64, 2, lib.PRO_IN_GELU, 1302), (64, 128, 1, lib.PRO_GELU, 450),
+                                        (128, 128, 1, lib.PRO_IN_GELU, 333), (128, 128, 2, lib.PRO_IN_GELU, 514), (64, 64, 1, lib.PRO_GELU, 64), (128, 128, 1, lib.PRO_GELU, 130)]:
+        x = torch.randn(B, cin, L) * 1.5 + 0.3; w = torch.randn(cout, cin, 3) / math.sqrt(3 * cin)
+        if pro == lib.PRO_IN_GELU:
+            st = torch.stack([x.mean(2), 1 / torch.sqrt(x.var(2, unbiased=False) + 1e-2)], -1).to(dev)
+            h = F.gelu(F.instance_norm(x, eps=1e-2))
+        else:
+            st, h = None, F.gelu(x)
+        want = F.conv1d(h.double(), w.double(), stride=stride, padding=1).float()
+        Lo = want.shape[-1]
+        wp = pack_fwd(w).to(dev); wh, wl = lib.frag_major_planes(wp.view(cout, 3 * cin))
+        y = torch.zeros(B, Lo, cout, device=dev)
+        a = lib.conv_args(x=cl(x).to(dev), w=wp, w_hi=wh, w_lo=wl, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=3, stride=stride, pad=1, pro=pro,
+                          pro_stats=st, epi=lib.EPI_STATS)
+        tile = lib.conv_tile_of(a); nt = (Lo + tile - 1) // tile
+        part = torch.full((B, nt, 2, cout), float('nan'), device=dev); lib.set_part(a, part)
+        lib.conv_forward(a)
+        tag = f'wide fwd {cin}->{cout} s{stride} pro{pro} L{L}'
+        report(tag + f' (tile {tile})', y, cl(want), tol=5e-5)
+        RES.append((tag + ' uses the 64-position tile', tile == 64))
+        out = torch.zeros(B, cout, 2, device=dev); lib.stats_finalize(part, B, nt, cout, Lo, 1e-2, 0, out)
+        report(tag + ' mean', out[..., 0], want.mean(2), tol=2e-5); report(tag + ' rstd', out[..., 1], 1 / torch.sqrt(want.var(2, unbiased=False) + 1e-2), tol=5e-5)
+    # data gradient of y_k = conv(h), h = GELU(n_in): gout = (W^T gy [+ add_even]) * GELU'(n_in), gy = IN-backward(g; y_k)
+    for (cg, ch, L, aux_norm, add_even) in [(64, 64, 700, True, False), (128, 128, 260, True, False), (64, 32, 500, False, True), (128, 64, 322, False, True),
+                                            (64, 64, 129, False, True), (128, 128, 64, False, False)]:
+        g = torch.randn(B, cg, L) * 0.1; yk = torch.randn(B, cg, L) * 2 + 0.2
+        w = torch.randn(cg, ch, 3) / math.sqrt(3 * ch)            # forward weight [cout = cg][cin = ch][3]
+        aux = torch.randn(B, ch, L) * 1.3 - 0.1                   # the layer's input-side pre-norm / pre-activation tensor
+        mean, rstd = yk.mean(2, keepdim=True), 1 / torch.sqrt(yk.var(2, unbiased=False, keepdim=True) + 1e-2)
+        n = (yk - mean) * rstd
+        s1, s2 = g.mean(2, keepdim=True), (g * n).mean(2, keepdim=True)
+        gy = rstd * (g - s1 - n * s2)
+        d = F.conv_transpose1d(gy.double(), w.double(), stride=1, padding=1).float()   # W^T gy
+        ev = torch.randn(B, ch, L // 2) * 0.05 if add_even else None
+        if add_even:
+            d[:, :, 0:2 * (L // 2):2] += ev
+        if aux_norm:
+            am, ar = aux.mean(2, keepdim=True), 1 / torch.sqrt(aux.var(2, unbiased=False, keepdim=True) + 1e-2)
+            na = (aux - am) * ar
+        else:
+            na = aux
+        nad = na.double().requires_grad_(True); F.gelu(nad).sum().backward()
+        want = d * nad.grad.float()
+        wb = w.permute(1, 2, 0).contiguous().to(dev); wh, wl = lib.frag_major_planes(wb.view(ch, 3 * cg))
+        st = torch.stack([mean.squeeze(2), rstd.squeeze(2)], -1).to(dev); bst = torch.stack([s1.squeeze(2), s2.squeeze(2)], -1).to(dev)
+        ast = torch.stack([am.squeeze(2), ar.squeeze(2)], -1).to(dev) if aux_norm else None
+        gout = torch.zeros(B, L, ch, device=dev)
+        a = lib.conv_args(x=cl(g).to(dev), x2=cl(yk).to(dev), w=wb, w_hi=wh, w_lo=wl, y=gout, B=B, L_in=L, L_out=L, cin=cg, cout=ch, taps=3, stride=1, pad=1, flip=1,
+                          pro=lib.PRO_INBWD, pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=cl(aux).to(dev), aux_stats=ast,
+                          add_even=cl(ev).to(dev) if add_even else None)
+        tile = lib.conv_tile_of(a); nt = (L + tile - 1) // tile
+        part = torch.full((B, nt, 2, ch), float('nan'), device=dev); lib.set_part(a, part)
+        lib.conv_forward(a)
+        tag = f'wide dgrad {cg}->{ch} L{L} norm{int(aux_norm)} even{int(add_even)}'
+        report(tag + f' (tile {tile})', gout, cl(want), tol=5e-5)
+        RES.append((tag + ' uses the 64-position tile', tile == 64))
+        out = torch.zeros(B, ch, 2, device=dev); lib.stats_finalize(part, B, nt, ch, L, 0.0, 1, out)
+        report(tag + ' sum g', out[..., 0], want.mean(2), tol=2e-5); report(tag + ' sum g*n', out[..., 1], (want * na).mean(2), tol=2e-5)
+
+
 def t_conv_dilated():
     B, C, S = 2, 128, 200
     for d in (1, 4, 32):
@@ -262,10 +327,10 @@ def t_head_optim():
     n = 10007
     p = torch.randn(n); g = torch.randn(n) * 3
     sd = {'p': p.clone()}; st = {}
-    gg = {'p': g.clone()}; gn = O.clip_grad_norm(gg, 1.0); O.adamw_step(sd, gg, st, 5e-7)
+    gg = {'p': g.clone()}; gn = O.clip_grad_norm(gg, 1.0); O.adamw_step(sd, gg, st, 1e-3)   # lr 1e-3: the update (1e-3 per element) is 1000x the tolerance
     pd, gd, m, v = p.to(dev), g.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
     parts = torch.zeros(64, device=dev); lib.sumsq_partial(gd, n, parts, 64)
-    hyper = torch.tensor([5e-7, 1e-4, 0.9, 0.999, 1e-8, 1 - 0.9, 1 - 0.999, 1.0], device=dev); nc2 = torch.zeros(2, device=dev)
+    hyper = torch.tensor([1e-3, 1e-4, 0.9, 0.999, 1e-8, 1 - 0.9, 1 - 0.999, 1.0], device=dev); nc2 = torch.zeros(2, device=dev)
     lib.clip_coef(parts, 64, hyper, nc2); lib.adamw(pd, gd, m, v, n, hyper, nc2)
     report('grad norm', nc2[0], torch.tensor(gn)); report('adamw param', pd, sd['p'], tol=1e-6)
 
@@ -559,7 +624,7 @@ def t_inkernel_finalize():
     report('in-kernel finalize gp_stats', so, ref, tol=1e-6)
 
 
-STAGES = dict(causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(wide=t_conv_wide, causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

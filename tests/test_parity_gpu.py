@@ -35,16 +35,19 @@ def build(signal_map, nc, dropout=0.0, causal=False, chunk_causal=False, embed_s
 
 
 def assert_logits_close(got, want):
+    """north_star: logits within 1e-3 rtol.  Max norm (|d| <= 1e-3 max|logit|) AND element-wise rtol 1e-3 with an absolute floor of
+    2e-4 of the logit scale (a logit that is itself ~0 has no relative error to speak of)."""
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
-    err, scale = np.abs(got - want).max(), np.abs(want).max()
-    assert err <= 1e-3 * scale, (err, scale)
+    err, scale = np.abs(got - want), np.abs(want).max()
+    assert err.max() <= 1e-3 * scale, (err.max(), scale)
+    assert (err <= 1e-3 * np.abs(want) + 2e-4 * scale).all(), (float((err - 1e-3 * np.abs(want)).max()), scale)
 
 
 def to_dev(x):
     return {k: v.to(DEV) for k, v in x.items()}
 
 
-@pytest.mark.parametrize('stage', ['conv', 'split', 'causal', 'fin', 'fwdfused', 'fusedbf', 'fold', 'first', 'batch', 'stats', 'dil', 'dgrad', 'wgrad', 'rowops', 'attn', 'head'])
+@pytest.mark.parametrize('stage', ['wide', 'conv', 'split', 'causal', 'fin', 'fwdfused', 'fusedbf', 'fold', 'first', 'batch', 'stats', 'dil', 'dgrad', 'wgrad', 'rowops', 'attn', 'head'])
 def test_kernels_against_cpu_torch(stage):
     """Every C-ABI kernel family against the stock CPU op it replaces (tests/gpu_check.py)."""
     from tests import gpu_check as G
@@ -567,12 +570,17 @@ def test_resume_from_a_torch_adamw_checkpoint_matches_the_oracle_continuation():
           'gradient_clip_val': 1.0, 'gradient_clip_algorithm': 'norm'}
     _, mod = _small_module(seed=99)
     W.load_lightning_checkpoint(ck, mod, restore_rng=False)
+    before = {k: v.clone() for k, v in sd.items()}
     loss_o, _, gn_o, lr_o = O.train_step(sd, cfg, x, y, st)
     out = mod.trainer.step(to_dev(x), y.to(DEV))
     assert out['lr'] == pytest.approx(lr_o) and float(out['loss']) == pytest.approx(float(loss_o), rel=1e-4)
     assert float(out['grad_norm']) == pytest.approx(gn_o, rel=2e-3)
-    for k, v in mod.model.state_dict().items():
-        torch.testing.assert_close(v.cpu(), sd[k], rtol=0, atol=2e-6)
+    # the third step moves the weights by ~lr = 1.5e-6: compare the MOVEMENT (relative L2 over all weights), so that wrong moments, a
+    # wrong step counter or a skipped update (each >= 30 % off) cannot hide inside an absolute tolerance of the movement's own size
+    new = mod.model.state_dict()
+    num = sum(float(((new[k].cpu() - before[k]) - (sd[k] - before[k])).double().pow(2).sum()) for k in sd)
+    den = sum(float((sd[k] - before[k]).double().pow(2).sum()) for k in sd)
+    assert den > 0 and (num / den) ** 0.5 <= 0.03, (num / den) ** 0.5
 
 
 def test_save_model_folder_is_what_load_model_reads(tmp_path):

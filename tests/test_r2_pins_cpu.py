@@ -1,0 +1,82 @@
+"""CPU pins added in round 2: restatements that were "parity unpinned" are now held against vectors produced by the reference itself
+(tests/golden/make_goldens_r2.py): the default initialisation under seed 42, the oracle on near-tied default-init logits,
+`ParquetDataset` / `_zscore_normalize` on committed parquet files."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import wav2sleep_amd as W
+from oracle import wav2sleep_oracle as O
+from tests.golden_util import GOLDEN_DIR, load
+
+SM4 = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
+
+
+def default_init_model(dropout=0.1):
+    """The build's parameter containers under scripts/config/main.yaml:35's seed, constructed as scripts/config/model/wav2sleep.yaml does."""
+    torch.manual_seed(42)
+    return W.Wav2Sleep(W.SignalEncoders(SM4, 128, 'gelu', norm='instance', causal=False, chunk_causal=False),
+                       W.MultiModalAttentionEmbedder(128, layers=2, dropout=dropout, dim_ff=512, nhead=8),
+                       W.SequenceCNN(128, dropout=dropout, norm='layer', causal=False, num_layers=2, kernel_size=7, num_dilations=6), 4)
+
+
+def test_default_init_equals_the_reference_init_under_seed_42():
+    """183 tensors, same names, same order, same values as the REFERENCE model built under torch.manual_seed(42) (checksums stored by
+    make_goldens_r2.py from the reference's own modules): the containers draw from the RNG exactly as the reference's modules do."""
+    g = load('default_init')
+    sd = default_init_model().state_dict()
+    assert list(sd.keys()) == [str(n) for n in g['names']]
+    got_abs = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    got_sum = np.array([float(v.double().sum()) for v in sd.values()])
+    got_first = np.array([float(v.flatten()[0]) for v in sd.values()])
+    np.testing.assert_array_equal(got_abs, g['abs_sums'])
+    np.testing.assert_array_equal(got_sum, g['sums'])
+    np.testing.assert_array_equal(got_first, g['first'])
+
+
+@pytest.mark.parametrize('tag,B,S,seed,missing', [('a', 2, 16, 4242, None), ('b', 3, 8, 4243, {'ABD': [0], 'ECG': [1], 'PPG': [2]})])
+def test_oracle_on_default_init_matches_reference_logits(tag, B, S, seed, missing):
+    """Near-tied logits (top-2 margin down to 3e-3): the oracle reproduces the reference's logits to fp32 round-off and its arg-max exactly."""
+    g = load('default_init')
+    cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
+    sd = {k: v.detach().clone() for k, v in default_init_model().state_dict().items()}
+    x, _ = O.make_inputs(cfg, B, S, seed=seed, missing=missing)
+    lg = O.forward(sd, cfg, x)
+    np.testing.assert_allclose(lg.numpy(), g[f'logits_{tag}'], rtol=1e-5, atol=2e-6)
+    assert np.array_equal(lg.argmax(-1).numpy(), g[f'pred_{tag}'])
+    assert float(g[f'margin_{tag}'].min()) < 0.02   # the case is what it claims to be
+
+
+def test_zscore_normalize_matches_reference():
+    """data/dataset.py:76-87 run by the reference on finite / constant / -inf / empty / NaN-carrying inputs."""
+    g = load('dataset')
+    names = sorted({k.split('.', 2)[2] for k in g.files if k.startswith('zs.in.')})
+    assert set(names) == {'a', 'const', 'inf', 'empty', 'tiny', 'one_nan'}
+    sig = {k: torch.from_numpy(g[f'zs.in.{k}']) for k in names}
+    got = W.ParquetDataset._zscore_normalize({k: v.clone() for k, v in sig.items()})
+    for k in names:
+        np.testing.assert_array_equal(got[k].numpy(), g[f'zs.out.{k}'], err_msg=k)
+        if sig[k].numel() and torch.isfinite(sig[k]).all():
+            np.testing.assert_allclose(O.zscore_normalize(sig[k]).numpy(), g[f'zs.out.{k}'], rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.parametrize('name,labels', [('full', True), ('no_ppg', True), ('flat_thx', False)])
+@pytest.mark.parametrize('nc', [4, 5])
+@pytest.mark.parametrize('mlh', [None, 0])
+def test_parquet_dataset_matches_reference(name, labels, nc, mlh):
+    """`ParquetDataset.__getitem__` (data/dataset.py:132-183) of the reference on the committed parquet files: key order, z-scored
+    signals, -inf padding of absent columns, label mapping (4 / 5 classes, out-of-map stage -> -1), truncation."""
+    pytest.importorskip('pyarrow')
+    g = load('dataset')
+    fp = os.path.join(GOLDEN_DIR, 'dataset', name + '.parquet')
+    ds = W.ParquetDataset([fp], columns=['ABD', 'THX', 'ECG', 'PPG'], num_classes=nc, require_labels=labels, max_length_hours=mlh)
+    x, y = ds[0]
+    tag = f'{name}.nc{nc}.mlh{mlh}'
+    assert list(x.keys()) == [str(k) for k in g[f'ds.{tag}.keys']]
+    for k, v in x.items():
+        np.testing.assert_array_equal(v.numpy(), g[f'ds.{tag}.x.{k}'], err_msg=k)
+        assert v.dtype == torch.float32
+    np.testing.assert_array_equal(y.numpy(), g[f'ds.{tag}.y'])
+    assert y.dtype == torch.float32

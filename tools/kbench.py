@@ -23,18 +23,20 @@ def conv_case(cin, cout, L, stride=1, pro=lib.PRO_IN_GELU, epi=lib.EPI_STATS, B=
     st = torch.rand(B, cin, 2, device=dev) + 0.5; bst = torch.rand(B, cin, 2, device=dev) * 0.01
     ost = torch.rand(B, cout, 2, device=dev) + 0.5
     aux = torch.randn(B, Lo, cout, device=dev) if epi in (lib.EPI_GP, lib.EPI_AUX_INGELU_ADD) else None
-    a0 = lib.ConvArgs(); a0.cin, a0.cout, a0.taps, a0.stride, a0.mode, a0.B, a0.L_out = cin, cout, taps, stride, mode, B, Lo
-    tile = lib.load().w2s_conv_tile(__import__('ctypes').byref(a0))
-    part = torch.empty(B, (Lo + tile - 1) // tile, 2, cout, device=dev)
     wh = wl = None
     if os.environ.get('BF') == '1':
         wh, wl = lib.frag_major_planes(w.view(cout, taps * cin))
     a = lib.conv_args(w_hi=wh, w_lo=wl, x=x, x2=x2 if pro >= lib.PRO_INBWD else None, w=w, y=y, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride,
                       pad=(1 if taps == 3 else 0) if pad is None else pad, dil=dil, bias=torch.randn(cout, device=dev) if epi == lib.EPI_BIAS else None, flip=flip, mode=mode, pro=pro, epi=epi, pro_stats=st, pro_bstats=bst, aux=aux, aux_stats=ost if aux is not None else None,
-                      part=part if epi in (lib.EPI_STATS, lib.EPI_GP) else None)
+                      part=None)
+    tile = lib.conv_tile_of(a)
+    part = torch.empty(B, (Lo + tile - 1) // tile, 2, cout, device=dev)
+    if epi in (lib.EPI_STATS, lib.EPI_GP):
+        lib.set_part(a, part)
+    keep = (x, x2, w, y, st, bst, ost, aux, part, wh, wl)   # the descriptor holds raw pointers
     nbytes = 4 * (B * L * cin * (2 if pro >= lib.PRO_INBWD else 1) + B * Lo * cout * (2 if aux is not None else 1))
     flops = 2 * B * Lo * cout * cin * (1.5 if mode == lib.MODE_UP2 else taps)
-    return (lambda: lib.conv_forward(a)), nbytes, flops
+    return (lambda keep=keep: lib.conv_forward(a)), nbytes, flops
 
 def wgrad_case(cin, cout, L, stride=1, taps=3, B=16, pro_g=lib.PRO_INBWD, pro_h=lib.PRO_IN_GELU):
     Lo = L // stride
@@ -102,6 +104,10 @@ CASES = {
     'f64': lambda: conv_case(64, 64, 61440),
     'd64': lambda: conv_case(64, 64, 61440, pro=lib.PRO_INBWD, epi=lib.EPI_GP, flip=1),
     'w64': lambda: wgrad_case(64, 64, 61440),
+    'f64s2': lambda: conv_case(64, 64, 61440, stride=2),
+    'f3264': lambda: conv_case(32, 64, 61440, pro=lib.PRO_GELU),
+    'f64128': lambda: conv_case(64, 128, 15360, pro=lib.PRO_GELU),
+    'f128s2': lambda: conv_case(128, 128, 15360, stride=2),
     'f128': lambda: conv_case(128, 128, 15360),
     'f128n': lambda: conv_case(128, 128, 15360, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN),
     'f64n': lambda: conv_case(64, 64, 61440, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN),

@@ -14,8 +14,13 @@ int w2s_conv_dispatch_44d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_33d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_up2(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_tile_impl(int cin, int cout, int taps, int stride, int mode, int B, int L_out);
+int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry);   // conv_wide.hip: 1 = not a wide-kernel shape
 
-extern "C" int w2s_conv_tile(const w2s_conv_args* a) { return w2s_conv_tile_impl(a->cin, a->cout, a->taps, a->stride, a->mode, a->B, a->L_out); }
+// positions per workgroup tile of the kernel that w2s_conv_forward(a) will launch (`a` filled as for the launch; y / part may be NULL)
+extern "C" int w2s_conv_tile(const w2s_conv_args* a) {
+  if (w2s_conv_wide_try(*a, nullptr, 1) == 0) return 64;
+  return w2s_conv_tile_impl(a->cin, a->cout, a->taps, a->stride, a->mode, a->B, a->L_out);
+}
 
 extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
   if (!ap) return W2S_EINVAL;
@@ -55,6 +60,10 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
     return W2S_EINVAL;
   }
   if (a.dil != 1) return W2S_EINVAL;
+  if (a.taps == 3) {   // >= 64-channel encoder layers: persistent kernel with register-resident weights (conv_wide.hip)
+    const int rc = w2s_conv_wide_try(a, s, 0);
+    if (rc != 1) return rc;
+  }
   if (a.taps == 3 && a.stride == 1) return w2s_conv_dispatch_31(a, s);
   if (a.taps == 3 && a.stride == 2) return w2s_conv_dispatch_32(a, s);
   if (a.taps == 1 && a.stride == 2) return w2s_conv_dispatch_12(a, s);

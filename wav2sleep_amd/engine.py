@@ -222,6 +222,20 @@ class Engine:
             kw['w_hi'], kw['w_lo'] = planes
         lib.conv_forward(lib.conv_args(**kw))
 
+    def _conv_part(self, *, B, L_out, cout, kind, **kw):
+        """A conv launch that also produces per-tile statistics partials: asks the library which kernel takes THIS descriptor (its tile
+        sizes the partials), allocates them, launches.  -> finalised statistics [B][cout][2] (kind 0: mean/rstd, 1: backward sums)."""
+        planes = self._bf.get(kw['w'].data_ptr()) if self.split_precision else None
+        if planes is not None:
+            kw['w_hi'], kw['w_lo'] = planes
+        so, sc = self._fin(B, cout, kw['x'].device)
+        a = lib.conv_args(B=B, L_out=L_out, cout=cout, part=None, stat_out=so, stat_cnt=sc, stat_eps=self.spec.instance_eps, **kw)
+        nt = _cdiv(L_out, lib.conv_tile_of(a))
+        part = torch.empty(B, nt, 2, cout, device=kw['x'].device, dtype=torch.float32)
+        lib.set_part(a, part)
+        lib.conv_forward(a)
+        return so if so is not None else self._finalize(part, B, nt, cout, L_out, kind)
+
     def _conv_stats(self, *, x, w, B, L_in, L_out, cin, cout, stride, pro, pro_stats=None, x2=None):
         """k=3 encoder conv writing the pre-norm tensor + instance-norm statistics (blocks.py:174-183)."""
         dev = x.device
@@ -235,14 +249,8 @@ class Engine:
             lib.conv_fwd_fused(x=x, w=w, st_in=pro_stats, w1=x2, y=y, part=part, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, stride=stride,
                                pro=pro, nwg=1024 if cin == 16 else 512, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps)
             return y, (so if so is not None else self._finalize(part, B, nt, cout, L_out, 0))
-        tile = lib.conv_tile(cin, cout, 3, stride, lib.MODE_CONTIG, B, L_out)
-        nt = _cdiv(L_out, tile)
-        part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
-        so, sc = self._fin(B, cout, dev)
-        self._conv(x=x, x2=x2, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=self.kpad, pro=pro,
-                   pro_stats=pro_stats, epi=lib.EPI_STATS, part=part, stat_out=so, stat_cnt=sc, stat_eps=self.spec.instance_eps,
-                   **({'ldx': 4} if pro == lib.PRO_FIRST else {}))
-        return y, (so if so is not None else self._finalize(part, B, nt, cout, L_out, 0))
+        return y, self._conv_part(x=x, x2=x2, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=self.kpad, pro=pro,
+                                  pro_stats=pro_stats, epi=lib.EPI_STATS, kind=0, **({'ldx': 4} if pro == lib.PRO_FIRST else {}))
 
     def _linear(self, x, w, bias, rows, cin, cout, ldx=None, y=None, ldy=None):
         """y[rows, cout] = x[rows, cin(*k)] @ w^T + bias; cin > 128 runs as k = cin/128 strided taps."""
@@ -682,11 +690,21 @@ class Engine:
             g.add_(tmp.t()) if rt in self._written else g.copy_(tmp.t())
             self._written.add(rt)
 
+        encs = [ec['enc'] for ec in c['enc']]
+        if not accumulate:
+            # encoders whose signals are not in this batch get no backward: their gradient is zero.  Written here, BEFORE any range is
+            # handed to the reducer, so that nothing touches a range on the compute stream once its all-reduce may be in flight.
+            for name, g in self.G.items():
+                if name.startswith('signal_encoders.encoders.') and name.split('.')[2] not in encs:
+                    g.zero_()
+                    self._written.add(name)
         if hook is not None:
             hook('_tail')  # mixer + sequence CNN + classifier gradients are final: their all-reduce can start
+            for e in dict.fromkeys(sp.signal_map.values()):
+                if e not in encs:
+                    hook(e)   # absent encoder: its (zero) range still takes part in the collective, the bucket layout is static
 
         # ---- encoders
-        encs = [ec['enc'] for ec in c['enc']]
         main = torch.cuda.current_stream(dev)
         for m, ec in enumerate(c['enc']):
             st = self._side_stream(ec['enc'], dev)
@@ -700,9 +718,9 @@ class Engine:
             main.wait_stream(self._side_stream(e, dev))
 
         if not accumulate:
-            for name, g in self.G.items():
-                if name not in self._written:
-                    g.zero_()
+            missing = [name for name in self.G if name not in self._written]
+            if missing:
+                raise RuntimeError(f'backward left gradients unwritten: {missing[:4]}')
         self.ctx = None
 
     def _ln_bwd(self, pfx, g, x, rstat, gadd, gx, rows):
@@ -773,22 +791,14 @@ class Engine:
                                       xin=ec['x'] if first else blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B,
                                       Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None)
             else:
-                tile = lib.conv_tile(c, c, 3, 2, lib.MODE_UP2, B, L)
-                nt = _cdiv(L, tile)
-                part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
-                self._conv(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
-                           pad=self.kpad, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP, aux=blk['y2'],
-                           aux_stats=blk['st2'], part=part, stat_out=(fin := self._fin(B, c, dev))[0], stat_cnt=fin[1])
-                bs2 = fin[0] if fin[0] is not None else self._bstats(part, B, nt, c, L)
+                bs2 = self._conv_part(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
+                                      pad=self.kpad, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP,
+                                      aux=blk['y2'], aux_stats=blk['st2'], kind=1)
                 self._wgrad(p + 'conv3.conv.weight', g=gpre, g2=blk['y3'], g_stats=blk['st3'], g_bstats=bs3, pro_g=lib.PRO_INBWD_GP, x=blk['y2'],
                             x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=self.kpad)
-                tile = lib.conv_tile(c, c, 3, 1, lib.MODE_CONTIG, B, L)
-                nt = _cdiv(L, tile)
-                part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
-                self._conv(x=gn2, x2=blk['y2'], w=PB[p + 'conv2.conv.weight'], y=gn1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1,
-                           pad=2 - self.kpad, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st2'], pro_bstats=bs2, epi=lib.EPI_GP, aux=blk['y1'],
-                           aux_stats=blk['st1'], part=part, stat_out=(fin := self._fin(B, c, dev))[0], stat_cnt=fin[1])
-                bs1 = fin[0] if fin[0] is not None else self._bstats(part, B, nt, c, L)
+                bs1 = self._conv_part(x=gn2, x2=blk['y2'], w=PB[p + 'conv2.conv.weight'], y=gn1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1,
+                                      pad=2 - self.kpad, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st2'], pro_bstats=bs2, epi=lib.EPI_GP,
+                                      aux=blk['y1'], aux_stats=blk['st1'], kind=1)
                 self._wgrad(p + 'conv2.conv.weight', g=gn2, g2=blk['y2'], g_stats=blk['st2'], g_bstats=bs2, pro_g=lib.PRO_INBWD, x=blk['y1'],
                             x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=self.kpad)
             del gn2

@@ -25,7 +25,8 @@ def zscore_normalize(signals: dict[str, torch.Tensor], eps: float = 1e-6) -> dic
         nblk = max(1, min(256, T // 4096))
         part = torch.empty(B * nblk * 3, device=x.device, dtype=torch.float64)
         y = torch.empty_like(x)
-        lib.zscore(x, y, B, T, part, nblk, eps)
+        with torch.cuda.device(x.device):
+            lib.zscore(x, y, B, T, part, nblk, eps)
         out[k] = y
     return out
 
@@ -43,7 +44,8 @@ def map_labels(stages: torch.Tensor, num_classes: int) -> torch.Tensor:
     """AASM stages {0..4, NaN} -> float labels in {0..num_classes-1, -1} (settings.py:52-56, dataset.py:174-182)."""
     src = stages.contiguous().float()
     dst = torch.empty_like(src)
-    lib.map_labels(src, dst, src.numel(), num_classes)
+    with torch.cuda.device(src.device):
+        lib.map_labels(src, dst, src.numel(), num_classes)
     return dst
 
 
@@ -60,7 +62,8 @@ def augment_(signals: dict[str, torch.Tensor], flip_polarity: bool = True, maske
         assert x.is_contiguous() and x.dtype == torch.float32
         sign = (2 * torch.randint(0, 2, (B,), dtype=torch.float, device=dev) - 1) if flip_polarity else None
         keep = keep_BC[:, j].to(torch.uint8).contiguous() if keep_BC is not None else None
-        lib.augment(x, B, x.shape[1], sign, keep)
+        with torch.cuda.device(dev):
+            lib.augment(x, B, x.shape[1], sign, keep)
     return signals
 
 

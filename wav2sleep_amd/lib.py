@@ -94,16 +94,27 @@ def _chk(rc: int, what: str):
         raise W2SError(f'{what} failed with code {rc} ({ {-1: "EINVAL", -2: "ELAUNCH"}.get(rc, "?")})')
 
 
+_last_dev = None   # device index of the most recent tensor argument (checked against the launch stream's device in _stream)
+
+
 def _p(t):
+    global _last_dev
     if t is None:
         return None
     if not t.is_cuda:
         raise W2SError('wav2sleep_amd kernels need device tensors (no CPU path)')
+    _last_dev = t.device.index
     return C.c_void_p(t.data_ptr())
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current device's current stream.  Every entry point evaluates its tensor arguments first, so `_last_dev` is the device
+    the buffers live on: a launch onto another device's stream (cuda:1 tensors while cuda:0 is current) raises instead of faulting.
+    Callers bracket their work with `torch.cuda.device(tensor.device)` (Wav2Sleep.forward, FusedTrainStep.step, inputs.*)."""
+    s = torch.cuda.current_stream()
+    if _last_dev is not None and s.device_index != _last_dev:
+        raise W2SError(f'tensors live on cuda:{_last_dev} but the current device is cuda:{s.device_index}: run under torch.cuda.device(...)')
+    return C.c_void_p(s.cuda_stream)
 
 
 def _f(t):
@@ -132,10 +143,20 @@ def conv_args(*, x, w, y, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, f
 
 
 def conv_tile(cin, cout, taps, stride, mode=MODE_CONTIG, B=0, L_out=0) -> int:
-    """Positions per workgroup tile (sizes the statistics partials); depends on the problem size for short sequences."""
+    """Positions per workgroup tile of the generic kernel (depends on the problem size for short sequences)."""
     a = ConvArgs()
     a.cin, a.cout, a.taps, a.stride, a.mode, a.B, a.L_out = cin, cout, taps, stride, mode, B, L_out
     return load().w2s_conv_tile(C.byref(a))
+
+
+def conv_tile_of(a: ConvArgs) -> int:
+    """Positions per tile of the kernel that conv_forward(a) will launch (sizes the statistics partials [B][ntiles][2][cout]): which
+    kernel takes a launch depends on the whole descriptor (the >= 64-channel persistent kernel uses 64-position tiles)."""
+    return load().w2s_conv_tile(C.byref(a))
+
+
+def set_part(a: ConvArgs, part):
+    a.part = _f(part)
 
 
 class LaunchTimer:
@@ -181,6 +202,12 @@ def conv_forward(a: ConvArgs):
     nbytes = 4 * (in_el + out_el * (2 if a.y2 else 1) + (out_el if a.aux else 0) + (out_el // 2 if a.add_even else 0))
     taps_eff = 1.5 if a.mode == MODE_UP2 else a.taps
     flops = int(2 * out_el * a.cin * taps_eff)
+    if a.taps == 3 and a.mode == MODE_CONTIG and a.w_hi and load().w2s_conv_tile(C.byref(a)) == 64 and a.cout >= 32 and max(a.cin, a.cout) >= 64 \
+            and (a.epi, bool(a.flip)) in ((EPI_STATS, False), (EPI_GP, True)):
+        key = f'conv_wide_kernel<{a.cin // 16}, {a.cout // 16}, {a.stride}, {a.pro}, {a.epi}>'
+        if DETAIL:
+            key += f' L{a.L_out}'
+        return _timed(key, nbytes, flops, run)
     nt = 8 if a.cout >= 128 else 4 if a.cout >= 64 else 2 if a.cout >= 32 else 1
     wn = 2 if nt >= 4 else 1
     tm = load().w2s_conv_tile(C.byref(a))

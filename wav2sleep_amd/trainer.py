@@ -106,21 +106,32 @@ class FusedTrainStep:
 
     loss = CrossEntropy(mean over labels != -1) per rank; DDP = mean of per-rank gradients (SURVEY 8e);
     clip_grad_norm_(max_norm) on the reduced gradient; AdamW(lr_k, wd); lr_k from ExpWarmUp at step k.
+
+    `accumulate=k` = Lightning's `accumulate_grad_batches=k`, how the reference reaches its effective batch 16 when one
+    micro-batch does not fit (scripts/train.py:59-76): every call of `step()` is one micro-batch whose loss is scaled by 1/k,
+    gradients add up in the flat buffer, and the all-reduce (Lightning's `no_sync` on the first k-1), clip, AdamW and
+    scheduler step run on the k-th call only.  `step_count` counts optimiser steps, as `trainer.global_step` does.
     """
 
     def __init__(self, model: Wav2Sleep, lr: float = 1e-3, weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 max_norm: float = 1.0, warmup_steps: int = 2000, tau: float = 10000.0, process_group=None, scheduler: bool = True):
+                 max_norm: float = 1.0, warmup_steps: int = 2000, tau: float = 10000.0, process_group=None, scheduler: bool = True,
+                 accumulate: int = 1):
         self.model = model
         model._ensure_flat()
         self.eng = model._engine
         flat = model._flat
         self.n = flat.numel()
         dev = flat.device
+        self.device = dev
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
         self.lr_max, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         self.warmup_steps, self.tau, self.use_sched = warmup_steps, tau, scheduler
-        self.step_count = 0
+        if accumulate < 1:
+            raise ValueError(f'accumulate must be >= 1, got {accumulate}')
+        self.accumulate = int(accumulate)
+        self.micro = 0       # micro-batches seen since the last optimiser step
+        self.step_count = 0  # optimiser steps
         self.nparts = 256
         self.sumsq = torch.empty(self.nparts, device=dev, dtype=torch.float32)
         self.hyper = torch.zeros(8, device=dev, dtype=torch.float32)
@@ -130,14 +141,24 @@ class FusedTrainStep:
         self.cmat = torch.zeros(nc, nc, device=dev, dtype=torch.int64)
         self.reducer = FlatGradReducer(model._flat_grad, group=process_group)
         self._range = reduce_ranges(model._layout, [n for n, _ in model.named_parameters()])
+        self.sync_parameters()
+
+    def sync_parameters(self):
+        """Rank 0's weights and AdamW moments to every rank (Lightning DDP broadcasts the module at construction; call again
+        after loading a checkpoint on rank 0 only).  A no-op at world size 1."""
+        if self.reducer.world > 1:
+            import torch.distributed as dist
+            src = dist.get_global_rank(self.reducer.group, 0) if self.reducer.group is not None else 0
+            for t in (self.model._flat, self.m, self.v):
+                dist.broadcast(t, src=src, group=self.reducer.group)
+            self.model.mark_params_dirty()
 
     def lr_at(self, step: int) -> float:
         return exp_warmup_lr(step, self.lr_max, self.warmup_steps, self.tau) if self.use_sched else self.lr_max
 
-    def step(self, x: dict[str, torch.Tensor], y: torch.Tensor) -> dict:
-        """x: dict signal -> [B, T] (device, fp32, -inf rows = missing modality); y: [B, S] float labels, -1 = ignore."""
-        model, eng = self.model, self.eng
-        model._ensure_flat()
+    def apply_optimizer(self) -> float:
+        """Global-norm clip + AdamW on the flat gradient buffer as it stands (3 launches); advances `step_count`; returns the lr used."""
+        model = self.model
         self.step_count += 1
         k = self.step_count
         b1, b2 = self.betas
@@ -146,29 +167,45 @@ class FusedTrainStep:
         # copies that read it have completed).
         h = torch.tensor([self.lr_at(k), self.wd, b1, b2, self.eps, 1 - b1 ** k, 1 - b2 ** k, self.max_norm if self.max_norm else 0.0],
                          dtype=torch.float32).pin_memory()
-        self.hyper.copy_(h, non_blocking=True)
-
-        eng.step_seed = model._next_seed()
-        logits = eng.forward(x, train=True, save=True, pack_key=model.param_version())
-        B, S, nc = logits.shape
-        rows = B * S
-        yv = y.reshape(rows)
-        if yv.dtype != torch.float32:
-            yv = yv.float()
-        part = torch.empty((rows + 255) // 256, 2, device=logits.device, dtype=torch.float32)
-        glogits = torch.empty(rows, nc, device=logits.device, dtype=torch.float32)
-        self.cmat.zero_()
-        lib.ce_fwd_bwd(logits, yv.contiguous(), rows, nc, part, self.loss_out, glogits, self.cmat, self.reducer.grad_scale)
-        if self.reducer.world > 1 or self.reducer.force:
-            eng.backward(glogits, hook=self._on_ready)
-            self.reducer.wait()
-        else:
-            eng.backward(glogits)
-        lib.sumsq_partial(model._flat_grad, self.n, self.sumsq, self.nparts)
-        lib.clip_coef(self.sumsq, self.nparts, self.hyper, self.normcoef)
-        lib.adamw(model._flat, model._flat_grad, self.m, self.v, self.n, self.hyper, self.normcoef)
+        with torch.cuda.device(self.device):
+            self.hyper.copy_(h, non_blocking=True)
+            lib.sumsq_partial(model._flat_grad, self.n, self.sumsq, self.nparts)
+            lib.clip_coef(self.sumsq, self.nparts, self.hyper, self.normcoef)
+            lib.adamw(model._flat, model._flat_grad, self.m, self.v, self.n, self.hyper, self.normcoef)
         model.mark_params_dirty()
-        return dict(loss=self.loss_out[0], count=self.loss_out[1], grad_norm=self.normcoef[0], cmat=self.cmat, logits=logits, lr=float(h[0]))
+        return float(h[0])
+
+    def step(self, x: dict[str, torch.Tensor], y: torch.Tensor) -> dict:
+        """x: dict signal -> [B, T] (device, fp32, -inf rows = missing modality); y: [B, S] float labels, -1 = ignore.
+        With accumulate = k > 1 this is one micro-batch; the returned dict has `stepped` = whether the optimiser ran."""
+        model, eng = self.model, self.eng
+        model._ensure_flat()
+        first = self.micro == 0
+        self.micro += 1
+        last = self.micro == self.accumulate
+        with torch.cuda.device(self.device):
+            eng.step_seed = model._next_seed()
+            logits = eng.forward(x, train=True, save=True, pack_key=model.param_version())
+            B, S, nc = logits.shape
+            rows = B * S
+            yv = y.reshape(rows)
+            if yv.dtype != torch.float32:
+                yv = yv.float()
+            part = torch.empty((rows + 255) // 256, 2, device=logits.device, dtype=torch.float32)
+            glogits = torch.empty(rows, nc, device=logits.device, dtype=torch.float32)
+            self.cmat.zero_()
+            lib.ce_fwd_bwd(logits, yv.contiguous(), rows, nc, part, self.loss_out, glogits, self.cmat, self.reducer.grad_scale / self.accumulate)
+            if last and (self.reducer.world > 1 or self.reducer.force):
+                eng.backward(glogits, accumulate=not first, hook=self._on_ready)
+                self.reducer.wait()
+            else:
+                eng.backward(glogits, accumulate=not first)
+        out = dict(loss=self.loss_out[0], count=self.loss_out[1], cmat=self.cmat, logits=logits, stepped=last)
+        if last:
+            self.micro = 0
+            out['lr'] = self.apply_optimizer()
+            out['grad_norm'] = self.normcoef[0]
+        return out
 
     def _on_ready(self, stage: str):
         lo, hi = self._range.get(stage, (0, 0))
@@ -179,16 +216,22 @@ class FusedTrainStep:
         return reduce_metrics(self.loss_out, self.cmat, self.reducer.group)
 
 
-def confusion_matrix_from_logits(logits: torch.Tensor, labels: torch.Tensor, num_classes: int) -> torch.Tensor:
-    """argmax + MulticlassConfusionMatrix(ignore_index=-1) on the device (trainer/main.py:49-59): rows true, cols pred."""
+def _loss_and_counts(logits: torch.Tensor, labels: torch.Tensor, num_classes: int):
+    """(loss_out [mean CE over labels != -1, count], confusion matrix [C, C] int64: rows true, cols pred) of one batch, on the device."""
     rows = logits.numel() // num_classes
     dev = logits.device
     part = torch.empty((rows + 255) // 256, 2, device=dev, dtype=torch.float32)
     out = torch.zeros(2, device=dev, dtype=torch.float32)
     cm = torch.zeros(num_classes, num_classes, device=dev, dtype=torch.int64)
-    lib.ce_fwd_bwd(logits.reshape(rows, num_classes).contiguous().float(), labels.reshape(rows).float().contiguous(), rows, num_classes, part, out,
-                   None, cm, 1.0)
-    return cm
+    with torch.cuda.device(dev):
+        lib.ce_fwd_bwd(logits.reshape(rows, num_classes).contiguous().float(), labels.reshape(rows).float().contiguous(), rows, num_classes, part, out,
+                       None, cm, 1.0)
+    return out, cm
+
+
+def confusion_matrix_from_logits(logits: torch.Tensor, labels: torch.Tensor, num_classes: int) -> torch.Tensor:
+    """argmax + MulticlassConfusionMatrix(ignore_index=-1) on the device (trainer/main.py:49-59): rows true, cols pred."""
+    return _loss_and_counts(logits, labels, num_classes)[1]
 
 
 class SleepModule:
@@ -200,7 +243,7 @@ class SleepModule:
     def __init__(self, model: Wav2Sleep, criterion=None, optimizer=None, aux_metrics=None, scheduler=None, debug_level=2,
                  on_step: bool = False, on_epoch: bool = True, num_classes: int = 4, masker: SignalMasker | None = None,
                  flip_polarity: bool = True, causal: bool = False, lr: float = 1e-3, weight_decay: float = 1e-4, max_norm: float = 1.0,
-                 process_group=None):
+                 process_group=None, accumulate_grad_batches: int = 1):
         self.model = model
         self.num_classes = num_classes
         self.masker = masker if isinstance(model, Wav2Sleep) else None
@@ -208,7 +251,8 @@ class SleepModule:
         self.causal = causal
         self.unified = len(model.signal_encoders) > 1
         self.aux_outputs = {mode: defaultdict(lambda: defaultdict(lambda: 0)) for mode in ('train', 'val', 'test')}
-        self.trainer = FusedTrainStep(model, lr=lr, weight_decay=weight_decay, max_norm=max_norm, process_group=process_group)
+        self.trainer = FusedTrainStep(model, lr=lr, weight_decay=weight_decay, max_norm=max_norm, process_group=process_group,
+                                      accumulate=accumulate_grad_batches)   # Trainer(accumulate_grad_batches=...), scripts/train.py:59-76
 
     def on_after_batch_transfer(self, batch, training: bool = True):
         x, y = batch
@@ -232,12 +276,7 @@ class SleepModule:
             x = {s: x[s] for s in signals}
         self.model.eval()
         logits = self.model(x)
-        rows = logits.shape[0] * logits.shape[1]
-        dev = logits.device
-        part = torch.empty((rows + 255) // 256, 2, device=dev, dtype=torch.float32)
-        out = torch.zeros(2, device=dev, dtype=torch.float32)
-        cm = torch.zeros(self.num_classes, self.num_classes, device=dev, dtype=torch.int64)
-        lib.ce_fwd_bwd(logits, y.reshape(rows).float().contiguous(), rows, self.num_classes, part, out, None, cm, 1.0)
+        out, cm = _loss_and_counts(logits, y, self.num_classes)
         _, _, cm = reduce_metrics(out, cm, self.trainer.reducer.group)
         prefix = '_'.join(signals) if signals is not None else (None if self.unified else '_'.join(x.keys()))
         self.aux_outputs[mode][prefix][ds_name] += cm
@@ -263,11 +302,7 @@ class SleepModule:
         logits = self.model.forward_subsets(x, subsets)
         losses = {}
         for sub, lg in logits.items():
-            rows = lg.shape[0] * lg.shape[1]
-            part = torch.empty((rows + 255) // 256, 2, device=lg.device, dtype=torch.float32)
-            out = torch.zeros(2, device=lg.device, dtype=torch.float32)
-            cm = torch.zeros(self.num_classes, self.num_classes, device=lg.device, dtype=torch.int64)
-            lib.ce_fwd_bwd(lg, y.reshape(rows).float().contiguous(), rows, self.num_classes, part, out, None, cm, 1.0)
+            out, cm = _loss_and_counts(lg, y, self.num_classes)
             _, _, cm = reduce_metrics(out, cm, self.trainer.reducer.group)
             prefix = '_'.join(sub) if sub is not None else (None if self.unified else '_'.join(x.keys()))
             self.aux_outputs[mode][prefix][ds_name] += cm

@@ -204,7 +204,8 @@ class SignalEncoders(_HandWritten, nn.Module):
                           max_channels=self.max_channels, causal=self.causal, chunk_causal=self.chunk_causal, embed_signals=self.embed_signals,
                           output_norm=self.use_output_norm, use_residual=self.use_residual)
         eng, ver = _standalone_engine(self, 'signal_encoders.', spec)
-        e = eng.encode(x, save=False, pack_key=ver, cls=False)
+        with torch.cuda.device(next(self.parameters()).device):   # kernels go to the current device's stream: make it the parameters' device
+            e = eng.encode(x, save=False, pack_key=ver, cls=False)
         B, S, F = e['B'], e['S'], self.feature_dim
         out = {}
         for m, sig in enumerate(e['sigs']):
@@ -257,8 +258,9 @@ class MultiModalAttentionEmbedder(_HandWritten, nn.Module):
         if D > 7:
             raise ValueError(f'{len(signals)} signals + {R1} CLS/register tokens: the attention kernels hold at most 7 tokens per epoch')
         tokens = torch.empty(N, D, F, device=first.device, dtype=torch.float32)
-        for r in range(R1):
-            lib.add_rows(tokens.view(-1)[r * F:], D * F, eng.P['epoch_mixer.register_tokens'].view(-1)[r:], R1, None, 1, N, F, False)
+        with torch.cuda.device(first.device):
+            for r in range(R1):
+                lib.add_rows(tokens.view(-1)[r * F:], D * F, eng.P['epoch_mixer.register_tokens'].view(-1)[r:], R1, None, 1, N, F, False)
         pads = [torch.zeros(B, dtype=torch.bool, device=first.device)] * R1
         for m, sig in enumerate(signals):  # host-side plumbing of [B,S,F] tensors: mask detection, zero fill, token slot copy
             z = z_dict[sig].float()
@@ -266,7 +268,8 @@ class MultiModalAttentionEmbedder(_HandWritten, nn.Module):
             tokens[:, R1 + m, :] = torch.where(m_B[:, None, None], 0.0, z).reshape(N, F)
             pads.append(m_B)
         keypad = torch.stack(pads, dim=1).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
-        X, _ = eng.mix(tokens, keypad, self.dropout_p if self.training else 0.0, save=False)
+        with torch.cuda.device(first.device):
+            X, _ = eng.mix(tokens, keypad, self.dropout_p if self.training else 0.0, save=False)
         return X.view(N, D * F)[:, :F].reshape(B, S, F).clone()
 
 
@@ -295,10 +298,11 @@ class SequenceCNN(_HandWritten, nn.Module):
                           seq_kernel=self.kernel_size, seq_dropout=self.dropout_p, seq_causal=self.causal)
         eng, ver = _standalone_engine(self, 'sequence_mixer.', spec)
         from . import lib
-        eng.ensure_packed(ver, need_bwd=False)
-        pre, _ = eng.seq(x_BSF.float().contiguous(), F, B, S, self.dropout_p if self.training else 0.0, save=False)
-        out = torch.empty_like(pre)
-        lib.eltwise(lib.ELT_GELU, pre, None, out, pre.numel())
+        with torch.cuda.device(x_BSF.device):
+            eng.ensure_packed(ver, need_bwd=False)
+            pre, _ = eng.seq(x_BSF.float().contiguous(), F, B, S, self.dropout_p if self.training else 0.0, save=False)
+            out = torch.empty_like(pre)
+            lib.eltwise(lib.ELT_GELU, pre, None, out, pre.numel())
         return out
 
 
@@ -310,7 +314,8 @@ class _W2SFunction(torch.autograd.Function):
         save = any(ctx.needs_input_grad[2:])  # (grad mode is off inside Function.forward)
         eng = model._engine
         eng.step_seed = model._next_seed() if model.training else 0
-        logits = eng.forward(x, train=model.training, save=save, pack_key=model.param_version())
+        with torch.cuda.device(model._flat.device):   # launches take the CURRENT device's stream (lib._stream)
+            logits = eng.forward(x, train=model.training, save=save, pack_key=model.param_version())
         ctx.model = model
         ctx.saved = eng.ctx
         eng.ctx = None
@@ -321,7 +326,8 @@ class _W2SFunction(torch.autograd.Function):
         model = ctx.model
         eng = model._engine
         eng.ctx = ctx.saved
-        eng.backward(glogits.contiguous().float())
+        with torch.cuda.device(model._flat.device):
+            eng.backward(glogits.contiguous().float())
         gflat = model._flat_grad.clone()  # fresh storage per backward: autograd may keep or accumulate these views
         grads = tuple(gflat[o:o + n].view(shape) for (o, n, shape) in model._layout)
         return (None, None) + grads
@@ -343,7 +349,7 @@ class Wav2Sleep(_HandWritten, nn.Module):
         self._flat_grad = None
         self._engine: Engine | None = None
         self._layout = []
-        self._seed_base = 0x5eed
+        self._seed_base = torch.initial_seed() & 0x7FFFFFFF   # dropout masks follow torch.manual_seed (checkpointed as `w2s_seed_state`)
         self._seed_ctr = 0
         self._param_epoch = 0
 
@@ -388,8 +394,12 @@ class Wav2Sleep(_HandWritten, nn.Module):
         all signals, ECG, ECG+THX, PPG, PPG+THX); the encoders are >95 % of the forward, and a subset only changes which
         tokens enter the set-fusion transformer, so the encoder outputs are computed once and re-used.
         subsets: iterable of tuples of signal names (None = all signals of `x`).  -> {subset: logits [B, S, nc]}"""
-        from . import lib
         self._ensure_flat()
+        with torch.cuda.device(self._flat.device):
+            return self._forward_subsets(x, subsets)
+
+    def _forward_subsets(self, x, subsets) -> dict:
+        from . import lib
         eng = self._engine
         e = eng.encode(x, save=False, pack_key=self.param_version())
         tokens, B, S, F = e['tokens'], e['B'], e['S'], self.feature_dim
