@@ -19,7 +19,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('$OUT/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name'][:60]
-        if 'conv_cl' in k or 'wgrad_' in k or 'bwd_fused' in k:
+        if 'conv_cl' in k or 'wgrad_' in k or 'bwd_fused' in k or 'conv_wide' in k or 'conv_fwd' in k:
             agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,d in agg.items():
     print(k)

@@ -18,7 +18,7 @@ int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry);   // conv
 
 // positions per workgroup tile of the kernel that w2s_conv_forward(a) will launch (`a` filled as for the launch; y / part may be NULL)
 extern "C" int w2s_conv_tile(const w2s_conv_args* a) {
-  if (w2s_conv_wide_try(*a, nullptr, 1) == 0) return 64;
+  { const int t = w2s_conv_wide_try(*a, nullptr, 1); if (t > 1) return t; }
   return w2s_conv_tile_impl(a->cin, a->cout, a->taps, a->stride, a->mode, a->B, a->L_out);
 }
 
@@ -48,7 +48,7 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
   if (a.mode == W2S_MODE_DILATED) {
     if (a.taps == 7 && a.stride == 1) {
       // whole dilated window (64-position tile + 6*dil halo rows, hi/lo planes or fp32) in LDS: single staging
-      if (a.dil >= 1 && (size_t)(64 + 6 * a.dil) * (a.cin + 8) * 4 <= 150 * 1024 && !getenv("W2S_SEQ_PER_TAP")) {
+      if (a.dil >= 1 && (size_t)(64 + 6 * a.dil) * (a.cin + 16) * 4 <= 150 * 1024 && !getenv("W2S_SEQ_PER_TAP")) {
         w2s_conv_args b = a;
         b.mode = W2S_MODE_CONTIG;
         return w2s_conv_dispatch_71(b, s);

@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include "w2s_common.h"
 
+__host__ __device__ constexpr int conv_bf_pad(int cin, int stride, int mode) { return (cin == 16 || (stride == 2 && mode == W2S_MODE_CONTIG)) ? 8 : 16; }
+
 struct ConvP {
   w2s_conv_args a;
   int ntiles;
@@ -71,7 +73,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
   const int b = blockIdx.z, tile = blockIdx.x, n0 = blockIdx.y * (NT * 16);
   const int t0 = tile * TM;
   const int cin = a.cin, RS = cin + 4, c4n = cin >> 2, rstep = 256 / c4n;
-  const int RSE = cin + 8;  // BF: bf16 elements per LDS row (16 B pad)
+  // BF: bf16 elements per LDS row.  +32 B makes the 16-lane groups of the stride-1 B-operand ds_read_b128 hit 16 distinct 16-B slots
+  // (+16 B rows were 2-way conflicted: SQ_LDS_BANK_CONFLICT = 48 % of SQ_LDS_IDX_ACTIVE); rows read 2 apart (stride 2) want +16 B
+  const int RSE = cin + conv_bf_pad(cin, STRIDE, MODE);
   __bf16* hiL = reinterpret_cast<__bf16*>(smem);
   __bf16* loL = hiL + P.nr_lds * RSE;
   const int K = TAPS * cin;
@@ -414,7 +418,7 @@ static int launch_conv(const w2s_conv_args& a, hipStream_t s) {
   P.ntiles = (a.L_out + TM - 1) / TM;
   const int NR = window_rows(TM, TAPS, STRIDE, MODE, a.dil > 0 ? a.dil : 1);
   P.nr_lds = NR;
-  size_t lds = BF ? (size_t)2 * NR * (a.cin + 8) * 2 : (size_t)NR * (a.cin + 4) * sizeof(float);
+  size_t lds = BF ? (size_t)2 * NR * (a.cin + conv_bf_pad(a.cin, STRIDE, MODE)) * 2 : (size_t)NR * (a.cin + 4) * sizeof(float);
   if (a.pro == W2S_PRO_FIRST) lds += (size_t)(NR + 2) * sizeof(float);
   size_t red = (size_t)4 * (NT / WN) * 4 * 8 * sizeof(float);
   if (lds < red) lds = red;

@@ -26,50 +26,65 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// erf as a clamped rational minimax x*P(x^2)/Q(x^2) (the Eigen/XLA float erf: |err| <= 4e-7 abs, ~3 ulp, no branches,
-// one v_rcp) -- 3x fewer VALU instructions than ocml's erff, which made every conv VALU-bound (profiles/r01 PMC).
-__device__ __forceinline__ float erf_fast(float x) {
-  x = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+// Phi(x) - 1/2 = erf(x / sqrt 2) / 2 as a clamped rational minimax x*P(x^2)/Q(x^2): the Eigen/XLA float erf (|err| <= 4e-7 abs, no
+// branches, one v_rcp) with the 1/sqrt 2 argument scaling folded into the coefficients (z^2 = x^2/2: exact powers of two) and the
+// factor 1/2 into P -- GELU(x) = x*(1/2 + t) and GELU'(x) = 1/2 + t + x*pdf(x) then need no extra multiplies.  ocml's erff has 3x the
+// VALU instructions, which made every conv VALU-bound (profiles/r01 PMC); the folding removes another ~25 % (r02: the >= 64-channel
+// layers are bound by VALU issue, every wave instruction counts).
+#define W2S_HE_P0 -1.5059950899190544e-12f
+#define W2S_HE_P1 3.0611993495632817e-10f
+#define W2S_HE_P2 -4.6426510635910745e-08f
+#define W2S_HE_P3 -2.5157562504318776e-06f
+#define W2S_HE_P4 -6.49646099191159e-05f
+#define W2S_HE_P5 -0.0005223043845035136f
+#define W2S_HE_P6 -0.00569080701097846f
+#define W2S_HE_Q0 -9.103794695874967e-07f
+#define W2S_HE_Q1 -2.6671756131690927e-05f
+#define W2S_HE_Q2 -0.0004207067540846765f
+#define W2S_HE_Q3 -0.0036866646260023117f
+#define W2S_HE_Q4 -0.014264739118516445f
+#define W2S_HE_CLAMP 5.65685424949238f   /* 4 sqrt 2: erf saturates to fp32 beyond */
+__device__ __forceinline__ float half_erf_fast(float x) {
+  x = __builtin_amdgcn_fmed3f(x, -W2S_HE_CLAMP, W2S_HE_CLAMP);
   const float x2 = x * x;
-  float p = fmaf(x2, -2.72614225801306e-10f, 2.77068142495902e-08f);
-  p = fmaf(x2, p, -2.10102402082508e-06f);
-  p = fmaf(x2, p, -5.69250639462346e-05f);
-  p = fmaf(x2, p, -7.34990630326855e-04f);
-  p = fmaf(x2, p, -2.95459980854025e-03f);
-  p = fmaf(x2, p, -1.60960333262415e-02f);
-  float q = fmaf(x2, -1.45660718464996e-05f, -2.13374055278905e-04f);
-  q = fmaf(x2, q, -1.68282697438203e-03f);
-  q = fmaf(x2, q, -7.37332916720468e-03f);
-  q = fmaf(x2, q, -1.42647390514189e-02f);
+  float p = fmaf(x2, W2S_HE_P0, W2S_HE_P1);
+  p = fmaf(x2, p, W2S_HE_P2);
+  p = fmaf(x2, p, W2S_HE_P3);
+  p = fmaf(x2, p, W2S_HE_P4);
+  p = fmaf(x2, p, W2S_HE_P5);
+  p = fmaf(x2, p, W2S_HE_P6);
+  float q = fmaf(x2, W2S_HE_Q0, W2S_HE_Q1);
+  q = fmaf(x2, q, W2S_HE_Q2);
+  q = fmaf(x2, q, W2S_HE_Q3);
+  q = fmaf(x2, q, W2S_HE_Q4);
   return (x * p) * __builtin_amdgcn_rcpf(q);
 }
 // exact-form (erf) GELU and its derivative -- models/utils.py:61-74 nn.GELU(approximate='none')
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_f(float x) { return x * (0.5f + half_erf_fast(x)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
+  const float cdf = 0.5f + half_erf_fast(x);
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);  // exp(-x^2/2)
   return cdf + x * pdf;
 }
 // 4-wide forms written on the vector type: every polynomial step is one float4 fma (two v_pk_fma_f32), and the four
-// divisions of the rational erf share ONE v_rcp_f32 (quarter-rate) through r = 1/(q0 q1 q2 q3); |q| is in [0.014, 2.4], so
-// the product cannot over/underflow.  The 16/32-channel kernels are VALU-co-limited (profiles/: VALU ~55 % busy at 4 TB/s), so
-// instruction count here is throughput.
+// divisions of the rational share ONE v_rcp_f32 (quarter-rate) through r = 1/(q0 q1 q2 q3); |q| is in [0.014, 2.4], so
+// the product cannot over/underflow.
 __device__ __forceinline__ f32x4 splat4(float c) { return (f32x4){c, c, c, c}; }
 __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x4 erf4(f32x4 x) {
-  x.x = __builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f); x.y = __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f);
-  x.z = __builtin_amdgcn_fmed3f(x.z, -4.0f, 4.0f); x.w = __builtin_amdgcn_fmed3f(x.w, -4.0f, 4.0f);
+__device__ __forceinline__ f32x4 half_erf4(f32x4 x) {
+  x.x = __builtin_amdgcn_fmed3f(x.x, -W2S_HE_CLAMP, W2S_HE_CLAMP); x.y = __builtin_amdgcn_fmed3f(x.y, -W2S_HE_CLAMP, W2S_HE_CLAMP);
+  x.z = __builtin_amdgcn_fmed3f(x.z, -W2S_HE_CLAMP, W2S_HE_CLAMP); x.w = __builtin_amdgcn_fmed3f(x.w, -W2S_HE_CLAMP, W2S_HE_CLAMP);
   const f32x4 x2 = x * x;
-  f32x4 p = fma4(x2, splat4(-2.72614225801306e-10f), splat4(2.77068142495902e-08f));
-  p = fma4(x2, p, splat4(-2.10102402082508e-06f));
-  p = fma4(x2, p, splat4(-5.69250639462346e-05f));
-  p = fma4(x2, p, splat4(-7.34990630326855e-04f));
-  p = fma4(x2, p, splat4(-2.95459980854025e-03f));
-  p = fma4(x2, p, splat4(-1.60960333262415e-02f));
-  f32x4 q = fma4(x2, splat4(-1.45660718464996e-05f), splat4(-2.13374055278905e-04f));
-  q = fma4(x2, q, splat4(-1.68282697438203e-03f));
-  q = fma4(x2, q, splat4(-7.37332916720468e-03f));
-  q = fma4(x2, q, splat4(-1.42647390514189e-02f));
+  f32x4 p = fma4(x2, splat4(W2S_HE_P0), splat4(W2S_HE_P1));
+  p = fma4(x2, p, splat4(W2S_HE_P2));
+  p = fma4(x2, p, splat4(W2S_HE_P3));
+  p = fma4(x2, p, splat4(W2S_HE_P4));
+  p = fma4(x2, p, splat4(W2S_HE_P5));
+  p = fma4(x2, p, splat4(W2S_HE_P6));
+  f32x4 q = fma4(x2, splat4(W2S_HE_Q0), splat4(W2S_HE_Q1));
+  q = fma4(x2, q, splat4(W2S_HE_Q2));
+  q = fma4(x2, q, splat4(W2S_HE_Q3));
+  q = fma4(x2, q, splat4(W2S_HE_Q4));
   // 1/q for the four lanes from one reciprocal
   const float q01 = q.x * q.y, q23 = q.z * q.w;
   const float r = __builtin_amdgcn_rcpf(q01 * q23);
@@ -77,19 +92,16 @@ __device__ __forceinline__ f32x4 erf4(f32x4 x) {
   const f32x4 inv = {r01 * q.y, r01 * q.x, r23 * q.w, r23 * q.z};
   return (x * p) * inv;
 }
-__device__ __forceinline__ f32x4 gelu4(f32x4 v) {
-  const f32x4 e = erf4(v * 0.70710678118654752440f);
-  return (v * 0.5f) * (e + 1.0f);
-}
+__device__ __forceinline__ f32x4 gelu4(f32x4 v) { return v * (half_erf4(v) + 0.5f); }
 __device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
-  const f32x4 cdf = fma4(erf4(v * 0.70710678118654752440f), splat4(0.5f), splat4(0.5f));
+  const f32x4 cdf = half_erf4(v) + 0.5f;
   const f32x4 t = v * v * -0.72134752044448170368f;  // exp(-x^2/2) = 2^t
   const f32x4 pdf = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y), __builtin_amdgcn_exp2f(t.z), __builtin_amdgcn_exp2f(t.w)};
   return fma4(v * 0.39894228040143267794f, pdf, cdf);
 }
 // GELU and GELU' of the same argument from ONE erf evaluation (the fused backward needs both for the tile's centre rows)
 __device__ __forceinline__ void gelu_both4(f32x4 v, f32x4& h, f32x4& gp) {
-  const f32x4 cdf = fma4(erf4(v * 0.70710678118654752440f), splat4(0.5f), splat4(0.5f));
+  const f32x4 cdf = half_erf4(v) + 0.5f;
   const f32x4 t = v * v * -0.72134752044448170368f;
   const f32x4 pdf = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y), __builtin_amdgcn_exp2f(t.z), __builtin_amdgcn_exp2f(t.w)};
   h = v * cdf;

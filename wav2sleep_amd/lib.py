@@ -202,7 +202,7 @@ def conv_forward(a: ConvArgs):
     nbytes = 4 * (in_el + out_el * (2 if a.y2 else 1) + (out_el if a.aux else 0) + (out_el // 2 if a.add_even else 0))
     taps_eff = 1.5 if a.mode == MODE_UP2 else a.taps
     flops = int(2 * out_el * a.cin * taps_eff)
-    if a.taps == 3 and a.mode == MODE_CONTIG and a.w_hi and load().w2s_conv_tile(C.byref(a)) == 64 and a.cout >= 32 and max(a.cin, a.cout) >= 64 \
+    if a.taps == 3 and a.mode == MODE_CONTIG and a.w_hi and load().w2s_conv_tile(C.byref(a)) in (64, 128) and a.cout >= 32 and max(a.cin, a.cout) >= 64 \
             and (a.epi, bool(a.flip)) in ((EPI_STATS, False), (EPI_GP, True)):
         key = f'conv_wide_kernel<{a.cin // 16}, {a.cout // 16}, {a.stride}, {a.pro}, {a.epi}>'
         if DETAIL:
