@@ -82,7 +82,7 @@ typedef struct w2s_conv_args {
   int32_t ldx, ldy, ldy2, ld_aux;
   int32_t pro, epi;
   float stat_eps;          /* variance epsilon of the in-kernel finalisation (models/wav2sleep.py:213-215: 1e-2) */
-  int32_t reserved;
+  int32_t reserved;        /* bit 0: y += result instead of y = result (a contraction split over several launches: cin > 128) */
 } w2s_conv_args;
 
 /* positions per workgroup tile for (cin,cout); ntiles = ceil(L_out / tile) sizes `part`. */
@@ -263,6 +263,18 @@ int w2s_causal_normalize_host(const double* x, long n, double sampling_freq, dou
                               double baseline_tau_seconds, double min_sigma, double* out, uint8_t* outlier);
 
 const char* w2s_version(void);
+
+/* ---- generic (untuned, inference) path: module variants outside the shipped production model (models/utils.py:26-96, ppgnet.py) ---- */
+/* y[row][c] = act(x[row][c]*scale[s][c] + shift[s][c]), s = (row / rows_per_sample) * sample_stride (0: one vector for every sample);
+ * scale == shift == NULL: activation only.  act: 0 linear, 1 ReLU, 2 LeakyReLU(slope), 3 GELU (erf), 4 SiLU (get_activation, utils.py:61-74).
+ * Instance norm / eval BatchNorm / GroupNorm with their statistics and affine folded into (scale, shift).  In place allowed. */
+int w2s_affine_act(const float* x, int ldx, const float* scale, const float* shift, int sample_stride, float* y, int ldy, int rows_per_sample,
+                   long rows, int C, int act, float slope, void* stream);
+/* per-position normalisation over C channels + activation: ConvLayerNorm (utils.py:9-23), ConvRMSNorm (rms != 0, beta NULL; :26-38), nn.LayerNorm */
+int w2s_rownorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, long rows, int C, float eps, int rms,
+                    int act, float slope, void* stream);
+/* nn.MultiheadAttention's attention core for any head size hd, D <= 16 tokens: qkv [N][D][3*H*hd], keypad [N][D] (1 = padded key), out [N][D][H*hd] */
+int w2s_attn_generic_fwd(const float* qkv, const unsigned char* keypad, float* out, long N, int D, int H, int hd, void* stream);
 
 #ifdef __cplusplus
 }

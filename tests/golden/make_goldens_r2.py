@@ -222,8 +222,48 @@ def run_ema():
     print('ema:', len(out), 'arrays')
 
 
+def run_variants():
+    """Eval (and one train-mode BatchNorm) forwards of the reference's modules in configurations outside the production family, default
+    initialisation under a seed + tests.golden_util.perturb_state; and SleepPPGNet on one 10-h input."""
+    from tests.golden_util import VARIANTS, perturb_state, variant_inputs
+    from wav2sleep.models.ppgnet import SleepPPGNet
+    out = {}
+    for name, v in VARIANTS.items():
+        torch.manual_seed(4000 + sorted(VARIANTS).index(name))
+        enc = SignalEncoders(**v['enc'])
+        model = Wav2Sleep(enc, MultiModalAttentionEmbedder(**v['mix']), SequenceCNN(**v['seq']), num_classes=v['nc'])
+        sd = perturb_state(model.state_dict(), seed=77)
+        model.load_state_dict(sd, strict=True)
+        out[f'{name}.keys'] = np.array(list(sd.keys()))
+        out[f'{name}.checksum'] = np.array([float(t.double().abs().sum()) for t in sd.values()])
+        model.train(bool(v.get('train')))
+        x = variant_inputs(name)
+        with torch.no_grad():
+            lg = model({k: t.clone() for k, t in x.items()})
+        out[f'{name}.logits'] = lg.numpy()
+        if v.get('train'):
+            after = model.state_dict()
+            for k in after:
+                if k.endswith('running_mean') or k.endswith('running_var'):
+                    out[f'{name}.after.{k}'] = after[k].numpy()
+        print('variant', name, tuple(lg.shape), 'max |logit|', float(lg.abs().max()))
+    torch.manual_seed(4100)
+    ppg = SleepPPGNet(n_classes=4, feature_dim=128, dropout=0.2, activation='leaky', norm='batch')
+    sd = perturb_state(ppg.state_dict(), seed=78)
+    ppg.load_state_dict(sd, strict=True)
+    ppg.eval()
+    out['ppgnet.keys'] = np.array(list(sd.keys()))
+    out['ppgnet.checksum'] = np.array([float(t.double().abs().sum()) for t in sd.values()])
+    x = torch.randn(1, 1228800, generator=torch.Generator().manual_seed(4101))
+    with torch.no_grad():
+        lg = ppg(x)
+    out['ppgnet.logits'] = lg.numpy()
+    print('ppgnet', tuple(lg.shape), 'max |logit|', float(lg.abs().max()))
+    np.savez_compressed(os.path.join(HERE, 'variants.npz'), **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for name, fn in (('default_init', run_default_init), ('optim', run_optim), ('train10', run_train10), ('dataset', run_dataset), ('ema', run_ema)):
+    for name, fn in (('default_init', run_default_init), ('optim', run_optim), ('train10', run_train10), ('dataset', run_dataset), ('ema', run_ema), ('variants', run_variants)):
         if not only or name in only:
             fn()

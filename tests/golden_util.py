@@ -71,3 +71,56 @@ def grad_sequence(shapes, steps, seed):
         scale = [3.0, 0.02, 1.0, 0.3, 5.0, 0.05, 0.7, 1.5, 0.01, 2.0][k % 10]   # global norms above and below the clip threshold
         seq.append([scale * torch.randn(s, generator=g) / (float(np.prod(s)) ** 0.5) for s in shapes])
     return seq
+
+
+# ---- generic-path variants (tests/golden/variants.npz): configurations of the reference's modules outside the production family ----
+VARIANTS = {
+    # tests/model/test_causality.py of the reference: feature_dim 16, ReLU, BatchNorm, causal (chunked) encoders, mixer / SequenceCNN defaults
+    'causality': dict(enc=dict(signal_map={'ECG': 'ECG', 'PPG': 'PPG'}, feature_dim=16, activation='relu', norm='batch', causal=True),
+                      mix=dict(feature_dim=16), seq=dict(feature_dim=16, causal=True, norm='batch'), nc=4, B=2, S=6, missing={'PPG': [1]}),
+    'causality_train': dict(enc=dict(signal_map={'ECG': 'ECG', 'PPG': 'PPG'}, feature_dim=16, activation='relu', norm='batch', causal=True),
+                            mix=dict(feature_dim=16), seq=dict(feature_dim=16, causal=True, norm='batch', dropout=0.0), nc=4, B=2, S=6, missing=None, train=True),
+    'leaky_auto_rms': dict(enc=dict(signal_map={'ABD': 'ABD', 'ECG': 'ECG'}, feature_dim=32, activation='leaky', norm='auto', max_channels=64),
+                           mix=dict(feature_dim=32, layers=1, nhead=2, dim_ff=128, activation='relu', norm_first=False, register_tokens=1),
+                           seq=dict(feature_dim=32, norm='rms', activation='silu', num_layers=1, num_dilations=3), nc=5, B=2, S=5, missing={'ABD': [0]}),
+    'silu_group': dict(enc=dict(signal_map={'THX': 'THX'}, feature_dim=64, activation='silu', norm='group', causal=True, chunk_causal=False, use_residual=False,
+                                output_norm=True),
+                       mix=dict(feature_dim=64, layers=2, nhead=4, dim_ff=256, activation='gelu'),
+                       seq=dict(feature_dim=64, norm='group', activation='leaky', causal=True), nc=4, B=3, S=4, missing=None),
+    'relu_nonorm': dict(enc=dict(signal_map={'ABD': 'RESP', 'THX': 'RESP'}, feature_dim=16, activation='relu', norm=None, embed_signals=True),
+                        mix=dict(feature_dim=16, layers=1, nhead=1, dim_ff=64), seq=dict(feature_dim=16, norm='layer', activation='gelu', num_layers=1), nc=4, B=2, S=4,
+                        missing=None),
+}
+
+
+def perturb_state(sd: dict, seed: int) -> dict:
+    """Deterministic non-trivial values for everything default initialisation leaves at 0 / 1 (norm affine parameters, BatchNorm running
+    statistics, biases of the norm-free convolutions) so that the variants' goldens exercise them; applied to the reference's and to the
+    build's state dict alike (same keys, same order)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        if k.endswith('running_mean'):
+            out[k] = 0.2 * torch.randn(v.shape, generator=g)
+        elif k.endswith('running_var'):
+            out[k] = 0.6 + torch.rand(v.shape, generator=g)
+        elif k.endswith('num_batches_tracked'):
+            out[k] = v.clone()
+        elif ('norm' in k and k.endswith('.weight')) or k.endswith('output_norm.weight'):
+            out[k] = 1.0 + 0.2 * torch.randn(v.shape, generator=g)
+        elif 'norm' in k and k.endswith('.bias'):
+            out[k] = 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def variant_inputs(name: str):
+    """Seeded inputs of a variant: dict signal -> [B, S * spe] with the listed samples' rows set to -inf."""
+    v = VARIANTS[name]
+    spe = {'ABD': 256, 'THX': 256, 'ECG': 1024, 'PPG': 1024, 'EOG-L': 4096, 'EOG-R': 4096}
+    g = torch.Generator().manual_seed(900 + sorted(VARIANTS).index(name))
+    x = {s: torch.randn(v['B'], v['S'] * spe[s], generator=g) for s in v['enc']['signal_map']}
+    for s, rows in (v.get('missing') or {}).items():
+        x[s][rows] = float('-inf')
+    return x

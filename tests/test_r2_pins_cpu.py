@@ -80,3 +80,45 @@ def test_parquet_dataset_matches_reference(name, labels, nc, mlh):
         assert v.dtype == torch.float32
     np.testing.assert_array_equal(y.numpy(), g[f'ds.{tag}.y'])
     assert y.dtype == torch.float32
+
+
+# ---- generic-path variants: the parameter containers match the reference's modules (keys, order, default initialisation under a seed) ----
+def build_variant(name):
+    from tests.golden_util import VARIANTS, perturb_state
+    v = VARIANTS[name]
+    torch.manual_seed(4000 + sorted(VARIANTS).index(name))
+    model = W.Wav2Sleep(W.SignalEncoders(**v['enc']), W.MultiModalAttentionEmbedder(**v['mix']), W.SequenceCNN(**v['seq']), num_classes=v['nc'])
+    model.load_state_dict(perturb_state(model.state_dict(), seed=77), strict=True)
+    return model
+
+
+def build_ppgnet():
+    from tests.golden_util import perturb_state
+    torch.manual_seed(4100)
+    ppg = W.SleepPPGNet(n_classes=4, feature_dim=128, dropout=0.2, activation='leaky', norm='batch')
+    ppg.load_state_dict(perturb_state(ppg.state_dict(), seed=78), strict=True)
+    return ppg
+
+
+@pytest.mark.parametrize('name', ['causality', 'causality_train', 'leaky_auto_rms', 'silu_group', 'relu_nonorm', 'ppgnet'])
+def test_variant_state_dicts_equal_the_reference_modules(name):
+    """Same keys in the same order and the same values as the REFERENCE modules built under the same seed (BatchNorm / GroupNorm /
+    RMS / layer / no norm, every activation, feature_dim 16..64, SleepPPGNet): checksums stored by make_goldens_r2.py."""
+    g = load('variants')
+    model = build_ppgnet() if name == 'ppgnet' else build_variant(name)
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g[f'{name}.keys']]
+    np.testing.assert_array_equal(np.array([float(t.double().abs().sum()) for t in sd.values()]), g[f'{name}.checksum'])
+    if name != 'ppgnet':
+        assert not model.fused_ok()          # these run on the generic path
+    with pytest.raises(W.lib.W2SError if hasattr(W, 'lib') else Exception):
+        model(torch.zeros(1, 1228800)) if name == 'ppgnet' else model({s: torch.zeros(1, 1024) for s in model.valid_signals})   # no CPU path
+
+
+def test_unknown_norm_and_activation_raise_like_the_reference():
+    with pytest.raises(ValueError):
+        W.ConvLayer1D(16, 16, norm='spectral')
+    with pytest.raises(ValueError):
+        W.ConvLayer1D(16, 16, activation='tanh')
+    with pytest.raises(ValueError):
+        W.wav2sleep.ConvGroupNorm(20, num_groups=8)

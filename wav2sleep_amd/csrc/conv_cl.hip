@@ -3,7 +3,6 @@
 #include <cstdlib>
 #include "w2s_common.h"
 
-static inline int pick_nt(int cout) { return cout >= 128 ? 8 : cout >= 64 ? 4 : cout >= 32 ? 2 : 1; }
 int w2s_conv_dispatch_31(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_32(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_12(const w2s_conv_args& a, hipStream_t s);

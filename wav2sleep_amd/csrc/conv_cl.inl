@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
         sB[nt] += v * v;
       }
       v = v * keep;
+      if (a.reserved & 1) v += ld4o(a.y + ob * a.ldy, (unsigned)pos * (unsigned)a.ldy + ch);   // accumulate: K split over several launches (generic path)
       st4o(a.y + ob * a.ldy, (unsigned)pos * (unsigned)a.ldy + ch, v);
       if (a.y2) st4o(a.y2 + ob * a.ldy2, (unsigned)pos * (unsigned)a.ldy2 + ch, gelu4(v));
     }
@@ -375,7 +376,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
 // ------------------------------------------------------------------------------------------------
 // tile configuration: (NT n-tiles per workgroup, MT m-tiles per wave, WN waves along channels); TM = 16*MT*(4/WN).
 // accumulators MT*NT/WN <= 16 float4 (64 VGPRs); staged window <= 72 KB so two workgroups share a CU.
-static inline int pick_nt(int cout) { return cout >= 128 ? 8 : cout >= 64 ? 4 : cout >= 32 ? 2 : 1; }
+// widest channel tile that divides cout (production: 16 / 32 / 64 / 128 / 384 / 512 -> as before; generic path: 48, 80, 96 ...)
+static inline int pick_nt(int cout) {
+  for (int nt = 8; nt > 1; nt >>= 1)
+    if (cout >= 16 * nt && cout % (16 * nt) == 0) return nt;
+  return 1;
+}
 static inline int window_rows(int tm, int taps, int stride, int mode, int dil = 1) {
   if (mode == W2S_MODE_CONTIG) return (tm - 1) * stride + (taps - 1) * dil + 1;
   if (mode == W2S_MODE_DILATED) return tm;
@@ -452,7 +458,7 @@ static int dispatch_cfg(const w2s_conv_args& a, hipStream_t s) {
 // hot (prologue, epilogue) pairs of the encoder get compile-time specialisations; everything else the runtime-switch kernel
 template <int TAPS, int STRIDE, int MODE>
 static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
-  const bool plain_io = !a.y2 && !a.rowkeep;
+  const bool plain_io = !a.y2 && !a.rowkeep && !a.reserved;
   if constexpr (MODE == W2S_MODE_CONTIG && TAPS == 3 && STRIDE == 1) if (plain_io) {
     if (a.pro == W2S_PRO_GELU && a.epi == W2S_EPI_STATS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_GELU, W2S_EPI_STATS>(a, s);
     if (a.pro == W2S_PRO_IN_GELU && a.epi == W2S_EPI_STATS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_IN_GELU, W2S_EPI_STATS>(a, s);

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
       stL[i] = P.st[i];
       if (TWO) stL[P.B * HC * 2 + i] = P.bst[i];
     }
+    __syncthreads();   // the producers read the table before the first round's barrier
   }
 
   // tiles of this workgroup: first, first + step, ...; iteration i of the producers stages tile i, iteration i + 1 of the consumers eats it
@@ -260,7 +261,7 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
 // 1 = this launch is not one of the wide kernel's shapes (the caller falls through to conv_cl_kernel)
 static bool wide_shape(const w2s_conv_args& a) {
   if (!a.w_hi || !a.w_lo || a.mode != W2S_MODE_CONTIG || a.taps != 3 || a.dil != 1 || a.pad != 1) return false;
-  if (a.y2 || a.rowkeep || a.bias || a.stat_out) return false;
+  if (a.y2 || a.rowkeep || a.bias || a.stat_out || a.reserved) return false;
   if ((size_t)a.B * a.cin * 16 > 32 * 1024) return false;   // the per-sample statistics tables live in LDS
   if (a.ldx != a.cin || a.ldy != a.cout || (a.aux && a.ld_aux != a.cout)) return false;
   if (a.cin < 32 || a.cout < 32 || (a.cin < 64 && a.cout < 64)) return false;

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 
 extern "C" int w2s_head_fwd(const float* pre, int ld, const float* w, const float* bias, float* logits, int rows, int F, int nc, int gelu_in,
                             void* stream) {
-  if (!pre || !w || !bias || !logits || nc > W2S_MAXC || nc <= 0 || (F & 63)) return W2S_EINVAL;
+  if (!pre || !w || !bias || !logits || nc > W2S_MAXC || nc <= 0 || (F & 3) || (ld & 3)) return W2S_EINVAL;
   const unsigned blocks = (unsigned)(((size_t)rows * 16 + 255) / 256);
   hipLaunchKernelGGL(head_fwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pre, ld, w, bias, logits, rows, F,
                      nc, gelu_in);

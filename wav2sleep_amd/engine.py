@@ -59,8 +59,9 @@ class EngineSpec:
             raise ValueError('kernels are built for feature_dim=128, head_dim=16 (scripts/config/model/wav2sleep.yaml)')
         if not 0 <= self.register_tokens <= 5:
             raise ValueError('register_tokens must be in 0..5 (the attention kernels hold up to 7 tokens per epoch)')
-        if self.mixer_dim_ff % 128 or self.seq_kernel != 7 or self.initial_channels != 16 or self.max_channels not in (16, 32, 64, 128):
-            raise ValueError('unsupported hyper-parameters for the gfx950 kernels')
+        if self.mixer_dim_ff not in (384, 512) or self.seq_kernel != 7 or self.initial_channels != 16 or self.max_channels not in (16, 32, 64, 128):
+            raise ValueError('unsupported hyper-parameters for the fused gfx950 kernels (dim_ff 384 / 512, kernel_size 7, channels 16 -> 128): '
+                             'other configurations run on the generic inference path (wav2sleep_amd/generic.py)')
 
     def channels(self, enc: str) -> list[int]:
         """models/wav2sleep.py:198-201"""

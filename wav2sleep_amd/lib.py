@@ -54,7 +54,7 @@ EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y',
            'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
-           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_version']
+           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version']
 
 _lib = None
 
@@ -126,8 +126,9 @@ def _f(t):
 def conv_args(*, x, w, y, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, flip=0, mode=MODE_CONTIG, ldx=None, ldy=None,
               pro=PRO_NONE, epi=EPI_PLAIN, x2=None, pro_stats=None, pro_bstats=None, aux=None, aux_stats=None, add_even=None,
               bias=None, rowkeep=None, part=None, y2=None, ldy2=0, ld_aux=0, w_hi=None, w_lo=None, stat_out=None, stat_cnt=None,
-              stat_eps=1e-2) -> ConvArgs:
+              stat_eps=1e-2, accumulate=False) -> ConvArgs:
     a = ConvArgs()
+    a.reserved = 1 if accumulate else 0
     a.w_hi, a.w_lo = _p(w_hi), _p(w_lo)
     a.stat_out, a.stat_cnt, a.stat_eps = _f(stat_out), _p(stat_cnt), stat_eps
     a.x, a.x2, a.w, a.y, a.y2 = _f(x), _f(x2), _f(w), _f(y), _f(y2)
@@ -492,6 +493,23 @@ def augment(x, B, T, sign, keep):
 
 def map_labels(src, dst, n, num_classes):
     _chk(load().w2s_map_labels(_f(src), _f(dst), C.c_long(n), num_classes, _stream()), 'w2s_map_labels')
+
+
+ACT = {'linear': 0, 'relu': 1, 'leaky': 2, 'gelu': 3, 'silu': 4, 'swish': 4}
+
+
+def affine_act(x, ldx, scale, shift, sample_stride, y, ldy, rows_per_sample, rows, Cc, act, slope=0.01):
+    _chk(load().w2s_affine_act(_f(x), ldx, _f(scale), _f(shift), sample_stride, _f(y), ldy, rows_per_sample, C.c_long(rows), Cc, act, C.c_float(slope),
+                               _stream()), 'w2s_affine_act')
+
+
+def rownorm_fwd(x, ldx, gamma, beta, y, ldy, rows, Cc, eps, rms=False, act=0, slope=0.01):
+    _chk(load().w2s_rownorm_fwd(_f(x), ldx, _f(gamma), _f(beta), _f(y), ldy, C.c_long(rows), Cc, C.c_float(eps), int(rms), act, C.c_float(slope),
+                                _stream()), 'w2s_rownorm_fwd')
+
+
+def attn_generic_fwd(qkv, keypad, out, N, D, H, hd):
+    _chk(load().w2s_attn_generic_fwd(_f(qkv), _p(keypad), _f(out), C.c_long(N), D, H, hd, _stream()), 'w2s_attn_generic_fwd')
 
 
 def version() -> str:

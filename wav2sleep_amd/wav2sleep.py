@@ -27,12 +27,24 @@ _NO_FORWARD = ('{} is a parameter container in wav2sleep_amd; run it through Wav
                '(the HIP engine fuses across module boundaries).')
 
 
+_ACTIVATIONS = ('relu', 'leaky', 'gelu', 'silu', 'swish', 'linear')
+
+
 def _check_activation(name: str):
-    """models/utils.py:61-74 (only GELU has gfx950 kernels)."""
-    if name not in ('relu', 'leaky', 'gelu', 'silu', 'swish', 'linear'):
+    """models/utils.py:61-74: the names get_activation accepts (GELU has fused kernels; the rest run on the generic path)."""
+    if name not in _ACTIVATIONS:
         raise ValueError(f'{name=} is unsupported.')
-    if name != 'gelu':
-        raise NotImplementedError(f"activation '{name}' has no gfx950 kernel yet (production config uses 'gelu')")
+
+
+def _gen(module: nn.Module):
+    """Generic-path walker for a stand-alone sub-module call (inference; see generic.py)."""
+    from .generic import GenericForward
+    from .lib import W2SError
+    for p in module.parameters():
+        if p.device.type != 'cuda':
+            raise W2SError('wav2sleep_amd runs on MI355X only: move the module to a cuda device (there is no CPU fallback)')
+        break
+    return GenericForward(training=module.training)
 
 
 def _standalone_engine(module: nn.Module, prefix: str, spec: EngineSpec) -> Engine:
@@ -73,88 +85,162 @@ class ConvLayerNorm(nn.Module):
         self.eps = eps
 
 
-class ConvLayer1D(nn.Module):
-    """models/blocks.py:129-186: holds `.conv` (+ `.norm` parameters for norm='layer')."""
+class ConvRMSNorm(nn.Module):
+    """models/utils.py:26-38."""
 
-    def __init__(self, input_dim, output_dim, kernel_size=3, stride=1, padding=1, dilation=1, norm='instance'):
+    def __init__(self, num_features: int, eps: float = 1e-5):
         super().__init__()
-        self.conv = nn.Conv1d(input_dim, output_dim, kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation, bias=False)
-        if norm == 'layer':
-            self.norm = ConvLayerNorm(output_dim)
-        elif norm == 'instance':
-            self.norm = nn.Identity()  # InstanceNorm1d(affine=False) contributes no keys
-        else:
-            raise NotImplementedError(f"norm '{norm}' has no gfx950 kernel yet (production config: instance / layer)")
+        self.weight = nn.Parameter(torch.ones(1, num_features, 1))
+        self.eps = eps
 
-    def forward(self, *a, **k):
-        raise NotImplementedError(_NO_FORWARD.format('ConvLayer1D'))
+
+class ConvGroupNorm(nn.Module):
+    """models/utils.py:41-58 (the `nn.GroupNorm` lives under `.norm`, as in the reference's state dict)."""
+
+    def __init__(self, num_features: int, num_groups: int = 8, channels_per_group: int | None = None, eps: float = 1e-5):
+        super().__init__()
+        if channels_per_group is not None:
+            num_groups = num_features // channels_per_group
+        if num_features < num_groups:
+            logger.warning(f'{num_features=} is less than {num_groups=}. Will function as instance norm.')
+            num_groups = num_features
+        if num_features % num_groups != 0:
+            raise ValueError(f'{num_features=} must be divisible by {num_groups=}.')
+        self.norm = nn.GroupNorm(num_groups=num_groups, num_channels=num_features, eps=eps)
+
+
+def get_norm(name: str | None = 'batch', causal: bool = False, *args, **kwargs) -> nn.Module:
+    """models/utils.py:77-96: the parameter container of a normalisation layer (torch's forwards never run)."""
+    norm_eps = kwargs.pop('norm_eps', None)
+    if name == 'batch':
+        return nn.BatchNorm1d(*args, **kwargs)
+    elif name == 'layer':
+        return ConvLayerNorm(*args, **kwargs)
+    elif name == 'rms':
+        return ConvRMSNorm(*args, **kwargs)
+    elif name is None:
+        return nn.Identity()
+    elif name == 'instance':
+        if norm_eps is not None:
+            kwargs['eps'] = norm_eps
+        return nn.InstanceNorm1d(*args, **kwargs)
+    elif name == 'group':
+        return ConvGroupNorm(*args, **kwargs)
+    else:
+        raise ValueError(f'Normalisation with {name=} and {causal=} unknown.')
+
+
+def _to_cl(x_BCL: Tensor) -> Tensor:
+    return x_BCL.transpose(1, 2).contiguous().float()
+
+
+class ConvLayer1D(nn.Module):
+    """models/blocks.py:129-186: conv -> (causal right trim) -> norm -> activation -> dropout.  Holds `.conv` and `.norm`."""
+
+    def __init__(self, input_dim, output_dim, kernel_size=3, stride=1, padding=1, dilation=1, dropout: float = 0.0, causal: bool = False,
+                 groups: int = 1, activation: str = 'relu', bias: bool = False, norm: str | None = 'batch', norm_eps: float | None = None):
+        super().__init__()
+        _check_activation(activation)
+        self.causal = causal
+        self.padding = (kernel_size - 1) * dilation if causal else padding
+        self.conv = nn.Conv1d(input_dim, output_dim, kernel_size=kernel_size, stride=stride, padding=self.padding, groups=groups,
+                              bias=bias or norm is None, dilation=dilation)
+        if norm == 'weight':
+            raise NotImplementedError("norm='weight' (weight-normalised convolution) has no gfx950 kernel")
+        norm_kwargs = {'norm_eps': norm_eps} if norm_eps is not None else {}
+        self.norm = get_norm(norm, causal=causal, num_features=output_dim, **norm_kwargs)
+        self.norm_name = norm
+        self.activation_name = activation
+        self.dropout_p = dropout
+        self.dropout = nn.Dropout(p=dropout)
+
+    @torch.no_grad()
+    def forward(self, x: Tensor) -> Tensor:
+        """[N, Cin, L] -> [N, Cout, L'] (channels-first like the reference; inference, generic path)."""
+        return _gen(self).conv_layer(self, _to_cl(x)).transpose(1, 2)
 
 
 class ConvBlock1D(nn.Module):
     """models/blocks.py:8-71."""
 
-    def __init__(self, input_dim, output_dim, norm='instance', use_residual=True):
+    def __init__(self, input_dim, output_dim, dropout: float = 0.0, activation: str = 'leaky', norm: str = 'batch', causal: bool = False,
+                 norm_eps: float | None = None, use_residual: bool = True):
         super().__init__()
         self.use_residual = use_residual
-        self.conv1 = ConvLayer1D(input_dim, output_dim, norm=norm)
-        self.conv2 = ConvLayer1D(output_dim, output_dim, norm=norm)
-        self.conv3 = ConvLayer1D(output_dim, output_dim, stride=2, norm=norm)
+        kw = dict(kernel_size=3, padding=1, activation=activation, norm=norm, dropout=dropout, causal=causal, norm_eps=norm_eps)
+        self.conv1 = ConvLayer1D(input_dim, output_dim, stride=1, **kw)
+        self.conv2 = ConvLayer1D(output_dim, output_dim, stride=1, **kw)
+        self.conv3 = ConvLayer1D(output_dim, output_dim, stride=2, **kw)
+        self.activation_name = activation
         if use_residual:
             self.downsample = nn.Conv1d(input_dim, output_dim, kernel_size=1, stride=2, padding=0, bias=False)
         else:
             self.register_parameter('downsample', None)   # blocks.py:53-55
 
-    def forward(self, *a, **k):
-        raise NotImplementedError(_NO_FORWARD.format('ConvBlock1D'))
+    @torch.no_grad()
+    def forward(self, x: Tensor) -> Tensor:
+        """[N, Cin, L] -> [N, Cout, L/2] (inference, generic path)."""
+        return _gen(self).conv_block(self, _to_cl(x)).transpose(1, 2)
 
 
 class DilatedConvBlock(nn.Module):
     """models/blocks.py:74-126."""
 
-    def __init__(self, feature_dim=128, dropout=0.2, norm='layer', kernel_size=7, num_dilations=6):
+    def __init__(self, feature_dim=128, dropout=0.2, activation: str = 'leaky', norm: str = 'batch', kernel_size=7, causal: bool = False,
+                 num_dilations=6):
         super().__init__()
         self.kernel_size = kernel_size
         self.dilations = [2 ** i for i in range(num_dilations)]
         blocks = []
         for d in self.dilations:
             k_eff = kernel_size + (kernel_size - 1) * (d - 1)
-            blocks.append(ConvLayer1D(feature_dim, feature_dim, kernel_size=kernel_size, dilation=d, padding=k_eff // 2, norm=norm))
-        self.conv_layers = nn.Sequential(*blocks)
+            blocks.append(ConvLayer1D(feature_dim, feature_dim, kernel_size=kernel_size, stride=1, dilation=d, padding=k_eff // 2,
+                                      activation=activation, norm=norm, causal=causal))
         self.dropout = nn.Dropout(p=dropout)
+        self.conv_layers = nn.Sequential(*blocks)
+        self.activation_name = activation
 
-    def forward(self, *a, **k):
-        raise NotImplementedError(_NO_FORWARD.format('DilatedConvBlock'))
+    @torch.no_grad()
+    def forward(self, x: Tensor) -> Tensor:
+        """[N, F, S] -> [N, F, S] (inference, generic path)."""
+        return _gen(self).dilated_block(self, _to_cl(x)).transpose(1, 2)
 
 
 class SignalEncoder(nn.Module):
     """models/wav2sleep.py:164-267: the whole-sequence path (:256-261), non-causal or -- `causal=True, chunk_causal=False`, what
-    scripts/config/model/wav2sleep.yaml:10-11 builds for `causal: True` -- with causal-padded convolutions in the blocks."""
+    scripts/config/model/wav2sleep.yaml:10-11 builds for `causal: True` -- with causal-padded convolutions in the blocks; `chunk_causal=True`
+    encodes every 30-s epoch on its own (:248-255)."""
 
     def __init__(self, input_dim=1, feature_dim=256, activation='gelu', samples_per_epoch=1024, norm='instance', initial_channels=16,
                  max_channels=128, causal=False, chunk_causal=True, output_norm=False, use_residual=True):
         super().__init__()
         _check_activation(activation)
-        if norm != 'instance':
-            raise NotImplementedError('non-instance encoder norms have no gfx950 kernels yet')
         self.feature_dim = feature_dim
         self.samples_per_epoch = samples_per_epoch
         self.causal = causal
         self.chunk_causal = chunk_causal
+        self.activation_name = activation
+        self.norm_name = norm
         if samples_per_epoch & (samples_per_epoch - 1) != 0:
             raise ValueError(f'samples_per_epoch must be a power of 2, got {samples_per_epoch}')
         num_blocks = int(math.log2(samples_per_epoch)) - 2
         channels = [min(initial_channels * 2 ** (i // 2), max_channels) for i in range(num_blocks)]
+        causal_conv = causal and not chunk_causal
         blocks = []
-        for c in channels:
-            blocks.append(ConvBlock1D(input_dim, c, norm=norm, use_residual=use_residual))
+        for i, c in enumerate(channels):
+            norm_i = ('instance' if i < 2 else 'layer') if norm == 'auto' else norm          # wav2sleep.py:206-212
+            blocks.append(ConvBlock1D(input_dim, c, activation=activation, norm=norm_i, norm_eps=1e-2 if norm_i == 'instance' else None,
+                                      causal=causal_conv, use_residual=use_residual))
             input_dim = c
         self.cnn = nn.Sequential(*blocks)
         self.epoch_dim = channels[-1] * 4
         self.linear = nn.Linear(self.epoch_dim, feature_dim)
         self.output_norm = nn.LayerNorm(feature_dim) if output_norm else nn.Identity()   # wav2sleep.py:232-233
 
-    def forward(self, *a, **k):
-        raise NotImplementedError(_NO_FORWARD.format('SignalEncoder'))
+    @torch.no_grad()
+    def forward(self, x: Tensor) -> Tensor:
+        """[B, T] -> [B, S, feature_dim] (inference, generic path; `SignalEncoders` / `Wav2Sleep` use the fused kernels for the production family)."""
+        return _gen(self).signal_encoder(self, x)
 
 
 class SignalEncoders(_HandWritten, nn.Module):
@@ -164,10 +250,13 @@ class SignalEncoders(_HandWritten, nn.Module):
                  chunk_causal: bool = True, embed_signals: bool = False, initial_channels: int = 16, max_channels: int = 128,
                  output_norm: bool = False, use_residual: bool = True) -> None:
         super().__init__()
+        _check_activation(activation)
         self.feature_dim = feature_dim
         self.signal_map = dict(signal_map)
         self.causal = causal
         self.chunk_causal = chunk_causal
+        self.activation_name = activation
+        self.norm_name = norm
         self.use_output_norm = output_norm
         self.use_residual = use_residual
         self.initial_channels = initial_channels
@@ -196,10 +285,19 @@ class SignalEncoders(_HandWritten, nn.Module):
     def get_encoder(self, signal_name: str) -> SignalEncoder:
         return self.encoders[self.signal_map[signal_name]]  # type: ignore
 
+    def fused_ok(self) -> bool:
+        """The production family the fused kernels are written for (scripts/config/model/wav2sleep.yaml): GELU, instance norm, 128 features,
+        16 -> 128 channels.  Everything else runs on the generic path (generic.py; inference)."""
+        return (self.activation_name == 'gelu' and self.norm_name == 'instance' and self.feature_dim == 128 and self.initial_channels == 16
+                and self.max_channels in (16, 32, 64, 128))
+
     @torch.no_grad()
     def forward(self, x: dict[str, Tensor]) -> dict[str, Tensor]:
         """models/wav2sleep.py:146-161, inference only (training goes through Wav2Sleep.forward, one fused autograd node):
         dict signal -> [B, T]  ->  dict signal -> [B, S, feature_dim]; samples whose input row is -inf come back as -inf."""
+        if not self.fused_ok():
+            with torch.cuda.device(next(self.parameters()).device):
+                return _gen(self).signal_encoders(self, x)
         spec = EngineSpec(signal_map=dict(self.signal_map), feature_dim=self.feature_dim, initial_channels=self.initial_channels,
                           max_channels=self.max_channels, causal=self.causal, chunk_causal=self.chunk_causal, embed_signals=self.embed_signals,
                           output_norm=self.use_output_norm, use_residual=self.use_residual)
@@ -221,27 +319,36 @@ class MultiModalAttentionEmbedder(_HandWritten, nn.Module):
                  norm_first: bool = True, nhead: int = 4, register_tokens: int = 0):
         super().__init__()
         _check_activation(activation)
-        if not norm_first:
-            raise NotImplementedError('the post-norm transformer layer has no gfx950 kernels yet')
-        if not 0 <= register_tokens <= 5:
-            raise ValueError('register_tokens must be in 0..5 (the attention kernels hold up to 7 tokens per epoch)')
         self.feature_dim = feature_dim
+        self.activation_name = activation
+        self.norm_first = norm_first
         self.dropout_p = dropout
         self.nhead = nhead
         self.dim_ff = dim_ff
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            encoder_layer = nn.TransformerEncoderLayer(d_model=feature_dim, dim_feedforward=dim_ff, activation=nn.GELU(), nhead=nhead,
+            encoder_layer = nn.TransformerEncoderLayer(d_model=feature_dim, dim_feedforward=dim_ff, activation={'relu': nn.ReLU(), 'leaky': nn.LeakyReLU(), 'gelu': nn.GELU(), 'silu': nn.SiLU(), 'swish': nn.SiLU(), 'linear': nn.Identity()}[activation], nhead=nhead,
                                                        batch_first=True, dropout=dropout, norm_first=norm_first)
             self.num_layers = layers
             self.transformer_encoder = nn.TransformerEncoder(encoder_layer, num_layers=layers)
         self.num_register_tokens = register_tokens
         self.register_tokens = nn.Parameter(torch.randn(1, 1, feature_dim, register_tokens + 1))
 
+    def fused_ok(self) -> bool:
+        """Pre-norm GELU layers with 128 features in 16-wide heads, FFN 384 or 512, at most 5 register tokens: the tuned attention / GEMM kernels."""
+        return (self.activation_name == 'gelu' and self.norm_first and self.feature_dim == 128 and self.nhead * 16 == self.feature_dim
+                and self.dim_ff in (384, 512) and 0 <= self.num_register_tokens <= 5)
+
     @torch.no_grad()
     def forward(self, z_dict: dict[str, Tensor]) -> Tensor:
         """models/wav2sleep.py:301-346, inference only: dict signal -> [B, S, F] (-inf rows = missing) -> CLS features [B, S, F]."""
+        if not self.fused_ok():
+            first_ = next(iter(z_dict.values())) if len(z_dict) else None
+            if first_ is None:
+                raise ValueError('No signals provided to MultiModalAttentionEmbedder.')
+            with torch.cuda.device(first_.device):
+                return _gen(self).mixer(self, z_dict)
         signals = sorted(z_dict.keys())
         if len(signals) == 0:
             raise ValueError('No signals provided to MultiModalAttentionEmbedder.')
@@ -280,20 +387,27 @@ class SequenceCNN(_HandWritten, nn.Module):
                  causal: bool = False, num_dilations: int = 6, kernel_size: int = 7) -> None:
         super().__init__()
         _check_activation(activation)
-        if norm != 'layer':
-            raise NotImplementedError("SequenceCNN kernels cover the production config (norm='layer')")
+        self.feature_dim = feature_dim
+        self.activation_name = activation
+        self.norm_name = norm
         self.causal = causal
         self.dropout_p = dropout
         self.num_layers = num_layers
         self.num_dilations = num_dilations
         self.kernel_size = kernel_size
-        self.dilated_convs = nn.Sequential(*[DilatedConvBlock(feature_dim=feature_dim, dropout=dropout, norm=norm, kernel_size=kernel_size,
-                                                              num_dilations=num_dilations) for _ in range(num_layers)])
+        self.dilated_convs = nn.Sequential(*[DilatedConvBlock(feature_dim=feature_dim, dropout=dropout, activation=activation, norm=norm, causal=causal,
+                                                              num_dilations=num_dilations, kernel_size=kernel_size) for _ in range(num_layers)])
+
+    def fused_ok(self) -> bool:
+        return self.activation_name == 'gelu' and self.norm_name == 'layer' and self.feature_dim == 128 and self.kernel_size == 7
 
     @torch.no_grad()
     def forward(self, x_BSF: Tensor) -> Tensor:
         """models/wav2sleep.py:379-390, inference only: [B, S, F] -> [B, S, F]."""
         B, S, F = x_BSF.shape
+        if not self.fused_ok():
+            with torch.cuda.device(x_BSF.device):
+                return _gen(self).sequence_cnn(self, x_BSF)
         spec = EngineSpec(signal_map={'ECG': 'ECG'}, feature_dim=F, seq_blocks=self.num_layers, seq_dilations=self.num_dilations,
                           seq_kernel=self.kernel_size, seq_dropout=self.dropout_p, seq_causal=self.causal)
         eng, ver = _standalone_engine(self, 'sequence_mixer.', spec)
@@ -358,8 +472,20 @@ class Wav2Sleep(_HandWritten, nn.Module):
     def valid_signals(self) -> list[str]:
         return list(self.signal_encoders.signal_map.keys())
 
+    def fused_ok(self) -> bool:
+        return self.signal_encoders.fused_ok() and self.epoch_mixer.fused_ok() and self.sequence_mixer.fused_ok() and self.num_classes <= 8
+
     def forward(self, x: dict[str, Tensor]) -> Tensor:
-        """dict[str -> [B, T_sig]] -> logits [B, S, num_classes]."""
+        """dict[str -> [B, T_sig]] -> logits [B, S, num_classes].  The production family runs on the fused kernels (one autograd node);
+        any other configuration of the reference's modules on the generic path (generic.py): forward only, no autograd graph."""
+        if not self.fused_ok():
+            from .generic import GenericForward
+            from .lib import W2SError
+            dev = next(self.parameters()).device
+            if dev.type != 'cuda':
+                raise W2SError('wav2sleep_amd runs on MI355X only: move the model to a cuda device (there is no CPU fallback)')
+            with torch.no_grad(), torch.cuda.device(dev):
+                return GenericForward(training=self.training, seed=self._next_seed() if self.training else 0).wav2sleep(self, x)
         self._ensure_flat()
         params = [p for _, p in self.named_parameters()]
         return _W2SFunction.apply(self, x, *params)
