@@ -67,11 +67,11 @@ from tests.golden_util import OPT_SHAPES, grad_sequence as _grad_sequence  # noq
 
 def run_optim():
     out = {}
-    for variant in ('const', 'sched'):
+    for variant in ('const', 'sched', 'wd'):
         g = torch.Generator().manual_seed(77)
         params = [torch.nn.Parameter(torch.randn(s, generator=g) * 0.2) for s in OPT_SHAPES]
         out['init'] = np.concatenate([p.detach().flatten().numpy() for p in params])
-        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4)   # optimizer/adamw.yaml
+        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-2 if variant == 'wd' else 1e-4)   # optimizer/adamw.yaml ('wd': 100x the decay, so that the decoupled-decay term is far above fp32 round-off)
         sched = ExpWarmUpScheduler(opt, lr_max=1e-3, warmup_steps=4, tau=5.0) if variant == 'sched' else None
         for k, grads in enumerate(_grad_sequence(OPT_SHAPES, 10, 78), start=1):
             opt.zero_grad()

@@ -126,7 +126,7 @@ class _FlatHolder:
         return torch.cat([t[o:o + n] for (o, n, _) in self._layout]).cpu()
 
 
-@pytest.mark.parametrize('variant', ['const', 'sched'])
+@pytest.mark.parametrize('variant', ['const', 'sched', 'wd'])
 def test_fused_clip_adamw_matches_torch_adamw_over_ten_steps(variant):
     """w2s_sumsq_partial + w2s_clip_coef + w2s_adamw on the flat buffers vs clip_grad_norm_(1.0) + torch.optim.AdamW(lr 1e-3, wd 1e-4)
     [+ ExpWarmUpScheduler(warmup 4, tau 5)] on the same seeded gradients: bias correction, decoupled weight decay, the clip coefficient
@@ -135,7 +135,7 @@ def test_fused_clip_adamw_matches_torch_adamw_over_ten_steps(variant):
     g = load('optim')
     holder = _FlatHolder(OPT_SHAPES, torch.from_numpy(g['init']))
     kw = dict(warmup_steps=4, tau=5.0, scheduler=True) if variant == 'sched' else dict(scheduler=False)
-    tr = W.FusedTrainStep(holder, lr=1e-3, weight_decay=1e-4, **kw)
+    tr = W.FusedTrainStep(holder, lr=1e-3, weight_decay=1e-2 if variant == 'wd' else 1e-4, **kw)
     init = torch.from_numpy(g['init']).double()
     for k, grads in enumerate(_grad_sequence(OPT_SHAPES, 10, 78), start=1):
         holder._flat_grad.copy_(_flat_of(grads, holder._layout, holder._flat.numel()))
@@ -146,8 +146,8 @@ def test_fused_clip_adamw_matches_torch_adamw_over_ten_steps(variant):
             want = torch.from_numpy(g[f'{variant}.param{k}'])
             moved = (want - init).abs().max()
             err = (holder.packed().double() - want).abs().max()
-            assert float(err) <= 1e-5 * float(moved) + 1.2e-7, (k, float(err), float(moved))   # 1.2e-7: one fp32 ulp of the largest weights (|p| < 2)
-    assert float(moved) > 5e-3 and holder._dirty == 10
+            assert float(err) <= 1e-5 * float(moved) + 4e-7, (k, float(err), float(moved))   # 4e-7: fp32 round-off of ten updates of weights of size <= 1 (ulp 6e-8 each)
+    assert float(moved) > 4e-3 and holder._dirty == 10
 
 
 def test_fused_adamw_detects_what_round1_could_not():
@@ -155,9 +155,10 @@ def test_fused_adamw_detects_what_round1_could_not():
     g = load('optim')
     init, p1, p10 = (torch.from_numpy(g[k]).double() for k in ('init', 'const.param1', 'const.param10'))
     moved = float((p10 - init).abs().max())
-    tol = 1e-5 * moved + 1.2e-7
+    tol = 1e-5 * moved + 4e-7
     assert float((p1 - init).abs().max()) > 100 * tol                          # losing step 1 (1e-3 per element) is visible
-    assert 1e-3 * 1e-4 * 10 * float(init.abs().max()) > 3 * tol                # so is losing the decoupled decay (lr*wd*|p| per step)
+    wd10 = torch.from_numpy(g['wd.param10']).double()
+    assert float((wd10 - p10).abs().max()) > 50 * tol                          # the 'wd' variant (decay 1e-2) separates decoupled weight decay from no decay
 
 
 def test_ten_train_steps_match_reference_run():
@@ -247,14 +248,14 @@ def test_ema_callback_matches_reference_callback(name):
             holder._flat[o:o + n] = traj[step, o2:o2 + n].to(DEV)
             o2 += n
         cb.on_train_batch_end(None, holder, None, None, step)
-        np.testing.assert_allclose(holder.packed(cb._ema_flat).numpy(), g[f'{name}.ema{step}'], rtol=1e-6, atol=1e-9, err_msg=f'step {step}')
+        np.testing.assert_allclose(holder.packed(cb._ema_flat).numpy(), g[f'{name}.ema{step}'], rtol=2e-6, atol=1e-8, err_msg=f'step {step}')
     assert cb.state_dict()['step_count'] == int(g[f'{name}.step_count'])
     cb.on_validation_epoch_start(None, holder)
-    np.testing.assert_allclose(holder.packed().numpy(), g[f'{name}.during_val'], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(holder.packed().numpy(), g[f'{name}.during_val'], rtol=2e-6, atol=1e-8)
     cb.on_validation_epoch_end(None, holder)
     np.testing.assert_array_equal(holder.packed().numpy(), g[f'{name}.after_val'])
     cb.on_train_end(None, holder)
-    np.testing.assert_allclose(holder.packed().numpy(), g[f'{name}.train_end'], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(holder.packed().numpy(), g[f'{name}.train_end'], rtol=2e-6, atol=1e-8)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs a second GPU')
