@@ -214,3 +214,21 @@ def test_save_predictions_tree_timestamps_and_overwrite(tmp_path):
     assert list(t1.columns) == ['Timestamp', 'Pred'] and list(t1['Pred']) == ((preds[i1] + 1) % 4).tolist()
     with pytest.raises(ValueError):
         W.predict_on_folder(str(src), str(out))                                                  # neither model nor model_folder
+
+
+def test_exported_scheduler_and_lr_state_is_what_torch_holds_after_k_steps():
+    """after k optimiser steps torch's param group and the scheduler hold lr(k + 1) (the scheduler has already stepped), and the
+    scheduler state dict has the key set of `ExpWarmUpScheduler.state_dict()`."""
+    from types import SimpleNamespace
+    from wav2sleep_amd.checkpoint import _scheduler_state
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=1e-4)
+    sched = W.ExpWarmUpScheduler(opt, lr_max=1e-3, warmup_steps=2000, tau=10000.0)
+    for _ in range(7):
+        p.grad = torch.ones(3); opt.step(); sched.step()
+    step = SimpleNamespace(lr_max=1e-3, warmup_steps=2000, tau=10000.0, step_count=7, lr_at=lambda k: W.exp_warmup_lr(k, 1e-3, 2000, 10000.0))
+    got, want = _scheduler_state(step), sched.state_dict()
+    assert set(got) == set(want)
+    assert got['last_epoch'] == want['last_epoch'] == 7 and got['_step_count'] == want['_step_count']
+    assert got['_last_lr'] == pytest.approx(want['_last_lr']) and got['_last_lr'][0] == pytest.approx(opt.param_groups[0]['lr'])
+    assert got['_last_lr'][0] == pytest.approx(1e-3 * 8 / 2000)

@@ -284,3 +284,68 @@ def test_wrong_device_stream_is_refused(monkeypatch):
     monkeypatch.setattr(lib, '_last_dev', t.device.index + 1)
     with pytest.raises(lib.W2SError):
         lib._stream()
+
+
+def test_augment_consumes_the_device_rng_like_the_reference():
+    """inputs.augment_ (one fused pass per signal) draws polarity for every signal first, then the masker's Bernoulli / categorical samples:
+    the order of trainer/main.py:131-138 (`invert_signals`, then `SignalMasker.__call__`), so under one seed both produce the same batch and
+    leave the generator in the same state."""
+    from wav2sleep_amd.inputs import augment_
+    names = ('ABD', 'THX', 'ECG', 'PPG')
+    g = torch.Generator().manual_seed(5)
+    x0 = {s: torch.randn(7, 96, generator=g) for s in names}
+    x0['ECG'][1] = float('-inf'); x0['ABD'][3] = float('-inf'); x0['PPG'][5] = float('-inf')
+    masker = W.SignalMasker({'ABD': 0.7, 'THX': 0.7, 'ECG': 0.5, 'PPG': 0.1}, backups=['ECG', 'PPG'])
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        a = augment_({k: v.clone().to(DEV) for k, v in x0.items()}, flip_polarity=True, masker=masker)
+        nxt_a = torch.rand(4, device=DEV)
+        torch.manual_seed(seed)
+        b = masker(W.invert_signals({k: v.clone().to(DEV) for k, v in x0.items()}))
+        nxt_b = torch.rand(4, device=DEV)
+        assert torch.equal(nxt_a, nxt_b)
+        for k in names:
+            ia, ib = torch.isinf(a[k]), torch.isinf(b[k])
+            assert torch.equal(ia, ib), k
+            assert torch.equal(torch.where(ia, torch.zeros_like(a[k]), a[k]), torch.where(ib, torch.zeros_like(b[k]), b[k])), k
+
+
+def test_model_compile_traces_through_the_custom_operator():
+    """tests/model/test_compile.py of the reference with torch.compile ACTUALLY invoked: `model.compile(mode='max-autotune', fullgraph=True)`
+    traces Wav2Sleep.forward as one `w2s::wav2sleep_forward` node (fake implementation for shapes, registered backward for autograd); the
+    compiled forward and a compiled training step give the eager results bit for bit."""
+    import torch._dynamo
+    sm = {'ECG': 'ECG', 'PPG': 'PPG'}
+    cfg = O.ModelConfig(signal_map=sm, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=6)
+
+    def make():
+        m = W.Wav2Sleep(W.SignalEncoders(sm, 128, 'gelu', norm='instance', chunk_causal=False),
+                        W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.0, dim_ff=512, nhead=8),
+                        W.SequenceCNN(128, dropout=0.0, norm='layer', num_layers=2, kernel_size=7, num_dilations=6), 4)
+        m.load_state_dict(sd)
+        return m.to(DEV)
+    x, y = O.make_inputs(cfg, 2, 6, seed=61)
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    eager, comp = make().eval(), make().eval()
+    torch._dynamo.reset()
+    try:
+        comp.compile(mode='max-autotune', fullgraph=True)
+        with torch.no_grad():
+            a, b = eager(xd), comp(xd)
+        assert torch.equal(a, b) and comp.compiled_with['fullgraph'] is True
+        eager.train(); comp.train()
+        la = torch.nn.functional.cross_entropy(eager(xd).view(-1, 4), y.to(DEV).view(-1).long(), ignore_index=-1)
+        lb = torch.nn.functional.cross_entropy(comp(xd).view(-1, 4), y.to(DEV).view(-1).long(), ignore_index=-1)
+        la.backward(); lb.backward()
+        assert float(la) == float(lb)
+        for (k, p), q in zip(eager.named_parameters(), comp.parameters()):
+            assert torch.equal(p.grad, q.grad), k
+        # the op is visible to torch.library tooling: fake tensor propagation gives the logits' shape without running a kernel
+        from torch._subclasses.fake_tensor import FakeTensorMode
+        with FakeTensorMode(allow_non_fake_inputs=True) as mode:
+            fx = [mode.from_tensor(v) for v in xd.values()]
+            out, ticket = torch.ops.w2s.wav2sleep_forward(eager._handle, False, False, ','.join(xd), fx, [mode.from_tensor(p.detach()) for p in eager.parameters()])
+            assert tuple(out.shape) == (2, 6, 4) and ticket.device.type == 'cpu'
+    finally:
+        torch._dynamo.reset()

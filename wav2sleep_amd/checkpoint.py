@@ -146,10 +146,26 @@ def _optimizer_state(step: 'FusedTrainStep') -> dict:
     for i, ((o, n, shape), _) in enumerate(zip(model._layout, model.named_parameters())):
         if step.step_count > 0:
             state[i] = {'step': k.clone(), 'exp_avg': step.m[o:o + n].view(shape).clone(), 'exp_avg_sq': step.v[o:o + n].view(shape).clone()}
-    group = dict(lr=step.lr_at(max(step.step_count, 1)), betas=tuple(step.betas), eps=step.eps, weight_decay=step.wd, amsgrad=False,
+    # after k optimiser steps the scheduler has stepped k times too: the group's lr is the one step k + 1 will use
+    group = dict(lr=step.lr_at(step.step_count + 1), betas=tuple(step.betas), eps=step.eps, weight_decay=step.wd, amsgrad=False,
                  maximize=False, foreach=None, capturable=False, differentiable=False, fused=None, initial_lr=step.lr_max,
                  params=list(range(len(model._layout))))
     return {'state': state, 'param_groups': [group]}
+
+
+def _scheduler_state(step: 'FusedTrainStep') -> dict:
+    """`ExpWarmUpScheduler.state_dict()` (trainer/scheduler.py:7-32: every attribute but the optimiser) after `step_count` optimiser steps,
+    produced by the scheduler class itself on a stand-in optimiser so that the key set is torch's own."""
+    from .trainer import ExpWarmUpScheduler
+    import warnings
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=step.lr_max)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        sched = ExpWarmUpScheduler(opt, lr_max=step.lr_max, warmup_steps=step.warmup_steps, tau=step.tau)
+    k = step.step_count
+    sd = sched.state_dict()
+    sd.update(last_epoch=k, _step_count=k + 1, _last_lr=[step.lr_at(k + 1)])
+    return sd
 
 
 def lightning_checkpoint(module, epoch: int = 0, callbacks: dict | None = None) -> dict:
@@ -163,9 +179,7 @@ def lightning_checkpoint(module, epoch: int = 0, callbacks: dict | None = None) 
         'pytorch-lightning_version': 'wav2sleep_amd',
         'state_dict': {'model.' + k: v.detach().clone() for k, v in model.state_dict().items()},
         'optimizer_states': [_optimizer_state(step)],
-        # ExpWarmUpScheduler is a LambdaLR-style scheduler stepped once per optimiser step (trainer/scheduler.py:7-32)
-        'lr_schedulers': [{'last_epoch': step.step_count, '_step_count': step.step_count + 1, 'base_lrs': [step.lr_max],
-                           '_last_lr': [step.lr_at(max(step.step_count, 1))], 'warmup_steps': step.warmup_steps, 'tau': step.tau}],
+        'lr_schedulers': [_scheduler_state(step)],
         'callbacks': dict(callbacks or {}),
         # SleepLightningModule.on_save_checkpoint (trainer/main.py:299-308)
         'gradient_clip_val': step.max_norm,

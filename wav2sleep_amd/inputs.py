@@ -50,20 +50,23 @@ def map_labels(stages: torch.Tensor, num_classes: int) -> torch.Tensor:
 
 
 def augment_(signals: dict[str, torch.Tensor], flip_polarity: bool = True, masker=None) -> dict[str, torch.Tensor]:
-    """invert_signals + SignalMasker, in place, one pass per signal (trainer/main.py:131-138)."""
+    """invert_signals + SignalMasker, in place, one pass per signal (trainer/main.py:131-138).  The random draws are made in the
+    reference's order -- the polarity of every signal first (`invert_signals`, one `randint` per signal in dict order, main.py:342-353),
+    then the masker's Bernoulli / categorical draws (masker.py:10-46) -- so a run seeded like the reference consumes the device RNG
+    stream identically; only the application is fused (w2s_augment: sign and -inf rows in one pass)."""
     names = list(signals.keys())
     first = signals[names[0]]
     B, dev = first.shape[0], first.device
+    signs = [(2 * torch.randint(0, 2, (B, 1), dtype=torch.float, device=dev) - 1).reshape(B) if flip_polarity else None for _ in names]
     keep_BC = None
     if masker is not None:
-        _, keep_BC = masker.draw(signals)
+        _, keep_BC = masker.draw(signals)   # availability is read from the -inf rows, which a sign flip leaves -inf or +inf alike
     for j, name in enumerate(names):
         x = signals[name]
         assert x.is_contiguous() and x.dtype == torch.float32
-        sign = (2 * torch.randint(0, 2, (B,), dtype=torch.float, device=dev) - 1) if flip_polarity else None
         keep = keep_BC[:, j].to(torch.uint8).contiguous() if keep_BC is not None else None
         with torch.cuda.device(dev):
-            lib.augment(x, B, x.shape[1], sign, keep)
+            lib.augment(x, B, x.shape[1], signs[j], keep)
     return signals
 
 

@@ -63,6 +63,17 @@ def _standalone_engine(module: nn.Module, prefix: str, spec: EngineSpec) -> Engi
     return module._w2s_engine[1], hash(key)
 
 
+class _SavedForwards(dict):
+    """Saved activations of forwards that are waiting for their backward, keyed by the logits' data pointer.  A forward whose graph is
+    dropped without a backward (evaluation with gradients enabled) would otherwise pin ~1.2 GB per recording: only the two most recent
+    forwards are kept."""
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        while len(self) > 2:
+            del self[next(iter(self))]
+
+
 class _HandWritten:
     """`nn.Module.compile()` hook for the modules whose forward is a sequence of hand-written HIP launches: the reference calls
     `model.compile()` / `encoders.compile(fullgraph=True)` (api.py:96-97, tests/model/test_compile.py); there is nothing for
@@ -72,6 +83,19 @@ class _HandWritten:
 
     def compile(self, *args, **kwargs):
         self.compiled_with = dict(args=args, **kwargs)
+        if isinstance(self, Wav2Sleep) and self.fused_ok():
+            # The forward is one custom operator: Dynamo traces it (fullgraph=True holds), and there is nothing for Inductor to generate, so
+            # the default backend is replaced by 'aot_eager' (fake tensors + the registered autograd formula, no code generation; `mode` /
+            # `options` are Inductor switches and are dropped with it).  W2S_COMPILE_BACKEND selects another backend.
+            import os
+            kw = dict(kwargs)
+            if 'backend' not in kw:
+                kw['backend'] = os.environ.get('W2S_COMPILE_BACKEND', 'aot_eager')
+                if kw['backend'] != 'inductor':
+                    kw.pop('mode', None)
+                    kw.pop('options', None)
+            self._ensure_flat()   # parameter storage is settled before tracing
+            return nn.Module.compile(self, *args, **kw)
         logger.info('%s.compile(%s): the forward already is hand-written gfx950 code; nothing to compile', type(self).__name__, kwargs)
 
 
@@ -420,33 +444,6 @@ class SequenceCNN(_HandWritten, nn.Module):
         return out
 
 
-class _W2SFunction(torch.autograd.Function):
-    """The whole forward/backward as one autograd node (inputs: the parameters, in named_parameters order)."""
-
-    @staticmethod
-    def forward(ctx, model, x, *params):
-        save = any(ctx.needs_input_grad[2:])  # (grad mode is off inside Function.forward)
-        eng = model._engine
-        eng.step_seed = model._next_seed() if model.training else 0
-        with torch.cuda.device(model._flat.device):   # launches take the CURRENT device's stream (lib._stream)
-            logits = eng.forward(x, train=model.training, save=save, pack_key=model.param_version())
-        ctx.model = model
-        ctx.saved = eng.ctx
-        eng.ctx = None
-        return logits
-
-    @staticmethod
-    def backward(ctx, glogits):
-        model = ctx.model
-        eng = model._engine
-        eng.ctx = ctx.saved
-        with torch.cuda.device(model._flat.device):
-            eng.backward(glogits.contiguous().float())
-        gflat = model._flat_grad.clone()  # fresh storage per backward: autograd may keep or accumulate these views
-        grads = tuple(gflat[o:o + n].view(shape) for (o, n, shape) in model._layout)
-        return (None, None) + grads
-
-
 class Wav2Sleep(_HandWritten, nn.Module):
     """models/wav2sleep.py:16-80 -- same constructor, attributes and state_dict; compute on libw2s_hip.so."""
 
@@ -466,6 +463,9 @@ class Wav2Sleep(_HandWritten, nn.Module):
         self._seed_base = torch.initial_seed() & 0x7FFFFFFF   # dropout masks follow torch.manual_seed (checkpointed as `w2s_seed_state`)
         self._seed_ctr = 0
         self._param_epoch = 0
+        from . import ops
+        self._handle = ops.register_model(self)
+        self._saved_ctx = _SavedForwards()
 
     # ---------------------------------------------------------------- reference API
     @property
@@ -486,9 +486,13 @@ class Wav2Sleep(_HandWritten, nn.Module):
                 raise W2SError('wav2sleep_amd runs on MI355X only: move the model to a cuda device (there is no CPU fallback)')
             with torch.no_grad(), torch.cuda.device(dev):
                 return GenericForward(training=self.training, seed=self._next_seed() if self.training else 0).wav2sleep(self, x)
-        self._ensure_flat()
-        params = [p for _, p in self.named_parameters()]
-        return _W2SFunction.apply(self, x, *params)
+        # ONE custom operator (ops.py: fake + autograd registered), so a caller's torch.compile traces through this forward
+        params = list(self.parameters())
+        if params[0].device.type != 'cuda' or any(v.device.type != 'cuda' for v in x.values()):
+            from .lib import W2SError
+            raise W2SError('wav2sleep_amd runs on MI355X only: move the model and its inputs to a cuda device (there is no CPU fallback)')
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return torch.ops.w2s.wav2sleep_forward(self._handle, self.training, save, ','.join(x.keys()), list(x.values()), params)[0]
 
     def predict(self, x: dict[str, Tensor]) -> Tensor:
         return self(x).argmax(axis=2)
