@@ -230,9 +230,8 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   }
 }
 
-template <int CI, int NW, int STRIDE, int PRO, int EPI, int MT>
+template <int CI, int NW, int STRIDE, int PRO, int EPI, int MT, int NP = 4>
 static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
-  constexpr int NP = 4;
   constexpr int TM = 16 * MT, HC = CI * 16, NR = (TM - 1) * STRIDE + 3, RSE = HC + (STRIDE == 1 ? 16 : 8);
   WideP P{a.x, a.x2, a.pro_stats, a.pro_bstats, static_cast<const __bf16*>(a.w_hi), static_cast<const __bf16*>(a.w_lo), a.aux, a.aux_stats,
           a.add_even, a.y, a.part, a.B, a.L_in, a.L_out, (a.L_out + TM - 1) / TM, a.flip, 0};
@@ -274,17 +273,14 @@ static bool wide_shape(const w2s_conv_args& a) {
 }
 // dry != 0: only answer which tile an instance would use for this launch (> 0) or that none takes it (1 -> the caller's generic kernel);
 // w2s_conv_tile sizes the statistics partials with it
-static int wide_mt() {
-  static const char* e = getenv("W2S_WIDE_MT");   // tuning only
-  return (e && atoi(e) == 8) ? 8 : 4;
-}
+static int wide_mt() { return 4; }   // 64-position tiles (128 were tried: no gain, more registers)
 int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry) {
   if (!wide_shape(a)) return 1;
   const int mt = wide_mt();
 #define W2S_WIDE(CI_, NW_, ST_, PRO_, EPI_) \
   if (a.cin == 16 * CI_ && a.cout == 16 * NW_ && a.stride == ST_ && a.pro == PRO_ && a.epi == EPI_) { \
     if (dry) return 16 * mt; \
-    return mt == 8 ? launch_wide<CI_, NW_, ST_, PRO_, EPI_, 8>(a, s) : launch_wide<CI_, NW_, ST_, PRO_, EPI_, 4>(a, s); \
+    return launch_wide<CI_, NW_, ST_, PRO_, EPI_, 4>(a, s); \
   }
   W2S_WIDE(2, 4, 1, W2S_PRO_GELU, W2S_EPI_STATS) W2S_WIDE(4, 4, 1, W2S_PRO_GELU, W2S_EPI_STATS)
   W2S_WIDE(4, 8, 1, W2S_PRO_GELU, W2S_EPI_STATS) W2S_WIDE(8, 8, 1, W2S_PRO_GELU, W2S_EPI_STATS)
