@@ -7,11 +7,12 @@ reference weights initialisation (random), fp32 end to end (the reference trains
 
 Prints ONE JSON line (rank 0).  Extra legs, outside the timed region: `roofline` (per-launch HIP-event timing of
 the dominant kernel in one extra step) and `cpu_baseline` (the CPU oracle = the stock-ATen path the reference runs,
-timed on this box's host cores on a bounded sample: the same workload at micro-batch 1).
+timed on this box's host cores on a bounded sample: the same workload at micro-batch 2).
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -24,6 +25,48 @@ SIGNAL_MAP = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
 SPE = {'ABD': 256, 'THX': 256, 'ECG': 1024, 'PPG': 1024}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak
+
+
+def pmc_key(name):
+    """rocprofv3 kernel name -> the LaunchTimer key (conv_wide: <CI, NW, NP, STRIDE, PRO, EPI, MT, PD> -> <CI, NW, STRIDE, PRO, EPI>)."""
+    m = re.match(r'conv_wide_kernel<(\d+), (\d+), \d+, (\d+), (\d+), (\d+), \d+, \d+>', name)
+    return f'conv_wide_kernel<{m[1]}, {m[2]}, {m[3]}, {m[4]}, {m[5]}>' if m else name
+
+
+def family_of(key):
+    """Kernel family of a LaunchTimer key (DESIGN.md section 4 names)."""
+    for prefix, fam in (('bwd_fused_bf_kernel', 'fused backward <=32ch (dgrad+wgrad)'), ('conv_fwd_bf_kernel', 'persistent forward <=32ch'),
+                        ('conv_wide_kernel', 'wide conv >=64ch (fwd + dgrad)'), ('wgrad', 'weight gradient >=64ch / k1 / dilated'),
+                        ('conv_cl_kernel', 'generic conv (1x1, dilated, downsample, UP2 dgrad)')):
+        if key.startswith(prefix):
+            return fam
+    return 'other'
+
+
+def step_traffic(profiles):
+    """HBM bytes one step moves: the committed PMC bytes/launch x the committed kernel-trace launch counts (all kernels, not only the
+    GEMM-shaped ones).  None when the two files are not both there."""
+    import csv
+    import glob
+    tr = sorted(glob.glob(os.path.join(profiles, 'r*_pmc_traffic.json')))
+    ks = sorted(glob.glob(os.path.join(profiles, 'r*_kernel_stats_bench_b16_single_stream.csv')))
+    if not tr or not ks:
+        return None
+    per = json.load(open(tr[-1]))
+    rows = list(csv.DictReader(ln for ln in open(ks[-1]) if not ln.startswith('#')))
+    steps = None
+    for ln in open(ks[-1]):
+        m = re.search(r'\((\d+) train steps', ln) if ln.startswith('#') else None
+        if m:
+            steps = int(m[1])
+    if steps is None:
+        return None
+    tot = 0.0
+    for r in rows:
+        k = r['Name'].split('(')[0].replace('void ', '').strip()
+        if k in per:
+            tot += per[k]['hbm_bytes_per_launch'] * int(r['Calls']) / steps
+    return int(tot)
 
 
 def make_batch(batch, epochs, num_classes, device, seed):
@@ -231,11 +274,13 @@ def main():
         else:
             ach = b_per / avg_s / 1e9
             roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
-        traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-        for fn in sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1:]:
-            t = json.load(open(fn)).get(key)
-            if t and args.batch == 16 and args.epochs == 960 and args.variant == 'cardio' and not args.causal:
-                traffic = int(t['hbm_bytes_per_launch'])
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); only valid for the workload
+        # they were collected on (the default one)
+        pmc = {}
+        if args.batch == 16 and args.epochs == 960 and args.variant == 'cardio' and not args.causal:
+            for fn in sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1:]:
+                pmc = {pmc_key(k): v['hbm_bytes_per_launch'] for k, v in json.load(open(fn)).items()}
+        traffic = int(pmc[key]) if key in pmc else None
         roof.update({'traffic': traffic, 'kernel': key, 'measured': 'HIP events, one extra single-stream step', 'launches_per_step': d['launches'], 'avg_us': round(avg_s * 1e6, 1),
                      'share_of_gemm_kernel_time': round(d['ms'] / total_ms, 3), 'algorithmic_bytes_per_launch': int(b_per),
                      'flops_per_launch': int(f_per)})
@@ -244,6 +289,22 @@ def main():
         step_bytes = 3 * 4 * sum(elems_fwd[s] for s in SIGNAL_MAP) * (args.epochs / 960) * args.batch
         roof['step_algorithmic_GBps'] = round(step_bytes / (dt / args.steps) / 1e9, 1)
         roof['step_frac_of_hbm_peak'] = round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
+        # every GEMM-shaped kernel family of the step, same measurement: time, launches, achieved algorithmic GB/s, and the ratio of
+        # measured HBM traffic (committed PMC) to algorithmic bytes where a counter value exists for every kernel of the family
+        fams = {}
+        for k, v in agg.items():
+            f = fams.setdefault(family_of(k), dict(ms=0.0, launches=0, bytes=0, traffic=0, covered=True))
+            f['ms'] += v['ms']; f['launches'] += v['launches']; f['bytes'] += v['bytes']
+            if k in pmc:
+                f['traffic'] += pmc[k] * v['launches']
+            else:
+                f['covered'] = False
+        roof['families'] = {n: {'ms': round(f['ms'], 3), 'launches': f['launches'], 'GBps': round(f['bytes'] / f['ms'] / 1e6, 1),
+                                'frac': round(f['bytes'] / f['ms'] / 1e6 / HBM_PEAK_GBS, 4),
+                                'traffic_over_algorithmic': round(f['traffic'] / f['bytes'], 3) if f['covered'] and pmc else None}
+                            for n, f in sorted(fams.items(), key=lambda kv: -kv[1]['ms'])}
+        roof['gemm_kernel_ms_per_step'] = round(total_ms, 3)
+        roof['step_traffic_bytes'] = step_traffic(os.path.join(ROOT, 'profiles')) if pmc else None
         line['roofline'] = roof
         top = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
