@@ -156,8 +156,7 @@ int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const
  * split_precision != 0: both products run as bf16x3 (hi/lo planes in LDS, fp32 accumulate).
  * Replaces aten::convolution_backward + native_batch_norm_backward + gelu_backward of blocks.py:173-186.
  */
-int w2s_bwd_fused_tile(int cg, int ch);
-int w2s_bwd_fused_tile_rd(int cg, int ch);   /* tile of the residual-fold form (gpre != NULL) */
+int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd);   /* rd: the residual-fold form (gpre != NULL) */
 int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                   const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
                   int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,

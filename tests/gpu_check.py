@@ -387,7 +387,7 @@ def t_fused_split_precision():
             st = torch.rand(B, cg, 2, device=dev) + 0.5; bst = torch.rand(B, cg, 2, device=dev) * 0.01; sti = torch.rand(B, ch, 2, device=dev) + 0.5
             add_even = torch.randn(B, Lh // 2, ch, device=dev)
             wb = torch.randn(ch, 3, cg, device=dev) / 7
-            tile = lib.bwd_fused_tile(cg, ch); nt = (Lh + tile - 1) // tile
+            tile = lib.bwd_fused_tile(cg, ch, stride); nt = (Lh + tile - 1) // tile
             outs = []
             for sp in (False, True):
                 gout = torch.zeros(B, Lh, ch, device=dev); part = torch.zeros(B, nt, 2, ch, device=dev)
@@ -410,7 +410,7 @@ def t_fused_residual_fold():
             st = torch.rand(B, cg, 2, device=dev) + 0.5; bst = torch.rand(B, cg, 2, device=dev) * 0.01
             gpre = torch.randn(B, Lh // 2, cg, device=dev)
             wb = torch.randn(ch, 3, cg, device=dev) / 7; wd = torch.randn(ch, 1, cg, device=dev) / 5
-            tile = lib.bwd_fused_tile(cg, ch, True); nt = (Lh + tile - 1) // tile; ns = min(B * nt, 5)
+            tile = lib.bwd_fused_tile(cg, ch, 1, True); nt = (Lh + tile - 1) // tile; ns = min(B * nt, 5)
             # reference arm: R = Wd^T gpre via a 1x1 conv, then add_even; downsample wgrad via w2s_wgrad on GELU(xin)
             Rr = torch.zeros(B, Lh // 2, ch, device=dev)
             lib.conv_forward(lib.conv_args(x=gpre, w=wd.view(ch, cg), y=Rr, B=B, L_in=Lh // 2, L_out=Lh // 2, cin=cg, cout=ch, taps=1, stride=1, pad=0))

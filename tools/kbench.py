@@ -59,7 +59,7 @@ def fused_case(cg, ch, L, stride=1, B=16, nslab=None):
     g = torch.randn(B, Lg, cg, device=dev); y = torch.randn(B, Lg, cg, device=dev); xin = torch.randn(B, L, ch, device=dev)
     st = torch.rand(B, cg, 2, device=dev) + 0.5; bst = torch.rand(B, cg, 2, device=dev) * 0.01; sti = torch.rand(B, ch, 2, device=dev) + 0.5
     wb = torch.randn(ch, 3, cg, device=dev) / 7; gout = torch.empty(B, L, ch, device=dev)
-    tile = lib.bwd_fused_tile(cg, ch); nt = (L + tile - 1) // tile
+    tile = lib.bwd_fused_tile(cg, ch, stride); nt = (L + tile - 1) // tile
     part = torch.empty(B, nt, 2, ch, device=dev)
     ns = nslab or int(os.environ.get('NSLAB', 1024))
     slab = torch.empty(ns * cg * ch * 3, device=dev)

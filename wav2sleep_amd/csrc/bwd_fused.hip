@@ -772,20 +772,21 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   return W2S_OK;
 }
 
-#ifndef W2S_BF_MT11
-#define W2S_BF_MT11 4
-#endif
-#ifndef W2S_BF_MT2
-#define W2S_BF_MT2 2
+#ifndef W2S_BF_MT22
+#define W2S_BF_MT22 2
 #endif
 #ifndef W2S_BF_PF
 #define W2S_BF_PF 1
 #endif
+// 64-position sub-tiles per workgroup tile.  16 -> 16: 4 (256 positions; the residual-fold form 2: register budget, see bfk_occ);
+// 32 -> 32 stride 1: W2S_BF_MT22; everything else 2 (the stride-2 form needs an even count: even / odd outputs are separate M tiles).
+constexpr int bf_mt(int cg, int ch, int up2, int rd) {
+  return (cg == 16 && ch == 16) ? (rd ? 2 : 4) : (cg == 32 && ch == 32 && !up2) ? W2S_BF_MT22 : 2;
+}
 // (cg, ch) pairs whose conv1 kernel can fold the residual branch (LDS budget: two workgroups per CU)
 extern "C" int w2s_bwd_fused_folds_residual(int cg, int ch) { return (cg == 16 && ch == 16) || (cg == 32 && ch == 16); }
-extern "C" int w2s_bwd_fused_tile(int cg, int ch) { return 64 * ((cg == 16 && ch == 16) ? W2S_BF_MT11 : W2S_BF_MT2); }
-// ... and of the residual-fold form (gpre != NULL)
-extern "C" int w2s_bwd_fused_tile_rd(int cg, int ch) { return 64 * W2S_BF_MT2; }
+// positions of the input side per tile (= rows of `part` per sample: ceil(Lh / tile)); rd: the residual-fold form (gpre != NULL)
+extern "C" int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd) { return 64 * bf_mt(cg, ch, stride == 2, rd); }
 
 // cg = channels of the gradient side (the forward conv's cout), ch = channels of the input side (its cin).
 extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
@@ -806,18 +807,19 @@ extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, 
   const int up2 = stride == 2;
   if (w1) {  // xin is the raw signal: conv2 of block 0
     if (rd || !st_in || stride != 1 || !split_precision || cg != 16 || ch != 16) return W2S_EINVAL;
-    return launch_bwd_bf<1, 1, W2S_BF_MT11, 0, 0, 1>(P, nslab, s);
+    return launch_bwd_bf<1, 1, bf_mt(16, 16, 0, 0), 0, 0, 1>(P, nslab, s);
   }
-  if (rd && cg == 16 && ch == 16) return launch_bwd_bf<1, 1, W2S_BF_MT2, 0, 1>(P, nslab, s);
-  if (rd && cg == 32 && ch == 16) return launch_bwd_bf<2, 1, W2S_BF_MT2, 0, 1>(P, nslab, s);
-#define W2S_BFS(CG_, CH_, MT_) \
+  if (rd && cg == 16 && ch == 16) return launch_bwd_bf<1, 1, bf_mt(16, 16, 0, 1), 0, 1>(P, nslab, s);
+  if (rd && cg == 32 && ch == 16) return launch_bwd_bf<2, 1, bf_mt(32, 16, 0, 1), 0, 1>(P, nslab, s);
+#define W2S_BFS(CG_, CH_) \
   if (split_precision && cg == 16 * CG_ && ch == 16 * CH_) \
-    return up2 ? launch_bwd_bf<CG_, CH_, MT_, 1, 0>(P, nslab, s) : launch_bwd_bf<CG_, CH_, MT_, 0, 0>(P, nslab, s);
-  W2S_BFS(1, 1, W2S_BF_MT11) W2S_BFS(2, 1, W2S_BF_MT2) W2S_BFS(2, 2, W2S_BF_MT2)
+    return up2 ? launch_bwd_bf<CG_, CH_, bf_mt(16 * CG_, 16 * CH_, 1, 0), 1, 0>(P, nslab, s) : launch_bwd_bf<CG_, CH_, bf_mt(16 * CG_, 16 * CH_, 0, 0), 0, 0>(P, nslab, s);
+  W2S_BFS(1, 1) W2S_BFS(2, 1) W2S_BFS(2, 2)
 #undef W2S_BFS
-#define W2S_BF(CG_, CH_, MT_) \
-  if (cg == 16 * CG_ && ch == 16 * CH_) return up2 ? launch_bwd<CG_, CH_, MT_, 1, W2S_BF_PF>(P, nslab, s) : launch_bwd<CG_, CH_, MT_, 0, W2S_BF_PF>(P, nslab, s);
-  W2S_BF(1, 1, W2S_BF_MT11) W2S_BF(2, 1, W2S_BF_MT2) W2S_BF(2, 2, W2S_BF_MT2)
+#define W2S_BF(CG_, CH_) \
+  if (cg == 16 * CG_ && ch == 16 * CH_) \
+    return up2 ? launch_bwd<CG_, CH_, bf_mt(16 * CG_, 16 * CH_, 1, 0), 1, W2S_BF_PF>(P, nslab, s) : launch_bwd<CG_, CH_, bf_mt(16 * CG_, 16 * CH_, 0, 0), 0, W2S_BF_PF>(P, nslab, s);
+  W2S_BF(1, 1) W2S_BF(2, 1) W2S_BF(2, 2)
 #undef W2S_BF
   return W2S_EINVAL;
 }

@@ -22,6 +22,7 @@ from . import lib
 from .settings import COLS_TO_SAMPLES_PER_EPOCH
 
 _BWD_WGS = int(os.environ.get('W2S_BWD_WGS', 512))       # persistent workgroups of the fused backward (2 per CU)
+_BWD_WGS32 = int(os.environ.get('W2S_BWD_WGS32', _BWD_WGS))
 _BWD_WGS_RD16 = int(os.environ.get('W2S_BWD_WGS_RD16', 768))  # the 16-channel residual-fold kernel fits three per CU
 
 FIRST_TILE = 1024  # positions per statistics partial of the Cin=1 layer
@@ -290,9 +291,9 @@ class Engine:
         """dgrad + wgrad of one k=3 encoder conv in one pass (<= 32 channels); returns the backward statistics or None.
         gpre / down (conv1 of a residual block): fold the 1x1/stride-2 residual branch `down` in as well."""
         dev = g.device
-        tile = lib.bwd_fused_tile(cg, ch, gpre is not None)
+        tile = lib.bwd_fused_tile(cg, ch, stride, gpre is not None)
         nt = _cdiv(Lh, tile)
-        nslab = max(1, min(B * nt, _BWD_WGS_RD16 if (cg == 16 and ch == 16 and gpre is not None) else _BWD_WGS))
+        nslab = max(1, min(B * nt, _BWD_WGS_RD16 if (cg == 16 and ch == 16 and gpre is not None) else _BWD_WGS32 if (cg == 32 and ch == 32) else _BWD_WGS))
         slab = self._slab(dev, nslab, cg * ch * 3)
         slab_d = self._slab(dev, nslab, cg * ch) if gpre is not None else None
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None

@@ -51,7 +51,7 @@ class WgradArgs(C.Structure):
 
 
 EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
-           'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_tile_rd', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
+           'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version']
@@ -289,8 +289,8 @@ def bwd_fused_supported(cg, ch) -> bool:
     return (cg, ch) in ((16, 16), (32, 16), (32, 32))
 
 
-def bwd_fused_tile(cg, ch, rd=False) -> int:
-    return load().w2s_bwd_fused_tile_rd(cg, ch) if rd else load().w2s_bwd_fused_tile(cg, ch)
+def bwd_fused_tile(cg, ch, stride=1, rd=False) -> int:
+    return load().w2s_bwd_fused_tile(cg, ch, stride, int(bool(rd)))
 
 
 def bwd_fused_folds_residual(cg, ch) -> bool:
@@ -307,9 +307,9 @@ def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, s
                   + (B * Lh * cg // 2 if gpre is not None else 0) + (B * Lh * ch if y3p is not None else 0))
     flops = 2 * B * Lg * cg * ch * 3 * 2
     if split_precision:
-        key = f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch, gpre is not None) // 64}, {1 if stride == 2 else 0}, {1 if gpre is not None else 0}, {1 if w1 is not None else 0}>'
+        key = f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch, stride, gpre is not None) // 64}, {1 if stride == 2 else 0}, {1 if gpre is not None else 0}, {1 if w1 is not None else 0}>'
     else:
-        key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch) // 64}, {1 if stride == 2 else 0}, 1>'
+        key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch, stride) // 64}, {1 if stride == 2 else 0}, 1>'
     if DETAIL:
         key += f' L{Lh}'
     _timed(key, nbytes, flops, run)
