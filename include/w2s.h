@@ -108,6 +108,8 @@ typedef struct w2s_wgrad_args {
   int32_t split_precision;                 /* != 0: bf16x3 matrix-core path where available (cin, cout >= 64) */
 } w2s_wgrad_args;
 int w2s_wgrad(const w2s_wgrad_args* a, void* stream);
+int w2s_wgrad_max_blocks(const w2s_wgrad_args* a);   /* grid.x (= nslab / slabs_per_block) the caller should not exceed for this launch (nslab ignored) */
+int w2s_wgrad_slabs_per_block_of(const w2s_wgrad_args* a); /* slabs one grid.x block of THIS launch writes: nslab = grid.x * this */
 int w2s_wgrad_slabs_per_block(int cin, int cout, int taps, int dil); /* slabs written per grid.x block: nslab = grid.x * this */
 int w2s_wgrad_grid_y(int cin, int cout, int taps, int dil); /* grid.y of w2s_wgrad: slab floats = nslab*cout*cin*taps */
 /* grad (+)= sum_s slab[s]; layout 0: grad[o][c][j] (torch Conv1d), 1: grad[o][j][c] (Linear over the flattened taps) */

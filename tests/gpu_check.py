@@ -210,6 +210,46 @@ def t_wgrad():
             lib.wgrad_reduce(slab, nslab, gw, cout, cin, taps, dil)
             report(f'wgrad bf16x3 {cin}->{cout} k{taps} s{stride} d{dil}', gw, w.grad, tol=3e-4)
 
+def t_wgrad_wide():
+    """role-split weight gradient of the >= 64-channel k=3 layers (wgrad_wide.hip) with its on-load transforms vs fp64 torch."""
+    B = 3
+    for (cin, cout, stride, pro_h, L) in [(64, 64, 1, lib.PRO_IN_GELU, 1000), (64, 64, 1, lib.PRO_GELU, 333), (64, 64, 2, lib.PRO_IN_GELU, 1026),
+                                          (128, 128, 1, lib.PRO_IN_GELU, 500), (128, 128, 1, lib.PRO_GELU, 97), (128, 128, 2, lib.PRO_IN_GELU, 258),
+                                          (64, 128, 1, lib.PRO_GELU, 640), (32, 64, 1, lib.PRO_GELU, 777), (64, 64, 1, lib.PRO_IN_GELU, 40), (128, 128, 2, lib.PRO_IN_GELU, 64)]:
+        Lo = L // stride
+        x = torch.randn(B, L, cin, device=dev); g = torch.randn(B, Lo, cout, device=dev); y = torch.randn(B, Lo, cout, device=dev)
+        st = torch.stack([torch.randn(B, cout, device=dev) * 0.1, torch.rand(B, cout, device=dev) + 0.5], dim=-1).contiguous()
+        bst = (torch.randn(B, cout, 2, device=dev) * 0.05).contiguous()
+        sti = torch.stack([torch.randn(B, cin, device=dev) * 0.1, torch.rand(B, cin, device=dev) + 0.5], dim=-1).contiguous()
+        pro_g = lib.PRO_INBWD if stride == 1 else lib.PRO_INBWD_GP
+        kw = dict(g=g, g2=y, g_stats=st, g_bstats=bst, x=x, x_stats=sti if pro_h == lib.PRO_IN_GELU else None, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout,
+                  taps=3, stride=stride, pad=1, pro_g=pro_g, pro_h=pro_h, split_precision=True)
+        assert lib.wgrad_max_blocks(slab=None, nslab=0, **kw) == 256 and lib.wgrad_slabs_per_block_of(slab=None, nslab=0, **kw) == 1, 'not taken by the role-split kernel'
+        nslab = min(5, (B * Lo + 255) // 256)   # the engine's rule: never more workgroups than 256-position chunks
+        slab = torch.full((nslab * cout * cin * 3,), float('nan'), device=dev)
+        lib.wgrad(slab=slab, nslab=nslab, **kw)
+        gw = torch.zeros(cout, cin, 3, device=dev)
+        lib.wgrad_reduce(slab, nslab, gw, cout, cin, 3, 1)
+        # fp64 reference
+        xd, gd, yd = x.double(), g.double(), y.double()
+        n = (yd - st[:, None, :, 0].double()) * st[:, None, :, 1].double()
+        gp = 0.5 * (1 + torch.erf(n / 2 ** 0.5)) + n * torch.exp(-0.5 * n * n) / (2 * math.pi) ** 0.5
+        gn = gd * gp if stride == 2 else gd
+        GY = st[:, None, :, 1].double() * (gn - bst[:, None, :, 0].double() - n * bst[:, None, :, 1].double())
+        hn = (xd - sti[:, None, :, 0].double()) * sti[:, None, :, 1].double() if pro_h == lib.PRO_IN_GELU else xd
+        H = 0.5 * hn * (1 + torch.erf(hn / 2 ** 0.5))
+        w = torch.zeros(cout, cin, 3, device=dev, dtype=torch.float64, requires_grad=True)
+        F.conv1d(H.transpose(1, 2), w, stride=stride, padding=1).backward(GY.transpose(1, 2)[:, :, :Lo])
+        report(f'wgrad wide {cin}->{cout} s{stride} pro_h={pro_h} L{L}', gw, w.grad.float(), tol=3e-4)
+        # many workgroups (one tile each) and the generic kernel must agree with it too
+        nslab2 = min(B * ((Lo + 63) // 64), 256)
+        slab2 = torch.full((nslab2 * cout * cin * 3,), float('nan'), device=dev)
+        lib.wgrad(slab=slab2, nslab=nslab2, **kw)
+        gw2 = torch.zeros(cout, cin, 3, device=dev)
+        lib.wgrad_reduce(slab2, nslab2, gw2, cout, cin, 3, 1)
+        report(f'wgrad wide {cin}->{cout} s{stride} pro_h={pro_h} L{L} ({nslab2} workgroups)', gw2, w.grad.float(), tol=3e-4)
+
+
 def t_causal():
     """Causal padding (blocks.py:150-152,178-182) through the C-ABI: forward pad (k-1)*dil, flipped-tap data gradient pad 0, the
     transposed stride-2 kernel with pad 2, weight gradient pad (k-1)*dil, and the Cin = 1 first layer with its `causal` shift."""
@@ -624,7 +664,7 @@ def t_inkernel_finalize():
     report('in-kernel finalize gp_stats', so, ref, tol=1e-6)
 
 
-STAGES = dict(wide=t_conv_wide, causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

@@ -115,6 +115,8 @@ CASES = {
     'f128s': lambda: conv_case(128, 128, 15360, pro=lib.PRO_NONE, epi=lib.EPI_STATS),
     'd128': lambda: conv_case(128, 128, 15360, pro=lib.PRO_INBWD, epi=lib.EPI_GP, flip=1),
     'w128': lambda: wgrad_case(128, 128, 15360),
+    'w64s2': lambda: wgrad_case(64, 64, 61440, stride=2, pro_g=lib.PRO_INBWD_GP),
+    'w128s2': lambda: wgrad_case(128, 128, 15360, stride=2, pro_g=lib.PRO_INBWD_GP),
     'qkv': lambda: conv_case(128, 384, 76800, B=1, taps=1, pro=lib.PRO_NONE, epi=lib.EPI_BIAS),
     'ff1': lambda: conv_case(128, 512, 76800, B=1, taps=1, pro=lib.PRO_NONE, epi=lib.EPI_BIAS),
     'proj': lambda: conv_case(128, 128, 76800, B=1, taps=1, pro=lib.PRO_NONE, epi=lib.EPI_BIAS),

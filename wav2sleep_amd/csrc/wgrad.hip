@@ -601,6 +601,20 @@ static int dispatch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
   return W2S_EINVAL;
 }
 
+int w2s_wgrad_wide_try(const w2s_wgrad_args& a, hipStream_t s, int dry);   // wgrad_wide.hip
+
+// grid.x the caller should not exceed: the role-split kernel of the >= 64-channel k=3 layers runs one workgroup per CU
+extern "C" int w2s_wgrad_max_blocks(const w2s_wgrad_args* ap) {
+  if (!ap) return W2S_EINVAL;
+  return w2s_wgrad_wide_try(*ap, nullptr, 1) == 0 ? 256 : 512;
+}
+
+// slabs one grid.x block of THIS launch writes (the role-split kernel: 1; otherwise w2s_wgrad_slabs_per_block)
+extern "C" int w2s_wgrad_slabs_per_block_of(const w2s_wgrad_args* ap) {
+  if (!ap) return W2S_EINVAL;
+  return w2s_wgrad_wide_try(*ap, nullptr, 1) == 0 ? 1 : (wg_cfg(ap->cin, ap->cout, ap->taps, ap->dil).ts ? 1 : 4);
+}
+
 extern "C" int w2s_wgrad(const w2s_wgrad_args* ap, void* stream) {
   if (!ap) return W2S_EINVAL;
   const w2s_wgrad_args& a = *ap;
@@ -610,6 +624,7 @@ extern "C" int w2s_wgrad(const w2s_wgrad_args* ap, void* stream) {
   if (a.pro_g >= W2S_PRO_IN_GELU && !a.g_stats) return W2S_EINVAL;
   if (a.pro_g >= W2S_PRO_INBWD && (!a.g_bstats || !a.g2)) return W2S_EINVAL;
   if (a.pro_h >= W2S_PRO_IN_GELU && !a.x_stats) return W2S_EINVAL;
+  if (const int rc = w2s_wgrad_wide_try(a, s, 0); rc != 1) return rc;
   if (a.stride == 1) return dispatch_wgrad<1>(a, s);
   if (a.stride == 2) return dispatch_wgrad<2>(a, s);
   if (a.stride == 4) return dispatch_wgrad<4>(a, s);

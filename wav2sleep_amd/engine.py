@@ -278,11 +278,12 @@ class Engine:
         """weight gradient -> slabs -> deterministic reduce into G[name] (accumulating if already written)."""
         gy = lib.wgrad_grid_y(cin, cout, taps, dil)
         work = _cdiv(B * L_out, 256)
-        gx = max(1, min(work, max(1, 512 // gy)))
-        nslab = gx * lib.wgrad_slabs_per_block(cin, cout, taps, dil)
+        args = dict(g=g, x=x, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad, dil=dil,
+                    split_precision=self.split_precision, **kw)
+        gx = max(1, min(work, max(1, lib.wgrad_max_blocks(slab=None, nslab=0, **args) // gy)))
+        nslab = gx * lib.wgrad_slabs_per_block_of(slab=None, nslab=0, **args)
         slab = self._slab(g.device, nslab, cout * cin * taps)
-        lib.wgrad(g=g, x=x, slab=slab, nslab=nslab, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad,
-                  dil=dil, split_precision=self.split_precision, **kw)
+        lib.wgrad(slab=slab, nslab=nslab, **args)
         self._rjobs.append((slab, nslab, self.G[name], cout, cin, taps, dil, name in self._written, layout))
         self._written.add(name)
 

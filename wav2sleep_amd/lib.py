@@ -50,7 +50,7 @@ class WgradArgs(C.Structure):
                                     'pro_g', 'pro_h', 'nslab', 'split_precision')]
 
 
-EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
+EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
            'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
@@ -229,8 +229,8 @@ def conv_forward(a: ConvArgs):
     _timed(key, nbytes, flops, run)
 
 
-def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, ldg=None, ldx=None, pro_g=PRO_NONE,
-          pro_h=PRO_NONE, g2=None, g_stats=None, g_bstats=None, x_stats=None, split_precision=False):
+def _wgrad_args(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, ldg=None, ldx=None, pro_g=PRO_NONE,
+                pro_h=PRO_NONE, g2=None, g_stats=None, g_bstats=None, x_stats=None, split_precision=False):
     a = WgradArgs()
     a.g, a.g2, a.g_stats, a.g_bstats, a.x, a.x_stats, a.slab = _f(g), _f(g2), _f(g_stats), _f(g_bstats), _f(x), _f(x_stats), _f(slab)
     a.B, a.L_in, a.L_out, a.cin, a.cout, a.taps, a.stride, a.dil, a.pad = B, L_in, L_out, cin, cout, taps, stride, dil, pad
@@ -238,11 +238,30 @@ def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, di
     a.ldx = cin if ldx is None else ldx
     a.pro_g, a.pro_h, a.nslab = pro_g, pro_h, nslab
     a.split_precision = int(bool(split_precision))
+    return a
+
+
+def wgrad_max_blocks(**kw) -> int:
+    """grid.x the caller should not exceed for this launch (same keyword arguments as `wgrad`; slab / nslab may be None / 0)."""
+    return load().w2s_wgrad_max_blocks(C.byref(_wgrad_args(**kw)))
+
+
+def wgrad_slabs_per_block_of(**kw) -> int:
+    """slabs one grid.x block of this launch writes (same keyword arguments as `wgrad`)."""
+    return load().w2s_wgrad_slabs_per_block_of(C.byref(_wgrad_args(**kw)))
+
+
+def wgrad(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, ldg=None, ldx=None, pro_g=PRO_NONE,
+          pro_h=PRO_NONE, g2=None, g_stats=None, g_bstats=None, x_stats=None, split_precision=False):
+    a = _wgrad_args(g=g, x=x, slab=slab, nslab=nslab, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad, dil=dil,
+                    ldg=ldg, ldx=ldx, pro_g=pro_g, pro_h=pro_h, g2=g2, g_stats=g_stats, g_bstats=g_bstats, x_stats=x_stats, split_precision=split_precision)
 
     def run():
         _chk(load().w2s_wgrad(C.byref(a), _stream()), f'w2s_wgrad(cin={cin},cout={cout},taps={taps},stride={stride})')
     nbytes = 4 * (B * L_out * cout * (2 if g2 is not None else 1) + B * L_in * cin)
     ntc = cin // 16
+    if TIMER is not None and load().w2s_wgrad_max_blocks(C.byref(a)) == 256:   # the role-split kernel takes it (wgrad_wide.hip)
+        return _timed(f'wgrad_wide_kernel<{cout // 16}, {cin // 16}, {stride}, {pro_g}, {pro_h}>', nbytes, 2 * B * L_out * cout * cin * taps, run)
     if cin >= 64 and cout >= 64:  # tile-split kernel (wg_cfg in wgrad.hip)
         tapst = 3 if (taps == 3 and dil == 1) else 1
         nw = 8 if cout >= 128 else 4
