@@ -167,8 +167,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
   const int wm0 = wave_m * (16 * MT);  // first tile-local output position of this wave
   const int wn0 = wave_n * (NTW * 16);  // first tile-local output channel of this wave
 
-  auto mma_tap = [&](int jw, int rowoff, int mtmask) {
-    // jw: weight tap index; rowoff: LDS row offset added to the per-position row; mtmask: which m-tiles take part
+  // Weight prefetch (trunk GEMMs only: transformer linears and SequenceCNN convs, PRO_NONE): those launches have 1-2 workgroups per
+  // CU, so nothing hides the L2 round trip of a K step's weight fragments (28 of them in a row for a k=7 conv: measured 41 us per launch
+  // for 5 us of MFMA work).  The fragments of the NEXT K step are requested before the current step's MFMAs; the first request goes
+  // out before the window is staged.  Not for the encoder layers: their occupancy hides the latency and the extra registers cost more.
+#ifdef W2S_NO_WPF
+  constexpr bool WPF = false;
+#else
+  constexpr bool WPF = BF && (PRO == W2S_PRO_NONE) && MODE != W2S_MODE_UP2;
+#endif
+  bf16x8 pah[NTW], pal[NTW];
+  auto load_frag = [&](int kidx) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const size_t wo = ((size_t)((n0 + wn0) / 16 + nt) * (K >> 5) + (size_t)kidx) * 512 + lane * 8;
+      pah[nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_hi) + wo);
+      pal[nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_lo) + wo);
+    }
+  };
+  if constexpr (WPF) { if (cin >= 32) load_frag(0); }
+
+  auto mma_tap = [&](int jw, int rowoff, int mtmask, int jw_next = -1) {
+    // jw: weight tap index; rowoff: LDS row offset added to the per-position row; mtmask: which m-tiles take part;
+    // jw_next (WPF): the tap whose first K step follows this tap's last one (-1: none)
+    if constexpr (WPF) {
+      const int QN = cin >> 5;
+      for (int q = 0; q < QN; ++q) {
+        bf16x8 bh[MT], bl[MT], ah[NTW], al[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) { ah[nt] = pah[nt]; al[nt] = pal[nt]; }
+        // no branch around the loads (a conditional load makes hipcc wait vmcnt(0) everywhere): with nothing left the current step is re-read
+        load_frag((q + 1 < QN) ? jw * QN + q + 1 : (jw_next >= 0 ? jw_next * QN : jw * QN + q));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int row = (MODE == W2S_MODE_DILATED) ? wm0 + mt * 16 + r : (wm0 + mt * 16 + r) * STRIDE + rowoff;
+          bh[mt] = *reinterpret_cast<const bf16x8*>(hiL + row * RSE + q * 32 + 8 * g);
+          bl[mt] = *reinterpret_cast<const bf16x8*>(loL + row * RSE + q * 32 + 8 * g);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          if (mtmask & (1 << mt))
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl[mt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh[mt], acc[mt][nt], 0, 0, 0);
+            }
+      }
+      return;
+    }
     if constexpr (BF) {
       // chunks of 32 input channels; lane (r, g) holds 8 consecutive channels 8g..8g+7 of its row (A: weights of output
       // channel r, B: activations of position r) -- the 16x16x32 bf16 operand layout
@@ -267,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < TAPS; ++j) mma_tap(j, (a.flip ? (TAPS - 1 - j) : j) * dil, (1 << MT) - 1);
+      for (int j = 0; j < TAPS; ++j) mma_tap(j, (a.flip ? (TAPS - 1 - j) : j) * dil, (1 << MT) - 1, j + 1 < TAPS ? j + 1 : -1);
     }
   } else if (MODE == W2S_MODE_DILATED) {
     for (int j = 0; j < TAPS; ++j) {
@@ -275,7 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
       __syncthreads();
       stage(t0 * STRIDE - a.pad + off * a.dil, TM, STRIDE);
       __syncthreads();
-      mma_tap(j, 0, (1 << MT) - 1);
+      mma_tap(j, 0, (1 << MT) - 1, j + 1 < TAPS ? j + 1 : -1);
     }
   } else {  // UP2: output position t' = 2u + phase; phase = mt & 1
     constexpr int EVEN = 0x55 & ((1 << MT) - 1), ODD = 0xAA & ((1 << MT) - 1);
