@@ -147,7 +147,8 @@ int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, vo
  */
 int w2s_conv_fwd_fused_tile(int cin, int cout, int stride);
 int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const float* w1, float* y, float* part, int B, int L_in,
-                       int L_out, int cin, int cout, int stride, int pro, int nwg, float* stat_out, int32_t* stat_cnt, float eps, void* stream);
+                       int L_out, int cin, int cout, int stride, int pad, int pro, int nwg, float* stat_out, int32_t* stat_cnt, float eps,
+                       void* stream);   /* pad: 1 = symmetric, 2 = causal (left pad k-1, blocks.py:150-152) */
 
 /*
  * Fused backward of one encoder ConvLayer1D (k=3, pad=1, stride 1 or 2) for the bandwidth-bound <=32-channel layers:
@@ -161,8 +162,9 @@ int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const
 int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd);   /* rd: the residual-fold form (gpre != NULL) */
 int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                   const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
-                  int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
-                  const float* w1, const float* y3p, const float* st3p, float* stat_out, int32_t* stat_cnt, void* stream);
+                  int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const float* gpre, const float* wd,
+                  float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int32_t* stat_cnt, void* stream);
+/* pad: the forward conv's left padding: 1 = symmetric, 2 = causal (blocks.py:150-152; split_precision only) */
 /* gpre != NULL (conv1 of a residual block; stride 1, split_precision, add_even NULL, w2s_bwd_fused_folds_residual(cg, ch)): the
  * block's 1x1/stride-2 residual branch (blocks.py:44-47,68) is folded in -- gout additionally receives Wd^T gpre[t/2] at even t
  * before the GELU' factor (gpre: [B][Lh/2][cg] = dL/d(block pre-activation), wd: [ch][cg]) and slab_d receives nslab raw-fragment

@@ -20,7 +20,7 @@ struct BwdP {
   const float* g; const float* y; const float* st_k; const float* bst_k;
   const float* xin; const float* st_in; const float* add_even; const float* wb;
   float* gout; float* part; float* slab;
-  int B, Lg, Lh, ntiles, pro;
+  int B, Lg, Lh, ntiles, pro, pad;   // pad 1: symmetric; 2: causal left padding (split-precision kernels only)
   // residual fold (conv1 of a block, split-precision kernel only): gpre = dL/d(block pre-activation) [B][Lh/2][GC],
   // wd = 1x1/stride-2 downsample weight as [HC][GC], slab_d = its weight-gradient slabs (one per workgroup)
   const float* gpre; const float* wd; float* slab_d;
@@ -340,7 +340,8 @@ void bwd_fused_bf_kernel(BwdP P) {
   static_assert(!(RD && UP2), "the residual fold belongs to the stride-1 conv1");
   static_assert(!FIRST || (HC == 16 && !UP2 && !RD), "first-layer recompute: conv2 of block 0");
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2;
-  constexpr int NRh = UP2 ? TM + 1 : TM + 2;
+  constexpr int NRh = TM + 2;                               // h window rows; row 0 = position t0 - pad (stride 2, symmetric: TM + 1 used)
+  const int PL = P.pad;                                     // 1: symmetric padding; 2: causal (left pad 2)
   // data-gradient K axis of the LDS weight image.  32 gradient channels: k = tap*32 + o (one tap per MFMA).
   // 16 gradient channels: two taps share one K = 32 step: stride 1: [tap0 | tap1] [tap2 | 0];
   // stride 2 (even outputs use tap 1, odd outputs taps 2 and 0): [tap1 | 0] [tap2 | tap0].
@@ -411,7 +412,7 @@ void bwd_fused_bf_kernel(BwdP P) {
     // no 64-bit VALU address arithmetic per load
     const float* gb = P.g + (size_t)b * Lg * GC;
     const float* yb = P.y + (size_t)b * Lg * GC;
-    const int rb = UP2 ? t0 / 2 : t0 - 1;
+    const int rb = UP2 ? t0 / 2 : t0 - 2 + PL;   // gy window: the data gradient reads gy[t' + pad - j] at window row (t' - t0) + 2 - j
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
       const int row = grow0 + k * rstep_g, gr = rb + row;
@@ -420,11 +421,11 @@ void bwd_fused_bf_kernel(BwdP P) {
       rg[k] = ok ? ld4o(gb, off) : (f32x4){0, 0, 0, 0};
       ry[k] = ok ? ld4o(yb, off) : (f32x4){0, 0, 0, 0};
     }
-    if (FIRST) {  // TM + 4 signal samples t0-2 .. t0+TM+1: one per thread (+4), exchanged through LDS at commit time
+    if (FIRST) {  // TM + 4 signal samples t0-2pad .. : one per thread (+4), exchanged through LDS at commit time (conv1 pads like this conv)
       const float* xs = P.xin + (size_t)b * Lh;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int i = tid + 256 * k, gr = t0 - 2 + i;
+        const int i = tid + 256 * k, gr = t0 - 2 * PL + i;
         const float xv = xs[min(max(gr, 0), Lh - 1)];
         rxs[k] = (i < TM + 4 && gr >= 0 && gr < Lh && !isinf(xv)) ? xv : 0.f;
       }
@@ -432,7 +433,7 @@ void bwd_fused_bf_kernel(BwdP P) {
       const float* xb = P.xin + (size_t)b * Lh * HC;
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
-        const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
+        const int row = hrow0 + k * rstep_h, gr = t0 - PL + row;
         const bool ok = row < NRh && gr >= 0 && gr < Lh;
         rh[k] = ok ? ld4o(xb, (unsigned)gr * HC + hch) : (f32x4){0, 0, 0, 0};
       }
@@ -467,7 +468,7 @@ void bwd_fused_bf_kernel(BwdP P) {
       f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
       ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z}; ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
     }
-    const int rb = UP2 ? t0 / 2 : t0 - 1;
+    const int rb = UP2 ? t0 / 2 : t0 - 2 + PL;
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
       const int row = grow0 + k * rstep_g, gr = rb + row;
@@ -490,11 +491,11 @@ void bwd_fused_bf_kernel(BwdP P) {
     }
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
-      const int row = hrow0 + k * rstep_h, gr = t0 - 1 + row;
+      const int row = hrow0 + k * rstep_h, gr = t0 - PL + row;
       if (row < NRh) {
         const bool ok = gr >= 0 && gr < Lh;
         f32x4 xv;
-        if (FIRST) {  // window row <-> position t0-1+row; xsL[i] <-> position t0-2+i
+        if (FIRST) {  // window row <-> position t0-pad+row; xsL[i] <-> position t0-2pad+i: conv1 taps at p-1,p,p+1 or p-2,p-1,p
           const float xm = xsL[row], xc = xsL[row + 1], xp = xsL[row + 2];
           xv.x = w1r[0][0] * xm + w1r[0][1] * xc + w1r[0][2] * xp;
           xv.y = w1r[1][0] * xm + w1r[1][1] * xc + w1r[1][2] * xp;
@@ -508,10 +509,10 @@ void bwd_fused_bf_kernel(BwdP P) {
           f32x4 hv, gpv;
           gelu_both4(nv, hv, gpv);
           split_store4(hH, hLo, row * RSh + hch, ok ? hv : (f32x4){0, 0, 0, 0});
-          if (row >= 1 && row <= TM) { st4(nL + (row - 1) * RSn + hch, nv); st4(gpL + (row - 1) * RSn + hch, gpv); }
+          if (row >= PL && row < TM + PL) { st4(nL + (row - PL) * RSn + hch, nv); st4(gpL + (row - PL) * RSn + hch, gpv); }
         } else {
           split_store4(hH, hLo, row * RSh + hch, ok ? gelu4(nv) : (f32x4){0, 0, 0, 0});
-          if (row >= 1 && row <= TM) st4(nL + (row - 1) * RSn + hch, nv);
+          if (row >= PL && row < TM + PL) st4(nL + (row - PL) * RSn + hch, nv);
         }
       }
     }
@@ -565,9 +566,15 @@ void bwd_fused_bf_kernel(BwdP P) {
       };
       if (UP2) {
         constexpr int EVEN = 0x55 & ((1 << MT) - 1), ODD = 0xAA & ((1 << MT) - 1);
-        mma_tap(1, 0, EVEN);
-        mma_tap(2, 0, ODD);
-        mma_tap(0, 1, ODD);
+        if (PL == 2) {          // causal (forward taps at 2u + j - 2): the parities swap roles
+          mma_tap(2, 0, EVEN);  // t' = 2u   : W_2^T g[u]
+          mma_tap(0, 1, EVEN);  //            + W_0^T g[u+1]
+          mma_tap(1, 1, ODD);   // t' = 2u+1 : W_1^T g[u+1]
+        } else {
+          mma_tap(1, 0, EVEN);
+          mma_tap(2, 0, ODD);
+          mma_tap(0, 1, ODD);
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 3; ++j) mma_tap(j, 2 - j, (1 << MT) - 1);
@@ -599,12 +606,21 @@ void bwd_fused_bf_kernel(BwdP P) {
           al[ks][nt] = *reinterpret_cast<const bf16x8*>(wLo + (nt * 16 + r) * WROW + ks * 32 + 8 * g);
         }
       const int col = 8 * (g & 1), second = g >> 1;
+      const bool cz = UP2 && PL == 2;   // causal stride 2: even outputs take [tap2 (row m) | tap0 (row m+1)], odd outputs [tap1 (row m+1) | 0]
+      if (cz) {
+#pragma unroll
+        for (int nt = 0; nt < CH; ++nt) {
+          const bf16x8 th = ah[0][nt], tl2 = al[0][nt];
+          ah[0][nt] = ah[1][nt]; al[0][nt] = al[1][nt];
+          ah[1][nt] = th; al[1][nt] = tl2;
+        }
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         if (UP2) {
           const int m = wave * (8 * MT) + (mt >> 1) * 16 + r;
-          const int ks = mt & 1;                         // even outputs: [tap1 | 0]; odd outputs: [tap2 (row m) | tap0 (row m+1)]
-          const int row = m + ((ks && second) ? 1 : 0);
+          const int ks = mt & 1;                         // even outputs: [tap1 | 0]; odd outputs: [tap2 (row m) | tap0 (row m+1)]  (causal: swapped above)
+          const int row = ((ks != 0) != cz) ? m + second : m + (cz ? 1 : 0);
           const bf16x8 bh = *reinterpret_cast<const bf16x8*>(gyH + row * RSg + col);
           const bf16x8 bl = *reinterpret_cast<const bf16x8*>(gyLo + row * RSg + col);
 #pragma unroll
@@ -689,7 +705,7 @@ void bwd_fused_bf_kernel(BwdP P) {
     for (int s0 = 0; s0 < KS; s0 += KW) {
       const int s = s0 + wk;
       const int p0 = 32 * s + 8 * g + q4;         // this lane's address row (gradient-side position) of the first 4-block
-      const int gr0 = UP2 ? p0 : p0 + 1;
+      const int gr0 = UP2 ? p0 : p0 + 2 - PL;     // window row of gradient-side position p0
       const int gcol = wi * 16 + 4 * p4;
       const bf16x8 ah = lds_tr8(gyH + gr0 * RSg + gcol, gyH + (gr0 + 4) * RSg + gcol);
       const bf16x8 al = lds_tr8(gyLo + gr0 * RSg + gcol, gyLo + (gr0 + 4) * RSg + gcol);
@@ -702,7 +718,7 @@ void bwd_fused_bf_kernel(BwdP P) {
         accw[j] = mfma_bf3(ah, al, bh, bl, accw[j]);
       }
     }
-    if (RD) {  // dWd[o][c] += sum_u gpre[u][o] * h[2u][c]   (window row of position t0 + 2u is 2u + 1)
+    if (RD) {  // dWd[o][c] += sum_u gpre[u][o] * h[2u][c]   (window row of position t0 + 2u is 2u + pad)
       constexpr int KSD = (TM / 2) / 32;
 #pragma unroll
       for (int s0 = 0; s0 < KSD; s0 += KW) {
@@ -712,8 +728,8 @@ void bwd_fused_bf_kernel(BwdP P) {
         const int gcol = wi * 16 + 4 * p4, hcol = wc * 16 + 4 * p4;
         const bf16x8 ah = lds_tr8(pH + p0 * RSg + gcol, pH + (p0 + 4) * RSg + gcol);
         const bf16x8 al = lds_tr8(pLo + p0 * RSg + gcol, pLo + (p0 + 4) * RSg + gcol);
-        const bf16x8 bh = lds_tr8(hH + (2 * p0 + 1) * RSh + hcol, hH + (2 * (p0 + 4) + 1) * RSh + hcol);
-        const bf16x8 bl = lds_tr8(hLo + (2 * p0 + 1) * RSh + hcol, hLo + (2 * (p0 + 4) + 1) * RSh + hcol);
+        const bf16x8 bh = lds_tr8(hH + (2 * p0 + PL) * RSh + hcol, hH + (2 * (p0 + 4) + PL) * RSh + hcol);
+        const bf16x8 bl = lds_tr8(hLo + (2 * p0 + PL) * RSh + hcol, hLo + (2 * (p0 + 4) + PL) * RSh + hcol);
         accd = mfma_bf3(ah, al, bh, bl, accd);
       }
     }
@@ -758,7 +774,7 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   constexpr int TM = 64 * MT, GC = CG * 16, HC = CH * 16, KD = (GC == 32) ? (RD ? 128 : 96) : 64;
   BwdP P = P0;
   P.ntiles = (P.Lh + TM - 1) / TM;
-  constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = UP2 ? TM + 1 : TM + 2, NRp = RD ? TM / 2 + 1 : 0;
+  constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = TM + 2, NRp = RD ? TM / 2 + 1 : 0;
   size_t lds = (size_t)TM * bwd_rs(HC) * 4 * (HC == 16 ? 2 : 1) + (size_t)bwd_redn(CH) * 4 +
                (size_t)2 * 2 * ((NRg + NRp) * bf_rs(GC) + NRh * bf_rs(HC) + HC * (KD + 8));
   if (FIRST) lds += (size_t)(TM + 4) * 4;
@@ -791,14 +807,15 @@ extern "C" int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd) { return 6
 // cg = channels of the gradient side (the forward conv's cout), ch = channels of the input side (its cin).
 extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                              const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
-                             int B, int Lg, int Lh, int cg, int ch, int stride, int split_precision, const float* gpre, const float* wd, float* slab_d,
-                             const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt, void* stream) {
+                             int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const float* gpre, const float* wd,
+                             float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt, void* stream) {
   if (!g || !y || !st_k || !bst_k || !xin || !wb || !gout || !slab || nslab <= 0) return W2S_EINVAL;
   if ((size_t)Lh * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;  // 32-bit lane offsets inside one sample
   if (pro != W2S_PRO_INBWD && pro != W2S_PRO_INBWD_GP) return W2S_EINVAL;
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
   if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in
-  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, gpre, wd, slab_d, w1, y3p, st3p, StatFin{stat_out, stat_cnt, 1.0 / (double)Lh, 0.f, 1}};
+  if (pad != 1 && !(pad == 2 && split_precision)) return W2S_EINVAL;                // causal padding: split-precision kernels only
+  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, pad, gpre, wd, slab_d, w1, y3p, st3p, StatFin{stat_out, stat_cnt, 1.0 / (double)Lh, 0.f, 1}};
   if (stat_out && (!stat_cnt || !part)) return W2S_EINVAL;
   if (y3p && (!gpre || !st3p || !part)) return W2S_EINVAL;
   const bool rd = gpre != nullptr;

@@ -23,7 +23,7 @@ struct WideP {
   const __bf16* w_hi; const __bf16* w_lo;
   const float* aux; const float* aux_st; const float* add_even;
   float* y; float* part;
-  int B, L_in, L_out, ntiles, flip;
+  int B, L_in, L_out, ntiles, flip, pad;   // window row 0 = input position t0*STRIDE - pad (1: symmetric; forward 2 / data gradient 0: causal)
   int dbg;   // tuning only (W2S_WIDE_DBG): 1 = no prologue arithmetic, 2 = no MFMA loop, 4 = no LDS staging, 8 = no stores, 16 = no loads
 };
 
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   // (lanes {0-3,12-15,20-27}, ... MI355X_MICROARCH.md LDS) hit 16 distinct 16-B slots: the +16 B rows of the first cut were 2-way
   // conflicted on every stride-1 read (SQ_LDS_BANK_CONFLICT = 48 % of SQ_LDS_IDX_ACTIVE)
   constexpr int RSE = HC + (STRIDE == 1 ? 16 : 8);
-  constexpr int NR = (TM - 1) * STRIDE + 3;              // window rows; row 0 = input position t0*STRIDE - 1
+  constexpr int NR = (TM - 1) * STRIDE + 3;              // window rows; row 0 = input position t0*STRIDE - pad
   constexpr int QN = HC / 32, KS = 3 * QN;               // K steps of 32: ks = tap * QN + q
   constexpr bool TWO = (PRO == W2S_PRO_INBWD);
   constexpr bool FLIP = (PRO == W2S_PRO_INBWD);          // the data gradient runs the taps backwards over the [cin][taps][cout] packing
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
       constexpr int S = decltype(SET)::value;
       const int tl = first + min(i, nt_wg - 1) * step;
       const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
-      const int row = min(row0 + k * rstep, NR - 1), gr = min(max(t0 * STRIDE - 1 + row, 0), L_in - 1);
+      const int row = min(row0 + k * rstep, NR - 1), gr = min(max(t0 * STRIDE - P.pad + row, 0), L_in - 1);
       const unsigned off = (unsigned)gr * HC + mych;
       rx[S][k] = ld4o(P.x + (size_t)b * L_in * HC, off);
       if constexpr (TWO) rx2[S][k] = ld4o(P.x2 + (size_t)b * L_in * HC, off);
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
       const bool live = i < nt_wg;   // uniform; padding rounds only keep the load queue regular
       const int tl = first + min(i, nt_wg - 1) * step;
       const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
-      const int rb = t0 * STRIDE - 1;
+      const int rb = t0 * STRIDE - P.pad;
       __bf16* hiL = lds + (i & 1) * BUF;
       __bf16* loL = hiL + NR * RSE;
       f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, ps1 = {0, 0, 0, 0}, ps2 = {0, 0, 0, 0};
@@ -234,7 +234,7 @@ template <int CI, int NW, int STRIDE, int PRO, int EPI, int MT, int NP = 4>
 static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
   constexpr int TM = 16 * MT, HC = CI * 16, NR = (TM - 1) * STRIDE + 3, RSE = HC + (STRIDE == 1 ? 16 : 8);
   WideP P{a.x, a.x2, a.pro_stats, a.pro_bstats, static_cast<const __bf16*>(a.w_hi), static_cast<const __bf16*>(a.w_lo), a.aux, a.aux_stats,
-          a.add_even, a.y, a.part, a.B, a.L_in, a.L_out, (a.L_out + TM - 1) / TM, a.flip, 0};
+          a.add_even, a.y, a.part, a.B, a.L_in, a.L_out, (a.L_out + TM - 1) / TM, a.flip, a.pad, 0};
   { static const char* d = getenv("W2S_WIDE_DBG"); if (d) P.dbg = atoi(d); }
   size_t lds = (size_t)2 * 2 * NR * RSE * 2;   // two window buffers x (hi, lo) planes, bf16
   if (PRO != W2S_PRO_GELU) lds += (size_t)a.B * HC * 2 * 4 * (PRO == W2S_PRO_INBWD ? 2 : 1);   // the statistics tables
@@ -259,7 +259,7 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
 
 // 1 = this launch is not one of the wide kernel's shapes (the caller falls through to conv_cl_kernel)
 static bool wide_shape(const w2s_conv_args& a) {
-  if (!a.w_hi || !a.w_lo || a.mode != W2S_MODE_CONTIG || a.taps != 3 || a.dil != 1 || a.pad != 1) return false;
+  if (!a.w_hi || !a.w_lo || a.mode != W2S_MODE_CONTIG || a.taps != 3 || a.dil != 1 || a.pad < 0 || a.pad > 2) return false;
   if (a.y2 || a.rowkeep || a.bias || a.stat_out || a.reserved) return false;
   if ((size_t)a.B * a.cin * 16 > 32 * 1024) return false;   // the per-sample statistics tables live in LDS
   if (a.ldx != a.cin || a.ldy != a.cout || (a.aux && a.ld_aux != a.cout)) return false;

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restr
 // => 6 multiply-adds per sample instead of 16 channels x 5, then a 32-thread expansion per tile.  fp32 partials per tile, fp64 in
 // w2s_stats_finalize as for every other layer.
 __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
-                                                             int L, int tile, int ntiles, StatFin fin) {
+                                                             int L, int tile, int ntiles, StatFin fin, int shift) {
   __shared__ float red[4][9];
   __shared__ float tot[9];
   const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __res
   // S0,S1,S2, A00,A11,A22, A01,A12,A02
   float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int t = t0 + tid; t < t1; t += 256) {
-    const float m = xs(t - 1), c = xs(t), p = xs(t + 1);
+    const float m = xs(t - 1 - shift), c = xs(t - shift), p = xs(t + 1 - shift);   // shift = 1: causal padding (taps at t-2, t-1, t)
     a[0] += m; a[1] += c; a[2] += p;
     a[3] += m * m; a[4] += c * c; a[5] += p * p;
     a[6] += m * c; a[7] += c * p; a[8] += m * p;
@@ -106,13 +106,12 @@ __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __res
 extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, float* stat_out,
                                  int* stat_cnt, float eps, int causal, void* stream) {
   if (!x || !w || !part || cout != 16 || tile < 64 || (tile & 63)) return W2S_EINVAL;  // y == NULL: statistics only
-  if (causal && !y) return W2S_EINVAL;  // the closed-form statistics kernel is written for the symmetric padding
   const int ntiles = (L + tile - 1) / tile;
   if (stat_out && !stat_cnt) return W2S_EINVAL;
   const StatFin fin{stat_out, stat_cnt, 1.0 / (double)L, eps, 0};
   if (!y) {
     hipLaunchKernelGGL(enc_first_stats_kernel, dim3(ntiles, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, part, L, tile, ntiles,
-                       fin);
+                       fin, causal ? 1 : 0);
     W2S_CHECK_LAUNCH();
     return W2S_OK;
   }

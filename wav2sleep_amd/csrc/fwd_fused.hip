@@ -1,6 +1,7 @@
 // Forward k=3 encoder conv for the HBM-heavy <= 32-channel layers as a PERSISTENT kernel (split precision):
 //
-//   y[b,t,o] = sum_{j,c} W[o][c][j] * h[b, t*stride + j - 1, c],    h = GELU(x) | GELU(IN(x)) | GELU(IN(conv1(signal)))
+//   y[b,t,o] = sum_{j,c} W[o][c][j] * h[b, t*stride + j - pad, c],    h = GELU(x) | GELU(IN(x)) | GELU(IN(conv1(signal)))
+//   pad = 1: symmetric padding; pad = 2: causal padding (blocks.py:150-152,178-182: left pad k-1, the right trim is not computed)
 //   part[b][tile][2][CO] = per-tile sums of y and y^2   (instance-norm statistics of the NEXT layer, blocks.py:173-186)
 //
 // Same contract as conv_cl_kernel with EPI_STATS, different execution shape: workgroups walk the (sample, tile) list with a
@@ -13,7 +14,7 @@
 struct FwdP {
   const float* x; const float* w; const float* st_in; const float* w1;
   float* y; float* part;
-  int B, L_in, L_out, ntiles, pro;
+  int B, L_in, L_out, ntiles, pro, pad;
   StatFin fin;   // in-kernel statistics finalisation (fin.out == NULL: partials only)
 };
 
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
   constexpr int TM = 64 * MT;
   constexpr int HC = CI * 16, OC = CO * 16;
   constexpr int RSh = ff_rs(HC);
-  constexpr int NRh = (TM - 1) * STRIDE + 3;             // window rows; row 0 = input position t0*STRIDE - 1
+  constexpr int NRh = (TM - 1) * STRIDE + 3;             // window rows; row 0 = input position t0*STRIDE - pad
   constexpr int KSP = (HC == 16) ? 2 : 3;                // K = 32 steps: [tap0|tap1] [tap2|0]  or one tap each
   constexpr int KD = KSP * 32, WROW = KD + 8;
   float* red = reinterpret_cast<float*>(smem4);          // [4][CO][4][8] statistics scratch
@@ -69,12 +70,12 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
   }
   auto prefetch = [&](int tl) {
     const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
-    const int rb = t0 * STRIDE - 1;
-    if (FIRST) {  // signal samples rb-1 .. rb+NRh
+    const int rb = t0 * STRIDE - P.pad;
+    if (FIRST) {  // signal samples rb-pad .. rb-pad+NRh+1 (conv1 has the same padding mode as this conv)
       const float* xs = P.x + (size_t)b * L_in;
 #pragma unroll
       for (int k = 0; k < NXS; ++k) {
-        const int i = tid + 256 * k, gr = rb - 1 + i;
+        const int i = tid + 256 * k, gr = rb - P.pad + i;
         const float xv = xs[min(max(gr, 0), L_in - 1)];
         rxs[k] = (i < NRh + 2 && gr >= 0 && gr < L_in && !isinf(xv)) ? xv : 0.f;
       }
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
   };
   auto commit = [&](int tl) {
     const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
-    const int rb = t0 * STRIDE - 1;
+    const int rb = t0 * STRIDE - P.pad;
     f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
     if (PRO != W2S_PRO_GELU) {
       const float* st = P.st_in + ((size_t)b * HC + hch) * 2;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
       if (row < NRh) {
         const bool ok = gr >= 0 && gr < L_in;
         f32x4 xv;
-        if (FIRST) {  // window row <-> position rb+row; xsL[i] <-> position rb-1+i
+        if (FIRST) {  // window row <-> position rb+row; xsL[i] <-> position rb-pad+i: taps at p-1,p,p+1 (pad 1) or p-2,p-1,p (pad 2)
           const float xm = xsL[row], xc = xsL[row + 1], xp = xsL[row + 2];
           xv.x = w1r[0][0] * xm + w1r[0][1] * xc + w1r[0][2] * xp;
           xv.y = w1r[1][0] * xm + w1r[1][1] * xc + w1r[1][2] * xp;
@@ -230,16 +231,16 @@ extern "C" int w2s_conv_fwd_fused_tile(int cin, int cout, int stride) {
 }
 
 extern "C" int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const float* w1, float* y, float* part, int B,
-                                  int L_in, int L_out, int cin, int cout, int stride, int pro, int nwg, float* stat_out, int* stat_cnt, float eps,
-                                  void* stream) {
+                                  int L_in, int L_out, int cin, int cout, int stride, int pad, int pro, int nwg, float* stat_out, int* stat_cnt,
+                                  float eps, void* stream) {
   if (!x || !w || !y || !part || B <= 0 || L_out <= 0 || nwg <= 0) return W2S_EINVAL;
   if (!w2s_conv_fwd_fused_tile(cin, cout, stride)) return W2S_EINVAL;
   if (pro != W2S_PRO_GELU && pro != W2S_PRO_IN_GELU && pro != W2S_PRO_FIRST) return W2S_EINVAL;
   if ((pro != W2S_PRO_GELU && !st_in) || (pro == W2S_PRO_FIRST && (!w1 || cin != 16 || stride != 1))) return W2S_EINVAL;
-  if ((stride == 1 && L_out != L_in) || (stride == 2 && 2 * L_out != L_in)) return W2S_EINVAL;
+  if ((stride == 1 && L_out != L_in) || (stride == 2 && 2 * L_out != L_in) || (pad != 1 && pad != 2)) return W2S_EINVAL;
   if ((size_t)L_in * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;
   if (stat_out && !stat_cnt) return W2S_EINVAL;
-  FwdP P{x, w, st_in, w1, y, part, B, L_in, L_out, 0, pro, StatFin{stat_out, stat_cnt, 1.0 / (double)L_out, eps, 0}};
+  FwdP P{x, w, st_in, w1, y, part, B, L_in, L_out, 0, pro, pad, StatFin{stat_out, stat_cnt, 1.0 / (double)L_out, eps, 0}};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define W2S_FF(CI_, CO_, MT_, ST_) \
   if (cin == 16 * CI_ && cout == 16 * CO_ && stride == ST_) { \

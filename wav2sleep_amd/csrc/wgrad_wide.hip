@@ -1,6 +1,6 @@
 // Weight gradient of the k=3 encoder convolutions with >= 64 channels on a side, as a PERSISTENT, ROLE-SPLIT split-precision kernel.
 //
-//   dW[o][j][c] = sum_{b,t} GY[b,t,o] * H[b, t*STRIDE + j - 1, c]          (w2s_wgrad's contract, taps = 3, dil = 1, pad = 1)
+//   dW[o][j][c] = sum_{b,t} GY[b,t,o] * H[b, t*STRIDE + j - pad, c]        (w2s_wgrad's contract, taps = 3, dil = 1, pad = 1 or 2 = causal)
 //   GY = instance-norm backward of the incoming gradient (PG = W2S_PRO_INBWD; W2S_PRO_INBWD_GP for the stride-2 conv3, whose incoming
 //        gradient is with respect to the block's pre-activation output), H = GELU(IN(x)) or GELU(x) (PH)
 //
@@ -22,7 +22,7 @@ struct WgWideP {
   const float* g; const float* g2; const float* gst; const float* gbst;
   const float* x; const float* xst;
   float* slab;
-  int B, Lg, Lh, ntiles;
+  int B, Lg, Lh, ntiles, pad;   // pad 1: symmetric; 2: causal
   int dbg;   // tuning only (W2S_WGW_DBG): 1 = no on-load arithmetic, 2 = no MFMA loop, 4 = no LDS staging
 };
 
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void wgrad_wide_kernel(WgWideP P) {
   extern __shared__ f32x4 smem4[];
   static_assert((CO / IB) * (CI / CB) == NWC, "consumer wave grid");
   constexpr int OC = CO * 16, HC = CI * 16, TM = 32 * MT, NPT = 256;
-  constexpr int NRh = (TM - 1) * STRIDE + 3;            // input-side window rows; row 0 = position t0*STRIDE - 1
+  constexpr int NRh = (TM - 1) * STRIDE + 3;            // input-side window rows; row 0 = position t0*STRIDE - pad
   constexpr int RSg = OC + 8, RSh = HC + 8;              // bf16 elements per LDS row
   constexpr int BUF = 2 * TM * RSg + 2 * NRh * RSh;      // one buffer: gy hi, gy lo, h hi, h lo
   constexpr bool HST = (PH == W2S_PRO_IN_GELU);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void wgrad_wide_kernel(WgWideP P) {
       constexpr int S = decltype(SET)::value;
       const int tl = first + min(i, nt_wg - 1) * step;
       const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
-      const int row = min(hrow0 + k * rsh, NRh - 1), gr = min(max(t0 * STRIDE - 1 + row, 0), P.Lh - 1);
+      const int row = min(hrow0 + k * rsh, NRh - 1), gr = min(max(t0 * STRIDE - P.pad + row, 0), P.Lh - 1);
       rh[S][k] = ld4o(P.x + (size_t)b * P.Lh * HC, (unsigned)gr * HC + hch);
     };
     auto stage = [&](auto SET, int i) {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void wgrad_wide_kernel(WgWideP P) {
         const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
         hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
       }
-      const int rb = t0 * STRIDE - 1;
+      const int rb = t0 * STRIDE - P.pad;
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
         const int row = hrow0 + k * rsh, gr = rb + row;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void wgrad_wide_kernel(WgWideP P) {
 template <int CO, int CI, int STRIDE, int PG, int PH, int MT, int NWC, int IB, int CB, int PD>
 static int launch_wgw(const w2s_wgrad_args& a, hipStream_t s, int dry) {
   constexpr int OC = CO * 16, HC = CI * 16, TM = 32 * MT, NRh = (TM - 1) * STRIDE + 3;
-  WgWideP P{a.g, a.g2, a.g_stats, a.g_bstats, a.x, a.x_stats, a.slab, a.B, a.L_out, a.L_in, (a.L_out + TM - 1) / TM, 0};
+  WgWideP P{a.g, a.g2, a.g_stats, a.g_bstats, a.x, a.x_stats, a.slab, a.B, a.L_out, a.L_in, (a.L_out + TM - 1) / TM, a.pad, 0};
   { static const char* d = getenv("W2S_WGW_DBG"); if (d) P.dbg = atoi(d); }
   size_t lds = (size_t)2 * (2 * TM * (OC + 8) + 2 * NRh * (HC + 8)) * 2 + (size_t)a.B * OC * 4 * 4 + (PH == W2S_PRO_IN_GELU ? (size_t)a.B * HC * 2 * 4 : 0);
   if (lds > 160 * 1024) return 1;   // (batch too large for the LDS statistics tables)
@@ -239,7 +239,7 @@ static int launch_wgw(const w2s_wgrad_args& a, hipStream_t s, int dry) {
 }
 
 static bool wgw_shape(const w2s_wgrad_args& a) {
-  if (!a.split_precision || a.taps != 3 || a.dil != 1 || a.pad != 1 || (a.stride != 1 && a.stride != 2)) return false;
+  if (!a.split_precision || a.taps != 3 || a.dil != 1 || (a.pad != 1 && a.pad != 2) || (a.stride != 1 && a.stride != 2)) return false;
   if (a.ldg != a.cout || a.ldx != a.cin || !a.g2 || !a.g_stats || !a.g_bstats) return false;
   if (a.cin < 32 || a.cout < 64) return false;
   static const char* off = getenv("W2S_NO_WGRAD_WIDE");   // tuning only

@@ -117,14 +117,13 @@ class Engine:
                         self.G[name] = torch.zeros(c, cin, 1, device=some.device, dtype=torch.float32)
                     cin = c
         # causal padding (scripts/config/main.yaml:22 `causal`): out[j] reads x[j*stride - (k-1-tap)*dil], zeros before the start.  Same
-        # kernels, different pad: forward pad (k-1)*dil, data-gradient (flipped taps) pad 0.  The <= 32-channel fused kernels and
-        # the first-layer recompute are written for the symmetric padding, so the causal model runs on the generic kernels.
+        # kernels, different pad: forward pad (k-1)*dil, data-gradient (flipped taps) pad 0; the fused / persistent kernels take the
+        # left padding as a parameter (window origin t0*stride - pad; the stride-2 transposed forms swap the roles of the parities).
         self.chunk = bool(spec.causal and spec.chunk_causal)
         self.causal = bool(spec.causal) and not self.chunk   # = `_causal_conv_mode`, wav2sleep.py:204
         self.seq_causal = bool(spec.seq_causal)
         self.kpad = 2 if self.causal else 1
-        if self.causal:
-            self.fused_forward = False
+        self._fused_bwd_ok = self.split_precision or not self.causal   # the exact-fp32 fused backward is written for symmetric padding
         lib.load()
 
     # ------------------------------------------------------------------ weights
@@ -245,14 +244,14 @@ class Engine:
         """k=3 encoder conv writing the pre-norm tensor + instance-norm statistics (blocks.py:174-183)."""
         dev = x.device
         y = torch.empty(B, L_out, cout, device=dev, dtype=torch.float32)
-        ftile = lib.conv_fwd_fused_tile(cin, cout, stride) if (self.split_precision and self.fused_forward and not self.causal) else 0
+        ftile = lib.conv_fwd_fused_tile(cin, cout, stride) if (self.split_precision and self.fused_forward) else 0
         if ftile and pro in (lib.PRO_GELU, lib.PRO_IN_GELU, lib.PRO_FIRST):
             # <= 32 channels: persistent split-precision forward kernel (prefetch + LDS-resident weights)
             nt = _cdiv(L_out, ftile)
             part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
             so, sc = self._fin(B, cout, dev)
             lib.conv_fwd_fused(x=x, w=w, st_in=pro_stats, w1=x2, y=y, part=part, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, stride=stride,
-                               pro=pro, nwg=1024 if cin == 16 else 512, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps)
+                               pro=pro, pad=self.kpad, nwg=1024 if cin == 16 else 512, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps)
             return y, (so if so is not None else self._finalize(part, B, nt, cout, L_out, 0))
         return y, self._conv_part(x=x, x2=x2, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=self.kpad, pro=pro,
                                   pro_stats=pro_stats, epi=lib.EPI_STATS, kind=0, **({'ldx': 4} if pro == lib.PRO_FIRST else {}))
@@ -300,7 +299,7 @@ class Engine:
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         so, sc = self._fin(B, ch, dev) if want_part else (None, None)
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
-                      part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, split_precision=self.split_precision,
+                      part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, pad=self.kpad, split_precision=self.split_precision,
                       gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1, y3p=y3p, st3p=st3p, stat_out=so, stat_cnt=sc)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
@@ -358,7 +357,7 @@ class Engine:
         # The Cin = 1 conv1 output (16 x T per recording: the largest tensor of the model) is only materialised when someone
         # needs it (debug taps, the exact-fp32 backward kernels); otherwise its consumers recompute it from the raw signal
         # (W2S_PRO_FIRST: 3 FMAs per element) and only its instance-norm statistics are computed here.
-        recompute = self.split_precision and self.taps is None and c == 16 and not self.causal
+        recompute = self.split_precision and self.taps is None and c == 16
         w1 = P[pfx + 'cnn.0.conv1.conv.weight']
         y1 = None if recompute else torch.empty(B, L, c, device=dev, dtype=torch.float32)
         nt = _cdiv(L, FIRST_TILE)
@@ -789,7 +788,7 @@ class Engine:
                 bs3 = so if so is not None else self._bstats(part, B, nt, c, Lh)
             gn2 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
             gn1 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
-            if lib.bwd_fused_supported(c, c) and not self.causal:
+            if lib.bwd_fused_supported(c, c) and self._fused_bwd_ok:
                 bs2 = self._bwd_fused(p + 'conv3.conv.weight', g=gpre, y=blk['y3'], st_k=blk['st3'], bst_k=bs3, pro=lib.PRO_INBWD_GP,
                                       xin=blk['y2'], st_in=blk['st2'], add_even=None, gout=gn2, want_part=True, B=B, Lg=Lh, Lh=L, cg=c, ch=c, stride=2)
                 first = i == 0 and blk['y1'] is None   # block 0's conv1 output is recomputed from the raw signal
@@ -808,7 +807,7 @@ class Engine:
                 self._wgrad(p + 'conv2.conv.weight', g=gn2, g2=blk['y2'], g_stats=blk['st2'], g_bstats=bs2, pro_g=lib.PRO_INBWD, x=blk['y1'],
                             x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=self.kpad)
             del gn2
-            if i > 0 and self.split_precision and not self.causal and lib.bwd_fused_supported(c, cin) and lib.bwd_fused_folds_residual(c, cin) and not (L & 1):
+            if i > 0 and self.split_precision and lib.bwd_fused_supported(c, cin) and lib.bwd_fused_folds_residual(c, cin) and not (L & 1):
                 # conv1 + the whole residual branch (its data gradient AND its weight gradient) in one pass over the tensors
                 gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
                 prev = ec['blocks'][i - 1] if self.fold_gp else dict(y3=None, st3=None)   # fold its conv3-backward statistics pre-pass in
@@ -823,7 +822,7 @@ class Engine:
                 Rr = torch.empty(B, Lh, cin, device=dev, dtype=torch.float32)
                 self._conv(x=gpre, w=PB[p + 'downsample.weight'], y=Rr, B=B, L_in=Lh, L_out=Lh, cin=c, cout=cin, taps=1, stride=1, pad=0)
                 gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
-                if lib.bwd_fused_supported(c, cin) and not self.causal:
+                if lib.bwd_fused_supported(c, cin) and self._fused_bwd_ok:
                     self._bwd_fused(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, pro=lib.PRO_INBWD, xin=blk['pin'],
                                     st_in=None, add_even=Rr, gout=gprev, want_part=False, B=B, Lg=L, Lh=L, cg=c, ch=cin, stride=1)
                 else:

@@ -291,9 +291,9 @@ def conv_fwd_fused_tile(cin, cout, stride) -> int:
     return load().w2s_conv_fwd_fused_tile(cin, cout, stride)
 
 
-def conv_fwd_fused(*, x, w, st_in, w1, y, part, B, L_in, L_out, cin, cout, stride, pro, nwg, stat_out=None, stat_cnt=None, eps=1e-2):
+def conv_fwd_fused(*, x, w, st_in, w1, y, part, B, L_in, L_out, cin, cout, stride, pro, nwg, pad=1, stat_out=None, stat_cnt=None, eps=1e-2):
     def run():
-        _chk(load().w2s_conv_fwd_fused(_f(x), _f(w), _f(st_in), _f(w1), _f(y), _f(part), B, L_in, L_out, cin, cout, stride, pro, nwg, _f(stat_out),
+        _chk(load().w2s_conv_fwd_fused(_f(x), _f(w), _f(st_in), _f(w1), _f(y), _f(part), B, L_in, L_out, cin, cout, stride, pad, pro, nwg, _f(stat_out),
                                        _p(stat_cnt), C.c_float(eps), _stream()),
              f'w2s_conv_fwd_fused(cin={cin},cout={cout},stride={stride},pro={pro})')
     nbytes = 4 * (B * L_in * (1 if pro == PRO_FIRST else cin) + B * L_out * cout)
@@ -316,11 +316,11 @@ def bwd_fused_folds_residual(cg, ch) -> bool:
     return bool(load().w2s_bwd_fused_folds_residual(cg, ch))
 
 
-def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False,
+def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False, pad=1,
               gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None, stat_out=None, stat_cnt=None):
     def run():
         _chk(load().w2s_bwd_fused(_f(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), _f(gout), _f(part),
-                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p), _f(stat_out), _p(stat_cnt), _stream()),
+                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, pad, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p), _f(stat_out), _p(stat_cnt), _stream()),
              f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
     nbytes = 4 * (2 * B * Lg * cg + (B * Lh * (ch + 1) if w1 is not None else 2 * B * Lh * ch) + (B * Lh * ch // 2 if add_even is not None else 0)
                   + (B * Lh * cg // 2 if gpre is not None else 0) + (B * Lh * ch if y3p is not None else 0))

@@ -94,7 +94,8 @@ class _HandWritten:
                 if kw['backend'] != 'inductor':
                     kw.pop('mode', None)
                     kw.pop('options', None)
-            self._ensure_flat()   # parameter storage is settled before tracing
+            if next(self.parameters()).device.type == 'cuda':
+                self._ensure_flat()   # parameter storage is settled before tracing (a model compiled on the host settles at its first forward)
             return nn.Module.compile(self, *args, **kw)
         logger.info('%s.compile(%s): the forward already is hand-written gfx950 code; nothing to compile', type(self).__name__, kwargs)
 
