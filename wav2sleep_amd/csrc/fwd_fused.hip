@@ -9,8 +9,12 @@
 // (conv_cl's one-tile workgroups serialise load latency, prologue arithmetic, MFMA and store drain), the weights live in
 // LDS as bf16 hi/lo planes for the whole launch, and every product is 3 x v_mfma_f32_16x16x32_bf16 (16 input channels: two
 // taps share one K = 32 step).  Replaces aten::convolution + native_batch_norm(statistics) of ConvLayer1D.forward.
+#include <type_traits>
 #include "conv_cl.inl"
 
+#ifndef W2S_FF_DBG
+#define W2S_FF_DBG 0   // tuning builds only: 1 = no on-load arithmetic, 2 = no MFMA loop, 4 = no LDS staging, 8 = no y stores
+#endif
 struct FwdP {
   const float* x; const float* w; const float* st_in; const float* w1;
   float* y; float* part;
@@ -26,16 +30,23 @@ __device__ __forceinline__ void fsplit_store4(__bf16* hi, __bf16* lo, int off, f
   *reinterpret_cast<bf16x4f*>(lo + off) = l;
 }
 __host__ __device__ constexpr int ff_rs(int c) { return c == 16 ? 16 : c + 8; }  // 32-B rows are conflict-free as they are
+// Output positions per tile.  The window of a TM-position tile has TM*stride + 2 (stride 1) / + 1 (stride 2) rows; 256 threads stage
+// 64 rows of 16 channels (32 rows of 32) per pass, so the two halo rows cost wave 0 a whole extra pass of prologue arithmetic (erf-GELU,
+// split) -- +25 % on the critical path of a VALU-bound kernel, and on the SIMD that hosts wave 0 of every workgroup.  Tiles of
+// TM - 2 (TM - 1) positions make the window exactly TM*stride (- 1) rows: no ragged pass; the matrix cores compute the 2 (1) spare
+// rows from whatever follows the window in LDS and the epilogue drops them.
+__host__ __device__ constexpr int ff_ts(int tm, int stride) { return stride == 1 ? tm - 2 : tm - 1; }
 
 // CI / CO: input / output channel tiles (16 each); MT: 16-position m-tiles per wave (TM = 64*MT outputs per tile);
 // PRO: W2S_PRO_GELU, W2S_PRO_IN_GELU or W2S_PRO_FIRST (x = raw signal, w1 = block 0's conv1 weight)
 template <int CI, int CO, int MT, int STRIDE, int PRO>
 __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
   extern __shared__ f32x4 smem4[];
-  constexpr int TM = 64 * MT;
+  constexpr int TM = 64 * MT;                            // output rows the matrix cores compute per tile ...
+  constexpr int TS = ff_ts(TM, STRIDE);                  // ... of which the first TS are the tile (the rest is discarded): see ff_ts
   constexpr int HC = CI * 16, OC = CO * 16;
   constexpr int RSh = ff_rs(HC);
-  constexpr int NRh = (TM - 1) * STRIDE + 3;             // window rows; row 0 = input position t0*STRIDE - pad
+  constexpr int NRh = (TS - 1) * STRIDE + 3;             // window rows; row 0 = input position t0*STRIDE - pad
   constexpr int KSP = (HC == 16) ? 2 : 3;                // K = 32 steps: [tap0|tap1] [tap2|0]  or one tap each
   constexpr int KD = KSP * 32, WROW = KD + 8;
   float* red = reinterpret_cast<float*>(smem4);          // [4][CO][4][8] statistics scratch
@@ -60,37 +71,39 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
   const int hc4 = tid % c4h, hrow0 = tid / c4h, hch = hc4 * 4;
   constexpr bool FIRST = PRO == W2S_PRO_FIRST;
   constexpr int NXS = FIRST ? (NRh + 2 + 255) / 256 : 1;
-  f32x4 rh[FIRST ? 1 : NH];
-  float rxs[NXS], w1r[4][3];
+  // two register sets: the raw windows of the next TWO tiles are in flight while one is transformed (bytes in flight per CU, not
+  // arithmetic, is what bounds these kernels).  Loads are unconditional (clamped addresses; out-of-range rows are zeroed at commit
+  // time): a conditional load makes hipcc drain the whole queue (vmcnt(0)) at every wait.
+  f32x4 rh[2][FIRST ? 1 : NH];
+  float rxs[2][NXS], w1r[4][3];
   if (FIRST) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) w1r[i][j] = P.w1[(hch + i) * 3 + j];
   }
-  auto prefetch = [&](int tl) {
-    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+  const int total = P.B * P.ntiles;
+  auto prefetch = [&](auto SET, int tl_) {
+    constexpr int S = decltype(SET)::value;
+    const int tl = min(tl_, total - 1);
+    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TS;
     const int rb = t0 * STRIDE - P.pad;
     if (FIRST) {  // signal samples rb-pad .. rb-pad+NRh+1 (conv1 has the same padding mode as this conv)
       const float* xs = P.x + (size_t)b * L_in;
 #pragma unroll
-      for (int k = 0; k < NXS; ++k) {
-        const int i = tid + 256 * k, gr = rb - P.pad + i;
-        const float xv = xs[min(max(gr, 0), L_in - 1)];
-        rxs[k] = (i < NRh + 2 && gr >= 0 && gr < L_in && !isinf(xv)) ? xv : 0.f;
-      }
+      for (int k = 0; k < NXS; ++k) rxs[S][k] = xs[min(max(rb - P.pad + tid + 256 * k, 0), L_in - 1)];
     } else {
       const float* xb = P.x + (size_t)b * L_in * HC;
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
-        const int row = hrow0 + k * rstep, gr = rb + row;
-        const bool ok = row < NRh && gr >= 0 && gr < L_in;
-        rh[k] = ok ? ld4o(xb, (unsigned)gr * HC + hch) : (f32x4){0, 0, 0, 0};
+        const int row = min(hrow0 + k * rstep, NRh - 1), gr = min(max(rb + row, 0), L_in - 1);
+        rh[S][k] = ld4o(xb, (unsigned)gr * HC + hch);
       }
     }
   };
-  auto commit = [&](int tl) {
-    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+  auto commit = [&](auto SET, int tl) {
+    constexpr int S = decltype(SET)::value;
+    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TS;
     const int rb = t0 * STRIDE - P.pad;
     f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
     if (PRO != W2S_PRO_GELU) {
@@ -100,8 +113,11 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
     }
     if (FIRST) {
 #pragma unroll
-      for (int k = 0; k < NXS; ++k)
-        if (tid + 256 * k < NRh + 2) xsL[tid + 256 * k] = rxs[k];
+      for (int k = 0; k < NXS; ++k) {
+        const int i = tid + 256 * k, gr = rb - P.pad + i;
+        const float xv = rxs[S][k];
+        if (i < NRh + 2) xsL[i] = (gr >= 0 && gr < L_in && !isinf(xv)) ? xv : 0.f;
+      }
       __syncthreads();
     }
 #pragma unroll
@@ -117,28 +133,30 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
           xv.z = w1r[2][0] * xm + w1r[2][1] * xc + w1r[2][2] * xp;
           xv.w = w1r[3][0] * xm + w1r[3][1] * xc + w1r[3][2] * xp;
         } else {
-          xv = rh[k];
+          xv = rh[S][k];
         }
-        fsplit_store4(hH, hLo, row * RSh + hch, ok ? gelu4((xv - hm) * hr) : (f32x4){0, 0, 0, 0});
+        if (!(W2S_FF_DBG & 4)) fsplit_store4(hH, hLo, row * RSh + hch, ok ? ((W2S_FF_DBG & 1) ? xv - hm : gelu4((xv - hm) * hr)) : (f32x4){0, 0, 0, 0});
       }
     }
   };
 
-  const int total = P.B * P.ntiles;
-  if ((int)blockIdx.x < total) prefetch(blockIdx.x);
-  for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
-    const int b = tl / P.ntiles, tile = tl % P.ntiles;
-    const int t0 = tile * TM;
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  auto body = [&](auto SET, int tl) {
+    const bool live = tl < total;   // workgroup-uniform; a dead round only keeps the load queue regular
+    const int b = min(tl, total - 1) / P.ntiles, tile = min(tl, total - 1) % P.ntiles;
+    const int t0 = tile * TS;
     __syncthreads();  // previous tile's LDS reads (and its statistics scratch) are done; weights are written
-    commit(tl);
-    if (tl + (int)gridDim.x < total) prefetch(tl + gridDim.x);
+    if (live) commit(SET, tl);
+    prefetch(SET, tl + 2 * (int)gridDim.x);
     __syncthreads();
+    if (!live) return;
 
     f32x4 acc[MT][CO];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < CO; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
+    if (!(W2S_FF_DBG & 2))
 #pragma unroll
     for (int ks = 0; ks < KSP; ++ks) {
       bf16x8 ah[CO], al[CO];
@@ -172,14 +190,14 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
     float* yb = P.y + (size_t)b * L_out * OC;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int pos = t0 + wave * (16 * MT) + mt * 16 + r;
-      if (pos >= L_out) continue;
+      const int m = wave * (16 * MT) + mt * 16 + r, pos = t0 + m;
+      if (pos >= L_out || m >= TS) continue;
 #pragma unroll
       for (int nt = 0; nt < CO; ++nt) {
         const f32x4 v = acc[mt][nt];
         sA[nt] += v;
         sB[nt] += v * v;
-        st4o(yb, (unsigned)pos * OC + nt * 16 + 4 * g, v);
+        if (!(W2S_FF_DBG & 8)) st4o(yb, (unsigned)pos * OC + nt * 16 + 4 * g, v);
       }
     }
 #pragma unroll
@@ -203,14 +221,21 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
       w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c], s);
     }
     w2s_stat_finish(P.fin, P.part, b, P.ntiles, OC, P.ntiles);
+  };
+  const int first = blockIdx.x, step = gridDim.x;   // the grid never exceeds the tile count
+  prefetch(I0{}, first);
+  prefetch(I1{}, first + step);
+  for (int tl = first; tl < total; tl += 2 * step) {
+    body(I0{}, tl);
+    body(I1{}, tl + step);
   }
 }
 
 template <int CI, int CO, int MT, int STRIDE, int PRO>
 static int launch_fwd(const FwdP& P0, int nwg, hipStream_t s) {
-  constexpr int TM = 64 * MT, HC = CI * 16, OC = CO * 16, NRh = (TM - 1) * STRIDE + 3, KD = (HC == 16 ? 2 : 3) * 32;
+  constexpr int TM = 64 * MT, TS = ff_ts(TM, STRIDE), HC = CI * 16, OC = CO * 16, NRh = (TS - 1) * STRIDE + 3, KD = (HC == 16 ? 2 : 3) * 32;
   FwdP P = P0;
-  P.ntiles = (P.L_out + TM - 1) / TM;
+  P.ntiles = (P.L_out + TS - 1) / TS;
   size_t lds = (size_t)4 * CO * 4 * 8 * 4 + (size_t)2 * 2 * (NRh * ff_rs(HC) + OC * (KD + 8));
   if (PRO == W2S_PRO_FIRST) lds += (size_t)(NRh + 2) * 4;
   auto kern = conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO>;
@@ -227,7 +252,7 @@ static inline int fwd_mt(int cin, int cout, int stride) { return (cin == 32 && s
 // positions per tile (sizes the statistics partials: [B][ceil(L_out/tile)][2][cout]); 0 = combination not covered
 extern "C" int w2s_conv_fwd_fused_tile(int cin, int cout, int stride) {
   const bool ok = (cin == 16 || cin == 32) && (cout == 16 || cout == 32) && cout >= cin && (stride == 1 || stride == 2);
-  return ok ? 64 * fwd_mt(cin, cout, stride) : 0;
+  return ok ? ff_ts(64 * fwd_mt(cin, cout, stride), stride) : 0;
 }
 
 extern "C" int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const float* w1, float* y, float* part, int B,

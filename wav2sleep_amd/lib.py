@@ -297,7 +297,7 @@ def conv_fwd_fused(*, x, w, st_in, w1, y, part, B, L_in, L_out, cin, cout, strid
                                        _p(stat_cnt), C.c_float(eps), _stream()),
              f'w2s_conv_fwd_fused(cin={cin},cout={cout},stride={stride},pro={pro})')
     nbytes = 4 * (B * L_in * (1 if pro == PRO_FIRST else cin) + B * L_out * cout)
-    mt = conv_fwd_fused_tile(cin, cout, stride) // 64
+    mt = (conv_fwd_fused_tile(cin, cout, stride) + 2) // 64   # tiles are 64*MT - 2 (stride 1) or - 1 (stride 2) positions
     key = f'conv_fwd_bf_kernel<{cin // 16}, {cout // 16}, {mt}, {stride}, {pro}>'
     if DETAIL:
         key += f' L{L_out}'
