@@ -210,6 +210,43 @@ def t_wgrad():
             lib.wgrad_reduce(slab, nslab, gw, cout, cin, taps, dil)
             report(f'wgrad bf16x3 {cin}->{cout} k{taps} s{stride} d{dil}', gw, w.grad, tol=3e-4)
 
+def t_conv_wide_up2():
+    """transposed stride-2 form of conv_wide_kernel (data gradient of the stride-2 conv3, >= 64 channels), symmetric and causal padding:
+    gout = (W^T (x) gy) * GELU'(IN(aux)), gy = IN-backward(g * GELU'(n3); y3) -- against the autograd of F.conv1d in fp64."""
+    B = 3
+    for (c, Lg, pad) in [(64, 500, 1), (128, 161, 1), (64, 333, 2), (128, 96, 2), (64, 32, 1)]:
+        L = 2 * Lg
+        g = torch.randn(B, c, Lg) * 0.1; y3 = torch.randn(B, c, Lg) * 2 + 0.2
+        w = torch.randn(c, c, 3) / math.sqrt(3 * c)              # forward weight of the stride-2 conv [cout][cin][3]
+        aux = torch.randn(B, c, L) * 1.3 - 0.1                    # y2: the conv's pre-norm input
+        mean, rstd = y3.mean(2, keepdim=True), 1 / torch.sqrt(y3.var(2, unbiased=False, keepdim=True) + 1e-2)
+        n = ((y3 - mean) * rstd).double().requires_grad_(True); F.gelu(n).sum().backward()
+        gn = (g.double() * n.grad).float(); n = n.detach().float()
+        s1, s2 = gn.mean(2, keepdim=True), (gn * n).mean(2, keepdim=True)
+        gy = rstd * (gn - s1 - n * s2)
+        # forward: y3[u] = sum_j W_j h[2u + j - pad] (pad 1: symmetric; pad 2: causal, left padding only); d = its data gradient
+        hz = torch.zeros(B, c, L, dtype=torch.float64, requires_grad=True)
+        F.conv1d(F.pad(hz, (pad, 2 - pad)), w.double(), stride=2).backward(gy.double())
+        d = hz.grad.float()
+        am, ar = aux.mean(2, keepdim=True), 1 / torch.sqrt(aux.var(2, unbiased=False, keepdim=True) + 1e-2)
+        na = ((aux - am) * ar).double().requires_grad_(True); F.gelu(na).sum().backward()
+        want = d * na.grad.float(); na = na.detach().float()
+        wb = w.permute(1, 2, 0).contiguous().to(dev); wh, wl = lib.frag_major_planes(wb.view(c, 3 * c))
+        st = torch.stack([mean.squeeze(2), rstd.squeeze(2)], -1).to(dev); bst = torch.stack([s1.squeeze(2), s2.squeeze(2)], -1).to(dev)
+        ast = torch.stack([am.squeeze(2), ar.squeeze(2)], -1).to(dev)
+        gout = torch.zeros(B, L, c, device=dev)
+        a = lib.conv_args(x=cl(g).to(dev), x2=cl(y3).to(dev), w=wb, w_hi=wh, w_lo=wl, y=gout, B=B, L_in=Lg, L_out=L, cin=c, cout=c, taps=3, stride=2, pad=pad,
+                          mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=cl(aux).to(dev), aux_stats=ast)
+        tile = lib.conv_tile_of(a); nt = (L + tile - 1) // tile
+        part = torch.full((B, nt, 2, c), float('nan'), device=dev); lib.set_part(a, part)
+        lib.conv_forward(a)
+        tag = f'wide up2 {c} Lg{Lg} pad{pad}'
+        report(tag + f' (tile {tile})', gout, cl(want), tol=5e-5)
+        RES.append((tag + ' uses the persistent wide kernel', tile in (64, 128)))
+        out = torch.zeros(B, c, 2, device=dev); lib.stats_finalize(part, B, nt, c, L, 0.0, 1, out)
+        report(tag + ' sum g', out[..., 0], want.mean(2), tol=2e-5); report(tag + ' sum g*n', out[..., 1], (want * na).mean(2), tol=2e-5)
+
+
 def t_wgrad_wide():
     """role-split weight gradient of the >= 64-channel k=3 layers (wgrad_wide.hip) with its on-load transforms vs fp64 torch."""
     B = 3
@@ -664,7 +701,7 @@ def t_inkernel_finalize():
     report('in-kernel finalize gp_stats', so, ref, tol=1e-6)
 
 
-STAGES = dict(wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

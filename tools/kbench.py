@@ -96,6 +96,8 @@ CASES = {
     'f16s2': lambda: conv_case(16, 16, 983040, stride=2),
     'd16': lambda: conv_case(16, 16, 983040, pro=lib.PRO_INBWD, epi=lib.EPI_GP, flip=1),
     'u16': lambda: conv_case(16, 16, 491520, stride=2, pro=lib.PRO_INBWD_GP, epi=lib.EPI_GP, mode=lib.MODE_UP2),
+    'u64': lambda: conv_case(64, 64, 30720, stride=2, pro=lib.PRO_INBWD_GP, epi=lib.EPI_GP, mode=lib.MODE_UP2),
+    'u128': lambda: conv_case(128, 128, 7680, stride=2, pro=lib.PRO_INBWD_GP, epi=lib.EPI_GP, mode=lib.MODE_UP2),
     'w16': lambda: wgrad_case(16, 16, 983040),
     'f32': lambda: conv_case(32, 32, 245760),
     'f32s2': lambda: conv_case(32, 32, 245760, stride=2),

@@ -42,6 +42,7 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
   if ((a.epi == W2S_EPI_AUX_INGELU_ADD && (!a.aux || !a.aux_stats)) || (a.epi == W2S_EPI_GP && !a.aux)) return W2S_EINVAL;
   if (a.mode == W2S_MODE_UP2) {
     if (a.taps != 3 || a.stride != 2 || (a.pad != 1 && a.pad != 2)) return W2S_EINVAL;  // pad 2 = gradient of the causal-padded conv
+    { const int rc = w2s_conv_wide_try(a, s, 0); if (rc != 1) return rc; }   // >= 64 channels: persistent role-split kernel
     return w2s_conv_dispatch_up2(a, s);
   }
   if (a.mode == W2S_MODE_DILATED) {

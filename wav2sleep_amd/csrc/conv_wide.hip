@@ -41,7 +41,10 @@ __device__ __forceinline__ void wsplit_store4(__bf16* hi, __bf16* lo, int off, f
 // runs beside the consumers' MFMAs instead of before them: with one role per wave the phases of a tile add up (measured on the
 // one-role form of this kernel: VALU 38 % + MFMA 19-30 % busy, waves waiting 50 % of their lifetime, compute alone 135 / 91 us
 // for the 64 / 128-channel conv2 against 93 / 38 us for its memory traffic alone).
-template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD>
+// UP2 = 1: the transposed stride-2 form (data gradient of the stride-2 conv3, w2s_conv_forward's W2S_MODE_UP2): output position
+// t' = 2u + phase reads the gradient rows u, u+1; m-tiles alternate phase (mt & 1), their row block is mt >> 1.  Symmetric padding:
+// even outputs W_1^T g[u], odd outputs W_2^T g[u] + W_0^T g[u+1]; causal (pad 2): even W_2^T g[u] + W_0^T g[u+1], odd W_1^T g[u+1].
+template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2 = 0, int CZ = 0>   // CZ: UP2 with causal padding
 __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 16 * MT;                            // output positions per tile (all consumer waves share them)
@@ -50,9 +53,9 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   // (lanes {0-3,12-15,20-27}, ... MI355X_MICROARCH.md LDS) hit 16 distinct 16-B slots: the +16 B rows of the first cut were 2-way
   // conflicted on every stride-1 read (SQ_LDS_BANK_CONFLICT = 48 % of SQ_LDS_IDX_ACTIVE)
   constexpr int RSE = HC + (STRIDE == 1 ? 16 : 8);
-  constexpr int NR = (TM - 1) * STRIDE + 3;              // window rows; row 0 = input position t0*STRIDE - pad
+  constexpr int NR = UP2 ? TM / 2 + 1 : (TM - 1) * STRIDE + 3;   // window rows; row 0 = input position t0*STRIDE - pad (UP2: t0/2)
   constexpr int QN = HC / 32, KS = 3 * QN;               // K steps of 32: ks = tap * QN + q
-  constexpr bool TWO = (PRO == W2S_PRO_INBWD);
+  constexpr bool TWO = (PRO == W2S_PRO_INBWD || PRO == W2S_PRO_INBWD_GP);
   constexpr bool FLIP = (PRO == W2S_PRO_INBWD);          // the data gradient runs the taps backwards over the [cin][taps][cout] packing
   constexpr int BUF = 2 * NR * RSE;                      // bf16 elements of one window buffer (hi plane, lo plane)
   __bf16* lds = reinterpret_cast<__bf16*>(smem4);
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
       constexpr int S = decltype(SET)::value;
       const int tl = first + min(i, nt_wg - 1) * step;
       const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
-      const int row = min(row0 + k * rstep, NR - 1), gr = min(max(t0 * STRIDE - P.pad + row, 0), L_in - 1);
+      const int row = min(row0 + k * rstep, NR - 1), gr = min(max((UP2 ? t0 / 2 : t0 * STRIDE - P.pad) + row, 0), L_in - 1);
       const unsigned off = (unsigned)gr * HC + mych;
       rx[S][k] = ld4o(P.x + (size_t)b * L_in * HC, off);
       if constexpr (TWO) rx2[S][k] = ld4o(P.x2 + (size_t)b * L_in * HC, off);
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
       const bool live = i < nt_wg;   // uniform; padding rounds only keep the load queue regular
       const int tl = first + min(i, nt_wg - 1) * step;
       const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
-      const int rb = t0 * STRIDE - P.pad;
+      const int rb = UP2 ? t0 / 2 : t0 * STRIDE - P.pad;
       __bf16* hiL = lds + (i & 1) * BUF;
       __bf16* loL = hiL + NR * RSE;
       f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, ps1 = {0, 0, 0, 0}, ps2 = {0, 0, 0, 0};
@@ -161,15 +164,15 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     const __bf16* hiL = lds + (i & 1) * BUF;
     const __bf16* loL = hiL + NR * RSE;
     // epilogue operands of THIS tile, issued now so that their latency hides behind the K loop
-    f32x4 ax[EPI == W2S_EPI_GP ? MT : 1], ae[EPI == W2S_EPI_GP ? MT : 1];
+    f32x4 ax[EPI == W2S_EPI_GP ? MT : 1], ae[(EPI == W2S_EPI_GP && !UP2) ? MT : 1];
     if (EPI == W2S_EPI_GP) {
       const float* ab = P.aux + (size_t)b * L_out * OC;
       const float* eb = P.add_even ? P.add_even + (size_t)b * (L_out >> 1) * OC : nullptr;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int pos = t0 + mt * 16 + r;
+        const int pos = UP2 ? t0 + 2 * ((mt >> 1) * 16 + r) + (mt & 1) : t0 + mt * 16 + r;
         ax[mt] = (pos < L_out) ? ld4o(ab, (unsigned)pos * OC + ch0) : (f32x4){0, 0, 0, 0};
-        ae[mt] = (eb && !(pos & 1) && (pos >> 1) < (L_out >> 1)) ? ld4o(eb, (unsigned)(pos >> 1) * OC + ch0) : (f32x4){0, 0, 0, 0};
+        if constexpr (!UP2) ae[mt] = (eb && !(pos & 1) && (pos >> 1) < (L_out >> 1)) ? ld4o(eb, (unsigned)(pos >> 1) * OC + ch0) : (f32x4){0, 0, 0, 0};
       }
     }
     f32x4 acc[MT];
@@ -179,10 +182,12 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int j = ks / QN, q = ks % QN;
-      const int rowoff = FLIP ? 2 - j : j;
+      const int rowoff = UP2 ? ((j == 0) ? 1 : (j == 1 && CZ) ? 1 : 0) : (FLIP ? 2 - j : j);
+      const int phase = (j == 1) ? (CZ ? 1 : 0) : (CZ ? 0 : 1);   // UP2: the output parity tap j feeds (compile-time: the other m-tiles vanish)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int row = (mt * 16 + r) * STRIDE + rowoff;
+        if (UP2 && (mt & 1) != phase) continue;
+        const int row = UP2 ? (mt >> 1) * 16 + r + rowoff : (mt * 16 + r) * STRIDE + rowoff;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hiL + row * RSE + q * 32 + 8 * g);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(loL + row * RSE + q * 32 + 8 * g);
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh, acc[mt], 0, 0, 0);
@@ -202,12 +207,13 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int pos = t0 + mt * 16 + r;
+      const int pos = UP2 ? t0 + 2 * ((mt >> 1) * 16 + r) + (mt & 1) : t0 + mt * 16 + r;
       if (pos >= L_out) continue;
       f32x4 v = acc[mt];
       if (EPI == W2S_EPI_GP) {
         const f32x4 n = (ax[mt] - am) * ar;
-        v = (v + ae[mt]) * gelu_grad4(n);
+        if constexpr (!UP2) v += ae[mt];
+        v = v * gelu_grad4(n);
         sA += v;
         sB += v * n;
       } else {
@@ -230,27 +236,28 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   }
 }
 
-template <int CI, int NW, int STRIDE, int PRO, int EPI, int MT, int NP = 4>
+template <int CI, int NW, int STRIDE, int PRO, int EPI, int MT, int NP = 4, int UP2 = 0, int CZ = 0>
 static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
-  constexpr int TM = 16 * MT, HC = CI * 16, NR = (TM - 1) * STRIDE + 3, RSE = HC + (STRIDE == 1 ? 16 : 8);
+  constexpr int TM = 16 * MT, HC = CI * 16, NR = UP2 ? TM / 2 + 1 : (TM - 1) * STRIDE + 3, RSE = HC + (STRIDE == 1 ? 16 : 8);
   WideP P{a.x, a.x2, a.pro_stats, a.pro_bstats, static_cast<const __bf16*>(a.w_hi), static_cast<const __bf16*>(a.w_lo), a.aux, a.aux_stats,
           a.add_even, a.y, a.part, a.B, a.L_in, a.L_out, (a.L_out + TM - 1) / TM, a.flip, a.pad, 0};
   { static const char* d = getenv("W2S_WIDE_DBG"); if (d) P.dbg = atoi(d); }
   size_t lds = (size_t)2 * 2 * NR * RSE * 2;   // two window buffers x (hi, lo) planes, bf16
-  if (PRO != W2S_PRO_GELU) lds += (size_t)a.B * HC * 2 * 4 * (PRO == W2S_PRO_INBWD ? 2 : 1);   // the statistics tables
+  constexpr bool TWO = (PRO == W2S_PRO_INBWD || PRO == W2S_PRO_INBWD_GP);
+  if (PRO != W2S_PRO_GELU) lds += (size_t)a.B * HC * 2 * 4 * (TWO ? 2 : 1);   // the statistics tables
   // producer prefetch depth: three tiles in flight where the register budget allows (kernel-wide allocation: 64-channel workgroups
   // of 8 waves run two per CU = 128 VGPRs; 128-channel workgroups of 12 waves run one per CU = 168 VGPRs)
   constexpr int NHr = (NR + (64 * NP) / (HC / 4) - 1) / ((64 * NP) / (HC / 4));
-  constexpr int SETV = NHr * 4 * (PRO == W2S_PRO_INBWD ? 2 : 1);
+  constexpr int SETV = NHr * 4 * (TWO ? 2 : 1);
   // bytes in flight per CU ~ PD x tile bytes x workgroups per CU >= ~64 KB; register sets beyond that only cost occupancy / spills
   constexpr int PD = NW >= 8 ? (SETV <= 36 ? 2 : 1) : (SETV <= 12 ? 3 : SETV <= 24 ? 2 : 1);
-  auto kern = conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD>;
+  auto kern = conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
   const int total = P.B * P.ntiles;
   static const char* e = getenv("W2S_WIDE_WGS");   // tuning only: workgroups per CU
-  const int per_cu = e ? atoi(e) : (NW >= 8 ? 1 : 2);
+  const int per_cu = e ? atoi(e) : ((NW >= 8 || UP2) ? 1 : 2);   // (the transposed form needs 166 registers: one 8-wave workgroup per CU)
   const int nwg = 256 * (per_cu > 0 ? per_cu : 1);
   hipLaunchKernelGGL(kern, dim3(nwg < total ? nwg : total), dim3(64 * (NW + NP)), lds, s, P);
   W2S_CHECK_LAUNCH();
@@ -259,14 +266,16 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
 
 // 1 = this launch is not one of the wide kernel's shapes (the caller falls through to conv_cl_kernel)
 static bool wide_shape(const w2s_conv_args& a) {
-  if (!a.w_hi || !a.w_lo || a.mode != W2S_MODE_CONTIG || a.taps != 3 || a.dil != 1 || a.pad < 0 || a.pad > 2) return false;
+  if (!a.w_hi || !a.w_lo || (a.mode != W2S_MODE_CONTIG && a.mode != W2S_MODE_UP2) || a.taps != 3 || a.dil != 1 || a.pad < 0 || a.pad > 2) return false;
   if (a.y2 || a.rowkeep || a.bias || a.stat_out || a.reserved) return false;
   if ((size_t)a.B * a.cin * 16 > 32 * 1024) return false;   // the per-sample statistics tables live in LDS
   if (a.ldx != a.cin || a.ldy != a.cout || (a.aux && a.ld_aux != a.cout)) return false;
   if (a.cin < 32 || a.cout < 32 || (a.cin < 64 && a.cout < 64)) return false;
   const bool fwd = a.epi == W2S_EPI_STATS && !a.flip && (a.pro == W2S_PRO_GELU || a.pro == W2S_PRO_IN_GELU);
   const bool dgr = a.epi == W2S_EPI_GP && a.flip && a.pro == W2S_PRO_INBWD && a.stride == 1;
-  if (!fwd && !dgr) return false;
+  const bool up2 = a.mode == W2S_MODE_UP2 && a.epi == W2S_EPI_GP && a.pro == W2S_PRO_INBWD_GP && a.stride == 2 && (a.pad == 1 || a.pad == 2) &&
+                   a.L_out == 2 * a.L_in && !a.add_even && a.cin == a.cout;
+  if (a.mode == W2S_MODE_UP2 ? !up2 : (!fwd && !dgr)) return false;
   if (a.pro == W2S_PRO_GELU && a.stride != 1) return false;
   static const char* off = getenv("W2S_NO_WIDE");   // tuning only
   return !off;
@@ -278,7 +287,7 @@ int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry) {
   if (!wide_shape(a)) return 1;
   const int mt = wide_mt();
 #define W2S_WIDE(CI_, NW_, ST_, PRO_, EPI_) \
-  if (a.cin == 16 * CI_ && a.cout == 16 * NW_ && a.stride == ST_ && a.pro == PRO_ && a.epi == EPI_) { \
+  if (a.mode == W2S_MODE_CONTIG && a.cin == 16 * CI_ && a.cout == 16 * NW_ && a.stride == ST_ && a.pro == PRO_ && a.epi == EPI_) { \
     if (dry) return 16 * mt; \
     return launch_wide<CI_, NW_, ST_, PRO_, EPI_, 4>(a, s); \
   }
@@ -289,5 +298,14 @@ int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry) {
   W2S_WIDE(4, 4, 1, W2S_PRO_INBWD, W2S_EPI_GP) W2S_WIDE(8, 8, 1, W2S_PRO_INBWD, W2S_EPI_GP)
   W2S_WIDE(4, 2, 1, W2S_PRO_INBWD, W2S_EPI_GP) W2S_WIDE(8, 4, 1, W2S_PRO_INBWD, W2S_EPI_GP)
 #undef W2S_WIDE
+  if (a.mode == W2S_MODE_UP2) {   // 64-position tiles = 32 gradient rows + 1 (128-position tiles spill)
+#ifndef W2S_UP2_MT
+#define W2S_UP2_MT 8
+#endif
+    if (a.cin == 64 && a.pad == 1) return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s);
+    if (a.cin == 64 && a.pad == 2) return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s);
+    if (a.cin == 128 && a.pad == 1) return dry ? 16 * W2S_UP2_MT : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s);
+    if (a.cin == 128 && a.pad == 2) return dry ? 16 * W2S_UP2_MT : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s);
+  }
   return 1;
 }

@@ -36,6 +36,7 @@ __host__ __device__ constexpr int ff_rs(int c) { return c == 16 ? 16 : c + 8; } 
 // TM - 2 (TM - 1) positions make the window exactly TM*stride (- 1) rows: no ragged pass; the matrix cores compute the 2 (1) spare
 // rows from whatever follows the window in LDS and the epilogue drops them.
 __host__ __device__ constexpr int ff_ts(int tm, int stride) { return stride == 1 ? tm - 2 : tm - 1; }
+__host__ __device__ constexpr bool ff_db(int hc, int stride) { return hc == 16 && stride == 1; }
 
 // CI / CO: input / output channel tiles (16 each); MT: 16-position m-tiles per wave (TM = 64*MT outputs per tile);
 // PRO: W2S_PRO_GELU, W2S_PRO_IN_GELU or W2S_PRO_FIRST (x = raw signal, w1 = block 0's conv1 weight)
@@ -50,9 +51,12 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
   constexpr int KSP = (HC == 16) ? 2 : 3;                // K = 32 steps: [tap0|tap1] [tap2|0]  or one tap each
   constexpr int KD = KSP * 32, WROW = KD + 8;
   float* red = reinterpret_cast<float*>(smem4);          // [4][CO][4][8] statistics scratch
-  __bf16* hH = reinterpret_cast<__bf16*>(red + 4 * CO * 4 * 8);
-  __bf16* hLo = hH + NRh * RSh;
-  __bf16* wH = hLo + NRh * RSh;                          // [OC][WROW]
+  // 16 input channels, stride 1: TWO window buffers (the LDS budget keeps four workgroups per CU), so a wave that is done with a tile's
+  // MFMAs / stores starts transforming the next window at once instead of waiting at a barrier for the slowest wave
+  constexpr bool DB = ff_db(HC, STRIDE);
+  constexpr int WIN = 2 * NRh * RSh;                     // one window: hi plane, lo plane
+  __bf16* hbase = reinterpret_cast<__bf16*>(red + 4 * CO * 4 * 8);
+  __bf16* wH = hbase + (DB ? 2 : 1) * WIN;               // [OC][WROW]
   __bf16* wLo = wH + OC * WROW;
   float* xsL = reinterpret_cast<float*>(wLo + OC * WROW);  // FIRST: NRh + 2 signal samples
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -103,6 +107,8 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
   };
   auto commit = [&](auto SET, int tl) {
     constexpr int S = decltype(SET)::value;
+    __bf16* hH = hbase + (DB ? S : 0) * WIN;
+    __bf16* hLo = hH + NRh * RSh;
     const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TS;
     const int rb = t0 * STRIDE - P.pad;
     f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
@@ -145,7 +151,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
     const bool live = tl < total;   // workgroup-uniform; a dead round only keeps the load queue regular
     const int b = min(tl, total - 1) / P.ntiles, tile = min(tl, total - 1) % P.ntiles;
     const int t0 = tile * TS;
-    __syncthreads();  // previous tile's LDS reads (and its statistics scratch) are done; weights are written
+    if (!DB) __syncthreads();  // single buffer: the previous tile's LDS reads are done (two buffers: the barriers of the round in between did that)
+    const __bf16* hH = hbase + (DB ? decltype(SET)::value : 0) * WIN;
+    const __bf16* hLo = hH + NRh * RSh;
     if (live) commit(SET, tl);
     prefetch(SET, tl + 2 * (int)gridDim.x);
     __syncthreads();
@@ -236,7 +244,7 @@ static int launch_fwd(const FwdP& P0, int nwg, hipStream_t s) {
   constexpr int TM = 64 * MT, TS = ff_ts(TM, STRIDE), HC = CI * 16, OC = CO * 16, NRh = (TS - 1) * STRIDE + 3, KD = (HC == 16 ? 2 : 3) * 32;
   FwdP P = P0;
   P.ntiles = (P.L_out + TS - 1) / TS;
-  size_t lds = (size_t)4 * CO * 4 * 8 * 4 + (size_t)2 * 2 * (NRh * ff_rs(HC) + OC * (KD + 8));
+  size_t lds = (size_t)4 * CO * 4 * 8 * 4 + (size_t)2 * 2 * ((ff_db(HC, STRIDE) ? 2 : 1) * NRh * ff_rs(HC) + OC * (KD + 8));
   if (PRO == W2S_PRO_FIRST) lds += (size_t)(NRh + 2) * 4;
   auto kern = conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO>;
   if (lds > 64 * 1024 &&
