@@ -100,7 +100,7 @@ class Engine:
         self._streams = {}
         self._rjobs = []
         self.fused_forward = os.environ.get('W2S_FUSED_FORWARD', '1') != '0'
-        self.fold_gp = os.environ.get('W2S_FOLD_GP', '0') == '1'
+        self.fold_gp = os.environ.get('W2S_FOLD_GP', '1') == '1'   # conv3-backward statistics of the previous block ride in the residual-fold conv1 kernel
         self.fused_finalize = os.environ.get('W2S_FUSED_FINALIZE', '0') != '0'
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
