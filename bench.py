@@ -307,6 +307,22 @@ def main():
                                 'traffic_over_algorithmic': round(f['traffic'] / f['bytes'], 3) if f['covered'] and pmc else None}
                             for n, f in sorted(fams.items(), key=lambda kv: -kv[1]['ms'])}
         roof['gemm_kernel_ms_per_step'] = round(total_ms, 3)
+        # what the memory system gives a plain 1-read : 1-write stream on THIS box (torch's device copy of 1 GiB, HIP events): the
+        # practical ceiling for these kernels -- the 8 TB/s `peak` is the spec number
+        src = torch.empty(1 << 28, device=dev, dtype=torch.float32).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+        roof['device_copy_GBps'] = round(copy_gbps, 1)
+        roof['frac_of_device_copy'] = round(roof['achieved'] / copy_gbps, 4) if roof['bound'] == 'hbm' else None
+        roof['step_frac_of_device_copy'] = round(step_bytes / (dt / args.steps) / 1e9 / copy_gbps, 4)
         roof['step_traffic_bytes'] = step_traffic(os.path.join(ROOT, 'profiles')) if pmc else None
         line['roofline'] = roof
         top = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])
