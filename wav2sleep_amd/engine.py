@@ -21,6 +21,7 @@ import torch
 from . import lib
 from .settings import COLS_TO_SAMPLES_PER_EPOCH
 
+_LONGEST_FIRST = os.environ.get('W2S_LONGEST_FIRST', '1') != '0'
 _BWD_WGS = int(os.environ.get('W2S_BWD_WGS', 512))       # persistent workgroups of the fused backward (2 per CU)
 _BWD_WGS32 = int(os.environ.get('W2S_BWD_WGS32', _BWD_WGS))
 _BWD_WGS_RD16 = int(os.environ.get('W2S_BWD_WGS_RD16', 768))  # the 16-channel residual-fold kernel fits three per CU
@@ -445,12 +446,14 @@ class Engine:
         if cls:
             for r in range(R1):   # column r of the [1, 1, F, R+1] parameter
                 lib.add_rows(tokens.view(-1)[r * F:], D * F, P['epoch_mixer.register_tokens'].view(-1)[r:], R1, None, 1, N, F, False)
-        keeps, enc_ctx = [], []
         # The encoders are independent until the set-fusion transformer: each runs on its own HIP stream, so the
         # matrix-core-bound 64/128-channel layers of one modality overlap the bandwidth-bound 16/32-channel layers of
         # another and grid tails are filled (signals sharing an encoder share a stream: their weight gradients accumulate).
         main = torch.cuda.current_stream(dev)
-        for m, s in enumerate(sigs):
+        keeps, enc_ctx = [None] * len(sigs), [None] * len(sigs)
+        # launch order: longest encoder first (the streams run side by side; the 1024-samples-per-epoch encoders take 4x the time of the
+        # 256 ones and set the end of this phase) -- token slot m stays the sorted position
+        for m, s in sorted(enumerate(sigs), key=lambda ms: -COLS_TO_SAMPLES_PER_EPOCH[ms[1]] if _LONGEST_FIRST else 0):
             xs = x[s]
             if xs.dtype != torch.float32 or not xs.is_contiguous():
                 xs = xs.float().contiguous()
@@ -458,9 +461,9 @@ class Engine:
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 keep = (~torch.isinf(xs[:, 0])).float()  # wav2sleep.py:150 (plumbing on B scalars)
-                keeps.append(keep)
+                keeps[m] = keep
                 slot = tokens.view(-1)[(R1 + m) * F:]
-                enc_ctx.append(self._encoder_forward(s, xs, keep, slot, D * F, save))
+                enc_ctx[m] = self._encoder_forward(s, xs, keep, slot, D * F, save)
                 if sp.embed_signals:   # + embedding row of this signal on the samples that have it (wav2sleep.py:155-159)
                     lib.add_rows(slot, D * F, P['signal_encoders.embedder.weight'][sorted(sp.signal_map).index(s)], 1, keep, S, N, F, True)
         for s in sigs:
@@ -711,7 +714,7 @@ class Engine:
 
         # ---- encoders
         main = torch.cuda.current_stream(dev)
-        for m, ec in enumerate(c['enc']):
+        for m, ec in sorted(enumerate(c['enc']), key=lambda me: -COLS_TO_SAMPLES_PER_EPOCH[me[1]['sig']] if _LONGEST_FIRST else 0):
             st = self._side_stream(ec['enc'], dev)
             st.wait_stream(main)
             with torch.cuda.stream(st):
