@@ -22,6 +22,8 @@ from . import lib
 from .settings import COLS_TO_SAMPLES_PER_EPOCH
 
 _LONGEST_FIRST = os.environ.get('W2S_LONGEST_FIRST', '1') != '0'
+_INTERLEAVE = os.environ.get('W2S_INTERLEAVE', '1') != '0'
+_DEFER_TRUNK = os.environ.get('W2S_DEFER_TRUNK', '1') != '0'
 _BWD_WGS = int(os.environ.get('W2S_BWD_WGS', 512))       # persistent workgroups of the fused backward (2 per CU)
 _BWD_WGS32 = int(os.environ.get('W2S_BWD_WGS32', _BWD_WGS))
 _BWD_WGS_RD16 = int(os.environ.get('W2S_BWD_WGS_RD16', 768))  # the 16-channel residual-fold kernel fits three per CU
@@ -100,6 +102,7 @@ class Engine:
         self._bfbuf = {}
         self._streams = {}
         self._rjobs = []
+        self._deferred = None
         self.fused_forward = os.environ.get('W2S_FUSED_FORWARD', '1') != '0'
         self.fold_gp = os.environ.get('W2S_FOLD_GP', '1') == '1'   # conv3-backward statistics of the previous block ride in the residual-fold conv1 kernel
         self.fused_finalize = os.environ.get('W2S_FUSED_FINALIZE', '0') != '0'
@@ -276,6 +279,10 @@ class Engine:
 
     def _wgrad(self, name, *, g, x, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, layout=0, **kw):
         """weight gradient -> slabs -> deterministic reduce into G[name] (accumulating if already written)."""
+        if self._deferred is not None:   # trunk backward: leaf work, enqueued after the encoder streams have been forked (backward())
+            self._deferred.append(lambda: self._wgrad(name, g=g, x=x, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride,
+                                                      pad=pad, dil=dil, layout=layout, **kw))
+            return
         gy = lib.wgrad_grid_y(cin, cout, taps, dil)
         work = _cdiv(B * L_out, 256)
         args = dict(g=g, x=x, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad, dil=dil,
@@ -323,8 +330,47 @@ class Engine:
         cjobs, self._cjobs = self._cjobs, []
         lib.colsum_batch(cjobs)
 
+    def _interleave(self, tasks, trunk=None):
+        """tasks: encoder -> (stream, [generators]).  Enqueue the encoders round-robin, one block per turn, each on its own stream: the
+        streams then start together and progress together, instead of the first encoder's whole pass being enqueued (and mostly executed)
+        before the second one's first kernel.  Signals that share an encoder share its stream and run one after the other.  The
+        queues of pending slab / column reductions are per encoder (they are flushed on that encoder's stream)."""
+        if not _INTERLEAVE:
+            for g in ([trunk[1]] if trunk else []):
+                for _ in g:
+                    pass
+            for st, gens in tasks.values():
+                with torch.cuda.stream(st):
+                    for g in gens:
+                        for _ in g:
+                            pass
+            return
+        live = {e: [st, list(gens), [], []] for e, (st, gens) in tasks.items()}
+        if trunk is not None:   # (stream, generator): the trunk's deferred leaf work; it inherits the reductions queued so far
+            live['_trunk'] = [trunk[0], [trunk[1]], self._rjobs, self._cjobs]
+            self._rjobs, self._cjobs = [], []
+        saved = (self._rjobs, self._cjobs)
+        while live:
+            for e in list(live):
+                st, gens, rj, cj = live[e]
+                self._rjobs, self._cjobs = rj, cj
+                with torch.cuda.stream(st):
+                    try:
+                        next(gens[0])
+                    except StopIteration:
+                        gens.pop(0)
+                live[e][2], live[e][3] = self._rjobs, self._cjobs   # (_flush_reduce replaces the lists)
+                if not gens:
+                    if self._rjobs or self._cjobs:
+                        raise RuntimeError('encoder pass ended with reductions still queued')
+                    del live[e]
+        self._rjobs, self._cjobs = saved
+
     def _colgrad(self, name, g, rows, C, ldg=None):
         """G[name][c] = sum_rows g[row, c]  (bias / CLS gradients)."""
+        if self._deferred is not None:
+            self._deferred.append(lambda: self._colgrad(name, g, rows, C, ldg))
+            return
         nparts = max(1, min(1024, _cdiv(rows, 64)))
         part = torch.empty(nparts, C, device=g.device, dtype=torch.float32)
         lib.bias_grad(g, rows, C, C if ldg is None else ldg, part, nparts)
@@ -336,6 +382,8 @@ class Engine:
 
     # ------------------------------------------------------------------ encoder forward
     def _encoder_forward(self, sig, x, keep, tok_slice, ldtok, save):
+        """Generator: yields after every block so that the caller can enqueue several encoders round-robin (`_interleave`); the
+        context dict (or None) is its return value."""
         sp, P, PF = self.spec, self.P, self.PF
         enc = sp.signal_map[sig]
         ch = sp.channels(enc)
@@ -381,6 +429,7 @@ class Engine:
         if save:
             blocks.append(dict(y1=y1, st1=st1, y2=y2, st2=st2, y3=y3, st3=st3, pin=None, L=L, cin=1, c=c))
         pin, cin, L = pre, c, L // 2
+        yield
         # ---- blocks 1..
         for i in range(1, len(ch)):
             c = ch[i]
@@ -398,6 +447,7 @@ class Engine:
             if self.taps is not None:
                 self.taps[f'{sig}.pre.{i}'] = pre
             pin, cin, L = pre, c, L // 2
+            yield
         # ---- time-distributed dense + GELU (wav2sleep.py:261-265): taps=4/stride=4 over the [B,4S,C] map
         F = sp.feature_dim
         zpre = torch.empty(Bfull, S, F, device=dev, dtype=torch.float32)
@@ -453,19 +503,23 @@ class Engine:
         keeps, enc_ctx = [None] * len(sigs), [None] * len(sigs)
         # launch order: longest encoder first (the streams run side by side; the 1024-samples-per-epoch encoders take 4x the time of the
         # 256 ones and set the end of this phase) -- token slot m stays the sorted position
+        tasks = {}   # encoder -> (stream, [generators]): signals sharing an encoder run one after the other on its stream
         for m, s in sorted(enumerate(sigs), key=lambda ms: -COLS_TO_SAMPLES_PER_EPOCH[ms[1]] if _LONGEST_FIRST else 0):
             xs = x[s]
             if xs.dtype != torch.float32 or not xs.is_contiguous():
                 xs = xs.float().contiguous()
             st = self._side_stream(sp.signal_map[s], dev)
             st.wait_stream(main)
-            with torch.cuda.stream(st):
+
+            def run(m=m, s=s, xs=xs):
                 keep = (~torch.isinf(xs[:, 0])).float()  # wav2sleep.py:150 (plumbing on B scalars)
                 keeps[m] = keep
                 slot = tokens.view(-1)[(R1 + m) * F:]
-                enc_ctx[m] = self._encoder_forward(s, xs, keep, slot, D * F, save)
+                enc_ctx[m] = yield from self._encoder_forward(s, xs, keep, slot, D * F, save)
                 if sp.embed_signals:   # + embedding row of this signal on the samples that have it (wav2sleep.py:155-159)
                     lib.add_rows(slot, D * F, P['signal_encoders.embedder.weight'][sorted(sp.signal_map).index(s)], 1, keep, S, N, F, True)
+            tasks.setdefault(sp.signal_map[s], (st, []))[1].append(run())
+        self._interleave(tasks)
         for s in sigs:
             main.wait_stream(self._side_stream(sp.signal_map[s], dev))
         keep_BD = torch.stack([torch.ones_like(keeps[0])] * R1 + keeps, dim=1)  # [B, D]
@@ -585,6 +639,9 @@ class Engine:
         self._written = set(self.G.keys()) if accumulate else set()
         self._rjobs = []
         self._cjobs = []
+        # weight / bias gradients of the trunk are leaves of the backward graph: they are queued here and enqueued on this stream AFTER the
+        # encoder streams have been forked, so that these small-grid kernels run beside the encoder backward instead of before it
+        self._deferred = [] if (_DEFER_TRUNK and self.multi_stream) else None
         B, S, D, N, F = c['B'], c['S'], c['D'], c['N'], sp.feature_dim
         dev = glogits.device
         nc = sp.num_classes
@@ -692,12 +749,7 @@ class Engine:
                 part = torch.empty(nparts, F, device=dev, dtype=torch.float32)
                 lib.bias_grad(gk, N, F, F, part, nparts)
                 self._colsum(part, nparts, F, self.G[ew][order.index(ec['sig'])], accumulate=True)
-        self._flush_reduce()
-        if R1 > 1:
-            g = self.G[rt].view(F, R1)
-            g.add_(tmp.t()) if rt in self._written else g.copy_(tmp.t())
-            self._written.add(rt)
-
+        deferred, self._deferred = self._deferred, None
         encs = [ec['enc'] for ec in c['enc']]
         if not accumulate:
             # encoders whose signals are not in this batch get no backward: their gradient is zero.  Written here, BEFORE any range is
@@ -706,22 +758,38 @@ class Engine:
                 if name.startswith('signal_encoders.encoders.') and name.split('.')[2] not in encs:
                     g.zero_()
                     self._written.add(name)
-        if hook is not None:
-            hook('_tail')  # mixer + sequence CNN + classifier gradients are final: their all-reduce can start
-            for e in dict.fromkeys(sp.signal_map.values()):
-                if e not in encs:
-                    hook(e)   # absent encoder: its (zero) range still takes part in the collective, the bucket layout is static
+
+        def trunk_leaves():
+            for k, fn in enumerate(deferred or ()):
+                fn()
+                if k % 3 == 2:
+                    yield
+            self._flush_reduce()
+            if R1 > 1:
+                g = self.G[rt].view(F, R1)
+                g.add_(tmp.t()) if rt in self._written else g.copy_(tmp.t())
+                self._written.add(rt)
+            if hook is not None:
+                hook('_tail')  # mixer + sequence CNN + classifier gradients are final: their all-reduce can start
+                for e in dict.fromkeys(sp.signal_map.values()):
+                    if e not in encs:
+                        hook(e)   # absent encoder: its (zero) range still takes part in the collective, the bucket layout is static
+            yield
 
         # ---- encoders
         main = torch.cuda.current_stream(dev)
+        tasks = {}
         for m, ec in sorted(enumerate(c['enc']), key=lambda me: -COLS_TO_SAMPLES_PER_EPOCH[me[1]['sig']] if _LONGEST_FIRST else 0):
             st = self._side_stream(ec['enc'], dev)
             st.wait_stream(main)
-            with torch.cuda.stream(st):
-                self._encoder_backward(ec, gX.view(-1)[(R1 + m) * F:], D * F)
+
+            def run(m=m, ec=ec):
+                yield from self._encoder_backward(ec, gX.view(-1)[(R1 + m) * F:], D * F)
                 self._flush_reduce()
                 if hook is not None and ec['enc'] not in encs[m + 1:]:
                     hook(ec['enc'])
+            tasks.setdefault(ec['enc'], (st, []))[1].append(run())
+        self._interleave(tasks, trunk=(main, trunk_leaves()))
         for e in dict.fromkeys(encs):
             main.wait_stream(self._side_stream(e, dev))
 
@@ -745,6 +813,7 @@ class Engine:
         return self._finalize(part, B, nt, C, count, 1)
 
     def _encoder_backward(self, ec, gtok, ldtok):
+        """Generator (see _encoder_forward): yields after every block."""
         sp, P, PB = self.spec, self.P, self.PB
         enc, B, S, F = ec['enc'], ec['B'], ec['S'], sp.feature_dim
         dev = gtok.device
@@ -845,3 +914,4 @@ class Engine:
                 self._colsum(slab, nslab, 48, self.G[n1], accumulate=n1 in self._written, ld=64)
                 self._colsum(slab.view(-1)[48:], nslab, 16, self.G[nd], accumulate=nd in self._written, ld=64)
                 self._written.update((n1, nd))
+            yield
