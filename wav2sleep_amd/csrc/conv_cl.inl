@@ -14,6 +14,7 @@
 // Reference ops replaced: see include/w2s.h (w2s_conv_args).
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 #include "w2s_common.h"
 
 __host__ __device__ constexpr int conv_bf_pad(int cin, int stride, int mode) { return (cin == 16 || (stride == 2 && mode == W2S_MODE_CONTIG)) ? 8 : 16; }
@@ -176,28 +177,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
 #else
   constexpr bool WPF = BF && (PRO == W2S_PRO_NONE) && MODE != W2S_MODE_UP2;
 #endif
-  bf16x8 pah[NTW], pal[NTW];
-  auto load_frag = [&](int kidx) {
+  // two prefetch slots: the fragments of K steps n + 1 and n + 2 are in flight while step n runs (the taps are visited in order, so
+  // the K-step index is simply linear: n = tap * (cin/32) + q).  One step ahead left the k=7 SequenceCNN conv at 30 us = 28 steps x
+  // one exposed L2 round trip; cin = 32 (one K step per tap) keeps the single slot.
+  bf16x8 pah[2][NTW], pal[2][NTW];
+  const int NSTEP = TAPS * (cin >> 5);
+  auto load_frag = [&](auto SLOT, int kidx_) {
+    constexpr int SL = decltype(SLOT)::value;
+    const int kidx = min(kidx_, NSTEP - 1);   // no branch around the loads (a conditional load makes hipcc wait vmcnt(0) everywhere)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       const size_t wo = ((size_t)((n0 + wn0) / 16 + nt) * (K >> 5) + (size_t)kidx) * 512 + lane * 8;
-      pah[nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_hi) + wo);
-      pal[nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_lo) + wo);
+      pah[SL][nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_hi) + wo);
+      pal[SL][nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_lo) + wo);
     }
   };
-  if constexpr (WPF) { if (cin >= 32) load_frag(0); }
+  using WS0 = std::integral_constant<int, 0>; using WS1 = std::integral_constant<int, 1>;
+  if constexpr (WPF) {
+    if (cin >= 32) { load_frag(WS0{}, 0); load_frag(WS1{}, 1); }
+  }
 
   auto mma_tap = [&](int jw, int rowoff, int mtmask, int jw_next = -1) {
-    // jw: weight tap index; rowoff: LDS row offset added to the per-position row; mtmask: which m-tiles take part;
-    // jw_next (WPF): the tap whose first K step follows this tap's last one (-1: none)
+    // jw: weight tap index; rowoff: LDS row offset added to the per-position row; mtmask: which m-tiles take part
     if constexpr (WPF) {
       const int QN = cin >> 5;
-      for (int q = 0; q < QN; ++q) {
+      auto step = [&](auto SLOT, int q, int ahead) {
+        constexpr int SL = decltype(SLOT)::value;
         bf16x8 bh[MT], bl[MT], ah[NTW], al[NTW];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) { ah[nt] = pah[nt]; al[nt] = pal[nt]; }
-        // no branch around the loads (a conditional load makes hipcc wait vmcnt(0) everywhere): with nothing left the current step is re-read
-        load_frag((q + 1 < QN) ? jw * QN + q + 1 : (jw_next >= 0 ? jw_next * QN : jw * QN + q));
+        for (int nt = 0; nt < NTW; ++nt) { ah[nt] = pah[SL][nt]; al[nt] = pal[SL][nt]; }
+        load_frag(SLOT, jw * QN + q + ahead);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int row = (MODE == W2S_MODE_DILATED) ? wm0 + mt * 16 + r : (wm0 + mt * 16 + r) * STRIDE + rowoff;
@@ -213,6 +222,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl[mt], acc[mt][nt], 0, 0, 0);
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh[mt], acc[mt][nt], 0, 0, 0);
             }
+      };
+      if (QN & 1) {   // one K step per tap (cin = 32): slot 0 only, one step ahead
+        for (int q = 0; q < QN; ++q) step(WS0{}, q, 1);
+      } else {
+        for (int q = 0; q < QN; q += 2) { step(WS0{}, q, 2); step(WS1{}, q + 1, 2); }
       }
       return;
     }
