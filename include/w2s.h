@@ -88,6 +88,8 @@ typedef struct w2s_conv_args {
 /* positions per workgroup tile for (cin,cout); ntiles = ceil(L_out / tile) sizes `part`. */
 int w2s_conv_tile(const w2s_conv_args* a);
 int w2s_conv_forward(const w2s_conv_args* a, void* stream);
+/* out4 = (NT, MT, WN, effective MODE) of the generic kernel instance that launch would use (profiling / bookkeeping only) */
+int w2s_conv_cfg(const w2s_conv_args* a, int32_t* out4);
 
 /*
  * Weight gradient: dW[o][j][c] = sum_{b,t} GY(g)[b,t,o] * H(x)[b, t*stride + j*dil - pad, c]

@@ -14,6 +14,18 @@ int w2s_conv_dispatch_33d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_up2(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_tile_impl(int cin, int cout, int taps, int stride, int mode, int B, int L_out);
 int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry);   // conv_wide.hip: 1 = not a wide-kernel shape
+void w2s_conv_cfg_impl(int cin, int cout, int taps, int stride, int mode, int B, int L_out, int dil, int* out3);
+
+// (NT, MT, WN) template arguments and the effective MODE of the conv_cl_kernel instance w2s_conv_forward(a) launches (profiling keys)
+extern "C" int w2s_conv_cfg(const w2s_conv_args* a, int* out4) {
+  if (!a || !out4) return W2S_EINVAL;
+  int mode = a->mode, dil = a->dil > 0 ? a->dil : 1;
+  if (mode == W2S_MODE_DILATED && a->taps == 7 && a->stride == 1 && (size_t)(64 + 6 * dil) * (a->cin + 16) * 4 <= 150 * 1024 && !getenv("W2S_SEQ_PER_TAP"))
+    mode = W2S_MODE_CONTIG;   // single staging of the whole dilated window (w2s_conv_forward)
+  w2s_conv_cfg_impl(a->cin, a->cout, a->taps, a->stride, mode, a->B, a->L_out, mode == W2S_MODE_CONTIG ? dil : 1, out4);
+  out4[3] = mode;
+  return W2S_OK;
+}
 
 // positions per workgroup tile of the kernel that w2s_conv_forward(a) will launch (`a` filled as for the launch; y / part may be NULL)
 extern "C" int w2s_conv_tile(const w2s_conv_args* a) {

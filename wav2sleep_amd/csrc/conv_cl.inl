@@ -470,6 +470,10 @@ static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode
     return (long)B * ((L_out + tm - 1) / tm) * (cout / (t.nt * 16));
   };
   if (B > 0 && L_out > 0) {
+    // ... unless the window is so large that one workgroup owns a CU's LDS (SequenceCNN at dilation 16 / 32: 92 / 147 KB) and the
+    // 128-wide grid fits the chip in ONE round: halving the tile width would make it two rounds of the same length (30 vs 18 us)
+    const size_t win = (size_t)window_rows(16 * c.mt * (4 / c.wn), taps, stride, mode, dil) * (cin + 16) * 4;
+    if (win > 80 * 1024 && wgs(c) <= 256) return c;
     if (wgs(c) < 512 && c.mt == 4 && c.wn != 4) c.mt = 2;
     if (wgs(c) < 512 && c.nt == 8) { c.nt = 4; if (c.wn == 4) { c.wn = 2; c.mt = 2; } }
   }

@@ -50,7 +50,7 @@ class WgradArgs(C.Structure):
                                     'pro_g', 'pro_h', 'nslab', 'split_precision')]
 
 
-EXPORTS = ['w2s_conv_tile', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
+EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
            'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
@@ -209,21 +209,18 @@ def conv_forward(a: ConvArgs):
         if DETAIL:
             key += f' L{a.L_out}'
         return _timed(key, nbytes, flops, run)
-    nt = 8 if a.cout >= 128 else 4 if a.cout >= 64 else 2 if a.cout >= 32 else 1
-    wn = 2 if nt >= 4 else 1
-    tm = load().w2s_conv_tile(C.byref(a))
-    mt = tm // (16 * (4 // wn))
-    if nt == 8 and mt == 2 and a.B * ((a.L_out + tm - 1) // tm) * (a.cout // 128) < 512:
-        nt = 4  # short-sequence configuration (pick_cfg in conv_cl.inl)
+    cfg = (C.c_int32 * 4)()
+    _chk(load().w2s_conv_cfg(C.byref(a), cfg), 'w2s_conv_cfg')
+    nt, mt, wn, mode = cfg[0], cfg[1], cfg[2], cfg[3]
     # key == the kernel name rocprofv3 reports, so bench.py's average can be checked against profiles/
     spec = (-1, -1)
     if not a.y2 and not a.rowkeep:
         hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4), (6, 1)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)],
                (0, 1, 1): [(0, 3), (0, 0)], (1, 4, 4): [(0, 3)], (1, 3, 3): [(0, 3)], (0, 7, 1): [(0, 0)], (1, 7, 1): [(0, 0)]}
-        if (a.pro, a.epi) in hot.get((a.mode, a.taps, a.stride), []):
+        if (a.pro, a.epi) in hot.get((mode, a.taps, a.stride), []):
             spec = (a.pro, a.epi)
-    bf = 1 if (a.w_hi and a.w_lo and ((a.cin >= 32 and nt >= 2) or (a.cin == 16 and a.mode == MODE_CONTIG and a.taps in (1, 3) and a.dil <= 1))) else 0
-    key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {a.mode}, {wn}, {spec[0]}, {spec[1]}, {bf}>'
+    bf = 1 if (a.w_hi and a.w_lo and ((a.cin >= 32 and nt >= 2) or (a.cin == 16 and mode == MODE_CONTIG and a.taps in (1, 3) and a.dil <= 1))) else 0
+    key = f'conv_cl_kernel<{nt}, {mt}, {a.taps}, {a.stride}, {mode}, {wn}, {spec[0]}, {spec[1]}, {bf}>'
     if DETAIL:
         key += f' {a.cin}->{a.cout} pro{a.pro} epi{a.epi} L{a.L_out}'
     _timed(key, nbytes, flops, run)
