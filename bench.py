@@ -29,7 +29,7 @@ MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak
 
 def pmc_key(name):
     """rocprofv3 kernel name -> the LaunchTimer key (conv_wide: <CI, NW, NP, STRIDE, PRO, EPI, MT, PD> -> <CI, NW, STRIDE, PRO, EPI>)."""
-    m = re.match(r'conv_wide_kernel<(\d+), (\d+), \d+, (\d+), (\d+), (\d+), \d+, \d+>', name)
+    m = re.match(r'conv_wide_kernel<(\d+), (\d+), \d+, (\d+), (\d+), (\d+), .*>', name)   # <CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ>
     if m:
         return f'conv_wide_kernel<{m[1]}, {m[2]}, {m[3]}, {m[4]}, {m[5]}>'
     m = re.match(r'wgrad_wide_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), .*>', name)   # <CO, CI, STRIDE, PG, PH, MT, NWC, IB, CB, PD>
