@@ -349,3 +349,35 @@ def test_model_compile_traces_through_the_custom_operator():
             assert tuple(out.shape) == (2, 6, 4) and ticket.device.type == 'cpu'
     finally:
         torch._dynamo.reset()
+
+
+def test_scheduling_switches_do_not_change_a_bit():
+    """Launch order of the encoder streams, round-robin enqueue and the deferred trunk weight gradients are pure scheduling: the flat
+    gradient of a train step must be bit-identical with all of them off (fixed-order reductions, no float atomics)."""
+    import wav2sleep_amd as W
+    from wav2sleep_amd import engine as E
+    sm = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
+    torch.manual_seed(7)
+    model = W.Wav2Sleep(W.SignalEncoders(sm, 128, 'gelu', norm='instance', causal=False, chunk_causal=False),
+                        W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.0, dim_ff=512, nhead=8),
+                        W.SequenceCNN(128, dropout=0.0, norm='layer', causal=False, num_layers=2, kernel_size=7, num_dilations=6), 4).to('cuda').train()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    spe = {'ABD': 256, 'THX': 256, 'ECG': 1024, 'PPG': 1024}
+    x = {s: torch.randn(3, 24 * spe[s], device='cuda', generator=g) for s in sm}
+    x['THX'][1] = float('-inf')
+    y = torch.randint(0, 4, (3, 24), device='cuda', generator=g).float()
+    grads = []
+    saved = (E._LONGEST_FIRST, E._INTERLEAVE, E._DEFER_TRUNK)
+    try:
+        for flags in ((True, True, True), (False, False, False), (True, False, True), (False, True, False)):
+            E._LONGEST_FIRST, E._INTERLEAVE, E._DEFER_TRUNK = flags
+            model.zero_grad(set_to_none=True)
+            logits = model(x)
+            loss = torch.nn.functional.cross_entropy(logits.reshape(-1, 4), y.reshape(-1).long())
+            loss.backward()
+            grads.append(model._flat_grad.clone())
+    finally:
+        E._LONGEST_FIRST, E._INTERLEAVE, E._DEFER_TRUNK = saved
+    assert float(grads[0].abs().max()) > 0
+    for k in range(1, len(grads)):
+        assert torch.equal(grads[0], grads[k]), f'schedule {k} changed {int((grads[0] != grads[k]).sum())} gradient elements'
