@@ -1,20 +1,19 @@
-// k=3 encoder convolutions of the >= 64-channel layers (forward, and the stride-1 data gradients) as a PERSISTENT split-precision
-// kernel with the weights held in REGISTERS.
+// k=3 encoder convolutions of the >= 64-channel layers (forward, the stride-1 data gradients and the transposed stride-2 data gradient)
+// as a PERSISTENT, ROLE-SPLIT split-precision kernel with the weights held in REGISTERS.
 //
-//   y[b,t,o] = EPI( sum_{j<3} sum_{c<HC} w[o][j][c] * PRO(x[b, t*STRIDE + roff(j) - 1, c]) )          (w2s_conv_forward's contract)
+//   y[b,t,o] = EPI( sum_{j<3} sum_{c<HC} w[o][j][c] * PRO(x[b, t*STRIDE + roff(j) - pad, c]) )          (w2s_conv_forward's contract)
 //
 // Why not conv_cl_kernel here (profiles/r01_*): its one-tile workgroups serialise stage -> K loop -> epilogue with 2-3 workgroups per
 // CU, and every wave re-fetches the layer's weight fragments from L2 on every K step (two dependent L2 round trips per 32 channels);
 // the 64/128-channel layers ran at 0.24-0.38 of the HBM roof with the matrix pipe 10-28 % busy -- on neither roof.  Here:
-//   * wave w of the workgroup owns output channels [16w, 16w+16) for ALL positions of a tile, so its A operand -- the 16 x K weight
-//     slice, K = 3*HC -- is loaded ONCE per launch into registers as bf16 hi/lo fragments (HC = 128: 96 VGPRs) and the K loop
-//     touches no global memory at all: 2 ds_read_b128 (activation hi/lo) feed 3 MFMAs;
-//   * workgroups are persistent (grid-stride over (sample, tile)); the next tile's raw window is prefetched into registers while
-//     the current one runs through the matrix cores, and is transformed (norm + GELU, or the instance-norm backward) on its way
-//     into LDS once the MFMAs are done -- HBM latency, VALU prologue and MFMA overlap across the two waves of each SIMD;
-//   * a wave's 16 channels x 64 positions need no cross-wave statistics reduction: the per-tile sums come out of a 16-lane DPP
-//     row reduction and go straight to the partials.
-// NW = waves per workgroup = cout / 16 (64 channels: 256 threads, 128 channels: 512 threads).
+//   * NW = cout/16 CONSUMER waves: wave w owns output channels [16w, 16w+16) for ALL positions of a tile, so its A operand -- the
+//     16 x K weight slice, K = 3*HC -- is loaded ONCE per launch into registers as bf16 hi/lo fragments (HC = 128: 96 VGPRs) and the
+//     K loop touches no global memory at all: 2 ds_read_b128 (activation hi/lo) feed 3 MFMAs; the epilogue (statistics partials by a
+//     16-lane DPP row reduction, or the GELU' product) stores y directly;
+//   * 4 PRODUCER waves stream the raw window of the next PD tiles into registers (unconditional, clamped loads), apply the on-load
+//     transform (norm + GELU, or the instance-norm backward) with the statistics from an LDS table, split into bf16 (hi, lo) and
+//     write the window of tile i + 1 into the other LDS buffer while the consumers run tile i through the matrix cores;
+//   * workgroups are persistent (grid-stride over (sample, tile)), one barrier per tile.
 #include <type_traits>
 #include "conv_cl.inl"
 
