@@ -24,6 +24,8 @@ from .settings import COLS_TO_SAMPLES_PER_EPOCH
 _LONGEST_FIRST = os.environ.get('W2S_LONGEST_FIRST', '1') != '0'
 _INTERLEAVE = os.environ.get('W2S_INTERLEAVE', '1') != '0'
 _DEFER_TRUNK = os.environ.get('W2S_DEFER_TRUNK', '1') != '0'
+# W2S_ENC_CHUNK='1024:4,256:8' (samples per chunk by samples-per-epoch of the signal; a bare number applies to every signal)
+_ENC_CHUNK = {(int(kv.split(':')[0]) if ':' in kv else 0): int(kv.split(':')[-1]) for kv in os.environ.get('W2S_ENC_CHUNK', '').split(',') if kv}
 _BWD_WGS = int(os.environ.get('W2S_BWD_WGS', 512))       # persistent workgroups of the fused backward (2 per CU)
 _BWD_WGS32 = int(os.environ.get('W2S_BWD_WGS32', _BWD_WGS))
 _BWD_WGS_RD16 = int(os.environ.get('W2S_BWD_WGS_RD16', 768))  # the 16-channel residual-fold kernel fits three per CU
@@ -330,6 +332,11 @@ class Engine:
         cjobs, self._cjobs = self._cjobs, []
         lib.colsum_batch(cjobs)
 
+    def _enc_chunk(self, sig, B):
+        """samples per depth-first chunk of this signal's encoder pass (0: the whole batch at once)"""
+        cb = _ENC_CHUNK.get(COLS_TO_SAMPLES_PER_EPOCH[sig], _ENC_CHUNK.get(0, 0))
+        return cb if (0 < cb < B and not self.chunk and self.taps is None) else 0
+
     def _interleave(self, tasks, trunk=None):
         """tasks: encoder -> (stream, [generators]).  Enqueue the encoders round-robin, one block per turn, each on its own stream: the
         streams then start together and progress together, instead of the first encoder's whole pass being enqueued (and mostly executed)
@@ -515,7 +522,18 @@ class Engine:
                 keep = (~torch.isinf(xs[:, 0])).float()  # wav2sleep.py:150 (plumbing on B scalars)
                 keeps[m] = keep
                 slot = tokens.view(-1)[(R1 + m) * F:]
-                enc_ctx[m] = yield from self._encoder_forward(s, xs, keep, slot, D * F, save)
+                cb = self._enc_chunk(s, B)
+                if cb:
+                    # sample chunks, depth-first through the whole encoder (every sample is independent there: instance norm): a tensor a
+                    # kernel has just written is then small enough (<= ~96 MB, tools/mall_probe.py) to still sit in the 256 MB Infinity
+                    # Cache when the next kernel reads it
+                    subs = []
+                    for b0 in range(0, B, cb):
+                        sub = yield from self._encoder_forward(s, xs[b0:b0 + cb], keep[b0:b0 + cb], slot[b0 * S * D * F:], D * F, save)
+                        subs.append((b0, sub))
+                    enc_ctx[m] = dict(sig=s, enc=sp.signal_map[s], keep=keep, chunks=subs) if save else None
+                else:
+                    enc_ctx[m] = yield from self._encoder_forward(s, xs, keep, slot, D * F, save)
                 if sp.embed_signals:   # + embedding row of this signal on the samples that have it (wav2sleep.py:155-159)
                     lib.add_rows(slot, D * F, P['signal_encoders.embedder.weight'][sorted(sp.signal_map).index(s)], 1, keep, S, N, F, True)
             tasks.setdefault(sp.signal_map[s], (st, []))[1].append(run())
@@ -784,8 +802,9 @@ class Engine:
             st.wait_stream(main)
 
             def run(m=m, ec=ec):
-                yield from self._encoder_backward(ec, gX.view(-1)[(R1 + m) * F:], D * F)
-                self._flush_reduce()
+                for b0, sub in ec.get('chunks', [(0, ec)]):   # (chunks share the weights: one flush per chunk, accumulating)
+                    yield from self._encoder_backward(sub, gX.view(-1)[(R1 + m) * F + b0 * S * D * F:], D * F)
+                    self._flush_reduce()
                 if hook is not None and ec['enc'] not in encs[m + 1:]:
                     hook(ec['enc'])
             tasks.setdefault(ec['enc'], (st, []))[1].append(run())
