@@ -189,11 +189,14 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
     const float* gb = gn1 + (size_t)b * L * 16;
     const float* yb = y1 ? y1 + (size_t)b * L * 16 : nullptr;
     const float* pb = gpre + (size_t)b * (L >> 1) * 16;
-#pragma unroll 4
+    // straight-line body: no break / divergent branch inside (positions past the end and odd positions contribute through a 0/1
+    // factor on clamped addresses).  The branchy form of this loop was NOT bit-reproducible when other kernels shared the CU
+    // (tools/determinism_probe*.py: identical inputs, different dW1 sums in situ, correct in isolation).
     for (int p = tid >> 2; p < 1024; p += 64) {
       const int t = t0 + p;
-      if (t >= L) break;
-      const unsigned off = (unsigned)t * 16 + og * 4;
+      const float live = (t < L) ? 1.f : 0.f;
+      const int tc = min(t, L - 1);
+      const unsigned off = (unsigned)tc * 16 + og * 4;
       const float xm = xs[p], xc = xs[p + 1], xp = xs[p + 2];
       f32x4 yv;
       if (yb) yv = ld4o(yb, off);
@@ -203,17 +206,25 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
         yv.z = wr[2][0] * xm + wr[2][1] * xc + wr[2][2] * xp;
         yv.w = wr[3][0] * xm + wr[3][1] * xc + wr[3][2] * xp;
       }
-      f32x4 n = (yv - mean) * rstd;
-      f32x4 gy = rstd * (ld4o(gb, off) - q1 - n * q2);
-      acc[0] += gy.x * xm; acc[1] += gy.x * xc; acc[2] += gy.x * xp;
-      acc[3] += gy.y * xm; acc[4] += gy.y * xc; acc[5] += gy.y * xp;
-      acc[6] += gy.z * xm; acc[7] += gy.z * xc; acc[8] += gy.z * xp;
-      acc[9] += gy.w * xm; acc[10] += gy.w * xc; acc[11] += gy.w * xp;
-      if (!(t & 1)) {
-        f32x4 gp = ld4o(pb, (unsigned)(t >> 1) * 16 + og * 4);
-        const float x0 = xs[p + 1 + shift];  // x[t]: the 1x1/stride-2 residual conv has no padding in either mode
-        acc[12] += gp.x * x0; acc[13] += gp.y * x0; acc[14] += gp.z * x0; acc[15] += gp.w * x0;
+      // scalar arithmetic on purpose: with float4 expressions hipcc built this block from v_pk_* instructions with op_sel operand
+      // swizzles, and the sums of the odd channels' middle tap (gy.y * xc, gy.w * xc) came out different from launch to launch when
+      // other kernels shared the CU -- a hazard of that instruction mix, not of the data (tools/determinism_probe3.py)
+      const f32x4 gv = ld4o(gb, off);
+      const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+      const float mm[4] = {mean.x, mean.y, mean.z, mean.w}, rr[4] = {rstd.x, rstd.y, rstd.z, rstd.w};
+      const float a1[4] = {q1.x, q1.y, q1.z, q1.w}, a2[4] = {q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float nn = (yy[i] - mm[i]) * rr[i];
+        const float gy = rr[i] * (gg[i] - a1[i] - nn * a2[i]) * live;
+        acc[3 * i] = fmaf(gy, xm, acc[3 * i]);
+        acc[3 * i + 1] = fmaf(gy, xc, acc[3 * i + 1]);
+        acc[3 * i + 2] = fmaf(gy, xp, acc[3 * i + 2]);
       }
+      const float even = (t & 1) ? 0.f : live;
+      const f32x4 gp = ld4o(pb, (unsigned)min(tc >> 1, (L >> 1) - 1) * 16 + og * 4);
+      const float x0 = xs[p + 1 + shift] * even;  // x[t]: the 1x1/stride-2 residual conv has no padding in either mode
+      acc[12] += gp.x * x0; acc[13] += gp.y * x0; acc[14] += gp.z * x0; acc[15] += gp.w * x0;
     }
   }
 #pragma unroll
