@@ -14,7 +14,8 @@ B, S = int(sys.argv[2]) if len(sys.argv) > 2 else 2, int(sys.argv[1]) if len(sys
 x, y = O.make_inputs(cfg, B, S, seed=123, missing={'THX': [1]})
 x = {k: v.to('cuda') for k, v in x.items()}; y = y.to('cuda')
 runs = []
-for r in range(8):
+NR = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+for r in range(NR):
     model.zero_grad(set_to_none=True)
     logits = model(x)
     loss = torch.nn.functional.cross_entropy(logits.reshape(-1, 4), y.reshape(-1).long(), ignore_index=-1)
@@ -23,8 +24,8 @@ for r in range(8):
     runs.append({n: p.grad.detach().clone() for n, p in model.named_parameters()})
 bad = 0
 for n in runs[0]:
-    d = max(float((runs[0][n] - runs[k][n]).abs().max()) for k in range(1, 8))
+    d = max(float((runs[0][n] - runs[k][n]).abs().max()) for k in range(1, NR))
     if d > 0:
         bad += 1
-        print(f'{n:60s} max |diff| over 8 runs {d:.3e}  (|g|max {float(runs[0][n].abs().max()):.3e})')
+        print(f'{n:60s} max |diff| over NR runs {d:.3e}  (|g|max {float(runs[0][n].abs().max()):.3e})')
 print(f'S={S} B={B}: {bad} of {len(runs[0])} gradient tensors are not bit-reproducible')
