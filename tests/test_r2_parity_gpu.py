@@ -468,3 +468,16 @@ def test_full_size_gradients_are_bit_reproducible():
     for k in range(1, 4):
         diff = runs[0] != runs[k]
         assert not bool(diff.any()), f'run {k}: {int(diff.sum())} gradient elements differ'
+
+
+def test_logits_do_not_depend_on_batch_neighbours_full_size():
+    """Instance / layer norms only: a recording's logits are the same BITS whether it is scored alone or inside a batch (full length, one
+    recording without ECG) -- tiles, partial sums and their fixed-order reductions are per sample."""
+    model = default_init_model().to(DEV).eval()
+    cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
+    x, _ = O.make_inputs(cfg, 5, 960, seed=5, missing={'ECG': [2]})
+    x = {k: v.to(DEV) for k, v in x.items()}
+    with torch.no_grad():
+        batch = model(x)
+        singles = torch.cat([model({k: v[i:i + 1] for k, v in x.items()}) for i in range(5)])
+    assert torch.equal(batch, singles), float((batch - singles).abs().max())
