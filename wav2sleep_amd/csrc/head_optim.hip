@@ -50,9 +50,6 @@ extern "C" int w2s_head_fwd(const float* pre, int ld, const float* w, const floa
 __global__ __launch_bounds__(256) void ce_partial_kernel(const float* __restrict__ logits, const float* __restrict__ labels, int rows, int nc,
                                                          float* __restrict__ part, long long* __restrict__ cmat) {
   __shared__ float red[2][256];
-  __shared__ unsigned int hist[W2S_MAXC * W2S_MAXC];   // confusion counts of this block: one global atomic per bin and block instead of
-  if (threadIdx.x < W2S_MAXC * W2S_MAXC) hist[threadIdx.x] = 0u;   // one per row (15 360 atomics on 16 addresses took 59 us)
-  __syncthreads();
   const int row = blockIdx.x * 256 + threadIdx.x;
   float nll = 0.f, cnt = 0.f;
   if (row < rows) {
@@ -68,14 +65,12 @@ __global__ __launch_bounds__(256) void ce_partial_kernel(const float* __restrict
       for (int c = 0; c < nc; ++c) den += expf(logits[(size_t)row * nc + c] - mx);
       nll = logf(den) + mx - logits[(size_t)row * nc + y];
       cnt = 1.f;
-      if (cmat) atomicAdd(&hist[y * nc + am], 1u);
+      if (cmat) atomicAdd(reinterpret_cast<unsigned long long*>(cmat + y * nc + am), 1ull);
     }
   }
   red[0][threadIdx.x] = nll;
   red[1][threadIdx.x] = cnt;
   __syncthreads();
-  if (cmat && threadIdx.x < nc * nc && hist[threadIdx.x])
-    atomicAdd(reinterpret_cast<unsigned long long*>(cmat + threadIdx.x), (unsigned long long)hist[threadIdx.x]);
   for (int s = 128; s > 0; s >>= 1) {
     if (threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
     __syncthreads();
