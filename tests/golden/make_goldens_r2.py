@@ -176,6 +176,64 @@ def run_dataset():
     print('dataset:', len(out), 'arrays;', {k: out[f'ds.{k}.nc4.mlhNone.y'].tolist() for k in files})
 
 
+
+def run_save_predictions():
+    """The reference `api.save_predictions` (api.py:193-221) on the committed parquet recordings + one with a DatetimeIndex: the CSV
+    text it writes.  api.py imports hydra / omegaconf / pyedflib at module level (absent here, none of them touched by this function):
+    empty stand-in modules; `numba.njit` bound to the identity as for the dataset goldens."""
+    import tempfile
+    import pandas as pd
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith('__'):
+                raise AttributeError(name)
+            return type(name, (), {})
+    for n in ('hydra', 'hydra.utils', 'omegaconf', 'pyedflib', 'mne'):
+        sys.modules.setdefault(n, _Any(n))
+    shim = types.ModuleType('numba'); shim.njit = lambda *a, **k: (lambda f: f)
+    sys.modules.setdefault('numba', shim)
+    data = types.ModuleType('wav2sleep.data'); data.__path__ = [REF + '/data']; sys.modules['wav2sleep.data'] = data
+    models = types.ModuleType('wav2sleep.models'); models.__path__ = [REF + '/models']; sys.modules.setdefault('wav2sleep.models', models)
+    from wav2sleep.data.dataset import ParquetDataset
+    import wav2sleep.api as api
+    ddir = os.path.join(HERE, 'dataset')
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, 'in'); os.makedirs(os.path.join(src, 'sub'))
+        import shutil
+        shutil.copy(os.path.join(ddir, 'full.parquet'), os.path.join(src, 'a.parquet'))
+        shutil.copy(os.path.join(ddir, 'no_ppg.parquet'), os.path.join(src, 'sub', 'b.parquet'))
+        # a recording indexed by absolute time (api.py:214-215)
+        df = pd.read_parquet(os.path.join(ddir, 'flat_thx.parquet'))
+        df.index = pd.Timestamp('2021-03-04 22:15:00') + pd.to_timedelta(df.index.values, unit='s')
+        df.index.name = 'Timestamp'
+        df.to_parquet(os.path.join(src, 'sub', 'c_abs.parquet'))
+        df.to_parquet(os.path.join(ddir, 'abs_time.parquet'))
+        files = sorted([os.path.join(src, 'a.parquet'), os.path.join(src, 'sub', 'b.parquet'), os.path.join(src, 'sub', 'c_abs.parquet')])
+        ds = ParquetDataset(files, columns=['ABD', 'THX', 'ECG', 'PPG'], num_classes=4, require_labels=False)
+        g = torch.Generator().manual_seed(17)
+        preds = [torch.randint(0, 4, (n,), generator=g) for n in (6, 5, 4)]
+        labels = [torch.randint(-1, 4, (n,), generator=g).float() for n in (6, 5, 4)]
+        for tag, lab in (('with_labels', labels), ('no_labels', None)):
+            dst = os.path.join(tmp, 'out_' + tag)
+            api.save_predictions(preds, src, dst, ds, labels=lab)
+            for fp in files:
+                rel = os.path.relpath(fp, src)
+                csv = os.path.join(dst, os.path.splitext(rel)[0] + '.preds.csv')
+                out[f'{tag}.{rel}'] = np.array(open(csv).read())
+        out['files'] = np.array([os.path.relpath(f, src) for f in files])
+        # api.load_dataset (api.py:141-159): which files, in which order, which columns
+        lds = api.load_dataset(src, ['ECG', 'THX'], num_classes=5, max_length_hours=None)
+        out['load_dataset.files'] = np.array([os.path.relpath(f, src) for f in lds.files])
+        out['load_dataset.columns'] = np.array(list(lds.columns))
+        x0, y0 = lds[0]
+        out['load_dataset.keys0'] = np.array(list(x0.keys())); out['load_dataset.y0'] = y0.numpy()
+        for i in range(3):
+            out[f'pred{i}'] = preds[i].numpy(); out[f'label{i}'] = labels[i].numpy()
+    np.savez_compressed(os.path.join(HERE, 'save_predictions.npz'), **out)
+    print('save_predictions:', {k: len(str(v)) for k, v in out.items() if k.startswith('with')})
+
 def run_ema():
     class _Any(types.ModuleType):   # any other name the module touches at import time (base classes of callbacks that are not used here)
         def __getattr__(self, name):
@@ -264,6 +322,6 @@ def run_variants():
 
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for name, fn in (('default_init', run_default_init), ('optim', run_optim), ('train10', run_train10), ('dataset', run_dataset), ('ema', run_ema), ('variants', run_variants)):
+    for name, fn in (('default_init', run_default_init), ('optim', run_optim), ('train10', run_train10), ('dataset', run_dataset), ('ema', run_ema), ('variants', run_variants), ('save_predictions', run_save_predictions)):
         if not only or name in only:
             fn()

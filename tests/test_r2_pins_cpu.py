@@ -122,3 +122,34 @@ def test_unknown_norm_and_activation_raise_like_the_reference():
         W.ConvLayer1D(16, 16, activation='tanh')
     with pytest.raises(ValueError):
         W.wav2sleep.ConvGroupNorm(20, num_groups=8)
+
+
+def test_save_predictions_writes_the_reference_csv_text(tmp_path):
+    """`save_predictions` against the REFERENCE function itself (api.py:193-221, run by make_goldens_r2.py with empty stand-ins for
+    the hydra / omegaconf / pyedflib imports of api.py): same tree, same CSV bytes, with and without labels, relative and
+    absolute (DatetimeIndex) time stamps."""
+    import shutil
+    g = load('save_predictions')
+    ddir = os.path.join(GOLDEN_DIR, 'dataset')
+    src = tmp_path / 'in'
+    (src / 'sub').mkdir(parents=True)
+    shutil.copy(os.path.join(ddir, 'full.parquet'), src / 'a.parquet')
+    shutil.copy(os.path.join(ddir, 'no_ppg.parquet'), src / 'sub' / 'b.parquet')
+    shutil.copy(os.path.join(ddir, 'abs_time.parquet'), src / 'sub' / 'c_abs.parquet')
+    files = sorted(str(src / f) for f in ('a.parquet', 'sub/b.parquet', 'sub/c_abs.parquet'))
+    assert [os.path.relpath(f, src) for f in files] == [str(f) for f in g['files']]
+    ds = W.ParquetDataset(files, columns=['ABD', 'THX', 'ECG', 'PPG'], num_classes=4, require_labels=False)
+    preds = [torch.from_numpy(g[f'pred{i}']) for i in range(3)]
+    labels = [torch.from_numpy(g[f'label{i}']) for i in range(3)]
+    for tag, lab in (('with_labels', labels), ('no_labels', None)):
+        dst = tmp_path / ('out_' + tag)
+        W.save_predictions(preds, str(src), str(dst), ds, labels=lab)
+        for fp in files:
+            rel = os.path.relpath(fp, src)
+            got = open(dst / (os.path.splitext(rel)[0] + '.preds.csv')).read()
+            assert got == str(g[f'{tag}.{rel}']), (tag, rel, got)
+    lds = W.load_dataset(str(src), ['ECG', 'THX'], num_classes=5, max_length_hours=None, normalize_on_device=False)
+    assert [os.path.relpath(f, src) for f in lds.files] == [str(f) for f in g['load_dataset.files']]
+    assert list(lds.columns) == [str(c) for c in g['load_dataset.columns']]
+    x0, y0 = lds[0]
+    assert list(x0.keys()) == [str(k) for k in g['load_dataset.keys0']] and np.array_equal(y0.numpy(), g['load_dataset.y0'], equal_nan=True)
