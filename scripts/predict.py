@@ -21,7 +21,7 @@ FLAGS = [
     ('--output-folder', dict(required=True, type=os.path.abspath, help='where the .preds.csv files go (input tree is mirrored)')),
     ('--model-folder', dict(default=None, help='folder holding config.yaml + state_dict.pth (no network here: hf:// URIs are refused)')),
     ('--signals', dict(default=None, help='comma-separated subset of the signals the model knows, e.g. ECG,THX (default: all)')),
-    ('--device', dict(default='auto', help="'auto', 'cuda' or 'cuda:N'")),
+    ('--device', dict(type=str, default='auto', help="'auto', 'cuda' or 'cuda:N'")),
     ('--batch-size', dict(type=int, default=4)),
     ('--num-workers', dict(type=int, default=4)),
     ('--no-preprocess', dict(action='store_true', help='inputs are model-ready parquet files (EDF/CSV ingestion is not part of this build)')),

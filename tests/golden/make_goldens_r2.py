@@ -234,6 +234,51 @@ def run_save_predictions():
     np.savez_compressed(os.path.join(HERE, 'save_predictions.npz'), **out)
     print('save_predictions:', {k: len(str(v)) for k, v in out.items() if k.startswith('with')})
 
+
+def run_cli():
+    """The argument parser of the reference's scripts/predict.py (its module imports torchmetrics / wav2sleep.api: stand-ins; the parser is
+    captured by intercepting ArgumentParser.parse_args): every option with its destination, default, type, action and required flag."""
+    import argparse
+    import importlib.util
+    import json
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith('__'):
+                raise AttributeError(name)
+            return type(name, (), {})
+    for n in ('torchmetrics', 'torchmetrics.classification', 'hydra', 'hydra.utils', 'omegaconf', 'pyedflib', 'mne'):
+        sys.modules.setdefault(n, _Any(n))
+    shim = types.ModuleType('numba'); shim.njit = lambda *a, **k: (lambda f: f)
+    sys.modules.setdefault('numba', shim)
+    data = types.ModuleType('wav2sleep.data'); data.__path__ = [REF + '/data']; sys.modules['wav2sleep.data'] = data
+    models = types.ModuleType('wav2sleep.models'); models.__path__ = [REF + '/models']; sys.modules.setdefault('wav2sleep.models', models)
+    spec = importlib.util.spec_from_file_location('ref_predict_cli', os.path.join(os.path.dirname(os.path.dirname(REF)), 'scripts', 'predict.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    captured = {}
+    real = argparse.ArgumentParser.parse_args
+
+    def spy(self, *a, **k):
+        captured['parser'] = self
+        raise SystemExit(0)
+    argparse.ArgumentParser.parse_args = spy
+    try:
+        mod.parse_args()
+    except SystemExit:
+        pass
+    finally:
+        argparse.ArgumentParser.parse_args = real
+    opts = []
+    for act in captured['parser']._actions:
+        if not act.option_strings or act.dest == 'help':
+            continue
+        opts.append(dict(flags=list(act.option_strings), dest=act.dest, default=act.default, required=bool(act.required),
+                         type=getattr(act.type, '__name__', None) if act.type else None, action=type(act).__name__, nargs=act.nargs))
+    with open(os.path.join(HERE, 'predict_cli.json'), 'w') as f:
+        json.dump(opts, f, indent=1)
+    print('cli:', [o['flags'][0] for o in opts])
+
 def run_ema():
     class _Any(types.ModuleType):   # any other name the module touches at import time (base classes of callbacks that are not used here)
         def __getattr__(self, name):
@@ -322,6 +367,6 @@ def run_variants():
 
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for name, fn in (('default_init', run_default_init), ('optim', run_optim), ('train10', run_train10), ('dataset', run_dataset), ('ema', run_ema), ('variants', run_variants), ('save_predictions', run_save_predictions)):
+    for name, fn in (('default_init', run_default_init), ('optim', run_optim), ('train10', run_train10), ('dataset', run_dataset), ('ema', run_ema), ('variants', run_variants), ('save_predictions', run_save_predictions), ('cli', run_cli)):
         if not only or name in only:
             fn()

@@ -153,3 +153,28 @@ def test_save_predictions_writes_the_reference_csv_text(tmp_path):
     assert list(lds.columns) == [str(c) for c in g['load_dataset.columns']]
     x0, y0 = lds[0]
     assert list(x0.keys()) == [str(k) for k in g['load_dataset.keys0']] and np.array_equal(y0.numpy(), g['load_dataset.y0'], equal_nan=True)
+
+
+def test_predict_cli_has_the_reference_flags():
+    """scripts/predict.py against the parser of the REFERENCE script (captured by make_goldens_r2.py `cli`): same options, destinations,
+    types, actions, required flags and defaults -- except --model-folder, whose reference default is a Hugging Face Hub URI (no network
+    here: the option must be given)."""
+    import argparse
+    import importlib.util
+    import json
+    ref = json.load(open(os.path.join(GOLDEN_DIR, 'predict_cli.json')))
+    spec = importlib.util.spec_from_file_location('w2s_predict_cli_flags', os.path.join(os.path.dirname(GOLDEN_DIR), '..', 'scripts', 'predict.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ap = argparse.ArgumentParser()
+    for flag, kw in mod.FLAGS:
+        ap.add_argument(flag, **kw)
+    mine = {a.option_strings[0]: a for a in ap._actions if a.option_strings and a.dest != 'help'}
+    assert list(mine) == [o['flags'][0] for o in ref]
+    for o in ref:
+        a = mine[o['flags'][0]]
+        assert a.dest == o['dest'] and bool(a.required) == o['required'] and type(a).__name__ == o['action'] and a.nargs == o['nargs'], o
+        assert (getattr(a.type, '__name__', None) if a.type else None) == o['type'], o
+        if o['dest'] != 'model_folder':
+            assert a.default == o['default'], o
+    assert ref[[o['dest'] for o in ref].index('model_folder')]['default'].startswith('hf://') and mine['--model-folder'].default is None
