@@ -28,9 +28,7 @@ def _run_ranks(out_dir, world, accumulate):
     try:
         for r in range(world):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                       W2S_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0',
-                       W2S_MULTI_STREAM='0')   # two processes share one GPU here: keep each to its compute stream + the reducer's (the
-            # gradients do not depend on the stream schedule: test_scheduling_switches_do_not_change_a_bit)
+                       W2S_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ddp_flow_worker.py'), str(out_dir), str(accumulate)], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     except PermissionError as e:   # exec refused (this process had already initialised the GPU)
