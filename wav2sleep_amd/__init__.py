@@ -10,10 +10,11 @@ from .stats import cohens_kappa, confusion_accuracy  # noqa: F401
 from .trainer import (ExpWarmUpScheduler, FusedTrainStep, SignalMasker, SleepLightningModule, SleepModule,  # noqa: F401
                       exp_warmup_lr, invert_signals)
 from .ppgnet import SleepPPGNet  # noqa: F401
+from .serving import GraphedForward  # noqa: F401
 from .wav2sleep import (ConvBlock1D, ConvLayer1D, DilatedConvBlock, MultiModalAttentionEmbedder, SequenceCNN, SignalEncoder,  # noqa: F401
                         SignalEncoders, Wav2Sleep)
 
-__all__ = ['Wav2Sleep', 'SleepPPGNet', 'SignalEncoder', 'ConvBlock1D', 'ConvLayer1D', 'DilatedConvBlock', 'SignalEncoders', 'MultiModalAttentionEmbedder', 'SequenceCNN', 'load_model', 'predict', 'FusedTrainStep',
+__all__ = ['Wav2Sleep', 'SleepPPGNet', 'GraphedForward', 'SignalEncoder', 'ConvBlock1D', 'ConvLayer1D', 'DilatedConvBlock', 'SignalEncoders', 'MultiModalAttentionEmbedder', 'SequenceCNN', 'load_model', 'predict', 'FusedTrainStep',
            'SleepModule', 'SleepLightningModule', 'SignalMasker', 'invert_signals', 'ExpWarmUpScheduler', 'exp_warmup_lr',
            'cohens_kappa', 'confusion_accuracy', 'EMACallback', 'lightning_checkpoint', 'save_lightning_checkpoint',
            'load_lightning_checkpoint', 'save_model', 'ParquetDataset', 'load_dataset', 'save_predictions', 'predict_on_folder', 'causal_rolling_normalize']
