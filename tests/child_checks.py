@@ -1,0 +1,199 @@
+"""Full-size / multi-process checks that run in a CHILD process of the pytest run (tests/test_a_children_gpu.py starts them before the
+pytest process has touched the GPU, each with a hard timeout that kills the child's process group: a hang costs one test, not the box).
+
+    python tests/child_checks.py <check> <result.json>
+
+Each check writes a JSON dict of measured values; the tolerances live in the pytest file.  The oracle is imported as the checker only.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+SM4 = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}
+SM5 = dict(SM4, **{'EOG-L': 'EOG-L'})
+SM6 = dict(SM5, **{'EOG-R': 'EOG-R'})
+EOG = {'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}
+DEV = 'cuda'
+CHECKS = {}
+
+
+def check(fn):
+    CHECKS[fn.__name__] = fn
+    return fn
+
+
+def build(W, signal_map, nc, dropout=0.0):
+    return W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', causal=False, chunk_causal=False),
+                       W.MultiModalAttentionEmbedder(128, layers=2, dropout=dropout, dim_ff=512, nhead=8),
+                       W.SequenceCNN(128, dropout=dropout, norm='layer', causal=False, num_layers=2, kernel_size=7, num_dilations=6), nc)
+
+
+def _grad_errors(model, want):
+    worst, over = ('', 0.0), []
+    for name, p in model.named_parameters():
+        w = want[name].double()
+        rel = float((p.grad.detach().cpu().double() - w).norm() / (w.norm() + 1e-30))
+        if rel > worst[1]:
+            worst = (name, rel)
+        if rel > 1e-3:
+            over.append((name, rel))
+    return worst, over
+
+
+@check
+def eog_fullsize_grad():
+    """BASELINE configs[3] at full size (EOG-L + EOG-R, 4096 samples per epoch: ten-block encoders, 3.9 M samples per recording, 5 classes),
+    B = 1: loss and every gradient tensor vs the oracle's autograd; two runs bit-identical (the 10-block encoders' reproducibility)."""
+    import wav2sleep_amd as W
+    from oracle import wav2sleep_oracle as O
+    torch.manual_seed(42)
+    model = build(W, EOG, 5).to(DEV).train()
+    cfg = O.ModelConfig(signal_map=EOG, num_classes=5)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x, y = O.make_inputs(cfg, 1, 960, seed=321)
+    runs = []
+    for _ in range(3):
+        model.zero_grad(set_to_none=True)
+        logits = model({k: v.to(DEV) for k, v in x.items()})
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, 5), y.to(DEV).reshape(-1).long(), ignore_index=-1)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append(model._flat_grad.clone())
+    want_loss, _, want = O.loss_and_grads(sd, cfg, x, y)
+    worst, over = _grad_errors(model, want)
+    return dict(bit_reproducible=all(torch.equal(runs[0], r) for r in runs[1:]), loss=float(loss), want_loss=float(want_loss), worst_tensor=worst[0],
+                worst_rel_l2=worst[1], over_1e3=over)
+
+
+@check
+def b16_fullsize_grad():
+    """The benchmark's own shape (4 modalities x 960 epochs, B = 16, default init, 6 missing (sample, modality) pairs): every gradient tensor of
+    ONE backward pass vs the oracle accumulated over 8 micro-batches of 2 (sum_mb (valid_mb / valid_total) * grad(mean loss of mb))."""
+    import wav2sleep_amd as W
+    from oracle import wav2sleep_oracle as O
+    torch.manual_seed(42)
+    model = build(W, SM4, 4).to(DEV).train()
+    cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    B, S = 16, 960
+    x, y = O.make_inputs(cfg, B, S, seed=77, missing={'ABD': [3], 'PPG': [3, 7], 'ECG': [11], 'THX': [0, 15]})
+    logits = model({k: v.to(DEV) for k, v in x.items()})
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, 4), y.to(DEV).reshape(-1).long(), ignore_index=-1)
+    loss.backward()
+    torch.cuda.synchronize()
+    total = int((y >= 0).sum())
+    want = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in sd.items()}
+    wl = 0.0
+    pred_want = []
+    for b0 in range(0, B, 2):
+        xm = {k: v[b0:b0 + 2] for k, v in x.items()}
+        ym = y[b0:b0 + 2]
+        l, lg, g = O.loss_and_grads(sd, cfg, xm, ym)
+        pred_want.append(lg.argmax(-1))
+        w = int((ym >= 0).sum()) / total
+        wl += w * l
+        for k in want:
+            want[k] += w * g[k].double()
+    worst, over = _grad_errors(model, want)
+    agree = float((logits.argmax(-1).cpu() == torch.cat(pred_want)).float().mean())
+    return dict(loss=float(loss), want_loss=float(wl), worst_tensor=worst[0], worst_rel_l2=worst[1], over_1e3=over, argmax_agreement=agree)
+
+
+@check
+def batch_invariance():
+    """A recording's logits must not depend on its batch neighbours (instance / layer norms only): B = 32 vs two halves of 16, B = 5 vs
+    single recordings; full length, bit for bit."""
+    import bench
+    import wav2sleep_amd as W
+    torch.manual_seed(42)
+    model = build(W, SM4, 4, dropout=0.1).to(DEV).eval()
+    dev = torch.device(DEV)
+    with torch.no_grad():
+        x, _ = bench.make_batch(32, 960, 4, dev, 99)
+        x['ECG'][5] = float('-inf')
+        x['ABD'][20] = float('-inf')
+        full = model(x)
+        halves = torch.cat([model({k: v[:16] for k, v in x.items()}), model({k: v[16:] for k, v in x.items()})])
+        x5 = {k: v[:5] for k, v in x.items()}
+        f5 = model(x5)
+        singles = torch.cat([model({k: v[i:i + 1] for k, v in x5.items()}) for i in range(5)])
+    return dict(b32_vs_halves_equal=torch.equal(full, halves), b32_max_diff=float((full - halves).abs().max()),
+                b5_vs_singles_equal=torch.equal(f5, singles), b5_max_diff=float((f5 - singles).abs().max()))
+
+
+@check
+def five_mod_fullsize_forward():
+    """BASELINE configs[4]'s modality set at full length: {ABD, THX, ECG, PPG, EOG-L} (D = 6 tokens; 6-, 8- and 10-block encoders side by
+    side), 960 epochs, B = 2, masks drawn by SignalMasker; forward vs oracle."""
+    import wav2sleep_amd as W
+    from oracle import wav2sleep_oracle as O
+    torch.manual_seed(42)
+    model = build(W, SM5, 4).to(DEV).eval()
+    cfg = O.ModelConfig(signal_map=SM5, num_classes=4)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x, y = O.make_inputs(cfg, 2, 960, seed=555, missing={'EOG-L': [1], 'ABD': [0]})
+    with torch.no_grad():
+        got = model({k: v.to(DEV) for k, v in x.items()}).cpu()
+    want = O.forward(sd, cfg, x)
+    err = (got - want).abs()
+    scale = float(want.abs().max())
+    return dict(max_abs_err=float(err.max()), max_abs_logit=scale, argmax_agreement=float((got.argmax(-1) == want.argmax(-1)).float().mean()),
+                worst_floored_rel=float((err / (want.abs() + 0.2 * scale)).max()))
+
+
+@check
+def nccl_forced_collectives():
+    """The RCCL + side-stream path on one GPU: FusedTrainStep with backend 'nccl', world size 1, W2S_FORCE_COLLECTIVES=1 against the same
+    steps without any collective: flat gradient and parameters bit for bit (a SUM over one rank is the identity)."""
+    import torch.distributed as dist
+    import wav2sleep_amd as W
+    from oracle import wav2sleep_oracle as O
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29591')
+    os.environ['RANK'], os.environ['WORLD_SIZE'] = '0', '1'
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=61)
+    batches = [O.make_inputs(cfg, 3, 40, seed=600 + k, missing={'THX': [1]} if k == 1 else None) for k in range(3)]
+
+    def run(force):
+        if force:
+            os.environ['W2S_FORCE_COLLECTIVES'] = '1'
+        else:
+            os.environ.pop('W2S_FORCE_COLLECTIVES', None)
+        model = build(W, SM4, 4)
+        model.load_state_dict(sd)
+        model.to(dev).train()
+        tr = W.FusedTrainStep(model, lr=1e-3, scheduler=False)
+        assert tr.reducer.force == force and (tr.reducer.stream is not None) == force
+        grads = []
+        for x, y in batches:
+            tr.step({k: v.to(dev) for k, v in x.items()}, y.to(dev))
+            grads.append(model._flat_grad.clone())
+        _, _, cm = tr.metrics()
+        torch.cuda.synchronize()
+        return grads, model._flat.clone(), cm.clone()
+
+    g0, p0, cm0 = run(False)
+    dist.init_process_group('nccl', device_id=dev)
+    g1, p1, cm1 = run(True)
+    dist.destroy_process_group()
+    return dict(grads_equal=all(torch.equal(a, b) for a, b in zip(g0, g1)), params_equal=torch.equal(p0, p1), cm_equal=torch.equal(cm0, cm1),
+                backend='nccl', steps=len(batches))
+
+
+if __name__ == '__main__':
+    name, out = sys.argv[1], sys.argv[2]
+    t0 = time.time()
+    res = CHECKS[name]()
+    res['seconds'] = round(time.time() - t0, 1)
+    with open(out, 'w') as f:
+        json.dump(res, f)
+    print(json.dumps(res))

@@ -74,6 +74,13 @@ CASES = {
     # shared encoder told apart by signal embeddings (embed_signals=True) + two register tokens next to CLS
     'c8_embed_reg': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [1]}, 18, 108),
     'c9_no_residual': ({'ABD': 'ABD', 'PPG': 'PPG'}, 4, 2, 4, None, 19, 109),
+    # BASELINE configs[4] as written: a map over {ABD, THX, ECG, PPG, EOG} (settings.py:19-26; mixed 6/8/10-block encoders, D = 6 tokens),
+    # ragged: sample 1 keeps only its backup channel (masker.py:30-48), sample 2 lacks the EOG
+    'c10_five_mod': ({'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG', 'EOG-L': 'EOG-L'}, 4, 3, 3,
+                     {'ABD': [1], 'THX': [1], 'PPG': [1], 'EOG-L': [1, 2], 'ECG': [0]}, 20, 110),
+    # ... and with EOG-R: D = 7 tokens, the attention kernels' limit; 5 classes
+    'c11_six_mod': ({'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG', 'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 2,
+                    {'THX': [0], 'EOG-R': [1], 'ECG': [1]}, 21, 111),
 }
 CAUSAL_CASES = {'c6_causal', 'c7_chunk_causal'}
 CHUNK_CASES = {'c7_chunk_causal'}

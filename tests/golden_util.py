@@ -16,6 +16,13 @@ CASES = {
     'c7_chunk_causal': ({'THX': 'THX', 'PPG': 'PPG'}, 4, 2, 6, {'THX': [0]}, 17, 107),
     'c8_embed_reg': ({'ABD': 'RESP', 'THX': 'RESP', 'ECG': 'ECG'}, 4, 2, 4, {'THX': [1]}, 18, 108),
     'c9_no_residual': ({'ABD': 'ABD', 'PPG': 'PPG'}, 4, 2, 4, None, 19, 109),
+    # BASELINE configs[4] as written: a map over {ABD, THX, ECG, PPG, EOG} (settings.py:19-26; mixed 6/8/10-block encoders, D = 6 tokens),
+    # ragged: sample 1 keeps only its backup channel (masker.py:30-48), sample 2 lacks the EOG
+    'c10_five_mod': ({'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG', 'EOG-L': 'EOG-L'}, 4, 3, 3,
+                     {'ABD': [1], 'THX': [1], 'PPG': [1], 'EOG-L': [1, 2], 'ECG': [0]}, 20, 110),
+    # ... and with EOG-R: D = 7 tokens, the attention kernels' limit; 5 classes
+    'c11_six_mod': ({'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG', 'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, 5, 2, 2,
+                    {'THX': [0], 'EOG-R': [1], 'ECG': [1]}, 21, 111),
 }
 CAUSAL_CASES = {'c6_causal', 'c7_chunk_causal'}  # `causal: True` (scripts/config/main.yaml:22)
 EXTRA = {'c8_embed_reg': dict(embed_signals=True, register_tokens=2, output_norm=True), 'c9_no_residual': dict(use_residual=False)}  # SignalEncoders(embed_signals=True), MultiModalAttentionEmbedder(register_tokens=2)

@@ -1,0 +1,101 @@
+"""Full-size and multi-process checks, each in its OWN child process with a hard time limit (tests/child_checks.py does the work).
+
+Round 2 lost a GPU box during a suite run that held two of these checks in-process ("An unexplained lost box"); the verdict
+asked for them back under `-m gpu` in a form where a hang costs one test, not the box: the child runs in its own session, is killed
+(whole process group) at the limit and the test fails -- no re-exec, no retry.  This file sorts before every in-process GPU test on
+purpose: the pool refuses to start a program from a process that has initialised the GPU, so the children are started while this
+pytest process has not (if it already has, the test is skipped with that reason).
+
+Covers: BASELINE configs[3] full-size gradients (+ bit-reproducibility of the ten-block encoders), the benchmark's own B = 16 shape
+against the oracle, batch invariance, configs[4]'s five-modality set at full length, the RCCL path (`nccl`, forced collectives at world
+size 1) and `bench.py --gpus 2` end to end over gloo."""
+import json
+import os
+import signal
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_child(cmd, limit, env=None, tag='child'):
+    """-> (returncode, combined output).  Kills the child's whole process group at `limit` seconds and fails the test."""
+    try:
+        p = subprocess.Popen(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(env or {})), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                             text=True, start_new_session=True, cwd=ROOT)
+    except PermissionError as e:   # exec refused: this process had already initialised the GPU
+        pytest.skip(f'child process could not be started from this process: {e}')
+    try:
+        out, _ = p.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, _ = p.communicate()
+        pytest.fail(f'{tag}: no result within {limit} s -- child killed.  Output so far:\n{(out or "")[-3000:]}')
+    return p.returncode, out
+
+
+def run_check(name, tmp_path, limit, env=None):
+    res = os.path.join(tmp_path, f'{name}.json')
+    rc, out = run_child([sys.executable, os.path.join(ROOT, 'tests', 'child_checks.py'), name, res], limit, env, tag=name)
+    assert rc == 0, f'{name} failed (exit {rc}):\n{out[-4000:]}'
+    return json.load(open(res))
+
+
+def test_configs3_eog_full_size_gradients_match_oracle_and_are_bit_reproducible(tmp_path):
+    """EOG-L + EOG-R, 3.9 M samples per recording, ten-block encoders, 5 classes, B = 1.  Bar: every gradient tensor <= 2e-3 relative L2."""
+    r = run_check('eog_fullsize_grad', tmp_path, 900)
+    assert r['bit_reproducible']
+    assert r['loss'] == pytest.approx(r['want_loss'], rel=1e-4)
+    assert r['worst_rel_l2'] <= 2e-3, (r['worst_tensor'], r['worst_rel_l2'])
+
+
+def test_benchmark_shape_batch16_gradients_match_oracle(tmp_path):
+    """4 modalities x 960 epochs, B = 16, ragged: one backward pass vs the oracle over 8 micro-batches of 2."""
+    r = run_check('b16_fullsize_grad', tmp_path, 1500)
+    assert r['loss'] == pytest.approx(r['want_loss'], rel=1e-4)
+    assert r['worst_rel_l2'] <= 2e-3, (r['worst_tensor'], r['worst_rel_l2'], r['over_1e3'])
+    assert r['argmax_agreement'] >= 0.9999
+
+
+def test_logits_do_not_depend_on_batch_neighbours_full_length(tmp_path):
+    r = run_check('batch_invariance', tmp_path, 600)
+    assert r['b32_vs_halves_equal'] and r['b5_vs_singles_equal'], r
+
+
+def test_configs4_five_modality_full_length_forward_matches_oracle(tmp_path):
+    """{ABD, THX, ECG, PPG, EOG-L}: D = 6 tokens, 6/8/10-block encoders on five streams, 960 epochs, B = 2, ragged."""
+    r = run_check('five_mod_fullsize_forward', tmp_path, 900)
+    assert r['max_abs_err'] <= 1e-3 * r['max_abs_logit'], r
+    assert r['argmax_agreement'] >= 0.9999, r
+
+
+def test_rccl_forced_collectives_leave_every_bit_unchanged(tmp_path):
+    """backend 'nccl' (= RCCL), world size 1, W2S_FORCE_COLLECTIVES=1: the ranged all-reduces on the side stream and the packed metric
+    all-reduce run for real; a SUM over one rank is the identity, so gradients, parameters and confusion counts must not change."""
+    r = run_check('nccl_forced_collectives', tmp_path, 600)
+    assert r['grads_equal'] and r['params_equal'] and r['cm_equal'], r
+
+
+def test_bench_two_ranks_end_to_end_over_gloo(tmp_path):
+    """`python bench.py --gpus 2` (spawns its two ranks through torch.distributed.run, both on this box's one GPU: gloo, since RCCL refuses
+    two ranks per device) -> ONE JSON line with n_gpus 2 and a positive whole-job value: the driver's multi-GPU launch cannot fail on plumbing."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    rc, out = run_child([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--epochs', '120',
+                         '--no-cpu'], 900, env=dict(W2S_DIST_BACKEND='gloo', MASTER_PORT=str(port)), tag='bench --gpus 2')
+    assert rc == 0, out[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['config']['global_batch'] == 4 and line['scaling'] == 'weak'
+    assert line['config']['parallelism'] == 'dp2'

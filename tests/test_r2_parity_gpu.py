@@ -281,7 +281,7 @@ def test_wrong_device_stream_is_refused(monkeypatch):
     from wav2sleep_amd import lib
     t = torch.zeros(8, device=DEV)
     lib._p(t)
-    monkeypatch.setattr(lib, '_last_dev', t.device.index + 1)
+    monkeypatch.setattr(lib._tls, 'dev', t.device.index + 1)
     with pytest.raises(lib.W2SError):
         lib._stream()
 

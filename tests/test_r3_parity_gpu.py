@@ -1,0 +1,146 @@
+"""Round-3 GPU parity tests: BASELINE configs[4] as written (five / six modalities including EOG, ragged masks from SignalMasker), the
+Lightning-shaped loop on the module surface with STOCK torch optimiser objects, autograd lifetimes of the one-node forward.
+Goldens c10_five_mod / c11_six_mod ride in the CASES-parametrised tests of test_parity_gpu.py."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import wav2sleep_amd as W  # noqa: E402
+from oracle import wav2sleep_oracle as O  # noqa: E402  (checker only)
+from tests.golden_util import CASES, assert_summary_close, case_config, load  # noqa: E402
+from tests.test_parity_gpu import assert_logits_close, build, to_dev  # noqa: E402
+
+DEV = 'cuda'
+SM5 = {'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG', 'EOG-L': 'EOG-L'}
+SM6 = dict(SM5, **{'EOG-R': 'EOG-R'})
+# inputs/cardiorespiratory/all.yaml:9-18 + inputs/neural/eog.yaml:7-11
+P_DROP = {'ABD': 0.7, 'THX': 0.7, 'ECG': 0.5, 'PPG': 0.1, 'EOG-L': 0.7, 'EOG-R': 0.7}
+
+
+@pytest.mark.parametrize('signal_map,nc', [(SM5, 4), (SM6, 5)], ids=['D6', 'D7'])
+def test_configs4_ragged_five_and_six_modalities_match_oracle(signal_map, nc):
+    """Random per-sample modality subsets drawn by the SignalMasker rule (trainer/masker.py:10-51) over {ABD, THX, ECG, PPG, EOG-L(, EOG-R)}:
+    D = 6 / 7 tokens (7 = the attention kernels' limit), 6-, 8- and 10-block encoders in one model; sample 0 arrives with nothing but its
+    backup channel.  Forward (logits, arg-max) and every gradient vs the oracle."""
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=nc)
+    model = build(signal_map, nc)
+    sd = O.make_state_dict(cfg, seed=91)
+    model.load_state_dict(sd)
+    model.to(DEV).train()
+    B, S = 5, 3
+    x, y = O.make_inputs(cfg, B, S, seed=910 + nc)
+    for s in signal_map:   # sample 0: only ECG was recorded -> whatever the masker draws, the backup channel must survive
+        if s != 'ECG':
+            x[s][0] = float('-inf')
+    torch.manual_seed(7 + nc)
+    xd = to_dev(x)
+    W.SignalMasker({k: P_DROP[k] for k in signal_map}, backups=['ECG', 'PPG'])(xd)
+    xm = {k: v.cpu() for k, v in xd.items()}
+    masks = np.array([[bool(torch.isinf(xm[s][b, 0])) for s in signal_map] for b in range(B)])
+    assert masks.any() and not masks.all(axis=1).any() and len({tuple(r) for r in masks}) >= 3, masks   # ragged: several distinct subsets
+    assert not masks[0, list(signal_map).index('ECG')] and masks[0].sum() == len(signal_map) - 1       # the all-but-backup sample
+
+    logits = model(xd)
+    loss = F.cross_entropy(logits.reshape(-1, nc), y.to(DEV).reshape(-1).long(), ignore_index=-1)
+    loss.backward()
+    want_loss, want_logits, want = O.loss_and_grads(sd, cfg, xm, y)
+    assert_logits_close(logits.detach().cpu().numpy(), want_logits.numpy())
+    assert torch.equal(logits.argmax(-1).cpu(), want_logits.argmax(-1))
+    assert float(loss) == pytest.approx(want_loss, rel=1e-4)
+    for name, p in model.named_parameters():
+        w = want[name]
+        if float(w.norm()) == 0.0:   # an encoder no sample of the batch kept: exactly zero here too
+            assert float(p.grad.abs().max()) == 0.0, name
+            continue
+        rel = float((p.grad.cpu() - w).norm() / w.norm())
+        assert rel <= 2e-3, (name, rel)
+
+
+def test_more_than_seven_tokens_is_refused():
+    model = build(SM6, 5)
+    model.epoch_mixer = W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.0, dim_ff=512, nhead=8, register_tokens=1)
+    model.to(DEV).eval()
+    x, _ = O.make_inputs(O.ModelConfig(signal_map=SM6, num_classes=5), 1, 2, seed=3)
+    with pytest.raises(ValueError, match='at most 7 tokens'):
+        model(to_dev(x))
+
+
+@pytest.mark.parametrize('name', ['c2_four_mod', 'c10_five_mod'])
+def test_stock_optimizer_loop_matches_reference_golden(name):
+    """scripts/train.py as Lightning runs it (trainer/main.py:273-297, training/main.yaml:21-22), with torch's OWN objects on the module
+    surface: logits = model(x) -> CE -> loss.backward() -> clip_grad_norm_(1.0) -> torch.optim.AdamW.step() -> ExpWarmUpScheduler.step(),
+    two steps.  The parameters are 183 views of one flat buffer and the packed kernel weights are keyed on their `_version`: an in-place
+    optimiser step by torch must be seen by the next forward.  Same goldens and tolerances as the FusedTrainStep test."""
+    signal_map, nc, B, S, missing, wseed, iseed = CASES[name]
+    g = load(name)
+    cfg = case_config(name)
+    model = build(signal_map, nc)
+    model.load_state_dict(O.make_state_dict(cfg, seed=wseed))
+    model.to(DEV).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    sched = W.ExpWarmUpScheduler(opt, lr_max=1e-3, warmup_steps=2000, tau=10000)
+    crit = torch.nn.CrossEntropyLoss(reduction='mean', label_smoothing=0.0, ignore_index=-1)
+    for step in range(2):
+        xs, ys = O.make_inputs(cfg, B, S, seed=iseed + 1000 * step, missing=missing)
+        opt.zero_grad()
+        logits = model(to_dev(xs))
+        loss = crit(logits.view(-1, nc), ys.to(DEV).view(-1).long())
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        assert opt.param_groups[0]['lr'] == pytest.approx(float(g[f'lr{step}']), rel=1e-6)
+        opt.step()
+        sched.step()
+        assert float(loss) == pytest.approx(float(g[f'loss{step}']), rel=1e-4)
+        assert float(gn) == pytest.approx(float(g[f'gnorm{step}']), rel=1e-3)
+    sd = model.state_dict()
+    for k in sd:
+        assert_summary_close(sd[k], g[f'param2.{k}'], rtol=1e-5, atol=1.1e-6, what=f'param2.{k}')
+    # the views still alias the flat buffer (the optimiser stepped in place; nothing re-allocated)
+    base = model._flat.data_ptr()
+    for (o, n, _), p in zip(model._layout, model.parameters()):
+        assert p.data_ptr() == base + 4 * o
+
+
+def test_autograd_lifetimes_follow_the_graph():
+    """the saved activations belong to the autograd node -- three forwards before one backward (summed micro-batch losses),
+    retain_graph=True followed by a second backward, and a dropped graph releasing its memory."""
+    cfg = O.ModelConfig(signal_map={'ABD': 'ABD', 'ECG': 'ECG'}, num_classes=4)
+    model = build(cfg.signal_map, 4)
+    sd = O.make_state_dict(cfg, seed=33)
+    model.load_state_dict(sd)
+    model.to(DEV).train()
+    batches = [O.make_inputs(cfg, 2, 4, seed=330 + k) for k in range(3)]
+
+    def loss_of(x, y):
+        return F.cross_entropy(model(to_dev(x)).reshape(-1, 4), y.to(DEV).reshape(-1).long(), ignore_index=-1)
+
+    total = sum(loss_of(x, y) for x, y in batches)   # three forwards in flight
+    assert len(model._saved_ctx) == 0                # nothing parked on the model in eager mode
+    total.backward(retain_graph=True)
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    want = {k: torch.zeros_like(v) for k, v in sd.items()}
+    for x, y in batches:
+        _, _, g = O.loss_and_grads(sd, cfg, x, y)
+        for k in want:
+            want[k] += g[k]
+    for k, v in g1.items():
+        assert float((v.cpu() - want[k]).norm() / want[k].norm()) <= 2e-3, k
+    model.zero_grad(set_to_none=True)
+    total.backward()                                  # second backward through the retained graph: same bits
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, g1[k]), k
+    with pytest.raises(RuntimeError):
+        total.backward()                              # graph freed now, as for any torch op
+    # a forward whose graph is dropped releases its activations with it
+    del total
+    torch.cuda.synchronize()
+    x, y = O.make_inputs(cfg, 2, 64, seed=340)
+    xd = to_dev(x)
+    base = torch.cuda.memory_allocated()
+    out = model(xd)
+    held = torch.cuda.memory_allocated() - base
+    del out
+    assert held > 20e6 and torch.cuda.memory_allocated() - base < 0.05 * held

@@ -233,6 +233,7 @@ def load_lightning_checkpoint(checkpoint, module, strict: bool = True, restore_r
         step.betas, step.eps, step.wd = tuple(g['betas']), g['eps'], g['weight_decay']
         step.lr_max = g.get('initial_lr', step.lr_max)
     step.step_count = k
+    step.micro = 0   # a load in the middle of an accumulation window starts a fresh window (the flat gradient holds another run's partial sum)
     if 'w2s_seed_state' in checkpoint:
         model._seed_base, model._seed_ctr = checkpoint['w2s_seed_state']
     if restore_rng:
@@ -243,6 +244,7 @@ def load_lightning_checkpoint(checkpoint, module, strict: bool = True, restore_r
                 torch.cuda.set_rng_state_all(checkpoint['cuda_rng_state_all'])
             except (RuntimeError, IndexError):  # different device count than the run that saved it
                 pass
+    step.sync_parameters()   # every rank ends with rank 0's weights and moments, whichever ranks read the file (a no-op at world size 1)
     return checkpoint
 
 

@@ -280,7 +280,9 @@ class Engine:
         return torch.empty(nslab * n, device=dev, dtype=torch.float32)
 
     def _wgrad(self, name, *, g, x, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, layout=0, **kw):
-        """weight gradient -> slabs -> deterministic reduce into G[name] (accumulating if already written)."""
+        """weight gradient -> slabs -> deterministic reduce into G[name] (accumulating if already written).
+        During the trunk's backward the call may be DEFERRED (queued as a closure over g / x and run after the encoder streams have forked):
+        the caller must not write g or x in place afterwards -- every trunk gradient tensor is a fresh allocation written exactly once."""
         if self._deferred is not None:   # trunk backward: leaf work, enqueued after the encoder streams have been forked (backward())
             self._deferred.append(lambda: self._wgrad(name, g=g, x=x, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride,
                                                       pad=pad, dil=dil, layout=layout, **kw))
@@ -649,6 +651,13 @@ class Engine:
     # ------------------------------------------------------------------ backward
     def backward(self, glogits: torch.Tensor, accumulate: bool = False, hook=None):
         """Gradients of everything saved by forward(save=True) into self.G (overwrite unless accumulate)."""
+        try:
+            self._backward(glogits, accumulate, hook)
+        finally:   # an exception mid-way must not leave queued closures / reductions (and the tensors they hold) behind
+            self._deferred = None
+            self._rjobs, self._cjobs = [], []
+
+    def _backward(self, glogits, accumulate, hook):
         sp, P, PB, c = self.spec, self.P, self.PB, self.ctx
         if c is None:
             raise RuntimeError('backward() needs forward(save=True) first')
@@ -778,9 +787,11 @@ class Engine:
                     self._written.add(name)
 
         def trunk_leaves():
-            for k, fn in enumerate(deferred or ()):
-                fn()
-                if k % 3 == 2:
+            k = 0
+            while deferred:
+                deferred.pop(0)()   # popped before it runs: the closure (and the trunk gradient tensors it holds) is released right after
+                k += 1
+                if k % 3 == 0:
                     yield
             self._flush_reduce()
             if R1 > 1:

@@ -94,26 +94,29 @@ def _chk(rc: int, what: str):
         raise W2SError(f'{what} failed with code {rc} ({ {-1: "EINVAL", -2: "ELAUNCH"}.get(rc, "?")})')
 
 
-_last_dev = None   # device index of the most recent tensor argument (checked against the launch stream's device in _stream)
+import threading
+
+_tls = threading.local()   # .dev: device index of the most recent tensor argument evaluated on THIS thread (checked in _stream)
 
 
 def _p(t):
-    global _last_dev
     if t is None:
         return None
     if not t.is_cuda:
         raise W2SError('wav2sleep_amd kernels need device tensors (no CPU path)')
-    _last_dev = t.device.index
+    _tls.dev = t.device.index
     return C.c_void_p(t.data_ptr())
 
 
 def _stream():
-    """The current device's current stream.  Every entry point evaluates its tensor arguments first, so `_last_dev` is the device
-    the buffers live on: a launch onto another device's stream (cuda:1 tensors while cuda:0 is current) raises instead of faulting.
+    """The current device's current stream.  Every entry point evaluates its tensor arguments first (on the calling thread: the record is
+    thread-local, so models driven from different threads on different GPUs do not see each other's), so `_tls.dev` is the device the
+    buffers live on: a launch onto another device's stream (cuda:1 tensors while cuda:0 is current) raises instead of faulting.
     Callers bracket their work with `torch.cuda.device(tensor.device)` (Wav2Sleep.forward, FusedTrainStep.step, inputs.*)."""
     s = torch.cuda.current_stream()
-    if _last_dev is not None and s.device_index != _last_dev:
-        raise W2SError(f'tensors live on cuda:{_last_dev} but the current device is cuda:{s.device_index}: run under torch.cuda.device(...)')
+    dev = getattr(_tls, 'dev', None)
+    if dev is not None and s.device_index != dev:
+        raise W2SError(f'tensors live on cuda:{dev} but the current device is cuda:{s.device_index}: run under torch.cuda.device(...)')
     return C.c_void_p(s.cuda_stream)
 
 

@@ -14,6 +14,7 @@ import weakref
 from typing import List
 
 import torch
+import torch.utils._pytree as pytree
 from torch import Tensor
 
 from .settings import COLS_TO_SAMPLES_PER_EPOCH
@@ -72,7 +73,7 @@ def wav2sleep_backward(handle: int, ticket: Tensor, glogits: Tensor) -> Tensor:
     saved = model._saved_ctx.pop(int(ticket), None)
     if saved is None:
         raise RuntimeError('w2s::wav2sleep_backward: no saved forward for this ticket (the forward ran with gradients disabled, its '
-                           'activations were dropped -- only the two most recent forwards are kept --, or backward ran twice)')
+                           'activations were dropped from the registry of the compiled path -- W2S_SAVED_FORWARDS --, or a compiled backward ran twice)')
     eng = model._engine
     eng.ctx = saved
     with torch.cuda.device(model._flat.device):
@@ -89,13 +90,37 @@ def _setup(ctx, inputs, output):
     handle, training, save, names, signals, params = inputs
     ctx.handle = handle
     ctx.nsig = len(signals)
-    ctx.save_for_backward(output[1])
+    ctx.w2s_spec = None
+    saved = None
+    if type(output[1]) is torch.Tensor:
+        # Eager mode (a real tensor, not a tracing proxy): the autograd node owns the saved activations from here on, under autograd's own
+        # lifetime rules -- every tensor of the engine's context goes through save_for_backward, so it is released right after this node's
+        # backward unless the caller asked for retain_graph=True, freed with the graph if backward never runs, and there is no limit on
+        # the number of forwards in flight.  Traced graphs cannot hold Python objects; there the activations stay in the model's ticket
+        # registry (wav2sleep._SavedForwards).
+        saved = _model(handle)._saved_ctx.pop(int(output[1]), None)
+    if saved is None:
+        ctx.save_for_backward(output[1])
+        return
+    leaves, spec = pytree.tree_flatten(saved)
+    idx = [i for i, leaf in enumerate(leaves) if isinstance(leaf, torch.Tensor)]
+    ctx.save_for_backward(output[1], *[leaves[i] for i in idx])
+    for i in idx:
+        leaves[i] = None
+    ctx.w2s_spec = (spec, leaves, idx)
 
 
 def _backward(ctx, glogits, gticket):
-    (ticket,) = ctx.saved_tensors
+    ticket, *tensors = ctx.saved_tensors
+    model = _model(ctx.handle)
+    if ctx.w2s_spec is not None:
+        spec, leaves, idx = ctx.w2s_spec
+        leaves = list(leaves)
+        for i, t in zip(idx, tensors):
+            leaves[i] = t
+        model._saved_ctx[int(ticket)] = pytree.tree_unflatten(leaves, spec)   # handed to the operator for this call (popped there)
     gflat = torch.ops.w2s.wav2sleep_backward(ctx.handle, ticket, glogits)
-    grads = [gflat[o:o + n].view(shape) for (o, n, shape) in _model(ctx.handle)._layout]
+    grads = [gflat[o:o + n].view(shape) for (o, n, shape) in model._layout]
     return None, None, None, None, [None] * ctx.nsig, grads
 
 

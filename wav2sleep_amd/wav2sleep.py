@@ -64,14 +64,24 @@ def _standalone_engine(module: nn.Module, prefix: str, spec: EngineSpec) -> Engi
 
 
 class _SavedForwards(dict):
-    """Saved activations of forwards that are waiting for their backward, keyed by the logits' data pointer.  A forward whose graph is
-    dropped without a backward (evaluation with gradients enabled) would otherwise pin ~1.2 GB per recording: only the two most recent
-    forwards are kept."""
+    """Saved activations of forwards whose backward has not run yet, keyed by ticket -- the COMPILED path's registry only: in eager mode
+    the autograd node itself owns them from `setup_context` on (ops.py), so any number of forwards may precede a backward,
+    `retain_graph=True` works, and a dropped graph frees its ~1.2 GB per recording with the node.  Under `torch.compile` the traced graph
+    carries only the ticket, so the activations wait here; a forward whose graph is then dropped without a backward would pin them, hence a
+    cap (W2S_SAVED_FORWARDS, default 2 most recent) with a warning when an entry is evicted."""
+
+    def __init__(self, cap: int | None = None):
+        super().__init__()
+        import os
+        self.cap = max(1, int(os.environ.get('W2S_SAVED_FORWARDS', 2) if cap is None else cap))
 
     def __setitem__(self, key, value):
         super().__setitem__(key, value)
-        while len(self) > 2:
-            del self[next(iter(self))]
+        while len(self) > self.cap:
+            old = next(iter(self))
+            logger.warning('wav2sleep_amd: dropping the saved activations of forward #%d (more than %d compiled forwards are waiting for a '
+                           'backward; raise W2S_SAVED_FORWARDS if that is intended) -- its backward will raise', old, self.cap)
+            del self[old]
 
 
 class _HandWritten:
