@@ -144,3 +144,24 @@ def test_autograd_lifetimes_follow_the_graph():
     held = torch.cuda.memory_allocated() - base
     del out
     assert held > 20e6 and torch.cuda.memory_allocated() - base < 0.05 * held
+
+
+def test_out_of_range_label_poisons_the_loss_and_touches_nothing_else():
+    """torch raises "Target out of bounds" for a label >= num_classes; a launch that cannot raise must still not index with it: the loss
+    comes back NaN (loud), the confusion counts hold exactly the in-range labels, and the memory behind the 4 x 4 count matrix is untouched."""
+    from wav2sleep_amd import lib
+    rows, nc = 600, 4
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(rows, nc, generator=g).to(DEV)
+    y = torch.randint(-1, nc, (rows,), generator=g).float()
+    y[17], y[301], y[599] = 4.0, 1e9, float('nan')
+    buf = torch.zeros(nc * nc + 64, dtype=torch.int64, device=DEV)   # the count matrix with a guard zone behind it
+    part = torch.empty((rows + 255) // 256, 2, device=DEV)
+    out = torch.zeros(2, device=DEV)
+    gl = torch.empty(rows, nc, device=DEV)
+    lib.ce_fwd_bwd(logits, y.to(DEV), rows, nc, part, out, gl, buf[:nc * nc].view(nc, nc), 1.0)
+    torch.cuda.synchronize()
+    ok = (y >= 0) & (y < nc)
+    assert torch.isnan(out[0]) and int(buf[:nc * nc].sum()) == int(ok.sum()) and int(buf[nc * nc:].abs().sum()) == 0
+    bad = torch.tensor([17, 301, 599])
+    assert torch.isnan(gl[bad.to(DEV)]).all() and torch.isfinite(gl[ok.to(DEV)]).all()

@@ -1,8 +1,12 @@
-"""enc_first_bwd_kernel in isolation: same inputs, repeated launches, with and without another stream keeping the GPU busy."""
+"""enc_first_bwd_kernel in isolation: same inputs, repeated launches, with and without another stream keeping the GPU busy (a device copy,
+a second instance, the split-precision fused backward / wide conv kernels looping -- what shares the CUs with it inside a train step).
+W2S_LIB=build_alt/libw2s_f4.so (tools/altlib.sh f4 "-DW2S_FIRST_BWD_FLOAT4=1" enc_misc.hip) runs the round-1 float4 form of the kernel."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wav2sleep_amd import lib
+os.environ.setdefault('BF', '1')
+from tools import kbench
 dev = torch.device('cuda')
 torch.manual_seed(0)
 B, L = 2, 983040
@@ -16,11 +20,16 @@ def run():
     lib.enc_first_bwd(x, gn1, None, st1, bs1, gpre, slab, nslab, B, L, 16, w1=w1, causal=False)
     return slab
 ref = run(); torch.cuda.synchronize()
-for mode in ('alone', 'with a copy stream', 'two instances on two streams'):
+hogs = {'with bwd_fused 16ch on a second stream': kbench.CASES['b16']()[0], 'with bwd_fused 32ch on a second stream': kbench.CASES['b32']()[0],
+        'with conv_wide 64ch dgrad on a second stream': kbench.CASES['d64']()[0]}
+for mode in ('alone', 'with a copy stream', 'two instances on two streams', *hogs):
     side = torch.cuda.Stream()
     big_a = torch.randn(1 << 28, device=dev); big_b = torch.empty_like(big_a)
     bad = 0
-    for it in range(20):
+    for it in range(int(os.environ.get('RUNS', 100))):
+        if mode in hogs:
+            with torch.cuda.stream(side):
+                for _ in range(3): hogs[mode]()
         if mode == 'with a copy stream':
             with torch.cuda.stream(side):
                 for _ in range(3): big_b.copy_(big_a)
@@ -32,4 +41,4 @@ for mode in ('alone', 'with a copy stream', 'two instances on two streams'):
         bad += int(not torch.equal(s, ref))
         if mode == 'two instances on two streams':
             bad += int(not torch.equal(s2, ref))
-    print(f'{mode:32s}: {bad} launches differ from the first result; columns that differ in the last: {sorted(set((s != ref).nonzero()[:, 1].tolist()))[:20]}')
+    print(f'{mode:46s}: {bad} launches differ from the first result; columns that differ in the last: {sorted(set((s != ref).nonzero()[:, 1].tolist()))[:20]}')

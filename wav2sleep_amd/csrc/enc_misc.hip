@@ -206,6 +206,22 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
         yv.z = wr[2][0] * xm + wr[2][1] * xc + wr[2][2] * xp;
         yv.w = wr[3][0] * xm + wr[3][1] * xc + wr[3][2] * xp;
       }
+#ifdef W2S_FIRST_BWD_FLOAT4
+      // The round-1 form of this block, kept for tools/first_bwd_race.py / tools/pk_fma_opsel_repro.hip only (build with tools/altlib.sh):
+      // float4 expressions, which hipcc lowers to v_pk_mul_f32 / v_pk_fma_f32 -- among them two `v_pk_fma_f32 ... op_sel:[0,1,0]`
+      // (both lanes multiply by the HIGH half of src1: acc4/acc5 += (xc, xp) * gy.y and acc10/acc11 += (xc, xp) * gy.w) whose LOW-lane
+      // results (the odd channels' middle tap) were the sums that differed from launch to launch.
+      const f32x4 n4 = (yv - mean) * rstd;
+      f32x4 gy4 = rstd * (ld4o(gb, off) - q1 - n4 * q2);
+#if W2S_FIRST_BWD_FLOAT4 == 2   // same arithmetic, the accumulate block fenced off from the producer of gy (scheduling / forwarding hazard?)
+      __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7"); __builtin_amdgcn_sched_barrier(0);
+#endif
+      gy4 = gy4 * live;
+      acc[0] += gy4.x * xm; acc[1] += gy4.x * xc; acc[2] += gy4.x * xp;
+      acc[3] += gy4.y * xm; acc[4] += gy4.y * xc; acc[5] += gy4.y * xp;
+      acc[6] += gy4.z * xm; acc[7] += gy4.z * xc; acc[8] += gy4.z * xp;
+      acc[9] += gy4.w * xm; acc[10] += gy4.w * xc; acc[11] += gy4.w * xp;
+#else
       // scalar arithmetic on purpose: with float4 expressions hipcc built this block from v_pk_* instructions with op_sel operand
       // swizzles, and the sums of the odd channels' middle tap (gy.y * xc, gy.w * xc) came out different from launch to launch when
       // other kernels shared the CU -- a hazard of that instruction mix, not of the data (tools/determinism_probe3.py)
@@ -221,6 +237,7 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
         acc[3 * i + 1] = fmaf(gy, xc, acc[3 * i + 1]);
         acc[3 * i + 2] = fmaf(gy, xp, acc[3 * i + 2]);
       }
+#endif
       const float even = (t & 1) ? 0.f : live;
       const f32x4 gp = ld4o(pb, (unsigned)min(tc >> 1, (L >> 1) - 1) * 16 + og * 4);
       const float x0 = xs[p + 1 + shift] * even;  // x[t]: the 1x1/stride-2 residual conv has no padding in either mode

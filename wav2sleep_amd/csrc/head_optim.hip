@@ -44,33 +44,44 @@ extern "C" int w2s_head_fwd(const float* pre, int ld, const float* w, const floa
 }
 
 // CrossEntropyLoss(reduction=mean, ignore_index=-1) (training/main.yaml:41-46, trainer/main.py:162-163):
-// pass 1: per-block partial (sum nll, valid count) + confusion counts (rows = true, cols = argmax; int64 atomics
+// pass 1: per-block partial (sum nll, valid count) + confusion counts (rows = true, cols = argmax; integer atomics
 // are order-independent);  pass 2 (1 block): loss = sum/count, written to out[0], count to out[1];
 // pass 3: glogits = (softmax - onehot) / count for valid rows, 0 otherwise.
+// A label outside {-1, 0 .. nc-1} (torch raises "Target out of bounds" there) touches no memory it must not: it poisons the loss
+// (NaN in out[0], NaN gradient row), which is how a launch that cannot return an error code fails loudly.
 __global__ __launch_bounds__(256) void ce_partial_kernel(const float* __restrict__ logits, const float* __restrict__ labels, int rows, int nc,
                                                          float* __restrict__ part, long long* __restrict__ cmat) {
   __shared__ float red[2][256];
+  __shared__ unsigned int hist[W2S_MAXC * W2S_MAXC];   // confusion counts of this block: one global atomic per bin and block instead of
+  if (threadIdx.x < W2S_MAXC * W2S_MAXC) hist[threadIdx.x] = 0u;   // one per row (15 360 atomics on 16 addresses took 59 us)
+  __syncthreads();
   const int row = blockIdx.x * 256 + threadIdx.x;
   float nll = 0.f, cnt = 0.f;
   if (row < rows) {
-    const int y = (int)labels[row];
+    const float yf = labels[row];
+    const int y = (yf >= -1.f && yf < (float)nc) ? (int)yf : nc;   // nc = out of range (NaN included)
     float mx = -INFINITY;
     int am = 0;
     for (int c = 0; c < nc; ++c) {
       const float v = logits[(size_t)row * nc + c];
       if (v > mx) { mx = v; am = c; }
     }
-    if (y >= 0) {
+    if (y == nc) {
+      nll = NAN;
+      cnt = 1.f;
+    } else if (y >= 0) {
       float den = 0.f;
       for (int c = 0; c < nc; ++c) den += expf(logits[(size_t)row * nc + c] - mx);
       nll = logf(den) + mx - logits[(size_t)row * nc + y];
       cnt = 1.f;
-      if (cmat) atomicAdd(reinterpret_cast<unsigned long long*>(cmat + y * nc + am), 1ull);
+      if (cmat) atomicAdd(&hist[y * nc + am], 1u);
     }
   }
   red[0][threadIdx.x] = nll;
   red[1][threadIdx.x] = cnt;
   __syncthreads();
+  if (cmat && threadIdx.x < nc * nc && hist[threadIdx.x])
+    atomicAdd(reinterpret_cast<unsigned long long*>(cmat + threadIdx.x), (unsigned long long)hist[threadIdx.x]);
   for (int s = 128; s > 0; s >>= 1) {
     if (threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
     __syncthreads();
@@ -88,8 +99,9 @@ __global__ __launch_bounds__(256) void ce_grad_kernel(const float* __restrict__ 
                                                       float gscale) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
-  const int y = (int)labels[row];
-  const float inv = gscale / lossout[1];
+  const float yf = labels[row];
+  const int y = (yf >= -1.f && yf < (float)nc) ? (int)yf : nc;
+  const float inv = (y == nc) ? NAN : gscale / lossout[1];
   float mx = -INFINITY;
   for (int c = 0; c < nc; ++c) mx = fmaxf(mx, logits[(size_t)row * nc + c]);
   float den = 0.f;
