@@ -39,7 +39,8 @@ def pmc_key(name):
 def family_of(key):
     """Kernel family of a LaunchTimer key (DESIGN.md section 4 names)."""
     for prefix, fam in (('bwd_fused_bf_kernel', 'fused backward <=32ch (dgrad+wgrad)'), ('conv_fwd_bf_kernel', 'persistent forward <=32ch'),
-                        ('conv_wide_kernel', 'wide conv >=64ch (fwd + dgrad)'), ('wgrad', 'weight gradient >=64ch / k1 / dilated'),
+                        ('conv_wide_kernel', 'wide conv >=64ch (fwd + dgrad)'), ('bwd_wide_kernel', 'fused backward 64ch (dgrad+wgrad)'),
+                        ('wgrad', 'weight gradient >=64ch / k1 / dilated'),
                         ('conv_cl_kernel', 'generic conv (1x1, dilated, downsample, UP2 dgrad)')):
         if key.startswith(prefix):
             return fam

@@ -178,6 +178,46 @@ int w2s_bwd_fused_folds_residual(int cg, int ch);
 /* w1 != NULL (conv2 of block 0; cg = ch = 16, stride 1, split_precision, st_in given): xin is the RAW 1-channel signal [B][Lh] and
  * the conv's input (block 0's conv1 output) is recomputed from it with w1 = conv1 weight [16][3] (the W2S_PRO_FIRST flow). */
 
+/*
+ * fp16 gradient chain (round 3).  Autograd's inter-layer gradient tensors of the encoder (the `grad_output`s that
+ * aten::convolution_backward / native_batch_norm_backward / gelu_backward hand to one another, blocks.py:173-186) are fp32 in the
+ * reference.  The *_h entry points store the ones that live between two fused-backward launches as fp16 with one power-of-two scale per
+ * tensor (fp32 accumulation and arithmetic throughout).  Every such tensor has a header of two floats: hdr[0] = scale (stored = true *
+ * scale), hdr[1] = max |true value| (float bits, accumulated by the producer with an integer atomic maximum; ZERO it before the producer
+ * runs).  A producer chooses its output scale from the maxima of the tensors it reads.
+ *   gmode 0: g / gpre / gout fp32 (= w2s_bwd_fused);  1: g fp32 with header hdr_g = {1, max} (from w2s_gp_stats_h), gout fp16;
+ *   2: g, gpre (headers hdr_g, hdr_p) and gout fp16.  hdr_o: header of gout.  Split-precision kernels only; shapes (16,16), (32,32),
+ *   the residual-fold forms (16,16), (32,16) and the first-layer form; gmode 1 only for the stride-2 conv3.
+ */
+int w2s_bwd_fused_h(const void* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin, const float* st_in,
+                    const float* add_even, const float* wb, void* gout, float* part, float* slab, int nslab, int B, int Lg, int Lh, int cg,
+                    int ch, int stride, int pad, const void* gpre, const float* wd, float* slab_d, const float* w1, const float* y3p,
+                    const float* st3p, int gmode, const float* hdr_g, const float* hdr_p, float* hdr_o, void* stream);
+/* w2s_gp_stats on an fp16 gradient (g_half != 0, hdr_g its header), or on an fp32 one while publishing its header (hdr_amax != NULL:
+ * {1, max |g|}) -- the entry of the chain */
+int w2s_gp_stats_h(const void* g, int g_half, const float* hdr_g, float* hdr_amax, const float* y, const float* stats, float* part, int B, int L,
+                   int C, int tile, void* stream);
+/* w2s_enc_first_bwd with gn1 / gpre stored as fp16 (headers hdr_n / hdr_p) */
+int w2s_enc_first_bwd_h(const float* x, const void* gn1, const float* hdr_n, const float* y1, const float* stats1, const float* bstats1,
+                        const void* gpre, const float* hdr_p, float* slab, int nslab, int B, int L, int cout, const float* w1, int causal,
+                        void* stream);
+
+/*
+ * Fused backward of one k=3 / stride-1 / symmetric-padding encoder conv with cg = 64 gradient-side channels and ch = 64 or 32 input-side
+ * channels (round 3, csrc/bwd_wide.hip): data gradient + weight gradient + GELU' + backward statistics in one persistent role-split pass
+ * -- the >= 64-channel counterpart of w2s_bwd_fused (same formulas; gy = instance-norm backward of g with (st_k, bst_k); h = GELU(IN(xin))
+ * with st_in, or GELU(xin) when st_in == NULL).  w_hi / w_lo: the data-gradient operand planes of the conv weight (w2s_repack_batch
+ * bwd_hi / bwd_lo).  part: [B][ceil(L/tile)][groups][2][ch] partial sums of gout and gout*n_in (tile / groups from the two queries
+ * below), or NULL.  slab: nslab (= grid size, <= B*ceil(L/tile)) raw-fragment slabs of cg*3*ch floats -> w2s_wgrad_reduce(slab, nslab,
+ * grad, cg, ch, 3, 1, ...).  Returns 1 when no instance takes the launch (dry != 0: only that answer, nothing is launched).
+ * Replaces aten::convolution_backward + native_batch_norm_backward + gelu_backward of blocks.py:173-186 for those layers.
+ */
+int w2s_bwd_wide_tile(int cg, int ch);     /* positions per tile (0: no instance for this channel pair) */
+int w2s_bwd_wide_groups(int cg, int ch);   /* statistics-partial rows per tile */
+int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
+                 const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B, int L,
+                 int cg, int ch, int dry, void* stream);
+
 /* In-kernel finalisation (stat_out / stat_cnt arguments of the producers above): the workgroup that writes the LAST partial of a sample
  * reduces all of that sample's partials in a fixed order (fp64) -- same result as this call, one launch less per layer.  stat_cnt is a
  * caller-owned int32 [B] buffer, zero before first use; kernels re-arm it.  One buffer per stream.

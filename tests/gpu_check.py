@@ -522,6 +522,121 @@ def t_fused_residual_fold():
             report(f'fold {cg}->{ch} L{Lh} gout (with stats fold)', gout2, outs[1][0], tol=0)
             report(f'fold {cg}->{ch} L{Lh} conv3 statistics', pt.sum(1), pg.sum(1), tol=2e-4)
 
+def t_bwd_wide():
+    """One-pass backward of the 64-channel stride-1 convs (bwd_wide.hip) against the two kernels it replaces on the same tensors: the
+    conv_wide data gradient (instance-norm-backward prologue, GELU' epilogue, residual add, backward statistics) and the wgrad_wide weight
+    gradient.  Same split-precision products, so the bars are tight (the erf evaluation is shared here, separate there)."""
+    B = 3
+    for (cg, ch, L, hst, add_even) in [(64, 64, 1000, True, False), (64, 64, 777, False, True), (64, 32, 500, False, True), (64, 64, 64, True, False),
+                                       (64, 32, 130, False, True), (64, 64, 4098, True, False), (64, 32, 2050, True, False)]:
+        g = torch.randn(B, L, cg, device=dev) * 0.1; y = torch.randn(B, L, cg, device=dev) * 2 + 0.2; x = torch.randn(B, L, ch, device=dev) * 1.3 - 0.1
+        st = torch.stack([torch.randn(B, cg, device=dev) * 0.1, torch.rand(B, cg, device=dev) + 0.5], dim=-1).contiguous()
+        bst = (torch.randn(B, cg, 2, device=dev) * 0.01).contiguous()
+        sti = torch.stack([torch.randn(B, ch, device=dev) * 0.1, torch.rand(B, ch, device=dev) + 0.5], dim=-1).contiguous() if hst else None
+        ev = torch.randn(B, L // 2, ch, device=dev) * 0.05 if add_even else None
+        w = torch.randn(cg, ch, 3) / math.sqrt(3 * ch)
+        wb = w.permute(1, 2, 0).contiguous().to(dev); wh, wl = lib.frag_major_planes(wb.view(ch, 3 * cg))
+        # the separate kernels
+        gout0 = torch.zeros(B, L, ch, device=dev)
+        a = lib.conv_args(x=g, x2=y, w=wb, w_hi=wh, w_lo=wl, y=gout0, B=B, L_in=L, L_out=L, cin=cg, cout=ch, taps=3, stride=1, pad=1, flip=1, pro=lib.PRO_INBWD,
+                          pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=x, aux_stats=sti, add_even=ev)
+        t0 = lib.conv_tile_of(a); nt0 = (L + t0 - 1) // t0
+        part0 = torch.zeros(B, nt0, 2, ch, device=dev); lib.set_part(a, part0)
+        lib.conv_forward(a)
+        kw = dict(g=g, g2=y, g_stats=st, g_bstats=bst, x=x, x_stats=sti, B=B, L_in=L, L_out=L, cin=ch, cout=cg, taps=3, stride=1, pad=1, pro_g=lib.PRO_INBWD,
+                  pro_h=lib.PRO_IN_GELU if hst else lib.PRO_GELU, split_precision=True)
+        ns0 = min(5, (B * L + 255) // 256)
+        slab0 = torch.zeros(ns0 * cg * ch * 3, device=dev); lib.wgrad(slab=slab0, nslab=ns0, **kw)
+        gw0 = torch.zeros(cg, ch, 3, device=dev); lib.wgrad_reduce(slab0, ns0, gw0, cg, ch, 3, 1)
+        # the fused kernel, with few and with many workgroups
+        tile, groups = lib.bwd_wide_tile(cg, ch), lib.bwd_wide_groups(cg, ch)
+        nt = (L + tile - 1) // tile
+        RES.append((f'bwd_wide {cg}->{ch} L{L} is taken', lib.bwd_wide_takes(B, L, cg, ch) and tile == 64))
+        for ns in (min(5, B * nt), min(256, B * nt)):
+            gout = torch.full((B, L, ch), float('nan'), device=dev); part = torch.full((B, nt * groups, 2, ch), float('nan'), device=dev)
+            slab = torch.full((ns * cg * ch * 3,), float('nan'), device=dev)
+            lib.bwd_wide(g=g, y=y, st_k=st, bst_k=bst, xin=x, st_in=sti, add_even=ev, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab, nslab=ns, B=B, L=L,
+                         cg=cg, ch=ch)
+            gw = torch.zeros(cg, ch, 3, device=dev); lib.wgrad_reduce(slab, ns, gw, cg, ch, 3, 1)
+            tag = f'bwd_wide {cg}->{ch} L{L} hst{int(hst)} ev{int(add_even)} wgs{ns}'
+            report(tag + ' gout', gout, gout0, tol=2e-6)
+            report(tag + ' statistics sums', part.sum(1), part0.sum(1), tol=2e-5)
+            report(tag + ' wgrad', gw, gw0, tol=2e-5)
+
+def t_grad_fp16_chain():
+    """The fp16 gradient-chain forms of the fused backward kernels (gmode 1 / 2, include/w2s.h) against the fp32 kernels: a power-of-two
+    scale and fp32 arithmetic make the relation EXACT -- fed with the dequantised fp16 gradient the fp32 kernel must give bit-identical
+    statistics partials and weight-gradient slabs, and an output whose fp16 rounding (x scale) is the fp16 kernel's output bit for bit;
+    the output header holds the scale derived from the input maxima and the output's own maximum."""
+    import math
+
+    def quant(t, ref=None):
+        a = float(t.abs().max()) if ref is None else ref
+        s = 2.0 ** (9 - math.frexp(a)[1])
+        h = (t * s).half()
+        return h, h.float() / s, torch.tensor([s, float((h.float() / s).abs().max())], device=dev)
+
+    cases = [(16, 16, 1, 0, 0, 2), (16, 16, 2, 0, 0, 2), (32, 32, 1, 0, 0, 2), (32, 32, 2, 0, 0, 2), (32, 32, 2, 0, 0, 1), (16, 16, 2, 0, 0, 1),
+             (16, 16, 1, 1, 0, 2), (32, 16, 1, 1, 0, 2), (16, 16, 1, 0, 1, 2)]
+    for cg, ch, stride, rd, first, gmode in cases:
+        for Lh in (1000, 4098):
+            B, Lg = 3, Lh // stride
+            g = torch.randn(B, Lg, cg, device=dev) * 3e-4; y = torch.randn(B, Lg, cg, device=dev)
+            xin = torch.randn(B, Lh, device=dev) if first else torch.randn(B, Lh, ch, device=dev)
+            st = torch.rand(B, cg, 2, device=dev) + 0.5; bst = torch.rand(B, cg, 2, device=dev) * 1e-6; sti = torch.rand(B, ch, 2, device=dev) + 0.5
+            wb = torch.randn(ch, 3, cg, device=dev) / 7; wd = torch.randn(ch, cg, device=dev) / 5; w1 = torch.randn(16, 1, 3, device=dev) / 2
+            gpre = torch.randn(B, Lh // 2, cg, device=dev) * 1e-3 if rd else None
+            add_even = torch.randn(B, Lh // 2, ch, device=dev) * 1e-3 if (not rd and stride == 1 and not first) else None
+            if gmode == 2:
+                g16, g32, hg = quant(g)
+            else:
+                g16, g32, hg = None, g, torch.tensor([1.0, float(g.abs().max())], device=dev)
+            p16 = p32 = hp = None
+            if rd:
+                p16, p32, hp = quant(gpre)
+            tile = lib.bwd_fused_tile(cg, ch, stride, bool(rd)); nt = (Lh + tile - 1) // tile; ns = min(B * nt, 5)
+            pro = lib.PRO_INBWD if stride == 1 else lib.PRO_INBWD_GP
+            res = []
+            for mode in (0, gmode):
+                gout = torch.zeros(B, Lh, ch, device=dev, dtype=torch.float16 if mode else torch.float32)
+                part = torch.zeros(B, nt, 2, ch, device=dev); slab = torch.zeros(ns * cg * ch * 3, device=dev)
+                slab_d = torch.zeros(ns * cg * ch, device=dev) if rd else None
+                ho = torch.zeros(2, device=dev)
+                lib.bwd_fused(g=(g16 if mode == 2 else g32), y=y, st_k=st, bst_k=bst, pro=pro, xin=xin, st_in=None if rd else sti, add_even=add_even, wb=wb,
+                              gout=gout, part=part, slab=slab, nslab=ns, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, split_precision=True,
+                              gpre=(p16 if mode == 2 else p32) if rd else None, wd=wd if rd else None, slab_d=slab_d, w1=w1 if first else None,
+                              gmode=mode, hdr_g=hg if mode else None, hdr_p=hp if (mode and rd) else None, hdr_o=ho if mode else None)
+                res.append((gout, part, slab, slab_d, ho))
+            tag = f'grad fp16 {cg}->{ch} s{stride} rd{rd} first{first} gmode{gmode} L{Lh}'
+            (o32, pt32, sl32, sd32, _), (o16, pt16, sl16, sd16, ho) = res
+            ref = max(float(hg[1]), float(hp[1]) if rd else 0.0)
+            s_out = 2.0 ** (9 - math.frexp(ref)[1])
+            report(tag + ' partials identical', pt16, pt32, tol=0)
+            report(tag + ' weight-gradient slabs identical', sl16, sl32, tol=0)
+            if rd:
+                report(tag + ' downsample slabs identical', sd16, sd32, tol=0)
+            report(tag + ' gout = fp16(scale * fp32 gout)', o16.float(), (o32 * s_out).half().float(), tol=0)
+            report(tag + ' header {scale, max}', ho, torch.tensor([s_out, float(o32.abs().max())]), tol=0)
+    # the two small readers of chain tensors: the conv3 pre-pass (also the chain's entry: publishes {1, max}) and the first-layer weight gradients
+    B, L, c = 2, 3000, 32
+    g = torch.randn(B, L, c, device=dev) * 2e-5; y = torch.randn(B, L, c, device=dev); st = torch.rand(B, c, 2, device=dev) + 0.5
+    g16, g32, hg = quant(g)
+    nt = (L + 511) // 512
+    pa = torch.zeros(B, nt, 2, c, device=dev); pb = torch.zeros_like(pa); pc = torch.zeros_like(pa); hm = torch.zeros(2, device=dev)
+    lib.gp_stats(g32, y, st, pa, B, L, c, 512)
+    lib.gp_stats(g16, y, st, pb, B, L, c, 512, hdr_g=hg)
+    lib.gp_stats(g32, y, st, pc, B, L, c, 512, hdr_amax=hm)
+    report('grad fp16 gp_stats (fp16 in) identical', pb, pa, tol=0)
+    report('grad fp16 gp_stats (entry) identical + header', torch.cat([pc.flatten(), hm]), torch.cat([pa.flatten(), torch.tensor([1.0, float(g32.abs().max())], device=dev)]), tol=0)
+    B, L, c = 2, 1500, 16
+    x = torch.randn(B, L, device=dev); w1 = torch.randn(16, 1, 3, device=dev) / 2
+    st1 = torch.rand(B, c, 2, device=dev) + 0.5; bs1 = torch.rand(B, c, 2, device=dev) * 1e-6
+    n16, n32, hn = quant(torch.randn(B, L, c, device=dev) * 1e-4); q16, q32, hq = quant(torch.randn(B, L // 2, c, device=dev) * 1e-3)
+    sa = torch.zeros(8, 64, device=dev); sb = torch.zeros(8, 64, device=dev)
+    lib.enc_first_bwd(x, n32, None, st1, bs1, q32, sa, 8, B, L, c, w1=w1)
+    lib.enc_first_bwd(x, n16, None, st1, bs1, q16, sb, 8, B, L, c, w1=w1, hdr_n=hn, hdr_p=hq)
+    report('grad fp16 first-layer weight gradients identical', sb, sa, tol=0)
+
 def t_first_layer_recompute():
     """W2S_PRO_FIRST flow: the consumers of block 0's conv1 output recompute it from the raw signal -- against the same
     kernels fed with the stored tensor (bit-level arithmetic differs only in the 3-FMA conv itself)."""
@@ -701,7 +816,7 @@ def t_inkernel_finalize():
     report('in-kernel finalize gp_stats', so, ref, tol=1e-6)
 
 
-STAGES = dict(wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

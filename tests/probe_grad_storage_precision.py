@@ -7,7 +7,9 @@ never see a gradient tensor, so the forward parity bar cannot move.
     python tests/probe_grad_storage_precision.py [S] [B] [eog]
 
 Modes: bf16 (round to nearest even); fp16 with ONE power-of-two scale per tensor chosen from the tensor's own max (the best a per-tensor
-scale can do); fp16 with the scale of the PREVIOUS tensor in the chain (what a producer kernel can know when it writes: delayed scaling).
+scale can do); fp16 with the scale derived from the PREVIOUS tensor of the chain, placed as the kernels place it (what a producer kernel
+can know when it writes; w2s_gscale_for in csrc/w2s_common.h); `chain32`: that rule on exactly the tensors the shipped kernels store as
+fp16 -- gn1 / gn2 of the <= 32-channel blocks 0..3 and the gpre tensors between them (W2S_GRAD_FP16, engine._encoder_backward).
 Reported: worst / median relative L2 error over all parameter-gradient tensors, and the dynamic range the chain tensors need."""
 import math
 import os
@@ -32,17 +34,19 @@ def _round(g, tag):
     if k == 'bf16':
         return g.bfloat16().float()
     if k == 'fp16_own':
-        ref = amax
-    else:   # 'fp16_prev': scale from the previous chain tensor's max (first one: its own)
+        s = 2.0 ** (14 - math.ceil(math.log2(amax)))   # max lands in [2^13, 2^14]: 4x headroom below fp16's 65504
+    else:   # 'fp16_prev' / 'chain32': scale from the previous chain tensor's max (first one: its own), the kernels' placement
         ref = MODE['prev_amax'] or amax
         MODE['prev_amax'] = amax
-    s = 2.0 ** (14 - math.ceil(math.log2(ref)))   # max lands in [2^13, 2^14]: 4x headroom below fp16's 65504
-    return (g * s).clamp(-65504, 65504).half().float() / s
+        s = 2.0 ** (9 - math.frexp(ref)[1])
+    return (g * s).half().float() / s   # no clamp: an overflow shows as inf, as in the kernels
 
 
 def conv_layer_in(x, w, stride, eps, causal=False, hook=True):
     y = O.causal_conv1d(x, w, stride) if causal else F.conv1d(x, w, None, stride=stride, padding=1)
     xhat = O.instance_norm(y, eps)
+    if MODE['kind'] == 'chain32' and w.size(0) > 32:
+        hook = False
     if hook and xhat.requires_grad:
         xhat.register_hook(lambda g: _round(g, 'gn'))
     return O.gelu(xhat)
@@ -54,7 +58,8 @@ def conv_block(sd, p, x, eps, taps=None, causal=False):
     h2 = conv_layer_in(h1, sd[p + 'conv2.conv.weight'], 1, eps, causal)
     h3 = conv_layer_in(h2, sd[p + 'conv3.conv.weight'], 2, eps, causal, hook=False)   # conv3's GELU' is applied on load from gpre
     pre = h3 + F.conv1d(x, sd[p + 'downsample.weight'], None, stride=2)
-    if pre.requires_grad:
+    blk = int(p.split('.')[-2])
+    if pre.requires_grad and not (MODE['kind'] == 'chain32' and blk > 2):   # chain32: gpre_0 .. gpre_2 (gpre_3 comes from the 64-channel kernels, fp32)
         pre.register_hook(lambda g: _round(g, 'gpre'))
     return O.gelu(pre)
 
@@ -77,7 +82,7 @@ if __name__ == '__main__':
         MODE['kind'] = None
         _, _, ref = O.loss_and_grads(sd, cfg, x, y)
         print(f'{name}  ({"EOG pair" if eog else "4 modalities"}, B={B}, S={S})')
-        for kind in ('bf16', 'fp16_own', 'fp16_prev'):
+        for kind in ('bf16', 'fp16_own', 'fp16_prev', 'chain32'):
             MODE.update(kind=kind, prev_amax=None, ranges=[])
             _, _, got = O.loss_and_grads(sd, cfg, x, y)
             rels = sorted(((float((got[k] - ref[k]).norm() / (ref[k].norm() + 1e-30)), k) for k in ref if float(ref[k].norm()) > 0), reverse=True)

@@ -165,3 +165,38 @@ def test_out_of_range_label_poisons_the_loss_and_touches_nothing_else():
     assert torch.isnan(out[0]) and int(buf[:nc * nc].sum()) == int(ok.sum()) and int(buf[nc * nc:].abs().sum()) == 0
     bad = torch.tensor([17, 301, 599])
     assert torch.isnan(gl[bad.to(DEV)]).all() and torch.isfinite(gl[ok.to(DEV)]).all()
+
+
+def test_fp16_gradient_chain_keeps_the_gradient_bar():
+    """W2S_GRAD_FP16 (off by default): gn1 / gn2 / gpre of the <= 32-channel blocks stored as fp16 with per-tensor
+    power-of-two scales.  Same bar as the fp32 chain (2e-3 relative L2 per tensor); logits cannot move (no gradient tensor feeds them);
+    two runs are bit-identical (integer atomic maxima); and the chain really is in use (fp16 launches counted)."""
+    from wav2sleep_amd import lib
+    sm = {'ABD': 'ABD', 'ECG': 'ECG', 'EOG-L': 'EOG-L'}
+    cfg = O.ModelConfig(signal_map=sm, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=77)
+    x, y = O.make_inputs(cfg, 2, 6, seed=770, missing={'ABD': [1]})
+    want_loss, want_logits, want = O.loss_and_grads(sd, cfg, x, y)
+    calls = []
+    real = lib.bwd_fused
+    lib.bwd_fused = lambda **kw: (calls.append(kw.get('gmode', 0)), real(**kw))[1]
+    try:
+        runs = []
+        for fp16 in (False, True, True):
+            model = build(sm, 4)
+            model.load_state_dict(sd)
+            model.to(DEV).train()
+            model._ensure_flat()
+            model._engine.grad_fp16 = fp16
+            calls.clear()
+            logits = model(to_dev(x))
+            F.cross_entropy(logits.reshape(-1, 4), y.to(DEV).reshape(-1).long(), ignore_index=-1).backward()
+            runs.append((logits.detach().clone(), model._flat_grad.clone(), list(calls)))
+            for name, p in model.named_parameters():
+                rel = float((p.grad.cpu() - want[name]).norm() / want[name].norm())
+                assert rel <= 2e-3, (fp16, name, rel)
+    finally:
+        lib.bwd_fused = real
+    assert set(runs[0][2]) == {0} and {1, 2} <= set(runs[1][2]) and 0 not in runs[1][2]   # every fused-backward launch of the chain run is an fp16 form
+    assert torch.equal(runs[0][0], runs[1][0])                                              # logits: untouched
+    assert torch.equal(runs[1][1], runs[2][1]) and not torch.equal(runs[0][1], runs[1][1])  # reproducible; and it does round

@@ -22,7 +22,10 @@ def run():
 ref = run(); torch.cuda.synchronize()
 hogs = {'with bwd_fused 16ch on a second stream': kbench.CASES['b16']()[0], 'with bwd_fused 32ch on a second stream': kbench.CASES['b32']()[0],
         'with conv_wide 64ch dgrad on a second stream': kbench.CASES['d64']()[0]}
+only = os.environ.get('MODES')   # comma-separated substrings: run only the matching modes
 for mode in ('alone', 'with a copy stream', 'two instances on two streams', *hogs):
+    if only and not any(o in mode for o in only.split(',')):
+        continue
     side = torch.cuda.Stream()
     big_a = torch.randn(1 << 28, device=dev); big_b = torch.empty_like(big_a)
     bad = 0

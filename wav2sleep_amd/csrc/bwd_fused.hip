@@ -14,6 +14,7 @@
 //   dgrad:  d[t'][c] = sum_{j,o} W[o][c][j] * gy[(t'+1-j)/stride][o]            (wb = [c][j][o])
 //   out  :  gout[t'][c] = (d [+ add_even[t'/2] if t' even]) * GELU'(n_in[t'][c]);  partial sums of gout, gout*n_in
 //   wgrad:  dW[o][j][c] = sum_t gy[t][o] * h[t*stride + j - 1][c]
+#include <type_traits>
 #include "conv_cl.inl"
 
 struct BwdP {
@@ -30,6 +31,9 @@ struct BwdP {
   // output [B][Lh][HC] (same positions as gout), st3p = its (mean, rstd); part then receives sums of gn = gout*GELU'(n3) and gn*n3
   const float* y3p; const float* st3p;
   StatFin fin;   // in-kernel finalisation of `part` into the backward statistics (fin.out == NULL: partials only)
+  // fp16 gradient chain (split-precision kernels; w2s_common.h): gmode 0 = g / gpre / gout are fp32; 1 = g fp32 (header hdr_g: scale 1,
+  // max from w2s_gp_stats), gout fp16; 2 = g, gpre and gout fp16.  hdr_o[1] must be zero at launch.
+  int gmode; const float* hdr_g; const float* hdr_p; float* hdr_o;
 };
 
 // LDS row strides: 16-channel rows stay unpadded (64-B rows: the three windows + weights of the 16x16 kernel then fit
@@ -330,9 +334,19 @@ __host__ __device__ constexpr int bf_rs(int c) { return c == 16 ? 16 : c + 8; } 
 // nothing).  The residual-fold kernel of the 16-channel blocks is the exception: at 256-position tiles it needs 244 registers (one
 // workgroup per CU); with 128-position tiles it fits three per CU and runs 21 % faster (1.39 -> 1.10 ms per step).
 __host__ __device__ constexpr int bfk_occ(int cg, int ch, int rd) { return (cg == 1 && ch == 1 && rd) ? 3 : 1; }
-template <int CG, int CH, int MT, int UP2, int RD, int FIRST>
+template <int CG, int CH, int MT, int UP2, int RD, int FIRST, int GM = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bfk_occ(CG, CH, RD))))
 void bwd_fused_bf_kernel(BwdP P) {
+  static_assert(GM != 1 || !RD, "a residual-fold kernel reads the chain from both sides: all fp32 or all fp16");
+  constexpr bool GH = (GM == 2), OH = (GM != 0);   // g (and gpre) / gout stored as fp16
+  using GRaw = std::conditional_t<GH, h16x4, f32x4>;
+  float inv_g = 1.f, inv_p = 1.f, s_out = 1.f, amax = 0.f;
+  if (OH) {   // uniform: the headers are final (their producers have completed)
+    float ref = P.hdr_g[1];
+    if (GH) inv_g = 1.f / P.hdr_g[0];
+    if (RD) { ref = fmaxf(ref, P.hdr_p[1]); inv_p = 1.f / P.hdr_p[0]; }
+    s_out = w2s_gscale_for(ref);
+  }
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 64 * MT;
   constexpr int GC = CG * 16, HC = CH * 16;
@@ -398,7 +412,8 @@ void bwd_fused_bf_kernel(BwdP P) {
   const int gc4 = tid % c4g, grow0 = tid / c4g, gch = gc4 * 4;
   const int hc4 = tid % c4h, hrow0 = tid / c4h, hch = hc4 * 4;
   constexpr int NP = RD ? (TM / 2 + rstep_g - 1) / rstep_g : 1;
-  f32x4 rg[NG], ry[NG], rh[FIRST ? 1 : NH], rp[NP], rq[RD ? MT * CH : 1];  // rq: previous block's y3 in the D-fragment layout
+  GRaw rg[NG], rp[NP];
+  f32x4 ry[NG], rh[FIRST ? 1 : NH], rq[RD ? MT * CH : 1];  // rq: previous block's y3 in the D-fragment layout
   float rxs[2], w1r[4][3];
   if (FIRST) {
 #pragma unroll
@@ -410,7 +425,7 @@ void bwd_fused_bf_kernel(BwdP P) {
     const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
     // wave-uniform 64-bit base per sample + 32-bit per-lane offsets (a sample's tensor is < 4 GB): scalar-base addressing,
     // no 64-bit VALU address arithmetic per load
-    const float* gb = P.g + (size_t)b * Lg * GC;
+    const char* gb = reinterpret_cast<const char*>(P.g) + (size_t)b * Lg * GC * (GH ? 2 : 4);
     const float* yb = P.y + (size_t)b * Lg * GC;
     const int rb = UP2 ? t0 / 2 : t0 - 2 + PL;   // gy window: the data gradient reads gy[t' + pad - j] at window row (t' - t0) + 2 - j
 #pragma unroll
@@ -418,7 +433,8 @@ void bwd_fused_bf_kernel(BwdP P) {
       const int row = grow0 + k * rstep_g, gr = rb + row;
       const bool ok = row < NRg && gr >= 0 && gr < Lg;
       const unsigned off = (unsigned)gr * GC + gch;
-      rg[k] = ok ? ld4o(gb, off) : (f32x4){0, 0, 0, 0};
+      if constexpr (GH) rg[k] = ok ? ld4h(gb, off) : (h16x4){0, 0, 0, 0};
+      else rg[k] = ok ? ld4o(reinterpret_cast<const float*>(gb), off) : (f32x4){0, 0, 0, 0};
       ry[k] = ok ? ld4o(yb, off) : (f32x4){0, 0, 0, 0};
     }
     if (FIRST) {  // TM + 4 signal samples t0-2pad .. : one per thread (+4), exchanged through LDS at commit time (conv1 pads like this conv)
@@ -449,11 +465,13 @@ void bwd_fused_bf_kernel(BwdP P) {
         }
     }
     if (RD) {
-      const float* pb = P.gpre + (size_t)b * (Lh >> 1) * GC;
+      const char* pb = reinterpret_cast<const char*>(P.gpre) + (size_t)b * (Lh >> 1) * GC * (GH ? 2 : 4);
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const int row = grow0 + k * rstep_g, gr = t0 / 2 + row;
-        rp[k] = (row < TM / 2 && gr < (Lh >> 1)) ? ld4o(pb, (unsigned)gr * GC + gch) : (f32x4){0, 0, 0, 0};
+        const bool ok = row < TM / 2 && gr < (Lh >> 1);
+        if constexpr (GH) rp[k] = ok ? ld4h(pb, (unsigned)gr * GC + gch) : (h16x4){0, 0, 0, 0};
+        else rp[k] = ok ? ld4o(reinterpret_cast<const float*>(pb), (unsigned)gr * GC + gch) : (f32x4){0, 0, 0, 0};
       }
     }
   };
@@ -474,8 +492,10 @@ void bwd_fused_bf_kernel(BwdP P) {
       const int row = grow0 + k * rstep_g, gr = rb + row;
       if (row < NRg) {
         const bool ok = gr >= 0 && gr < Lg;
+        f32x4 gv;
+        if constexpr (GH) gv = h2f4(rg[k]) * inv_g; else gv = rg[k];
         split_store4(gyH, gyLo, row * RSg + gch,
-                     ok ? pro_apply(UP2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD, rg[k], ry[k], pm, pr, ps1, ps2) : (f32x4){0, 0, 0, 0});
+                     ok ? pro_apply(UP2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD, gv, ry[k], pm, pr, ps1, ps2) : (f32x4){0, 0, 0, 0});
       }
     }
     f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
@@ -520,7 +540,9 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const int row = grow0 + k * rstep_g;
-        if (row < TM / 2) split_store4(pH, pLo, row * RSg + gch, rp[k]);
+        f32x4 pv;
+        if constexpr (GH) pv = h2f4(rp[k]) * inv_p; else pv = rp[k];
+        if (row < TM / 2) split_store4(pH, pLo, row * RSg + gch, pv);
       }
     }
   };
@@ -672,7 +694,12 @@ void bwd_fused_bf_kernel(BwdP P) {
           sA[nt] += v;
           sB[nt] += v * n;
         }
-        st4o(P.gout + (size_t)b * Lh * HC, (unsigned)pos * HC + ch, v);
+        if constexpr (OH) {
+          amax = amax4(amax, v);
+          st4h(reinterpret_cast<char*>(P.gout) + (size_t)b * Lh * HC * 2, (unsigned)pos * HC + ch, f2h4(v * s_out));
+        } else {
+          st4o(P.gout + (size_t)b * Lh * HC, (unsigned)pos * HC + ch, v);
+        }
       }
     }
     if (P.part) {
@@ -735,6 +762,7 @@ void bwd_fused_bf_kernel(BwdP P) {
     }
   }
 
+  if (OH) w2s_amax_commit(P.hdr_o, amax, s_out);
   // ---- one slab per workgroup, raw-fragment layout [tile(i,j,c)][lane][4]; waves sharing a tile pair sum in wave order
   float* out = P.slab + (size_t)blockIdx.x * (CG * 3 * CH) * 256;
   float* outd = RD ? P.slab_d + (size_t)blockIdx.x * (CG * CH) * 256 : nullptr;
@@ -769,7 +797,7 @@ void bwd_fused_bf_kernel(BwdP P) {
   }
 }
 
-template <int CG, int CH, int MT, int UP2, int RD, int FIRST = 0>
+template <int CG, int CH, int MT, int UP2, int RD, int FIRST = 0, int GM = 0>
 static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   constexpr int TM = 64 * MT, GC = CG * 16, HC = CH * 16, KD = (GC == 32) ? (RD ? 128 : 96) : 64;
   BwdP P = P0;
@@ -779,7 +807,7 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
                (size_t)2 * 2 * ((NRg + NRp) * bf_rs(GC) + NRh * bf_rs(HC) + HC * (KD + 8));
   if (FIRST) lds += (size_t)(TM + 4) * 4;
   if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4]
-  auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST>;
+  auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST, GM>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -805,29 +833,45 @@ extern "C" int w2s_bwd_fused_folds_residual(int cg, int ch) { return (cg == 16 &
 extern "C" int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd) { return 64 * bf_mt(cg, ch, stride == 2, rd); }
 
 // cg = channels of the gradient side (the forward conv's cout), ch = channels of the input side (its cin).
-extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
-                             const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
-                             int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const float* gpre, const float* wd,
-                             float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt, void* stream) {
+static int bwd_fused_impl(const void* gv, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
+                          const float* st_in, const float* add_even, const float* wb, void* goutv, float* part, float* slab, int nslab,
+                          int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const void* gprev, const float* wd,
+                          float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt,
+                          int gmode, const float* hdr_g, const float* hdr_p, float* hdr_o, void* stream) {
+  const float* g = static_cast<const float*>(gv);
+  const float* gpre = static_cast<const float*>(gprev);
+  float* gout = static_cast<float*>(goutv);
   if (!g || !y || !st_k || !bst_k || !xin || !wb || !gout || !slab || nslab <= 0) return W2S_EINVAL;
   if ((size_t)Lh * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;  // 32-bit lane offsets inside one sample
   if (pro != W2S_PRO_INBWD && pro != W2S_PRO_INBWD_GP) return W2S_EINVAL;
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
   if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in
   if (pad != 1 && !(pad == 2 && split_precision)) return W2S_EINVAL;                // causal padding: split-precision kernels only
-  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, pad, gpre, wd, slab_d, w1, y3p, st3p, StatFin{stat_out, stat_cnt, 1.0 / (double)Lh, 0.f, 1}};
+  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, pad, gpre, wd, slab_d, w1, y3p, st3p, StatFin{stat_out, stat_cnt, 1.0 / (double)Lh, 0.f, 1},
+         gmode, hdr_g, hdr_p, hdr_o};
   if (stat_out && (!stat_cnt || !part)) return W2S_EINVAL;
   if (y3p && (!gpre || !st3p || !part)) return W2S_EINVAL;
   const bool rd = gpre != nullptr;
   if (rd && (!wd || !slab_d || add_even || stride != 1 || !split_precision || !w2s_bwd_fused_folds_residual(cg, ch) || (Lh & 1))) return W2S_EINVAL;
+  if (gmode < 0 || gmode > 2 || (gmode && (!split_precision || !hdr_g || !hdr_o || (rd && (gmode != 2 || !hdr_p))))) return W2S_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int up2 = stride == 2;
   if (w1) {  // xin is the raw signal: conv2 of block 0
-    if (rd || !st_in || stride != 1 || !split_precision || cg != 16 || ch != 16) return W2S_EINVAL;
-    return launch_bwd_bf<1, 1, bf_mt(16, 16, 0, 0), 0, 0, 1>(P, nslab, s);
+    if (rd || !st_in || stride != 1 || !split_precision || cg != 16 || ch != 16 || gmode == 1) return W2S_EINVAL;
+    return gmode ? launch_bwd_bf<1, 1, bf_mt(16, 16, 0, 0), 0, 0, 1, 2>(P, nslab, s) : launch_bwd_bf<1, 1, bf_mt(16, 16, 0, 0), 0, 0, 1>(P, nslab, s);
   }
-  if (rd && cg == 16 && ch == 16) return launch_bwd_bf<1, 1, bf_mt(16, 16, 0, 1), 0, 1>(P, nslab, s);
-  if (rd && cg == 32 && ch == 16) return launch_bwd_bf<2, 1, bf_mt(32, 16, 0, 1), 0, 1>(P, nslab, s);
+  if (rd && cg == 16 && ch == 16)
+    return gmode ? launch_bwd_bf<1, 1, bf_mt(16, 16, 0, 1), 0, 1, 0, 2>(P, nslab, s) : launch_bwd_bf<1, 1, bf_mt(16, 16, 0, 1), 0, 1>(P, nslab, s);
+  if (rd && cg == 32 && ch == 16)
+    return gmode ? launch_bwd_bf<2, 1, bf_mt(32, 16, 0, 1), 0, 1, 0, 2>(P, nslab, s) : launch_bwd_bf<2, 1, bf_mt(32, 16, 0, 1), 0, 1>(P, nslab, s);
+  // fp16 chain: the shapes the engine's chain reaches -- (16,16) and (32,32), both strides, fp16 in; (32,32) / (16,16) stride 2 also with
+  // an fp32 gradient in (the chain's entry: conv3 of the topmost <= 32-channel block)
+#define W2S_BFH(CG_, CH_, UP_, GM_) \
+  if (gmode == GM_ && cg == 16 * CG_ && ch == 16 * CH_ && up2 == UP_) \
+    return launch_bwd_bf<CG_, CH_, bf_mt(16 * CG_, 16 * CH_, UP_, 0), UP_, 0, 0, GM_>(P, nslab, s);
+  W2S_BFH(1, 1, 0, 2) W2S_BFH(1, 1, 1, 2) W2S_BFH(2, 2, 0, 2) W2S_BFH(2, 2, 1, 2) W2S_BFH(2, 2, 1, 1) W2S_BFH(1, 1, 1, 1)
+#undef W2S_BFH
+  if (gmode) return W2S_EINVAL;
 #define W2S_BFS(CG_, CH_) \
   if (split_precision && cg == 16 * CG_ && ch == 16 * CH_) \
     return up2 ? launch_bwd_bf<CG_, CH_, bf_mt(16 * CG_, 16 * CH_, 1, 0), 1, 0>(P, nslab, s) : launch_bwd_bf<CG_, CH_, bf_mt(16 * CG_, 16 * CH_, 0, 0), 0, 0>(P, nslab, s);
@@ -839,4 +883,21 @@ extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, 
   W2S_BF(1, 1) W2S_BF(2, 1) W2S_BF(2, 2)
 #undef W2S_BF
   return W2S_EINVAL;
+}
+
+extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
+                             const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
+                             int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const float* gpre, const float* wd,
+                             float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt, void* stream) {
+  return bwd_fused_impl(g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, pad, split_precision, gpre,
+                        wd, slab_d, w1, y3p, st3p, stat_out, stat_cnt, 0, nullptr, nullptr, nullptr, stream);
+}
+// the same launch with the gradient chain stored as fp16 (include/w2s.h, "fp16 gradient chain")
+extern "C" int w2s_bwd_fused_h(const void* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
+                               const float* st_in, const float* add_even, const float* wb, void* gout, float* part, float* slab, int nslab,
+                               int B, int Lg, int Lh, int cg, int ch, int stride, int pad, const void* gpre, const float* wd, float* slab_d,
+                               const float* w1, const float* y3p, const float* st3p, int gmode, const float* hdr_g, const float* hdr_p,
+                               float* hdr_o, void* stream) {
+  return bwd_fused_impl(g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, pad, 1, gpre, wd, slab_d, w1,
+                        y3p, st3p, nullptr, nullptr, gmode, hdr_g, hdr_p, hdr_o, stream);
 }

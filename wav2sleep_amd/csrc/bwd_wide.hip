@@ -1,0 +1,337 @@
+// Backward of one k=3 / stride-1 encoder convolution with 64 gradient-side channels in ONE pass: data gradient + weight gradient +
+// GELU' + backward statistics from the same staged tiles -- the >= 64-channel counterpart of bwd_fused_bf_kernel, in the persistent
+// role-split form of conv_wide_kernel / wgrad_wide_kernel (round 3).
+//
+//   gy     = rstd_k * (g - s1 - n_k s2),  n_k = (y_k - mean_k) rstd_k                      (W2S_PRO_INBWD of the incoming gradient g)
+//   n_in   = (xin - mean_in) rstd_in  (st_in given: conv2, xin = y_{k-1})   or   xin   (conv1, xin = the previous block's stored pre-activation)
+//   h      = GELU(n_in),  gp = GELU'(n_in)                                                 (ONE erf evaluation for both)
+//   dgrad :  gout[t][c] = (sum_{j,o} W[o][c][j] gy[t+1-j][o]  [+ add_even[t/2][c] at even t]) * gp[t][c];  partial sums of gout, gout*n_in
+//   wgrad :  dW[o][j][c] = sum_t gy[t][o] h[t+j-1][c]
+//
+// Before: conv_wide (dgrad) and wgrad_wide each streamed g, y_k and xin, each ran the instance-norm backward on g, one evaluated GELU'
+// and the other GELU of the same n_in (two erf's) -- 7 tensor passes and twice the producer arithmetic for 4 passes' worth of work
+// (profiles/r02: traffic 1.10-1.20 x algorithmic, and the producers' VALU, not HBM, set the pace of both).  Here:
+//   * 4 PRODUCER waves stream the raw rows of g, y_k and xin of the next PD tiles into registers (unconditional clamped loads), apply the
+//     on-load transforms with the per-sample statistics from an LDS table, and write tile i + 1 into the other LDS buffer: gy as bf16
+//     (hi, lo) planes [TM + 2 rows][OC], h as bf16 (hi, lo) planes [TM + 2 rows][HC], gp as fp32 [TM][HC];
+//   * NWC CONSUMER waves: wave w owns input-side channels [16 (w % CI), +16) of a position group for the data gradient -- its 16 x K
+//     weight slice (K = 3 OC) lives in registers for the whole launch, B operands are ds_read_b128 of the row-major gy planes -- and
+//     IB x CB (cout tile, cin tile) pairs x 3 taps of weight-gradient accumulators, fed by transposing LDS reads of the SAME planes
+//     (ds_read_b64_tr_b16: the contraction index is the position); epilogue: * gp, statistics partials, store;
+//   * one barrier per tile; one slab per workgroup (raw-fragment layout of wgrad_wide_kernel), summed by w2s_wgrad_reduce.
+#include <type_traits>
+#include "conv_cl.inl"
+
+struct BwdWideP {
+  const float* g; const float* y; const float* st_k; const float* bst_k;
+  const float* xin; const float* st_in; const float* add_even;
+  const __bf16* w_hi; const __bf16* w_lo;   // data-gradient operand: [cin][taps][cout] as fragment-major planes (w2s_repack_batch bwd_hi / bwd_lo)
+  float* gout; float* part; float* slab;
+  int B, L, ntiles;
+};
+
+typedef __bf16 wbbf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wbbf16x4v __attribute__((__vector_size__(4 * sizeof(__bf16))));
+__device__ __forceinline__ void wb_split_store4(__bf16* hi, __bf16* lo, int off, f32x4 t) {
+  wbbf16x4 h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
+  wbbf16x4 l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
+  *reinterpret_cast<wbbf16x4*>(hi + off) = h;
+  *reinterpret_cast<wbbf16x4*>(lo + off) = l;
+}
+__device__ __forceinline__ bf16x8 wb_tr8(const __bf16* p0, const __bf16* p1) {
+  typedef __attribute__((address_space(3))) wbbf16x4v* lds_p;
+  wbbf16x4v a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p0));
+  wbbf16x4v b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p1));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// CO / CI: 16-channel tiles on the gradient / input side; HST: xin carries statistics (conv2); MT: 16-position m-tiles per tile;
+// NWC consumer waves = (CO / IB) x (CI / CB) weight-gradient owners = CI x (NWC / CI) data-gradient owners; PD: producer prefetch depth
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD>
+__global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
+  extern __shared__ f32x4 smem4[];
+  static_assert((CO / IB) * (CI / CB) == NWC && NWC % CI == 0 && MT % (NWC / CI) == 0, "consumer wave grid");
+  constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NPT = 256, NR = TM + 2;   // window rows: positions t0 - 1 .. t0 + TM
+  constexpr int RSg = OC + 16, RSh = HC + 8;                                         // bf16 elements per LDS row
+  constexpr int RSp = HC + 4;                                                        // floats per row of the gp plane
+  constexpr int BUFH = 2 * NR * RSg + 2 * NR * RSh;                                  // bf16 elements: gy hi, gy lo, h hi, h lo
+  constexpr int BUFB = BUFH * 2 + TM * RSp * 4;                                      // bytes of one buffer (gp plane behind the bf16 planes)
+  static_assert(BUFB % 16 == 0, "buffer alignment");
+  constexpr int PG = NWC / CI, MTW = MT / PG;                                        // position groups / m-tiles per wave of the data gradient
+  constexpr int QN = OC / 32, KS = 3 * QN;                                           // data-gradient K steps: ks = tap * QN + q
+  char* lds = reinterpret_cast<char*>(smem4);
+  float* stL = reinterpret_cast<float*>(lds + 2 * BUFB);   // [B][OC][2] (mean, rstd), [B][OC][2] backward sums, then [B][HC][2] (HST)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int total = P.B * P.ntiles;
+  const int first = blockIdx.x, step = gridDim.x;
+  for (int i = tid; i < P.B * OC * 2; i += 64 * (NWC + 4)) {
+    stL[i] = P.st_k[i];
+    stL[P.B * OC * 2 + i] = P.bst_k[i];
+  }
+  if (HST)
+    for (int i = tid; i < P.B * HC * 2; i += 64 * (NWC + 4)) stL[P.B * OC * 4 + i] = P.st_in[i];
+  __syncthreads();
+
+  const int nt_wg = (total - first + step - 1) / step;            // >= 1 (the grid never exceeds the tile count)
+  const int NI = ((nt_wg + 1 + PD - 1) / PD) * PD;                // barrier rounds, padded to whole prefetch cycles
+  const int L = P.L;
+
+  if (wave >= NWC) {
+    // ================================================= producer waves =================================================
+    const int pt = tid - 64 * NWC;
+    constexpr int c4g = OC / 4, rsg = NPT / c4g, NG = (NR + rsg - 1) / rsg;
+    constexpr int c4h = HC / 4, rsh = NPT / c4h, NH = (NR + rsh - 1) / rsh;
+    const int gch = (pt % c4g) * 4, grow0 = pt / c4g;
+    const int hch = (pt % c4h) * 4, hrow0 = pt / c4h;
+    f32x4 rg[PD][NG] = {}, ry[PD][NG] = {}, rh[PD][NH] = {};
+    auto load_g = [&](auto SET, int i, int k) {
+      constexpr int S = decltype(SET)::value;
+      const int tl = first + min(i, nt_wg - 1) * step;
+      const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+      const int row = min(grow0 + k * rsg, NR - 1), gr = min(max(t0 - 1 + row, 0), L - 1);
+      const unsigned off = (unsigned)gr * OC + gch;
+      rg[S][k] = ld4o(P.g + (size_t)b * L * OC, off);
+      ry[S][k] = ld4o(P.y + (size_t)b * L * OC, off);
+    };
+    auto load_h = [&](auto SET, int i, int k) {
+      constexpr int S = decltype(SET)::value;
+      const int tl = first + min(i, nt_wg - 1) * step;
+      const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+      const int row = min(hrow0 + k * rsh, NR - 1), gr = min(max(t0 - 1 + row, 0), L - 1);
+      rh[S][k] = ld4o(P.xin + (size_t)b * L * HC, (unsigned)gr * HC + hch);
+    };
+    auto stage = [&](auto SET, int i) {
+      constexpr int S = decltype(SET)::value;
+      const bool live = i < nt_wg;   // uniform; padding rounds only keep the load queue regular
+      const int tl = first + min(i, nt_wg - 1) * step;
+      const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+      __bf16* gH = reinterpret_cast<__bf16*>(lds + (i & 1) * BUFB);
+      __bf16* gL = gH + NR * RSg;
+      __bf16* hH = gL + NR * RSg;
+      __bf16* hL = hH + NR * RSh;
+      float* gpL = reinterpret_cast<float*>(hL + NR * RSh);
+      f32x4 pm, pr, ps1, ps2;
+      {
+        const float* st = stL + (b * OC + gch) * 2;
+        const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+        pm = (f32x4){s01.x, s01.z, s23.x, s23.z}; pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+        const float* bs = stL + ((P.B + b) * OC + gch) * 2;
+        const f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
+        ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z}; ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
+      }
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        const int row = grow0 + k * rsg, gr = t0 - 1 + row;
+        const f32x4 v1 = rg[S][k], v2 = ry[S][k];
+        load_g(SET, i + PD, k);
+        if (live && row < NR) {
+          const f32x4 tv = pro_apply(W2S_PRO_INBWD, v1, v2, pm, pr, ps1, ps2);
+          wb_split_store4(gH, gL, row * RSg + gch, (gr >= 0 && gr < L) ? tv : (f32x4){0, 0, 0, 0});
+        }
+      }
+      f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
+      if (HST) {
+        const float* st = stL + P.B * OC * 4 + (b * HC + hch) * 2;
+        const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+        hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+      }
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const int row = hrow0 + k * rsh, gr = t0 - 1 + row;
+        const f32x4 v = rh[S][k];
+        load_h(SET, i + PD, k);
+        if (live && row < NR) {
+          f32x4 hv, gpv;
+          gelu_both4((v - hm) * hr, hv, gpv);
+          wb_split_store4(hH, hL, row * RSh + hch, (gr >= 0 && gr < L) ? hv : (f32x4){0, 0, 0, 0});
+          if (row >= 1 && row <= TM) st4(gpL + (row - 1) * RSp + hch, gpv);
+        }
+      }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      load_g(I0{}, 0, k);
+      if constexpr (PD > 1) load_g(I1{}, 1, k);
+      if constexpr (PD > 2) load_g(I2{}, 2, k);
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      load_h(I0{}, 0, k);
+      if constexpr (PD > 1) load_h(I1{}, 1, k);
+      if constexpr (PD > 2) load_h(I2{}, 2, k);
+    }
+    for (int it = 0; it < NI; it += PD) {
+      stage(I0{}, it);
+      __syncthreads();
+      if constexpr (PD > 1) { stage(I1{}, it + 1); __syncthreads(); }
+      if constexpr (PD > 2) { stage(I2{}, it + 2); __syncthreads(); }
+    }
+    return;
+  }
+
+  // =================================================== consumer waves ===================================================
+  const int r = lane & 15, g = lane >> 4, q4 = r >> 2, p4 = r & 3;
+  const int wi = wave / (CI / CB), wc = wave % (CI / CB);   // weight gradient: cout tiles [wi IB, +IB) x cin tiles [wc CB, +CB)
+  const int dn = wave % CI, dg = wave / CI;                 // data gradient: input-side channel tile dn, position group dg
+  f32x4 accw[IB][3][CB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) accw[i][j][c] = (f32x4){0, 0, 0, 0};
+  bf16x8 wh[KS], wl[KS];   // this wave's 16 x K data-gradient weight slice, once per launch: fragment-major planes [HC/16][KS][64 lanes][8]
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const size_t wo = ((size_t)dn * KS + ks) * 512 + lane * 8;
+    wh[ks] = *reinterpret_cast<const bf16x8*>(P.w_hi + wo);
+    wl[ks] = *reinterpret_cast<const bf16x8*>(P.w_lo + wo);
+  }
+  const int ch0 = dn * 16 + 4 * g;   // this lane's 4 consecutive output channels (D fragment: position r, channels 4g .. 4g+3)
+  __syncthreads();                   // round 0 of the producers: the first windows are in buffer 0
+  for (int it = 0; it < NI - 1; ++it) {
+    if (it >= nt_wg) { __syncthreads(); continue; }   // padding rounds of the producers' prefetch cycle
+    const int tl = first + it * step;
+    const int b = tl / P.ntiles, tile = tl % P.ntiles, t0 = tile * TM;
+    const __bf16* gH = reinterpret_cast<const __bf16*>(lds + (it & 1) * BUFB);
+    const __bf16* gL = gH + NR * RSg;
+    const __bf16* hH = gL + NR * RSg;
+    const __bf16* hL = hH + NR * RSh;
+    const float* gpL = reinterpret_cast<const float*>(hL + NR * RSh);
+    // epilogue operands of THIS tile, issued now so that their latency hides behind the MFMA loops: raw xin (statistics) and add_even
+    f32x4 ax[MTW], ae[MTW];
+    {
+      const float* xb = P.xin + (size_t)b * L * HC;
+      const float* eb = P.add_even ? P.add_even + (size_t)b * (L >> 1) * HC : nullptr;
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        const int pos = t0 + (dg * MTW + mt) * 16 + r;
+        ax[mt] = (pos < L) ? ld4o(xb, (unsigned)pos * HC + ch0) : (f32x4){0, 0, 0, 0};
+        ae[mt] = (eb && !(pos & 1) && (pos >> 1) < (L >> 1)) ? ld4o(eb, (unsigned)(pos >> 1) * HC + ch0) : (f32x4){0, 0, 0, 0};
+      }
+    }
+    // ---- data gradient: K = (tap, gradient channel); window row of gy[t + 1 - j] is (t - t0) + 2 - j
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int j = ks / QN, q = ks % QN;
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        const int row = (dg * MTW + mt) * 16 + r + 2 - j;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(gH + row * RSg + q * 32 + 8 * g);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(gL + row * RSg + q * 32 + 8 * g);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bl, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], bh, acc[mt], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: * GELU'(n_in), statistics partials, store
+    f32x4 sA = {0, 0, 0, 0}, sB = {0, 0, 0, 0};
+    f32x4 am = {0, 0, 0, 0}, ar = {1, 1, 1, 1};
+    if (HST) {
+      const float* st = stL + P.B * OC * 4 + (b * HC + ch0) * 2;
+      const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+      am = (f32x4){s01.x, s01.z, s23.x, s23.z}; ar = (f32x4){s01.y, s01.w, s23.y, s23.w};
+    }
+    float* ob = P.gout + (size_t)b * L * HC;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int m = (dg * MTW + mt) * 16 + r, pos = t0 + m;
+      if (pos >= L) continue;
+      const f32x4 v = (acc[mt] + ae[mt]) * ld4(gpL + m * RSp + ch0);
+      const f32x4 n = (ax[mt] - am) * ar;
+      sA += v;
+      sB += v * n;
+      st4o(ob, (unsigned)pos * HC + ch0, v);
+    }
+    if (P.part) {   // [B][ntiles][PG][2][HC]: one row per (tile, position group), written once
+      f32x4 x1, x2;
+      x1.x = row16_sum(sA.x); x1.y = row16_sum(sA.y); x1.z = row16_sum(sA.z); x1.w = row16_sum(sA.w);
+      x2.x = row16_sum(sB.x); x2.y = row16_sum(sB.y); x2.z = row16_sum(sB.z); x2.w = row16_sum(sB.w);
+      if (r == 0) {
+        float* d = P.part + ((((size_t)b * P.ntiles + tile) * PG + dg) * 2) * HC + ch0;
+        st4(d, x1);
+        st4(d + HC, x2);
+      }
+    }
+    // ---- weight gradient: k-step = 32 positions; gradient-side position p <-> gy window row p + 1, h[t + j - 1] <-> window row p + j
+#pragma unroll
+    for (int s = 0; s < TM / 32; ++s) {
+      const int p0 = 32 * s + 8 * g + q4;   // this lane's address row (position) of the first 4-position block
+      bf16x8 ah[IB], al[IB];
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        const int col = (wi * IB + i) * 16 + 4 * p4;
+        ah[i] = wb_tr8(gH + (p0 + 1) * RSg + col, gH + (p0 + 5) * RSg + col);
+        al[i] = wb_tr8(gL + (p0 + 1) * RSg + col, gL + (p0 + 5) * RSg + col);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+          const int col = (wc * CB + c) * 16 + 4 * p4;
+          const bf16x8 bh = wb_tr8(hH + (p0 + j) * RSh + col, hH + (p0 + 4 + j) * RSh + col);
+          const bf16x8 bl = wb_tr8(hL + (p0 + j) * RSh + col, hL + (p0 + 4 + j) * RSh + col);
+#pragma unroll
+          for (int i = 0; i < IB; ++i) {
+            accw[i][j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, accw[i][j][c], 0, 0, 0);
+            accw[i][j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, accw[i][j][c], 0, 0, 0);
+            accw[i][j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, accw[i][j][c], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();   // the producers have staged the next windows; these may be overwritten
+  }
+  float* out = P.slab + (size_t)blockIdx.x * (CO * 3 * CI) * 256 + lane * 4;
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) st4(out + (size_t)(((wi * IB + i) * 3 + j) * CI + wc * CB + c) * 256, accw[i][j][c]);
+}
+
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD>
+static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
+  constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NR = TM + 2;
+  BwdWideP P = P0;
+  P.ntiles = (P.L + TM - 1) / TM;
+  const size_t lds = (size_t)2 * ((2 * NR * (OC + 16) + 2 * NR * (HC + 8)) * 2 + TM * (HC + 4) * 4) + (size_t)P.B * OC * 4 * 4 + (HST ? (size_t)P.B * HC * 2 * 4 : 0);
+  if (lds > 160 * 1024) return 1;   // (batch too large for the LDS statistics tables: the caller runs the separate kernels)
+  if (dry) return 0;
+  if (nslab <= 0 || (long)nslab > (long)P.B * P.ntiles) return W2S_EINVAL;   // every workgroup writes a slab: it needs a tile
+  auto kern = bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return W2S_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(nslab), dim3(64 * (NWC + 4)), lds, s, P);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// positions per tile and statistics-partial rows per tile of the (cg, ch) instance; 0: no instance
+extern "C" int w2s_bwd_wide_tile(int cg, int ch) { return (cg == 64 && (ch == 64 || ch == 32)) ? 64 : 0; }
+extern "C" int w2s_bwd_wide_groups(int cg, int ch) { return (cg == 64 && ch == 32) ? 2 : (cg == 64 && ch == 64) ? 1 : 0; }
+
+// One pass for the backward of a k=3 / stride-1 / symmetric-padding encoder conv with cg = 64 gradient-side and ch = 64 or 32 input-side
+// channels.  w_hi / w_lo: the data-gradient operand planes (w2s_repack_batch bwd_hi / bwd_lo of the conv's weight).  part: [B][ntiles]
+// [groups][2][ch] partial sums of gout and gout * n_in (rows = ntiles * groups for w2s_stats_finalize), or NULL.  slab: nslab slabs of
+// cg * 3 * ch floats (nslab = grid size <= B * ntiles) for w2s_wgrad_reduce(..., cg, ch, 3, 1, ...).  dry != 0: only answer whether an
+// instance takes this launch (0) or not (1).
+extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
+                            const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B,
+                            int L, int cg, int ch, int dry, void* stream) {
+  if (!w2s_bwd_wide_tile(cg, ch)) return 1;
+  if (!dry && (!g || !y || !st_k || !bst_k || !xin || !w_hi || !w_lo || !gout || !slab)) return W2S_EINVAL;
+  if ((size_t)L * 64 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;   // 32-bit lane offsets inside one sample
+  static const char* off = getenv("W2S_NO_BWD_WIDE");   // tuning only
+  if (off) return 1;
+  BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, B, L, 0};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (ch == 64) return st_in ? launch_bww<4, 4, 1, 4, 4, 2, 2, 2>(P, nslab, s, dry) : launch_bww<4, 4, 0, 4, 4, 2, 2, 2>(P, nslab, s, dry);
+  return st_in ? launch_bww<4, 2, 1, 4, 4, 2, 1, 2>(P, nslab, s, dry) : launch_bww<4, 2, 0, 4, 4, 2, 1, 2>(P, nslab, s, dry);
+}

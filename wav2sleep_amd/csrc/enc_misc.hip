@@ -152,10 +152,16 @@ extern "C" int w2s_enc_first_join(const float* x, const float* wd, const float* 
 //   dW1[o][j] = sum_{b,t} gy1[b,t,o] * san(x[b,t+j-1]),  gy1 = IN-backward(gn1; y1)
 //   dWd[o]    = sum_{b,u} gpre[b,u,o] * san(x[b,2u])
 // slab[wg][64]: [0..47] = dW1[o][j], [48..63] = dWd[o].  Sum the slabs with w2s_colsum.
-__global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gn1,
+// GH: gn1 and gpre are stored as fp16 (the fp16 gradient chain, w2s_common.h): scale_n / scale_p = their headers' scales.
+template <int GH>
+__global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restrict__ x, const void* __restrict__ gn1v,
                                                             const float* __restrict__ y1, const float* __restrict__ stats1,
-                                                            const float* __restrict__ bstats1, const float* __restrict__ gpre,
-                                                            float* __restrict__ slab, int B, int L, const float* __restrict__ w1, int shift) {
+                                                            const float* __restrict__ bstats1, const void* __restrict__ gprev,
+                                                            float* __restrict__ slab, int B, int L, const float* __restrict__ w1, int shift,
+                                                            const float* __restrict__ hdr_n, const float* __restrict__ hdr_p) {
+  const float* gn1 = static_cast<const float*>(gn1v);
+  const float* gpre = static_cast<const float*>(gprev);
+  const float inv_n = GH ? 1.f / hdr_n[0] : 1.f, inv_p = GH ? 1.f / hdr_p[0] : 1.f;
   __shared__ float red[4][4][16];
   __shared__ float xs[1026];
   const int tid = threadIdx.x, og = tid & 3, lane = tid & 63, wave = tid >> 6;
@@ -186,9 +192,9 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
       xs[i] = (t >= 0 && t < L && !isinf(xv)) ? xv : 0.f;
     }
     __syncthreads();
-    const float* gb = gn1 + (size_t)b * L * 16;
+    const char* gb = reinterpret_cast<const char*>(gn1) + (size_t)b * L * 16 * (GH ? 2 : 4);
     const float* yb = y1 ? y1 + (size_t)b * L * 16 : nullptr;
-    const float* pb = gpre + (size_t)b * (L >> 1) * 16;
+    const char* pb = reinterpret_cast<const char*>(gpre) + (size_t)b * (L >> 1) * 16 * (GH ? 2 : 4);
     // straight-line body: no break / divergent branch inside (positions past the end and odd positions contribute through a 0/1
     // factor on clamped addresses).  The branchy form of this loop was NOT bit-reproducible when other kernels shared the CU
     // (tools/determinism_probe*.py: identical inputs, different dW1 sums in situ, correct in isolation).
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
       // (both lanes multiply by the HIGH half of src1: acc4/acc5 += (xc, xp) * gy.y and acc10/acc11 += (xc, xp) * gy.w) whose LOW-lane
       // results (the odd channels' middle tap) were the sums that differed from launch to launch.
       const f32x4 n4 = (yv - mean) * rstd;
-      f32x4 gy4 = rstd * (ld4o(gb, off) - q1 - n4 * q2);
+      f32x4 gy4 = rstd * (ld4o(reinterpret_cast<const float*>(gb), off) - q1 - n4 * q2);
 #if W2S_FIRST_BWD_FLOAT4 == 2   // same arithmetic, the accumulate block fenced off from the producer of gy (scheduling / forwarding hazard?)
       __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7"); __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -225,7 +231,8 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
       // scalar arithmetic on purpose: with float4 expressions hipcc built this block from v_pk_* instructions with op_sel operand
       // swizzles, and the sums of the odd channels' middle tap (gy.y * xc, gy.w * xc) came out different from launch to launch when
       // other kernels shared the CU -- a hazard of that instruction mix, not of the data (tools/determinism_probe3.py)
-      const f32x4 gv = ld4o(gb, off);
+      f32x4 gv;
+      if constexpr (GH) gv = h2f4(ld4h(gb, off)) * inv_n; else gv = ld4o(reinterpret_cast<const float*>(gb), off);
       const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
       const float mm[4] = {mean.x, mean.y, mean.z, mean.w}, rr[4] = {rstd.x, rstd.y, rstd.z, rstd.w};
       const float a1[4] = {q1.x, q1.y, q1.z, q1.w}, a2[4] = {q2.x, q2.y, q2.z, q2.w};
@@ -239,7 +246,9 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
       }
 #endif
       const float even = (t & 1) ? 0.f : live;
-      const f32x4 gp = ld4o(pb, (unsigned)min(tc >> 1, (L >> 1) - 1) * 16 + og * 4);
+      f32x4 gp;
+      if constexpr (GH) gp = h2f4(ld4h(pb, (unsigned)min(tc >> 1, (L >> 1) - 1) * 16 + og * 4)) * inv_p;
+      else gp = ld4o(reinterpret_cast<const float*>(pb), (unsigned)min(tc >> 1, (L >> 1) - 1) * 16 + og * 4);
       const float x0 = xs[p + 1 + shift] * even;  // x[t]: the 1x1/stride-2 residual conv has no padding in either mode
       acc[12] += gp.x * x0; acc[13] += gp.y * x0; acc[14] += gp.z * x0; acc[15] += gp.w * x0;
     }
@@ -270,8 +279,18 @@ __global__ __launch_bounds__(256) void enc_first_bwd_kernel(const float* __restr
 extern "C" int w2s_enc_first_bwd(const float* x, const float* gn1, const float* y1, const float* stats1, const float* bstats1,
                                  const float* gpre, float* slab, int nslab, int B, int L, int cout, const float* w1, int causal, void* stream) {
   if (!x || !gn1 || (!y1 && !w1) || !stats1 || !bstats1 || !gpre || !slab || cout != 16 || nslab <= 0) return W2S_EINVAL;
-  hipLaunchKernelGGL(enc_first_bwd_kernel, dim3(nslab), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gn1, y1, stats1, bstats1,
-                     gpre, slab, B, L, y1 ? nullptr : w1, causal ? 1 : 0);
+  hipLaunchKernelGGL(enc_first_bwd_kernel<0>, dim3(nslab), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gn1, y1, stats1, bstats1,
+                     gpre, slab, B, L, y1 ? nullptr : w1, causal ? 1 : 0, nullptr, nullptr);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+// gn1 / gpre stored as fp16 with the scales in their headers (the fp16 gradient chain)
+extern "C" int w2s_enc_first_bwd_h(const float* x, const void* gn1, const float* hdr_n, const float* y1, const float* stats1, const float* bstats1,
+                                   const void* gpre, const float* hdr_p, float* slab, int nslab, int B, int L, int cout, const float* w1, int causal,
+                                   void* stream) {
+  if (!x || !gn1 || !hdr_n || !hdr_p || (!y1 && !w1) || !stats1 || !bstats1 || !gpre || !slab || cout != 16 || nslab <= 0) return W2S_EINVAL;
+  hipLaunchKernelGGL(enc_first_bwd_kernel<1>, dim3(nslab), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gn1, y1, stats1, bstats1,
+                     gpre, slab, B, L, y1 ? nullptr : w1, causal ? 1 : 0, hdr_n, hdr_p);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
@@ -332,9 +351,15 @@ extern "C" int w2s_stats_finalize(const float* part, int B, int ntiles, int C, l
 // ---------------------------------------------------------------------------------------------------
 // conv3 backward pre-pass: gn = g * GELU'(n), n = IN(y);  partial sums of gn and gn*n per (b, tile, c).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_stats_kernel(const float* __restrict__ g, const float* __restrict__ y,
+// GH: g is stored as fp16 (header hdr_g = {scale, max}); hdr_amax != NULL (fp32 g only): also publish max |g| and scale 1 -- the
+// entry of the fp16 gradient chain (w2s_common.h) derives its first output scale from it.
+template <int GH>
+__global__ __launch_bounds__(256) void gp_stats_kernel(const void* __restrict__ gv, const float* __restrict__ y,
                                                        const float* __restrict__ stats, float* __restrict__ part, int L, int C, int tile,
-                                                       int ntiles, StatFin fin) {
+                                                       int ntiles, StatFin fin, const float* __restrict__ hdr_g, float* __restrict__ hdr_amax) {
+  const float* g = static_cast<const float*>(gv);
+  const float inv_g = GH ? 1.f / hdr_g[0] : 1.f;
+  float amax = 0.f;
   extern __shared__ float sm[];  // [256][8]
   const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x;
   const int c4n = C >> 2, myc4 = tid % c4n, row0 = tid / c4n, rstep = 256 / c4n;
@@ -347,7 +372,11 @@ __global__ __launch_bounds__(256) void gp_stats_kernel(const float* __restrict__
     if (t >= L) break;
     const size_t off = ((size_t)b * L + t) * C + myc4 * 4;
     f32x4 n = (ld4(y + off) - mean) * rstd;
-    f32x4 gn = ld4(g + off) * gelu_grad4(n);
+    f32x4 graw;
+    if constexpr (GH) graw = h2f4(*reinterpret_cast<const h16x4*>(static_cast<const _Float16*>(gv) + off)) * inv_g;
+    else graw = ld4(g + off);
+    amax = amax4(amax, graw);
+    f32x4 gn = graw * gelu_grad4(n);
     a1 += gn;
     a2 += gn * n;
   }
@@ -360,17 +389,31 @@ __global__ __launch_bounds__(256) void gp_stats_kernel(const float* __restrict__
     for (int rl = 0; rl < rstep; ++rl) s += sm[(rl * c4n + (c >> 2)) * 8 + k * 4 + (c & 3)];
     w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * C + c], s);
   }
+  if (!GH && hdr_amax) w2s_amax_commit(hdr_amax, amax, 1.f);   // uniform
   w2s_stat_finish(fin, part, b, ntiles, C, ntiles);
 }
 
-extern "C" int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, float* stat_out,
-                            int* stat_cnt, void* stream) {
+static int gp_stats_impl(const void* g, int g_half, const float* hdr_g, float* hdr_amax, const float* y, const float* stats, float* part, int B, int L,
+                         int C, int tile, float* stat_out, int* stat_cnt, void* stream) {
   if (!g || !y || !stats || !part || C < 16 || C > 128 || (C & (C - 1)) || tile <= 0) return W2S_EINVAL;
+  if (g_half ? (!hdr_g || hdr_amax) : (hdr_g != nullptr)) return W2S_EINVAL;
   const int ntiles = (L + tile - 1) / tile;
   if (stat_out && !stat_cnt) return W2S_EINVAL;
   const StatFin fin{stat_out, stat_cnt, 1.0 / (double)L, 0.f, 1};
-  hipLaunchKernelGGL(gp_stats_kernel, dim3(ntiles, B), dim3(256), 256 * 8 * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y,
-                     stats, part, L, C, tile, ntiles, fin);
+  if (g_half)
+    hipLaunchKernelGGL(gp_stats_kernel<1>, dim3(ntiles, B), dim3(256), 256 * 8 * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y,
+                       stats, part, L, C, tile, ntiles, fin, hdr_g, hdr_amax);
+  else
+    hipLaunchKernelGGL(gp_stats_kernel<0>, dim3(ntiles, B), dim3(256), 256 * 8 * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y,
+                       stats, part, L, C, tile, ntiles, fin, hdr_g, hdr_amax);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
+}
+extern "C" int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, float* stat_out,
+                            int* stat_cnt, void* stream) {
+  return gp_stats_impl(g, 0, nullptr, nullptr, y, stats, part, B, L, C, tile, stat_out, stat_cnt, stream);
+}
+extern "C" int w2s_gp_stats_h(const void* g, int g_half, const float* hdr_g, float* hdr_amax, const float* y, const float* stats, float* part, int B,
+                              int L, int C, int tile, void* stream) {
+  return gp_stats_impl(g, g_half, hdr_g, hdr_amax, y, stats, part, B, L, C, tile, nullptr, nullptr, stream);
 }

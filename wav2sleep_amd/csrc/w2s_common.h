@@ -119,6 +119,38 @@ __device__ __forceinline__ void st4o(float* base, unsigned elem_off, f32x4 v) {
   *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + (elem_off << 2)) = v;
 }
 
+// ---- fp16 storage of the encoder's gradient chain (W2S_GRAD_FP16) --------------------------------------------
+// The gradient tensors between two fused-backward kernels of the <= 32-channel blocks (d/d xhat1, d/d xhat2, d/d pre: half of those
+// kernels' bytes) are stored as fp16 with ONE power-of-two scale per tensor; everything is accumulated and applied in fp32.  A tensor
+// carries a two-float header: hdr[0] = scale (stored = true * scale), hdr[1] = max |true value| as float bits, accumulated by its
+// producer with an integer atomicMax (order-independent => runs stay bit-reproducible).  A producer derives its output scale from the
+// maximum of the tensor(s) it READS (final when it starts): stored values then sit near 2^8 with 2^7 of headroom below fp16's 65504 (a
+// layer's gain is bounded by rstd <= 10 times the weights' row sums) and keep all 11 significant bits down to 2^-22 of the maximum.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h16x4 ld4h(const void* base, unsigned elem_off) {
+  return *reinterpret_cast<const h16x4*>(reinterpret_cast<const char*>(base) + (elem_off << 1));
+}
+__device__ __forceinline__ void st4h(void* base, unsigned elem_off, h16x4 v) {
+  *reinterpret_cast<h16x4*>(reinterpret_cast<char*>(base) + (elem_off << 1)) = v;
+}
+__device__ __forceinline__ f32x4 h2f4(h16x4 h) { return __builtin_convertvector(h, f32x4); }
+__device__ __forceinline__ h16x4 f2h4(f32x4 v) { return __builtin_convertvector(v, h16x4); }   // round to nearest even
+__device__ __forceinline__ float w2s_gscale_for(float ref) {
+  if (!(ref > 0.f) || !(ref < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(ref, &e);   // ref = m * 2^e, m in [0.5, 1)
+  return ldexpf(1.f, min(9 - e, 120));
+}
+__device__ __forceinline__ float amax4(float a, f32x4 v) {
+  return fmaxf(fmaxf(a, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+// end of a producer kernel: wave maximum, one integer atomic per wave; workgroup 0 publishes the scale
+__device__ __forceinline__ void w2s_amax_commit(float* hdr, float amax, float scale) {
+  for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(hdr + 1), __float_as_uint(amax));
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hdr[0] = scale;
+}
+
 // counter-based RNG for dropout: splitmix64 of (seed, element index) -> uniform [0,1).  The same
 // (seed, index) regenerates the same mask in the backward pass; nothing is stored.
 __device__ __forceinline__ float w2s_uniform(uint64_t seed, uint64_t idx) {

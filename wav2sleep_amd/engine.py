@@ -108,6 +108,11 @@ class Engine:
         self.fused_forward = os.environ.get('W2S_FUSED_FORWARD', '1') != '0'
         self.fold_gp = os.environ.get('W2S_FOLD_GP', '1') == '1'   # conv3-backward statistics of the previous block ride in the residual-fold conv1 kernel
         self.fused_finalize = os.environ.get('W2S_FUSED_FINALIZE', '0') != '0'
+        # fp16 storage of the gradient tensors between the fused-backward launches of the <= 32-channel blocks: half of
+        # those kernels' gradient bytes, fp32 arithmetic.  Measured round 3: -14 GB of traffic bought only -0.45 ms (those kernels are not
+        # bandwidth-bound) while the worst full-size gradient error went 4.4e-4 -> 1.0e-3: OFF by default, W2S_GRAD_FP16=1 switches it on
+        self.grad_fp16 = os.environ.get('W2S_GRAD_FP16', '0') == '1'
+        self.bwd_wide = os.environ.get('W2S_BWD_WIDE', '1') != '0'   # one-pass backward of the 64-channel stride-1 convs (csrc/bwd_wide.hip)
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
         if not spec.use_residual:
@@ -299,7 +304,7 @@ class Engine:
         self._written.add(name)
 
     def _bwd_fused(self, name, *, g, y, st_k, bst_k, pro, xin, st_in, add_even, gout, want_part, B, Lg, Lh, cg, ch, stride,
-                   gpre=None, down=None, w1=None, y3p=None, st3p=None):
+                   gpre=None, down=None, w1=None, y3p=None, st3p=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None):
         """dgrad + wgrad of one k=3 encoder conv in one pass (<= 32 channels); returns the backward statistics or None.
         gpre / down (conv1 of a residual block): fold the 1x1/stride-2 residual branch `down` in as well."""
         dev = g.device
@@ -309,10 +314,11 @@ class Engine:
         slab = self._slab(dev, nslab, cg * ch * 3)
         slab_d = self._slab(dev, nslab, cg * ch) if gpre is not None else None
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
-        so, sc = self._fin(B, ch, dev) if want_part else (None, None)
+        so, sc = self._fin(B, ch, dev) if (want_part and not gmode) else (None, None)
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
                       part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, pad=self.kpad, split_precision=self.split_precision,
-                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1, y3p=y3p, st3p=st3p, stat_out=so, stat_cnt=sc)
+                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1, y3p=y3p, st3p=st3p, stat_out=so, stat_cnt=sc,
+                      gmode=gmode, hdr_g=hdr_g, hdr_p=hdr_p, hdr_o=hdr_o)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         if gpre is not None:
@@ -321,6 +327,25 @@ class Engine:
         if not want_part:
             return None
         return so if so is not None else self._bstats(part, B, nt, ch, Lh)
+
+    def _bwd_wide_ok(self, B, L, cg, ch):
+        """the one-pass backward of a >= 64-channel stride-1 conv (csrc/bwd_wide.hip): split precision, symmetric padding"""
+        return self.bwd_wide and self.split_precision and self.kpad == 1 and lib.bwd_wide_takes(B, L, cg, ch)
+
+    def _bwd_wide(self, name, *, g, y, st_k, bst_k, xin, st_in, add_even, gout, want_part, B, L, cg, ch):
+        """dgrad + wgrad + GELU' + backward statistics of one 64-channel k=3 / stride-1 conv in one pass; returns the statistics or None."""
+        dev = g.device
+        tile, groups = lib.bwd_wide_tile(cg, ch), lib.bwd_wide_groups(cg, ch)
+        nt = _cdiv(L, tile)
+        nslab = max(1, min(B * nt, 256))
+        slab = self._slab(dev, nslab, cg * ch * 3)
+        part = torch.empty(B, nt * groups, 2, ch, device=dev, dtype=torch.float32) if want_part else None
+        wh, wl = self._bf[self.PB[name].data_ptr()]
+        lib.bwd_wide(g=g, y=y, st_k=st_k, bst_k=bst_k, xin=xin, st_in=st_in, add_even=add_even, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab,
+                     nslab=nslab, B=B, L=L, cg=cg, ch=ch)
+        self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
+        self._written.add(name)
+        return self._bstats(part, B, nt * groups, ch, L) if want_part else None
 
     def _colsum(self, part, nparts, C, out, accumulate=False, ld=None):
         """queued column sum (flushed with the slab reductions): out[c] (+)= sum_p part[p*ld + c]"""
@@ -873,11 +898,38 @@ class Engine:
                    epi=lib.EPI_GP, aux=ec['plast'], ld_aux=4 * cl)
         B = ec['Bc']   # chunk-causal: the conv stack ran on B*S one-epoch samples; gpre [B, 4S, C] is its [B*S, 4, C] gradient
         bs3_folded = None   # conv3 backward statistics of block i produced by block i+1's fused conv1 kernel (no gp_stats pre-pass)
+
+        def fused(j):
+            return lib.bwd_fused_supported(ch[j], ch[j]) and self._fused_bwd_ok
+
+        def will_fold(j):
+            bj = ec['blocks'][j]
+            return (j > 0 and self.split_precision and lib.bwd_fused_supported(bj['c'], bj['cin']) and lib.bwd_fused_folds_residual(bj['c'], bj['cin'])
+                    and not (bj['L'] & 1))
+        # fp16 gradient chain: from its ENTRY block (the topmost fused block whose conv1 is not a residual-fold kernel: its gpre arrives
+        # fp32 from outside the chain and only its conv3 kernel reads it) down to block 0, provided every block below is one the fp16
+        # kernels cover (fused, residual-fold conv1; block 0: the first-layer kernels).  Production: blocks 3 .. 0 of every encoder.
+        entry = -1
+        if self.grad_fp16 and self.split_precision and self._fused_bwd_ok and fused(0):
+            for j in reversed(range(1, len(ch))):
+                if fused(j) and not will_fold(j) and (ch[j], ec['blocks'][j]['cin']) in ((16, 16), (32, 32)) and all(fused(k) and will_fold(k) for k in range(1, j)):
+                    entry = j
+                    break
+        hdrs = torch.zeros(3 * (entry + 1) + 1, 2, device=dev, dtype=torch.float32) if entry >= 0 else None   # {scale, max} per chain tensor
+        nh = [0]
+
+        def new_hdr():
+            nh[0] += 1
+            return hdrs[nh[0] - 1]
+        gpre_hdr = None   # header of gpre: set once gpre is a chain tensor (fp16) or the chain's fp32 entry (gp_stats publishes its maximum)
         for i in reversed(range(len(ch))):
             blk = ec['blocks'][i]
             p = f'{pfx}cnn.{i}.'
             c, cin, L = blk['c'], blk['cin'], blk['L']
             Lh = L // 2
+            h16 = i <= entry                       # this block's gn2 / gn1 (and its gprev, if i > 0) are fp16
+            gdt = torch.float16 if h16 else torch.float32
+            ghalf = gpre.dtype == torch.float16
             # conv3 (stride 2): pre-pass for the instance-norm backward sums, then data + weight gradient
             if bs3_folded is not None:
                 bs3, bs3_folded = bs3_folded, None
@@ -885,48 +937,68 @@ class Engine:
                 tile = 512
                 nt = _cdiv(Lh, tile)
                 part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
-                so, sc = self._fin(B, c, dev)
-                lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile, stat_out=so, stat_cnt=sc)
-                bs3 = so if so is not None else self._bstats(part, B, nt, c, Lh)
-            gn2 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
-            gn1 = torch.empty(B, L, c, device=dev, dtype=torch.float32)
+                if h16 or ghalf:
+                    if not ghalf:
+                        gpre_hdr = new_hdr()
+                    lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile, hdr_g=gpre_hdr if ghalf else None, hdr_amax=None if ghalf else gpre_hdr)
+                    bs3 = self._bstats(part, B, nt, c, Lh)
+                else:
+                    so, sc = self._fin(B, c, dev)
+                    lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile, stat_out=so, stat_cnt=sc)
+                    bs3 = so if so is not None else self._bstats(part, B, nt, c, Lh)
+            gn2 = torch.empty(B, L, c, device=dev, dtype=gdt)
+            gn1 = torch.empty(B, L, c, device=dev, dtype=gdt)
+            h2 = new_hdr() if h16 else None
+            h1 = new_hdr() if h16 else None
             if lib.bwd_fused_supported(c, c) and self._fused_bwd_ok:
                 bs2 = self._bwd_fused(p + 'conv3.conv.weight', g=gpre, y=blk['y3'], st_k=blk['st3'], bst_k=bs3, pro=lib.PRO_INBWD_GP,
-                                      xin=blk['y2'], st_in=blk['st2'], add_even=None, gout=gn2, want_part=True, B=B, Lg=Lh, Lh=L, cg=c, ch=c, stride=2)
+                                      xin=blk['y2'], st_in=blk['st2'], add_even=None, gout=gn2, want_part=True, B=B, Lg=Lh, Lh=L, cg=c, ch=c, stride=2,
+                                      gmode=(2 if ghalf else 1) if h16 else 0, hdr_g=gpre_hdr, hdr_o=h2)
                 first = i == 0 and blk['y1'] is None   # block 0's conv1 output is recomputed from the raw signal
                 bs1 = self._bwd_fused(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, pro=lib.PRO_INBWD,
                                       xin=ec['x'] if first else blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B,
-                                      Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None)
+                                      Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None,
+                                      gmode=2 if h16 else 0, hdr_g=h2, hdr_o=h1)
             else:
                 bs2 = self._conv_part(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
                                       pad=self.kpad, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP,
                                       aux=blk['y2'], aux_stats=blk['st2'], kind=1)
                 self._wgrad(p + 'conv3.conv.weight', g=gpre, g2=blk['y3'], g_stats=blk['st3'], g_bstats=bs3, pro_g=lib.PRO_INBWD_GP, x=blk['y2'],
                             x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=self.kpad)
-                bs1 = self._conv_part(x=gn2, x2=blk['y2'], w=PB[p + 'conv2.conv.weight'], y=gn1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1,
-                                      pad=2 - self.kpad, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st2'], pro_bstats=bs2, epi=lib.EPI_GP,
-                                      aux=blk['y1'], aux_stats=blk['st1'], kind=1)
-                self._wgrad(p + 'conv2.conv.weight', g=gn2, g2=blk['y2'], g_stats=blk['st2'], g_bstats=bs2, pro_g=lib.PRO_INBWD, x=blk['y1'],
-                            x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=self.kpad)
+                if self._bwd_wide_ok(B, L, c, c):
+                    bs1 = self._bwd_wide(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, xin=blk['y1'], st_in=blk['st1'],
+                                         add_even=None, gout=gn1, want_part=True, B=B, L=L, cg=c, ch=c)
+                else:
+                    bs1 = self._conv_part(x=gn2, x2=blk['y2'], w=PB[p + 'conv2.conv.weight'], y=gn1, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1,
+                                          pad=2 - self.kpad, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st2'], pro_bstats=bs2, epi=lib.EPI_GP,
+                                          aux=blk['y1'], aux_stats=blk['st1'], kind=1)
+                    self._wgrad(p + 'conv2.conv.weight', g=gn2, g2=blk['y2'], g_stats=blk['st2'], g_bstats=bs2, pro_g=lib.PRO_INBWD, x=blk['y1'],
+                                x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=self.kpad)
             del gn2
+            hp = new_hdr() if (h16 and i > 0) else None
             if i > 0 and self.split_precision and lib.bwd_fused_supported(c, cin) and lib.bwd_fused_folds_residual(c, cin) and not (L & 1):
                 # conv1 + the whole residual branch (its data gradient AND its weight gradient) in one pass over the tensors
-                gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
+                gprev = torch.empty(B, L, cin, device=dev, dtype=gdt)
                 prev = ec['blocks'][i - 1] if self.fold_gp else dict(y3=None, st3=None)   # fold its conv3-backward statistics pre-pass in
                 bs3_folded = self._bwd_fused(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, pro=lib.PRO_INBWD,
                                              xin=blk['pin'], st_in=None, add_even=None, gout=gprev, want_part=self.fold_gp, B=B, Lg=L, Lh=L, cg=c,
-                                             ch=cin, stride=1, gpre=gpre, down=p + 'downsample.weight', y3p=prev['y3'], st3p=prev['st3'])
+                                             ch=cin, stride=1, gpre=gpre, down=p + 'downsample.weight', y3p=prev['y3'], st3p=prev['st3'],
+                                             gmode=2 if h16 else 0, hdr_g=h1, hdr_p=gpre_hdr, hdr_o=hp)
                 if not self.fold_gp:
                     bs3_folded = None
-                gpre = gprev
+                gpre, gpre_hdr = gprev, hp
             elif i > 0:
                 # residual 1x1/stride-2 branch: R = Wd^T gpre, added at even positions inside conv1's data-gradient epilogue
                 Rr = torch.empty(B, Lh, cin, device=dev, dtype=torch.float32)
                 self._conv(x=gpre, w=PB[p + 'downsample.weight'], y=Rr, B=B, L_in=Lh, L_out=Lh, cin=c, cout=cin, taps=1, stride=1, pad=0)
-                gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
+                gprev = torch.empty(B, L, cin, device=dev, dtype=gdt)
                 if lib.bwd_fused_supported(c, cin) and self._fused_bwd_ok:
                     self._bwd_fused(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, pro=lib.PRO_INBWD, xin=blk['pin'],
-                                    st_in=None, add_even=Rr, gout=gprev, want_part=False, B=B, Lg=L, Lh=L, cg=c, ch=cin, stride=1)
+                                    st_in=None, add_even=Rr, gout=gprev, want_part=False, B=B, Lg=L, Lh=L, cg=c, ch=cin, stride=1,
+                                    gmode=2 if h16 else 0, hdr_g=h1, hdr_o=hp)
+                elif self._bwd_wide_ok(B, L, c, cin):
+                    self._bwd_wide(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, xin=blk['pin'], st_in=None, add_even=Rr,
+                                   gout=gprev, want_part=False, B=B, L=L, cg=c, ch=cin)
                 else:
                     self._conv(x=gn1, x2=blk['y1'], w=PB[p + 'conv1.conv.weight'], y=gprev, B=B, L_in=L, L_out=L, cin=c, cout=cin, taps=3,
                                stride=1, pad=2 - self.kpad, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st1'], pro_bstats=bs1, epi=lib.EPI_GP, aux=blk['pin'],
@@ -935,11 +1007,12 @@ class Engine:
                                 x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=L, cin=cin, cout=c, taps=3, stride=1, pad=self.kpad)
                 self._wgrad(p + 'downsample.weight', g=gpre, x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=Lh, cin=cin, cout=c,
                             taps=1, stride=2, pad=0)
-                gpre = gprev
+                gpre, gpre_hdr = gprev, hp
             else:
                 nslab = max(1, min(1024, _cdiv(B * L, 4096)))
                 slab = torch.empty(nslab, 64, device=dev, dtype=torch.float32)
-                lib.enc_first_bwd(ec['x'], gn1, blk['y1'], blk['st1'], bs1, gpre, slab, nslab, B, L, c, w1=P[p + 'conv1.conv.weight'], causal=self.causal)
+                lib.enc_first_bwd(ec['x'], gn1, blk['y1'], blk['st1'], bs1, gpre, slab, nslab, B, L, c, w1=P[p + 'conv1.conv.weight'], causal=self.causal,
+                                  hdr_n=h1, hdr_p=gpre_hdr)
                 n1, nd = p + 'conv1.conv.weight', p + 'downsample.weight'
                 self._colsum(slab, nslab, 48, self.G[n1], accumulate=n1 in self._written, ld=64)
                 self._colsum(slab.view(-1)[48:], nslab, 16, self.G[nd], accumulate=nd in self._written, ld=64)

@@ -51,7 +51,7 @@ class WgradArgs(C.Structure):
 
 
 EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
-           'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
+           'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version']
@@ -317,22 +317,62 @@ def bwd_fused_folds_residual(cg, ch) -> bool:
     return bool(load().w2s_bwd_fused_folds_residual(cg, ch))
 
 
+def _h(t):
+    assert t is None or t.dtype == torch.float16, 'fp16 tensor expected'
+    return _p(t)
+
+
 def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False, pad=1,
-              gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None, stat_out=None, stat_cnt=None):
+              gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None, stat_out=None, stat_cnt=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None):
+    """gmode 1 / 2: the fp16 gradient chain (include/w2s.h): gout (and, gmode 2, g / gpre) are fp16 tensors with the headers hdr_*."""
+    gin = _h if gmode == 2 else _f
+    gou = _h if gmode else _f
+
     def run():
+        if gmode:
+            _chk(load().w2s_bwd_fused_h(gin(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), gou(gout), _f(part),
+                                        _f(slab), nslab, B, Lg, Lh, cg, ch, stride, pad, gin(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p),
+                                        gmode, _f(hdr_g), _f(hdr_p), _f(hdr_o), _stream()), f'w2s_bwd_fused_h(cg={cg},ch={ch},stride={stride},gmode={gmode})')
+            return
         _chk(load().w2s_bwd_fused(_f(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), _f(gout), _f(part),
                                   _f(slab), nslab, B, Lg, Lh, cg, ch, stride, pad, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p), _f(stat_out), _p(stat_cnt), _stream()),
              f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
-    nbytes = 4 * (2 * B * Lg * cg + (B * Lh * (ch + 1) if w1 is not None else 2 * B * Lh * ch) + (B * Lh * ch // 2 if add_even is not None else 0)
-                  + (B * Lh * cg // 2 if gpre is not None else 0) + (B * Lh * ch if y3p is not None else 0))
+    wg, wo = (2 if gmode == 2 else 4), (2 if gmode else 4)   # bytes per stored gradient element in / out
+    nbytes = (B * Lg * cg * (wg + 4) + (B * Lh * (4 * 1 + wo * ch) if w1 is not None else B * Lh * ch * (4 + wo)) + (4 * B * Lh * ch // 2 if add_even is not None else 0)
+              + (wg * B * Lh * cg // 2 if gpre is not None else 0) + (4 * B * Lh * ch if y3p is not None else 0))
     flops = 2 * B * Lg * cg * ch * 3 * 2
-    if split_precision:
-        key = f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch, stride, gpre is not None) // 64}, {1 if stride == 2 else 0}, {1 if gpre is not None else 0}, {1 if w1 is not None else 0}>'
+    if split_precision or gmode:
+        key = (f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch, stride, gpre is not None) // 64}, {1 if stride == 2 else 0}, '
+               f'{1 if gpre is not None else 0}, {1 if w1 is not None else 0}, {gmode}>')
     else:
         key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch, stride) // 64}, {1 if stride == 2 else 0}, 1>'
     if DETAIL:
         key += f' L{Lh}'
     _timed(key, nbytes, flops, run)
+
+
+def bwd_wide_tile(cg, ch) -> int:
+    return load().w2s_bwd_wide_tile(cg, ch)
+
+
+def bwd_wide_groups(cg, ch) -> int:
+    return load().w2s_bwd_wide_groups(cg, ch)
+
+
+def bwd_wide_takes(B, L, cg, ch) -> bool:
+    """Would w2s_bwd_wide take this launch (instance exists, the statistics tables of B samples fit its LDS)?"""
+    return load().w2s_bwd_wide(None, None, None, None, None, None, None, None, None, None, None, None, 0, B, L, cg, ch, 1, None) == 0
+
+
+def bwd_wide(*, g, y, st_k, bst_k, xin, st_in, add_even, w_hi, w_lo, gout, part, slab, nslab, B, L, cg, ch):
+    def run():
+        _chk(load().w2s_bwd_wide(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(st_in), _f(add_even), _p(w_hi), _p(w_lo), _f(gout), _f(part), _f(slab), nslab,
+                                 B, L, cg, ch, 0, _stream()), f'w2s_bwd_wide(cg={cg},ch={ch})')
+    nbytes = 4 * (2 * B * L * cg + 2 * B * L * ch + (B * L * ch // 2 if add_even is not None else 0))
+    key = f'bwd_wide_kernel<{cg // 16}, {ch // 16}, {1 if st_in is not None else 0}>'
+    if DETAIL:
+        key += f' L{L}'
+    _timed(key, nbytes, 2 * B * L * cg * ch * 3 * 2, run)
 
 
 def wgrad_slabs_per_block(cin, cout, taps, dil=1) -> int:
@@ -406,12 +446,22 @@ def enc_first_join(x, wd, y3, stats3, pre, B, L, cout):
     _chk(load().w2s_enc_first_join(_f(x), _f(wd), _f(y3), _f(stats3), _f(pre), B, L, cout, _stream()), 'w2s_enc_first_join')
 
 
-def enc_first_bwd(x, gn1, y1, stats1, bstats1, gpre, slab, nslab, B, L, cout, w1=None, causal=False):
+def enc_first_bwd(x, gn1, y1, stats1, bstats1, gpre, slab, nslab, B, L, cout, w1=None, causal=False, hdr_n=None, hdr_p=None):
+    if gn1.dtype == torch.float16:   # the fp16 gradient chain
+        _chk(load().w2s_enc_first_bwd_h(_f(x), _h(gn1), _f(hdr_n), _f(y1), _f(stats1), _f(bstats1), _h(gpre), _f(hdr_p), _f(slab), nslab, B, L, cout, _f(w1),
+                                        int(causal), _stream()), 'w2s_enc_first_bwd_h')
+        return
     _chk(load().w2s_enc_first_bwd(_f(x), _f(gn1), _f(y1), _f(stats1), _f(bstats1), _f(gpre), _f(slab), nslab, B, L, cout, _f(w1), int(causal), _stream()),
          'w2s_enc_first_bwd')
 
 
-def gp_stats(g, y, stats, part, B, L, Cc, tile, stat_out=None, stat_cnt=None):
+def gp_stats(g, y, stats, part, B, L, Cc, tile, stat_out=None, stat_cnt=None, hdr_g=None, hdr_amax=None):
+    """hdr_g: g is an fp16 chain tensor with that header; hdr_amax (fp32 g): also publish {1, max |g|} there (the chain's entry)."""
+    if hdr_g is not None or hdr_amax is not None:
+        half = g.dtype == torch.float16
+        _chk(load().w2s_gp_stats_h(_h(g) if half else _f(g), int(half), _f(hdr_g), _f(hdr_amax), _f(y), _f(stats), _f(part), B, L, Cc, tile, _stream()),
+             'w2s_gp_stats_h')
+        return
     _chk(load().w2s_gp_stats(_f(g), _f(y), _f(stats), _f(part), B, L, Cc, tile, _f(stat_out), _p(stat_cnt), _stream()), 'w2s_gp_stats')
 
 
