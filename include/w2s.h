@@ -203,20 +203,22 @@ int w2s_enc_first_bwd_h(const float* x, const void* gn1, const float* hdr_n, con
                         void* stream);
 
 /*
- * Fused backward of one k=3 / stride-1 / symmetric-padding encoder conv with cg = 64 gradient-side channels and ch = 64 or 32 input-side
- * channels (round 3, csrc/bwd_wide.hip): data gradient + weight gradient + GELU' + backward statistics in one persistent role-split pass
- * -- the >= 64-channel counterpart of w2s_bwd_fused (same formulas; gy = instance-norm backward of g with (st_k, bst_k); h = GELU(IN(xin))
- * with st_in, or GELU(xin) when st_in == NULL).  w_hi / w_lo: the data-gradient operand planes of the conv weight (w2s_repack_batch
- * bwd_hi / bwd_lo).  part: [B][ceil(L/tile)][groups][2][ch] partial sums of gout and gout*n_in (tile / groups from the two queries
- * below), or NULL.  slab: nslab (= grid size, <= B*ceil(L/tile)) raw-fragment slabs of cg*3*ch floats -> w2s_wgrad_reduce(slab, nslab,
- * grad, cg, ch, 3, 1, ...).  Returns 1 when no instance takes the launch (dry != 0: only that answer, nothing is launched).
+ * Fused backward of one k=3 / symmetric-padding encoder conv with cg = 64 gradient-side channels (round 3, csrc/bwd_wide.hip): data
+ * gradient + weight gradient + GELU' + backward statistics in one persistent role-split pass -- the >= 64-channel counterpart of
+ * w2s_bwd_fused (same formulas).  stride 1: ch = 64 or 32 input-side channels, gy = instance-norm backward of g with (st_k, bst_k), h =
+ * GELU(IN(xin)) with st_in or GELU(xin) when st_in == NULL.  stride 2 (the block's conv3; ch = 64, st_in required): g = dL/d(block
+ * pre-activation) [B][L/2][cg], gy = instance-norm backward of g * GELU'(n_k).  L = input-side length.  w_hi / w_lo: the data-gradient
+ * operand planes of the conv weight (w2s_repack_batch bwd_hi / bwd_lo).  part: [B][ceil(L/tile)][groups][2][ch] partial sums of gout and
+ * gout*n_in (tile / groups from the two queries below), or NULL.  slab: nslab (= grid size, <= B*ceil(L/tile)) raw-fragment slabs of
+ * cg*3*ch floats -> w2s_wgrad_reduce(slab, nslab, grad, cg, ch, 3, 1, ...).  Returns 1 when no instance takes the launch (dry != 0: only
+ * that answer, nothing is launched; st_in then only says whether the input side carries statistics).
  * Replaces aten::convolution_backward + native_batch_norm_backward + gelu_backward of blocks.py:173-186 for those layers.
  */
-int w2s_bwd_wide_tile(int cg, int ch);     /* positions per tile (0: no instance for this channel pair) */
-int w2s_bwd_wide_groups(int cg, int ch);   /* statistics-partial rows per tile */
+int w2s_bwd_wide_tile(int cg, int ch, int stride);     /* input-side positions per tile (0: no instance) */
+int w2s_bwd_wide_groups(int cg, int ch, int stride);   /* statistics-partial rows per tile */
 int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                  const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B, int L,
-                 int cg, int ch, int dry, void* stream);
+                 int cg, int ch, int stride, int dry, void* stream);
 
 /* In-kernel finalisation (stat_out / stat_cnt arguments of the producers above): the workgroup that writes the LAST partial of a sample
  * reduces all of that sample's partials in a fixed order (fp64) -- same result as this call, one launch less per layer.  stat_cnt is a

@@ -523,45 +523,53 @@ def t_fused_residual_fold():
             report(f'fold {cg}->{ch} L{Lh} conv3 statistics', pt.sum(1), pg.sum(1), tol=2e-4)
 
 def t_bwd_wide():
-    """One-pass backward of the 64-channel stride-1 convs (bwd_wide.hip) against the two kernels it replaces on the same tensors: the
-    conv_wide data gradient (instance-norm-backward prologue, GELU' epilogue, residual add, backward statistics) and the wgrad_wide weight
-    gradient.  Same split-precision products, so the bars are tight (the erf evaluation is shared here, separate there)."""
+    """One-pass backward of the 64-channel convs (bwd_wide.hip; stride 1 and the stride-2 conv3) against the two kernels it replaces on the
+    same tensors: the conv_wide data gradient (instance-norm-backward prologue, GELU' epilogue, residual add, backward statistics) and the
+    wgrad_wide weight gradient.  Same split-precision products in the same order: the bars are tight."""
     B = 3
-    for (cg, ch, L, hst, add_even) in [(64, 64, 1000, True, False), (64, 64, 777, False, True), (64, 32, 500, False, True), (64, 64, 64, True, False),
-                                       (64, 32, 130, False, True), (64, 64, 4098, True, False), (64, 32, 2050, True, False)]:
-        g = torch.randn(B, L, cg, device=dev) * 0.1; y = torch.randn(B, L, cg, device=dev) * 2 + 0.2; x = torch.randn(B, L, ch, device=dev) * 1.3 - 0.1
+    for (cg, ch, L, hst, add_even, stride) in [(64, 64, 1000, True, False, 1), (64, 64, 777, False, True, 1), (64, 32, 500, False, True, 1), (64, 64, 64, True, False, 1),
+                                               (64, 32, 130, False, True, 1), (64, 64, 4098, True, False, 1), (64, 32, 2050, True, False, 1),
+                                               (64, 64, 1000, True, False, 2), (64, 64, 64, True, False, 2), (64, 64, 4098, True, False, 2), (64, 64, 130, True, False, 2)]:
+        Lg = L // stride
+        g = torch.randn(B, Lg, cg, device=dev) * 0.1; y = torch.randn(B, Lg, cg, device=dev) * 2 + 0.2; x = torch.randn(B, L, ch, device=dev) * 1.3 - 0.1
         st = torch.stack([torch.randn(B, cg, device=dev) * 0.1, torch.rand(B, cg, device=dev) + 0.5], dim=-1).contiguous()
         bst = (torch.randn(B, cg, 2, device=dev) * 0.01).contiguous()
         sti = torch.stack([torch.randn(B, ch, device=dev) * 0.1, torch.rand(B, ch, device=dev) + 0.5], dim=-1).contiguous() if hst else None
         ev = torch.randn(B, L // 2, ch, device=dev) * 0.05 if add_even else None
         w = torch.randn(cg, ch, 3) / math.sqrt(3 * ch)
         wb = w.permute(1, 2, 0).contiguous().to(dev); wh, wl = lib.frag_major_planes(wb.view(ch, 3 * cg))
+        pro_g = lib.PRO_INBWD if stride == 1 else lib.PRO_INBWD_GP
         # the separate kernels
         gout0 = torch.zeros(B, L, ch, device=dev)
-        a = lib.conv_args(x=g, x2=y, w=wb, w_hi=wh, w_lo=wl, y=gout0, B=B, L_in=L, L_out=L, cin=cg, cout=ch, taps=3, stride=1, pad=1, flip=1, pro=lib.PRO_INBWD,
-                          pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=x, aux_stats=sti, add_even=ev)
+        if stride == 1:
+            a = lib.conv_args(x=g, x2=y, w=wb, w_hi=wh, w_lo=wl, y=gout0, B=B, L_in=L, L_out=L, cin=cg, cout=ch, taps=3, stride=1, pad=1, flip=1, pro=pro_g,
+                              pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=x, aux_stats=sti, add_even=ev)
+        else:
+            a = lib.conv_args(x=g, x2=y, w=wb, w_hi=wh, w_lo=wl, y=gout0, B=B, L_in=Lg, L_out=L, cin=cg, cout=ch, taps=3, stride=2, pad=1, mode=lib.MODE_UP2,
+                              pro=pro_g, pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=x, aux_stats=sti)
         t0 = lib.conv_tile_of(a); nt0 = (L + t0 - 1) // t0
         part0 = torch.zeros(B, nt0, 2, ch, device=dev); lib.set_part(a, part0)
         lib.conv_forward(a)
-        kw = dict(g=g, g2=y, g_stats=st, g_bstats=bst, x=x, x_stats=sti, B=B, L_in=L, L_out=L, cin=ch, cout=cg, taps=3, stride=1, pad=1, pro_g=lib.PRO_INBWD,
+        kw = dict(g=g, g2=y, g_stats=st, g_bstats=bst, x=x, x_stats=sti, B=B, L_in=L, L_out=Lg, cin=ch, cout=cg, taps=3, stride=stride, pad=1, pro_g=pro_g,
                   pro_h=lib.PRO_IN_GELU if hst else lib.PRO_GELU, split_precision=True)
-        ns0 = min(5, (B * L + 255) // 256)
+        ns0 = min(5, (B * Lg + 255) // 256)
         slab0 = torch.zeros(ns0 * cg * ch * 3, device=dev); lib.wgrad(slab=slab0, nslab=ns0, **kw)
         gw0 = torch.zeros(cg, ch, 3, device=dev); lib.wgrad_reduce(slab0, ns0, gw0, cg, ch, 3, 1)
         # the fused kernel, with few and with many workgroups
-        tile, groups = lib.bwd_wide_tile(cg, ch), lib.bwd_wide_groups(cg, ch)
+        tile, groups = lib.bwd_wide_tile(cg, ch, stride), lib.bwd_wide_groups(cg, ch, stride)
         nt = (L + tile - 1) // tile
-        RES.append((f'bwd_wide {cg}->{ch} L{L} is taken', lib.bwd_wide_takes(B, L, cg, ch) and tile == 64))
+        RES.append((f'bwd_wide {cg}->{ch} s{stride} L{L} is taken', lib.bwd_wide_takes(B, L, cg, ch, stride, hst) and tile == 64))
         for ns in (min(5, B * nt), min(256, B * nt)):
             gout = torch.full((B, L, ch), float('nan'), device=dev); part = torch.full((B, nt * groups, 2, ch), float('nan'), device=dev)
             slab = torch.full((ns * cg * ch * 3,), float('nan'), device=dev)
             lib.bwd_wide(g=g, y=y, st_k=st, bst_k=bst, xin=x, st_in=sti, add_even=ev, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab, nslab=ns, B=B, L=L,
-                         cg=cg, ch=ch)
+                         cg=cg, ch=ch, stride=stride)
             gw = torch.zeros(cg, ch, 3, device=dev); lib.wgrad_reduce(slab, ns, gw, cg, ch, 3, 1)
-            tag = f'bwd_wide {cg}->{ch} L{L} hst{int(hst)} ev{int(add_even)} wgs{ns}'
+            tag = f'bwd_wide {cg}->{ch} s{stride} L{L} hst{int(hst)} ev{int(add_even)} wgs{ns}'
             report(tag + ' gout', gout, gout0, tol=2e-6)
             report(tag + ' statistics sums', part.sum(1), part0.sum(1), tol=2e-5)
             report(tag + ' wgrad', gw, gw0, tol=2e-5)
+    RES.append(('bwd_wide refuses a batch whose statistics tables do not fit its LDS', not lib.bwd_wide_takes(48, 640, 64, 64, 1, True) and lib.bwd_wide_takes(40, 640, 64, 64, 1, False)))
 
 def t_grad_fp16_chain():
     """The fp16 gradient-chain forms of the fused backward kernels (gmode 1 / 2, include/w2s.h) against the fp32 kernels: a power-of-two

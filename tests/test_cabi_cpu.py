@@ -75,3 +75,16 @@ def test_cpu_tensors_are_refused(built_lib):
     import torch
     with pytest.raises(built_lib.W2SError):
         built_lib.eltwise(0, torch.zeros(4), None, torch.zeros(4), 4)
+
+
+def test_library_has_no_packed_fp32_instruction_with_src1_high_half_in_the_low_lane():
+    """gfx950 erratum found in round 3 (tools/pk_fma_opsel_repro.hip): v_pk_{fma,mul,add}_f32 with op_sel:[x,1,..] return wrong low-lane
+    results while a bf16 MFMA runs on the same CU.  The shipped code objects must not contain that form (wav2sleep_amd/isa_audit.py)."""
+    import os
+    import pytest
+    from wav2sleep_amd import isa_audit, lib
+    if not os.path.exists(isa_audit.OBJDUMP):
+        pytest.skip('llvm-objdump not in this image')
+    n, bad = isa_audit.audit(lib.LIB_PATH)
+    assert n > 100000, n          # the disassembly really saw the kernels
+    assert not bad, bad[:10]

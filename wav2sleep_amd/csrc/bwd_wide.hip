@@ -1,4 +1,4 @@
-// Backward of one k=3 / stride-1 encoder convolution with 64 gradient-side channels in ONE pass: data gradient + weight gradient +
+// Backward of one k=3 encoder convolution (stride 1, or the block's stride-2 conv3) with 64 gradient-side channels in ONE pass: data gradient + weight gradient +
 // GELU' + backward statistics from the same staged tiles -- the >= 64-channel counterpart of bwd_fused_bf_kernel, in the persistent
 // role-split form of conv_wide_kernel / wgrad_wide_kernel (round 3).
 //
@@ -7,6 +7,8 @@
 //   h      = GELU(n_in),  gp = GELU'(n_in)                                                 (ONE erf evaluation for both)
 //   dgrad :  gout[t][c] = (sum_{j,o} W[o][c][j] gy[t+1-j][o]  [+ add_even[t/2][c] at even t]) * gp[t][c];  partial sums of gout, gout*n_in
 //   wgrad :  dW[o][j][c] = sum_t gy[t][o] h[t+j-1][c]
+// UP2 (the stride-2 conv3, g = dL/d(block pre-activation) at half the length): gy = instance-norm backward of g * GELU'(n_k) (W2S_PRO_INBWD_GP);
+//   dgrad: gout[2u] = W_1^T gy[u], gout[2u+1] = W_2^T gy[u] + W_0^T gy[u+1];  wgrad: dW[o][j][c] = sum_u gy[u][o] h[2u+j-1][c]
 //
 // Before: conv_wide (dgrad) and wgrad_wide each streamed g, y_k and xin, each ran the instance-norm backward on g, one evaluated GELU'
 // and the other GELU of the same n_in (two erf's) -- 7 tensor passes and twice the producer arithmetic for 4 passes' worth of work
@@ -27,7 +29,7 @@ struct BwdWideP {
   const float* xin; const float* st_in; const float* add_even;
   const __bf16* w_hi; const __bf16* w_lo;   // data-gradient operand: [cin][taps][cout] as fragment-major planes (w2s_repack_batch bwd_hi / bwd_lo)
   float* gout; float* part; float* slab;
-  int B, L, ntiles;
+  int B, L, Lg, ntiles;   // L: input-side length; Lg: gradient-side length (L, or L / 2 for the stride-2 form)
 };
 
 typedef __bf16 wbbf16x4 __attribute__((ext_vector_type(4)));
@@ -47,14 +49,17 @@ __device__ __forceinline__ bf16x8 wb_tr8(const __bf16* p0, const __bf16* p1) {
 
 // CO / CI: 16-channel tiles on the gradient / input side; HST: xin carries statistics (conv2); MT: 16-position m-tiles per tile;
 // NWC consumer waves = (CO / IB) x (CI / CB) weight-gradient owners = CI x (NWC / CI) data-gradient owners; PD: producer prefetch depth
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD>
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0>
 __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
   extern __shared__ f32x4 smem4[];
   static_assert((CO / IB) * (CI / CB) == NWC && NWC % CI == 0 && MT % (NWC / CI) == 0, "consumer wave grid");
-  constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NPT = 256, NR = TM + 2;   // window rows: positions t0 - 1 .. t0 + TM
+  static_assert(!UP2 || (NWC == CI && MT % 2 == 0 && (8 * MT) % 32 == 0), "stride-2 form: one position group, even / odd m-tiles");
+  constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NPT = 256, NR = TM + 2;   // h window rows: positions t0 - 1 .. t0 + TM
+  constexpr int NRG = UP2 ? TM / 2 + 1 : TM + 2;                                     // gy window rows: t0 - 1 .. t0 + TM (UP2: t0/2 .. t0/2 + TM/2)
+  constexpr int TG = UP2 ? TM / 2 : TM;                                              // gradient-side positions per tile
   constexpr int RSg = OC + 16, RSh = HC + 8;                                         // bf16 elements per LDS row
   constexpr int RSp = HC + 4;                                                        // floats per row of the gp plane
-  constexpr int BUFH = 2 * NR * RSg + 2 * NR * RSh;                                  // bf16 elements: gy hi, gy lo, h hi, h lo
+  constexpr int BUFH = 2 * NRG * RSg + 2 * NR * RSh;                                 // bf16 elements: gy hi, gy lo, h hi, h lo
   constexpr int BUFB = BUFH * 2 + TM * RSp * 4;                                      // bytes of one buffer (gp plane behind the bf16 planes)
   static_assert(BUFB % 16 == 0, "buffer alignment");
   constexpr int PG = NWC / CI, MTW = MT / PG;                                        // position groups / m-tiles per wave of the data gradient
@@ -74,12 +79,12 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
 
   const int nt_wg = (total - first + step - 1) / step;            // >= 1 (the grid never exceeds the tile count)
   const int NI = ((nt_wg + 1 + PD - 1) / PD) * PD;                // barrier rounds, padded to whole prefetch cycles
-  const int L = P.L;
+  const int L = P.L, Lg = P.Lg;
 
   if (wave >= NWC) {
     // ================================================= producer waves =================================================
     const int pt = tid - 64 * NWC;
-    constexpr int c4g = OC / 4, rsg = NPT / c4g, NG = (NR + rsg - 1) / rsg;
+    constexpr int c4g = OC / 4, rsg = NPT / c4g, NG = (NRG + rsg - 1) / rsg;
     constexpr int c4h = HC / 4, rsh = NPT / c4h, NH = (NR + rsh - 1) / rsh;
     const int gch = (pt % c4g) * 4, grow0 = pt / c4g;
     const int hch = (pt % c4h) * 4, hrow0 = pt / c4h;
@@ -88,10 +93,10 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       constexpr int S = decltype(SET)::value;
       const int tl = first + min(i, nt_wg - 1) * step;
       const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
-      const int row = min(grow0 + k * rsg, NR - 1), gr = min(max(t0 - 1 + row, 0), L - 1);
+      const int row = min(grow0 + k * rsg, NRG - 1), gr = min(max((UP2 ? t0 / 2 : t0 - 1) + row, 0), Lg - 1);
       const unsigned off = (unsigned)gr * OC + gch;
-      rg[S][k] = ld4o(P.g + (size_t)b * L * OC, off);
-      ry[S][k] = ld4o(P.y + (size_t)b * L * OC, off);
+      rg[S][k] = ld4o(P.g + (size_t)b * Lg * OC, off);
+      ry[S][k] = ld4o(P.y + (size_t)b * Lg * OC, off);
     };
     auto load_h = [&](auto SET, int i, int k) {
       constexpr int S = decltype(SET)::value;
@@ -106,8 +111,8 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       const int tl = first + min(i, nt_wg - 1) * step;
       const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
       __bf16* gH = reinterpret_cast<__bf16*>(lds + (i & 1) * BUFB);
-      __bf16* gL = gH + NR * RSg;
-      __bf16* hH = gL + NR * RSg;
+      __bf16* gL = gH + NRG * RSg;
+      __bf16* hH = gL + NRG * RSg;
       __bf16* hL = hH + NR * RSh;
       float* gpL = reinterpret_cast<float*>(hL + NR * RSh);
       f32x4 pm, pr, ps1, ps2;
@@ -121,12 +126,12 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       }
 #pragma unroll
       for (int k = 0; k < NG; ++k) {
-        const int row = grow0 + k * rsg, gr = t0 - 1 + row;
+        const int row = grow0 + k * rsg, gr = (UP2 ? t0 / 2 : t0 - 1) + row;
         const f32x4 v1 = rg[S][k], v2 = ry[S][k];
         load_g(SET, i + PD, k);
-        if (live && row < NR) {
-          const f32x4 tv = pro_apply(W2S_PRO_INBWD, v1, v2, pm, pr, ps1, ps2);
-          wb_split_store4(gH, gL, row * RSg + gch, (gr >= 0 && gr < L) ? tv : (f32x4){0, 0, 0, 0});
+        if (live && row < NRG) {
+          const f32x4 tv = pro_apply(UP2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD, v1, v2, pm, pr, ps1, ps2);
+          wb_split_store4(gH, gL, row * RSg + gch, (gr >= 0 && gr < Lg) ? tv : (f32x4){0, 0, 0, 0});
         }
       }
       f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     const int tl = first + it * step;
     const int b = tl / P.ntiles, tile = tl % P.ntiles, t0 = tile * TM;
     const __bf16* gH = reinterpret_cast<const __bf16*>(lds + (it & 1) * BUFB);
-    const __bf16* gL = gH + NR * RSg;
-    const __bf16* hH = gL + NR * RSg;
+    const __bf16* gL = gH + NRG * RSg;
+    const __bf16* hH = gL + NRG * RSg;
     const __bf16* hL = hH + NR * RSh;
     const float* gpL = reinterpret_cast<const float*>(hL + NR * RSh);
     // epilogue operands of THIS tile, issued now so that their latency hides behind the MFMA loops: raw xin (statistics) and add_even
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       const float* eb = P.add_even ? P.add_even + (size_t)b * (L >> 1) * HC : nullptr;
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
-        const int pos = t0 + (dg * MTW + mt) * 16 + r;
+        const int pos = UP2 ? t0 + 2 * ((mt >> 1) * 16 + r) + (mt & 1) : t0 + (dg * MTW + mt) * 16 + r;
         ax[mt] = (pos < L) ? ld4o(xb, (unsigned)pos * HC + ch0) : (f32x4){0, 0, 0, 0};
         ae[mt] = (eb && !(pos & 1) && (pos >> 1) < (L >> 1)) ? ld4o(eb, (unsigned)(pos >> 1) * HC + ch0) : (f32x4){0, 0, 0, 0};
       }
@@ -220,7 +225,8 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       const int j = ks / QN, q = ks % QN;
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
-        const int row = (dg * MTW + mt) * 16 + r + 2 - j;
+        if (UP2 && (mt & 1) != (j == 1 ? 0 : 1)) continue;   // even outputs: tap 1; odd outputs: taps 2 (row u) and 0 (row u + 1)
+        const int row = UP2 ? (mt >> 1) * 16 + r + (j == 0 ? 1 : 0) : (dg * MTW + mt) * 16 + r + 2 - j;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(gH + row * RSg + q * 32 + 8 * g);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(gL + row * RSg + q * 32 + 8 * g);
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, acc[mt], 0, 0, 0);
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     float* ob = P.gout + (size_t)b * L * HC;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-      const int m = (dg * MTW + mt) * 16 + r, pos = t0 + m;
+      const int m = UP2 ? 2 * ((mt >> 1) * 16 + r) + (mt & 1) : (dg * MTW + mt) * 16 + r, pos = t0 + m;
       if (pos >= L) continue;
       const f32x4 v = (acc[mt] + ae[mt]) * ld4(gpL + m * RSp + ch0);
       const f32x4 n = (ax[mt] - am) * ar;
@@ -259,22 +265,24 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     }
     // ---- weight gradient: k-step = 32 positions; gradient-side position p <-> gy window row p + 1, h[t + j - 1] <-> window row p + j
 #pragma unroll
-    for (int s = 0; s < TM / 32; ++s) {
-      const int p0 = 32 * s + 8 * g + q4;   // this lane's address row (position) of the first 4-position block
+    for (int s = 0; s < TG / 32; ++s) {
+      const int p0 = 32 * s + 8 * g + q4;   // this lane's address row (gradient-side position) of the first 4-position block
+      const int gr0 = UP2 ? p0 : p0 + 1;    // its gy window row
       bf16x8 ah[IB], al[IB];
 #pragma unroll
       for (int i = 0; i < IB; ++i) {
         const int col = (wi * IB + i) * 16 + 4 * p4;
-        ah[i] = wb_tr8(gH + (p0 + 1) * RSg + col, gH + (p0 + 5) * RSg + col);
-        al[i] = wb_tr8(gL + (p0 + 1) * RSg + col, gL + (p0 + 5) * RSg + col);
+        ah[i] = wb_tr8(gH + gr0 * RSg + col, gH + (gr0 + 4) * RSg + col);
+        al[i] = wb_tr8(gL + gr0 * RSg + col, gL + (gr0 + 4) * RSg + col);
       }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
           const int col = (wc * CB + c) * 16 + 4 * p4;
-          const bf16x8 bh = wb_tr8(hH + (p0 + j) * RSh + col, hH + (p0 + 4 + j) * RSh + col);
-          const bf16x8 bl = wb_tr8(hL + (p0 + j) * RSh + col, hL + (p0 + 4 + j) * RSh + col);
+          const int h0 = UP2 ? 2 * p0 + j : p0 + j, h1 = UP2 ? 2 * (p0 + 4) + j : p0 + 4 + j;   // window row of h[(t or 2u) + j - 1]
+          const bf16x8 bh = wb_tr8(hH + h0 * RSh + col, hH + h1 * RSh + col);
+          const bf16x8 bl = wb_tr8(hL + h0 * RSh + col, hL + h1 * RSh + col);
 #pragma unroll
           for (int i = 0; i < IB; ++i) {
             accw[i][j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, accw[i][j][c], 0, 0, 0);
@@ -295,16 +303,16 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       for (int c = 0; c < CB; ++c) st4(out + (size_t)(((wi * IB + i) * 3 + j) * CI + wc * CB + c) * 256, accw[i][j][c]);
 }
 
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD>
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0>
 static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
-  constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NR = TM + 2;
+  constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NR = TM + 2, NRG = UP2 ? TM / 2 + 1 : TM + 2;
   BwdWideP P = P0;
   P.ntiles = (P.L + TM - 1) / TM;
-  const size_t lds = (size_t)2 * ((2 * NR * (OC + 16) + 2 * NR * (HC + 8)) * 2 + TM * (HC + 4) * 4) + (size_t)P.B * OC * 4 * 4 + (HST ? (size_t)P.B * HC * 2 * 4 : 0);
+  const size_t lds = (size_t)2 * ((2 * NRG * (OC + 16) + 2 * NR * (HC + 8)) * 2 + TM * (HC + 4) * 4) + (size_t)P.B * OC * 4 * 4 + (HST ? (size_t)P.B * HC * 2 * 4 : 0);
   if (lds > 160 * 1024) return 1;   // (batch too large for the LDS statistics tables: the caller runs the separate kernels)
   if (dry) return 0;
   if (nslab <= 0 || (long)nslab > (long)P.B * P.ntiles) return W2S_EINVAL;   // every workgroup writes a slab: it needs a tile
-  auto kern = bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD>;
+  auto kern = bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -313,25 +321,30 @@ static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
   return W2S_OK;
 }
 
-// positions per tile and statistics-partial rows per tile of the (cg, ch) instance; 0: no instance
-extern "C" int w2s_bwd_wide_tile(int cg, int ch) { return (cg == 64 && (ch == 64 || ch == 32)) ? 64 : 0; }
-extern "C" int w2s_bwd_wide_groups(int cg, int ch) { return (cg == 64 && ch == 32) ? 2 : (cg == 64 && ch == 64) ? 1 : 0; }
+// positions (input side) per tile and statistics-partial rows per tile of the (cg, ch, stride) instance; 0: no instance
+extern "C" int w2s_bwd_wide_tile(int cg, int ch, int stride) {
+  return (cg == 64 && ((ch == 64 && (stride == 1 || stride == 2)) || (ch == 32 && stride == 1))) ? 64 : 0;
+}
+extern "C" int w2s_bwd_wide_groups(int cg, int ch, int stride) { return !w2s_bwd_wide_tile(cg, ch, stride) ? 0 : (ch == 32) ? 2 : 1; }
 
-// One pass for the backward of a k=3 / stride-1 / symmetric-padding encoder conv with cg = 64 gradient-side and ch = 64 or 32 input-side
-// channels.  w_hi / w_lo: the data-gradient operand planes (w2s_repack_batch bwd_hi / bwd_lo of the conv's weight).  part: [B][ntiles]
-// [groups][2][ch] partial sums of gout and gout * n_in (rows = ntiles * groups for w2s_stats_finalize), or NULL.  slab: nslab slabs of
-// cg * 3 * ch floats (nslab = grid size <= B * ntiles) for w2s_wgrad_reduce(..., cg, ch, 3, 1, ...).  dry != 0: only answer whether an
-// instance takes this launch (0) or not (1).
+// One pass for the backward of a k=3 / symmetric-padding encoder conv with cg = 64 gradient-side channels: stride 1 with ch = 64 or 32
+// input-side channels, or stride 2 (the block's conv3: g = dL/d(block pre-activation), [B][L/2][cg]) with ch = 64.  L: input-side length.
+// w_hi / w_lo: the data-gradient operand planes (w2s_repack_batch bwd_hi / bwd_lo of the conv's weight).  part: [B][ntiles][groups][2][ch]
+// partial sums of gout and gout * n_in (rows = ntiles * groups for w2s_stats_finalize), or NULL.  slab: nslab slabs of cg * 3 * ch floats
+// (nslab = grid size <= B * ntiles) for w2s_wgrad_reduce(..., cg, ch, 3, 1, ...).  dry != 0: only answer whether an instance takes this
+// launch (0) or not (1) -- st_in then only says WHETHER the input side carries statistics (any non-NULL value).
 extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                             const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B,
-                            int L, int cg, int ch, int dry, void* stream) {
-  if (!w2s_bwd_wide_tile(cg, ch)) return 1;
+                            int L, int cg, int ch, int stride, int dry, void* stream) {
+  if (!w2s_bwd_wide_tile(cg, ch, stride)) return 1;
+  if (stride == 2 && (!st_in || add_even || (L & 1))) return dry ? 1 : W2S_EINVAL;
   if (!dry && (!g || !y || !st_k || !bst_k || !xin || !w_hi || !w_lo || !gout || !slab)) return W2S_EINVAL;
   if ((size_t)L * 64 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;   // 32-bit lane offsets inside one sample
   static const char* off = getenv("W2S_NO_BWD_WIDE");   // tuning only
   if (off) return 1;
-  BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, B, L, 0};
+  BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, B, L, L / stride, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stride == 2) return launch_bww<4, 4, 1, 4, 4, 2, 2, 2, 1>(P, nslab, s, dry);
   if (ch == 64) return st_in ? launch_bww<4, 4, 1, 4, 4, 2, 2, 2>(P, nslab, s, dry) : launch_bww<4, 4, 0, 4, 4, 2, 2, 2>(P, nslab, s, dry);
   return st_in ? launch_bww<4, 2, 1, 4, 4, 2, 1, 2>(P, nslab, s, dry) : launch_bww<4, 2, 0, 4, 4, 2, 1, 2>(P, nslab, s, dry);
 }

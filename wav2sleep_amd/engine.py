@@ -328,21 +328,21 @@ class Engine:
             return None
         return so if so is not None else self._bstats(part, B, nt, ch, Lh)
 
-    def _bwd_wide_ok(self, B, L, cg, ch):
-        """the one-pass backward of a >= 64-channel stride-1 conv (csrc/bwd_wide.hip): split precision, symmetric padding"""
-        return self.bwd_wide and self.split_precision and self.kpad == 1 and lib.bwd_wide_takes(B, L, cg, ch)
+    def _bwd_wide_ok(self, B, L, cg, ch, stride=1, hst=True):
+        """the one-pass backward of a 64-channel conv (csrc/bwd_wide.hip): split precision, symmetric padding; L = input-side length"""
+        return self.bwd_wide and self.split_precision and self.kpad == 1 and lib.bwd_wide_takes(B, L, cg, ch, stride, hst)
 
-    def _bwd_wide(self, name, *, g, y, st_k, bst_k, xin, st_in, add_even, gout, want_part, B, L, cg, ch):
-        """dgrad + wgrad + GELU' + backward statistics of one 64-channel k=3 / stride-1 conv in one pass; returns the statistics or None."""
+    def _bwd_wide(self, name, *, g, y, st_k, bst_k, xin, st_in, add_even, gout, want_part, B, L, cg, ch, stride=1):
+        """dgrad + wgrad + GELU' + backward statistics of one 64-channel k=3 conv in one pass; returns the statistics or None."""
         dev = g.device
-        tile, groups = lib.bwd_wide_tile(cg, ch), lib.bwd_wide_groups(cg, ch)
+        tile, groups = lib.bwd_wide_tile(cg, ch, stride), lib.bwd_wide_groups(cg, ch, stride)
         nt = _cdiv(L, tile)
         nslab = max(1, min(B * nt, 256))
         slab = self._slab(dev, nslab, cg * ch * 3)
         part = torch.empty(B, nt * groups, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         wh, wl = self._bf[self.PB[name].data_ptr()]
         lib.bwd_wide(g=g, y=y, st_k=st_k, bst_k=bst_k, xin=xin, st_in=st_in, add_even=add_even, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab,
-                     nslab=nslab, B=B, L=L, cg=cg, ch=ch)
+                     nslab=nslab, B=B, L=L, cg=cg, ch=ch, stride=stride)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         return self._bstats(part, B, nt * groups, ch, L) if want_part else None
@@ -960,11 +960,15 @@ class Engine:
                                       Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None,
                                       gmode=2 if h16 else 0, hdr_g=h2, hdr_o=h1)
             else:
-                bs2 = self._conv_part(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
-                                      pad=self.kpad, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP,
-                                      aux=blk['y2'], aux_stats=blk['st2'], kind=1)
-                self._wgrad(p + 'conv3.conv.weight', g=gpre, g2=blk['y3'], g_stats=blk['st3'], g_bstats=bs3, pro_g=lib.PRO_INBWD_GP, x=blk['y2'],
-                            x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=self.kpad)
+                if not (L & 1) and self._bwd_wide_ok(B, L, c, c, stride=2):
+                    bs2 = self._bwd_wide(p + 'conv3.conv.weight', g=gpre, y=blk['y3'], st_k=blk['st3'], bst_k=bs3, xin=blk['y2'], st_in=blk['st2'],
+                                         add_even=None, gout=gn2, want_part=True, B=B, L=L, cg=c, ch=c, stride=2)
+                else:
+                    bs2 = self._conv_part(x=gpre, x2=blk['y3'], w=PB[p + 'conv3.conv.weight'], y=gn2, B=B, L_in=Lh, L_out=L, cin=c, cout=c, taps=3, stride=2,
+                                          pad=self.kpad, mode=lib.MODE_UP2, pro=lib.PRO_INBWD_GP, pro_stats=blk['st3'], pro_bstats=bs3, epi=lib.EPI_GP,
+                                          aux=blk['y2'], aux_stats=blk['st2'], kind=1)
+                    self._wgrad(p + 'conv3.conv.weight', g=gpre, g2=blk['y3'], g_stats=blk['st3'], g_bstats=bs3, pro_g=lib.PRO_INBWD_GP, x=blk['y2'],
+                                x_stats=blk['st2'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=Lh, cin=c, cout=c, taps=3, stride=2, pad=self.kpad)
                 if self._bwd_wide_ok(B, L, c, c):
                     bs1 = self._bwd_wide(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, xin=blk['y1'], st_in=blk['st1'],
                                          add_even=None, gout=gn1, want_part=True, B=B, L=L, cg=c, ch=c)
@@ -996,7 +1000,7 @@ class Engine:
                     self._bwd_fused(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, pro=lib.PRO_INBWD, xin=blk['pin'],
                                     st_in=None, add_even=Rr, gout=gprev, want_part=False, B=B, Lg=L, Lh=L, cg=c, ch=cin, stride=1,
                                     gmode=2 if h16 else 0, hdr_g=h1, hdr_o=hp)
-                elif self._bwd_wide_ok(B, L, c, cin):
+                elif self._bwd_wide_ok(B, L, c, cin, hst=False):
                     self._bwd_wide(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, xin=blk['pin'], st_in=None, add_even=Rr,
                                    gout=gprev, want_part=False, B=B, L=L, cg=c, ch=cin)
                 else:

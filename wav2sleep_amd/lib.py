@@ -66,6 +66,12 @@ def build(verbose: bool = False) -> str:
         raise RuntimeError('building libw2s_hip.so failed:\n' + r.stdout[-4000:] + r.stderr[-4000:])
     if verbose:
         print(r.stdout[-2000:])
+    from .isa_audit import OBJDUMP, audit
+    if os.path.exists(OBJDUMP):   # the build must not contain the packed-fp32 form that misbehaves on gfx950 (isa_audit.py)
+        _, bad = audit(LIB_PATH)
+        if bad:
+            raise RuntimeError('libw2s_hip.so contains packed-fp32 instructions whose low lane reads the high half of src1 (wrong results on gfx950 '
+                               'beside bf16 MFMA waves, tools/pk_fma_opsel_repro.hip):\n' + '\n'.join(f'  {k}: {i}' for k, i in bad[:20]))
     return LIB_PATH
 
 
@@ -351,28 +357,29 @@ def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, s
     _timed(key, nbytes, flops, run)
 
 
-def bwd_wide_tile(cg, ch) -> int:
-    return load().w2s_bwd_wide_tile(cg, ch)
+def bwd_wide_tile(cg, ch, stride=1) -> int:
+    return load().w2s_bwd_wide_tile(cg, ch, stride)
 
 
-def bwd_wide_groups(cg, ch) -> int:
-    return load().w2s_bwd_wide_groups(cg, ch)
+def bwd_wide_groups(cg, ch, stride=1) -> int:
+    return load().w2s_bwd_wide_groups(cg, ch, stride)
 
 
-def bwd_wide_takes(B, L, cg, ch) -> bool:
-    """Would w2s_bwd_wide take this launch (instance exists, the statistics tables of B samples fit its LDS)?"""
-    return load().w2s_bwd_wide(None, None, None, None, None, None, None, None, None, None, None, None, 0, B, L, cg, ch, 1, None) == 0
+def bwd_wide_takes(B, L, cg, ch, stride=1, hst=True) -> bool:
+    """Would w2s_bwd_wide take this launch (instance exists, the statistics tables of B samples fit its LDS)?  L: input-side length."""
+    return load().w2s_bwd_wide(None, None, None, None, None, C.c_void_p(1) if hst else None, None, None, None, None, None, None, 0, B, L, cg, ch, stride, 1,
+                               None) == 0
 
 
-def bwd_wide(*, g, y, st_k, bst_k, xin, st_in, add_even, w_hi, w_lo, gout, part, slab, nslab, B, L, cg, ch):
+def bwd_wide(*, g, y, st_k, bst_k, xin, st_in, add_even, w_hi, w_lo, gout, part, slab, nslab, B, L, cg, ch, stride=1):
     def run():
         _chk(load().w2s_bwd_wide(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(st_in), _f(add_even), _p(w_hi), _p(w_lo), _f(gout), _f(part), _f(slab), nslab,
-                                 B, L, cg, ch, 0, _stream()), f'w2s_bwd_wide(cg={cg},ch={ch})')
-    nbytes = 4 * (2 * B * L * cg + 2 * B * L * ch + (B * L * ch // 2 if add_even is not None else 0))
-    key = f'bwd_wide_kernel<{cg // 16}, {ch // 16}, {1 if st_in is not None else 0}>'
+                                 B, L, cg, ch, stride, 0, _stream()), f'w2s_bwd_wide(cg={cg},ch={ch},stride={stride})')
+    nbytes = 4 * (2 * B * (L // stride) * cg + 2 * B * L * ch + (B * L * ch // 2 if add_even is not None else 0))
+    key = f'bwd_wide_kernel<{cg // 16}, {ch // 16}, {1 if st_in is not None else 0}, {stride}>'
     if DETAIL:
         key += f' L{L}'
-    _timed(key, nbytes, 2 * B * L * cg * ch * 3 * 2, run)
+    _timed(key, nbytes, 2 * B * (L // stride) * cg * ch * 3 * 2, run)
 
 
 def wgrad_slabs_per_block(cin, cout, taps, dil=1) -> int:
