@@ -218,7 +218,10 @@ int w2s_bwd_wide_tile(int cg, int ch, int stride);     /* input-side positions p
 int w2s_bwd_wide_groups(int cg, int ch, int stride);   /* statistics-partial rows per tile */
 int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                  const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B, int L,
-                 int cg, int ch, int stride, int dry, void* stream);
+                 int cg, int ch, int stride, const float* y3p, const float* st3p, int dry, void* stream);
+/* y3p != NULL (stride 1, part given): additionally fold the PREVIOUS block's conv3-backward pre-pass (w2s_gp_stats) in, as w2s_bwd_fused
+ * does: y3p = that block's pre-norm conv3 output [B][L][ch], st3p = its (mean, rstd) [B][ch][2]; `part` then holds the partial sums of
+ * gout*GELU'(n3) and gout*GELU'(n3)*n3, n3 = IN(y3p). */
 
 /* In-kernel finalisation (stat_out / stat_cnt arguments of the producers above): the workgroup that writes the LAST partial of a sample
  * reduces all of that sample's partials in a fixed order (fp64) -- same result as this call, one launch less per layer.  stat_cnt is a

@@ -569,6 +569,18 @@ def t_bwd_wide():
             report(tag + ' gout', gout, gout0, tol=2e-6)
             report(tag + ' statistics sums', part.sum(1), part0.sum(1), tol=2e-5)
             report(tag + ' wgrad', gw, gw0, tol=2e-5)
+        if stride == 1 and not hst:   # conv1 of a block: the previous block's conv3-backward statistics folded in vs the w2s_gp_stats pre-pass
+            y3p = torch.randn(B, L, ch, device=dev)
+            st3 = torch.stack([torch.randn(B, ch, device=dev) * 0.1, torch.rand(B, ch, device=dev) + 0.5], dim=-1).contiguous()
+            gout2 = torch.full((B, L, ch), float('nan'), device=dev); part2 = torch.full((B, nt * groups, 2, ch), float('nan'), device=dev)
+            slab2 = torch.zeros(ns * cg * ch * 3, device=dev)
+            lib.bwd_wide(g=g, y=y, st_k=st, bst_k=bst, xin=x, st_in=sti, add_even=ev, w_hi=wh, w_lo=wl, gout=gout2, part=part2, slab=slab2, nslab=ns, B=B, L=L,
+                         cg=cg, ch=ch, stride=1, y3p=y3p, st3p=st3)
+            ntg = (L + 511) // 512
+            pg = torch.zeros(B, ntg, 2, ch, device=dev)
+            lib.gp_stats(gout2, y3p, st3, pg, B, L, ch, 512)
+            report(f'bwd_wide {cg}->{ch} L{L} gout with the statistics fold', gout2, gout, tol=0)
+            report(f'bwd_wide {cg}->{ch} L{L} folded conv3 statistics', part2.sum(1), pg.sum(1), tol=2e-5)
     RES.append(('bwd_wide refuses a batch whose statistics tables do not fit its LDS', not lib.bwd_wide_takes(48, 640, 64, 64, 1, True) and lib.bwd_wide_takes(40, 640, 64, 64, 1, False)))
 
 def t_grad_fp16_chain():

@@ -29,6 +29,9 @@ struct BwdWideP {
   const float* xin; const float* st_in; const float* add_even;
   const __bf16* w_hi; const __bf16* w_lo;   // data-gradient operand: [cin][taps][cout] as fragment-major planes (w2s_repack_batch bwd_hi / bwd_lo)
   float* gout; float* part; float* slab;
+  // conv1 of a block (stride 1): fold the PREVIOUS block's conv3-backward pre-pass (w2s_gp_stats) in, as w2s_bwd_fused does: y3p = that block's
+  // pre-norm conv3 output [B][L][HC] (same positions as gout), st3p = its (mean, rstd); `part` then holds the sums of gout*GELU'(n3) and *n3
+  const float* y3p; const float* st3p;
   int B, L, Lg, ntiles;   // L: input-side length; Lg: gradient-side length (L, or L / 2 for the stride-2 form)
 };
 
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     // epilogue operands of THIS tile, issued now so that their latency hides behind the MFMA loops: raw xin (statistics) and add_even
     f32x4 ax[MTW], ae[MTW];
     {
-      const float* xb = P.xin + (size_t)b * L * HC;
+      const float* xb = P.y3p ? P.y3p + (size_t)b * L * HC : P.xin + (size_t)b * L * HC;   // statistics side: n_in, or the folded n3
       const float* eb = P.add_even ? P.add_even + (size_t)b * (L >> 1) * HC : nullptr;
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
@@ -237,7 +240,11 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     // ---- epilogue: * GELU'(n_in), statistics partials, store
     f32x4 sA = {0, 0, 0, 0}, sB = {0, 0, 0, 0};
     f32x4 am = {0, 0, 0, 0}, ar = {1, 1, 1, 1};
-    if (HST) {
+    if (P.y3p) {
+      const float* st = P.st3p + ((size_t)b * HC + ch0) * 2;
+      const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+      am = (f32x4){s01.x, s01.z, s23.x, s23.z}; ar = (f32x4){s01.y, s01.w, s23.y, s23.w};
+    } else if (HST) {
       const float* st = stL + P.B * OC * 4 + (b * HC + ch0) * 2;
       const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
       am = (f32x4){s01.x, s01.z, s23.x, s23.z}; ar = (f32x4){s01.y, s01.w, s23.y, s23.w};
@@ -249,8 +256,9 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       if (pos >= L) continue;
       const f32x4 v = (acc[mt] + ae[mt]) * ld4(gpL + m * RSp + ch0);
       const f32x4 n = (ax[mt] - am) * ar;
-      sA += v;
-      sB += v * n;
+      const f32x4 sv = P.y3p ? v * gelu_grad4(n) : v;   // folded: gn = gout * GELU'(n3), sums of gn and gn * n3
+      sA += sv;
+      sB += sv * n;
       st4o(ob, (unsigned)pos * HC + ch0, v);
     }
     if (P.part) {   // [B][ntiles][PG][2][HC]: one row per (tile, position group), written once
@@ -332,17 +340,19 @@ extern "C" int w2s_bwd_wide_groups(int cg, int ch, int stride) { return !w2s_bwd
 // w_hi / w_lo: the data-gradient operand planes (w2s_repack_batch bwd_hi / bwd_lo of the conv's weight).  part: [B][ntiles][groups][2][ch]
 // partial sums of gout and gout * n_in (rows = ntiles * groups for w2s_stats_finalize), or NULL.  slab: nslab slabs of cg * 3 * ch floats
 // (nslab = grid size <= B * ntiles) for w2s_wgrad_reduce(..., cg, ch, 3, 1, ...).  dry != 0: only answer whether an instance takes this
-// launch (0) or not (1) -- st_in then only says WHETHER the input side carries statistics (any non-NULL value).
+// launch (0) or not (1) -- st_in then only says WHETHER the input side carries statistics (any non-NULL value).  y3p / st3p (stride 1, with
+// part): fold the previous block's conv3-backward statistics pre-pass in (see BwdWideP).
 extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                             const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B,
-                            int L, int cg, int ch, int stride, int dry, void* stream) {
+                            int L, int cg, int ch, int stride, const float* y3p, const float* st3p, int dry, void* stream) {
   if (!w2s_bwd_wide_tile(cg, ch, stride)) return 1;
-  if (stride == 2 && (!st_in || add_even || (L & 1))) return dry ? 1 : W2S_EINVAL;
+  if (stride == 2 && (!st_in || add_even || (L & 1) || y3p)) return dry ? 1 : W2S_EINVAL;
+  if (y3p && (!st3p || !part)) return W2S_EINVAL;
   if (!dry && (!g || !y || !st_k || !bst_k || !xin || !w_hi || !w_lo || !gout || !slab)) return W2S_EINVAL;
   if ((size_t)L * 64 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;   // 32-bit lane offsets inside one sample
   static const char* off = getenv("W2S_NO_BWD_WIDE");   // tuning only
   if (off) return 1;
-  BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, B, L, L / stride, 0};
+  BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, y3p, st3p, B, L, L / stride, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (stride == 2) return launch_bww<4, 4, 1, 4, 4, 2, 2, 2, 1>(P, nslab, s, dry);
   if (ch == 64) return st_in ? launch_bww<4, 4, 1, 4, 4, 2, 2, 2>(P, nslab, s, dry) : launch_bww<4, 4, 0, 4, 4, 2, 2, 2>(P, nslab, s, dry);

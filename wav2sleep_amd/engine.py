@@ -332,7 +332,7 @@ class Engine:
         """the one-pass backward of a 64-channel conv (csrc/bwd_wide.hip): split precision, symmetric padding; L = input-side length"""
         return self.bwd_wide and self.split_precision and self.kpad == 1 and lib.bwd_wide_takes(B, L, cg, ch, stride, hst)
 
-    def _bwd_wide(self, name, *, g, y, st_k, bst_k, xin, st_in, add_even, gout, want_part, B, L, cg, ch, stride=1):
+    def _bwd_wide(self, name, *, g, y, st_k, bst_k, xin, st_in, add_even, gout, want_part, B, L, cg, ch, stride=1, y3p=None, st3p=None):
         """dgrad + wgrad + GELU' + backward statistics of one 64-channel k=3 conv in one pass; returns the statistics or None."""
         dev = g.device
         tile, groups = lib.bwd_wide_tile(cg, ch, stride), lib.bwd_wide_groups(cg, ch, stride)
@@ -342,7 +342,7 @@ class Engine:
         part = torch.empty(B, nt * groups, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         wh, wl = self._bf[self.PB[name].data_ptr()]
         lib.bwd_wide(g=g, y=y, st_k=st_k, bst_k=bst_k, xin=xin, st_in=st_in, add_even=add_even, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab,
-                     nslab=nslab, B=B, L=L, cg=cg, ch=ch, stride=stride)
+                     nslab=nslab, B=B, L=L, cg=cg, ch=ch, stride=stride, y3p=y3p, st3p=st3p)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         return self._bstats(part, B, nt * groups, ch, L) if want_part else None
@@ -980,6 +980,7 @@ class Engine:
                                 x_stats=blk['st1'], pro_h=lib.PRO_IN_GELU, B=B, L_in=L, L_out=L, cin=c, cout=c, taps=3, stride=1, pad=self.kpad)
             del gn2
             hp = new_hdr() if (h16 and i > 0) else None
+            h16_next = (i - 1) <= entry   # the block below is the fp16 chain's entry: its gp_stats launch also publishes max |gpre| (keep it)
             if i > 0 and self.split_precision and lib.bwd_fused_supported(c, cin) and lib.bwd_fused_folds_residual(c, cin) and not (L & 1):
                 # conv1 + the whole residual branch (its data gradient AND its weight gradient) in one pass over the tensors
                 gprev = torch.empty(B, L, cin, device=dev, dtype=gdt)
@@ -1001,8 +1002,11 @@ class Engine:
                                     st_in=None, add_even=Rr, gout=gprev, want_part=False, B=B, Lg=L, Lh=L, cg=c, ch=cin, stride=1,
                                     gmode=2 if h16 else 0, hdr_g=h1, hdr_o=hp)
                 elif self._bwd_wide_ok(B, L, c, cin, hst=False):
-                    self._bwd_wide(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, xin=blk['pin'], st_in=None, add_even=Rr,
-                                   gout=gprev, want_part=False, B=B, L=L, cg=c, ch=cin)
+                    # ... with the previous block's conv3-backward statistics pre-pass folded in (its gp_stats launch read gprev and y3 again)
+                    prev = ec['blocks'][i - 1] if (self.fold_gp and not h16_next) else None
+                    bs3_folded = self._bwd_wide(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, xin=blk['pin'], st_in=None,
+                                                add_even=Rr, gout=gprev, want_part=prev is not None, B=B, L=L, cg=c, ch=cin,
+                                                y3p=prev['y3'] if prev else None, st3p=prev['st3'] if prev else None)
                 else:
                     self._conv(x=gn1, x2=blk['y1'], w=PB[p + 'conv1.conv.weight'], y=gprev, B=B, L_in=L, L_out=L, cin=c, cout=cin, taps=3,
                                stride=1, pad=2 - self.kpad, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st1'], pro_bstats=bs1, epi=lib.EPI_GP, aux=blk['pin'],

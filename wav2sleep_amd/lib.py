@@ -367,15 +367,15 @@ def bwd_wide_groups(cg, ch, stride=1) -> int:
 
 def bwd_wide_takes(B, L, cg, ch, stride=1, hst=True) -> bool:
     """Would w2s_bwd_wide take this launch (instance exists, the statistics tables of B samples fit its LDS)?  L: input-side length."""
-    return load().w2s_bwd_wide(None, None, None, None, None, C.c_void_p(1) if hst else None, None, None, None, None, None, None, 0, B, L, cg, ch, stride, 1,
-                               None) == 0
+    return load().w2s_bwd_wide(None, None, None, None, None, C.c_void_p(1) if hst else None, None, None, None, None, None, None, 0, B, L, cg, ch, stride,
+                               None, None, 1, None) == 0
 
 
-def bwd_wide(*, g, y, st_k, bst_k, xin, st_in, add_even, w_hi, w_lo, gout, part, slab, nslab, B, L, cg, ch, stride=1):
+def bwd_wide(*, g, y, st_k, bst_k, xin, st_in, add_even, w_hi, w_lo, gout, part, slab, nslab, B, L, cg, ch, stride=1, y3p=None, st3p=None):
     def run():
         _chk(load().w2s_bwd_wide(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(st_in), _f(add_even), _p(w_hi), _p(w_lo), _f(gout), _f(part), _f(slab), nslab,
-                                 B, L, cg, ch, stride, 0, _stream()), f'w2s_bwd_wide(cg={cg},ch={ch},stride={stride})')
-    nbytes = 4 * (2 * B * (L // stride) * cg + 2 * B * L * ch + (B * L * ch // 2 if add_even is not None else 0))
+                                 B, L, cg, ch, stride, _f(y3p), _f(st3p), 0, _stream()), f'w2s_bwd_wide(cg={cg},ch={ch},stride={stride})')
+    nbytes = 4 * (2 * B * (L // stride) * cg + 2 * B * L * ch + (B * L * ch // 2 if add_even is not None else 0) + (B * L * ch if y3p is not None else 0))
     key = f'bwd_wide_kernel<{cg // 16}, {ch // 16}, {1 if st_in is not None else 0}, {stride}>'
     if DETAIL:
         key += f' L{L}'
