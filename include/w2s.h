@@ -83,7 +83,16 @@ typedef struct w2s_conv_args {
   int32_t pro, epi;
   float stat_eps;          /* variance epsilon of the in-kernel finalisation (models/wav2sleep.py:213-215: 1e-2) */
   int32_t reserved;        /* bit 0: y += result instead of y = result (a contraction split over several launches: cin > 128) */
+                           /* EPI_BIAS fusions of the set-fusion transformer (TransformerEncoderLayer, wav2sleep.py:286-296; W2S_FUSE_*):      */
+                           /* bit 1: y = aux + drop(result)            (residual add + dropout: x + Dropout(sublayer(x)))                       */
+                           /* bit 2: y2 = drop(GELU(y)) instead of GELU(y)   (linear1 -> activation -> dropout; y keeps the pre-activation)     */
+                           /* bit 3: y = result * GELU'(aux) * dropmask      (backward of bit 2 in the data-gradient GEMM of linear2)           */
+  float drop_p;            /* dropout probability of those fusions (0: no dropout) and the mask seed: the mask of element i of the [rows][ld]    */
+  uint64_t drop_seed;      /* output is keep / (1 - p) with the counter-based generator of w2s_eltwise's dropout modes at (drop_seed, i)            */
 } w2s_conv_args;
+#define W2S_FUSE_ADD_DROP 2
+#define W2S_FUSE_Y2_GELU_DROP 4
+#define W2S_FUSE_GELU_BWD_DROP 8
 
 /* positions per workgroup tile for (cin,cout); ntiles = ceil(L_out / tile) sizes `part`. */
 int w2s_conv_tile(const w2s_conv_args* a);

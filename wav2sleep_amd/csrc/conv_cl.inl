@@ -375,6 +375,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
       const size_t ob = (size_t)b * L_out;   // uniform row base; per-lane parts stay 32-bit
       if (epi == W2S_EPI_BIAS) {
         if (a.bias) v += ld4(a.bias + ch);
+        if (a.reserved & (W2S_FUSE_ADD_DROP | W2S_FUSE_GELU_BWD_DROP)) {   // uniform: the transformer's residual / activation-backward fusions
+          const size_t i0 = (ob + pos) * (size_t)a.ldy + ch;
+          f32x4 m = {1, 1, 1, 1};
+          if (a.drop_p > 0.f) {
+            m.x = w2s_dropscale(a.drop_seed, i0, a.drop_p); m.y = w2s_dropscale(a.drop_seed, i0 + 1, a.drop_p);
+            m.z = w2s_dropscale(a.drop_seed, i0 + 2, a.drop_p); m.w = w2s_dropscale(a.drop_seed, i0 + 3, a.drop_p);
+          }
+          const f32x4 ax = ld4o(a.aux + ob * a.ld_aux, (unsigned)pos * (unsigned)a.ld_aux + ch);
+          v = (a.reserved & W2S_FUSE_ADD_DROP) ? ax + v * m : v * m * gelu_grad4(ax);
+        }
       } else if (epi == W2S_EPI_AUX_INGELU_ADD) {
         f32x4 ax = ld4o(a.aux + ob * a.ld_aux, (unsigned)pos * (unsigned)a.ld_aux + ch);
         const float* st = a.aux_stats + ((size_t)b * cout + ch) * 2;
@@ -400,7 +410,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2
       v = v * keep;
       if (a.reserved & 1) v += ld4o(a.y + ob * a.ldy, (unsigned)pos * (unsigned)a.ldy + ch);   // accumulate: K split over several launches (generic path)
       st4o(a.y + ob * a.ldy, (unsigned)pos * (unsigned)a.ldy + ch, v);
-      if (a.y2) st4o(a.y2 + ob * a.ldy2, (unsigned)pos * (unsigned)a.ldy2 + ch, gelu4(v));
+      if (a.y2) {
+        f32x4 h = gelu4(v);
+        if ((a.reserved & W2S_FUSE_Y2_GELU_DROP) && a.drop_p > 0.f) {
+          const size_t i0 = (ob + pos) * (size_t)a.ldy2 + ch;
+          h.x *= w2s_dropscale(a.drop_seed, i0, a.drop_p); h.y *= w2s_dropscale(a.drop_seed, i0 + 1, a.drop_p);
+          h.z *= w2s_dropscale(a.drop_seed, i0 + 2, a.drop_p); h.w *= w2s_dropscale(a.drop_seed, i0 + 3, a.drop_p);
+        }
+        st4o(a.y2 + ob * a.ldy2, (unsigned)pos * (unsigned)a.ldy2 + ch, h);
+      }
     }
   }
 
@@ -539,7 +557,8 @@ static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
   // transformer / SequenceCNN GEMMs (no on-load transform): without the prologue variants the 128-wide instance keeps its
   // accumulators in AGPRs and two waves per SIMD
   if constexpr ((MODE == W2S_MODE_CONTIG && TAPS == 1 && STRIDE == 1) || (MODE == W2S_MODE_DILATED && TAPS == STRIDE))
-    if (plain_io && a.pro == W2S_PRO_NONE && a.epi == W2S_EPI_BIAS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_NONE, W2S_EPI_BIAS>(a, s);
+    if (!a.rowkeep && !(a.reserved & 1) && (!a.y2 || (a.reserved & W2S_FUSE_Y2_GELU_DROP)) && a.pro == W2S_PRO_NONE && a.epi == W2S_EPI_BIAS)
+      return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_NONE, W2S_EPI_BIAS>(a, s);   // (the residual / dropout / GELU fusions of the transformer included)
   if constexpr (MODE == W2S_MODE_CONTIG && TAPS == 1 && STRIDE == 1)
     if (plain_io && a.pro == W2S_PRO_NONE && a.epi == W2S_EPI_PLAIN) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_NONE, W2S_EPI_PLAIN>(a, s);
   if constexpr (TAPS == 7 && STRIDE == 1)

@@ -267,18 +267,19 @@ class Engine:
         return y, self._conv_part(x=x, x2=x2, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=self.kpad, pro=pro,
                                   pro_stats=pro_stats, epi=lib.EPI_STATS, kind=0, **({'ldx': 4} if pro == lib.PRO_FIRST else {}))
 
-    def _linear(self, x, w, bias, rows, cin, cout, ldx=None, y=None, ldy=None):
-        """y[rows, cout] = x[rows, cin(*k)] @ w^T + bias; cin > 128 runs as k = cin/128 strided taps."""
+    def _linear(self, x, w, bias, rows, cin, cout, ldx=None, y=None, ldy=None, **fuse):
+        """y[rows, cout] = x[rows, cin(*k)] @ w^T + bias; cin > 128 runs as k = cin/128 strided taps.
+        fuse: epilogue fusions of the transformer layer (lib.conv_args: fuse=FUSE_*, aux, y2, drop_p, drop_seed)."""
         if y is None:
             y = torch.empty(rows, cout, device=x.device, dtype=torch.float32)
         if cin <= 128:
             self._conv(x=x, w=w, y=y, B=1, L_in=rows, L_out=rows, cin=cin, cout=cout, taps=1, stride=1, pad=0, ldx=ldx, ldy=ldy,
-                       epi=lib.EPI_BIAS, bias=bias)
+                       epi=lib.EPI_BIAS, bias=bias, **fuse)
         else:
             k = cin // 128
             assert cin % 128 == 0 and k in (3, 4) and ldx is None
             self._conv(x=x, w=w, y=y, B=1, L_in=rows * k, L_out=rows, cin=128, cout=cout, taps=k, stride=k, pad=0, mode=lib.MODE_DILATED,
-                       ldy=ldy, epi=lib.EPI_BIAS, bias=bias)
+                       ldy=ldy, epi=lib.EPI_BIAS, bias=bias, **fuse)
         return y
 
     def _slab(self, dev, nslab, n):
@@ -590,19 +591,18 @@ class Engine:
             qkv = self._linear(h, P[p + 'self_attn.in_proj_weight'], P[p + 'self_attn.in_proj_bias'], R, F, 3 * F)
             ao = torch.empty(R, F, device=dev, dtype=torch.float32)
             lib.attn_fwd(qkv, keypad, ao, N, D, sp.mixer_nhead, pm, self._seed(10 * l + 1))
-            proj = self._linear(ao, P[p + 'self_attn.out_proj.weight'], P[p + 'self_attn.out_proj.bias'], R, F, F)
-            X1 = torch.empty(R, F, device=dev, dtype=torch.float32)
-            lib.eltwise(lib.ELT_ADD_DROP, X, proj, X1, R * F, pm, self._seed(10 * l + 2))
+            # x + Dropout(out_proj(attention)): the residual add and the dropout ride in the projection's epilogue (no `proj` tensor)
+            X1 = self._linear(ao, P[p + 'self_attn.out_proj.weight'], P[p + 'self_attn.out_proj.bias'], R, F, F, fuse=lib.FUSE_ADD_DROP, aux=X,
+                              drop_p=pm, drop_seed=self._seed(10 * l + 2))
             h2 = torch.empty(R, F, device=dev, dtype=torch.float32)
             rs2 = torch.empty(R, 2, device=dev, dtype=torch.float32)
             lib.layernorm_fwd(X1, F, P[p + 'norm2.weight'], P[p + 'norm2.bias'], h2, F, rs2, R, F, sp.layer_eps)
             FF = sp.mixer_dim_ff
-            f1 = self._linear(h2, P[p + 'linear1.weight'], P[p + 'linear1.bias'], R, F, FF)
-            a1 = torch.empty(R, FF, device=dev, dtype=torch.float32)
-            lib.eltwise(lib.ELT_GELU_DROP, f1, None, a1, R * FF, pm, self._seed(10 * l + 3))
-            f2 = self._linear(a1, P[p + 'linear2.weight'], P[p + 'linear2.bias'], R, FF, F)
-            X2 = torch.empty(R, F, device=dev, dtype=torch.float32)
-            lib.eltwise(lib.ELT_ADD_DROP, X1, f2, X2, R * F, pm, self._seed(10 * l + 4))
+            a1 = torch.empty(R, FF, device=dev, dtype=torch.float32)   # Dropout(GELU(linear1)): second output of linear1's epilogue
+            f1 = self._linear(h2, P[p + 'linear1.weight'], P[p + 'linear1.bias'], R, F, FF, fuse=lib.FUSE_Y2_GELU_DROP, y2=a1, ldy2=FF, drop_p=pm,
+                              drop_seed=self._seed(10 * l + 3))
+            X2 = self._linear(a1, P[p + 'linear2.weight'], P[p + 'linear2.bias'], R, FF, F, fuse=lib.FUSE_ADD_DROP, aux=X1, drop_p=pm,
+                              drop_seed=self._seed(10 * l + 4))
             if save:
                 layers.append(dict(X=X, rs1=rs1, h=h, qkv=qkv, ao=ao, X1=X1, rs2=rs2, h2=h2, f1=f1, a1=a1))
             X = X2
@@ -755,9 +755,9 @@ class Engine:
             self._colgrad(p + 'linear2.bias', gf2, R, F)
             self._wgrad(p + 'linear2.weight', g=gf2, x=L['a1'], B=1, L_in=R * (FF // 128), L_out=R, cin=128, cout=F, taps=FF // 128,
                         stride=FF // 128, pad=0, layout=1)
-            ga1 = self._linear(gf2, PB[p + 'linear2.weight'], None, R, F, FF)
-            gf1 = torch.empty(R, FF, device=dev, dtype=torch.float32)
-            lib.eltwise(lib.ELT_GELU_DROP_BWD, L['f1'], ga1, gf1, R * FF, pm, self._seed(10 * l + 3))
+            # d/d(linear1 output) = (W2^T g) * dropmask * GELU'(f1): in the data-gradient GEMM's epilogue
+            gf1 = self._linear(gf2, PB[p + 'linear2.weight'], None, R, F, FF, fuse=lib.FUSE_GELU_BWD_DROP, aux=L['f1'], ld_aux=FF, drop_p=pm,
+                               drop_seed=self._seed(10 * l + 3))
             self._colgrad(p + 'linear1.bias', gf1, R, FF)
             self._wgrad(p + 'linear1.weight', g=gf1, x=L['h2'], B=1, L_in=R, L_out=R, cin=F, cout=FF, taps=1, stride=1, pad=0)
             gh2 = self._linear(gf1, PB[p + 'linear1.weight'], None, R, FF, F)

@@ -20,6 +20,7 @@ PRO_NONE, PRO_SANITIZE, PRO_GELU, PRO_IN_GELU, PRO_INBWD, PRO_INBWD_GP, PRO_FIRS
 EPI_PLAIN, EPI_STATS, EPI_AUX_INGELU_ADD, EPI_BIAS, EPI_GP = range(5)
 MODE_CONTIG, MODE_DILATED, MODE_UP2 = range(3)
 ELT_GELU, ELT_GELU_BWD, ELT_ADD, ELT_ADD_DROP, ELT_DROP, ELT_GELU_DROP, ELT_GELU_DROP_BWD = range(7)
+FUSE_ADD_DROP, FUSE_Y2_GELU_DROP, FUSE_GELU_BWD_DROP = 2, 4, 8
 
 _fp = C.c_void_p
 _i32 = C.c_int32
@@ -29,7 +30,8 @@ class ConvArgs(C.Structure):
     _fields_ = [(n, _fp) for n in ('x', 'x2', 'w', 'y', 'y2', 'pro_stats', 'pro_bstats', 'aux', 'aux_stats', 'add_even', 'bias',
                                    'rowkeep', 'part', 'w_hi', 'w_lo', 'stat_out', 'stat_cnt')] + \
                [(n, _i32) for n in ('B', 'L_in', 'L_out', 'cin', 'cout', 'taps', 'stride', 'dil', 'pad', 'flip', 'mode',
-                                    'ldx', 'ldy', 'ldy2', 'ld_aux', 'pro', 'epi')] + [('stat_eps', C.c_float), ('reserved', _i32)]
+                                    'ldx', 'ldy', 'ldy2', 'ld_aux', 'pro', 'epi')] + [('stat_eps', C.c_float), ('reserved', _i32), ('drop_p', C.c_float),
+                                                                                            ('drop_seed', C.c_uint64)]
 
 
 class ReduceJob(C.Structure):
@@ -135,9 +137,10 @@ def _f(t):
 def conv_args(*, x, w, y, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, flip=0, mode=MODE_CONTIG, ldx=None, ldy=None,
               pro=PRO_NONE, epi=EPI_PLAIN, x2=None, pro_stats=None, pro_bstats=None, aux=None, aux_stats=None, add_even=None,
               bias=None, rowkeep=None, part=None, y2=None, ldy2=0, ld_aux=0, w_hi=None, w_lo=None, stat_out=None, stat_cnt=None,
-              stat_eps=1e-2, accumulate=False) -> ConvArgs:
+              stat_eps=1e-2, accumulate=False, fuse=0, drop_p=0.0, drop_seed=0) -> ConvArgs:
     a = ConvArgs()
-    a.reserved = 1 if accumulate else 0
+    a.reserved = (1 if accumulate else 0) | fuse   # fuse: FUSE_* bits (EPI_BIAS only)
+    a.drop_p, a.drop_seed = drop_p, drop_seed
     a.w_hi, a.w_lo = _p(w_hi), _p(w_lo)
     a.stat_out, a.stat_cnt, a.stat_eps = _f(stat_out), _p(stat_cnt), stat_eps
     a.x, a.x2, a.w, a.y, a.y2 = _f(x), _f(x2), _f(w), _f(y), _f(y2)
@@ -224,7 +227,10 @@ def conv_forward(a: ConvArgs):
     nt, mt, wn, mode = cfg[0], cfg[1], cfg[2], cfg[3]
     # key == the kernel name rocprofv3 reports, so bench.py's average can be checked against profiles/
     spec = (-1, -1)
-    if not a.y2 and not a.rowkeep:
+    if (a.pro, a.epi) == (PRO_NONE, EPI_BIAS) and not a.rowkeep and not (a.reserved & 1) and (not a.y2 or (a.reserved & FUSE_Y2_GELU_DROP)) and \
+            ((mode, a.taps, a.stride) == (0, 1, 1) or (mode == 1 and a.taps == a.stride)):
+        spec = (a.pro, a.epi)
+    elif not a.y2 and not a.rowkeep and not a.reserved:
         hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4), (6, 1)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)],
                (0, 1, 1): [(0, 3), (0, 0)], (1, 4, 4): [(0, 3)], (1, 3, 3): [(0, 3)], (0, 7, 1): [(0, 0)], (1, 7, 1): [(0, 0)]}
         if (a.pro, a.epi) in hot.get((mode, a.taps, a.stride), []):
