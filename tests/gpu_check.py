@@ -529,7 +529,8 @@ def t_bwd_wide():
     B = 3
     for (cg, ch, L, hst, add_even, stride) in [(64, 64, 1000, True, False, 1), (64, 64, 777, False, True, 1), (64, 32, 500, False, True, 1), (64, 64, 64, True, False, 1),
                                                (64, 32, 130, False, True, 1), (64, 64, 4098, True, False, 1), (64, 32, 2050, True, False, 1),
-                                               (64, 64, 1000, True, False, 2), (64, 64, 64, True, False, 2), (64, 64, 4098, True, False, 2), (64, 64, 130, True, False, 2)]:
+                                               (64, 64, 1000, True, False, 2), (64, 64, 64, True, False, 2), (64, 64, 4098, True, False, 2), (64, 64, 130, True, False, 2),
+                                               (32, 32, 1000, True, False, 1), (32, 32, 130, False, True, 1), (32, 32, 4098, True, False, 1)]:   # (W2S_BWD_WIDE32: vs the generic kernels)
         Lg = L // stride
         g = torch.randn(B, Lg, cg, device=dev) * 0.1; y = torch.randn(B, Lg, cg, device=dev) * 2 + 0.2; x = torch.randn(B, L, ch, device=dev) * 1.3 - 0.1
         st = torch.stack([torch.randn(B, cg, device=dev) * 0.1, torch.rand(B, cg, device=dev) + 0.5], dim=-1).contiguous()
@@ -566,9 +567,10 @@ def t_bwd_wide():
                          cg=cg, ch=ch, stride=stride)
             gw = torch.zeros(cg, ch, 3, device=dev); lib.wgrad_reduce(slab, ns, gw, cg, ch, 3, 1)
             tag = f'bwd_wide {cg}->{ch} s{stride} L{L} hst{int(hst)} ev{int(add_even)} wgs{ns}'
-            report(tag + ' gout', gout, gout0, tol=2e-6)
-            report(tag + ' statistics sums', part.sum(1), part0.sum(1), tol=2e-5)
-            report(tag + ' wgrad', gw, gw0, tol=2e-5)
+            loose = 20 if cg == 32 else 1   # 32 channels: the reference arm is the generic kernels (fp32 weight-gradient products)
+            report(tag + ' gout', gout, gout0, tol=2e-6 * loose)
+            report(tag + ' statistics sums', part.sum(1), part0.sum(1), tol=2e-5 * loose)
+            report(tag + ' wgrad', gw, gw0, tol=2e-5 * loose)
         if stride == 1 and not hst:   # conv1 of a block: the previous block's conv3-backward statistics folded in vs the w2s_gp_stats pre-pass
             y3p = torch.randn(B, L, ch, device=dev)
             st3 = torch.stack([torch.randn(B, ch, device=dev) * 0.1, torch.rand(B, ch, device=dev) + 0.5], dim=-1).contiguous()

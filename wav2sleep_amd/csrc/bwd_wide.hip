@@ -331,6 +331,7 @@ static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
 
 // positions (input side) per tile and statistics-partial rows per tile of the (cg, ch, stride) instance; 0: no instance
 extern "C" int w2s_bwd_wide_tile(int cg, int ch, int stride) {
+  if (cg == 32 && ch == 32 && stride == 1) return 64;   // (the 32-channel stride-1 convs: an alternative to w2s_bwd_fused, W2S_BWD_WIDE32)
   return (cg == 64 && ((ch == 64 && (stride == 1 || stride == 2)) || (ch == 32 && stride == 1))) ? 64 : 0;
 }
 extern "C" int w2s_bwd_wide_groups(int cg, int ch, int stride) { return !w2s_bwd_wide_tile(cg, ch, stride) ? 0 : (ch == 32) ? 2 : 1; }
@@ -354,6 +355,7 @@ extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, c
   if (off) return 1;
   BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, y3p, st3p, B, L, L / stride, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (cg == 32) return st_in ? launch_bww<2, 2, 1, 4, 4, 1, 1, 3>(P, nslab, s, dry) : launch_bww<2, 2, 0, 4, 4, 1, 1, 3>(P, nslab, s, dry);
   if (stride == 2) return launch_bww<4, 4, 1, 4, 4, 2, 2, 2, 1>(P, nslab, s, dry);
   if (ch == 64) return st_in ? launch_bww<4, 4, 1, 4, 4, 2, 2, 2>(P, nslab, s, dry) : launch_bww<4, 4, 0, 4, 4, 2, 2, 2>(P, nslab, s, dry);
   return st_in ? launch_bww<4, 2, 1, 4, 4, 2, 1, 2>(P, nslab, s, dry) : launch_bww<4, 2, 0, 4, 4, 2, 1, 2>(P, nslab, s, dry);

@@ -113,6 +113,7 @@ class Engine:
         # bandwidth-bound) while the worst full-size gradient error went 4.4e-4 -> 1.0e-3: OFF by default, W2S_GRAD_FP16=1 switches it on
         self.grad_fp16 = os.environ.get('W2S_GRAD_FP16', '0') == '1'
         self.bwd_wide = os.environ.get('W2S_BWD_WIDE', '1') != '0'   # one-pass backward of the 64-channel stride-1 convs (csrc/bwd_wide.hip)
+        self.bwd_wide32 = os.environ.get('W2S_BWD_WIDE32', '0') == '1'   # ... and of the 32 -> 32 stride-1 convs in the same role-split form (experiment)
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
         if not spec.use_residual:
@@ -338,7 +339,7 @@ class Engine:
         dev = g.device
         tile, groups = lib.bwd_wide_tile(cg, ch, stride), lib.bwd_wide_groups(cg, ch, stride)
         nt = _cdiv(L, tile)
-        nslab = max(1, min(B * nt, 256))
+        nslab = max(1, min(B * nt, 256 if cg == 64 else int(os.environ.get('W2S_BWD_WIDE32_WGS', 512))))   # one / two workgroups per CU (LDS)
         slab = self._slab(dev, nslab, cg * ch * 3)
         part = torch.empty(B, nt * groups, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         wh, wl = self._bf[self.PB[name].data_ptr()]
@@ -955,10 +956,14 @@ class Engine:
                                       xin=blk['y2'], st_in=blk['st2'], add_even=None, gout=gn2, want_part=True, B=B, Lg=Lh, Lh=L, cg=c, ch=c, stride=2,
                                       gmode=(2 if ghalf else 1) if h16 else 0, hdr_g=gpre_hdr, hdr_o=h2)
                 first = i == 0 and blk['y1'] is None   # block 0's conv1 output is recomputed from the raw signal
-                bs1 = self._bwd_fused(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, pro=lib.PRO_INBWD,
-                                      xin=ec['x'] if first else blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B,
-                                      Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None,
-                                      gmode=2 if h16 else 0, hdr_g=h2, hdr_o=h1)
+                if self.bwd_wide32 and c == 32 and not h16 and self._bwd_wide_ok(B, L, c, c):
+                    bs1 = self._bwd_wide(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, xin=blk['y1'], st_in=blk['st1'],
+                                         add_even=None, gout=gn1, want_part=True, B=B, L=L, cg=c, ch=c)
+                else:
+                    bs1 = self._bwd_fused(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, pro=lib.PRO_INBWD,
+                                          xin=ec['x'] if first else blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B,
+                                          Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None,
+                                          gmode=2 if h16 else 0, hdr_g=h2, hdr_o=h1)
             else:
                 if not (L & 1) and self._bwd_wide_ok(B, L, c, c, stride=2):
                     bs2 = self._bwd_wide(p + 'conv3.conv.weight', g=gpre, y=blk['y3'], st_k=blk['st3'], bst_k=bs3, xin=blk['y2'], st_in=blk['st2'],
