@@ -333,7 +333,10 @@ __host__ __device__ constexpr int bf_rs(int c) { return c == 16 ? 16 : c + 8; } 
 // Occupancy: the kernels take what their registers allow (2 waves per SIMD; measured: forcing 2 on the variants that land on 1 changes
 // nothing).  The residual-fold kernel of the 16-channel blocks is the exception: at 256-position tiles it needs 244 registers (one
 // workgroup per CU); with 128-position tiles it fits three per CU and runs 21 % faster (1.39 -> 1.10 ms per step).
-__host__ __device__ constexpr int bfk_occ(int cg, int ch, int rd) { return (cg == 1 && ch == 1 && rd) ? 3 : 1; }
+#ifndef W2S_BF_OCC11
+#define W2S_BF_OCC11 1   // tuning: waves per SIMD asked for the plain 16 -> 16 kernels (with W2S_BF_MT11 = 2: 128-position tiles)
+#endif
+__host__ __device__ constexpr int bfk_occ(int cg, int ch, int rd) { return (cg == 1 && ch == 1 && rd) ? 3 : (cg == 1 && ch == 1) ? W2S_BF_OCC11 : 1; }
 template <int CG, int CH, int MT, int UP2, int RD, int FIRST, int GM = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bfk_occ(CG, CH, RD))))
 void bwd_fused_bf_kernel(BwdP P) {
@@ -819,13 +822,16 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
 #ifndef W2S_BF_MT22
 #define W2S_BF_MT22 2
 #endif
+#ifndef W2S_BF_MT11
+#define W2S_BF_MT11 4
+#endif
 #ifndef W2S_BF_PF
 #define W2S_BF_PF 1
 #endif
 // 64-position sub-tiles per workgroup tile.  16 -> 16: 4 (256 positions; the residual-fold form 2: register budget, see bfk_occ);
 // 32 -> 32 stride 1: W2S_BF_MT22; everything else 2 (the stride-2 form needs an even count: even / odd outputs are separate M tiles).
 constexpr int bf_mt(int cg, int ch, int up2, int rd) {
-  return (cg == 16 && ch == 16) ? (rd ? 2 : 4) : (cg == 32 && ch == 32 && !up2) ? W2S_BF_MT22 : 2;
+  return (cg == 16 && ch == 16) ? (rd ? 2 : W2S_BF_MT11) : (cg == 32 && ch == 32 && !up2) ? W2S_BF_MT22 : 2;
 }
 // (cg, ch) pairs whose conv1 kernel can fold the residual branch (LDS budget: two workgroups per CU)
 extern "C" int w2s_bwd_fused_folds_residual(int cg, int ch) { return (cg == 16 && ch == 16) || (cg == 32 && ch == 16); }
