@@ -336,7 +336,10 @@ __host__ __device__ constexpr int bf_rs(int c) { return c == 16 ? 16 : c + 8; } 
 #ifndef W2S_BF_OCC11
 #define W2S_BF_OCC11 1   // tuning: waves per SIMD asked for the plain 16 -> 16 kernels (with W2S_BF_MT11 = 2: 128-position tiles)
 #endif
-__host__ __device__ constexpr int bfk_occ(int cg, int ch, int rd) { return (cg == 1 && ch == 1 && rd) ? 3 : (cg == 1 && ch == 1) ? W2S_BF_OCC11 : 1; }
+#ifndef W2S_BF_OCC22
+#define W2S_BF_OCC22 1   // tuning: the same for the 32-channel kernels ((32,32) both strides, (32,16) fold)
+#endif
+__host__ __device__ constexpr int bfk_occ(int cg, int ch, int rd) { return (cg == 1 && ch == 1 && rd) ? 3 : (cg == 1 && ch == 1) ? W2S_BF_OCC11 : W2S_BF_OCC22; }
 template <int CG, int CH, int MT, int UP2, int RD, int FIRST, int GM = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bfk_occ(CG, CH, RD))))
 void bwd_fused_bf_kernel(BwdP P) {
@@ -508,7 +511,7 @@ void bwd_fused_bf_kernel(BwdP P) {
       hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
     }
     if (FIRST) {
-      xsL[tid] = rxs[0];
+      if (tid < TM + 4) xsL[tid] = rxs[0];
       if (tid < TM + 4 - 256) xsL[256 + tid] = rxs[1];
       __syncthreads();
     }
@@ -734,6 +737,7 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
     for (int s0 = 0; s0 < KS; s0 += KW) {
       const int s = s0 + wk;
+      if (KS % KW != 0 && s >= KS) break;         // fewer k-steps than sharing waves (128-position stride-2 tiles: 2 steps, 4 waves)
       const int p0 = 32 * s + 8 * g + q4;         // this lane's address row (gradient-side position) of the first 4-block
       const int gr0 = UP2 ? p0 : p0 + 2 - PL;     // window row of gradient-side position p0
       const int gcol = wi * 16 + 4 * p4;

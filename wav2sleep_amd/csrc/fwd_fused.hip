@@ -40,8 +40,13 @@ __host__ __device__ constexpr bool ff_db(int hc, int stride) { return hc == 16 &
 
 // CI / CO: input / output channel tiles (16 each); MT: 16-position m-tiles per wave (TM = 64*MT outputs per tile);
 // PRO: W2S_PRO_GELU, W2S_PRO_IN_GELU or W2S_PRO_FIRST (x = raw signal, w1 = block 0's conv1 weight)
+// tuning: waves per SIMD asked of the variants that otherwise land on 2 (stride 2, or 32 channels on a side: 164-192 VGPRs)
+#ifndef W2S_FF_OCC2
+#define W2S_FF_OCC2 1
+#endif
+__host__ __device__ constexpr int ffk_occ(int ci, int co, int stride) { return (ci == 1 && co == 1 && stride == 1) ? 1 : W2S_FF_OCC2; }
 template <int CI, int CO, int MT, int STRIDE, int PRO>
-__global__ __launch_bounds__(256) void conv_fwd_bf_kernel(FwdP P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI, CO, STRIDE)))) void conv_fwd_bf_kernel(FwdP P) {
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 64 * MT;                            // output rows the matrix cores compute per tile ...
   constexpr int TS = ff_ts(TM, STRIDE);                  // ... of which the first TS are the tile (the rest is discarded): see ff_ts

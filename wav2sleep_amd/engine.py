@@ -29,6 +29,8 @@ _ENC_CHUNK = {(int(kv.split(':')[0]) if ':' in kv else 0): int(kv.split(':')[-1]
 _BWD_WGS = int(os.environ.get('W2S_BWD_WGS', 512))       # persistent workgroups of the fused backward (2 per CU)
 _BWD_WGS32 = int(os.environ.get('W2S_BWD_WGS32', _BWD_WGS))
 _BWD_WGS_RD16 = int(os.environ.get('W2S_BWD_WGS_RD16', 768))  # the 16-channel residual-fold kernel fits three per CU
+_FWD_WGS16 = int(os.environ.get('W2S_FWD_WGS16', 1024))    # persistent workgroups of the forward kernel: 16 input channels (four per CU) ...
+_FWD_WGS = int(os.environ.get('W2S_FWD_WGS', 512))        # ... and the other forms
 
 FIRST_TILE = 1024  # positions per statistics partial of the Cin=1 layer
 
@@ -263,7 +265,7 @@ class Engine:
             part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
             so, sc = self._fin(B, cout, dev)
             lib.conv_fwd_fused(x=x, w=w, st_in=pro_stats, w1=x2, y=y, part=part, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, stride=stride,
-                               pro=pro, pad=self.kpad, nwg=1024 if cin == 16 else 512, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps)
+                               pro=pro, pad=self.kpad, nwg=_FWD_WGS16 if cin == 16 else _FWD_WGS, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps)
             return y, (so if so is not None else self._finalize(part, B, nt, cout, L_out, 0))
         return y, self._conv_part(x=x, x2=x2, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=self.kpad, pro=pro,
                                   pro_stats=pro_stats, epi=lib.EPI_STATS, kind=0, **({'ldx': 4} if pro == lib.PRO_FIRST else {}))
