@@ -227,7 +227,12 @@ int w2s_bwd_wide_tile(int cg, int ch, int stride);     /* input-side positions p
 int w2s_bwd_wide_groups(int cg, int ch, int stride);   /* statistics-partial rows per tile */
 int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                  const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B, int L,
-                 int cg, int ch, int stride, const float* y3p, const float* st3p, int dry, void* stream);
+                 int cg, int ch, int stride, const float* y3p, const float* st3p, const float* gpre, const void* wd_hi, const void* wd_lo,
+                 float* slab_d, int dry, void* stream);
+/* gpre != NULL (conv1 of a residual block: stride 1, st_in and add_even NULL, L even): the block's 1x1/stride-2 residual branch
+ * (blocks.py:44-47,68) folded in as in w2s_bwd_fused -- gout additionally receives Wd^T gpre[t/2] at even t before the GELU' factor (gpre:
+ * [B][L/2][cg], wd_hi / wd_lo: w2s_repack_batch bwd planes of the downsample weight) and slab_d receives nslab raw-fragment slabs of the
+ * downsample weight gradient -> w2s_wgrad_reduce(slab_d, nslab, grad_wd, cg, ch, 1, 1, ...). */
 /* y3p != NULL (stride 1, part given): additionally fold the PREVIOUS block's conv3-backward pre-pass (w2s_gp_stats) in, as w2s_bwd_fused
  * does: y3p = that block's pre-norm conv3 output [B][L][ch], st3p = its (mean, rstd) [B][ch][2]; `part` then holds the partial sums of
  * gout*GELU'(n3) and gout*GELU'(n3)*n3, n3 = IN(y3p). */

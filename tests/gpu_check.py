@@ -590,6 +590,29 @@ def t_bwd_wide():
             lib.gp_stats(gout2, y3p, st3, pg, B, L, ch, 512)
             report(f'bwd_wide {cg}->{ch} L{L} gout with the statistics fold', gout2, gout, tol=0)
             report(f'bwd_wide {cg}->{ch} L{L} folded conv3 statistics', part2.sum(1), pg.sum(1), tol=2e-5)
+        if stride == 1 and not hst and cg == 64 and not (L & 1):   # ... and the block's residual branch folded in vs (1x1 conv -> add_even) + downsample wgrad
+            gpre = torch.randn(B, L // 2, cg, device=dev) * 0.1
+            wd = (torch.randn(ch, cg) / math.sqrt(cg)).to(dev); dh, dl = lib.frag_major_planes(wd)
+            Rr = torch.zeros(B, L // 2, ch, device=dev)
+            lib.conv_forward(lib.conv_args(x=gpre, w=wd, y=Rr, B=B, L_in=L // 2, L_out=L // 2, cin=cg, cout=ch, taps=1, stride=1, pad=0))
+            outs = []
+            for fold in (False, True):
+                go = torch.full((B, L, ch), float('nan'), device=dev); pt = torch.full((B, nt * groups, 2, ch), float('nan'), device=dev)
+                sl = torch.zeros(ns * cg * ch * 3, device=dev); sd = torch.zeros(ns * cg * ch, device=dev) if fold else None
+                lib.bwd_wide(g=g, y=y, st_k=st, bst_k=bst, xin=x, st_in=None, add_even=None if fold else Rr, w_hi=wh, w_lo=wl, gout=go, part=pt, slab=sl, nslab=ns,
+                             B=B, L=L, cg=cg, ch=ch, stride=1, gpre=gpre if fold else None, wd_hi=dh if fold else None, wd_lo=dl if fold else None, slab_d=sd)
+                gwf = torch.zeros(cg, ch, 3, device=dev); lib.wgrad_reduce(sl, ns, gwf, cg, ch, 3, 1)
+                gd = torch.zeros(cg, ch, 1, device=dev)
+                if fold:
+                    lib.wgrad_reduce(sd, ns, gd, cg, ch, 1, 1)
+                outs.append((go, pt, gwf, gd))
+            hcl = F.gelu(x)[:, 0:2 * (L // 2):2, :]
+            want_gd = torch.einsum('buo,buc->oc', gpre.double().cpu(), hcl.double().cpu()).float().view(cg, ch, 1)
+            RES.append((f'bwd_wide {cg}->{ch} L{L} residual fold is taken', lib.bwd_wide_takes(B, L, cg, ch, 1, False, rd=True)))
+            report(f'bwd_wide {cg}->{ch} L{L} residual fold gout', outs[1][0], outs[0][0], tol=2e-5)
+            report(f'bwd_wide {cg}->{ch} L{L} residual fold statistics', outs[1][1].sum(1), outs[0][1].sum(1), tol=2e-4)
+            report(f'bwd_wide {cg}->{ch} L{L} residual fold conv wgrad identical', outs[1][2], outs[0][2], tol=0)
+            report(f'bwd_wide {cg}->{ch} L{L} residual fold downsample wgrad', outs[1][3], want_gd, tol=3e-4)
     RES.append(('bwd_wide refuses a batch whose statistics tables do not fit its LDS', not lib.bwd_wide_takes(48, 640, 64, 64, 1, True) and lib.bwd_wide_takes(40, 640, 64, 64, 1, False)))
 
 def t_grad_fp16_chain():

@@ -32,6 +32,10 @@ struct BwdWideP {
   // conv1 of a block (stride 1): fold the PREVIOUS block's conv3-backward pre-pass (w2s_gp_stats) in, as w2s_bwd_fused does: y3p = that block's
   // pre-norm conv3 output [B][L][HC] (same positions as gout), st3p = its (mean, rstd); `part` then holds the sums of gout*GELU'(n3) and *n3
   const float* y3p; const float* st3p;
+  // residual fold (RD; conv1 of a block, stride 1, no add_even): the block's 1x1/stride-2 residual branch in the same pass, as w2s_bwd_fused
+  // does for <= 32 channels: gout additionally receives Wd^T gpre[t/2] at even t before the GELU' factor, and slab_d the weight gradient
+  // sum_u gpre[u] x h[2u].  gpre = dL/d(block pre-activation) [B][L/2][OC]; wd_hi / wd_lo = data-gradient planes of the downsample weight
+  const float* gpre; const __bf16* wd_hi; const __bf16* wd_lo; float* slab_d;
   int B, L, Lg, ntiles;   // L: input-side length; Lg: gradient-side length (L, or L / 2 for the stride-2 form)
 };
 
@@ -52,8 +56,9 @@ __device__ __forceinline__ bf16x8 wb_tr8(const __bf16* p0, const __bf16* p1) {
 
 // CO / CI: 16-channel tiles on the gradient / input side; HST: xin carries statistics (conv2); MT: 16-position m-tiles per tile;
 // NWC consumer waves = (CO / IB) x (CI / CB) weight-gradient owners = CI x (NWC / CI) data-gradient owners; PD: producer prefetch depth
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0>
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0, int RD = 0>
 __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
+  static_assert(!RD || (!UP2 && !HST && MT % 2 == 0), "residual fold: the stride-1 conv1 (its input is a stored pre-activation)");
   extern __shared__ f32x4 smem4[];
   static_assert((CO / IB) * (CI / CB) == NWC && NWC % CI == 0 && MT % (NWC / CI) == 0, "consumer wave grid");
   static_assert(!UP2 || (NWC == CI && MT % 2 == 0 && (8 * MT) % 32 == 0), "stride-2 form: one position group, even / odd m-tiles");
@@ -62,7 +67,8 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
   constexpr int TG = UP2 ? TM / 2 : TM;                                              // gradient-side positions per tile
   constexpr int RSg = OC + 16, RSh = HC + 8;                                         // bf16 elements per LDS row
   constexpr int RSp = HC + 4;                                                        // floats per row of the gp plane
-  constexpr int BUFH = 2 * NRG * RSg + 2 * NR * RSh;                                 // bf16 elements: gy hi, gy lo, h hi, h lo
+  constexpr int NRP = RD ? TM / 2 + 1 : 0;                                           // gpre rows of the tile + one all-zero row (odd output positions)
+  constexpr int BUFH = 2 * NRG * RSg + 2 * NR * RSh + 2 * NRP * RSg;                 // bf16 elements: gy hi, gy lo, h hi, h lo[, gpre hi, gpre lo]
   constexpr int BUFB = BUFH * 2 + TM * RSp * 4;                                      // bytes of one buffer (gp plane behind the bf16 planes)
   static_assert(BUFB % 16 == 0, "buffer alignment");
   constexpr int PG = NWC / CI, MTW = MT / PG;                                        // position groups / m-tiles per wave of the data gradient
@@ -78,6 +84,13 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
   }
   if (HST)
     for (int i = tid; i < P.B * HC * 2; i += 64 * (NWC + 4)) stL[P.B * OC * 4 + i] = P.st_in[i];
+  if (RD) {   // the zero row of the gpre planes, both buffers (the producers only ever write rows 0 .. TM/2 - 1)
+    for (int i = tid; i < 2 * 2 * RSg; i += 64 * (NWC + 4)) {
+      const int buf = i / (2 * RSg), k = i % (2 * RSg);
+      __bf16* pz = reinterpret_cast<__bf16*>(lds + buf * BUFB) + 2 * NRG * RSg + 2 * NR * RSh + (k / RSg) * NRP * RSg + (TM / 2) * RSg + (k % RSg);
+      *pz = (__bf16)0.f;
+    }
+  }
   __syncthreads();
 
   const int nt_wg = (total - first + step - 1) / step;            // >= 1 (the grid never exceeds the tile count)
@@ -91,7 +104,15 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     constexpr int c4h = HC / 4, rsh = NPT / c4h, NH = (NR + rsh - 1) / rsh;
     const int gch = (pt % c4g) * 4, grow0 = pt / c4g;
     const int hch = (pt % c4h) * 4, hrow0 = pt / c4h;
-    f32x4 rg[PD][NG] = {}, ry[PD][NG] = {}, rh[PD][NH] = {};
+    constexpr int NP = RD ? (TM / 2 + rsg - 1) / rsg : 1;
+    f32x4 rg[PD][NG] = {}, ry[PD][NG] = {}, rh[PD][NH] = {}, rp[RD ? PD : 1][NP] = {};
+    auto load_p = [&](auto SET, int i, int k) {
+      constexpr int S = decltype(SET)::value;
+      const int tl = first + min(i, nt_wg - 1) * step;
+      const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+      const int row = min(grow0 + k * rsg, TM / 2 - 1), gr = min(t0 / 2 + row, (L >> 1) - 1);
+      rp[S][k] = ld4o(P.gpre + (size_t)b * (L >> 1) * OC, (unsigned)gr * OC + gch);
+    };
     auto load_g = [&](auto SET, int i, int k) {
       constexpr int S = decltype(SET)::value;
       const int tl = first + min(i, nt_wg - 1) * step;
@@ -117,7 +138,9 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       __bf16* gL = gH + NRG * RSg;
       __bf16* hH = gL + NRG * RSg;
       __bf16* hL = hH + NR * RSh;
-      float* gpL = reinterpret_cast<float*>(hL + NR * RSh);
+      __bf16* pH = hL + NR * RSh;
+      __bf16* pL = pH + NRP * RSg;
+      float* gpL = reinterpret_cast<float*>(pL + NRP * RSg);
       f32x4 pm, pr, ps1, ps2;
       {
         const float* st = stL + (b * OC + gch) * 2;
@@ -155,6 +178,15 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
           if (row >= 1 && row <= TM) st4(gpL + (row - 1) * RSp + hch, gpv);
         }
       }
+      if constexpr (RD) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const int row = grow0 + k * rsg, gr = t0 / 2 + row;
+          const f32x4 v = rp[S][k];
+          load_p(SET, i + PD, k);
+          if (live && row < TM / 2) wb_split_store4(pH, pL, row * RSg + gch, (gr < (L >> 1)) ? v : (f32x4){0, 0, 0, 0});
+        }
+      }
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
 #pragma unroll
@@ -168,6 +200,14 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       load_h(I0{}, 0, k);
       if constexpr (PD > 1) load_h(I1{}, 1, k);
       if constexpr (PD > 2) load_h(I2{}, 2, k);
+    }
+    if constexpr (RD) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        load_p(I0{}, 0, k);
+        if constexpr (PD > 1) load_p(I1{}, 1, k);
+        if constexpr (PD > 2) load_p(I2{}, 2, k);
+      }
     }
     for (int it = 0; it < NI; it += PD) {
       stage(I0{}, it);
@@ -196,6 +236,20 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     wh[ks] = *reinterpret_cast<const bf16x8*>(P.w_hi + wo);
     wl[ks] = *reinterpret_cast<const bf16x8*>(P.w_lo + wo);
   }
+  bf16x8 dh[RD ? QN : 1], dl[RD ? QN : 1];   // RD: the 16 x OC slice of Wd^T (planes [HC/16][QN][64 lanes][8])
+  f32x4 accd[RD ? IB : 1][RD ? CB : 1];
+  if (RD) {
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      const size_t wo = ((size_t)dn * QN + q) * 512 + lane * 8;
+      dh[q] = *reinterpret_cast<const bf16x8*>(P.wd_hi + wo);
+      dl[q] = *reinterpret_cast<const bf16x8*>(P.wd_lo + wo);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) accd[i][c] = (f32x4){0, 0, 0, 0};
+  }
   const int ch0 = dn * 16 + 4 * g;   // this lane's 4 consecutive output channels (D fragment: position r, channels 4g .. 4g+3)
   __syncthreads();                   // round 0 of the producers: the first windows are in buffer 0
   for (int it = 0; it < NI - 1; ++it) {
@@ -206,7 +260,9 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     const __bf16* gL = gH + NRG * RSg;
     const __bf16* hH = gL + NRG * RSg;
     const __bf16* hL = hH + NR * RSh;
-    const float* gpL = reinterpret_cast<const float*>(hL + NR * RSh);
+    const __bf16* pH = hL + NR * RSh;
+    const __bf16* pL = pH + NRP * RSg;
+    const float* gpL = reinterpret_cast<const float*>(pL + NRP * RSg);
     // epilogue operands of THIS tile, issued now so that their latency hides behind the MFMA loops: raw xin (statistics) and add_even
     f32x4 ax[MTW], ae[MTW];
     {
@@ -236,6 +292,20 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bl, acc[mt], 0, 0, 0);
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], bh, acc[mt], 0, 0, 0);
       }
+    }
+    if constexpr (RD) {   // + Wd^T gpre[t/2] at even t (odd positions read the zero row)
+#pragma unroll
+      for (int q = 0; q < QN; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int m = (dg * MTW + mt) * 16 + r;
+          const int prow = (m & 1) ? TM / 2 : (m >> 1);
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pH + prow * RSg + q * 32 + 8 * g);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pL + prow * RSg + q * 32 + 8 * g);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh[q], bh, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh[q], bl, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl[q], bh, acc[mt], 0, 0, 0);
+        }
     }
     // ---- epilogue: * GELU'(n_in), statistics partials, store
     f32x4 sA = {0, 0, 0, 0}, sB = {0, 0, 0, 0};
@@ -300,7 +370,39 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
         }
       }
     }
+    if constexpr (RD) {   // dWd[o][c] += sum_u gpre[u][o] h[2u][c]: window row of position t0 + 2u is 2u + 1
+#pragma unroll
+      for (int s = 0; s < TM / 64; ++s) {
+        const int p0 = 32 * s + 8 * g + q4;
+        bf16x8 ah[IB], al[IB];
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+          const int col = (wi * IB + i) * 16 + 4 * p4;
+          ah[i] = wb_tr8(pH + p0 * RSg + col, pH + (p0 + 4) * RSg + col);
+          al[i] = wb_tr8(pL + p0 * RSg + col, pL + (p0 + 4) * RSg + col);
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+          const int col = (wc * CB + c) * 16 + 4 * p4;
+          const bf16x8 bh = wb_tr8(hH + (2 * p0 + 1) * RSh + col, hH + (2 * (p0 + 4) + 1) * RSh + col);
+          const bf16x8 bl = wb_tr8(hL + (2 * p0 + 1) * RSh + col, hL + (2 * (p0 + 4) + 1) * RSh + col);
+#pragma unroll
+          for (int i = 0; i < IB; ++i) {
+            accd[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, accd[i][c], 0, 0, 0);
+            accd[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, accd[i][c], 0, 0, 0);
+            accd[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, accd[i][c], 0, 0, 0);
+          }
+        }
+      }
+    }
     __syncthreads();   // the producers have staged the next windows; these may be overwritten
+  }
+  if (RD) {
+    float* outd = P.slab_d + (size_t)blockIdx.x * (CO * CI) * 256 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) st4(outd + (size_t)((wi * IB + i) * CI + wc * CB + c) * 256, accd[i][c]);
   }
   float* out = P.slab + (size_t)blockIdx.x * (CO * 3 * CI) * 256 + lane * 4;
 #pragma unroll
@@ -311,16 +413,16 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       for (int c = 0; c < CB; ++c) st4(out + (size_t)(((wi * IB + i) * 3 + j) * CI + wc * CB + c) * 256, accw[i][j][c]);
 }
 
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0>
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0, int RD = 0>
 static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
-  constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NR = TM + 2, NRG = UP2 ? TM / 2 + 1 : TM + 2;
+  constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NR = TM + 2, NRG = UP2 ? TM / 2 + 1 : TM + 2, NRP = RD ? TM / 2 + 1 : 0;
   BwdWideP P = P0;
   P.ntiles = (P.L + TM - 1) / TM;
-  const size_t lds = (size_t)2 * ((2 * NRG * (OC + 16) + 2 * NR * (HC + 8)) * 2 + TM * (HC + 4) * 4) + (size_t)P.B * OC * 4 * 4 + (HST ? (size_t)P.B * HC * 2 * 4 : 0);
+  const size_t lds = (size_t)2 * ((2 * (NRG + NRP) * (OC + 16) + 2 * NR * (HC + 8)) * 2 + TM * (HC + 4) * 4) + (size_t)P.B * OC * 4 * 4 + (HST ? (size_t)P.B * HC * 2 * 4 : 0);
   if (lds > 160 * 1024) return 1;   // (batch too large for the LDS statistics tables: the caller runs the separate kernels)
   if (dry) return 0;
   if (nslab <= 0 || (long)nslab > (long)P.B * P.ntiles) return W2S_EINVAL;   // every workgroup writes a slab: it needs a tile
-  auto kern = bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2>;
+  auto kern = bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -342,21 +444,28 @@ extern "C" int w2s_bwd_wide_groups(int cg, int ch, int stride) { return !w2s_bwd
 // partial sums of gout and gout * n_in (rows = ntiles * groups for w2s_stats_finalize), or NULL.  slab: nslab slabs of cg * 3 * ch floats
 // (nslab = grid size <= B * ntiles) for w2s_wgrad_reduce(..., cg, ch, 3, 1, ...).  dry != 0: only answer whether an instance takes this
 // launch (0) or not (1) -- st_in then only says WHETHER the input side carries statistics (any non-NULL value).  y3p / st3p (stride 1, with
-// part): fold the previous block's conv3-backward statistics pre-pass in (see BwdWideP).
+// part): fold the previous block's conv3-backward statistics pre-pass in (see BwdWideP).  gpre / wd_hi / wd_lo / slab_d (stride 1, st_in and
+// add_even NULL, L even): the residual fold (see BwdWideP); slab_d: nslab slabs of cg * ch floats for w2s_wgrad_reduce(..., cg, ch, 1, 1, ...).
+// In dry mode gpre only says WHETHER the fold is asked for.
 extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                             const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B,
-                            int L, int cg, int ch, int stride, const float* y3p, const float* st3p, int dry, void* stream) {
+                            int L, int cg, int ch, int stride, const float* y3p, const float* st3p, const float* gpre, const void* wd_hi,
+                            const void* wd_lo, float* slab_d, int dry, void* stream) {
   if (!w2s_bwd_wide_tile(cg, ch, stride)) return 1;
+  const bool rd = gpre != nullptr;
+  if (rd && (cg != 64 || stride != 1 || st_in || add_even || (L & 1) || (!dry && (!wd_hi || !wd_lo || !slab_d)))) return dry ? 1 : W2S_EINVAL;
   if (stride == 2 && (!st_in || add_even || (L & 1) || y3p)) return dry ? 1 : W2S_EINVAL;
   if (y3p && (!st3p || !part)) return W2S_EINVAL;
   if (!dry && (!g || !y || !st_k || !bst_k || !xin || !w_hi || !w_lo || !gout || !slab)) return W2S_EINVAL;
   if ((size_t)L * 64 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;   // 32-bit lane offsets inside one sample
   static const char* off = getenv("W2S_NO_BWD_WIDE");   // tuning only
   if (off) return 1;
-  BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, y3p, st3p, B, L, L / stride, 0};
+  BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, y3p, st3p, gpre,
+             static_cast<const __bf16*>(wd_hi), static_cast<const __bf16*>(wd_lo), slab_d, B, L, L / stride, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (cg == 32) return st_in ? launch_bww<2, 2, 1, 4, 4, 1, 1, 3>(P, nslab, s, dry) : launch_bww<2, 2, 0, 4, 4, 1, 1, 3>(P, nslab, s, dry);
   if (stride == 2) return launch_bww<4, 4, 1, 4, 4, 2, 2, 2, 1>(P, nslab, s, dry);
+  if (rd) return ch == 64 ? launch_bww<4, 4, 0, 4, 4, 2, 2, 2, 0, 1>(P, nslab, s, dry) : launch_bww<4, 2, 0, 4, 4, 2, 1, 2, 0, 1>(P, nslab, s, dry);
   if (ch == 64) return st_in ? launch_bww<4, 4, 1, 4, 4, 2, 2, 2>(P, nslab, s, dry) : launch_bww<4, 4, 0, 4, 4, 2, 2, 2>(P, nslab, s, dry);
   return st_in ? launch_bww<4, 2, 1, 4, 4, 2, 1, 2>(P, nslab, s, dry) : launch_bww<4, 2, 0, 4, 4, 2, 1, 2>(P, nslab, s, dry);
 }

@@ -116,6 +116,7 @@ class Engine:
         self.grad_fp16 = os.environ.get('W2S_GRAD_FP16', '0') == '1'
         self.bwd_wide = os.environ.get('W2S_BWD_WIDE', '1') != '0'   # one-pass backward of the 64-channel stride-1 convs (csrc/bwd_wide.hip)
         self.bwd_wide32 = os.environ.get('W2S_BWD_WIDE32', '0') == '1'   # ... and of the 32 -> 32 stride-1 convs in the same role-split form (experiment)
+        self.bwd_wide_rd = os.environ.get('W2S_BWD_WIDE_RD', '1') != '0'   # 64-channel conv1: residual branch folded into the one-pass kernel
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
         if not spec.use_residual:
@@ -336,7 +337,8 @@ class Engine:
         """the one-pass backward of a 64-channel conv (csrc/bwd_wide.hip): split precision, symmetric padding; L = input-side length"""
         return self.bwd_wide and self.split_precision and self.kpad == 1 and lib.bwd_wide_takes(B, L, cg, ch, stride, hst)
 
-    def _bwd_wide(self, name, *, g, y, st_k, bst_k, xin, st_in, add_even, gout, want_part, B, L, cg, ch, stride=1, y3p=None, st3p=None):
+    def _bwd_wide(self, name, *, g, y, st_k, bst_k, xin, st_in, add_even, gout, want_part, B, L, cg, ch, stride=1, y3p=None, st3p=None,
+                  gpre=None, down=None):
         """dgrad + wgrad + GELU' + backward statistics of one 64-channel k=3 conv in one pass; returns the statistics or None."""
         dev = g.device
         tile, groups = lib.bwd_wide_tile(cg, ch, stride), lib.bwd_wide_groups(cg, ch, stride)
@@ -345,10 +347,15 @@ class Engine:
         slab = self._slab(dev, nslab, cg * ch * 3)
         part = torch.empty(B, nt * groups, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         wh, wl = self._bf[self.PB[name].data_ptr()]
+        dh, dl = self._bf[self.PB[down].data_ptr()] if gpre is not None else (None, None)
+        slab_d = self._slab(dev, nslab, cg * ch) if gpre is not None else None
         lib.bwd_wide(g=g, y=y, st_k=st_k, bst_k=bst_k, xin=xin, st_in=st_in, add_even=add_even, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab,
-                     nslab=nslab, B=B, L=L, cg=cg, ch=ch, stride=stride, y3p=y3p, st3p=st3p)
+                     nslab=nslab, B=B, L=L, cg=cg, ch=ch, stride=stride, y3p=y3p, st3p=st3p, gpre=gpre, wd_hi=dh, wd_lo=dl, slab_d=slab_d)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
+        if gpre is not None:
+            self._rjobs.append((slab_d, nslab, self.G[down], cg, ch, 1, 1, down in self._written, 0))
+            self._written.add(down)
         return self._bstats(part, B, nt * groups, ch, L) if want_part else None
 
     def _colsum(self, part, nparts, C, out, accumulate=False, ld=None):
@@ -998,6 +1005,16 @@ class Engine:
                                              gmode=2 if h16 else 0, hdr_g=h1, hdr_p=gpre_hdr, hdr_o=hp)
                 if not self.fold_gp:
                     bs3_folded = None
+                gpre, gpre_hdr = gprev, hp
+            elif (i > 0 and self.bwd_wide_rd and self.bwd_wide and self.split_precision and self.kpad == 1 and not (L & 1) and (p + 'downsample.weight') in self.G
+                  and self.PB[p + 'downsample.weight'].data_ptr() in self._bf and lib.bwd_wide_takes(B, L, c, cin, 1, False, rd=True)):
+                # 64-channel conv1: the whole residual branch (Wd^T gpre into the data gradient, the downsample weight gradient) and the
+                # previous block's conv3-backward statistics in the one-pass kernel -- no R tensor, no 1x1 conv launch, no separate weight gradient
+                gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
+                prev = ec['blocks'][i - 1] if (self.fold_gp and not h16_next) else None
+                bs3_folded = self._bwd_wide(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, xin=blk['pin'], st_in=None,
+                                            add_even=None, gout=gprev, want_part=prev is not None, B=B, L=L, cg=c, ch=cin,
+                                            y3p=prev['y3'] if prev else None, st3p=prev['st3'] if prev else None, gpre=gpre, down=p + 'downsample.weight')
                 gpre, gpre_hdr = gprev, hp
             elif i > 0:
                 # residual 1x1/stride-2 branch: R = Wd^T gpre, added at even positions inside conv1's data-gradient epilogue

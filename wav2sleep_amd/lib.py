@@ -371,18 +371,23 @@ def bwd_wide_groups(cg, ch, stride=1) -> int:
     return load().w2s_bwd_wide_groups(cg, ch, stride)
 
 
-def bwd_wide_takes(B, L, cg, ch, stride=1, hst=True) -> bool:
-    """Would w2s_bwd_wide take this launch (instance exists, the statistics tables of B samples fit its LDS)?  L: input-side length."""
-    return load().w2s_bwd_wide(None, None, None, None, None, C.c_void_p(1) if hst else None, None, None, None, None, None, None, 0, B, L, cg, ch, stride,
-                               None, None, 1, None) == 0
+def bwd_wide_takes(B, L, cg, ch, stride=1, hst=True, rd=False) -> bool:
+    """Would w2s_bwd_wide take this launch (instance exists, the statistics tables of B samples fit its LDS)?  L: input-side length;
+    rd: with the residual branch folded in (gpre given)."""
+    one = C.c_void_p(1)
+    return load().w2s_bwd_wide(None, None, None, None, None, one if hst else None, None, None, None, None, None, None, 0, B, L, cg, ch, stride,
+                               None, None, one if rd else None, None, None, None, 1, None) == 0
 
 
-def bwd_wide(*, g, y, st_k, bst_k, xin, st_in, add_even, w_hi, w_lo, gout, part, slab, nslab, B, L, cg, ch, stride=1, y3p=None, st3p=None):
+def bwd_wide(*, g, y, st_k, bst_k, xin, st_in, add_even, w_hi, w_lo, gout, part, slab, nslab, B, L, cg, ch, stride=1, y3p=None, st3p=None,
+             gpre=None, wd_hi=None, wd_lo=None, slab_d=None):
     def run():
         _chk(load().w2s_bwd_wide(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(st_in), _f(add_even), _p(w_hi), _p(w_lo), _f(gout), _f(part), _f(slab), nslab,
-                                 B, L, cg, ch, stride, _f(y3p), _f(st3p), 0, _stream()), f'w2s_bwd_wide(cg={cg},ch={ch},stride={stride})')
-    nbytes = 4 * (2 * B * (L // stride) * cg + 2 * B * L * ch + (B * L * ch // 2 if add_even is not None else 0) + (B * L * ch if y3p is not None else 0))
-    key = f'bwd_wide_kernel<{cg // 16}, {ch // 16}, {1 if st_in is not None else 0}, {stride}>'
+                                 B, L, cg, ch, stride, _f(y3p), _f(st3p), _f(gpre), _p(wd_hi), _p(wd_lo), _f(slab_d), 0, _stream()),
+             f'w2s_bwd_wide(cg={cg},ch={ch},stride={stride})')
+    nbytes = 4 * (2 * B * (L // stride) * cg + 2 * B * L * ch + (B * L * ch // 2 if add_even is not None else 0) + (B * L * ch if y3p is not None else 0)
+                  + (B * L * cg // 2 if gpre is not None else 0))
+    key = f'bwd_wide_kernel<{cg // 16}, {ch // 16}, {1 if st_in is not None else 0}, {stride}{", rd" if gpre is not None else ""}>'
     if DETAIL:
         key += f' L{L}'
     _timed(key, nbytes, 2 * B * (L // stride) * cg * ch * 3 * 2, run)
