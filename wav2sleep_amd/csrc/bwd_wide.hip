@@ -453,7 +453,7 @@ extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, c
                             const void* wd_lo, float* slab_d, int dry, void* stream) {
   if (!w2s_bwd_wide_tile(cg, ch, stride)) return 1;
   const bool rd = gpre != nullptr;
-  if (rd && (cg != 64 || stride != 1 || st_in || add_even || (L & 1) || (!dry && (!wd_hi || !wd_lo || !slab_d)))) return dry ? 1 : W2S_EINVAL;
+  if (rd && (stride != 1 || st_in || add_even || (L & 1) || (!dry && (!wd_hi || !wd_lo || !slab_d)))) return dry ? 1 : W2S_EINVAL;
   if (stride == 2 && (!st_in || add_even || (L & 1) || y3p)) return dry ? 1 : W2S_EINVAL;
   if (y3p && (!st3p || !part)) return W2S_EINVAL;
   if (!dry && (!g || !y || !st_k || !bst_k || !xin || !w_hi || !w_lo || !gout || !slab)) return W2S_EINVAL;
@@ -463,6 +463,7 @@ extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, c
   BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, y3p, st3p, gpre,
              static_cast<const __bf16*>(wd_hi), static_cast<const __bf16*>(wd_lo), slab_d, B, L, L / stride, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (cg == 32 && rd) return launch_bww<2, 2, 0, 4, 4, 1, 1, 3, 0, 1>(P, nslab, s, dry);
   if (cg == 32) return st_in ? launch_bww<2, 2, 1, 4, 4, 1, 1, 3>(P, nslab, s, dry) : launch_bww<2, 2, 0, 4, 4, 1, 1, 3>(P, nslab, s, dry);
   if (stride == 2) return launch_bww<4, 4, 1, 4, 4, 2, 2, 2, 1>(P, nslab, s, dry);
   if (rd) return ch == 64 ? launch_bww<4, 4, 0, 4, 4, 2, 2, 2, 0, 1>(P, nslab, s, dry) : launch_bww<4, 2, 0, 4, 4, 2, 1, 2, 0, 1>(P, nslab, s, dry);

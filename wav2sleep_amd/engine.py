@@ -117,6 +117,7 @@ class Engine:
         self.bwd_wide = os.environ.get('W2S_BWD_WIDE', '1') != '0'   # one-pass backward of the 64-channel stride-1 convs (csrc/bwd_wide.hip)
         self.bwd_wide32 = os.environ.get('W2S_BWD_WIDE32', '0') == '1'   # ... and of the 32 -> 32 stride-1 convs in the same role-split form (experiment)
         self.bwd_wide_rd = os.environ.get('W2S_BWD_WIDE_RD', '1') != '0'   # 64-channel conv1: residual branch folded into the one-pass kernel
+        self.bwd_wide_rd32 = os.environ.get('W2S_BWD_WIDE_RD32', '0') == '1'   # ... and the 32 -> 32 conv1 (block 3) the same way (experiment)
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
         if not spec.use_residual:
@@ -1007,7 +1008,8 @@ class Engine:
                     bs3_folded = None
                 gpre, gpre_hdr = gprev, hp
             elif (i > 0 and self.bwd_wide_rd and self.bwd_wide and self.split_precision and self.kpad == 1 and not (L & 1) and (p + 'downsample.weight') in self.G
-                  and self.PB[p + 'downsample.weight'].data_ptr() in self._bf and lib.bwd_wide_takes(B, L, c, cin, 1, False, rd=True)):
+                  and (c >= 64 or (self.bwd_wide_rd32 and not h16)) and self.PB[p + 'downsample.weight'].data_ptr() in self._bf
+                  and self.PB[p + 'conv1.conv.weight'].data_ptr() in self._bf and lib.bwd_wide_takes(B, L, c, cin, 1, False, rd=True)):
                 # 64-channel conv1: the whole residual branch (Wd^T gpre into the data gradient, the downsample weight gradient) and the
                 # previous block's conv3-backward statistics in the one-pass kernel -- no R tensor, no 1x1 conv launch, no separate weight gradient
                 gprev = torch.empty(B, L, cin, device=dev, dtype=torch.float32)
