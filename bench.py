@@ -250,7 +250,9 @@ def main():
                                    f'full train step fwd+CE+bwd+clip+AdamW' + (', causal convolutions (causal: True)' if args.causal else ''), 'global_batch': args.batch * world, 'epochs': args.epochs,
                        'parallelism': f'dp{world}', 'final_loss': round(loss, 5),
                        'precision': "fp32 storage + fp32 accumulate; >=32-channel GEMMs as bf16x3 split products on the matrix cores "
-                                    "(= the reference's float32_matmul_precision('high')); W2S_EXACT_FP32=1 for fp32 MFMA throughout"}}
+                                    "(= the reference's float32_matmul_precision('high')); W2S_EXACT_FP32=1 for fp32 MFMA throughout" +
+                                    ("; W2S_GRAD_FP16=1: inter-kernel gradient tensors of the <=32-channel encoder blocks stored as fp16 with "
+                                     "per-tensor power-of-two scales" if os.environ.get('W2S_GRAD_FP16') == '1' else '')}}
 
     agg = None
     if not args.no_roofline:

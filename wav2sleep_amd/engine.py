@@ -110,9 +110,10 @@ class Engine:
         self.fused_forward = os.environ.get('W2S_FUSED_FORWARD', '1') != '0'
         self.fold_gp = os.environ.get('W2S_FOLD_GP', '1') == '1'   # conv3-backward statistics of the previous block ride in the residual-fold conv1 kernel
         self.fused_finalize = os.environ.get('W2S_FUSED_FINALIZE', '0') != '0'
-        # fp16 storage of the gradient tensors between the fused-backward launches of the <= 32-channel blocks: half of
-        # those kernels' gradient bytes, fp32 arithmetic.  Measured round 3: -14 GB of traffic bought only -0.45 ms (those kernels are not
-        # bandwidth-bound) while the worst full-size gradient error went 4.4e-4 -> 1.0e-3: OFF by default, W2S_GRAD_FP16=1 switches it on
+        # W2S_GRAD_FP16=1: fp16 storage (one power-of-two scale per tensor, fp32 arithmetic) of the gradient tensors between the fused-backward
+        # launches of the <= 32-channel blocks.  Measured round 3, full suite green with it: -14 GB of traffic,
+        # 33.3 -> 32.8 ms per step (-1.6 %); worst full-size gradient tensor 4.4e-4 -> 1.1e-3 relative L2 (EOG 8.3e-4 -> 1.25e-3; bar 2e-3).
+        # OFF by default: 2.5 x the gradient error for 1.6 % is a trade a user should choose, not inherit
         self.grad_fp16 = os.environ.get('W2S_GRAD_FP16', '0') == '1'
         self.bwd_wide = os.environ.get('W2S_BWD_WIDE', '1') != '0'   # one-pass backward of the 64-channel stride-1 convs (csrc/bwd_wide.hip)
         self.bwd_wide32 = os.environ.get('W2S_BWD_WIDE32', '0') == '1'   # ... and of the 32 -> 32 stride-1 convs in the same role-split form (experiment)
