@@ -200,29 +200,3 @@ def test_fp16_gradient_chain_keeps_the_gradient_bar():
     assert set(runs[0][2]) == {0} and {1, 2} <= set(runs[1][2]) and 0 not in runs[1][2]   # every fused-backward launch of the chain run is an fp16 form
     assert torch.equal(runs[0][0], runs[1][0])                                              # logits: untouched
     assert torch.equal(runs[1][1], runs[2][1]) and not torch.equal(runs[0][1], runs[1][1])  # reproducible; and it does round
-
-
-def test_sequence_cnn_sample_split_does_not_change_a_bit():
-    """W2S_SEQ_SPLIT: the SequenceCNN's chain runs as two sample groups on two streams (pure scheduling: samples are independent there and
-    the gamma / beta partial sums keep their 32-row blocks when S is a multiple of 32): logits and the flat gradient must be bit-identical
-    to the unsplit run; with dropout the two groups draw different masks but forward and backward agree (the step still trains)."""
-    from wav2sleep_amd import engine as E
-    sm = {'ABD': 'ABD', 'ECG': 'ECG'}
-    cfg = O.ModelConfig(signal_map=sm, num_classes=4)
-    sd = O.make_state_dict(cfg, seed=44)
-    x, y = O.make_inputs(cfg, 4, 32, seed=440, missing={'ABD': [2]})
-    saved = E._SEQ_SPLIT
-    outs = []
-    try:
-        for split in (1, 2):
-            E._SEQ_SPLIT = split
-            model = build(sm, 4)
-            model.load_state_dict(sd)
-            model.to(DEV).train()
-            logits = model(to_dev(x))
-            F.cross_entropy(logits.reshape(-1, 4), y.to(DEV).reshape(-1).long(), ignore_index=-1).backward()
-            outs.append((logits.detach().clone(), model._flat_grad.clone()))
-    finally:
-        E._SEQ_SPLIT = saved
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert float(outs[0][1].abs().max()) > 0

@@ -31,7 +31,6 @@ _BWD_WGS32 = int(os.environ.get('W2S_BWD_WGS32', _BWD_WGS))
 _BWD_WGS_RD16 = int(os.environ.get('W2S_BWD_WGS_RD16', 768))  # the 16-channel residual-fold kernel fits three per CU
 _FWD_WGS16 = int(os.environ.get('W2S_FWD_WGS16', 1024))    # persistent workgroups of the forward kernel: 16 input channels (four per CU) ...
 _FWD_WGS = int(os.environ.get('W2S_FWD_WGS', 512))        # ... and the other forms
-_SEQ_SPLIT = int(os.environ.get('W2S_SEQ_SPLIT', 2))      # SequenceCNN: the batch as this many sample groups on separate streams (1: off)
 
 FIRST_TILE = 1024  # positions per statistics partial of the Cin=1 layer
 
@@ -622,18 +621,6 @@ class Engine:
 
         return X, layers
 
-    def _seq_parts(self, B, dev):
-        """[(first sample, samples, stream)] of the SequenceCNN's sample split: its 24 + 24 convolutions / row norms work on [B, S, 128]
-        tensors of 8 MB -- one wave of 240 workgroups each, latency-bound, and serial on the step's critical path with nothing beside them.
-        Samples are independent there (channel LayerNorm, per-sample convolutions), so the batch runs as W2S_SEQ_SPLIT halves on separate
-        streams: two half-size chains side by side."""
-        n = _SEQ_SPLIT if (self.multi_stream and B >= 2 * _SEQ_SPLIT and _SEQ_SPLIT > 1) else 1
-        main = torch.cuda.current_stream(dev)
-        if n == 1:
-            return [(0, B, main)], main
-        per = _cdiv(B, n)
-        return [(b0, min(per, B - b0), self._side_stream(f'_seq{k}', dev)) for k, b0 in enumerate(range(0, B, per))], main
-
     def seq(self, xin: torch.Tensor, ldin: int, B: int, S: int, ps: float = 0.0, save: bool = False):
         """SequenceCNN.forward (models/wav2sleep.py:379-390) on rows [B*S] of `xin` (row stride ldin); returns the last block's
         PRE-activation output [B, S, F] (the module output is GELU of it) and the saved tensors."""
@@ -645,16 +632,6 @@ class Engine:
         xin, ldin = X, D * F
         seq = []
         pre_out = None
-        parts, main = self._seq_parts(B, dev)
-        keep = []   # every tensor the part streams touch stays referenced until they have joined (all are allocated on the main stream)
-        for _, _, st in parts:
-            if st is not main:
-                st.wait_stream(main)
-
-        def each(fn):
-            for k, (b0, nb, st) in enumerate(parts):
-                with torch.cuda.stream(st):
-                    fn(k, b0, nb)
         for b in range(sp.seq_blocks):
             hcur, ldh = xin, ldin
             convs = []
@@ -662,39 +639,28 @@ class Engine:
                 d = 2 ** j
                 p = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.'
                 y = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                self._conv(x=hcur, w=self.PF[p + 'conv.weight'], y=y, B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1,
+                           dil=d, pad=(sp.seq_kernel - 1) * d if self.seq_causal else (sp.seq_kernel // 2) * d, mode=lib.MODE_DILATED, ldx=ldh)
                 hn = torch.empty(B, S, F, device=dev, dtype=torch.float32)
                 rs = torch.empty(B * S, 2, device=dev, dtype=torch.float32)
-                keep += [y, hn, rs, hcur]
-
-                def layer(k, b0, nb, hcur=hcur, ldh=ldh, y=y, hn=hn, rs=rs, p=p, d=d):
-                    self._conv(x=hcur.view(-1)[b0 * S * ldh:], w=self.PF[p + 'conv.weight'], y=y[b0:b0 + nb], B=nb, L_in=S, L_out=S, cin=F, cout=F,
-                               taps=sp.seq_kernel, stride=1, dil=d, pad=(sp.seq_kernel - 1) * d if self.seq_causal else (sp.seq_kernel // 2) * d,
-                               mode=lib.MODE_DILATED, ldx=ldh)
-                    lib.layernorm_fwd(y[b0:b0 + nb], F, P[p + 'norm.weight'], P[p + 'norm.bias'], hn[b0:b0 + nb], F, rs[b0 * S:], nb * S, F, sp.layer_eps, gelu=True)
-                each(layer)
+                lib.layernorm_fwd(y, F, P[p + 'norm.weight'], P[p + 'norm.bias'], hn, F, rs, B * S, F, sp.layer_eps, gelu=True)
                 if save:
                     convs.append(dict(hin=hcur, ldh=ldh, y=y, rs=rs))
                 hcur, ldh = hn, F
             pre_out = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-            xg = xin if ldin == F else torch.empty(B, S, F, device=dev, dtype=torch.float32)   # block 0 reads the strided CLS rows: gathered once (small)
-            act = torch.empty(B, S, F, device=dev, dtype=torch.float32) if b + 1 < sp.seq_blocks else None
-            keep += [pre_out, xg, act, xin, hcur]
-
-            def tail(k, b0, nb, xin=xin, ldin=ldin, xg=xg, hcur=hcur, pre_out=pre_out, act=act, b=b):
-                if ldin != F:
-                    xg.view(N, F)[b0 * S:(b0 + nb) * S].copy_(xin.view(N, D * F)[b0 * S:(b0 + nb) * S, :F])  # strided device copy (plumbing)
-                lib.eltwise(lib.ELT_ADD_DROP, xg[b0:b0 + nb], hcur[b0:b0 + nb], pre_out[b0:b0 + nb], nb * S * F, ps, self._seed(100 + b + 50 * k))
-                if act is not None:
-                    lib.eltwise(lib.ELT_GELU, pre_out[b0:b0 + nb], None, act[b0:b0 + nb], nb * S * F)
-            each(tail)
+            if ldin == F:
+                lib.eltwise(lib.ELT_ADD_DROP, xin, hcur, pre_out, B * S * F, ps, self._seed(100 + b))
+            else:  # block 0 reads the strided CLS rows: gather them once (small)
+                xg = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                xg.view(N, F).copy_(xin.view(N, D * F)[:, :F])  # strided device copy (plumbing)
+                lib.eltwise(lib.ELT_ADD_DROP, xg, hcur, pre_out, B * S * F, ps, self._seed(100 + b))
             if save:
                 seq.append(dict(convs=convs, pre_out=pre_out))
-            if act is not None:
+            if b + 1 < sp.seq_blocks:
+                act = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                lib.eltwise(lib.ELT_GELU, pre_out, None, act, B * S * F)
                 xin, ldin = act, F
-        for _, _, st in parts:
-            if st is not main:
-                main.wait_stream(st)
-        del keep
+
         return pre_out, seq
 
     def forward(self, x: dict[str, torch.Tensor], train: bool = False, save: bool = False, pack_key=None) -> torch.Tensor:
@@ -756,66 +722,36 @@ class Engine:
         self._colsum(part.view(-1)[nc * F:], nparts, nc, self.G['classifier.bias'], accumulate='classifier.bias' in self._written, ld=nc * F + nc)
         self._written.update(('classifier.weight', 'classifier.bias'))
 
-        # ---- SequenceCNN (the sample split of seq(): the data-gradient chain per half on its own stream; the weight gradients stay whole-batch
-        #      leaves, queued behind the join)
-        parts, main_s = self._seq_parts(B, dev)
-        keep = []
-        for _, _, st in parts:
-            if st is not main_s:
-                st.wait_stream(main_s)
-
-        def each(fn):
-            for k, (b0, nb, st) in enumerate(parts):
-                with torch.cuda.stream(st):
-                    fn(k, b0, nb)
-        leaves = []
+        # ---- SequenceCNN
         for b in reversed(range(sp.seq_blocks)):
             blk = c['seq'][b]
             gh = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-            keep += [g_pre, gh]
-            each(lambda k, b0, nb, g_pre=g_pre, gh=gh, b=b: lib.eltwise(lib.ELT_DROP, g_pre[b0:b0 + nb], None, gh[b0:b0 + nb], nb * S * F, ps,
-                                                                       self._seed(100 + b + 50 * k)))
+            lib.eltwise(lib.ELT_DROP, g_pre, None, gh, rows * F, ps, self._seed(100 + b))
             for j in reversed(range(sp.seq_dilations)):
                 d = 2 ** j
                 cv = blk['convs'][j]
                 p = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.'
                 gy = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-                nps = [max(1, min(1024, _cdiv(nb * S, 32))) for _, nb, _ in parts]   # partial rows of the gamma / beta sums per part
-                pg = torch.empty(sum(nps), F, device=dev, dtype=torch.float32)
-                pb = torch.empty(sum(nps), F, device=dev, dtype=torch.float32)
-                gh2 = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                npl = max(1, min(1024, _cdiv(rows, 32)))
+                pg = torch.empty(npl, F, device=dev, dtype=torch.float32)
+                pb = torch.empty(npl, F, device=dev, dtype=torch.float32)
+                lib.layernorm_bwd(gh, F, cv['y'], F, P[p + 'norm.weight'], P[p + 'norm.bias'], cv['rs'], None, gy, F, pg, pb, rows, F, True, npl)
+                self._colsum(pg, npl, F, self.G[p + 'norm.weight'], accumulate=(p + 'norm.weight') in self._written)
+                self._colsum(pb, npl, F, self.G[p + 'norm.bias'], accumulate=(p + 'norm.bias') in self._written)
+                self._written.update((p + 'norm.weight', p + 'norm.bias'))
                 pad = (sp.seq_kernel - 1) * d if self.seq_causal else (sp.seq_kernel // 2) * d
-                keep += [gy, pg, pb, gh2, gh]
-
-                def layer(k, b0, nb, gh=gh, gy=gy, pg=pg, pb=pb, gh2=gh2, cv=cv, p=p, d=d, pad=pad, nps=nps):
-                    r0 = sum(nps[:k])
-                    lib.layernorm_bwd(gh[b0:b0 + nb], F, cv['y'][b0:b0 + nb], F, P[p + 'norm.weight'], P[p + 'norm.bias'], cv['rs'][b0 * S:], None, gy[b0:b0 + nb], F,
-                                      pg[r0:], pb[r0:], nb * S, F, True, nps[k])
-                    self._conv(x=gy[b0:b0 + nb], w=PB[p + 'conv.weight'], y=gh2[b0:b0 + nb], B=nb, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1,
-                               dil=d, pad=(sp.seq_kernel - 1) * d - pad, flip=1, mode=lib.MODE_DILATED)
-                each(layer)
-                leaves.append((p, pg, pb, sum(nps), gy, cv, pad, d))
-                gh = gh2
+                self._wgrad(p + 'conv.weight', g=gy, x=cv['hin'], ldx=cv['ldh'], B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel,
+                            stride=1, pad=pad, dil=d)
+                gh = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                self._conv(x=gy, w=PB[p + 'conv.weight'], y=gh, B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1, dil=d,
+                           pad=(sp.seq_kernel - 1) * d - pad, flip=1, mode=lib.MODE_DILATED)
             gx = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-            g_new = torch.empty(B, S, F, device=dev, dtype=torch.float32) if b > 0 else None
-            keep += [gx, g_new, gh, g_pre]
-
-            def tail(k, b0, nb, g_pre=g_pre, gh=gh, gx=gx, g_new=g_new, b=b):
-                lib.eltwise(lib.ELT_ADD, g_pre[b0:b0 + nb], gh[b0:b0 + nb], gx[b0:b0 + nb], nb * S * F)
-                if g_new is not None:
-                    lib.eltwise(lib.ELT_GELU_BWD, c['seq'][b - 1]['pre_out'][b0:b0 + nb], gx[b0:b0 + nb], g_new[b0:b0 + nb], nb * S * F)
-            each(tail)
-            g_pre = g_new if b > 0 else gx   # (b == 0: the gradient w.r.t. the CLS rows of the transformer output)
-        for _, _, st in parts:
-            if st is not main_s:
-                main_s.wait_stream(st)
-        del keep
-        for p, pg, pb, npl, gy, cv, pad, d in leaves:   # whole-batch leaves of the chain above (deferred like the other trunk leaves)
-            self._colsum(pg, npl, F, self.G[p + 'norm.weight'], accumulate=(p + 'norm.weight') in self._written)
-            self._colsum(pb, npl, F, self.G[p + 'norm.bias'], accumulate=(p + 'norm.bias') in self._written)
-            self._written.update((p + 'norm.weight', p + 'norm.bias'))
-            self._wgrad(p + 'conv.weight', g=gy, x=cv['hin'], ldx=cv['ldh'], B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel,
-                        stride=1, pad=pad, dil=d)
+            lib.eltwise(lib.ELT_ADD, g_pre, gh, gx, rows * F)
+            if b > 0:
+                g_pre = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                lib.eltwise(lib.ELT_GELU_BWD, c['seq'][b - 1]['pre_out'], gx, g_pre, rows * F)
+            else:
+                g_pre = gx  # gradient w.r.t. the CLS rows of the transformer output
 
         # ---- set-fusion transformer
         R = N * D
