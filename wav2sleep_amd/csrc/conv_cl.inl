@@ -551,7 +551,7 @@ static int dispatch_tile(const w2s_conv_args& a, hipStream_t s) {
   }
   if constexpr (MODE == W2S_MODE_CONTIG && TAPS == 3 && STRIDE == 2)
     if (plain_io && a.pro == W2S_PRO_IN_GELU && a.epi == W2S_EPI_STATS) return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_IN_GELU, W2S_EPI_STATS>(a, s);
-  if constexpr (MODE == W2S_MODE_CONTIG && TAPS == 1 && STRIDE == 2)
+  if constexpr (TAPS == 1 && STRIDE == 2)   // (contiguous or per-tap window)
     if (plain_io && a.pro == W2S_PRO_GELU && a.epi == W2S_EPI_AUX_INGELU_ADD)
       return dispatch_cfg<TAPS, STRIDE, MODE, W2S_PRO_GELU, W2S_EPI_AUX_INGELU_ADD>(a, s);
   // transformer / SequenceCNN GEMMs (no on-load transform): without the prologue variants the 128-wide instance keeps its

@@ -231,7 +231,7 @@ def conv_forward(a: ConvArgs):
             ((mode, a.taps, a.stride) == (0, 1, 1) or (mode == 1 and a.taps == a.stride)):
         spec = (a.pro, a.epi)
     elif not a.y2 and not a.rowkeep and not a.reserved:
-        hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4), (6, 1)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)],
+        hot = {(0, 3, 1): [(2, 1), (3, 1), (4, 4), (6, 1)], (0, 3, 2): [(3, 1)], (0, 1, 2): [(2, 2)], (1, 1, 2): [(2, 2)], (2, 3, 2): [(5, 4)],
                (0, 1, 1): [(0, 3), (0, 0)], (1, 4, 4): [(0, 3)], (1, 3, 3): [(0, 3)], (0, 7, 1): [(0, 0)], (1, 7, 1): [(0, 0)]}
         if (a.pro, a.epi) in hot.get((mode, a.taps, a.stride), []):
             spec = (a.pro, a.epi)
