@@ -300,6 +300,14 @@ int w2s_head_fwd(const float* pre, int ld, const float* w, const float* bias, fl
  * glogits (optional) = gscale * dLoss/dlogits; cmat (optional) int64 [nc][nc] += counts (rows = true, cols = argmax) */
 int w2s_ce_fwd_bwd(const float* logits, const float* labels, int rows, int nc, float* part, float* loss_out, float* glogits,
                    long long* cmat, float gscale, void* stream);
+/* The same loss when the batch is processed as sample waves (FusedTrainStep's pipelined step): count[0] = number of labels != -1 of the
+ * WHOLE batch (a function of the labels alone: known before any logits exist); w2s_ce_wave = passes 1 and 3 of w2s_ce_fwd_bwd on one
+ * wave's rows (partials into part[ceil(rows/256)][2] -- the caller lays the waves' slices out one after the other -- and the gradient
+ * scaled by gscale / count[0]); w2s_ce_final = pass 2 over all `nblocks` partials: loss_out as above. */
+int w2s_ce_count(const float* labels, int rows, int nc, float* count, void* stream);
+int w2s_ce_wave(const float* logits, const float* labels, int rows, int nc, float* part, const float* count, float* glogits,
+                long long* cmat, float gscale, void* stream);
+int w2s_ce_final(const float* part, int nblocks, float* loss_out, void* stream);
 /* gpre = (glogits . W) * (gelu_in ? GELU'(pre) : 1); part[nparts][nc*F + nc] = block partials of dW, db (sum with w2s_colsum) */
 int w2s_head_bwd(const float* pre, int ld, const float* w, const float* glogits, float* gpre, int ldg, float* part, int nparts,
                  int rows, int F, int nc, int gelu_in, void* stream);

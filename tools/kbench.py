@@ -125,6 +125,9 @@ CASES = {
     'ff2': lambda: conv_case(128, 128, 76800 * 4, stride=4, B=1, taps=4, pro=lib.PRO_NONE, epi=lib.EPI_BIAS, mode=lib.MODE_DILATED),
     'seq1': lambda: conv_case(128, 128, 960, B=16, taps=7, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN, mode=lib.MODE_DILATED, dil=1, pad=3),
     'seq32': lambda: conv_case(128, 128, 960, B=16, taps=7, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN, mode=lib.MODE_DILATED, dil=32, pad=96),
+    **{f'seq{d}{m}': (lambda d=d, m=m: conv_case(128, 128, 960, B=16, taps=7, pro=lib.PRO_NONE, epi=lib.EPI_PLAIN,
+                                                 mode=lib.MODE_CONTIG if m == 'c' else lib.MODE_DILATED, dil=d, pad=3 * d))
+       for d in (1, 2, 4, 8, 16, 32) for m in 'cd'},
 }
 if __name__ == '__main__':
     ap = argparse.ArgumentParser(); ap.add_argument('names', nargs='*'); ap.add_argument('--iters', type=int, default=20)

@@ -32,5 +32,8 @@ for t, d in ev:
     act += d; last = t if act == 0 else last
     if act == 0: last = t
 out.append(f'device idle within the step: {idle / 1e6:.3f} ms; gaps > 20 us: ' + ', '.join(f'{a:.2f}ms:{g:.0f}us' for a, g in gaps[:30]))
+with open('gpurun_out/step_kernels.txt', 'w') as fk:   # every launch of the step: start (us), duration (us), queue, name
+    for r in step:
+        fk.write(f"{(int(r['Start_Timestamp']) - T0) / 1e3:10.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} q{r['Queue_Id']} {r['Kernel_Name'][:110]}\n")
 open('gpurun_out/step_timeline.txt', 'w').write('\n'.join(out) + '\n'); print('\n'.join(out))
 PY

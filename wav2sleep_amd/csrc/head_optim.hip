@@ -95,13 +95,13 @@ __global__ void ce_final_kernel(const float* __restrict__ part, int nblocks, flo
   out[1] = (float)c;
 }
 __global__ __launch_bounds__(256) void ce_grad_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
-                                                      const float* __restrict__ lossout, float* __restrict__ glogits, int rows, int nc,
+                                                      const float* __restrict__ count, float* __restrict__ glogits, int rows, int nc,
                                                       float gscale) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   const float yf = labels[row];
   const int y = (yf >= -1.f && yf < (float)nc) ? (int)yf : nc;
-  const float inv = (y == nc) ? NAN : gscale / lossout[1];
+  const float inv = (y == nc) ? NAN : gscale / count[0];
   float mx = -INFINITY;
   for (int c = 0; c < nc; ++c) mx = fmaxf(mx, logits[(size_t)row * nc + c]);
   float den = 0.f;
@@ -120,7 +120,49 @@ extern "C" int w2s_ce_fwd_bwd(const float* logits, const float* labels, int rows
   const int nb = (rows + 255) / 256;
   hipLaunchKernelGGL(ce_partial_kernel, dim3(nb), dim3(256), 0, s, logits, labels, rows, nc, part, cmat);
   hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(1), 0, s, part, nb, loss_out);
-  if (glogits) hipLaunchKernelGGL(ce_grad_kernel, dim3(nb), dim3(256), 0, s, logits, labels, loss_out, glogits, rows, nc, gscale);
+  if (glogits) hipLaunchKernelGGL(ce_grad_kernel, dim3(nb), dim3(256), 0, s, logits, labels, loss_out + 1, glogits, rows, nc, gscale);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// The same loss over a batch that arrives in sample waves (trainer.FusedTrainStep, W2S_WAVES): the number of counted labels is a function
+// of the labels alone, so it is known before the first wave's logits exist (w2s_ce_count); every wave then runs passes 1 and 3 on its rows
+// (w2s_ce_wave: partials into its slice of `part`, gradient scaled by the WHOLE batch's count), and pass 2 runs once over all partials.
+__global__ __launch_bounds__(256) void ce_count_kernel(const float* __restrict__ labels, int rows, int nc, float* __restrict__ count) {
+  __shared__ int red[256];
+  int n = 0;
+  for (int row = threadIdx.x; row < rows; row += 256) {
+    const float yf = labels[row];
+    const int y = (yf >= -1.f && yf < (float)nc) ? (int)yf : nc;
+    n += (y != -1);
+  }
+  red[threadIdx.x] = n;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count[0] = (float)red[0];
+}
+extern "C" int w2s_ce_count(const float* labels, int rows, int nc, float* count, void* stream) {
+  if (!labels || !count || rows < 0 || nc <= 0 || nc > W2S_MAXC) return W2S_EINVAL;
+  hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), labels, rows, nc, count);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+extern "C" int w2s_ce_wave(const float* logits, const float* labels, int rows, int nc, float* part, const float* count, float* glogits,
+                           long long* cmat, float gscale, void* stream) {
+  if (!logits || !labels || !part || !count || !glogits || nc <= 0 || nc > W2S_MAXC) return W2S_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nb = (rows + 255) / 256;
+  hipLaunchKernelGGL(ce_partial_kernel, dim3(nb), dim3(256), 0, s, logits, labels, rows, nc, part, cmat);
+  hipLaunchKernelGGL(ce_grad_kernel, dim3(nb), dim3(256), 0, s, logits, labels, count, glogits, rows, nc, gscale);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+extern "C" int w2s_ce_final(const float* part, int nblocks, float* loss_out, void* stream) {
+  if (!part || !loss_out || nblocks <= 0) return W2S_EINVAL;
+  hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), part, nblocks, loss_out);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

@@ -512,11 +512,8 @@ class Engine:
         return dict(sig=sig, enc=enc, x=x, keep=keep, blocks=blocks, plast=pin, zpre=zpre, zact=zact, rs_out=rs_out, S=S, B=Bfull, Bc=B) if save else None
 
     # ------------------------------------------------------------------ full forward
-    def encode(self, x: dict[str, torch.Tensor], save: bool = False, pack_key=None, cls: bool = True):
-        """SignalEncoders.forward (models/wav2sleep.py:146-161) + token assembly (:319-330): returns the set-fusion input
-        tokens [N, D, F] (token 0 = CLS, tokens 1.. = modalities in sorted order, zero rows for missing ones), the per-signal
-        keep masks [B] and, if `save`, what backward needs."""
-        sp, P = self.spec, self.P
+    def _validate(self, x: dict[str, torch.Tensor]):
+        sp = self.spec
         if len(x) == 0:
             raise ValueError('No signals provided to MultiModalAttentionEmbedder.')
         for s in x:
@@ -528,7 +525,13 @@ class Engine:
                 raise ValueError(f'Input length {tuple(v.shape)} of {s} must be [B, T] with T divisible by samples_per_epoch={spe}.')
         if len({(v.shape[0], v.shape[1] // COLS_TO_SAMPLES_PER_EPOCH[s]) for s, v in x.items()}) != 1:
             raise ValueError('all signals must share batch size and number of epochs')
-        self.ensure_packed(pack_key, need_bwd=save)
+        if len(x) + sp.register_tokens + 1 > 7:
+            raise ValueError(f'{len(x)} signals + {sp.register_tokens + 1} CLS/register tokens: the attention kernels hold at most 7 tokens per epoch')
+
+    def _encode_begin(self, x: dict[str, torch.Tensor], save: bool, cls: bool = True):
+        """Token tensor (CLS / register rows written on the current stream) and the encoder passes as generators, one list per encoder
+        stream; nothing of the encoders is enqueued yet.  Returns (state, tasks) for `_interleave` / `_encode_end`."""
+        sp, P = self.spec, self.P
         sigs = sorted(x.keys())  # wav2sleep.py:311
         first = x[sigs[0]]
         dev = first.device
@@ -536,17 +539,11 @@ class Engine:
         S = first.shape[1] // COLS_TO_SAMPLES_PER_EPOCH[sigs[0]]
         R1 = sp.register_tokens + 1   # CLS + register tokens occupy token slots 0..R
         F, D, N = sp.feature_dim, len(sigs) + R1, B * S
-        if D > 7:
-            raise ValueError(f'{len(sigs)} signals + {R1} CLS/register tokens: the attention kernels hold at most 7 tokens per epoch')
 
         tokens = torch.empty(N, D, F, device=dev, dtype=torch.float32)
         if cls:
             for r in range(R1):   # column r of the [1, 1, F, R+1] parameter
                 lib.add_rows(tokens.view(-1)[r * F:], D * F, P['epoch_mixer.register_tokens'].view(-1)[r:], R1, None, 1, N, F, False)
-        # The encoders are independent until the set-fusion transformer: each runs on its own HIP stream, so the
-        # matrix-core-bound 64/128-channel layers of one modality overlap the bandwidth-bound 16/32-channel layers of
-        # another and grid tails are filled (signals sharing an encoder share a stream: their weight gradients accumulate).
-        main = torch.cuda.current_stream(dev)
         keeps, enc_ctx = [None] * len(sigs), [None] * len(sigs)
         # launch order: longest encoder first (the streams run side by side; the 1024-samples-per-epoch encoders take 4x the time of the
         # 256 ones and set the end of this phase) -- token slot m stays the sorted position
@@ -556,7 +553,6 @@ class Engine:
             if xs.dtype != torch.float32 or not xs.is_contiguous():
                 xs = xs.float().contiguous()
             st = self._side_stream(sp.signal_map[s], dev)
-            st.wait_stream(main)
 
             def run(m=m, s=s, xs=xs):
                 keep = (~torch.isinf(xs[:, 0])).float()  # wav2sleep.py:150 (plumbing on B scalars)
@@ -577,13 +573,32 @@ class Engine:
                 if sp.embed_signals:   # + embedding row of this signal on the samples that have it (wav2sleep.py:155-159)
                     lib.add_rows(slot, D * F, P['signal_encoders.embedder.weight'][sorted(sp.signal_map).index(s)], 1, keep, S, N, F, True)
             tasks.setdefault(sp.signal_map[s], (st, []))[1].append(run())
-        self._interleave(tasks)
-        for s in sigs:
-            main.wait_stream(self._side_stream(sp.signal_map[s], dev))
-        keep_BD = torch.stack([torch.ones_like(keeps[0])] * R1 + keeps, dim=1)  # [B, D]
-        keypad = (keep_BD == 0).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
+        return dict(tokens=tokens, keeps=keeps, enc=enc_ctx, sigs=sigs, B=B, S=S, D=D, N=N, R1=R1), tasks
 
-        return dict(tokens=tokens, keeps=keeps, keypad=keypad, enc=enc_ctx, sigs=sigs, B=B, S=S, D=D, N=N, R1=R1)
+    def _encode_end(self, e):
+        """key-padding mask of the set-fusion transformer (the encoder streams have been joined / waited for)"""
+        B, S, D, N, keeps = e['B'], e['S'], e['D'], e['N'], e['keeps']
+        keep_BD = torch.stack([torch.ones_like(keeps[0])] * e['R1'] + keeps, dim=1)  # [B, D]
+        e['keypad'] = (keep_BD == 0).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
+        return e
+
+    def encode(self, x: dict[str, torch.Tensor], save: bool = False, pack_key=None, cls: bool = True):
+        """SignalEncoders.forward (models/wav2sleep.py:146-161) + token assembly (:319-330): returns the set-fusion input
+        tokens [N, D, F] (token 0 = CLS, tokens 1.. = modalities in sorted order, zero rows for missing ones), the per-signal
+        keep masks [B] and, if `save`, what backward needs."""
+        self._validate(x)
+        self.ensure_packed(pack_key, need_bwd=save)
+        e, tasks = self._encode_begin(x, save, cls)
+        # The encoders are independent until the set-fusion transformer: each runs on its own HIP stream, so the
+        # matrix-core-bound 64/128-channel layers of one modality overlap the bandwidth-bound 16/32-channel layers of
+        # another and grid tails are filled (signals sharing an encoder share a stream: their weight gradients accumulate).
+        main = torch.cuda.current_stream(e['tokens'].device)
+        for st, _ in tasks.values():
+            st.wait_stream(main)
+        self._interleave(tasks)
+        for st, _ in tasks.values():
+            main.wait_stream(st)
+        return self._encode_end(e)
 
     def mix(self, tokens: torch.Tensor, keypad: torch.Tensor, pm: float = 0.0, save: bool = False):
         """MultiModalAttentionEmbedder's transformer (models/wav2sleep.py:341-345) on tokens [N, D, F]; returns the final
@@ -663,12 +678,10 @@ class Engine:
 
         return pre_out, seq
 
-    def forward(self, x: dict[str, torch.Tensor], train: bool = False, save: bool = False, pack_key=None) -> torch.Tensor:
+    def _trunk_forward(self, e, pm, ps, save, logits=None):
+        """set-fusion transformer + SequenceCNN + classifier on the tokens of `e`; returns (logits [B, S, nc], saved context or None)"""
         sp, P = self.spec, self.P
         F = sp.feature_dim
-        pm = sp.mixer_dropout if train else 0.0
-        ps = sp.seq_dropout if train else 0.0
-        e = self.encode(x, save=save, pack_key=pack_key)
         tokens, keypad, B, S, D, N = e['tokens'], e['keypad'], e['B'], e['S'], e['D'], e['N']
         dev = tokens.device
         X, layers = self.mix(tokens, keypad, pm, save)
@@ -678,11 +691,19 @@ class Engine:
         pre_out, seq = self.seq(X, D * F, B, S, ps, save)
         if self.taps is not None:
             self.taps['seq_pre'] = pre_out
-        logits = torch.empty(B, S, sp.num_classes, device=dev, dtype=torch.float32)
+        if logits is None:
+            logits = torch.empty(B, S, sp.num_classes, device=dev, dtype=torch.float32)
         lib.head_fwd(pre_out, F, P['classifier.weight'], P['classifier.bias'], logits, B * S, F, sp.num_classes, True)
+        ctx = dict(B=B, S=S, D=D, N=N, sigs=e['sigs'], enc=e['enc'], keypad=keypad, layers=layers, seq=seq, pre_out=pre_out, pm=pm,
+                   ps=ps, tokens=tokens) if save else None
+        return logits, ctx
+
+    def forward(self, x: dict[str, torch.Tensor], train: bool = False, save: bool = False, pack_key=None) -> torch.Tensor:
+        sp = self.spec
+        e = self.encode(x, save=save, pack_key=pack_key)
+        logits, ctx = self._trunk_forward(e, sp.mixer_dropout if train else 0.0, sp.seq_dropout if train else 0.0, save)
         if save:
-            self.ctx = dict(B=B, S=S, D=D, N=N, sigs=e['sigs'], enc=e['enc'], keypad=keypad, layers=layers, seq=seq, pre_out=pre_out, pm=pm,
-                            ps=ps, tokens=tokens)
+            self.ctx = ctx
         return logits
 
     # ------------------------------------------------------------------ backward
@@ -695,9 +716,25 @@ class Engine:
             self._rjobs, self._cjobs = [], []
 
     def _backward(self, glogits, accumulate, hook):
-        sp, P, PB, c = self.spec, self.P, self.PB, self.ctx
+        c = self.ctx
         if c is None:
             raise RuntimeError('backward() needs forward(save=True) first')
+        self._backward_begin(accumulate)
+        dev = glogits.device
+        gX = self._backward_trunk(c, glogits, accumulate)
+        deferred, self._deferred = self._deferred, None
+        # ---- encoders
+        main = torch.cuda.current_stream(dev)
+        tasks = self._backward_tasks(c, gX, hook)
+        for st, _ in tasks.values():
+            st.wait_stream(main)
+        self._interleave(tasks, trunk=(main, self._trunk_leaves(deferred, [c], hook)))
+        for st, _ in tasks.values():
+            main.wait_stream(st)
+        self._backward_end(accumulate)
+        self.ctx = None
+
+    def _backward_begin(self, accumulate):
         if self.G is None:
             raise RuntimeError('engine was built without gradient buffers')
         self._written = set(self.G.keys()) if accumulate else set()
@@ -706,6 +743,17 @@ class Engine:
         # weight / bias gradients of the trunk are leaves of the backward graph: they are queued here and enqueued on this stream AFTER the
         # encoder streams have been forked, so that these small-grid kernels run beside the encoder backward instead of before it
         self._deferred = [] if (_DEFER_TRUNK and self.multi_stream) else None
+
+    def _backward_end(self, accumulate):
+        if not accumulate:
+            missing = [name for name in self.G if name not in self._written]
+            if missing:
+                raise RuntimeError(f'backward left gradients unwritten: {missing[:4]}')
+
+    def _backward_trunk(self, c, glogits, accumulate):
+        """classifier, SequenceCNN and set-fusion transformer backward of one saved context on the current stream (the data-gradient
+        chain; weight / bias gradients go to `self._deferred` when that is a list).  Returns the token gradient gX [N*D, F]."""
+        sp, P, PB = self.spec, self.P, self.PB
         B, S, D, N, F = c['B'], c['S'], c['D'], c['N'], sp.feature_dim
         dev = glogits.device
         nc = sp.num_classes
@@ -793,8 +841,7 @@ class Engine:
         if R1 == 1:
             self._colgrad('epoch_mixer.register_tokens', gX, N, F, ldg=D * F)
         else:
-            rt = 'epoch_mixer.register_tokens'
-            tmp = torch.empty(R1, F, device=dev, dtype=torch.float32)
+            c['rt_tmp'] = tmp = torch.empty(R1, F, device=dev, dtype=torch.float32)
             for r in range(R1):
                 nparts = max(1, min(1024, _cdiv(N, 64)))
                 part = torch.empty(nparts, F, device=dev, dtype=torch.float32)
@@ -813,41 +860,50 @@ class Engine:
                 part = torch.empty(nparts, F, device=dev, dtype=torch.float32)
                 lib.bias_grad(gk, N, F, F, part, nparts)
                 self._colsum(part, nparts, F, self.G[ew][order.index(ec['sig'])], accumulate=True)
-        deferred, self._deferred = self._deferred, None
         encs = [ec['enc'] for ec in c['enc']]
         if not accumulate:
             # encoders whose signals are not in this batch get no backward: their gradient is zero.  Written here, BEFORE any range is
             # handed to the reducer, so that nothing touches a range on the compute stream once its all-reduce may be in flight.
             for name, g in self.G.items():
-                if name.startswith('signal_encoders.encoders.') and name.split('.')[2] not in encs:
+                if name.startswith('signal_encoders.encoders.') and name.split('.')[2] not in encs and name not in self._written:
                     g.zero_()
                     self._written.add(name)
+        return gX
 
-        def trunk_leaves():
-            k = 0
-            while deferred:
-                deferred.pop(0)()   # popped before it runs: the closure (and the trunk gradient tensors it holds) is released right after
-                k += 1
-                if k % 3 == 0:
-                    yield
-            self._flush_reduce()
-            if R1 > 1:
+    def _trunk_leaves(self, deferred, ctxs, hook):
+        """Generator: the queued weight / bias gradients of the trunk (of every context in `ctxs`, in order), three per turn."""
+        sp = self.spec
+        F, R1 = sp.feature_dim, sp.register_tokens + 1
+        k = 0
+        while deferred:
+            deferred.pop(0)()   # popped before it runs: the closure (and the trunk gradient tensors it holds) is released right after
+            k += 1
+            if k % 3 == 0:
+                yield
+        self._flush_reduce()
+        if R1 > 1:
+            rt = 'epoch_mixer.register_tokens'
+            for c in ctxs:
                 g = self.G[rt].view(F, R1)
-                g.add_(tmp.t()) if rt in self._written else g.copy_(tmp.t())
+                g.add_(c['rt_tmp'].t()) if rt in self._written else g.copy_(c['rt_tmp'].t())
                 self._written.add(rt)
-            if hook is not None:
-                hook('_tail')  # mixer + sequence CNN + classifier gradients are final: their all-reduce can start
-                for e in dict.fromkeys(sp.signal_map.values()):
-                    if e not in encs:
-                        hook(e)   # absent encoder: its (zero) range still takes part in the collective, the bucket layout is static
-            yield
+        if hook is not None:
+            encs = [ec['enc'] for ec in ctxs[0]['enc']]
+            hook('_tail')  # mixer + sequence CNN + classifier gradients are final: their all-reduce can start
+            for e in dict.fromkeys(sp.signal_map.values()):
+                if e not in encs:
+                    hook(e)   # absent encoder: its (zero) range still takes part in the collective, the bucket layout is static
+        yield
 
-        # ---- encoders
-        main = torch.cuda.current_stream(dev)
+    def _backward_tasks(self, c, gX, hook):
+        """encoder -> (stream, [generators]) of one context's encoder backward (reads the token gradient gX)"""
+        sp = self.spec
+        B, S, D, F, R1 = c['B'], c['S'], c['D'], sp.feature_dim, sp.register_tokens + 1
+        dev = gX.device
+        encs = [ec['enc'] for ec in c['enc']]
         tasks = {}
         for m, ec in sorted(enumerate(c['enc']), key=lambda me: -COLS_TO_SAMPLES_PER_EPOCH[me[1]['sig']] if _LONGEST_FIRST else 0):
             st = self._side_stream(ec['enc'], dev)
-            st.wait_stream(main)
 
             def run(m=m, ec=ec):
                 for b0, sub in ec.get('chunks', [(0, ec)]):   # (chunks share the weights: one flush per chunk, accumulating)
@@ -856,15 +912,92 @@ class Engine:
                 if hook is not None and ec['enc'] not in encs[m + 1:]:
                     hook(ec['enc'])
             tasks.setdefault(ec['enc'], (st, []))[1].append(run())
-        self._interleave(tasks, trunk=(main, trunk_leaves()))
-        for e in dict.fromkeys(encs):
-            main.wait_stream(self._side_stream(e, dev))
+        return tasks
 
-        if not accumulate:
-            missing = [name for name in self.G if name not in self._written]
-            if missing:
-                raise RuntimeError(f'backward left gradients unwritten: {missing[:4]}')
-        self.ctx = None
+    def train_waves(self, x: dict[str, torch.Tensor], ce, bounds, seeds, logits: torch.Tensor, pack_key=None, accumulate: bool = False,
+                    hook=None):
+        """Forward + backward of one batch as SAMPLE WAVES (`bounds`: [(b0, b1), ...]) in a software pipeline.  Every sample is independent
+        up to the loss (instance norm in the encoders, layer norm in the trunk), so the trunk of wave w -- a serial chain of ~100 small
+        launches that leaves most of the device idle -- runs on the main stream BESIDE the encoder forward of wave w+1 / the encoder
+        backward of wave w-1 on the encoder streams, instead of between the two with nothing beside it:
+
+            encoder streams:  F(0) F(1) ... F(n-1) | B(0)       B(1) ...        B(n-1)
+            main stream:           T(0) ... T(n-2)   T(n-1) + trunk leaves (weight gradients of every wave)      -> joined
+
+        T(w) = set-fusion transformer + SequenceCNN + classifier + loss + their data-gradient chain of wave w; it waits for the event
+        recorded behind F(w) on every encoder stream, and B(w) waits for the event recorded behind T(w).  `ce(logits_w, b0, b1)` enqueues
+        the loss of one wave and returns d loss / d logits_w; the logits go to `logits[b0:b1]`.  Gradients of wave 0 overwrite (unless
+        `accumulate`), the later waves add -- the sums are those of gradient accumulation over the waves, in a fixed order."""
+        try:
+            self._train_waves(x, ce, bounds, seeds, logits, pack_key, accumulate, hook)
+        finally:
+            self._deferred = None
+            self._rjobs, self._cjobs = [], []
+
+    def _train_waves(self, x, ce, bounds, seeds, logits, pack_key, accumulate, hook):
+        sp = self.spec
+        self._validate(x)
+        self.ensure_packed(pack_key, need_bwd=True)
+        dev = logits.device
+        main = torch.cuda.current_stream(dev)
+        pm, ps = sp.mixer_dropout, sp.seq_dropout
+        # ---- encoder forward of every wave (tokens are allocated and their CLS rows written on the main stream BEFORE the fork)
+        waves = []
+        for (b0, b1), seed in zip(bounds, seeds):
+            self.step_seed = seed
+            waves.append(self._encode_begin({s: v[b0:b1] for s, v in x.items()}, True))
+        streams = list(dict.fromkeys(st for _, tasks in waves for st, _ in tasks.values()))
+        for st in streams:
+            st.wait_stream(main)
+        fwd_done = []
+        for (e, tasks), seed in zip(waves, seeds):
+            self.step_seed = seed
+            self._interleave(tasks)
+            evs = []
+            for st in streams:
+                if st != main:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    evs.append(ev)
+            fwd_done.append(evs)
+        # ---- trunk of every wave on the main stream
+        self._backward_begin(accumulate)
+        ctxs, gXs, trunk_done = [], [], []
+        for w, ((e, _), seed, (b0, b1)) in enumerate(zip(waves, seeds, bounds)):
+            self.step_seed = seed
+            for ev in fwd_done[w]:
+                main.wait_event(ev)
+            self._encode_end(e)
+            lg, c = self._trunk_forward(e, pm, ps, True, logits=logits[b0:b1])
+            gX = self._backward_trunk(c, ce(lg, b0, b1), accumulate or w > 0)
+            # a weight may appear once per reduction flush: close this wave's queue (behind its own leaves when those are deferred)
+            if self._deferred is not None:
+                rj, cj, self._rjobs, self._cjobs = self._rjobs, self._cjobs, [], []
+
+                def flush(rj=rj, cj=cj):
+                    self._rjobs[:0] = rj
+                    self._cjobs[:0] = cj
+                    self._flush_reduce()
+                self._deferred.append(flush)
+            else:
+                self._flush_reduce()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            ctxs.append(c)
+            gXs.append(gX)
+            trunk_done.append(ev)
+        deferred, self._deferred = self._deferred, None
+        # ---- encoder backward of every wave; the trunk's leaves ride beside the first one
+        for w, (c, gX, seed) in enumerate(zip(ctxs, gXs, seeds)):
+            self.step_seed = seed
+            tasks = self._backward_tasks(c, gX, hook if w == len(ctxs) - 1 else None)
+            for st, _ in tasks.values():
+                if st != main:
+                    st.wait_event(trunk_done[w])
+            self._interleave(tasks, trunk=(main, self._trunk_leaves(deferred, ctxs, hook)) if w == 0 else None)
+        for st in streams:
+            main.wait_stream(st)   # every tensor that crossed streams (tokens, gX, keeps) is still referenced here
+        self._backward_end(accumulate)
 
     def _ln_bwd(self, pfx, g, x, rstat, gadd, gx, rows):
         F = self.spec.feature_dim

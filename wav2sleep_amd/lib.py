@@ -55,7 +55,7 @@ class WgradArgs(C.Structure):
 EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
            'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
-           'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_head_bwd', 'w2s_sumsq_partial',
+           'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version']
 
 _lib = None
@@ -543,6 +543,18 @@ def head_fwd(pre, ld, w, bias, logits, rows, F, nc, gelu_in):
 def ce_fwd_bwd(logits, labels, rows, nc, part, loss_out, glogits, cmat, gscale=1.0):
     _chk(load().w2s_ce_fwd_bwd(_f(logits), _f(labels), rows, nc, _f(part), _f(loss_out), _f(glogits), _p(cmat), C.c_float(gscale), _stream()),
          'w2s_ce_fwd_bwd')
+
+
+def ce_count(labels, rows, nc, count):
+    _chk(load().w2s_ce_count(_f(labels), rows, nc, _f(count), _stream()), 'w2s_ce_count')
+
+
+def ce_wave(logits, labels, rows, nc, part, count, glogits, cmat, gscale=1.0):
+    _chk(load().w2s_ce_wave(_f(logits), _f(labels), rows, nc, _f(part), _f(count), _f(glogits), _p(cmat), C.c_float(gscale), _stream()), 'w2s_ce_wave')
+
+
+def ce_final(part, nblocks, loss_out):
+    _chk(load().w2s_ce_final(_f(part), nblocks, _f(loss_out), _stream()), 'w2s_ce_final')
 
 
 def head_bwd(pre, ld, w, glogits, gpre, ldg, part, nparts, rows, F, nc, gelu_in):

@@ -12,6 +12,7 @@
 from __future__ import annotations
 
 import math
+import os
 from collections import defaultdict
 
 import torch
@@ -115,8 +116,10 @@ class FusedTrainStep:
 
     def __init__(self, model: Wav2Sleep, lr: float = 1e-3, weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_norm: float = 1.0, warmup_steps: int = 2000, tau: float = 10000.0, process_group=None, scheduler: bool = True,
-                 accumulate: int = 1):
+                 accumulate: int = 1, waves: int | None = None):
         self.model = model
+        # sample waves of the pipelined step (engine.train_waves); 1 = the whole batch in one pass
+        self.waves = max(1, int(os.environ.get('W2S_WAVES', '1')) if waves is None else int(waves))
         model._ensure_flat()
         self.eng = model._engine
         flat = model._flat
@@ -192,30 +195,67 @@ class FusedTrainStep:
         first = self.micro == 0
         self.micro += 1
         last = self.micro == self.accumulate
+        B = next(iter(x.values())).shape[0] if len(x) else 0
+        nw = min(self.waves, B)
+        reduce = last and (self.reducer.world > 1 or self.reducer.force)
         with torch.cuda.device(self.device):
-            eng.step_seed = model._next_seed()
-            logits = eng.forward(x, train=True, save=True, pack_key=model.param_version())
-            B, S, nc = logits.shape
-            rows = B * S
-            yv = y.reshape(rows)
-            if yv.dtype != torch.float32:
-                yv = yv.float()
-            part = torch.empty((rows + 255) // 256, 2, device=logits.device, dtype=torch.float32)
-            glogits = torch.empty(rows, nc, device=logits.device, dtype=torch.float32)
-            self.cmat.zero_()
-            lib.ce_fwd_bwd(logits, yv.contiguous(), rows, nc, part, self.loss_out, glogits, self.cmat, self.reducer.grad_scale / self.accumulate)
-            if last and (self.reducer.world > 1 or self.reducer.force):
-                eng.backward(glogits, accumulate=not first, hook=self._on_ready)
+            if nw > 1:
+                logits = self._step_waves(x, y, nw, first, self._on_ready if reduce else None)
+            else:
+                eng.step_seed = model._next_seed()
+                logits = eng.forward(x, train=True, save=True, pack_key=model.param_version())
+                B, S, nc = logits.shape
+                rows = B * S
+                yv = y.reshape(rows)
+                if yv.dtype != torch.float32:
+                    yv = yv.float()
+                part = torch.empty((rows + 255) // 256, 2, device=logits.device, dtype=torch.float32)
+                glogits = torch.empty(rows, nc, device=logits.device, dtype=torch.float32)
+                self.cmat.zero_()
+                lib.ce_fwd_bwd(logits, yv.contiguous(), rows, nc, part, self.loss_out, glogits, self.cmat, self.reducer.grad_scale / self.accumulate)
+                eng.backward(glogits, accumulate=not first, hook=self._on_ready if reduce else None)
+            if reduce:
                 self.reducer.reduce_range(*self._enc_range)   # the encoder streams have joined the current stream
                 self.reducer.wait()
-            else:
-                eng.backward(glogits, accumulate=not first)
         out = dict(loss=self.loss_out[0], count=self.loss_out[1], cmat=self.cmat, logits=logits, stepped=last)
         if last:
             self.micro = 0
             out['lr'] = self.apply_optimizer()
             out['grad_norm'] = self.normcoef[0]
         return out
+
+    def _step_waves(self, x, y, nw, first, hook):
+        """The same micro-batch as `nw` sample waves in a software pipeline (engine.train_waves): the trunk of one wave runs beside the
+        encoders of its neighbours.  The loss is the mean over the WHOLE batch's counted labels: their number is taken from the labels
+        before anything else runs, every wave's gradient is scaled by it, and the loss value is reduced once over all waves' partials."""
+        model, eng = self.model, self.eng
+        dev = self.device
+        nc = model.num_classes
+        B, S = y.shape[0], y.numel() // max(1, y.shape[0])
+        rows = B * S
+        yv = y.reshape(rows)
+        if yv.dtype != torch.float32:
+            yv = yv.float()
+        yv = yv.contiguous()
+        bounds = [(B * i // nw, B * (i + 1) // nw) for i in range(nw)]
+        nblk = [((b1 - b0) * S + 255) // 256 for b0, b1 in bounds]
+        part = torch.empty(sum(nblk), 2, device=dev, dtype=torch.float32)
+        count = torch.empty(1, device=dev, dtype=torch.float32)
+        logits = torch.empty(B, S, nc, device=dev, dtype=torch.float32)
+        self.cmat.zero_()
+        lib.ce_count(yv, rows, nc, count)
+        scale = self.reducer.grad_scale / self.accumulate
+
+        def ce(lg, b0, b1):
+            w = [b[0] for b in bounds].index(b0)
+            r = (b1 - b0) * S
+            g = torch.empty(r, nc, device=dev, dtype=torch.float32)
+            lib.ce_wave(lg, yv[b0 * S:], r, nc, part[sum(nblk[:w]):], count, g, self.cmat, scale)
+            return g
+        eng.train_waves(x, ce, bounds, [model._next_seed() for _ in bounds], logits, pack_key=model.param_version(), accumulate=not first,
+                        hook=hook)
+        lib.ce_final(part, sum(nblk), self.loss_out)
+        return logits
 
     def _on_ready(self, stage: str):
         if stage == '_tail':
