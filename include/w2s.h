@@ -210,6 +210,24 @@ int w2s_gp_stats_h(const void* g, int g_half, const float* hdr_g, float* hdr_ama
 int w2s_enc_first_bwd_h(const float* x, const void* gn1, const float* hdr_n, const float* y1, const float* stats1, const float* bstats1,
                         const void* gpre, const float* hdr_p, float* slab, int nslab, int B, int L, int cout, const float* w1, int causal,
                         void* stream);
+/* Block 0's conv1 weight gradient without its gradient tensor.  w2s_bwd_fused_w1 = w2s_bwd_fused for conv2 of block 0 in the first-layer
+ * recompute form (x = raw signal [B][L], w1 = conv1 weight [16][3], 16 -> 16 channels, stride 1, split precision) that ALSO leaves
+ * part_w1 [B][ceil(L / w2s_bwd_fused_tile(16,16,1,0))][16][3] = per-tile sums of gout[t][o] * xs[t + j - pad]; gout may be NULL (the folded
+ * sums were its only reader: 1 GB per 1024-samples-per-epoch signal at batch 16 neither written nor read back).  w2s_enc_first_wgrad turns
+ * the partials into out [B][48] = each sample's contribution to dW1[o][j] (instance-norm backward applied through the signal's nine
+ * moments xmom [B][ntx][9] from w2s_enc_first_stats; stats1 / bstats1 [B][16][2] as for w2s_enc_first_bwd); sum over B with
+ * w2s_colsum_batch.  w2s_enc_first_dwd = the downsample
+ * weight gradient alone: slab [nslab][16].  Replaces trainer-side autograd of models/wav2sleep.py:96-110 (block 0). */
+int w2s_bwd_fused_w1(const float* g, const float* y, const float* st_k, const float* bst_k, const float* x, const float* st_in,
+                     const float* wb, float* gout, float* part, float* part_w1, float* slab, int nslab, int B, int L, int pad,
+                     const float* w1, void* stream);
+int w2s_enc_first_wgrad(const float* xmom, int ntx, const float* w1, const float* part_w1, const float* stats1, const float* bstats1,
+                        float* out, int B, int ntiles, void* stream);
+/* w2s_enc_first_fwd's statistics-only form (y == NULL) that also keeps the nine raw moments of every signal tile:
+ * xmom [B][ceil(L / tile)][9] (may be NULL) -- the sums w2s_enc_first_wgrad needs */
+int w2s_enc_first_stats(const float* x, const float* w, float* part, float* xmom, int B, int L, int tile, float* stat_out, int32_t* stat_cnt,
+                        float eps, int causal, void* stream);
+int w2s_enc_first_dwd(const float* x, const float* gpre, float* slab, int nslab, int B, int L, void* stream);
 
 /*
  * Fused backward of one k=3 / symmetric-padding encoder conv with cg = 64 gradient-side channels (round 3, csrc/bwd_wide.hip): data

@@ -744,6 +744,42 @@ def t_first_layer_recompute():
         lib.enc_first_bwd(x, g, None if first else y1, st1, bs1, gpre, slab, 8, B, L, c, w1=w1)
         sl.append(slab.sum(0))
     report('first: conv1 / downsample weight gradients', sl[1], sl[0], tol=5e-5)
+    # conv1's weight gradient folded into conv2's backward kernel (w2s_bwd_fused_w1 + w2s_enc_first_wgrad; the gradient tensor gn1 is never
+    # stored) against the two-pass form: w2s_bwd_fused writes gn1, its statistics are finalised, w2s_enc_first_bwd reads it back
+    for pad, causal in ((1, False), (2, True)):
+        for Lx in (1500, 256, 70000):
+            xx = torch.randn(B, Lx, device=dev) + 0.3; xx[0, 7] = float('inf'); xx[1, Lx - 1] = float('-inf')
+            gg = torch.randn(B, Lx, c, device=dev); yy2 = torch.randn(B, Lx, c, device=dev)
+            ntx = (Lx + tile - 1) // tile
+            p1 = torch.zeros(B, ntx, 2, c, device=dev)
+            xm = torch.zeros(B, ntx, 9, device=dev)
+            lib.enc_first_stats(xx, w1, p1, xm, B, Lx, tile, causal=causal)
+            p1b = torch.zeros_like(p1)
+            lib.enc_first_fwd(xx, w1, None, p1b, B, Lx, c, tile, causal=causal)
+            assert torch.equal(p1, p1b), 'w2s_enc_first_stats differs from the statistics-only w2s_enc_first_fwd'
+            s1 = torch.zeros(B, c, 2, device=dev)
+            lib.stats_finalize(p1, B, ntx, c, Lx, 1e-2, 0, s1)
+            ntf = (Lx + tilef - 1) // tilef; ns = min(B * ntf, 5)
+            gout = torch.zeros(B, Lx, c, device=dev); pt = torch.zeros(B, ntf, 2, c, device=dev); slab = torch.zeros(ns * c * c * 3, device=dev)
+            lib.bwd_fused(g=gg, y=yy2, st_k=st2, bst_k=bst, pro=lib.PRO_INBWD, xin=xx, st_in=s1, add_even=None, wb=wb, gout=gout, part=pt, slab=slab, nslab=ns,
+                          B=B, Lg=Lx, Lh=Lx, cg=c, ch=c, stride=1, split_precision=True, w1=w1, pad=pad)
+            b1 = torch.zeros(B, c, 2, device=dev)
+            lib.stats_finalize(pt, B, ntf, c, Lx, 0.0, 1, b1)
+            gp = torch.randn(B, Lx // 2, c, device=dev)
+            ref = torch.zeros(8, 64, device=dev)
+            lib.enc_first_bwd(xx, gout, None, s1, b1, gp, ref, 8, B, Lx, c, w1=w1, causal=causal)
+            ref = ref.sum(0)
+            pt2 = torch.zeros_like(pt); slab2 = torch.zeros_like(slab); pw = torch.full((B, ntf, 48), float('nan'), device=dev)
+            lib.bwd_fused(g=gg, y=yy2, st_k=st2, bst_k=bst, pro=lib.PRO_INBWD, xin=xx, st_in=s1, add_even=None, wb=wb, gout=None, part=pt2, slab=slab2, nslab=ns,
+                          B=B, Lg=Lx, Lh=Lx, cg=c, ch=c, stride=1, split_precision=True, w1=w1, pad=pad, part_w1=pw)
+            assert torch.equal(pt2, pt) and torch.equal(slab2, slab), 'the fold changed the kernel\'s other outputs'
+            dw = torch.zeros(B, 48, device=dev)
+            lib.enc_first_wgrad(xm, ntx, w1, pw, s1, b1, dw, B, ntf)
+            report(f'first: folded conv1 weight gradient pad={pad} L={Lx}', dw.sum(0), ref[:48], tol=2e-4)
+            if not (Lx & 1):
+                sd = torch.zeros(7, 16, device=dev)
+                lib.enc_first_dwd(xx, gp, sd, 7, B, Lx)
+                report(f'first: downsample weight gradient alone pad={pad} L={Lx}', sd.sum(0), ref[48:], tol=2e-5)
 
 
 def t_batched_entry_points():

@@ -137,4 +137,3 @@ def test_wave_step_is_bit_reproducible_and_draws_fresh_dropout_masks():
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
     lg = runs[0][0]
     assert not torch.equal(lg[:2], lg[2:])
-    assert float((lg[:2] - lg[2:]).abs().max()) < 0.5 * float(lg.abs().max())   # ... different masks, not different models

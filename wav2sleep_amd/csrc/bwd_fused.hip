@@ -34,6 +34,10 @@ struct BwdP {
   // fp16 gradient chain (split-precision kernels; w2s_common.h): gmode 0 = g / gpre / gout are fp32; 1 = g fp32 (header hdr_g: scale 1,
   // max from w2s_gp_stats), gout fp16; 2 = g, gpre and gout fp16.  hdr_o[1] must be zero at launch.
   int gmode; const float* hdr_g; const float* hdr_p; float* hdr_o;
+  // first-layer weight gradient folded in (first-layer recompute form only): part_w1[b][tile][16][3] = sum over the tile's positions of
+  // gout[t][o] * xs[t + j - pad] (xs = the sanitised, zero-padded signal) -- what w2s_enc_first_wgrad turns into dW1 without gout ever
+  // being stored (gout may then be NULL)
+  float* part_w1;
 };
 
 // LDS row strides: 16-channel rows stay unpadded (64-B rows: the three windows + weights of the 16x16 kernel then fit
@@ -383,6 +387,7 @@ void bwd_fused_bf_kernel(BwdP P) {
   __bf16* pH = wLo + HC * WROW;
   __bf16* pLo = pH + NRp * RSg;
   float* xsL = reinterpret_cast<float*>(pLo + NRp * RSg);   // FIRST: TM + 4 signal samples
+  float* redA = xsL + TM + 4;                               // FIRST: [4 waves][4 lane groups][12] scratch of the folded first-layer weight gradient
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4, q4 = r >> 2, p4 = r & 3;
   const int Lg = P.Lg, Lh = P.Lh;
@@ -677,6 +682,9 @@ void bwd_fused_bf_kernel(BwdP P) {
     f32x4 sA[CH], sB[CH];
 #pragma unroll
     for (int nt = 0; nt < CH; ++nt) { sA[nt] = (f32x4){0, 0, 0, 0}; sB[nt] = (f32x4){0, 0, 0, 0}; }
+    float aw[FIRST ? 12 : 1];   // FIRST + part_w1: this lane's sums of gout[pos][4g + e] * xs[pos + j - pad]  (index 3e + j)
+#pragma unroll
+    for (int k = 0; k < (FIRST ? 12 : 1); ++k) aw[k] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int pos = UP2 ? t0 + 2 * (wave * (8 * MT) + (mt >> 1) * 16 + r) + (mt & 1) : t0 + wave * (16 * MT) + mt * 16 + r;
@@ -700,11 +708,34 @@ void bwd_fused_bf_kernel(BwdP P) {
           sA[nt] += v;
           sB[nt] += v * n;
         }
+        if constexpr (FIRST) {
+          if (P.part_w1) {   // uniform.  xsL[i] <-> position t0 - 2 pad + i: conv1's tap j of position pos reads xsL[pos - t0 + pad + j]
+            const int xi = pos - t0 + PL;
+            const float x0 = xsL[xi], x1 = xsL[xi + 1], x2 = xsL[xi + 2];
+            const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              aw[3 * e] = fmaf(ve[e], x0, aw[3 * e]);
+              aw[3 * e + 1] = fmaf(ve[e], x1, aw[3 * e + 1]);
+              aw[3 * e + 2] = fmaf(ve[e], x2, aw[3 * e + 2]);
+            }
+          }
+        }
+        if (FIRST && !P.gout) continue;   // uniform: the folded first-layer weight gradient was this tensor's only reader
         if constexpr (OH) {
           amax = amax4(amax, v);
           st4h(reinterpret_cast<char*>(P.gout) + (size_t)b * Lh * HC * 2, (unsigned)pos * HC + ch, f2h4(v * s_out));
         } else {
           st4o(P.gout + (size_t)b * Lh * HC, (unsigned)pos * HC + ch, v);
+        }
+      }
+    }
+    if constexpr (FIRST) {
+      if (P.part_w1) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          const float sk = row16_sum(aw[k]);
+          if (r == 0) redA[(wave * 4 + g) * 12 + k] = sk;
         }
       }
     }
@@ -728,6 +759,15 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
         w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
+      }
+      if constexpr (FIRST) {
+        if (P.part_w1 && tid >= 64 && tid < 112) {   // (o, j) = ((tid - 64) / 3, (tid - 64) % 3); channel o sits in lane group o >> 2, slot o & 3
+          const int idx = tid - 64, o = idx / 3, j = idx % 3;
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) s += redA[(w * 4 + (o >> 2)) * 12 + (o & 3) * 3 + j];
+          P.part_w1[((size_t)b * P.ntiles + tile) * 48 + idx] = s;
+        }
       }
       w2s_stat_finish(P.fin, P.part, b, P.ntiles, HC, P.ntiles);
     }
@@ -812,7 +852,7 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = TM + 2, NRp = RD ? TM / 2 + 1 : 0;
   size_t lds = (size_t)TM * bwd_rs(HC) * 4 * (HC == 16 ? 2 : 1) + (size_t)bwd_redn(CH) * 4 +
                (size_t)2 * 2 * ((NRg + NRp) * bf_rs(GC) + NRh * bf_rs(HC) + HC * (KD + 8));
-  if (FIRST) lds += (size_t)(TM + 4) * 4;
+  if (FIRST) lds += (size_t)(TM + 4) * 4 + 4 * 4 * 12 * 4;
   if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4]
   auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST, GM>;
   if (lds > 64 * 1024 &&
@@ -847,18 +887,19 @@ static int bwd_fused_impl(const void* gv, const float* y, const float* st_k, con
                           const float* st_in, const float* add_even, const float* wb, void* goutv, float* part, float* slab, int nslab,
                           int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const void* gprev, const float* wd,
                           float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt,
-                          int gmode, const float* hdr_g, const float* hdr_p, float* hdr_o, void* stream) {
+                          int gmode, const float* hdr_g, const float* hdr_p, float* hdr_o, void* stream, float* part_w1 = nullptr) {
   const float* g = static_cast<const float*>(gv);
   const float* gpre = static_cast<const float*>(gprev);
   float* gout = static_cast<float*>(goutv);
-  if (!g || !y || !st_k || !bst_k || !xin || !wb || !gout || !slab || nslab <= 0) return W2S_EINVAL;
+  if (!g || !y || !st_k || !bst_k || !xin || !wb || (!gout && !part_w1) || !slab || nslab <= 0) return W2S_EINVAL;
+  if (part_w1 && (!w1 || !part || gmode)) return W2S_EINVAL;   // the fold lives in the first-layer recompute form (fp32 chain)
   if ((size_t)Lh * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;  // 32-bit lane offsets inside one sample
   if (pro != W2S_PRO_INBWD && pro != W2S_PRO_INBWD_GP) return W2S_EINVAL;
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
   if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in
   if (pad != 1 && !(pad == 2 && split_precision)) return W2S_EINVAL;                // causal padding: split-precision kernels only
   BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, pad, gpre, wd, slab_d, w1, y3p, st3p, StatFin{stat_out, stat_cnt, 1.0 / (double)Lh, 0.f, 1},
-         gmode, hdr_g, hdr_p, hdr_o};
+         gmode, hdr_g, hdr_p, hdr_o, part_w1};
   if (stat_out && (!stat_cnt || !part)) return W2S_EINVAL;
   if (y3p && (!gpre || !st3p || !part)) return W2S_EINVAL;
   const bool rd = gpre != nullptr;
@@ -901,6 +942,15 @@ extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, 
                              float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt, void* stream) {
   return bwd_fused_impl(g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, pad, split_precision, gpre,
                         wd, slab_d, w1, y3p, st3p, stat_out, stat_cnt, 0, nullptr, nullptr, nullptr, stream);
+}
+// conv2 of block 0 (first-layer recompute form: w1 != NULL) with the first layer's weight gradient folded in: per-tile partial sums into
+// part_w1 [B][ceil(L / tile)][16][3]; gout may be NULL (nothing else reads it).  w2s_enc_first_wgrad finishes the job.
+extern "C" int w2s_bwd_fused_w1(const float* g, const float* y, const float* st_k, const float* bst_k, const float* x, const float* st_in,
+                                const float* wb, float* gout, float* part, float* part_w1, float* slab, int nslab, int B, int L, int pad,
+                                const float* w1, void* stream) {
+  if (!part_w1) return W2S_EINVAL;
+  return bwd_fused_impl(g, y, st_k, bst_k, W2S_PRO_INBWD, x, st_in, nullptr, wb, gout, part, slab, nslab, B, L, L, 16, 16, 1, pad, 1, nullptr, nullptr,
+                        nullptr, w1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream, part_w1);
 }
 // the same launch with the gradient chain stored as fp16 (include/w2s.h, "fp16 gradient chain")
 extern "C" int w2s_bwd_fused_h(const void* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,

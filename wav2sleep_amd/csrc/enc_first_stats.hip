@@ -12,7 +12,7 @@
 // => 6 multiply-adds per sample instead of 16 channels x 5, then a 32-thread expansion per tile.  fp32 partials per tile, fp64 in
 // w2s_stats_finalize as for every other layer.
 __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
-                                                             int L, int tile, int ntiles, StatFin fin, int shift) {
+                                                             int L, int tile, int ntiles, StatFin fin, int shift, float* __restrict__ xmom) {
   __shared__ float red[4][9];
   __shared__ float tot[9];
   const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __res
   __syncthreads();
   if (tid < 9) tot[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   __syncthreads();
+  if (xmom && tid >= 32 && tid < 41) xmom[((size_t)b * ntiles + tl) * 9 + (tid - 32)] = tot[tid - 32];   // the tile's nine raw moments (w2s_enc_first_wgrad)
   if (tid < 32) {
     const int k = tid >> 4, o = tid & 15;
     const float w0 = w[o * 3], w1 = w[o * 3 + 1], w2 = w[o * 3 + 2];
@@ -48,8 +49,9 @@ __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __res
 }
 
 // launcher for w2s_enc_first_fwd (enc_misc.hip)
-int w2s_enc_first_stats_launch(const float* x, const float* w, float* part, int B, int L, int tile, int ntiles, StatFin fin, int shift, hipStream_t s) {
-  hipLaunchKernelGGL(enc_first_stats_kernel, dim3(ntiles, B), dim3(256), 0, s, x, w, part, L, tile, ntiles, fin, shift);
+int w2s_enc_first_stats_launch(const float* x, const float* w, float* part, int B, int L, int tile, int ntiles, StatFin fin, int shift, hipStream_t s,
+                               float* xmom) {
+  hipLaunchKernelGGL(enc_first_stats_kernel, dim3(ntiles, B), dim3(256), 0, s, x, w, part, L, tile, ntiles, fin, shift, xmom);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restr
   w2s_stat_finish(fin, part, b, ntiles, 16, ntiles);
 }
 
-int w2s_enc_first_stats_launch(const float* x, const float* w, float* part, int B, int L, int tile, int ntiles, StatFin fin, int shift, hipStream_t s);   // enc_first_stats.hip
+int w2s_enc_first_stats_launch(const float* x, const float* w, float* part, int B, int L, int tile, int ntiles, StatFin fin, int shift, hipStream_t s,
+                               float* xmom = nullptr);   // enc_first_stats.hip
 
 extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, float* stat_out,
                                  int* stat_cnt, float eps, int causal, void* stream) {
@@ -76,6 +77,16 @@ extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float
                      ntiles, fin, causal ? 1 : 0);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
+}
+
+// statistics-only form that also keeps the nine raw moments of every tile of the signal: xmom [B][ceil(L/tile)][9] (S0,S1,S2, A00,A11,A22,
+// A01,A12,A02 of enc_first_stats.hip) -- w2s_enc_first_wgrad needs their sums and this kernel has them anyway
+extern "C" int w2s_enc_first_stats(const float* x, const float* w, float* part, float* xmom, int B, int L, int tile, float* stat_out, int* stat_cnt,
+                                   float eps, int causal, void* stream) {
+  if (!x || !w || !part || tile < 64 || (tile & 63)) return W2S_EINVAL;
+  if (stat_out && !stat_cnt) return W2S_EINVAL;
+  const StatFin fin{stat_out, stat_cnt, 1.0 / (double)L, eps, 0};
+  return w2s_enc_first_stats_launch(x, w, part, B, L, tile, (L + tile - 1) / tile, fin, causal ? 1 : 0, reinterpret_cast<hipStream_t>(stream), xmom);
 }
 
 // pre[b,u,o] = GELU(IN(y3[b,u,o])) + wd[o] * san(x[b,2u])     (blocks.py:67-69, stored pre-activation)
@@ -253,6 +264,114 @@ extern "C" int w2s_enc_first_bwd_h(const float* x, const void* gn1, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------
+// First-layer weight gradient WITHOUT the gradient tensor gn1 (w2s_bwd_fused_w1 leaves per-tile sums A[o][j] = sum_t gn1[t][o] xs_j[t],
+// xs_j[t] = sanitised zero-padded signal at conv1's tap j of position t).  gy1 = rstd (gn1 - q1 - n1 q2) is linear in gn1, so
+//   dW1[o][j] = sum_b rstd_o ( A[o][j] - q1_o X[j] - q2_o N[o][j] ),   X[j] = sum_t xs_j[t],
+//   N[o][j] = sum_t n1[t][o] xs_j[t] = rstd_o ( sum_k w1[o][k] XX[k][j] - mean_o X[j] ),   XX[k][j] = sum_t xs_k[t] xs_j[t]
+// (n1 = IN(conv1(x)) is itself linear in the signal: the nine moments X, XX of each sample replace the [L][16] tensor; the forward's
+// statistics kernel leaves them per tile, w2s_enc_first_stats).  One workgroup per sample, everything summed in a fixed order in fp64;
+// out[b][48] = that sample's term (summed over b by w2s_colsum_batch like every other slab).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void enc_first_wgrad_kernel(const float* __restrict__ xmom, int ntx, const float* __restrict__ w1,
+                                                               const float* __restrict__ part_w1, const float* __restrict__ stats1,
+                                                               const float* __restrict__ bstats1, float* __restrict__ out, int ntiles) {
+  __shared__ double mred[64][9];
+  __shared__ double mom[9];
+  __shared__ double ared[21][48];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64 * 9) {   // signal moments: thread (ln, k) = (tid / 9, tid % 9) walks the signal tiles ln, ln + 64, ...
+    const int ln = tid / 9, k = tid % 9;
+    double s = 0.0;
+    for (int t = ln; t < ntx; t += 64) s += (double)xmom[((size_t)b * ntx + t) * 9 + k];
+    mred[ln][k] = s;
+  }
+  if (tid < 21 * 48) {  // tile partials: thread (ln, k) = (tid / 48, tid % 48) walks tiles ln, ln + 21, ...
+    const int ln = tid / 48, k = tid % 48;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const float* p = part_w1 + (size_t)b * ntiles * 48 + k;
+    int t = ln;
+    for (; t + 63 < ntiles; t += 84) {   // four loads in flight
+      s0 += (double)p[(size_t)t * 48]; s1 += (double)p[(size_t)(t + 21) * 48];
+      s2 += (double)p[(size_t)(t + 42) * 48]; s3 += (double)p[(size_t)(t + 63) * 48];
+    }
+    for (; t < ntiles; t += 21) s0 += (double)p[(size_t)t * 48];
+    ared[ln][k] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  if (tid < 9) {
+    double v = 0.0;
+    for (int w = 0; w < 64; ++w) v += mred[w][tid];
+    mom[tid] = v;
+  }
+  __syncthreads();
+  if (tid < 48) {
+    const int o = tid / 3, j = tid % 3;
+    double A = 0.0;
+    for (int ln = 0; ln < 21; ++ln) A += ared[ln][tid];
+    const double X[3] = {mom[0], mom[1], mom[2]};
+    const double XX[3][3] = {{mom[3], mom[6], mom[8]}, {mom[6], mom[4], mom[7]}, {mom[8], mom[7], mom[5]}};   // XX[k][j]
+    const double mean = stats1[((size_t)b * 16 + o) * 2], rstd = stats1[((size_t)b * 16 + o) * 2 + 1];
+    const double q1 = bstats1[((size_t)b * 16 + o) * 2], q2 = bstats1[((size_t)b * 16 + o) * 2 + 1];
+    double wx = 0.0;
+    for (int k = 0; k < 3; ++k) wx += (double)w1[o * 3 + k] * XX[k][j];
+    const double N = rstd * (wx - mean * X[j]);
+    out[(size_t)b * 48 + tid] = (float)(rstd * (A - q1 * X[j] - q2 * N));
+  }
+}
+extern "C" int w2s_enc_first_wgrad(const float* xmom, int ntx, const float* w1, const float* part_w1, const float* stats1, const float* bstats1,
+                                   float* out, int B, int ntiles, void* stream) {
+  if (!xmom || !w1 || !part_w1 || !stats1 || !bstats1 || !out || B <= 0 || ntx <= 0 || ntiles <= 0) return W2S_EINVAL;
+  hipLaunchKernelGGL(enc_first_wgrad_kernel, dim3(B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), xmom, ntx, w1, part_w1, stats1, bstats1,
+                     out, ntiles);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// Weight gradient of block 0's 1x1 / stride-2 residual conv alone: dWd[o] = sum_{b,u} gpre[b][u][o] * san(x[b][2u]); slab[wg][16].
+__global__ __launch_bounds__(256) void enc_first_dwd_kernel(const float* __restrict__ x, const float* __restrict__ gpre, float* __restrict__ slab,
+                                                            int B, int L) {
+  __shared__ float red[4][4][4];
+  const int tid = threadIdx.x, og = tid & 3, lane = tid & 63, wave = tid >> 6;
+  const int Lh = L >> 1;
+  const size_t total = (size_t)B * Lh;
+  f32x4 acc = {0, 0, 0, 0};
+  // thread = (position lane tid >> 2, channel group og); four positions in flight
+  for (size_t u0 = (size_t)blockIdx.x * 256 + (tid >> 2); u0 < total; u0 += (size_t)gridDim.x * 256) {   // (a wave reads 16 consecutive rows)
+    f32x4 gv[4];
+    float xv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = u0 + 64 * k < total;
+      const size_t u = ok ? u0 + 64 * k : total - 1;
+      gv[k] = ld4(gpre + u * 16 + og * 4);
+      const size_t b = u / Lh, uu = u % Lh;
+      const float v = x[b * L + 2 * uu];
+      xv[k] = (ok && !isinf(v)) ? v : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc.x = fmaf(gv[k].x, xv[k], acc.x); acc.y = fmaf(gv[k].y, xv[k], acc.y);
+      acc.z = fmaf(gv[k].z, xv[k], acc.z); acc.w = fmaf(gv[k].w, xv[k], acc.w);
+    }
+  }
+  float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float s = v[e];
+    s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    if (lane < 4) red[wave][lane][e] = s;
+  }
+  __syncthreads();
+  if (tid < 16) slab[(size_t)blockIdx.x * 16 + tid] = (red[0][tid >> 2][tid & 3] + red[1][tid >> 2][tid & 3]) + (red[2][tid >> 2][tid & 3] + red[3][tid >> 2][tid & 3]);
+}
+extern "C" int w2s_enc_first_dwd(const float* x, const float* gpre, float* slab, int nslab, int B, int L, void* stream) {
+  if (!x || !gpre || !slab || nslab <= 0 || B <= 0 || L <= 0 || (L & 1)) return W2S_EINVAL;
+  hipLaunchKernelGGL(enc_first_dwd_kernel, dim3(nslab), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gpre, slab, B, L);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // partial sums -> per-(b,c) statistics.  kind 0: (mean, rstd) with biased variance + eps
 // (nn.InstanceNorm1d, models/utils.py:89-92);  kind 1: (sum1/count, sum2/count).  fp64 accumulation.
 // ---------------------------------------------------------------------------------------------------
@@ -324,18 +443,29 @@ __global__ __launch_bounds__(256) void gp_stats_kernel(const void* __restrict__ 
   f32x4 s01 = ld4(st), s23 = ld4(st + 4);
   f32x4 mean = {s01.x, s01.z, s23.x, s23.z}, rstd = {s01.y, s01.w, s23.y, s23.w};
   f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
-  for (int rr = row0; rr < tile; rr += rstep) {
-    const int t = tl * tile + rr;
-    if (t >= L) break;
-    const size_t off = ((size_t)b * L + t) * C + myc4 * 4;
-    f32x4 n = (ld4(y + off) - mean) * rstd;
-    f32x4 graw;
-    if constexpr (GH) graw = h2f4(*reinterpret_cast<const h16x4*>(static_cast<const _Float16*>(gv) + off)) * inv_g;
-    else graw = ld4(g + off);
-    amax = amax4(amax, graw);
-    f32x4 gn = graw * gelu_grad4(n);
-    a1 += gn;
-    a2 += gn * n;
+  // four rows in flight per thread (the deep layers run this kernel with a few hundred workgroups: one dependent load pair per
+  // iteration left it at 45 us for 60 MB); rows beyond the recording load row L-1 again and are masked out
+  for (int rr = row0; rr < tile; rr += 4 * rstep) {
+    f32x4 yv[4], gr[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tl * tile + rr + u * rstep;
+      ok[u] = (rr + u * rstep < tile) && (t < L);
+      const size_t off = ((size_t)b * L + (ok[u] ? t : L - 1)) * C + myc4 * 4;
+      yv[u] = ld4(y + off);
+      if constexpr (GH) gr[u] = h2f4(*reinterpret_cast<const h16x4*>(static_cast<const _Float16*>(gv) + off)) * inv_g;
+      else gr[u] = ld4(g + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      const f32x4 n = (yv[u] - mean) * rstd;
+      amax = amax4(amax, gr[u]);
+      const f32x4 gn = gr[u] * gelu_grad4(n);
+      a1 += gn;
+      a2 += gn * n;
+    }
   }
   st4(sm + tid * 8, a1);
   st4(sm + tid * 8 + 4, a2);

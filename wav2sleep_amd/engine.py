@@ -110,6 +110,7 @@ class Engine:
         self.fused_forward = os.environ.get('W2S_FUSED_FORWARD', '1') != '0'
         self.fold_gp = os.environ.get('W2S_FOLD_GP', '1') == '1'   # conv3-backward statistics of the previous block ride in the residual-fold conv1 kernel
         self.fused_finalize = os.environ.get('W2S_FUSED_FINALIZE', '0') != '0'
+        self.fold_w1 = os.environ.get('W2S_FOLD_W1', '1') != '0'   # block 0: conv1's weight gradient inside conv2's backward kernel, gn1 never stored
         # W2S_GRAD_FP16=1: fp16 storage (one power-of-two scale per tensor, fp32 arithmetic) of the gradient tensors between the fused-backward
         # launches of the <= 32-channel blocks.  Measured round 3, full suite green with it: -14 GB of traffic,
         # 33.3 -> 32.8 ms per step (-1.6 %); worst full-size gradient tensor 4.4e-4 -> 1.1e-3 relative L2 (EOG 8.3e-4 -> 1.25e-3; bar 2e-3).
@@ -311,7 +312,7 @@ class Engine:
         self._written.add(name)
 
     def _bwd_fused(self, name, *, g, y, st_k, bst_k, pro, xin, st_in, add_even, gout, want_part, B, Lg, Lh, cg, ch, stride,
-                   gpre=None, down=None, w1=None, y3p=None, st3p=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None):
+                   gpre=None, down=None, w1=None, y3p=None, st3p=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None, part_w1=None):
         """dgrad + wgrad of one k=3 encoder conv in one pass (<= 32 channels); returns the backward statistics or None.
         gpre / down (conv1 of a residual block): fold the 1x1/stride-2 residual branch `down` in as well."""
         dev = g.device
@@ -325,7 +326,7 @@ class Engine:
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
                       part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, pad=self.kpad, split_precision=self.split_precision,
                       gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1, y3p=y3p, st3p=st3p, stat_out=so, stat_cnt=sc,
-                      gmode=gmode, hdr_g=hdr_g, hdr_p=hdr_p, hdr_o=hdr_o)
+                      gmode=gmode, hdr_g=hdr_g, hdr_p=hdr_p, hdr_o=hdr_o, part_w1=part_w1)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         if gpre is not None:
@@ -459,7 +460,11 @@ class Engine:
         nt = _cdiv(L, FIRST_TILE)
         part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
         so, sc = self._fin(B, c, dev)
-        lib.enc_first_fwd(x, w1, y1, part, B, L, c, FIRST_TILE, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps, causal=self.causal)
+        xmom = torch.empty(B, nt, 9, device=dev, dtype=torch.float32) if (recompute and save and self.fold_w1) else None
+        if xmom is not None:   # (the signal's raw moments per tile: what the folded first-layer weight gradient needs in backward)
+            lib.enc_first_stats(x, w1, part, xmom, B, L, FIRST_TILE, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps, causal=self.causal)
+        else:
+            lib.enc_first_fwd(x, w1, y1, part, B, L, c, FIRST_TILE, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps, causal=self.causal)
         st1 = so if so is not None else self._finalize(part, B, nt, c, L, 0)
         if recompute:
             y2, st2 = self._conv_stats(x=x, x2=w1, w=PF[pfx + 'cnn.0.conv2.conv.weight'], B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1,
@@ -509,7 +514,7 @@ class Engine:
             lib.layernorm_fwd(zact, F, P[pfx + 'output_norm.weight'], P[pfx + 'output_norm.bias'], tok_slice, ldtok, rs_out, Bfull * S, F, sp.layer_eps)
         if self.taps is not None:
             self.taps[f'{sig}.zpre'] = zpre
-        return dict(sig=sig, enc=enc, x=x, keep=keep, blocks=blocks, plast=pin, zpre=zpre, zact=zact, rs_out=rs_out, S=S, B=Bfull, Bc=B) if save else None
+        return dict(sig=sig, enc=enc, x=x, xmom=xmom, keep=keep, blocks=blocks, plast=pin, zpre=zpre, zact=zact, rs_out=rs_out, S=S, B=Bfull, Bc=B) if save else None
 
     # ------------------------------------------------------------------ full forward
     def _validate(self, x: dict[str, torch.Tensor]):
@@ -1080,6 +1085,8 @@ class Engine:
                 bs3, bs3_folded = bs3_folded, None
             else:
                 tile = 512
+                while tile > 64 and B * _cdiv(Lh, tile) < 1024:   # deep layers: enough workgroups to fill the device
+                    tile //= 2
                 nt = _cdiv(Lh, tile)
                 part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
                 if h16 or ghalf:
@@ -1091,8 +1098,12 @@ class Engine:
                     so, sc = self._fin(B, c, dev)
                     lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile, stat_out=so, stat_cnt=sc)
                     bs3 = so if so is not None else self._bstats(part, B, nt, c, Lh)
+            # block 0 in the first-layer recompute flow: conv1's weight gradient rides in conv2's backward kernel (per-tile sums of gn1 x signal
+            # taps), so gn1 -- which only that weight gradient would read -- is never stored (fp32 chain, split-precision kernels)
+            fold_w1 = (i == 0 and blk['y1'] is None and ec.get('xmom') is not None and not h16 and self.split_precision and c == 16
+                       and lib.bwd_fused_supported(c, c) and self._fused_bwd_ok)
             gn2 = torch.empty(B, L, c, device=dev, dtype=gdt)
-            gn1 = torch.empty(B, L, c, device=dev, dtype=gdt)
+            gn1 = None if fold_w1 else torch.empty(B, L, c, device=dev, dtype=gdt)
             h2 = new_hdr() if h16 else None
             h1 = new_hdr() if h16 else None
             if lib.bwd_fused_supported(c, c) and self._fused_bwd_ok:
@@ -1104,10 +1115,12 @@ class Engine:
                     bs1 = self._bwd_wide(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, xin=blk['y1'], st_in=blk['st1'],
                                          add_even=None, gout=gn1, want_part=True, B=B, L=L, cg=c, ch=c)
                 else:
+                    if fold_w1:
+                        part_w1 = torch.empty(B, _cdiv(L, lib.bwd_fused_tile(c, c, 1, False)), 48, device=dev, dtype=torch.float32)
                     bs1 = self._bwd_fused(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, pro=lib.PRO_INBWD,
                                           xin=ec['x'] if first else blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B,
                                           Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None,
-                                          gmode=2 if h16 else 0, hdr_g=h2, hdr_o=h1)
+                                          gmode=2 if h16 else 0, hdr_g=h2, hdr_o=h1, part_w1=part_w1 if fold_w1 else None)
             else:
                 if not (L & 1) and self._bwd_wide_ok(B, L, c, c, stride=2):
                     bs2 = self._bwd_wide(p + 'conv3.conv.weight', g=gpre, y=blk['y3'], st_k=blk['st3'], bst_k=bs3, xin=blk['y2'], st_in=blk['st2'],
@@ -1176,6 +1189,16 @@ class Engine:
                 self._wgrad(p + 'downsample.weight', g=gpre, x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=Lh, cin=cin, cout=c,
                             taps=1, stride=2, pad=0)
                 gpre, gpre_hdr = gprev, hp
+            elif gn1 is None:   # (fold_w1) conv1's weight gradient from the folded partials; the downsample weight gradient on its own
+                n1, nd = p + 'conv1.conv.weight', p + 'downsample.weight'
+                dw1 = torch.empty(B, 48, device=dev, dtype=torch.float32)
+                lib.enc_first_wgrad(ec['xmom'], ec['xmom'].shape[1], P[n1], part_w1, blk['st1'], bs1, dw1, B, part_w1.shape[1])
+                self._colsum(dw1, B, 48, self.G[n1], accumulate=n1 in self._written)
+                nslab = max(1, min(1024, _cdiv(B * Lh, 2048)))
+                slab = torch.empty(nslab, 16, device=dev, dtype=torch.float32)
+                lib.enc_first_dwd(ec['x'], gpre, slab, nslab, B, L)
+                self._colsum(slab, nslab, 16, self.G[nd], accumulate=nd in self._written)
+                self._written.update((n1, nd))
             else:
                 nslab = max(1, min(1024, _cdiv(B * L, 4096)))
                 slab = torch.empty(nslab, 64, device=dev, dtype=torch.float32)

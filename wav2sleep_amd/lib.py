@@ -53,7 +53,7 @@ class WgradArgs(C.Structure):
 
 
 EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
-           'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
+           'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version']
@@ -335,8 +335,10 @@ def _h(t):
 
 
 def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False, pad=1,
-              gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None, stat_out=None, stat_cnt=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None):
-    """gmode 1 / 2: the fp16 gradient chain (include/w2s.h): gout (and, gmode 2, g / gpre) are fp16 tensors with the headers hdr_*."""
+              gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None, stat_out=None, stat_cnt=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None,
+              part_w1=None):
+    """part_w1 (conv2 of block 0, w1 given): also leave the first layer's weight-gradient partials; gout may then be None.
+    gmode 1 / 2: the fp16 gradient chain (include/w2s.h): gout (and, gmode 2, g / gpre) are fp16 tensors with the headers hdr_*."""
     gin = _h if gmode == 2 else _f
     gou = _h if gmode else _f
 
@@ -346,11 +348,15 @@ def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, s
                                         _f(slab), nslab, B, Lg, Lh, cg, ch, stride, pad, gin(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p),
                                         gmode, _f(hdr_g), _f(hdr_p), _f(hdr_o), _stream()), f'w2s_bwd_fused_h(cg={cg},ch={ch},stride={stride},gmode={gmode})')
             return
+        if part_w1 is not None:
+            _chk(load().w2s_bwd_fused_w1(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(st_in), _f(wb), _f(gout), _f(part), _f(part_w1), _f(slab), nslab, B, Lh,
+                                         pad, _f(w1), _stream()), 'w2s_bwd_fused_w1')
+            return
         _chk(load().w2s_bwd_fused(_f(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), _f(gout), _f(part),
                                   _f(slab), nslab, B, Lg, Lh, cg, ch, stride, pad, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p), _f(stat_out), _p(stat_cnt), _stream()),
              f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
     wg, wo = (2 if gmode == 2 else 4), (2 if gmode else 4)   # bytes per stored gradient element in / out
-    nbytes = (B * Lg * cg * (wg + 4) + (B * Lh * (4 * 1 + wo * ch) if w1 is not None else B * Lh * ch * (4 + wo)) + (4 * B * Lh * ch // 2 if add_even is not None else 0)
+    nbytes = (B * Lg * cg * (wg + 4) + (B * Lh * (4 * 1 + (wo * ch if gout is not None else 0)) if w1 is not None else B * Lh * ch * (4 + wo)) + (4 * B * Lh * ch // 2 if add_even is not None else 0)
               + (wg * B * Lh * cg // 2 if gpre is not None else 0) + (4 * B * Lh * ch if y3p is not None else 0))
     flops = 2 * B * Lg * cg * ch * 3 * 2
     if split_precision or gmode:
@@ -471,6 +477,19 @@ def enc_first_bwd(x, gn1, y1, stats1, bstats1, gpre, slab, nslab, B, L, cout, w1
         return
     _chk(load().w2s_enc_first_bwd(_f(x), _f(gn1), _f(y1), _f(stats1), _f(bstats1), _f(gpre), _f(slab), nslab, B, L, cout, _f(w1), int(causal), _stream()),
          'w2s_enc_first_bwd')
+
+
+def enc_first_wgrad(xmom, ntx, w1, part_w1, stats1, bstats1, out, B, ntiles):
+    _chk(load().w2s_enc_first_wgrad(_f(xmom), ntx, _f(w1), _f(part_w1), _f(stats1), _f(bstats1), _f(out), B, ntiles, _stream()), 'w2s_enc_first_wgrad')
+
+
+def enc_first_stats(x, w, part, xmom, B, L, tile, stat_out=None, stat_cnt=None, eps=1e-2, causal=False):
+    _chk(load().w2s_enc_first_stats(_f(x), _f(w), _f(part), _f(xmom), B, L, tile, _f(stat_out), _p(stat_cnt), C.c_float(eps), int(causal), _stream()),
+         'w2s_enc_first_stats')
+
+
+def enc_first_dwd(x, gpre, slab, nslab, B, L):
+    _chk(load().w2s_enc_first_dwd(_f(x), _f(gpre), _f(slab), nslab, B, L, _stream()), 'w2s_enc_first_dwd')
 
 
 def gp_stats(g, y, stats, part, B, L, Cc, tile, stat_out=None, stat_cnt=None, hdr_g=None, hdr_amax=None):
