@@ -228,6 +228,12 @@ int w2s_enc_first_wgrad(const float* xmom, int ntx, const float* w1, const float
 int w2s_enc_first_stats(const float* x, const float* w, float* part, float* xmom, int B, int L, int tile, float* stat_out, int32_t* stat_cnt,
                         float eps, int causal, void* stream);
 int w2s_enc_first_dwd(const float* x, const float* gpre, float* slab, int nslab, int B, int L, void* stream);
+/* ... or folded as well: w2s_bwd_fused_wd = w2s_bwd_fused for conv1 of block 1 in its residual-fold form (16 -> 16; gpre / wd / slab_d /
+ * y3p / st3p as there) whose gout IS block 0's gpre; part_wd [nslab][16] = per-workgroup sums of gout[u][o] * san(x0[2u]), x0 = the raw
+ * signal [B][2 L].  Sum the rows with w2s_colsum_batch; w2s_enc_first_dwd is then not needed. */
+int w2s_bwd_fused_wd(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* wb, float* gout,
+                     float* part, float* slab, int nslab, int B, int L, int pad, const float* gpre, const float* wd, float* slab_d,
+                     const float* y3p, const float* st3p, const float* x0, float* part_wd, void* stream);
 
 /*
  * Fused backward of one k=3 / symmetric-padding encoder conv with cg = 64 gradient-side channels (round 3, csrc/bwd_wide.hip): data

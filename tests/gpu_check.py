@@ -521,6 +521,20 @@ def t_fused_residual_fold():
             lib.gp_stats(gout2, y3p, st3, pg, B, Lh, ch, 512)
             report(f'fold {cg}->{ch} L{Lh} gout (with stats fold)', gout2, outs[1][0], tol=0)
             report(f'fold {cg}->{ch} L{Lh} conv3 statistics', pt.sum(1), pg.sum(1), tol=2e-4)
+            if (cg, ch) == (16, 16):
+                # ... and block 0's downsample weight gradient (this kernel's gout x every other sample of the raw signal) vs w2s_enc_first_dwd,
+                # with and without the statistics partials (the two barrier paths of the epilogue)
+                x0 = torch.randn(B, 2 * Lh, device=dev); x0[1, 4] = float('inf'); x0[2, 2 * Lh - 2] = float('-inf')
+                ref = torch.zeros(6, 16, device=dev)
+                lib.enc_first_dwd(x0, gout2, ref, 6, B, 2 * Lh)
+                for with_part in (True, False):
+                    go = torch.zeros(B, Lh, ch, device=dev); pt2 = torch.zeros(B, nt, 2, ch, device=dev); pw = torch.full((ns, 16), float('nan'), device=dev)
+                    sl2 = torch.zeros_like(slab); sd2 = torch.zeros_like(slab_d)
+                    lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=lib.PRO_INBWD, xin=xin, st_in=None, add_even=None, wb=wb, gout=go, part=pt2 if with_part else None,
+                                  slab=sl2, nslab=ns, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=1, split_precision=True, gpre=gpre, wd=wd.view(ch, cg), slab_d=sd2,
+                                  y3p=y3p if with_part else None, st3p=st3 if with_part else None, x0=x0, part_wd=pw)
+                    assert torch.equal(go, gout2) and torch.equal(sl2, slab) and torch.equal(sd2, slab_d) and (not with_part or torch.equal(pt2, pt)), 'fold changed other outputs'
+                    report(f'fold 16->16 L{Lh} block-0 downsample wgrad (part={with_part})', pw.sum(0), ref.sum(0), tol=2e-5)
 
 def t_bwd_wide():
     """One-pass backward of the 64-channel convs (bwd_wide.hip; stride 1 and the stride-2 conv3) against the two kernels it replaces on the

@@ -38,6 +38,9 @@ struct BwdP {
   // gout[t][o] * xs[t + j - pad] (xs = the sanitised, zero-padded signal) -- what w2s_enc_first_wgrad turns into dW1 without gout ever
   // being stored (gout may then be NULL)
   float* part_w1;
+  // block 0's downsample weight gradient folded into block 1's conv1 (residual-fold) kernel, whose gout IS block 0's gpre:
+  // part_wd[workgroup][16] = sum over the workgroup's tiles and positions u of gout[u][o] * san(x0[b][2u]), x0 = the raw signal [B][2 Lh]
+  const float* x0; float* part_wd;
 };
 
 // LDS row strides: 16-channel rows stay unpadded (64-B rows: the three windows + weights of the 16x16 kernel then fit
@@ -388,9 +391,13 @@ void bwd_fused_bf_kernel(BwdP P) {
   __bf16* pLo = pH + NRp * RSg;
   float* xsL = reinterpret_cast<float*>(pLo + NRp * RSg);   // FIRST: TM + 4 signal samples
   float* redA = xsL + TM + 4;                               // FIRST: [4 waves][4 lane groups][12] scratch of the folded first-layer weight gradient
+  float* redD = xsL;                                        // RD + part_wd: [4 waves][4 lane groups][4] scratch of the folded downsample weight gradient
+  float* accD = redD + 64;                                  //               [16] running sums of this workgroup (thread 112 + o owns entry o)
+  constexpr bool WDFC = RD && CG == 1 && CH == 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4, q4 = r >> 2, p4 = r & 3;
   const int Lg = P.Lg, Lh = P.Lh;
+  if (WDFC && tid >= 112 && tid < 128) accD[tid - 112] = 0.f;
 
   // weight-gradient ownership: the CG*CH (cout tile, cin tile) pairs are spread over the 4 waves; KW waves share a
   // pair and take every KW-th k-step (summed through LDS at the end, fixed order)
@@ -685,6 +692,16 @@ void bwd_fused_bf_kernel(BwdP P) {
     float aw[FIRST ? 12 : 1];   // FIRST + part_w1: this lane's sums of gout[pos][4g + e] * xs[pos + j - pad]  (index 3e + j)
 #pragma unroll
     for (int k = 0; k < (FIRST ? 12 : 1); ++k) aw[k] = 0.f;
+    const bool wdf = WDFC && P.part_wd;   // uniform
+    float ad[4] = {0.f, 0.f, 0.f, 0.f}, xd[MT];   // RD + part_wd: sums of gout[pos][4g + e] * san(x0[2 pos])
+    if (wdf) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int pos = t0 + wave * (16 * MT) + mt * 16 + r;
+        const float xr = P.x0[(size_t)b * 2 * Lh + 2 * (size_t)min(pos, Lh - 1)];
+        xd[mt] = isinf(xr) ? 0.f : xr;
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int pos = UP2 ? t0 + 2 * (wave * (8 * MT) + (mt >> 1) * 16 + r) + (mt & 1) : t0 + wave * (16 * MT) + mt * 16 + r;
@@ -721,6 +738,11 @@ void bwd_fused_bf_kernel(BwdP P) {
             }
           }
         }
+        if (wdf) {   // (element by element on purpose: see wav2sleep_amd/isa_audit.py)
+          const float vd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ad[e] = fmaf(vd[e], xd[mt], ad[e]);
+        }
         if (FIRST && !P.gout) continue;   // uniform: the folded first-layer weight gradient was this tensor's only reader
         if constexpr (OH) {
           amax = amax4(amax, v);
@@ -738,6 +760,21 @@ void bwd_fused_bf_kernel(BwdP P) {
           if (r == 0) redA[(wave * 4 + g) * 12 + k] = sk;
         }
       }
+    }
+    if (wdf) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float se = row16_sum(ad[e]);
+        if (r == 0) redD[(wave * 4 + g) * 4 + e] = se;
+      }
+      if (!P.part) __syncthreads();
+    }
+    if (wdf && tid >= 112 && tid < 128 && !P.part) {
+      const int o = tid - 112;
+      float sd = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sd += redD[(w * 4 + (o >> 2)) * 4 + (o & 3)];
+      accD[o] += sd;
     }
     if (P.part) {
 #pragma unroll
@@ -759,6 +796,13 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
         w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
+      }
+      if (wdf && tid >= 112 && tid < 128) {
+        const int o = tid - 112;
+        float sd = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sd += redD[(w * 4 + (o >> 2)) * 4 + (o & 3)];
+        accD[o] += sd;
       }
       if constexpr (FIRST) {
         if (P.part_w1 && tid >= 64 && tid < 112) {   // (o, j) = ((tid - 64) / 3, (tid - 64) % 3); channel o sits in lane group o >> 2, slot o & 3
@@ -810,6 +854,7 @@ void bwd_fused_bf_kernel(BwdP P) {
   }
 
   if (OH) w2s_amax_commit(P.hdr_o, amax, s_out);
+  if (WDFC && P.part_wd && tid >= 112 && tid < 128) P.part_wd[(size_t)blockIdx.x * 16 + (tid - 112)] = accD[tid - 112];
   // ---- one slab per workgroup, raw-fragment layout [tile(i,j,c)][lane][4]; waves sharing a tile pair sum in wave order
   float* out = P.slab + (size_t)blockIdx.x * (CG * 3 * CH) * 256;
   float* outd = RD ? P.slab_d + (size_t)blockIdx.x * (CG * CH) * 256 : nullptr;
@@ -853,6 +898,7 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   size_t lds = (size_t)TM * bwd_rs(HC) * 4 * (HC == 16 ? 2 : 1) + (size_t)bwd_redn(CH) * 4 +
                (size_t)2 * 2 * ((NRg + NRp) * bf_rs(GC) + NRh * bf_rs(HC) + HC * (KD + 8));
   if (FIRST) lds += (size_t)(TM + 4) * 4 + 4 * 4 * 12 * 4;
+  if (RD) lds += (4 * 4 * 4 + 16) * 4;
   if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4]
   auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST, GM>;
   if (lds > 64 * 1024 &&
@@ -887,7 +933,8 @@ static int bwd_fused_impl(const void* gv, const float* y, const float* st_k, con
                           const float* st_in, const float* add_even, const float* wb, void* goutv, float* part, float* slab, int nslab,
                           int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const void* gprev, const float* wd,
                           float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt,
-                          int gmode, const float* hdr_g, const float* hdr_p, float* hdr_o, void* stream, float* part_w1 = nullptr) {
+                          int gmode, const float* hdr_g, const float* hdr_p, float* hdr_o, void* stream, float* part_w1 = nullptr,
+                          const float* x0 = nullptr, float* part_wd = nullptr) {
   const float* g = static_cast<const float*>(gv);
   const float* gpre = static_cast<const float*>(gprev);
   float* gout = static_cast<float*>(goutv);
@@ -899,7 +946,8 @@ static int bwd_fused_impl(const void* gv, const float* y, const float* st_k, con
   if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in
   if (pad != 1 && !(pad == 2 && split_precision)) return W2S_EINVAL;                // causal padding: split-precision kernels only
   BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, pad, gpre, wd, slab_d, w1, y3p, st3p, StatFin{stat_out, stat_cnt, 1.0 / (double)Lh, 0.f, 1},
-         gmode, hdr_g, hdr_p, hdr_o, part_w1};
+         gmode, hdr_g, hdr_p, hdr_o, part_w1, x0, part_wd};
+  if ((x0 != nullptr) != (part_wd != nullptr) || (part_wd && (!gpre || cg != 16 || ch != 16 || gmode))) return W2S_EINVAL;
   if (stat_out && (!stat_cnt || !part)) return W2S_EINVAL;
   if (y3p && (!gpre || !st3p || !part)) return W2S_EINVAL;
   const bool rd = gpre != nullptr;
@@ -951,6 +999,16 @@ extern "C" int w2s_bwd_fused_w1(const float* g, const float* y, const float* st_
   if (!part_w1) return W2S_EINVAL;
   return bwd_fused_impl(g, y, st_k, bst_k, W2S_PRO_INBWD, x, st_in, nullptr, wb, gout, part, slab, nslab, B, L, L, 16, 16, 1, pad, 1, nullptr, nullptr,
                         nullptr, w1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream, part_w1);
+}
+// conv1 of block 1 (residual-fold form, 16 -> 16) with block 0's downsample weight gradient folded in: this kernel's gout is block 0's
+// gpre, so part_wd [nslab][16] = per-workgroup sums of gout[u][o] * san(x0[2u]) (x0 = the raw signal [B][2 Lh]) replaces a pass over
+// that tensor.  Sum the rows with w2s_colsum_batch.
+extern "C" int w2s_bwd_fused_wd(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* wb, float* gout,
+                                float* part, float* slab, int nslab, int B, int L, int pad, const float* gpre, const float* wd, float* slab_d,
+                                const float* y3p, const float* st3p, const float* x0, float* part_wd, void* stream) {
+  if (!x0 || !part_wd) return W2S_EINVAL;
+  return bwd_fused_impl(g, y, st_k, bst_k, W2S_PRO_INBWD, xin, nullptr, nullptr, wb, gout, part, slab, nslab, B, L, L, 16, 16, 1, pad, 1, gpre, wd, slab_d,
+                        nullptr, y3p, st3p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream, nullptr, x0, part_wd);
 }
 // the same launch with the gradient chain stored as fp16 (include/w2s.h, "fp16 gradient chain")
 extern "C" int w2s_bwd_fused_h(const void* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,

@@ -312,7 +312,7 @@ class Engine:
         self._written.add(name)
 
     def _bwd_fused(self, name, *, g, y, st_k, bst_k, pro, xin, st_in, add_even, gout, want_part, B, Lg, Lh, cg, ch, stride,
-                   gpre=None, down=None, w1=None, y3p=None, st3p=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None, part_w1=None):
+                   gpre=None, down=None, w1=None, y3p=None, st3p=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None, part_w1=None, x0=None, down0=None):
         """dgrad + wgrad of one k=3 encoder conv in one pass (<= 32 channels); returns the backward statistics or None.
         gpre / down (conv1 of a residual block): fold the 1x1/stride-2 residual branch `down` in as well."""
         dev = g.device
@@ -323,15 +323,19 @@ class Engine:
         slab_d = self._slab(dev, nslab, cg * ch) if gpre is not None else None
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         so, sc = self._fin(B, ch, dev) if (want_part and not gmode) else (None, None)
+        part_wd = torch.empty(nslab, 16, device=dev, dtype=torch.float32) if x0 is not None else None   # block 0's downsample weight gradient (down0)
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
                       part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, pad=self.kpad, split_precision=self.split_precision,
                       gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1, y3p=y3p, st3p=st3p, stat_out=so, stat_cnt=sc,
-                      gmode=gmode, hdr_g=hdr_g, hdr_p=hdr_p, hdr_o=hdr_o, part_w1=part_w1)
+                      gmode=gmode, hdr_g=hdr_g, hdr_p=hdr_p, hdr_o=hdr_o, part_w1=part_w1, x0=x0, part_wd=part_wd)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         if gpre is not None:
             self._rjobs.append((slab_d, nslab, self.G[down], cg, ch, 1, 1, down in self._written, 0))
             self._written.add(down)
+        if part_wd is not None:
+            self._colsum(part_wd, nslab, 16, self.G[down0], accumulate=down0 in self._written)
+            self._written.add(down0)
         if not want_part:
             return None
         return so if so is not None else self._bstats(part, B, nt, ch, Lh)
@@ -535,7 +539,7 @@ class Engine:
 
     def _encode_begin(self, x: dict[str, torch.Tensor], save: bool, cls: bool = True):
         """Token tensor (CLS / register rows written on the current stream) and the encoder passes as generators, one list per encoder
-        stream; nothing of the encoders is enqueued yet.  Returns (state, tasks) for `_interleave` / `_encode_end`."""
+        stream; nothing of the encoders is enqueued yet.  Returns (state, tasks) for `_interleave`."""
         sp, P = self.spec, self.P
         sigs = sorted(x.keys())  # wav2sleep.py:311
         first = x[sigs[0]]
@@ -578,13 +582,15 @@ class Engine:
                 if sp.embed_signals:   # + embedding row of this signal on the samples that have it (wav2sleep.py:155-159)
                     lib.add_rows(slot, D * F, P['signal_encoders.embedder.weight'][sorted(sp.signal_map).index(s)], 1, keep, S, N, F, True)
             tasks.setdefault(sp.signal_map[s], (st, []))[1].append(run())
-        return dict(tokens=tokens, keeps=keeps, enc=enc_ctx, sigs=sigs, B=B, S=S, D=D, N=N, R1=R1), tasks
+        return dict(tokens=tokens, keeps=keeps, enc=enc_ctx, sigs=sigs, B=B, S=S, D=D, N=N, R1=R1, x0=[x[s][:, 0] for s in sigs]), tasks
 
-    def _encode_end(self, e):
-        """key-padding mask of the set-fusion transformer (the encoder streams have been joined / waited for)"""
-        B, S, D, N, keeps = e['B'], e['S'], e['D'], e['N'], e['keeps']
-        keep_BD = torch.stack([torch.ones_like(keeps[0])] * e['R1'] + keeps, dim=1)  # [B, D]
-        e['keypad'] = (keep_BD == 0).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
+    def _encode_keypad(self, e):
+        """key-padding mask of the set-fusion transformer, from the inputs alone (a sample lacks a modality when its row is -inf,
+        wav2sleep.py:150): a handful of launches on B x D values, enqueued on the current stream right AFTER the encoder streams have
+        forked, so that they run beside the encoders instead of between the encoders and the transformer."""
+        B, S, D, N = e['B'], e['S'], e['D'], e['N']
+        miss = torch.stack([torch.zeros_like(e['x0'][0], dtype=torch.bool)] * e['R1'] + [torch.isinf(v) for v in e['x0']], dim=1)   # [B, D]
+        e['keypad'] = miss.to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
         return e
 
     def encode(self, x: dict[str, torch.Tensor], save: bool = False, pack_key=None, cls: bool = True):
@@ -600,10 +606,11 @@ class Engine:
         main = torch.cuda.current_stream(e['tokens'].device)
         for st, _ in tasks.values():
             st.wait_stream(main)
+        self._encode_keypad(e)
         self._interleave(tasks)
         for st, _ in tasks.values():
             main.wait_stream(st)
-        return self._encode_end(e)
+        return e
 
     def mix(self, tokens: torch.Tensor, keypad: torch.Tensor, pm: float = 0.0, save: bool = False):
         """MultiModalAttentionEmbedder's transformer (models/wav2sleep.py:341-345) on tokens [N, D, F]; returns the final
@@ -954,6 +961,8 @@ class Engine:
         streams = list(dict.fromkeys(st for _, tasks in waves for st, _ in tasks.values()))
         for st in streams:
             st.wait_stream(main)
+        for e, _ in waves:
+            self._encode_keypad(e)
         fwd_done = []
         for (e, tasks), seed in zip(waves, seeds):
             self.step_seed = seed
@@ -972,7 +981,6 @@ class Engine:
             self.step_seed = seed
             for ev in fwd_done[w]:
                 main.wait_event(ev)
-            self._encode_end(e)
             lg, c = self._trunk_forward(e, pm, ps, True, logits=logits[b0:b1])
             gX = self._backward_trunk(c, ce(lg, b0, b1), accumulate or w > 0)
             # a weight may appear once per reduction flush: close this wave's queue (behind its own leaves when those are deferred)
@@ -1071,6 +1079,7 @@ class Engine:
         def new_hdr():
             nh[0] += 1
             return hdrs[nh[0] - 1]
+        wd_folded = False   # block 0's downsample weight gradient already produced by block 1's conv1 kernel
         gpre_hdr = None   # header of gpre: set once gpre is a chain tensor (fp16) or the chain's fp32 entry (gp_stats publishes its maximum)
         for i in reversed(range(len(ch))):
             blk = ec['blocks'][i]
@@ -1147,10 +1156,16 @@ class Engine:
                 # conv1 + the whole residual branch (its data gradient AND its weight gradient) in one pass over the tensors
                 gprev = torch.empty(B, L, cin, device=dev, dtype=gdt)
                 prev = ec['blocks'][i - 1] if self.fold_gp else dict(y3=None, st3=None)   # fold its conv3-backward statistics pre-pass in
+                # block 1: this kernel's gout is block 0's gpre -- block 0's downsample weight gradient (gpre x every other signal sample)
+                # rides in its epilogue instead of a pass of its own over that tensor
+                fold_wd = False
+                if i == 1 and ec.get('xmom') is not None and entry < 0 and c == 16 and cin == 16 and ec['blocks'][0]['y1'] is None and self._fused_bwd_ok:
+                    fold_wd = wd_folded = True
                 bs3_folded = self._bwd_fused(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, pro=lib.PRO_INBWD,
                                              xin=blk['pin'], st_in=None, add_even=None, gout=gprev, want_part=self.fold_gp, B=B, Lg=L, Lh=L, cg=c,
                                              ch=cin, stride=1, gpre=gpre, down=p + 'downsample.weight', y3p=prev['y3'], st3p=prev['st3'],
-                                             gmode=2 if h16 else 0, hdr_g=h1, hdr_p=gpre_hdr, hdr_o=hp)
+                                             gmode=2 if h16 else 0, hdr_g=h1, hdr_p=gpre_hdr, hdr_o=hp, x0=ec['x'] if fold_wd else None,
+                                             down0=f'{pfx}cnn.0.downsample.weight')
                 if not self.fold_gp:
                     bs3_folded = None
                 gpre, gpre_hdr = gprev, hp
@@ -1194,10 +1209,11 @@ class Engine:
                 dw1 = torch.empty(B, 48, device=dev, dtype=torch.float32)
                 lib.enc_first_wgrad(ec['xmom'], ec['xmom'].shape[1], P[n1], part_w1, blk['st1'], bs1, dw1, B, part_w1.shape[1])
                 self._colsum(dw1, B, 48, self.G[n1], accumulate=n1 in self._written)
-                nslab = max(1, min(1024, _cdiv(B * Lh, 2048)))
-                slab = torch.empty(nslab, 16, device=dev, dtype=torch.float32)
-                lib.enc_first_dwd(ec['x'], gpre, slab, nslab, B, L)
-                self._colsum(slab, nslab, 16, self.G[nd], accumulate=nd in self._written)
+                if not wd_folded:
+                    nslab = max(1, min(1024, _cdiv(B * Lh, 2048)))
+                    slab = torch.empty(nslab, 16, device=dev, dtype=torch.float32)
+                    lib.enc_first_dwd(ec['x'], gpre, slab, nslab, B, L)
+                    self._colsum(slab, nslab, 16, self.G[nd], accumulate=nd in self._written)
                 self._written.update((n1, nd))
             else:
                 nslab = max(1, min(1024, _cdiv(B * L, 4096)))

@@ -53,7 +53,7 @@ class WgradArgs(C.Structure):
 
 
 EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
-           'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
+           'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_bwd_fused_wd', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version']
@@ -336,7 +336,7 @@ def _h(t):
 
 def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False, pad=1,
               gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None, stat_out=None, stat_cnt=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None,
-              part_w1=None):
+              part_w1=None, x0=None, part_wd=None):
     """part_w1 (conv2 of block 0, w1 given): also leave the first layer's weight-gradient partials; gout may then be None.
     gmode 1 / 2: the fp16 gradient chain (include/w2s.h): gout (and, gmode 2, g / gpre) are fp16 tensors with the headers hdr_*."""
     gin = _h if gmode == 2 else _f
@@ -347,6 +347,10 @@ def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, s
             _chk(load().w2s_bwd_fused_h(gin(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), gou(gout), _f(part),
                                         _f(slab), nslab, B, Lg, Lh, cg, ch, stride, pad, gin(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p),
                                         gmode, _f(hdr_g), _f(hdr_p), _f(hdr_o), _stream()), f'w2s_bwd_fused_h(cg={cg},ch={ch},stride={stride},gmode={gmode})')
+            return
+        if part_wd is not None:
+            _chk(load().w2s_bwd_fused_wd(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(wb), _f(gout), _f(part), _f(slab), nslab, B, Lh, pad, _f(gpre), _f(wd),
+                                         _f(slab_d), _f(y3p), _f(st3p), _f(x0), _f(part_wd), _stream()), 'w2s_bwd_fused_wd')
             return
         if part_w1 is not None:
             _chk(load().w2s_bwd_fused_w1(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(st_in), _f(wb), _f(gout), _f(part), _f(part_w1), _f(slab), nslab, B, Lh,
