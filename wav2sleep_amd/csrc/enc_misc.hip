@@ -383,7 +383,19 @@ __global__ __launch_bounds__(1024) void stats_finalize_kernel(const float* __res
   const int CQ = C >> 2, c0 = blockIdx.y * CQ;
   const int c = tid % CQ, rl = tid / CQ, nrl = 1024 / CQ;
   double s1 = 0.0, s2 = 0.0;
-  for (int t = rl; t < ntiles; t += nrl) {
+  int t = rl;
+  for (; t + 3 * nrl < ntiles; t += 4 * nrl) {   // four rows in flight, added in the same order as the plain loop
+    float v1[4], v2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* p = part + (((size_t)b * ntiles + t + u * nrl) * 2) * C + c0;
+      v1[u] = p[c];
+      v2[u] = p[C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
+  }
+  for (; t < ntiles; t += nrl) {
     const float* p = part + (((size_t)b * ntiles + t) * 2) * C + c0;
     s1 += (double)p[c];
     s2 += (double)p[C + c];
