@@ -63,7 +63,10 @@ __device__ __forceinline__ f32x4 pro_apply(int pro, f32x4 v, f32x4 v2, f32x4 mea
 // 128-wide tiles are LDS-limited to two workgroups per CU anyway: cap the allocator at two waves per SIMD's worth of registers
 // (the generic split-precision instance landed on 257 registers = one wave per SIMD, -35 % on the transformer GEMMs)
 template <int NT, int MT, int TAPS, int STRIDE, int MODE, int WN, int PRO, int EPI, int BF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? 2 : 1))) void conv_cl_kernel(ConvP P) {
+#ifndef W2S_CL_OCC8
+#define W2S_CL_OCC8 2   // tuning: waves per SIMD asked for the 128-wide instances
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W2S_CL_OCC8 : 1))) void conv_cl_kernel(ConvP P) {
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
   const w2s_conv_args& a = P.a;
