@@ -213,7 +213,7 @@ def conv_forward(a: ConvArgs):
         return run()
     out_el = a.B * a.L_out * a.cout
     in_el = a.B * a.L_in if a.pro == PRO_FIRST else a.B * a.L_in * a.cin * (2 if a.x2 else 1)
-    nbytes = 4 * (in_el + out_el * (2 if a.y2 else 1) + (out_el if a.aux else 0) + (out_el // 2 if a.add_even else 0) + (out_el if a.fold_y3 else 0))
+    nbytes = 4 * (in_el + out_el * (2 if a.y2 else 1) + (out_el if a.aux else 0) + (out_el // 2 if a.add_even else 0))
     taps_eff = 1.5 if a.mode == MODE_UP2 else a.taps
     flops = int(2 * out_el * a.cin * taps_eff)
     wide_up2 = a.mode == MODE_UP2 and a.w_hi and a.cin >= 64 and a.cin == a.cout and a.epi == EPI_GP and a.pro == PRO_INBWD_GP and not a.add_even
