@@ -89,9 +89,6 @@ typedef struct w2s_conv_args {
                            /* bit 3: y = result * GELU'(aux) * dropmask      (backward of bit 2 in the data-gradient GEMM of linear2)           */
   float drop_p;            /* dropout probability of those fusions (0: no dropout) and the mask seed: the mask of element i of the [rows][ld]    */
   uint64_t drop_seed;      /* output is keep / (1 - p) with the counter-based generator of w2s_eltwise's dropout modes at (drop_seed, i)            */
-  const float* fold_y3;    /* EPI_GP data gradient of a >= 64-channel conv1 (flip, stride 1, split precision), optional: `part` receives the sums  */
-  const float* fold_st3;   /* of gn = y * GELU'(n3) and gn * n3, n3 = IN(fold_y3 [B][L_out][cout]) with fold_st3 [B][cout][2] -- the conv3-backward   */
-                           /* statistics of the block below (w2s_gp_stats on this launch's output, folded in); other shapes: W2S_EINVAL            */
 } w2s_conv_args;
 #define W2S_FUSE_ADD_DROP 2
 #define W2S_FUSE_Y2_GELU_DROP 4

@@ -149,23 +149,6 @@ def t_conv_wide():
         RES.append((tag + ' uses the persistent wide kernel', tile in (64, 128)))
         out = torch.zeros(B, ch, 2, device=dev); lib.stats_finalize(part, B, nt, ch, L, 0.0, 1, out)
         report(tag + ' sum g', out[..., 0], want.mean(2), tol=2e-5); report(tag + ' sum g*n', out[..., 1], (want * na).mean(2), tol=2e-5)
-        if not aux_norm:
-            # the same launch with the next kernel's statistics pre-pass folded in (fold_y3): same output bits, `part` = what w2s_gp_stats
-            # computes from that output and the block below's y3
-            y3 = torch.randn(B, L, ch, device=dev) * 1.7 + 0.2
-            st3 = torch.stack([y3.mean(1), 1 / torch.sqrt(y3.var(1, unbiased=False) + 1e-2)], -1).contiguous()
-            gout2 = torch.zeros(B, L, ch, device=dev)
-            a2 = lib.conv_args(x=cl(g).to(dev), x2=cl(yk).to(dev), w=wb, w_hi=wh, w_lo=wl, y=gout2, B=B, L_in=L, L_out=L, cin=cg, cout=ch, taps=3, stride=1, pad=1,
-                               flip=1, pro=lib.PRO_INBWD, pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=cl(aux).to(dev), aux_stats=None,
-                               add_even=cl(ev).to(dev) if add_even else None, fold_y3=y3, fold_st3=st3)
-            part2 = torch.full((B, nt, 2, ch), float('nan'), device=dev); lib.set_part(a2, part2)
-            assert lib.conv_tile_of(a2) == tile
-            lib.conv_forward(a2)
-            RES.append((tag + ' statistics fold leaves the output bits alone', bool(torch.equal(gout2, gout))))
-            ntg = (L + 127) // 128
-            pg = torch.zeros(B, ntg, 2, ch, device=dev)
-            lib.gp_stats(gout, y3, st3, pg, B, L, ch, 128)
-            report(tag + ' folded conv3 statistics', part2.sum(1), pg.sum(1), tol=2e-5)
 
 
 def t_conv_dilated():

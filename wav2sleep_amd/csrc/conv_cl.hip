@@ -78,7 +78,6 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
     const int rc = w2s_conv_wide_try(a, s, 0);
     if (rc != 1) return rc;
   }
-  if (a.fold_y3) return W2S_EINVAL;   // only the wide data-gradient kernel folds the next statistics pre-pass in
   if (a.taps == 3 && a.stride == 1) return w2s_conv_dispatch_31(a, s);
   if (a.taps == 3 && a.stride == 2) return w2s_conv_dispatch_32(a, s);
   if (a.taps == 1 && a.stride == 2) {

@@ -24,9 +24,6 @@ struct WideP {
   float* y; float* part;
   int B, L_in, L_out, ntiles, flip, pad;   // window row 0 = input position t0*STRIDE - pad (1: symmetric; forward 2 / data gradient 0: causal)
   int dbg;   // tuning only (W2S_WIDE_DBG): 1 = no prologue arithmetic, 2 = no MFMA loop, 4 = no LDS staging, 8 = no stores, 16 = no loads
-  // EPI_GP with the NEXT kernel's statistics pre-pass folded in (w2s_conv_args.fold_y3): part = sums of gn = y * GELU'(n3) and gn * n3,
-  // n3 = IN(y3p) with st3p -- the conv3-backward statistics of the block below, whose gpre this launch writes
-  const float* y3p; const float* st3p;
 };
 
 typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
@@ -166,7 +163,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     const __bf16* hiL = lds + (i & 1) * BUF;
     const __bf16* loL = hiL + NR * RSE;
     // epilogue operands of THIS tile, issued now so that their latency hides behind the K loop
-    f32x4 ax[EPI == W2S_EPI_GP ? MT : 1], ae[(EPI == W2S_EPI_GP && !UP2) ? MT : 1], aq[(EPI == W2S_EPI_GP && !UP2) ? MT : 1];
+    f32x4 ax[EPI == W2S_EPI_GP ? MT : 1], ae[(EPI == W2S_EPI_GP && !UP2) ? MT : 1];
     if (EPI == W2S_EPI_GP) {
       const float* ab = P.aux + (size_t)b * L_out * OC;
       const float* eb = P.add_even ? P.add_even + (size_t)b * (L_out >> 1) * OC : nullptr;
@@ -175,7 +172,6 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
         const int pos = UP2 ? t0 + 2 * ((mt >> 1) * 16 + r) + (mt & 1) : t0 + mt * 16 + r;
         ax[mt] = (pos < L_out) ? ld4o(ab, (unsigned)pos * OC + ch0) : (f32x4){0, 0, 0, 0};
         if constexpr (!UP2) ae[mt] = (eb && !(pos & 1) && (pos >> 1) < (L_out >> 1)) ? ld4o(eb, (unsigned)(pos >> 1) * OC + ch0) : (f32x4){0, 0, 0, 0};
-        if constexpr (!UP2) aq[mt] = (P.y3p && pos < L_out) ? ld4o(P.y3p + (size_t)b * L_out * OC, (unsigned)pos * OC + ch0) : (f32x4){0, 0, 0, 0};
       }
     }
     f32x4 acc[MT];
@@ -208,13 +204,6 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
       const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
       am = (f32x4){s01.x, s01.z, s23.x, s23.z}; ar = (f32x4){s01.y, s01.w, s23.y, s23.w};
     }
-    f32x4 m3 = {0, 0, 0, 0}, r3 = {1, 1, 1, 1};
-    const bool fold3 = EPI == W2S_EPI_GP && !UP2 && P.y3p;   // uniform
-    if (fold3) {
-      const float* st = P.st3p + ((size_t)b * OC + ch0) * 2;
-      const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-      m3 = (f32x4){s01.x, s01.z, s23.x, s23.z}; r3 = (f32x4){s01.y, s01.w, s23.y, s23.w};
-    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int pos = UP2 ? t0 + 2 * ((mt >> 1) * 16 + r) + (mt & 1) : t0 + mt * 16 + r;
@@ -224,17 +213,8 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
         const f32x4 n = (ax[mt] - am) * ar;
         if constexpr (!UP2) v += ae[mt];
         v = v * gelu_grad4(n);
-        if (fold3) {
-          if constexpr (!UP2) {
-            const f32x4 n3 = (aq[mt] - m3) * r3;
-            const f32x4 gn = v * gelu_grad4(n3);
-            sA += gn;
-            sB += gn * n3;
-          }
-        } else {
-          sA += v;
-          sB += v * n;
-        }
+        sA += v;
+        sB += v * n;
       } else {
         sA += v;
         sB += v * v;
@@ -259,7 +239,7 @@ template <int CI, int NW, int STRIDE, int PRO, int EPI, int MT, int NP = 4, int 
 static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
   constexpr int TM = 16 * MT, HC = CI * 16, NR = UP2 ? TM / 2 + 1 : (TM - 1) * STRIDE + 3, RSE = HC + (STRIDE == 1 ? 16 : 8);
   WideP P{a.x, a.x2, a.pro_stats, a.pro_bstats, static_cast<const __bf16*>(a.w_hi), static_cast<const __bf16*>(a.w_lo), a.aux, a.aux_stats,
-          a.add_even, a.y, a.part, a.B, a.L_in, a.L_out, (a.L_out + TM - 1) / TM, a.flip, a.pad, 0, a.fold_y3, a.fold_st3};
+          a.add_even, a.y, a.part, a.B, a.L_in, a.L_out, (a.L_out + TM - 1) / TM, a.flip, a.pad, 0};
   { static const char* d = getenv("W2S_WIDE_DBG"); if (d) P.dbg = atoi(d); }
   size_t lds = (size_t)2 * 2 * NR * RSE * 2;   // two window buffers x (hi, lo) planes, bf16
   constexpr bool TWO = (PRO == W2S_PRO_INBWD || PRO == W2S_PRO_INBWD_GP);
@@ -292,7 +272,6 @@ static bool wide_shape(const w2s_conv_args& a) {
   if (a.cin < 32 || a.cout < 32 || (a.cin < 64 && a.cout < 64)) return false;
   const bool fwd = a.epi == W2S_EPI_STATS && !a.flip && (a.pro == W2S_PRO_GELU || a.pro == W2S_PRO_IN_GELU);
   const bool dgr = a.epi == W2S_EPI_GP && a.flip && a.pro == W2S_PRO_INBWD && a.stride == 1;
-  if (a.fold_y3 && (!dgr || !a.fold_st3)) return false;   // the statistics fold exists in the stride-1 data-gradient form only
   const bool up2 = a.mode == W2S_MODE_UP2 && a.epi == W2S_EPI_GP && a.pro == W2S_PRO_INBWD_GP && a.stride == 2 && (a.pad == 1 || a.pad == 2) &&
                    a.L_out == 2 * a.L_in && !a.add_even && a.cin == a.cout;
   if (a.mode == W2S_MODE_UP2 ? !up2 : (!fwd && !dgr)) return false;
@@ -305,7 +284,6 @@ static bool wide_shape(const w2s_conv_args& a) {
 static int wide_mt() { return 4; }   // 64-position tiles (128 were tried: no gain, more registers)
 int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry) {
   if (!wide_shape(a)) return 1;
-  if (!dry && a.fold_y3 && !a.part) return W2S_EINVAL;   // (the tile query comes before the partials exist)
   const int mt = wide_mt();
 #define W2S_WIDE(CI_, NW_, ST_, PRO_, EPI_) \
   if (a.mode == W2S_MODE_CONTIG && a.cin == 16 * CI_ && a.cout == 16 * NW_ && a.stride == ST_ && a.pro == PRO_ && a.epi == EPI_) { \

@@ -1195,16 +1195,6 @@ class Engine:
                     bs3_folded = self._bwd_wide(p + 'conv1.conv.weight', g=gn1, y=blk['y1'], st_k=blk['st1'], bst_k=bs1, xin=blk['pin'], st_in=None,
                                                 add_even=Rr, gout=gprev, want_part=prev is not None, B=B, L=L, cg=c, ch=cin,
                                                 y3p=prev['y3'] if prev else None, st3p=prev['st3'] if prev else None)
-                elif (self.fold_gp and not h16_next and self.split_precision and (c, cin) in ((128, 128), (128, 64), (64, 64), (64, 32))
-                      and PB[p + 'conv1.conv.weight'].data_ptr() in self._bf and B * c * 16 <= 32 * 1024):
-                    # >= 64-channel conv1 data gradient (persistent wide kernel) with the statistics pre-pass of the block below folded into
-                    # its epilogue: that block's w2s_gp_stats launch read this kernel's output and y3 again
-                    prev = ec['blocks'][i - 1]
-                    bs3_folded = self._conv_part(x=gn1, x2=blk['y1'], w=PB[p + 'conv1.conv.weight'], y=gprev, B=B, L_in=L, L_out=L, cin=c, cout=cin, taps=3,
-                                                 stride=1, pad=2 - self.kpad, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st1'], pro_bstats=bs1, epi=lib.EPI_GP,
-                                                 aux=blk['pin'], add_even=Rr, fold_y3=prev['y3'], fold_st3=prev['st3'], kind=1)
-                    self._wgrad(p + 'conv1.conv.weight', g=gn1, g2=blk['y1'], g_stats=blk['st1'], g_bstats=bs1, pro_g=lib.PRO_INBWD,
-                                x=blk['pin'], pro_h=lib.PRO_GELU, B=B, L_in=L, L_out=L, cin=cin, cout=c, taps=3, stride=1, pad=self.kpad)
                 else:
                     self._conv(x=gn1, x2=blk['y1'], w=PB[p + 'conv1.conv.weight'], y=gprev, B=B, L_in=L, L_out=L, cin=c, cout=cin, taps=3,
                                stride=1, pad=2 - self.kpad, flip=1, pro=lib.PRO_INBWD, pro_stats=blk['st1'], pro_bstats=bs1, epi=lib.EPI_GP, aux=blk['pin'],

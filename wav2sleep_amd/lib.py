@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
                                    'rowkeep', 'part', 'w_hi', 'w_lo', 'stat_out', 'stat_cnt')] + \
                [(n, _i32) for n in ('B', 'L_in', 'L_out', 'cin', 'cout', 'taps', 'stride', 'dil', 'pad', 'flip', 'mode',
                                     'ldx', 'ldy', 'ldy2', 'ld_aux', 'pro', 'epi')] + [('stat_eps', C.c_float), ('reserved', _i32), ('drop_p', C.c_float),
-                                                                                            ('drop_seed', C.c_uint64), ('fold_y3', _fp), ('fold_st3', _fp)]
+                                                                                            ('drop_seed', C.c_uint64)]
 
 
 class ReduceJob(C.Structure):
@@ -137,9 +137,8 @@ def _f(t):
 def conv_args(*, x, w, y, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, flip=0, mode=MODE_CONTIG, ldx=None, ldy=None,
               pro=PRO_NONE, epi=EPI_PLAIN, x2=None, pro_stats=None, pro_bstats=None, aux=None, aux_stats=None, add_even=None,
               bias=None, rowkeep=None, part=None, y2=None, ldy2=0, ld_aux=0, w_hi=None, w_lo=None, stat_out=None, stat_cnt=None,
-              stat_eps=1e-2, accumulate=False, fuse=0, drop_p=0.0, drop_seed=0, fold_y3=None, fold_st3=None) -> ConvArgs:
+              stat_eps=1e-2, accumulate=False, fuse=0, drop_p=0.0, drop_seed=0) -> ConvArgs:
     a = ConvArgs()
-    a.fold_y3, a.fold_st3 = _f(fold_y3), _f(fold_st3)
     a.reserved = (1 if accumulate else 0) | fuse   # fuse: FUSE_* bits (EPI_BIAS only)
     a.drop_p, a.drop_seed = drop_p, drop_seed
     a.w_hi, a.w_lo = _p(w_hi), _p(w_lo)
