@@ -24,6 +24,7 @@ from .settings import COLS_TO_SAMPLES_PER_EPOCH
 _LONGEST_FIRST = os.environ.get('W2S_LONGEST_FIRST', '1') != '0'
 _INTERLEAVE = os.environ.get('W2S_INTERLEAVE', '1') != '0'
 _DEFER_TRUNK = os.environ.get('W2S_DEFER_TRUNK', '1') != '0'
+_CLS_ONLY = os.environ.get('W2S_CLS_ONLY', '1') != '0'   # last transformer layer: row-wise tail on the CLS rows only
 # W2S_ENC_CHUNK='1024:4,256:8' (samples per chunk by samples-per-epoch of the signal; a bare number applies to every signal)
 _ENC_CHUNK = {(int(kv.split(':')[0]) if ':' in kv else 0): int(kv.split(':')[-1]) for kv in os.environ.get('W2S_ENC_CHUNK', '').split(',') if kv}
 _BWD_WGS = int(os.environ.get('W2S_BWD_WGS', 512))       # persistent workgroups of the fused backward (2 per CU)
@@ -630,23 +631,28 @@ class Engine:
             qkv = self._linear(h, P[p + 'self_attn.in_proj_weight'], P[p + 'self_attn.in_proj_bias'], R, F, 3 * F)
             ao = torch.empty(R, F, device=dev, dtype=torch.float32)
             lib.attn_fwd(qkv, keypad, ao, N, D, sp.mixer_nhead, pm, self._seed(10 * l + 1))
+            # Only token 0 of the LAST layer's output is read (wav2sleep.py:345 returns the CLS token): behind that layer's attention, every
+            # row-wise op -- out_proj, the residual adds, norm2, the feed-forward block -- runs on the N CLS rows instead of all N x D token
+            # rows (row stride D*F in, compact [N][F] out); the other tokens' outputs were never used and their gradients are exactly zero
+            cls = _CLS_ONLY and l == sp.mixer_layers - 1 and D > 1
+            Rr, ldr = (N, D * F) if cls else (R, F)
             # x + Dropout(out_proj(attention)): the residual add and the dropout ride in the projection's epilogue (no `proj` tensor)
-            X1 = self._linear(ao, P[p + 'self_attn.out_proj.weight'], P[p + 'self_attn.out_proj.bias'], R, F, F, fuse=lib.FUSE_ADD_DROP, aux=X,
-                              drop_p=pm, drop_seed=self._seed(10 * l + 2))
-            h2 = torch.empty(R, F, device=dev, dtype=torch.float32)
-            rs2 = torch.empty(R, 2, device=dev, dtype=torch.float32)
-            lib.layernorm_fwd(X1, F, P[p + 'norm2.weight'], P[p + 'norm2.bias'], h2, F, rs2, R, F, sp.layer_eps)
+            X1 = self._linear(ao, P[p + 'self_attn.out_proj.weight'], P[p + 'self_attn.out_proj.bias'], Rr, F, F, ldx=ldr, fuse=lib.FUSE_ADD_DROP, aux=X,
+                              ld_aux=ldr, drop_p=pm, drop_seed=self._seed(10 * l + 2))
+            h2 = torch.empty(Rr, F, device=dev, dtype=torch.float32)
+            rs2 = torch.empty(Rr, 2, device=dev, dtype=torch.float32)
+            lib.layernorm_fwd(X1, F, P[p + 'norm2.weight'], P[p + 'norm2.bias'], h2, F, rs2, Rr, F, sp.layer_eps)
             FF = sp.mixer_dim_ff
-            a1 = torch.empty(R, FF, device=dev, dtype=torch.float32)   # Dropout(GELU(linear1)): second output of linear1's epilogue
-            f1 = self._linear(h2, P[p + 'linear1.weight'], P[p + 'linear1.bias'], R, F, FF, fuse=lib.FUSE_Y2_GELU_DROP, y2=a1, ldy2=FF, drop_p=pm,
+            a1 = torch.empty(Rr, FF, device=dev, dtype=torch.float32)   # Dropout(GELU(linear1)): second output of linear1's epilogue
+            f1 = self._linear(h2, P[p + 'linear1.weight'], P[p + 'linear1.bias'], Rr, F, FF, fuse=lib.FUSE_Y2_GELU_DROP, y2=a1, ldy2=FF, drop_p=pm,
                               drop_seed=self._seed(10 * l + 3))
-            X2 = self._linear(a1, P[p + 'linear2.weight'], P[p + 'linear2.bias'], R, FF, F, fuse=lib.FUSE_ADD_DROP, aux=X1, drop_p=pm,
+            X2 = self._linear(a1, P[p + 'linear2.weight'], P[p + 'linear2.bias'], Rr, FF, F, fuse=lib.FUSE_ADD_DROP, aux=X1, drop_p=pm,
                               drop_seed=self._seed(10 * l + 4))
             if save:
-                layers.append(dict(X=X, rs1=rs1, h=h, qkv=qkv, ao=ao, X1=X1, rs2=rs2, h2=h2, f1=f1, a1=a1))
+                layers.append(dict(X=X, rs1=rs1, h=h, qkv=qkv, ao=ao, X1=X1, rs2=rs2, h2=h2, f1=f1, a1=a1, cls=cls))
             X = X2
 
-        return X, layers
+        return X, layers   # [N*D, F] (row n*D = CLS), or the CLS rows alone [N, F] when the last layer ran on those only
 
     def seq(self, xin: torch.Tensor, ldin: int, B: int, S: int, ps: float = 0.0, save: bool = False):
         """SequenceCNN.forward (models/wav2sleep.py:379-390) on rows [B*S] of `xin` (row stride ldin); returns the last block's
@@ -697,10 +703,11 @@ class Engine:
         tokens, keypad, B, S, D, N = e['tokens'], e['keypad'], e['B'], e['S'], e['D'], e['N']
         dev = tokens.device
         X, layers = self.mix(tokens, keypad, pm, save)
+        ldX = X.numel() // N   # D*F, or F when the last transformer layer produced the CLS rows only
         if self.taps is not None:
             self.taps['tokens'] = tokens
-            self.taps['mixer'] = X.view(N, D * F)[:, :F].reshape(B, S, F)
-        pre_out, seq = self.seq(X, D * F, B, S, ps, save)
+            self.taps['mixer'] = X.view(N, ldX)[:, :F].reshape(B, S, F)
+        pre_out, seq = self.seq(X, ldX, B, S, ps, save)
         if self.taps is not None:
             self.taps['seq_pre'] = pre_out
         if logits is None:
@@ -815,31 +822,44 @@ class Engine:
 
         # ---- set-fusion transformer
         R = N * D
-        gX = torch.zeros(N, D, F, device=dev, dtype=torch.float32)
-        gX[:, 0, :].copy_(g_pre.view(N, F))  # only token 0 is returned (wav2sleep.py:345)
-        gX = gX.view(R, F)
         FF = sp.mixer_dim_ff
+        gX = None   # [R, F] gradient w.r.t. a layer's output; None: only the CLS rows (g_pre [N, F]) carry a gradient so far
         for l in reversed(range(sp.mixer_layers)):
             L = c['layers'][l]
             p = f'epoch_mixer.transformer_encoder.layers.{l}.'
-            gf2 = torch.empty(R, F, device=dev, dtype=torch.float32)
-            lib.eltwise(lib.ELT_DROP, gX, None, gf2, R * F, pm, self._seed(10 * l + 4))
-            self._colgrad(p + 'linear2.bias', gf2, R, F)
-            self._wgrad(p + 'linear2.weight', g=gf2, x=L['a1'], B=1, L_in=R * (FF // 128), L_out=R, cin=128, cout=F, taps=FF // 128,
+            cls = L.get('cls', False)   # the forward ran this layer's row-wise tail on the CLS rows only: so does the backward
+            if gX is None and not cls:
+                gX = torch.zeros(N, D, F, device=dev, dtype=torch.float32)
+                gX[:, 0, :].copy_(g_pre.view(N, F))  # only token 0 is returned (wav2sleep.py:345)
+                gX = gX.view(R, F)
+            gin = g_pre.view(N, F) if cls else gX
+            Rr, ldr = (N, D * F) if cls else (R, F)
+            gf2 = torch.empty(Rr, F, device=dev, dtype=torch.float32)
+            lib.eltwise(lib.ELT_DROP, gin, None, gf2, Rr * F, pm, self._seed(10 * l + 4))
+            self._colgrad(p + 'linear2.bias', gf2, Rr, F)
+            self._wgrad(p + 'linear2.weight', g=gf2, x=L['a1'], B=1, L_in=Rr * (FF // 128), L_out=Rr, cin=128, cout=F, taps=FF // 128,
                         stride=FF // 128, pad=0, layout=1)
             # d/d(linear1 output) = (W2^T g) * dropmask * GELU'(f1): in the data-gradient GEMM's epilogue
-            gf1 = self._linear(gf2, PB[p + 'linear2.weight'], None, R, F, FF, fuse=lib.FUSE_GELU_BWD_DROP, aux=L['f1'], ld_aux=FF, drop_p=pm,
+            gf1 = self._linear(gf2, PB[p + 'linear2.weight'], None, Rr, F, FF, fuse=lib.FUSE_GELU_BWD_DROP, aux=L['f1'], ld_aux=FF, drop_p=pm,
                                drop_seed=self._seed(10 * l + 3))
-            self._colgrad(p + 'linear1.bias', gf1, R, FF)
-            self._wgrad(p + 'linear1.weight', g=gf1, x=L['h2'], B=1, L_in=R, L_out=R, cin=F, cout=FF, taps=1, stride=1, pad=0)
-            gh2 = self._linear(gf1, PB[p + 'linear1.weight'], None, R, FF, F)
-            gX1 = torch.empty(R, F, device=dev, dtype=torch.float32)
-            self._ln_bwd(p + 'norm2', gh2, L['X1'], L['rs2'], gX, gX1, R)
-            gproj = torch.empty(R, F, device=dev, dtype=torch.float32)
-            lib.eltwise(lib.ELT_DROP, gX1, None, gproj, R * F, pm, self._seed(10 * l + 2))
-            self._colgrad(p + 'self_attn.out_proj.bias', gproj, R, F)
-            self._wgrad(p + 'self_attn.out_proj.weight', g=gproj, x=L['ao'], B=1, L_in=R, L_out=R, cin=F, cout=F, taps=1, stride=1, pad=0)
-            gao = self._linear(gproj, PB[p + 'self_attn.out_proj.weight'], None, R, F, F)
+            self._colgrad(p + 'linear1.bias', gf1, Rr, FF)
+            self._wgrad(p + 'linear1.weight', g=gf1, x=L['h2'], B=1, L_in=Rr, L_out=Rr, cin=F, cout=FF, taps=1, stride=1, pad=0)
+            gh2 = self._linear(gf1, PB[p + 'linear1.weight'], None, Rr, FF, F)
+            gX1 = torch.empty(Rr, F, device=dev, dtype=torch.float32)
+            self._ln_bwd(p + 'norm2', gh2, L['X1'], L['rs2'], gin, gX1, Rr)
+            gproj = torch.empty(Rr, F, device=dev, dtype=torch.float32)
+            lib.eltwise(lib.ELT_DROP, gX1, None, gproj, Rr * F, pm, self._seed(10 * l + 2))
+            self._colgrad(p + 'self_attn.out_proj.bias', gproj, Rr, F)
+            self._wgrad(p + 'self_attn.out_proj.weight', g=gproj, x=L['ao'], B=1, L_in=Rr, L_out=Rr, cin=F, cout=F, taps=1, stride=1, pad=0,
+                        **(dict(ldx=ldr) if cls else {}))
+            if cls:   # back to all token rows: the attention spreads the CLS query's gradient over every token's keys and values
+                gao = torch.zeros(R, F, device=dev, dtype=torch.float32)
+                self._linear(gproj, PB[p + 'self_attn.out_proj.weight'], None, N, F, F, y=gao, ldy=D * F)
+                gX1f = torch.zeros(N, D, F, device=dev, dtype=torch.float32)
+                gX1f[:, 0, :].copy_(gX1)
+                gX1 = gX1f.view(R, F)
+            else:
+                gao = self._linear(gproj, PB[p + 'self_attn.out_proj.weight'], None, R, F, F)
             gqkv = torch.empty(R, 3 * F, device=dev, dtype=torch.float32)
             lib.attn_bwd(L['qkv'], c['keypad'], gao, gqkv, N, D, sp.mixer_nhead, pm, self._seed(10 * l + 1))
             self._colgrad(p + 'self_attn.in_proj_bias', gqkv, R, 3 * F)

@@ -412,7 +412,7 @@ class MultiModalAttentionEmbedder(_HandWritten, nn.Module):
         keypad = torch.stack(pads, dim=1).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
         with torch.cuda.device(first.device):
             X, _ = eng.mix(tokens, keypad, self.dropout_p if self.training else 0.0, save=False)
-        return X.view(N, D * F)[:, :F].reshape(B, S, F).clone()
+        return X.view(N, X.numel() // N)[:, :F].reshape(B, S, F).clone()   # (row stride D*F, or F: the last layer may return the CLS rows alone)
 
 
 class SequenceCNN(_HandWritten, nn.Module):
@@ -558,7 +558,7 @@ class Wav2Sleep(_HandWritten, nn.Module):
             keep = torch.stack([torch.ones(B, device=tok.device)] * R1 + [e['keeps'][sigs.index(n)] for n in names], dim=1)
             keypad = (keep == 0).to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
             X, _ = eng.mix(tok, keypad, 0.0, save=False)
-            pre, _ = eng.seq(X, D * F, B, S, 0.0, save=False)
+            pre, _ = eng.seq(X, X.numel() // N, B, S, 0.0, save=False)
             logits = torch.empty(B, S, self.num_classes, device=tok.device, dtype=torch.float32)
             lib.head_fwd(pre, F, eng.P['classifier.weight'], eng.P['classifier.bias'], logits, N, F, self.num_classes, True)
             out[tuple(sub) if sub is not None else None] = logits
