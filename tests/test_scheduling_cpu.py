@@ -90,3 +90,21 @@ def test_bench_bookkeeping_helpers():
     assert len(fams) == 5 and 'other' not in fams
     t = bench.step_traffic(os.path.join(ROOT, 'profiles'))   # committed PMC bytes/launch x committed launch counts
     assert t is not None and 100e9 < t < 200e9
+
+
+def test_wave_layout_covers_the_batch_once_and_sizes_the_loss_partials():
+    """FusedTrainStep(waves=n): contiguous, non-empty, disjoint sample ranges covering the batch; per-wave loss-partial block counts."""
+    from wav2sleep_amd.trainer import wave_layout
+    for B in (1, 2, 3, 5, 16, 33):
+        for nw in range(1, B + 1):
+            bounds, nblk = wave_layout(B, 960, nw)
+            assert bounds[0][0] == 0 and bounds[-1][1] == B and len(bounds) == nw
+            assert all(a1 == b0 for (_, a1), (b0, _) in zip(bounds, bounds[1:]))
+            sizes = [b1 - b0 for b0, b1 in bounds]
+            assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
+            assert nblk == [(n * 960 + 255) // 256 for n in sizes]
+    bounds, nblk = wave_layout(5, 3, 3)
+    assert bounds == [(0, 1), (1, 3), (3, 5)] and nblk == [1, 1, 1]
+    import pytest
+    with pytest.raises(ValueError):
+        wave_layout(2, 10, 3)

@@ -102,6 +102,15 @@ class SignalMasker:
         return signals
 
 
+def wave_layout(B: int, S: int, nw: int):
+    """Sample ranges [(b0, b1), ...] of the `nw` waves of a batch of B recordings (sizes differ by at most one, none empty for nw <= B) and
+    the number of 256-row loss partial blocks each wave owns (the waves' partials lie one after the other: w2s_ce_wave / w2s_ce_final)."""
+    if not 1 <= nw <= B:
+        raise ValueError(f'{nw} waves for a batch of {B}')
+    bounds = [(B * i // nw, B * (i + 1) // nw) for i in range(nw)]
+    return bounds, [((b1 - b0) * S + 255) // 256 for b0, b1 in bounds]
+
+
 class FusedTrainStep:
     """One optimiser step of the reference's recipe on the HIP engine (fp32, deterministic reductions).
 
@@ -237,8 +246,7 @@ class FusedTrainStep:
         if yv.dtype != torch.float32:
             yv = yv.float()
         yv = yv.contiguous()
-        bounds = [(B * i // nw, B * (i + 1) // nw) for i in range(nw)]
-        nblk = [((b1 - b0) * S + 255) // 256 for b0, b1 in bounds]
+        bounds, nblk = wave_layout(B, S, nw)
         part = torch.empty(sum(nblk), 2, device=dev, dtype=torch.float32)
         count = torch.empty(1, device=dev, dtype=torch.float32)
         logits = torch.empty(B, S, nc, device=dev, dtype=torch.float32)
