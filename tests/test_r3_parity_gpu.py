@@ -200,3 +200,29 @@ def test_fp16_gradient_chain_keeps_the_gradient_bar():
     assert set(runs[0][2]) == {0} and {1, 2} <= set(runs[1][2]) and 0 not in runs[1][2]   # every fused-backward launch of the chain run is an fp16 form
     assert torch.equal(runs[0][0], runs[1][0])                                              # logits: untouched
     assert torch.equal(runs[1][1], runs[2][1]) and not torch.equal(runs[0][1], runs[1][1])  # reproducible; and it does round
+
+
+def test_last_transformer_layer_on_cls_rows_equals_all_rows(monkeypatch):
+    """Only token 0 of the set-fusion transformer is read (wav2sleep.py:345): the last layer's row-wise tail (out_proj, norm2, feed-forward)
+    runs on the CLS rows alone.  Against the all-rows form (W2S_CLS_ONLY=0): the same logits bit for bit (every row of those GEMMs is computed
+    independently of its neighbours), every gradient to fp32 summation order (the weight gradients sum N instead of N x D rows, the others
+    contributing exact zeros)."""
+    import wav2sleep_amd.engine as E
+    cfg = O.ModelConfig(signal_map=SM5, num_classes=4)
+    sd = O.make_state_dict(cfg, seed=93)
+    x, y = O.make_inputs(cfg, 3, 4, seed=94, missing={'ABD': [0], 'EOG-L': [2]})
+    outs = []
+    for flag in (False, True):
+        monkeypatch.setattr(E, '_CLS_ONLY', flag)
+        model = build(SM5, 4)
+        model.load_state_dict(sd)
+        model.to(DEV).train()
+        logits = model(to_dev(x))
+        loss = F.cross_entropy(logits.reshape(-1, 4), y.to(DEV).reshape(-1).long(), ignore_index=-1)
+        loss.backward()
+        outs.append((logits.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for n, g0 in outs[0][1].items():
+        g1 = outs[1][1][n]
+        scale = float(g0.abs().max())
+        assert float((g0 - g1).abs().max()) <= 2e-5 * max(scale, 1e-12), (n, float((g0 - g1).abs().max()), scale)
