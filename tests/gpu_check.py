@@ -536,6 +536,32 @@ def t_fused_residual_fold():
                     assert torch.equal(go, gout2) and torch.equal(sl2, slab) and torch.equal(sd2, slab_d) and (not with_part or torch.equal(pt2, pt)), 'fold changed other outputs'
                     report(f'fold 16->16 L{Lh} block-0 downsample wgrad (part={with_part})', pw.sum(0), ref.sum(0), tol=2e-5)
 
+def _gelu_grad64(n):
+    return 0.5 * (1 + torch.erf(n / 2 ** 0.5)) + n * torch.exp(-0.5 * n * n) / (2 * math.pi) ** 0.5
+
+def Rr_fp64(gpre, wd):
+    """data gradient of the 1x1 / stride-2 residual conv at the even input rows: R[u] = Wd^T gpre[u]  (wd: [ch][cg], the kernels' layout)"""
+    return torch.einsum('buc,oc->buo', gpre.double().cpu(), wd.double().cpu())
+
+def _bwd_wide_fp64(g, y, st, bst, x, sti, ev, w, stride):
+    """fp64 restatement of one encoder conv's backward as blocks.py:174-183 + autograd define it (channels-last device tensors in, CPU out):
+    gy = IN-backward of g (x GELU'(n) first for the stride-2 conv3) with the GIVEN statistics / backward sums; H = GELU(IN(x)) (or GELU(x));
+    dH, dW = autograd of F.conv1d(H, W, stride, padding=1); gout = (dH + ev at the even rows) x GELU'; sums = means of gout, gout x n_in."""
+    g, y, st, bst, x = (t.double().cpu() for t in (g, y, st, bst, x))
+    n = (y - st[:, None, :, 0]) * st[:, None, :, 1]
+    gn = g * _gelu_grad64(n) if stride == 2 else g
+    GY = st[:, None, :, 1] * (gn - bst[:, None, :, 0] - n * bst[:, None, :, 1])
+    hn = (x - sti[:, None, :, 0].double().cpu()) * sti[:, None, :, 1].double().cpu() if sti is not None else x
+    H = (0.5 * hn * (1 + torch.erf(hn / 2 ** 0.5))).transpose(1, 2).contiguous().requires_grad_(True)
+    W = w.double().cpu().clone().requires_grad_(True)   # [cg][ch][3]
+    F.conv1d(H, W, stride=stride, padding=1).backward(GY.transpose(1, 2)[:, :, :x.shape[1] // stride].contiguous())
+    dH = H.grad.transpose(1, 2).clone()
+    if ev is not None:
+        dH[:, 0:2 * ev.shape[1]:2, :] += ev.double().cpu()
+    gout = dH * _gelu_grad64(hn)
+    sums = torch.stack([gout.mean(1), (gout * hn).mean(1)], dim=1)   # [B][2][ch]
+    return gout.float(), W.grad.float(), sums.float()
+
 def t_bwd_wide():
     """One-pass backward of the 64-channel convs (bwd_wide.hip; stride 1 and the stride-2 conv3) against the two kernels it replaces on the
     same tensors: the conv_wide data gradient (instance-norm-backward prologue, GELU' epilogue, residual add, backward statistics) and the
@@ -592,6 +618,13 @@ def t_bwd_wide():
             report(tag + ' gout', gout, gout0, tol=2e-6 * loose)
             report(tag + ' statistics sums', part.sum(1), part0.sum(1), tol=2e-5 * loose)
             report(tag + ' wgrad', gw, gw0, tol=2e-5 * loose)
+        if (cg, ch, L, stride) in ((64, 64, 1000, 1), (64, 64, 1000, 2), (64, 32, 500, 1)):
+            # CPU arm (round-3 verdict): the same outputs against fp64 autograd of F.conv1d, independent of every sibling HIP kernel
+            want_gout, want_gw, want_s = _bwd_wide_fp64(g, y, st, bst, x, sti, ev, w, stride)
+            report(tag + ' gout vs fp64 autograd', gout, want_gout, tol=1e-4)
+            report(tag + ' wgrad vs fp64 autograd', gw, want_gw, tol=3e-4)
+            if hst:
+                report(tag + ' statistics sums vs fp64', part.sum(1) / L, want_s, tol=5e-5)
         if stride == 1 and not hst:   # conv1 of a block: the previous block's conv3-backward statistics folded in vs the w2s_gp_stats pre-pass
             y3p = torch.randn(B, L, ch, device=dev)
             st3 = torch.stack([torch.randn(B, ch, device=dev) * 0.1, torch.rand(B, ch, device=dev) + 0.5], dim=-1).contiguous()
@@ -627,6 +660,10 @@ def t_bwd_wide():
             report(f'bwd_wide {cg}->{ch} L{L} residual fold statistics', outs[1][1].sum(1), outs[0][1].sum(1), tol=2e-4)
             report(f'bwd_wide {cg}->{ch} L{L} residual fold conv wgrad identical', outs[1][2], outs[0][2], tol=0)
             report(f'bwd_wide {cg}->{ch} L{L} residual fold downsample wgrad', outs[1][3], want_gd, tol=3e-4)
+            if (cg, ch, L) == (64, 32, 500):   # CPU arm of the residual-fold form: (W^T gy + Wd^T gpre at the even rows) x GELU'(pin), fp64
+                want_gout, want_gw, _ = _bwd_wide_fp64(g, y, st, bst, x, None, Rr_fp64(gpre, wd), w, 1)
+                report(f'bwd_wide {cg}->{ch} L{L} residual fold gout vs fp64 autograd', outs[1][0], want_gout, tol=1e-4)
+                report(f'bwd_wide {cg}->{ch} L{L} residual fold wgrad vs fp64 autograd', outs[1][2], want_gw, tol=3e-4)
     RES.append(('bwd_wide refuses a batch whose statistics tables do not fit its LDS', not lib.bwd_wide_takes(48, 640, 64, 64, 1, True) and lib.bwd_wide_takes(40, 640, 64, 64, 1, False)))
 
 def t_grad_fp16_chain():

@@ -69,6 +69,19 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.bwd_fused_folds_residual(16, 16) and L.bwd_fused_folds_residual(32, 16) and not L.bwd_fused_folds_residual(32, 32)
     assert dll.w2s_wgrad_reduce_batch(None, 1, None) == -1 and dll.w2s_repack_batch(None, 0, None) == -1 and dll.w2s_colsum_batch(None, 3, None) == -1
     assert dll.w2s_conv_fwd_fused(None, None, None, None, None, None, 1, 8, 8, 16, 16, 1, 2, 4, None) == -1
+    # transformer epilogue fusions (W2S_FUSE_* in `reserved`): a bit whose operand is NULL, or any bit outside the bias epilogue, is EINVAL
+    # (the pointers are never dereferenced on this path: validation happens before the launch)
+    def desc(**kw):
+        d = L.ConvArgs()
+        d.x = d.w = d.y = 4096
+        d.B, d.L_in, d.L_out, d.cin, d.cout, d.taps, d.stride, d.dil, d.ldx, d.ldy, d.epi = 1, 64, 64, 128, 128, 1, 1, 1, 128, 128, L.EPI_BIAS
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    assert dll.w2s_conv_forward(ctypes.byref(desc(reserved=L.FUSE_ADD_DROP)), None) == -1              # aux == NULL
+    assert dll.w2s_conv_forward(ctypes.byref(desc(reserved=L.FUSE_GELU_BWD_DROP)), None) == -1         # aux == NULL
+    assert dll.w2s_conv_forward(ctypes.byref(desc(reserved=L.FUSE_Y2_GELU_DROP)), None) == -1          # y2 == NULL
+    assert dll.w2s_conv_forward(ctypes.byref(desc(reserved=L.FUSE_ADD_DROP, aux=4096, epi=L.EPI_PLAIN)), None) == -1   # not the bias epilogue
 
 
 def test_cpu_tensors_are_refused(built_lib):

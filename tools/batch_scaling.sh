@@ -1,4 +1,7 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+#!/bin/bash
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+export TMPDIR=/tmp
 export W2S_MULTI_STREAM=0
 for b in 8 16; do
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/b$b -- python3 bench.py --steps 4 --warmup 2 --batch $b --no-cpu --no-roofline > gpurun_out/b$b.log 2>&1

@@ -1,5 +1,8 @@
+#!/bin/bash
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 # the round's closing run on the GPU box (tools/round_close.sh [tag]): stage checks, full suite, bench line, launch census, profile set
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r3z
+mkdir -p gpurun_out/r3z
 timeout 900 python3 tests/gpu_check.py bwdwide gradh 2>&1 | grep -E "FAIL|SUMMARY" > gpurun_out/r3z/gpu_check.txt
 timeout 2400 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r3z/pytest.txt
 python3 bench.py > gpurun_out/r3z/bench_line.json 2> gpurun_out/r3z/bench.err

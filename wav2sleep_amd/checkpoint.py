@@ -201,7 +201,11 @@ def save_lightning_checkpoint(path: str, module, epoch: int = 0, callbacks: dict
 def load_lightning_checkpoint(checkpoint, module, strict: bool = True, restore_rng: bool = True) -> dict:
     """Resume `module` (SleepModule) from a Lightning `.ckpt` path or dict written by the reference or by
     `save_lightning_checkpoint`: weights, AdamW moments, step / scheduler position, RNG, and the gradient-clipping
-    consistency warning of SleepLightningModule.on_load_checkpoint (trainer/main.py:310-334)."""
+    consistency warning of SleepLightningModule.on_load_checkpoint (trainer/main.py:310-334).
+
+    With a process group (world > 1) this is a COLLECTIVE call, as Lightning's resume is: EVERY rank calls it with the same checkpoint;
+    it ends with `FusedTrainStep.sync_parameters()`, which broadcasts rank 0's weights, moments and scalar optimiser state, so the ranks
+    leave identical whatever each of them read.  Do not call `sync_parameters()` again on a subset of ranks afterwards."""
     if not isinstance(checkpoint, dict):
         checkpoint = torch.load(checkpoint, map_location='cpu', weights_only=False)
     step = module.trainer
@@ -244,7 +248,7 @@ def load_lightning_checkpoint(checkpoint, module, strict: bool = True, restore_r
                 torch.cuda.set_rng_state_all(checkpoint['cuda_rng_state_all'])
             except (RuntimeError, IndexError):  # different device count than the run that saved it
                 pass
-    step.sync_parameters()   # every rank ends with rank 0's weights and moments, whichever ranks read the file (a no-op at world size 1)
+    step.sync_parameters()   # collective (every rank is in this function): rank 0's weights, moments and scalar state everywhere; a no-op at world size 1
     return checkpoint
 
 

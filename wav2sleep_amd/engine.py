@@ -713,8 +713,10 @@ class Engine:
         if logits is None:
             logits = torch.empty(B, S, sp.num_classes, device=dev, dtype=torch.float32)
         lib.head_fwd(pre_out, F, P['classifier.weight'], P['classifier.bias'], logits, B * S, F, sp.num_classes, True)
+        # seed: the dropout masks of THIS forward (counter-based RNG, regenerated in backward) -- part of the saved context, because
+        # `self.step_seed` belongs to whichever forward ran last (several forwards may be in flight before one backward: ops.py)
         ctx = dict(B=B, S=S, D=D, N=N, sigs=e['sigs'], enc=e['enc'], keypad=keypad, layers=layers, seq=seq, pre_out=pre_out, pm=pm,
-                   ps=ps, tokens=tokens) if save else None
+                   ps=ps, tokens=tokens, seed=self.step_seed) if save else None
         return logits, ctx
 
     def forward(self, x: dict[str, torch.Tensor], train: bool = False, save: bool = False, pack_key=None) -> torch.Tensor:
@@ -778,6 +780,7 @@ class Engine:
         nc = sp.num_classes
         rows = B * S
         pm, ps = c['pm'], c['ps']
+        self.step_seed = c['seed']   # regenerate the masks of the forward that saved this context, not of the latest one
         glogits = glogits.reshape(rows, nc).contiguous()
 
         # ---- classifier

@@ -15,8 +15,28 @@ import struct
 import subprocess
 import tempfile
 
+import shutil
+
 _MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
-OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+_CCOB = b'CCOB'   # header of a COMPRESSED offload bundle (hipcc --offload-compress): not readable here, must not pass as "nothing found"
+
+
+def _find_objdump() -> str:
+    """llvm-objdump of the ROCm installation that built the library: $ROCM_PATH, next to hipcc, then the image's default."""
+    cands = []
+    if os.environ.get('ROCM_PATH'):
+        cands.append(os.path.join(os.environ['ROCM_PATH'], 'lib', 'llvm', 'bin', 'llvm-objdump'))
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), 'lib', 'llvm', 'bin', 'llvm-objdump'))
+    cands.append('/opt/rocm/lib/llvm/bin/llvm-objdump')
+    for c in cands:
+        if os.path.exists(c):
+            return c
+    return shutil.which('llvm-objdump') or cands[-1]
+
+
+OBJDUMP = _find_objdump()
+MIN_PACKED = 100000   # the shipped library holds ~4e5 packed-fp32 instructions: far fewer means the audit did not see the code
 _BAD = re.compile(r'\bv_pk_(?:fma|mul|add)_f32\b.*\bop_sel:\[[01],1')
 
 
@@ -45,7 +65,13 @@ def audit(path: str) -> tuple[int, list[tuple[str, str]]]:
     if not os.path.exists(OBJDUMP):
         raise RuntimeError(f'{OBJDUMP} not found: cannot audit {path}')
     seen, bad = 0, []
-    for _, blob in code_objects(path):
+    blobs = list(code_objects(path))
+    if not blobs:
+        raw = open(path, 'rb').read()
+        raise RuntimeError(f'{path}: no gfx950 code object found in an uncompressed clang offload bundle'
+                           + (' (the file holds COMPRESSED bundles: build without --offload-compress)' if _CCOB in raw else '')
+                           + ' -- the audit cannot vouch for this build')
+    for _, blob in blobs:
         with tempfile.NamedTemporaryFile(suffix='.co', delete=False) as f:
             f.write(blob)
         try:

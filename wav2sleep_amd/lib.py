@@ -68,12 +68,16 @@ def build(verbose: bool = False) -> str:
         raise RuntimeError('building libw2s_hip.so failed:\n' + r.stdout[-4000:] + r.stderr[-4000:])
     if verbose:
         print(r.stdout[-2000:])
-    from .isa_audit import OBJDUMP, audit
-    if os.path.exists(OBJDUMP):   # the build must not contain the packed-fp32 form that misbehaves on gfx950 (isa_audit.py)
-        _, bad = audit(LIB_PATH)
-        if bad:
-            raise RuntimeError('libw2s_hip.so contains packed-fp32 instructions whose low lane reads the high half of src1 (wrong results on gfx950 '
-                               'beside bf16 MFMA waves, tools/pk_fma_opsel_repro.hip):\n' + '\n'.join(f'  {k}: {i}' for k, i in bad[:20]))
+    # the build must not contain the packed-fp32 form that misbehaves on gfx950 (isa_audit.py).  A gate that cannot see the code is no
+    # gate: a missing disassembler, no gfx950 code object, or implausibly few packed instructions FAIL the build instead of passing it
+    from .isa_audit import MIN_PACKED, audit
+    seen, bad = audit(LIB_PATH)   # raises if llvm-objdump or the code objects are not found
+    if bad:
+        raise RuntimeError('libw2s_hip.so contains packed-fp32 instructions whose low lane reads the high half of src1 (wrong results on gfx950 '
+                           'beside bf16 MFMA waves, tools/pk_fma_opsel_repro.hip):\n' + '\n'.join(f'  {k}: {i}' for k, i in bad[:20]))
+    if seen < MIN_PACKED and not os.environ.get('W2S_LIB'):
+        raise RuntimeError(f'ISA audit saw only {seen} packed-fp32 instructions in {LIB_PATH} (expected > {MIN_PACKED}): the disassembly is '
+                           f'not covering the library, so the gfx950 op_sel gate would pass vacuously')
     return LIB_PATH
 
 

@@ -165,14 +165,24 @@ class FusedTrainStep:
         self.sync_parameters()
 
     def sync_parameters(self):
-        """Rank 0's weights and AdamW moments to every rank (Lightning DDP broadcasts the module at construction; call again
-        after loading a checkpoint on rank 0 only).  A no-op at world size 1."""
+        """Rank 0's weights, AdamW moments AND scalar optimiser state (step / schedule position, lr_max, betas, eps, weight decay, the
+        dropout seed state) to every rank: Lightning DDP broadcasts the module at construction.  COLLECTIVE: every rank of the group
+        calls it the same number of times (four broadcasts).  `load_lightning_checkpoint` ends with one call of it, so a resume is
+        "every rank calls the loader" -- do not call it again on a subset of ranks.  A no-op at world size 1."""
         if self.reducer.world > 1:
             import torch.distributed as dist
             src = dist.get_global_rank(self.reducer.group, 0) if self.reducer.group is not None else 0
             for t in (self.model._flat, self.m, self.v):
                 dist.broadcast(t, src=src, group=self.reducer.group)
-            self.model.mark_params_dirty()
+            model = self.model
+            sc = torch.tensor([self.step_count, self.micro, self.lr_max, self.betas[0], self.betas[1], self.eps, self.wd,
+                               model._seed_base, model._seed_ctr], dtype=torch.float64, device=model._flat.device)
+            dist.broadcast(sc, src=src, group=self.reducer.group)
+            sc = sc.tolist()
+            self.step_count, self.micro = int(sc[0]), int(sc[1])
+            self.lr_max, self.betas, self.eps, self.wd = sc[2], (sc[3], sc[4]), sc[5], sc[6]
+            model._seed_base, model._seed_ctr = int(sc[7]), int(sc[8])
+            model.mark_params_dirty()
 
     def lr_at(self, step: int) -> float:
         return exp_warmup_lr(step, self.lr_max, self.warmup_steps, self.tau) if self.use_sched else self.lr_max
