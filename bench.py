@@ -117,13 +117,13 @@ def cpu_baseline(epochs, num_classes, signal_map, budget_s=60.0):
     model, cores, logical = host_cpu()
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else logical
     # thread count: "all physical cores" over-subscribes the memory-bound CPU path on a 128-core host (SURVEY measured 0.26 recordings/s on
-    # 8 cores, round 3 0.124 on 128).  Probe 16 / 32 / 64 / all cores once on a short sample of the same workload (1/8 of the epochs,
+    # 8 cores, round 3 0.124 on 128).  Probe 4 / 8 / 16 / 32 / 64 / all cores once on a short sample of the same workload (1/8 of the epochs,
     # forward + backward) and run the bounded sample at the fastest count: the baseline is the reference's CPU path at ITS best here.
     cfg_p = O.ModelConfig(signal_map=signal_map, num_classes=num_classes)
     sd_p = O.make_state_dict(cfg_p, seed=42)
     xp, yp = O.make_inputs(cfg_p, 2, max(8, epochs // 8), seed=99)
     probe = {}
-    for th in sorted({min(t, cores, avail) for t in (16, 32, 64, cores)}):
+    for th in sorted({min(t, cores, avail) for t in (4, 8, 16, 32, 64, cores)}):
         torch.set_num_threads(max(1, th))
         O.loss_and_grads(sd_p, cfg_p, xp, yp)   # warm-up at this count
         t1 = time.time()

@@ -76,8 +76,8 @@ typedef struct w2s_conv_args {
   float* part;             /* EPI_STATS / EPI_GP: [B][ntiles][2][cout] partial sums, or NULL */
   const void* w_hi;        /* optional bf16 planes of w (w = hi + lo, layout as w; see w2s_repack_bf16): enables the split-  */
   const void* w_lo;        /* precision matrix-core path for cin >= 32 and cout >= 64; NULL = exact fp32 MFMA               */
-  float* stat_out;         /* optional, with `part`: [B][cout][2] finalised IN the kernel by the workgroup that writes a sample's  */
-  int32_t* stat_cnt;       /* last partial (EPI_STATS: mean, rstd with stat_eps; EPI_GP: sums / L_out); stat_cnt: [B] zeroed once   */
+  float* stat_out;         /* optional: [B][cout][2] finalised IN the kernel (EPI_STATS: mean, rstd with stat_eps; EPI_GP: sums /   */
+  int32_t* stat_cnt;       /* L_out); `part` is then the row scratch sized by w2s_conv_stat_rows; stat_cnt: [B] zeroed once          */
   int32_t B, L_in, L_out, cin, cout, taps, stride, dil, pad, flip, mode;
   int32_t ldx, ldy, ldy2, ld_aux;
   int32_t pro, epi;
@@ -153,7 +153,7 @@ int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, vo
  * pro in {W2S_PRO_GELU, W2S_PRO_IN_GELU, W2S_PRO_FIRST} and W2S_EPI_STATS.  x: [B][L_in][cin] (pro FIRST: the raw signal [B][L_in],
  * w1 = block 0's conv1 weight), w: [cout][3][cin] (w2s_repack forward layout), st_in: [B][cin][2] (mean, rstd) unless pro == GELU,
  * y: [B][L_out][cout], part: [B][ceil(L_out/tile)][2][cout] with tile = w2s_conv_fwd_fused_tile (0 = combination not covered),
- * nwg = workgroups to launch (grid-stride over tiles).  Replaces aten::convolution + the statistics half of native_batch_norm
+ * nwg = workgroups to launch (each takes a contiguous run of the (sample, tile) list).  Replaces aten::convolution + the statistics half of native_batch_norm
  * (blocks.py:173-186).
  */
 int w2s_conv_fwd_fused_tile(int cin, int cout, int stride);
@@ -220,7 +220,7 @@ int w2s_enc_first_bwd_h(const float* x, const void* gn1, const float* hdr_n, con
  * weight gradient alone: slab [nslab][16].  Replaces trainer-side autograd of models/wav2sleep.py:96-110 (block 0). */
 int w2s_bwd_fused_w1(const float* g, const float* y, const float* st_k, const float* bst_k, const float* x, const float* st_in,
                      const float* wb, float* gout, float* part, float* part_w1, float* slab, int nslab, int B, int L, int pad,
-                     const float* w1, void* stream);
+                     const float* w1, float* stat_out, int32_t* stat_cnt, void* stream);   /* stat_out: as for w2s_bwd_fused */
 int w2s_enc_first_wgrad(const float* xmom, int ntx, const float* w1, const float* part_w1, const float* stats1, const float* bstats1,
                         float* out, int B, int ntiles, void* stream);
 /* w2s_enc_first_fwd's statistics-only form (y == NULL) that also keeps the nine raw moments of every signal tile:
@@ -233,7 +233,7 @@ int w2s_enc_first_dwd(const float* x, const float* gpre, float* slab, int nslab,
  * signal [B][2 L].  Sum the rows with w2s_colsum_batch; w2s_enc_first_dwd is then not needed. */
 int w2s_bwd_fused_wd(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* wb, float* gout,
                      float* part, float* slab, int nslab, int B, int L, int pad, const float* gpre, const float* wd, float* slab_d,
-                     const float* y3p, const float* st3p, const float* x0, float* part_wd, void* stream);
+                     const float* y3p, const float* st3p, const float* x0, float* part_wd, float* stat_out, int32_t* stat_cnt, void* stream);
 
 /*
  * Fused backward of one k=3 / symmetric-padding encoder conv with cg = 64 gradient-side channels (round 3, csrc/bwd_wide.hip): data
@@ -252,7 +252,9 @@ int w2s_bwd_wide_groups(int cg, int ch, int stride);   /* statistics-partial row
 int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                  const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B, int L,
                  int cg, int ch, int stride, const float* y3p, const float* st3p, const float* gpre, const void* wd_hi, const void* wd_lo,
-                 float* slab_d, int dry, void* stream);
+                 float* slab_d, float* stat_out, int32_t* stat_cnt, int dry, void* stream);
+/* stat_out / stat_cnt: in-kernel statistics finalisation (below); `part` is then the row scratch of B * w2s_stat_rows(B, ntiles, nslab) *
+ * w2s_bwd_wide_groups rows. */
 /* gpre != NULL (conv1 of a residual block: stride 1, st_in and add_even NULL, L even): the block's 1x1/stride-2 residual branch
  * (blocks.py:44-47,68) folded in as in w2s_bwd_fused -- gout additionally receives Wd^T gpre[t/2] at even t before the GELU' factor (gpre:
  * [B][L/2][cg], wd_hi / wd_lo: w2s_repack_batch bwd planes of the downsample weight) and slab_d receives nslab raw-fragment slabs of the
@@ -261,11 +263,19 @@ int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float*
  * does: y3p = that block's pre-norm conv3 output [B][L][ch], st3p = its (mean, rstd) [B][ch][2]; `part` then holds the partial sums of
  * gout*GELU'(n3) and gout*GELU'(n3)*n3, n3 = IN(y3p). */
 
-/* In-kernel finalisation (stat_out / stat_cnt arguments of the producers above): the workgroup that writes the LAST partial of a sample
- * reduces all of that sample's partials in a fixed order (fp64) -- same result as this call, one launch less per layer.  stat_cnt is a
- * caller-owned int32 [B] buffer, zero before first use; kernels re-arm it.  One buffer per stream.
- * partial sums [B][ntiles][2][C] -> per-(b,c) pairs [B][C][2]: kind 0 = (mean, rstd) with biased variance + eps
+/* In-kernel finalisation (stat_out / stat_cnt arguments of the producers above; round 4: per WORKGROUP, not per tile).  The persistent
+ * producers take their tiles blocked (a workgroup owns a contiguous run of the (sample, tile) list), keep exact (double-double) running
+ * sums of their run, and at the end of their run of a sample store ONE row and take ONE ticket from stat_cnt[b]; the workgroup that draws a
+ * sample's last ticket sums its rows in row order and writes stat_out[b][C][2] -- same result contract as w2s_stats_finalize, no launch.
+ * With stat_out set, `part` is NOT the per-tile partials but the ROW SCRATCH: [B][rows][2][C] pairs of doubles (hi, lo), 16-byte aligned,
+ * rows = w2s_stat_rows(B, ntiles, grid) for w2s_conv_fwd_fused (grid = min(nwg, B * ntiles)), w2s_bwd_fused (grid = nslab) and
+ * w2s_bwd_wide (grid = nslab; times w2s_bwd_wide_groups), w2s_conv_stat_rows(&a) for w2s_conv_forward (0: that descriptor's kernel has
+ * no in-kernel finalisation -- leave stat_out NULL), ntiles for the tile-per-workgroup kernels (w2s_gp_stats, w2s_enc_first_*).
+ * stat_cnt is a caller-owned int32 [B] buffer, zero before first use; the kernels re-arm it.  One buffer per stream.
+ * w2s_stats_finalize: partial sums [B][ntiles][2][C] -> per-(b,c) pairs [B][C][2]: kind 0 = (mean, rstd) with biased variance + eps
  * (nn.InstanceNorm1d, models/utils.py:89-92), kind 1 = (sum1, sum2)/count.  fp64 accumulation, fixed order. */
+int w2s_stat_rows(int B, int ntiles, int grid);
+int w2s_conv_stat_rows(const w2s_conv_args* a);
 int w2s_stats_finalize(const float* part, int B, int ntiles, int C, long count, float eps, int kind, float* out, void* stream);
 
 /* First encoder layer, Cin = 1 (blocks.py:46, conv1 of block 0): y[b,t,o] = sum_j w[o][j]*san(x[b,t+j-1]);

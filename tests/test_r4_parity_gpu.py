@@ -113,16 +113,21 @@ def test_stock_optimizer_loop_at_a_step_size_the_tolerance_resolves():
         return model, got
 
     model, got = run(False)
-    for (gl, gg), (wl, wg) in zip(got, want):
-        assert gl == pytest.approx(wl, rel=2e-4), (got, want)
-        assert gg == pytest.approx(wg, rel=2e-3), (got, want)
+    # step 0 runs on the initial weights: the forward bar (1e-4).  Steps 1.. run on weights one / two Adam steps away: the first steps are
+    # ~lr * sign(g), elements whose gradient is within kernel error of zero may take the other sign (the train10 golden's observation), which
+    # moves the loss by a few 1e-4 relative -- bar 2e-3 there, an order of magnitude under what a skipped update does (the control below)
+    assert got[0][0] == pytest.approx(want[0][0], rel=1e-4), (got, want)
+    for (gl, gg), (wl, wg) in zip(got[1:], want[1:]):
+        assert gl == pytest.approx(wl, rel=2e-3), (got, want)
+        assert gg == pytest.approx(wg, rel=2e-2), (got, want)
     new = model.state_dict()
-    # movement of all weights in relative L2 (Adam's first steps are ~lr * sign(g): elements whose gradient is within kernel error of zero
-    # may take the other sign -- the bar of the ten-step golden test, 5e-2)
+    # movement of all weights in relative L2 (the bar of the ten-step golden test, 5e-2)
     num = sum(float(((new[k].cpu() - sd0[k]) - (sd_ref[k] - sd0[k])).double().pow(2).sum()) for k in sd0)
     den = sum(float((sd_ref[k] - sd0[k]).double().pow(2).sum()) for k in sd0)
     assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
     # negative control: stale packed weights after torch's in-place step
     _, stale = run(True)
-    assert stale[0][0] == pytest.approx(want[0][0], rel=2e-4)            # step 0 ran on the freshly packed weights
-    assert abs(stale[1][0] - want[1][0]) > 20 * 2e-4 * abs(want[1][0]), (stale, want)   # step 1 did not see the update: far outside the bar
+    assert stale[0][0] == pytest.approx(want[0][0], rel=1e-4)            # step 0 ran on the freshly packed weights
+    err_fresh = max(abs(g[0] - w[0]) / abs(w[0]) for g, w in zip(got[1:], want[1:]))
+    err_stale = max(abs(g[0] - w[0]) / abs(w[0]) for g, w in zip(stale[1:], want[1:]))
+    assert err_stale > 2e-2 and err_stale > 10 * err_fresh, (err_fresh, err_stale, stale, want)   # a stale pack is far outside the bar

@@ -77,7 +77,34 @@ def ffwd_case(cin, cout, L, stride=1, B=16, pro=lib.PRO_IN_GELU):
     fn = lambda: lib.conv_fwd_fused(x=x, w=w, st_in=st, w1=None, y=y, part=part, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, stride=stride, pro=pro, nwg=nwg)
     return fn, 4 * (B * L * cin + B * Lo * cout), 2 * B * Lo * cout * cin * 3
 
+def bfirst_case(L=983040, B=16):
+    """block 0's conv2 backward in the first-layer recompute form (bwd_fused_bf_kernel<1,1,4,0,0,1,0>): input side rebuilt from the raw
+    signal, conv1's weight-gradient partials in the epilogue, gn1 not stored -- the step's third-largest kernel"""
+    c = 16
+    g = torch.randn(B, L, c, device=dev); y = torch.randn(B, L, c, device=dev); x = torch.randn(B, L, device=dev)
+    st = torch.rand(B, c, 2, device=dev) + 0.5; bst = torch.rand(B, c, 2, device=dev) * 0.01; sti = torch.rand(B, c, 2, device=dev) + 0.5
+    wb = torch.randn(c, 3, c, device=dev) / 7; w1 = torch.randn(c, 1, 3, device=dev) / 2
+    tile = lib.bwd_fused_tile(c, c, 1); nt = (L + tile - 1) // tile
+    part = torch.empty(B, nt, 2, c, device=dev); part_w1 = torch.empty(B, nt, 48, device=dev)
+    ns = int(os.environ.get('NSLAB', 512)); slab = torch.empty(ns * c * c * 3, device=dev)
+    fn = lambda: lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=lib.PRO_INBWD, xin=x, st_in=sti, add_even=None, wb=wb, gout=None, part=part, slab=slab, nslab=ns,
+                               B=B, Lg=L, Lh=L, cg=c, ch=c, stride=1, split_precision=True, w1=w1, part_w1=part_w1)
+    return fn, 4 * (2 * B * L * c + B * L), 2 * B * L * c * c * 3 * 2
+
+def ffirst_case(L=983040, B=16):
+    """block 0's conv2 forward with the first-layer recompute prologue (conv_fwd_bf_kernel<1,1,4,1,6>)"""
+    c = 16
+    x = torch.randn(B, L, device=dev); w = torch.randn(c, 3, c, device=dev) / 7; w1 = torch.randn(c, 1, 3, device=dev) / 2
+    st = torch.rand(B, c, 2, device=dev) + 0.5
+    t = lib.conv_fwd_fused_tile(c, c, 1)
+    y = torch.empty(B, L, c, device=dev); part = torch.empty(B, (L + t - 1) // t, 2, c, device=dev)
+    nwg = int(os.environ.get('NWG', 512))
+    fn = lambda: lib.conv_fwd_fused(x=x, w=w, st_in=st, w1=w1, y=y, part=part, B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1, pro=lib.PRO_FIRST, nwg=nwg)
+    return fn, 4 * (B * L + B * L * c), 2 * B * L * c * c * 3
+
 CASES = {
+    'bfirst': bfirst_case,
+    'ffirst': ffirst_case,
     'ff16': lambda: ffwd_case(16, 16, 983040),
     'ff16s2': lambda: ffwd_case(16, 16, 983040, stride=2),
     'ff1632': lambda: ffwd_case(16, 32, 245760),

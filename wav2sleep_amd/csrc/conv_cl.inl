@@ -450,8 +450,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
       for (int wm = 0; wm < WM; ++wm) s += red[(((wm * WN + wn) * NTW + nt) * 4 + gg) * 8 + k * 4 + e];
       w2s_part_store(&a.part[(((size_t)b * P.ntiles + tile) * 2 + k) * cout + n0 + c], s);
     }
-    w2s_stat_finish(StatFin{a.stat_out, a.stat_cnt, 1.0 / (double)L_out, a.stat_eps, epi == W2S_EPI_STATS ? 0 : 1}, a.part, b, P.ntiles, cout,
-                    P.ntiles * (int)gridDim.y);
   }
 }
 

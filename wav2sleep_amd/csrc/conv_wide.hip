@@ -24,6 +24,7 @@ struct WideP {
   float* y; float* part;
   int B, L_in, L_out, ntiles, flip, pad;   // window row 0 = input position t0*STRIDE - pad (1: symmetric; forward 2 / data gradient 0: causal)
   int dbg;   // tuning only (W2S_WIDE_DBG): 1 = no prologue arithmetic, 2 = no MFMA loop, 4 = no LDS staging, 8 = no stores, 16 = no loads
+  StatFin fin;   // in-kernel statistics finalisation (fin.out == NULL: per-tile partials in `part`)
 };
 
 typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
@@ -62,7 +63,12 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L_in = P.L_in, L_out = P.L_out;
   const int total = P.B * P.ntiles;
-  const int first = blockIdx.x, step = gridDim.x;
+  // tiles of this workgroup: a contiguous run of the (sample, tile) list (blocked; w2s_common.h "Statistics finalisation"); the grid
+  // never exceeds the tile count
+  const W2SRun wrun = w2s_block_part(total, gridDim.x, blockIdx.x);
+  const int first = wrun.first, step = 1;
+  // running statistics sums of this workgroup's run [2][OC] (hi, lo), behind the tables (in-kernel statistics finalisation)
+  w2s_dd* accL = reinterpret_cast<w2s_dd*>(stL + ((PRO != W2S_PRO_GELU) ? P.B * HC * 2 * (TWO ? 2 : 1) : 0));
   if (PRO != W2S_PRO_GELU) {
     for (int i = tid; i < P.B * HC * 2; i += 64 * (NW + NP)) {
       stL[i] = P.st[i];
@@ -71,8 +77,8 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     __syncthreads();   // the producers read the table before the first round's barrier
   }
 
-  // tiles of this workgroup: first, first + step, ...; iteration i of the producers stages tile i, iteration i + 1 of the consumers eats it
-  const int nt_wg = (total - first + step - 1) / step;            // >= 1 (the grid never exceeds the tile count)
+  // tiles of this workgroup: first, first + 1, ...; iteration i of the producers stages tile i, iteration i + 1 of the consumers eats it
+  const int nt_wg = wrun.count;                                   // >= 1 (the grid never exceeds the tile count)
   const int NI = ((nt_wg + 1 + PD - 1) / PD) * PD;                // barrier rounds, padded to whole prefetch cycles
 
   if (wave >= NW) {
@@ -154,6 +160,10 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     al[ks] = *reinterpret_cast<const bf16x8*>(P.w_lo + wo);
   }
   const int ch0 = wave * 16 + 4 * g;   // this lane's 4 consecutive output channels (D fragment: position r, channels 4g..4g+3)
+  if (P.fin.out && r == 0) {           // this lane's eight running sums (nobody else touches them)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { accL[ch0 + e] = (w2s_dd){0.0, 0.0}; accL[OC + ch0 + e] = (w2s_dd){0.0, 0.0}; }
+  }
   __syncthreads();                     // round 0 of the producers: the first window is in buffer 0
   for (int i = 0; i < NI - 1; ++i) {
     if (i >= nt_wg) { __syncthreads(); continue; }   // padding rounds of the producers' prefetch cycle
@@ -225,7 +235,19 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
       f32x4 x1, x2;
       x1.x = row16_sum(sA.x); x1.y = row16_sum(sA.y); x1.z = row16_sum(sA.z); x1.w = row16_sum(sA.w);
       x2.x = row16_sum(sB.x); x2.y = row16_sum(sB.y); x2.z = row16_sum(sB.z); x2.w = row16_sum(sB.w);
-      if (r == 0) {
+      if (P.fin.out) {   // (uniform) running sums of this run; the run of sample b ends with this tile: the sums go to the row scratch
+        if (r == 0) {
+          const bool endrun = (i + 1 >= nt_wg) || ((tl + 1) / P.ntiles != b);
+          double* row = nullptr;
+          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row) * (2 * OC) * 2;
+          const float v1[4] = {x1.x, x1.y, x1.z, x1.w}, v2[4] = {x2.x, x2.y, x2.z, x2.w};
+#pragma unroll 1
+          for (int e = 0; e < 4; ++e) {
+            w2s_run_add(accL, ch0 + e, v1[e], endrun, row);
+            w2s_run_add(accL, OC + ch0 + e, v2[e], endrun, row);
+          }
+        }
+      } else if (r == 0) {
         float* d = P.part + (((size_t)b * P.ntiles + tile) * 2) * OC + ch0;
         st4(d, x1);
         st4(d + OC, x2);
@@ -233,17 +255,22 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     }
     __syncthreads();   // the producers have staged the next window; this one may be overwritten
   }
+  // tickets of the samples this run touched (the consumer waves; the producers have passed their last barrier and end): the last
+  // arriver of a sample finalises its statistics (w2s_common.h).  Scratch: the window buffers, dead now.
+  if (P.fin.out) w2s_rows_tail(P.fin, total, gridDim.x, P.ntiles, blockIdx.x, first / P.ntiles, (first + nt_wg - 1) / P.ntiles, OC, 1, 64 * NW, smem4);
 }
 
 template <int CI, int NW, int STRIDE, int PRO, int EPI, int MT, int NP = 4, int UP2 = 0, int CZ = 0>
-static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
+static int launch_wide(const w2s_conv_args& a, hipStream_t s, int* rows_only = nullptr) {   // rows_only: answer the row count of the in-kernel finalisation, launch nothing
   constexpr int TM = 16 * MT, HC = CI * 16, NR = UP2 ? TM / 2 + 1 : (TM - 1) * STRIDE + 3, RSE = HC + (STRIDE == 1 ? 16 : 8);
   WideP P{a.x, a.x2, a.pro_stats, a.pro_bstats, static_cast<const __bf16*>(a.w_hi), static_cast<const __bf16*>(a.w_lo), a.aux, a.aux_stats,
-          a.add_even, a.y, a.part, a.B, a.L_in, a.L_out, (a.L_out + TM - 1) / TM, a.flip, a.pad, 0};
+          a.add_even, a.y, a.part, a.B, a.L_in, a.L_out, (a.L_out + TM - 1) / TM, a.flip, a.pad, 0,
+          StatFin{a.stat_out, a.stat_cnt, reinterpret_cast<double*>(a.part), 0, 1.0 / (double)a.L_out, a.stat_eps, a.epi == W2S_EPI_STATS ? 0 : 1}};
   { static const char* d = getenv("W2S_WIDE_DBG"); if (d) P.dbg = atoi(d); }
   size_t lds = (size_t)2 * 2 * NR * RSE * 2;   // two window buffers x (hi, lo) planes, bf16
   constexpr bool TWO = (PRO == W2S_PRO_INBWD || PRO == W2S_PRO_INBWD_GP);
   if (PRO != W2S_PRO_GELU) lds += (size_t)a.B * HC * 2 * 4 * (TWO ? 2 : 1);   // the statistics tables
+  lds += (size_t)2 * 16 * NW * 16;                                              // running statistics sums [2][OC] (hi, lo)
   // producer prefetch depth: three tiles in flight where the register budget allows (kernel-wide allocation: 64-channel workgroups
   // of 8 waves run two per CU = 128 VGPRs; 128-channel workgroups of 12 waves run one per CU = 168 VGPRs)
   constexpr int NHr = (NR + (64 * NP) / (HC / 4) - 1) / ((64 * NP) / (HC / 4));
@@ -257,8 +284,10 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
   const int total = P.B * P.ntiles;
   static const char* e = getenv("W2S_WIDE_WGS");   // tuning only: workgroups per CU
   const int per_cu = e ? atoi(e) : ((NW >= 8 || UP2) ? 1 : 2);   // (the transposed form needs 166 registers: one 8-wave workgroup per CU)
-  const int nwg = 256 * (per_cu > 0 ? per_cu : 1);
-  hipLaunchKernelGGL(kern, dim3(nwg < total ? nwg : total), dim3(64 * (NW + NP)), lds, s, P);
+  const int nwg = 256 * (per_cu > 0 ? per_cu : 1), grid = nwg < total ? nwg : total;
+  P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, grid);
+  if (rows_only) { *rows_only = P.fin.rows_cap; return W2S_OK; }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NW + NP)), lds, s, P);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
@@ -266,7 +295,8 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
 // 1 = this launch is not one of the wide kernel's shapes (the caller falls through to conv_cl_kernel)
 static bool wide_shape(const w2s_conv_args& a) {
   if (!a.w_hi || !a.w_lo || (a.mode != W2S_MODE_CONTIG && a.mode != W2S_MODE_UP2) || a.taps != 3 || a.dil != 1 || a.pad < 0 || a.pad > 2) return false;
-  if (a.y2 || a.rowkeep || a.bias || a.stat_out || a.reserved) return false;
+  if (a.y2 || a.rowkeep || a.bias || a.reserved) return false;
+  if (a.stat_out && (!a.stat_cnt || !a.part || ((uintptr_t)a.part & 15))) return false;
   if ((size_t)a.B * a.cin * 16 > 32 * 1024) return false;   // the per-sample statistics tables live in LDS
   if (a.ldx != a.cin || a.ldy != a.cout || (a.aux && a.ld_aux != a.cout)) return false;
   if (a.cin < 32 || a.cout < 32 || (a.cin < 64 && a.cout < 64)) return false;
@@ -280,13 +310,15 @@ static bool wide_shape(const w2s_conv_args& a) {
   return !off;
 }
 // dry != 0: only answer which tile an instance would use for this launch (> 0) or that none takes it (1 -> the caller's generic kernel);
-// w2s_conv_tile sizes the statistics partials with it
+// w2s_conv_tile sizes the statistics partials with it.  rows != NULL (with dry): also the rows per sample of the in-kernel statistics
+// finalisation's scratch (w2s_conv_stat_rows)
 static int wide_mt() { return 4; }   // 64-position tiles (128 were tried: no gain, more registers)
-int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry) {
+int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry, int* rows) {
   if (!wide_shape(a)) return 1;
   const int mt = wide_mt();
 #define W2S_WIDE(CI_, NW_, ST_, PRO_, EPI_) \
   if (a.mode == W2S_MODE_CONTIG && a.cin == 16 * CI_ && a.cout == 16 * NW_ && a.stride == ST_ && a.pro == PRO_ && a.epi == EPI_) { \
+    if (dry && rows) launch_wide<CI_, NW_, ST_, PRO_, EPI_, 4>(a, s, rows); \
     if (dry) return 16 * mt; \
     return launch_wide<CI_, NW_, ST_, PRO_, EPI_, 4>(a, s); \
   }
@@ -301,10 +333,10 @@ int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry) {
 #ifndef W2S_UP2_MT
 #define W2S_UP2_MT 8
 #endif
-    if (a.cin == 64 && a.pad == 1) return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s);
-    if (a.cin == 64 && a.pad == 2) return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s);
-    if (a.cin == 128 && a.pad == 1) return dry ? 16 * W2S_UP2_MT : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s);
-    if (a.cin == 128 && a.pad == 2) return dry ? 16 * W2S_UP2_MT : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s);
+    if (a.cin == 64 && a.pad == 1) { if (dry && rows) launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s, rows); return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s); }
+    if (a.cin == 64 && a.pad == 2) { if (dry && rows) launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s, rows); return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s); }
+    if (a.cin == 128 && a.pad == 1) { if (dry && rows) launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s, rows); return dry ? 16 * W2S_UP2_MT : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s); }
+    if (a.cin == 128 && a.pad == 2) { if (dry && rows) launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s, rows); return dry ? 16 * W2S_UP2_MT : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s); }
   }
   return 1;
 }

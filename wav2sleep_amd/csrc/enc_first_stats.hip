@@ -37,15 +37,17 @@ __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __res
   if (tid < 9) tot[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   __syncthreads();
   if (xmom && tid >= 32 && tid < 41) xmom[((size_t)b * ntiles + tl) * 9 + (tid - 32)] = tot[tid - 32];   // the tile's nine raw moments (w2s_enc_first_wgrad)
+  float sown = 0.f;
   if (tid < 32) {
     const int k = tid >> 4, o = tid & 15;
     const float w0 = w[o * 3], w1 = w[o * 3 + 1], w2 = w[o * 3 + 2];
     float s;
     if (k == 0) s = w0 * tot[0] + w1 * tot[1] + w2 * tot[2];
     else s = w0 * w0 * tot[3] + w1 * w1 * tot[4] + w2 * w2 * tot[5] + 2.f * (w0 * w1 * tot[6] + w1 * w2 * tot[7] + w0 * w2 * tot[8]);
-    w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + o], s);
+    sown = s;
+    if (!fin.out) w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + o], s);
   }
-  w2s_stat_finish(fin, part, b, ntiles, 16, ntiles);
+  if (fin.out) w2s_row_per_workgroup(fin, b, tl, ntiles, 16, sown);   // uniform
 }
 
 // launcher for w2s_enc_first_fwd (enc_misc.hip)

@@ -51,14 +51,16 @@ __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restr
     for (int k = 0; k < 8; ++k) red[wave][lane][k] = a[k];
   }
   __syncthreads();
+  float sown = 0.f;
   if (tid < 32) {
     const int k = tid >> 4, c = tid & 15;  // k: 0 sum, 1 sumsq
     float s = 0.f;
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv) s += red[wv][c >> 2][k * 4 + (c & 3)];
-    w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + c], s);
+    sown = s;
+    if (!fin.out) w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + c], s);
   }
-  w2s_stat_finish(fin, part, b, ntiles, 16, ntiles);
+  if (fin.out) w2s_row_per_workgroup(fin, b, tl, ntiles, 16, sown);   // uniform
 }
 
 int w2s_enc_first_stats_launch(const float* x, const float* w, float* part, int B, int L, int tile, int ntiles, StatFin fin, int shift, hipStream_t s,
@@ -68,8 +70,8 @@ extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float
                                  int* stat_cnt, float eps, int causal, void* stream) {
   if (!x || !w || !part || cout != 16 || tile < 64 || (tile & 63)) return W2S_EINVAL;  // y == NULL: statistics only
   const int ntiles = (L + tile - 1) / tile;
-  if (stat_out && !stat_cnt) return W2S_EINVAL;
-  const StatFin fin{stat_out, stat_cnt, 1.0 / (double)L, eps, 0};
+  if (stat_out && (!stat_cnt || ((uintptr_t)part & 15))) return W2S_EINVAL;   // stat_out: `part` is the ROW scratch [B][ntiles][2][16] of (hi, lo) doubles
+  const StatFin fin{stat_out, stat_cnt, reinterpret_cast<double*>(part), ntiles, 1.0 / (double)L, eps, 0};
   if (!y) {
     return w2s_enc_first_stats_launch(x, w, part, B, L, tile, ntiles, fin, causal ? 1 : 0, reinterpret_cast<hipStream_t>(stream));
   }
@@ -84,8 +86,8 @@ extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float
 extern "C" int w2s_enc_first_stats(const float* x, const float* w, float* part, float* xmom, int B, int L, int tile, float* stat_out, int* stat_cnt,
                                    float eps, int causal, void* stream) {
   if (!x || !w || !part || tile < 64 || (tile & 63)) return W2S_EINVAL;
-  if (stat_out && !stat_cnt) return W2S_EINVAL;
-  const StatFin fin{stat_out, stat_cnt, 1.0 / (double)L, eps, 0};
+  if (stat_out && (!stat_cnt || ((uintptr_t)part & 15))) return W2S_EINVAL;   // stat_out: `part` is the ROW scratch [B][ntiles][2][16] of (hi, lo) doubles
+  const StatFin fin{stat_out, stat_cnt, reinterpret_cast<double*>(part), (L + tile - 1) / tile, 1.0 / (double)L, eps, 0};
   return w2s_enc_first_stats_launch(x, w, part, B, L, tile, (L + tile - 1) / tile, fin, causal ? 1 : 0, reinterpret_cast<hipStream_t>(stream), xmom);
 }
 
@@ -482,14 +484,16 @@ __global__ __launch_bounds__(256) void gp_stats_kernel(const void* __restrict__ 
   st4(sm + tid * 8, a1);
   st4(sm + tid * 8 + 4, a2);
   __syncthreads();
+  float sown = 0.f;
   if (tid < 2 * C) {
     const int k = tid / C, c = tid % C;
     float s = 0.f;
     for (int rl = 0; rl < rstep; ++rl) s += sm[(rl * c4n + (c >> 2)) * 8 + k * 4 + (c & 3)];
-    w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * C + c], s);
+    sown = s;
+    if (!fin.out) w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * C + c], s);
   }
   if (!GH && hdr_amax) w2s_amax_commit(hdr_amax, amax, 1.f);   // uniform
-  w2s_stat_finish(fin, part, b, ntiles, C, ntiles);
+  if (fin.out) w2s_row_per_workgroup(fin, b, tl, ntiles, C, sown);   // uniform
 }
 
 static int gp_stats_impl(const void* g, int g_half, const float* hdr_g, float* hdr_amax, const float* y, const float* stats, float* part, int B, int L,
@@ -497,8 +501,8 @@ static int gp_stats_impl(const void* g, int g_half, const float* hdr_g, float* h
   if (!g || !y || !stats || !part || C < 16 || C > 128 || (C & (C - 1)) || tile <= 0) return W2S_EINVAL;
   if (g_half ? (!hdr_g || hdr_amax) : (hdr_g != nullptr)) return W2S_EINVAL;
   const int ntiles = (L + tile - 1) / tile;
-  if (stat_out && !stat_cnt) return W2S_EINVAL;
-  const StatFin fin{stat_out, stat_cnt, 1.0 / (double)L, 0.f, 1};
+  if (stat_out && (!stat_cnt || ((uintptr_t)part & 15))) return W2S_EINVAL;   // stat_out: `part` is the ROW scratch [B][ntiles][2][C] of (hi, lo) doubles
+  const StatFin fin{stat_out, stat_cnt, reinterpret_cast<double*>(part), ntiles, 1.0 / (double)L, 0.f, 1};
   if (g_half)
     hipLaunchKernelGGL(gp_stats_kernel<1>, dim3(ntiles, B), dim3(256), 256 * 8 * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y,
                        stats, part, L, C, tile, ntiles, fin, hdr_g, hdr_amax);

@@ -4,8 +4,9 @@
 //   pad = 1: symmetric padding; pad = 2: causal padding (blocks.py:150-152,178-182: left pad k-1, the right trim is not computed)
 //   part[b][tile][2][CO] = per-tile sums of y and y^2   (instance-norm statistics of the NEXT layer, blocks.py:173-186)
 //
-// Same contract as conv_cl_kernel with EPI_STATS, different execution shape: workgroups walk the (sample, tile) list with a
-// grid stride, the NEXT tile's window is prefetched into registers while the current tile runs through the matrix cores
+// Same contract as conv_cl_kernel with EPI_STATS, different execution shape: every workgroup owns a contiguous run of the (sample, tile)
+// list (blocked: w2s_block_part -- a workgroup then meets one or two samples, which is what lets it finalise the statistics itself, see
+// w2s_common.h), the NEXT tile's window is prefetched into registers while the current tile runs through the matrix cores
 // (conv_cl's one-tile workgroups serialise load latency, prologue arithmetic, MFMA and store drain), the weights live in
 // LDS as bf16 hi/lo planes for the whole launch, and every product is 3 x v_mfma_f32_16x16x32_bf16 (16 input channels: two
 // taps share one K = 32 step).  Replaces aten::convolution + native_batch_norm(statistics) of ConvLayer1D.forward.
@@ -19,6 +20,7 @@ struct FwdP {
   const float* x; const float* w; const float* st_in; const float* w1;
   float* y; float* part;
   int B, L_in, L_out, ntiles, pro, pad;
+  int acc_off;   // byte offset of the running statistics sums in the dynamic LDS
   StatFin fin;   // in-kernel statistics finalisation (fin.out == NULL: partials only)
 };
 
@@ -64,6 +66,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
   __bf16* wH = hbase + (DB ? 2 : 1) * WIN;               // [OC][WROW]
   __bf16* wLo = wH + OC * WROW;
   float* xsL = reinterpret_cast<float*>(wLo + OC * WROW);  // FIRST: NRh + 2 signal samples
+  // running (double-double) sums of this workgroup's run [2][OC], one slot per thread < 2*OC (in-kernel statistics finalisation)
+  w2s_dd* accL = reinterpret_cast<w2s_dd*>(reinterpret_cast<char*>(smem4) + P.acc_off);
+  if (threadIdx.x < 2 * OC) accL[threadIdx.x] = (w2s_dd){0.0, 0.0};
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int L_in = P.L_in, L_out = P.L_out;
@@ -92,9 +97,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
       for (int j = 0; j < 3; ++j) w1r[i][j] = P.w1[(hch + i) * 3 + j];
   }
   const int total = P.B * P.ntiles;
+  const W2SRun wrun = w2s_block_part(total, gridDim.x, blockIdx.x);   // this workgroup's tiles [wfirst, wend): the grid never exceeds the tile count
+  const int wfirst = wrun.first, wend = wrun.first + wrun.count;
   auto prefetch = [&](auto SET, int tl_) {
     constexpr int S = decltype(SET)::value;
-    const int tl = min(tl_, total - 1);
+    const int tl = min(tl_, wend - 1);
     const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TS;
     const int rb = t0 * STRIDE - P.pad;
     if (FIRST) {  // signal samples rb-pad .. rb-pad+NRh+1 (conv1 has the same padding mode as this conv)
@@ -153,14 +160,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
 
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   auto body = [&](auto SET, int tl) {
-    const bool live = tl < total;   // workgroup-uniform; a dead round only keeps the load queue regular
-    const int b = min(tl, total - 1) / P.ntiles, tile = min(tl, total - 1) % P.ntiles;
+    const bool live = tl < wend;   // workgroup-uniform; a dead round only keeps the load queue regular
+    const int b = min(tl, wend - 1) / P.ntiles, tile = min(tl, wend - 1) % P.ntiles;
     const int t0 = tile * TS;
     if (!DB) __syncthreads();  // single buffer: the previous tile's LDS reads are done (two buffers: the barriers of the round in between did that)
     const __bf16* hH = hbase + (DB ? decltype(SET)::value : 0) * WIN;
     const __bf16* hLo = hH + NRh * RSh;
     if (live) commit(SET, tl);
-    prefetch(SET, tl + 2 * (int)gridDim.x);
+    prefetch(SET, tl + 2);
     __syncthreads();
     if (!live) return;
 
@@ -231,17 +238,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) s += red[((w * CO + nt) * 4 + gg) * 8 + k * 4 + e];
-      w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c], s);
+      if (P.fin.out) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
+        const bool endrun = tl + 1 >= wend || (tl + 1) / P.ntiles != b;
+        double* row = nullptr;
+        if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row) * (2 * OC) * 2;
+        w2s_run_add(accL, tid, s, endrun, row);
+      } else {
+        w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c], s);
+      }
     }
-    w2s_stat_finish(P.fin, P.part, b, P.ntiles, OC, P.ntiles);
   };
-  const int first = blockIdx.x, step = gridDim.x;   // the grid never exceeds the tile count
-  prefetch(I0{}, first);
-  prefetch(I1{}, first + step);
-  for (int tl = first; tl < total; tl += 2 * step) {
+  prefetch(I0{}, wfirst);
+  prefetch(I1{}, wfirst + 1);
+  for (int tl = wfirst; tl < wend; tl += 2) {
     body(I0{}, tl);
-    body(I1{}, tl + step);
+    body(I1{}, tl + 1);
   }
+  // tickets of the samples this run touched; the last arriver of a sample finalises its statistics (w2s_common.h)
+  if (P.fin.out) w2s_rows_tail(P.fin, total, gridDim.x, P.ntiles, blockIdx.x, wfirst / P.ntiles, (wend - 1) / P.ntiles, OC, 1, 256, smem4);
 }
 
 template <int CI, int CO, int MT, int STRIDE, int PRO>
@@ -251,12 +265,16 @@ static int launch_fwd(const FwdP& P0, int nwg, hipStream_t s) {
   P.ntiles = (P.L_out + TS - 1) / TS;
   size_t lds = (size_t)4 * CO * 4 * 8 * 4 + (size_t)2 * 2 * ((ff_db(HC, STRIDE) ? 2 : 1) * NRh * ff_rs(HC) + OC * (KD + 8));
   if (PRO == W2S_PRO_FIRST) lds += (size_t)(NRh + 2) * 4;
+  lds = (lds + 15) & ~(size_t)15;
+  P.acc_off = (int)lds;
+  lds += (size_t)2 * OC * 16;
   auto kern = conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
-  const int total = P.B * P.ntiles;
-  hipLaunchKernelGGL(kern, dim3(nwg < total ? nwg : total), dim3(256), lds, s, P);
+  const int total = P.B * P.ntiles, grid = nwg < total ? nwg : total;
+  P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, grid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, P);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
@@ -271,14 +289,16 @@ extern "C" int w2s_conv_fwd_fused_tile(int cin, int cout, int stride) {
 extern "C" int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const float* w1, float* y, float* part, int B,
                                   int L_in, int L_out, int cin, int cout, int stride, int pad, int pro, int nwg, float* stat_out, int* stat_cnt,
                                   float eps, void* stream) {
+  // stat_out given: the statistics are finalised in the kernel and `part` is its ROW scratch instead of the per-tile partials --
+  // B * w2s_stat_rows(B, ntiles, min(nwg, B * ntiles)) * 2 * cout (hi, lo) pairs of doubles, 16-byte aligned (w2s_common.h)
   if (!x || !w || !y || !part || B <= 0 || L_out <= 0 || nwg <= 0) return W2S_EINVAL;
   if (!w2s_conv_fwd_fused_tile(cin, cout, stride)) return W2S_EINVAL;
   if (pro != W2S_PRO_GELU && pro != W2S_PRO_IN_GELU && pro != W2S_PRO_FIRST) return W2S_EINVAL;
   if ((pro != W2S_PRO_GELU && !st_in) || (pro == W2S_PRO_FIRST && (!w1 || cin != 16 || stride != 1))) return W2S_EINVAL;
   if ((stride == 1 && L_out != L_in) || (stride == 2 && 2 * L_out != L_in) || (pad != 1 && pad != 2)) return W2S_EINVAL;
   if ((size_t)L_in * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;
-  if (stat_out && !stat_cnt) return W2S_EINVAL;
-  FwdP P{x, w, st_in, w1, y, part, B, L_in, L_out, 0, pro, pad, StatFin{stat_out, stat_cnt, 1.0 / (double)L_out, eps, 0}};
+  if (stat_out && (!stat_cnt || ((uintptr_t)part & 15))) return W2S_EINVAL;
+  FwdP P{x, w, st_in, w1, y, part, B, L_in, L_out, 0, pro, pad, 0, StatFin{stat_out, stat_cnt, reinterpret_cast<double*>(part), 0, 1.0 / (double)L_out, eps, 0}};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define W2S_FF(CI_, CO_, MT_, ST_) \
   if (cin == 16 * CI_ && cout == 16 * CO_ && stride == ST_) { \

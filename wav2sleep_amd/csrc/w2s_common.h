@@ -44,7 +44,12 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #define W2S_HE_Q3 -0.0036866646260023117f
 #define W2S_HE_Q4 -0.014264739118516445f
 #define W2S_HE_CLAMP 5.65685424949238f   /* 4 sqrt 2: erf saturates to fp32 beyond */
+// -DW2S_ERF_IDENTITY: timing-only build (tools/altlib.sh; numerics WRONG on purpose): the rational erf and the exp2 of GELU' collapse
+// to one multiply each -- how fast is the skeleton of a kernel without its transcendental work?  
 __device__ __forceinline__ float half_erf_fast(float x) {
+#ifdef W2S_ERF_IDENTITY
+  return x * 0.125f;
+#endif
   x = __builtin_amdgcn_fmed3f(x, -W2S_HE_CLAMP, W2S_HE_CLAMP);
   const float x2 = x * x;
   float p = fmaf(x2, W2S_HE_P0, W2S_HE_P1);
@@ -71,7 +76,15 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // the product cannot over/underflow.
 __device__ __forceinline__ f32x4 splat4(float c) { return (f32x4){c, c, c, c}; }
 __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+#ifdef W2S_ERF_IDENTITY
+#define W2S_EXP2(t) ((t) * 0.03125f)
+#else
+#define W2S_EXP2(t) __builtin_amdgcn_exp2f(t)
+#endif
 __device__ __forceinline__ f32x4 half_erf4(f32x4 x) {
+#ifdef W2S_ERF_IDENTITY
+  return x * 0.125f;
+#endif
   x.x = __builtin_amdgcn_fmed3f(x.x, -W2S_HE_CLAMP, W2S_HE_CLAMP); x.y = __builtin_amdgcn_fmed3f(x.y, -W2S_HE_CLAMP, W2S_HE_CLAMP);
   x.z = __builtin_amdgcn_fmed3f(x.z, -W2S_HE_CLAMP, W2S_HE_CLAMP); x.w = __builtin_amdgcn_fmed3f(x.w, -W2S_HE_CLAMP, W2S_HE_CLAMP);
   const f32x4 x2 = x * x;
@@ -96,14 +109,14 @@ __device__ __forceinline__ f32x4 gelu4(f32x4 v) { return v * (half_erf4(v) + 0.5
 __device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
   const f32x4 cdf = half_erf4(v) + 0.5f;
   const f32x4 t = v * v * -0.72134752044448170368f;  // exp(-x^2/2) = 2^t
-  const f32x4 pdf = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y), __builtin_amdgcn_exp2f(t.z), __builtin_amdgcn_exp2f(t.w)};
+  const f32x4 pdf = {W2S_EXP2(t.x), W2S_EXP2(t.y), W2S_EXP2(t.z), W2S_EXP2(t.w)};
   return fma4(v * 0.39894228040143267794f, pdf, cdf);
 }
 // GELU and GELU' of the same argument from ONE erf evaluation (the fused backward needs both for the tile's centre rows)
 __device__ __forceinline__ void gelu_both4(f32x4 v, f32x4& h, f32x4& gp) {
   const f32x4 cdf = half_erf4(v) + 0.5f;
   const f32x4 t = v * v * -0.72134752044448170368f;
-  const f32x4 pdf = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y), __builtin_amdgcn_exp2f(t.z), __builtin_amdgcn_exp2f(t.w)};
+  const f32x4 pdf = {W2S_EXP2(t.x), W2S_EXP2(t.y), W2S_EXP2(t.z), W2S_EXP2(t.w)};
   h = v * cdf;
   gp = fma4(v * 0.39894228040143267794f, pdf, cdf);
 }
@@ -165,87 +178,148 @@ __device__ __forceinline__ float w2s_dropscale(uint64_t seed, uint64_t idx, floa
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Statistics finalisation inside the PRODUCER kernel (replaces a w2s_stats_finalize launch between every two encoder layers:
-// 168 launches and ~1.3 ms per train step on the critical path).  Every workgroup that has written its per-tile partial
-// sums for sample b takes a ticket from counter[b]; the workgroup that draws the last ticket re-reads all of that sample's
-// partials and reduces them in a FIXED order in fp64 -- the result does not depend on which workgroup happens to be last, so
-// runs stay bit-reproducible.  Release/acquire: partial stores -> __threadfence -> ticket (device-scope atomic); last
-// workgroup: ticket -> __threadfence (L1 invalidate) -> loads.  The last workgroup also re-arms the counter.
-// part: [B][ntiles][2][C];  kind 0: out = (mean, rstd = 1/sqrt(biased var + eps));  kind 1: out = (sum1/count, sum2/count).
+// Statistics finalisation inside the PRODUCER kernel, per WORKGROUP (round 4; replaces the w2s_stats_finalize launch between every two
+// encoder layers: 168 launches per train step).  The persistent producers take their tiles BLOCKED -- workgroup w owns a contiguous run of
+// the flattened (sample, tile) list (w2s_block_part) -- so a workgroup meets one or two samples and a sample is covered by a handful of
+// workgroups.  In its tile loop a workgroup only keeps running sums of its tiles' per-tile fp32 sums in a small LDS table (double-double:
+// the total is exact to ~2^-100, so the finalised fp32 values do not depend on how batch size / grid happened to cut a sample into runs)
+// and, when its run of sample b ends, stores ONE row [2][C] of (hi, lo) pairs with agent-scope write-through stores.  AFTER the loop
+// (w2s_rows_tail: nothing of the loop is live any more, so none of this counts against the loop's register budget) it waits for the
+// acknowledgement of its stores and takes ONE ticket per sample of its run from cnt[b]; the workgroup whose ticket is a sample's last sums
+// that sample's rows -- all its threads, a fixed partition and order -- and writes out[b][C][2] = (mean, rstd) or (sum1, sum2)/count; it
+// also re-arms the counter.  Protocol = MI355X_MICROARCH.md, "Valid forms": sc1 payload stores, drained by every storing wave, a
+// workgroup barrier, ONE lane's agent-scope atomic add; the workgroup whose add returned last loads with sc1 loads behind an agent-scope
+// acquire (several workgroups share a CU here).  The round-1 form of this took a ticket per TILE and stalled the persistent workgroups on
+// every one of them (47 ms vs 38.5 ms per step); this one costs a workgroup one or two tickets per launch, after its work.
 // ------------------------------------------------------------------------------------------------------------------
-// per-tile partial sums that another workgroup of the SAME launch may read (w2s_stat_finish): agent-scope relaxed accesses
-__device__ __forceinline__ void w2s_part_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float w2s_part_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-struct StatFin { float* out; int* cnt; double inv_count; float eps; int kind; };
-__device__ __forceinline__ void w2s_stat_finish(const StatFin& F, const float* part, int b, int ntiles, int C, int expected) {
-  __shared__ double fin_red[256];
-  __shared__ double fin_sum[256];
-  __shared__ int fin_last;
-  if (!F.out) return;  // uniform
+struct StatFin { float* out; int* cnt; double* rows; int rows_cap; double inv_count; float eps; int kind; };   // out == NULL: per-tile partials only
+
+// balanced blocked partition of `total` items over `grid` workgroups: the first total % grid runs are one longer (surplus workgroups: empty)
+struct W2SRun { int first, count; };
+__host__ __device__ __forceinline__ W2SRun w2s_block_part(int total, int grid, int w) {
+  if (grid > total) grid = total;
+  if (w >= grid) return W2SRun{total, 0};
+  const int base = total / grid, rem = total % grid;
+  return W2SRun{w * base + (w < rem ? w : rem), base + (w < rem ? 1 : 0)};
+}
+__host__ __device__ __forceinline__ int w2s_block_owner(int total, int grid, int t) {
+  if (grid > total) grid = total;
+  const int base = total / grid, rem = total % grid, cut = rem * (base + 1);
+  return t < cut ? t / (base + 1) : rem + (t - cut) / base;
+}
+// rows a sample can have (sizes the row scratch [B][rows][2][C] of (hi, lo) pairs): the runs that can intersect ntiles consecutive items
+__host__ __device__ __forceinline__ int w2s_stat_rows_of(int B, int ntiles, int grid) {
+  const int total = B * ntiles, g = grid < total ? grid : total, base = total / (g > 0 ? g : 1);
+  const int r = (ntiles + base - 1) / base + 1;
+  return r < g ? r : g;
+}
+
+typedef double w2s_dd __attribute__((ext_vector_type(2)));   // (hi, lo): value = hi + lo
+__device__ __forceinline__ void w2s_dd_add(w2s_dd& a, double x) {   // a += x, error-free in the high word (Knuth TwoSum)
+  const double s = a.x + x, bb = s - a.x;
+  a.y += (a.x - (s - bb)) + (x - bb);
+  a.x = s;
+}
+__device__ __forceinline__ void w2s_dd_add2(w2s_dd& a, w2s_dd b) { w2s_dd_add(a, b.x); a.y += b.y; }
+// agent-scope write-through store / L1-bypassing load of one (hi, lo) pair (two 8-byte accesses: the guide's table covers 8-B sc1 forms)
+__device__ __forceinline__ void w2s_row_store(double* p, w2s_dd v) {
+  __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ w2s_dd w2s_row_load(const double* p) {
+  return (w2s_dd){__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+}
+// per-tile partial sums of the partials-only mode (F.out == NULL): plain stores, read by a later launch (w2s_stats_finalize)
+__device__ __forceinline__ void w2s_part_store(float* p, float v) { *p = v; }
+
+// Which row of sample b workgroup w writes, and how many workgroups write rows of b
+struct W2SRowPos { int row, expected; };
+__device__ __forceinline__ W2SRowPos w2s_row_pos(int total, int grid, int ntiles, int b, int w) {
+  const int w0 = w2s_block_owner(total, grid, b * ntiles), w1 = w2s_block_owner(total, grid, (b + 1) * ntiles - 1);
+  return W2SRowPos{w - w0, w1 - w0 + 1};
+}
+// In the tile loop, thread-private: running sum `idx` (a value of the row [groups][2][C], owned by exactly one thread) += the tile's fp32 sum;
+// with `endrun` (the workgroup's run of sample b ends with this tile) the sum goes to the row and the slot is cleared.  acc: LDS table.
+__device__ __forceinline__ void w2s_run_add(w2s_dd* acc, int idx, float s, bool endrun, double* row) {
+  w2s_dd a = acc[idx];
+  w2s_dd_add(a, (double)s);
+  if (endrun) { w2s_row_store(row + 2 * idx, a); a = (w2s_dd){0.0, 0.0}; }
+  acc[idx] = a;
+}
+// After the tile loop; reached by the NT threads (tid 0 .. NT-1, whole waves) that stored rows or share a barrier with those that did --
+// every thread of the workgroup, or the consumer waves of a role-split kernel once its producer waves have ended.  Workgroup w's run
+// covered samples b0 .. b1 (b1 < b0: empty run).  `lds`: >= NT * 16 + 16 bytes of LDS nobody else uses any more, 16-byte aligned.
+// rows: [B][rows_cap][2][C] pairs; a workgroup wrote `groups` consecutive rows per sample (position groups of a tile: row*groups + g).
+__device__ __forceinline__ void w2s_rows_tail(const StatFin& F, int total, int grid, int ntiles, int w, int b0, int b1, int C, int groups, int NT, void* lds) {
   const int tid = threadIdx.x;
-  // The partials were written with agent-scope write-through stores (w2s_part_store); waiting for their acknowledgement is all the
-  // release this needs.  A __threadfence() here would write back / invalidate the whole XCD L2 once per tile (measured: 8x slower step).
-  __builtin_amdgcn_s_waitcnt(0);
+  w2s_dd* red = reinterpret_cast<w2s_dd*>(lds);
+  int* flag = reinterpret_cast<int*>(red + NT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its row stores are acknowledged (write-through: at the memory side)
   __syncthreads();
-  if (tid == 0) fin_last = (__hip_atomic_fetch_add(&F.cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1) ? 1 : 0;
-  __syncthreads();
-  if (!fin_last) return;
-  // one partial row = 2C floats ([2][C]); thread = (4-float slot q of the row, tile lane ln); agent-scope loads (they bypass the
-  // non-coherent L1 / remote-XCD L2 lines), four rows = 16 loads in flight per thread
-  const int qn = (2 * C) >> 2, nl = 256 / qn;   // C = 16: 32 tile lanes ... C = 128: 4
-  const int q = tid % qn, ln = tid / qn;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  {
-    const float* p = part + ((size_t)b * ntiles) * (2 * C) + q * 4;
-    int t = ln;
-    for (; t + 3 * nl < ntiles; t += 4 * nl) {
-      float v[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[u][e] = w2s_part_load(p + (size_t)(t + u * nl) * (2 * C) + e);
-      s0 += ((double)v[0][0] + (double)v[1][0]) + ((double)v[2][0] + (double)v[3][0]);
-      s1 += ((double)v[0][1] + (double)v[1][1]) + ((double)v[2][1] + (double)v[3][1]);
-      s2 += ((double)v[0][2] + (double)v[1][2]) + ((double)v[2][2] + (double)v[3][2]);
-      s3 += ((double)v[0][3] + (double)v[1][3]) + ((double)v[2][3] + (double)v[3][3]);
+  const int V = 2 * C, slots = NT / V;   // thread = (row slot, value of the row); NT >= 2C in every caller (C = 128 with 256 threads: one slot)
+  for (int b = b0; b <= b1; ++b) {
+    const W2SRowPos rp = w2s_row_pos(total, grid, ntiles, b, w);
+    if (tid == 0) {
+      const int lastw = (__hip_atomic_fetch_add(&F.cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rp.expected - 1) ? 1 : 0;
+#ifndef W2S_FIN_NOFENCE   // (tuning builds: without the acquire -- every load of the rows is an sc1 load, which bypasses L1 by itself)
+      if (lastw) {   // ONE lane's agent-scope acquire (drops this CU's L1 copies: several workgroups share a CU), complete before the barrier
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#endif
+      *flag = lastw;
     }
-    for (; t < ntiles; t += nl) {
-      const float* r = p + (size_t)t * (2 * C);
-      s0 += (double)w2s_part_load(r); s1 += (double)w2s_part_load(r + 1); s2 += (double)w2s_part_load(r + 2); s3 += (double)w2s_part_load(r + 3);
-    }
-  }
-  // fixed-order tree over the tile lanes, one float4 component at a time (fin_red holds 256 doubles)
-  double tot[4] = {s0, s1, s2, s3};
+    __syncthreads();
+    const bool last = *flag != 0;
+    if (last) {   // uniform
+      const int nrows = rp.expected * groups;
+      const double* base = F.rows + ((size_t)b * F.rows_cap) * V * 2;
+      const int v = tid % V, slot = tid / V;
+      w2s_dd a = {0.0, 0.0};
+      if (slot < slots) {
+        int r = slot;
+        for (; r + 3 * slots < nrows; r += 4 * slots) {   // four rows in flight per thread
+          w2s_dd x[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    __syncthreads();
-    fin_red[tid] = tot[e];
-    __syncthreads();
-    for (int half = nl >> 1; half > 0; half >>= 1) {
-      if (ln < half) fin_red[tid] += fin_red[tid + half * qn];
+          for (int u = 0; u < 4; ++u) x[u] = w2s_row_load(base + ((size_t)(r + u * slots) * V + v) * 2);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w2s_dd_add2(a, x[u]);
+        }
+        for (; r < nrows; r += slots) w2s_dd_add2(a, w2s_row_load(base + ((size_t)r * V + v) * 2));
+      }
+      red[tid] = a;
       __syncthreads();
+      if (tid < C) {
+        w2s_dd s1 = {0.0, 0.0}, s2 = {0.0, 0.0};
+        for (int sl = 0; sl < slots; ++sl) { w2s_dd_add2(s1, red[sl * V + tid]); w2s_dd_add2(s2, red[sl * V + C + tid]); }
+        const double t1 = s1.x + s1.y, t2 = s2.x + s2.y;
+        float o0, o1;
+        if (F.kind == 0) {
+          const double mean = t1 * F.inv_count;
+          double var = t2 * F.inv_count - mean * mean;
+          if (var < 0.0) var = 0.0;
+          o0 = (float)mean;
+          o1 = (float)(1.0 / sqrt(var + (double)F.eps));
+        } else {
+          o0 = (float)(t1 * F.inv_count);
+          o1 = (float)(t2 * F.inv_count);
+        }
+        F.out[((size_t)b * C + tid) * 2] = o0;
+        F.out[((size_t)b * C + tid) * 2 + 1] = o1;
+      }
+      if (tid == 0) __hip_atomic_store(&F.cnt[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch on this stream
     }
-    if (ln == 0) fin_sum[q * 4 + e] = fin_red[tid];   // fin_sum[k*C + c]
+    __syncthreads();   // flag / red are reused by the next sample of the run
   }
-  __syncthreads();
-  if (tid < C) {
-    const double a1 = fin_sum[tid], a2 = fin_sum[C + tid];
-    float o0, o1;
-    if (F.kind == 0) {
-      const double mean = a1 * F.inv_count;
-      double var = a2 * F.inv_count - mean * mean;
-      if (var < 0.0) var = 0.0;
-      o0 = (float)mean;
-      o1 = (float)(1.0 / sqrt(var + (double)F.eps));
-    } else {
-      o0 = (float)(a1 * F.inv_count);
-      o1 = (float)(a2 * F.inv_count);
-    }
-    F.out[((size_t)b * C + tid) * 2] = o0;
-    F.out[((size_t)b * C + tid) * 2 + 1] = o1;
-  }
-  if (tid == 0) __hip_atomic_store(&F.cnt[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();  // fin_red / fin_last are reused by the next tile of a persistent workgroup
+}
+
+// Tile-per-workgroup kernels (w2s_gp_stats, the Cin = 1 statistics kernels; grid (ntiles, B), 256 threads): workgroup (tile tl of sample b)
+// is row tl of its sample's ntiles rows; threads < 2C hold the row's values.  Reached by every thread of the workgroup.
+__device__ __forceinline__ void w2s_row_per_workgroup(const StatFin& F, int b, int tl, int ntiles, int C, float s) {
+  __shared__ __attribute__((aligned(16))) char fin_lds[256 * 16 + 16];
+  if ((int)threadIdx.x < 2 * C) w2s_row_store(F.rows + (((size_t)b * F.rows_cap + tl) * (2 * C) + threadIdx.x) * 2, (w2s_dd){(double)s, 0.0});
+  // (as a blocked partition: B * ntiles items over as many workgroups, this one is number b * ntiles + tl)
+  w2s_rows_tail(F, gridDim.y * ntiles, gridDim.y * ntiles, ntiles, b * ntiles + tl, b, b, C, 1, 256, fin_lds);
 }
 
 // sum over the 16 lanes that share (lane >> 4)  [row of the MFMA output fragment]
