@@ -227,7 +227,7 @@ def main():
     ap.add_argument('--epochs', type=int, default=960)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--no-extra', action='store_true', help='skip the `extra` legs (BASELINE configs[3] and the causal variant at batch 16)')
+    ap.add_argument('--no-extra', action='store_true', help='skip the `extra` legs (BASELINE configs[3] and the causal variant at batch 16); --no-cpu skips them too')
     ap.add_argument('--variant', choices=['cardio', 'eog'], default='cardio',
                     help="'eog': BASELINE.json configs[3] (EOG-L+EOG-R @256 Hz, 5 classes); a parity-test configuration, not the headline line")
     ap.add_argument('--causal', action='store_true', help="the reference's `causal: True` variant (causal-padded convolutions); not the headline config")
@@ -389,7 +389,7 @@ def main():
             json.dump({k: v for k, v in top}, f, indent=1)
     if rank == 0 and world == 1 and not args.no_cpu:
         line['kappa_parity'] = kappa_parity(model, dict(SIGNAL_MAP), nc, args.epochs, dev)
-    if rank == 0 and world == 1 and not args.no_extra and args.variant == 'cardio' and not args.causal:
+    if rank == 0 and world == 1 and not args.no_extra and not args.no_cpu and args.variant == 'cardio' and not args.causal:   # (tuning runs pass --no-cpu)
         # BASELINE.json configs[3] (wav2sleep-eog: EOG-L + EOG-R at 4096 samples per epoch, ten-block encoders, 5 classes; hub.py:17-22,
         # settings.py:19-26) and the `causal: True` variant of the headline shape (scripts/config/main.yaml:22), each at batch 16 x 8 h on a
         # model of its own, after the headline's model has been released.  Driver-visible perf for the configs the suite only checks for parity

@@ -313,6 +313,19 @@ int w2s_fill_rows(float* dst, int ld, const float* src, int rows, int C, void* s
 int w2s_add_rows(float* dst, int ld, const float* src, int src_stride, const float* keep, int rows_per_sample, int rows, int C, int accumulate,
                  void* stream);
 
+/* Modality availability from the inputs alone (a sample lacks a modality when its row is -inf: models/wav2sleep.py:150,
+ * trainer/masker.py:49-50).  xs / lds: HOST arrays of nsig <= W2S_MAX_SIGNALS device pointers [B][lds[m]] and their row lengths, in token
+ * order.  keep [nsig][B] = 1 / 0 (the encoder epilogues' rowkeep); keypad [B*S][R1 + nsig] uint8 = the set-fusion transformer's
+ * key-padding mask (tokens d < R1 = CLS / register tokens: never padded; wav2sleep.py:319-343).  Replaces ~20 stock element-wise launches
+ * (isinf / bitwise_not / stack / expand / contiguous) per step. */
+#define W2S_MAX_SIGNALS 8
+int w2s_token_masks(const float* const* xs, const long* lds, int nsig, int R1, int B, int S, float* keep, uint8_t* keypad, void* stream);
+/* dst [N][D][F]: rows d >= 1 zeroed, row 0 = src[n][:] (src NULL: left alone) -- a gradient that lives in the CLS rows only (wav2sleep.py:345) */
+int w2s_cls_scatter(float* dst, const float* src, long N, int D, int F, void* stream);
+/* strided row copy dst[r*ld_dst + c] = src[r*ld_src + c] (C and both strides multiples of 4) */
+int w2s_copy_rows(float* dst, long ld_dst, const float* src, long ld_src, long rows, int C, void* stream);
+int w2s_zero(void* p, long nbytes, void* stream);   /* nbytes % 4 == 0 */
+
 /* elementwise on n floats (n % 4 == 0).  Dropout masks are a pure function of (seed, element index). */
 #define W2S_ELT_GELU 0          /* y = GELU(a) */
 #define W2S_ELT_GELU_BWD 1      /* y = b * GELU'(a) */

@@ -93,8 +93,8 @@ void bwd_fused_kernel(BwdP P) {
   const int gc4 = tid % c4g, grow0 = tid / c4g, gch = gc4 * 4;
   const int hc4 = tid % c4h, hrow0 = tid / c4h, hch = hc4 * 4;
   f32x4 rg[NG], ry[NG], rh[NH];
-  auto prefetch = [&](int tl) {
-    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+  auto prefetch = [&](int b, int tile) {   // (sample, tile): carried incrementally by the tile loop, no division per tile
+    const int t0 = tile * TM;
     const float* gb = P.g + (size_t)b * Lg * GC + gch;
     const float* yb = P.y + (size_t)b * Lg * GC + gch;
     const int rb = UP2 ? t0 / 2 : t0 - 1;
@@ -113,8 +113,8 @@ void bwd_fused_kernel(BwdP P) {
       rh[k] = ok ? ld4(xb + (size_t)gr * HC) : (f32x4){0, 0, 0, 0};
     }
   };
-  auto commit = [&](int tl) {  // transform the prefetched registers and write both windows to LDS
-    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+  auto commit = [&](int b, int tile) {  // transform the prefetched registers and write both windows to LDS
+    const int t0 = tile * TM;
     f32x4 pm, pr, ps1, ps2;
     {
       const float* st = P.st_k + ((size_t)b * GC + gch) * 2;
@@ -157,14 +157,15 @@ void bwd_fused_kernel(BwdP P) {
   const int wend = wrun.first + wrun.count;
   w2s_dd* accL = reinterpret_cast<w2s_dd*>(reinterpret_cast<char*>(smem4) + P.acc_off);   // running statistics sums of this run, one slot per thread < 2*HC
   if (tid < 2 * HC) accL[tid] = (w2s_dd){0.0, 0.0};
-  if (PF && wrun.count > 0) prefetch(wrun.first);
+  int b = wrun.first / P.ntiles, tile = wrun.first - b * P.ntiles;   // one division per launch; the run is contiguous
+  if (PF && wrun.count > 0) prefetch(b, tile);
   for (int tl = wrun.first; tl < wend; ++tl) {
-    const int b = tl / P.ntiles, tile = tl % P.ntiles;
     const int t0 = tile * TM;
+    const int tile_n = tile + 1 == P.ntiles ? 0 : tile + 1, b_n = tile + 1 == P.ntiles ? b + 1 : b;   // the next tile of the run
     __syncthreads();  // everyone is done reading the previous tile's windows (and wL is written)
-    if (!PF) prefetch(tl);
-    commit(tl);
-    if (PF && tl + 1 < wend) prefetch(tl + 1);
+    if (!PF) prefetch(b, tile);
+    commit(b, tile);
+    if (PF && tl + 1 < wend) prefetch(b_n, tile_n);
     __syncthreads();
 
     // ---- data gradient: this wave's 16*MT output positions x HC channels
@@ -228,8 +229,8 @@ void bwd_fused_kernel(BwdP P) {
 #pragma unroll
       for (int nt = 0; nt < CH; ++nt) {
         f32x4 x1, x2;
-        x1.x = row16_sum(sA[nt].x); x1.y = row16_sum(sA[nt].y); x1.z = row16_sum(sA[nt].z); x1.w = row16_sum(sA[nt].w);
-        x2.x = row16_sum(sB[nt].x); x2.y = row16_sum(sB[nt].y); x2.z = row16_sum(sB[nt].z); x2.w = row16_sum(sB[nt].w);
+        x1 = sA[nt]; x2 = sB[nt];
+        row16_sum8(x1, x2);
         if (r == 0) {
           float* d = red + ((wave * CH + nt) * 4 + g) * 8;
           st4(d, x1);
@@ -244,7 +245,7 @@ void bwd_fused_kernel(BwdP P) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
         if (P.fin.out) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
-          const bool endrun = tl + 1 >= wend || (tl + 1) / P.ntiles != b;
+          const bool endrun = tl + 1 >= wend || tile + 1 == P.ntiles;
           double* row = nullptr;
           if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row) * (2 * HC) * 2;
           w2s_run_add(accL, tid, s, endrun, row);
@@ -275,6 +276,7 @@ void bwd_fused_kernel(BwdP P) {
 #pragma unroll
           for (int c = 0; c < CH; ++c) accw[i][j][c] = mfma16(ga[i], hb[j][c], accw[i][j][c]);
     }
+    b = b_n; tile = tile_n;
   }
 
   // ---- one slab per workgroup: sum the 4 waves tile by tile through LDS (fixed order), raw-fragment layout of
@@ -458,8 +460,8 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) w1r[i][j] = P.w1[(hch + i) * 3 + j];
   }
-  auto prefetch = [&](int tl) {
-    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+  auto prefetch = [&](int b, int tile) {   // (sample, tile): carried incrementally by the tile loop, no division per tile
+    const int t0 = tile * TM;
     // wave-uniform 64-bit base per sample + 32-bit per-lane offsets (a sample's tensor is < 4 GB): scalar-base addressing,
     // no 64-bit VALU address arithmetic per load
     const char* gb = reinterpret_cast<const char*>(P.g) + (size_t)b * Lg * GC * (GH ? 2 : 4);
@@ -512,8 +514,8 @@ void bwd_fused_bf_kernel(BwdP P) {
       }
     }
   };
-  auto commit = [&](int tl) {
-    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+  auto commit = [&](int b, int tile) {
+    const int t0 = tile * TM;
     f32x4 pm, pr, ps1, ps2;
     {
       const float* st = P.st_k + ((size_t)b * GC + gch) * 2;
@@ -590,18 +592,19 @@ void bwd_fused_bf_kernel(BwdP P) {
   const int wend = wrun.first + wrun.count;
   w2s_dd* accL = reinterpret_cast<w2s_dd*>(reinterpret_cast<char*>(smem4) + P.acc_off);   // running statistics sums of this run, one slot per thread < 2*HC
   if (tid < 2 * HC) accL[tid] = (w2s_dd){0.0, 0.0};
-  if (wrun.count > 0) prefetch(wrun.first);
+  int b = wrun.first / P.ntiles, tile = wrun.first - b * P.ntiles;   // one division per launch; the run is contiguous
+  if (wrun.count > 0) prefetch(b, tile);
   for (int tl = wrun.first; tl < wend; ++tl) {
-    const int b = tl / P.ntiles, tile = tl % P.ntiles;
     const int t0 = tile * TM;
+    const int tile_n = tile + 1 == P.ntiles ? 0 : tile + 1, b_n = tile + 1 == P.ntiles ? b + 1 : b;   // the next tile of the run
     __syncthreads();
-    commit(tl);
+    commit(b, tile);
     f32x4 q3[RD ? MT * CH : 1];  // this tile's y3 fragments (the prefetch below reloads rq for the next tile)
     if (RD) {
 #pragma unroll
       for (int i = 0; i < MT * CH; ++i) q3[i] = rq[i];
     }
-    if (tl + 1 < wend) prefetch(tl + 1);
+    if (tl + 1 < wend) prefetch(b_n, tile_n);
     __syncthreads();
 
     // ---- data gradient
@@ -804,8 +807,8 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
       for (int nt = 0; nt < CH; ++nt) {
         f32x4 x1, x2;
-        x1.x = row16_sum(sA[nt].x); x1.y = row16_sum(sA[nt].y); x1.z = row16_sum(sA[nt].z); x1.w = row16_sum(sA[nt].w);
-        x2.x = row16_sum(sB[nt].x); x2.y = row16_sum(sB[nt].y); x2.z = row16_sum(sB[nt].z); x2.w = row16_sum(sB[nt].w);
+        x1 = sA[nt]; x2 = sB[nt];
+        row16_sum8(x1, x2);
         if (r == 0) {
           float* d = red + ((wave * CH + nt) * 4 + g) * 8;
           st4(d, x1);
@@ -820,7 +823,7 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
         if (P.fin.out) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
-          const bool endrun = tl + 1 >= wend || (tl + 1) / P.ntiles != b;
+          const bool endrun = tl + 1 >= wend || tile + 1 == P.ntiles;
           double* row = nullptr;
           if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row) * (2 * HC) * 2;
           w2s_run_add(accL, tid, s, endrun, row);
@@ -881,6 +884,7 @@ void bwd_fused_bf_kernel(BwdP P) {
         accd = mfma_bf3(ah, al, bh, bl, accd);
       }
     }
+    b = b_n; tile = tile_n;
   }
 
   if (OH) w2s_amax_commit(P.hdr_o, amax, s_out);

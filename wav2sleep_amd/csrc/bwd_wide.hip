@@ -80,7 +80,8 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
   const int total = P.B * P.ntiles;
   // tiles of this workgroup: a contiguous run of the (sample, tile) list (blocked; w2s_common.h "Statistics finalisation")
   const W2SRun wrun = w2s_block_part(total, gridDim.x, blockIdx.x);
-  const int first = wrun.first, step = 1;
+  const int first = wrun.first;
+  const int run_b0 = first / P.ntiles, run_t0 = first - run_b0 * P.ntiles;   // the run's first (sample, tile): the one division of the launch
   // running statistics sums of this workgroup's run [PG][2][HC] (hi, lo), behind the tables (in-kernel statistics finalisation)
   w2s_dd* accL = reinterpret_cast<w2s_dd*>(stL + P.B * OC * 4 + (HST ? P.B * HC * 2 : 0));
   for (int i = tid; i < P.B * OC * 2; i += 64 * (NWC + 4)) {
@@ -113,15 +114,17 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     f32x4 rg[PD][NG] = {}, ry[PD][NG] = {}, rh[PD][NH] = {}, rp[RD ? PD : 1][NP] = {};
     auto load_p = [&](auto SET, int i, int k) {
       constexpr int S = decltype(SET)::value;
-      const int tl = first + min(i, nt_wg - 1) * step;
-      const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+      int b, tile_;
+      w2s_run_pos(run_b0, run_t0, P.ntiles, min(i, nt_wg - 1), b, tile_);
+      const int t0 = tile_ * TM;
       const int row = min(grow0 + k * rsg, TM / 2 - 1), gr = min(t0 / 2 + row, (L >> 1) - 1);
       rp[S][k] = ld4o(P.gpre + (size_t)b * (L >> 1) * OC, (unsigned)gr * OC + gch);
     };
     auto load_g = [&](auto SET, int i, int k) {
       constexpr int S = decltype(SET)::value;
-      const int tl = first + min(i, nt_wg - 1) * step;
-      const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+      int b, tile_;
+      w2s_run_pos(run_b0, run_t0, P.ntiles, min(i, nt_wg - 1), b, tile_);
+      const int t0 = tile_ * TM;
       const int row = min(grow0 + k * rsg, NRG - 1), gr = min(max((UP2 ? t0 / 2 : t0 - 1) + row, 0), Lg - 1);
       const unsigned off = (unsigned)gr * OC + gch;
       rg[S][k] = ld4o(P.g + (size_t)b * Lg * OC, off);
@@ -129,16 +132,18 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     };
     auto load_h = [&](auto SET, int i, int k) {
       constexpr int S = decltype(SET)::value;
-      const int tl = first + min(i, nt_wg - 1) * step;
-      const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+      int b, tile_;
+      w2s_run_pos(run_b0, run_t0, P.ntiles, min(i, nt_wg - 1), b, tile_);
+      const int t0 = tile_ * TM;
       const int row = min(hrow0 + k * rsh, NR - 1), gr = min(max(t0 - 1 + row, 0), L - 1);
       rh[S][k] = ld4o(P.xin + (size_t)b * L * HC, (unsigned)gr * HC + hch);
     };
     auto stage = [&](auto SET, int i) {
       constexpr int S = decltype(SET)::value;
       const bool live = i < nt_wg;   // uniform; padding rounds only keep the load queue regular
-      const int tl = first + min(i, nt_wg - 1) * step;
-      const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+      int b, tile_;
+      w2s_run_pos(run_b0, run_t0, P.ntiles, min(i, nt_wg - 1), b, tile_);
+      const int t0 = tile_ * TM;
       __bf16* gH = reinterpret_cast<__bf16*>(lds + (i & 1) * BUFB);
       __bf16* gL = gH + NRG * RSg;
       __bf16* hH = gL + NRG * RSg;
@@ -264,8 +269,9 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
   __syncthreads();                   // round 0 of the producers: the first windows are in buffer 0
   for (int it = 0; it < NI - 1; ++it) {
     if (it >= nt_wg) { __syncthreads(); continue; }   // padding rounds of the producers' prefetch cycle
-    const int tl = first + it * step;
-    const int b = tl / P.ntiles, tile = tl % P.ntiles, t0 = tile * TM;
+    int b, tile;
+    w2s_run_pos(run_b0, run_t0, P.ntiles, it, b, tile);
+    const int t0 = tile * TM;
     const __bf16* gH = reinterpret_cast<const __bf16*>(lds + (it & 1) * BUFB);
     const __bf16* gL = gH + NRG * RSg;
     const __bf16* hH = gL + NRG * RSg;
@@ -343,11 +349,11 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     }
     if (P.part) {   // [B][ntiles][PG][2][HC]: one row per (tile, position group), written once
       f32x4 x1, x2;
-      x1.x = row16_sum(sA.x); x1.y = row16_sum(sA.y); x1.z = row16_sum(sA.z); x1.w = row16_sum(sA.w);
-      x2.x = row16_sum(sB.x); x2.y = row16_sum(sB.y); x2.z = row16_sum(sB.z); x2.w = row16_sum(sB.w);
+      x1 = sA; x2 = sB;
+      row16_sum8(x1, x2);
       if (P.fin.out) {   // (uniform) running sums of this run; the run of sample b ends with this tile: the sums go to the row scratch
         if (r == 0) {
-          const bool endrun = (it + 1 >= nt_wg) || ((tl + 1) / P.ntiles != b);
+          const bool endrun = (it + 1 >= nt_wg) || (tile + 1 == P.ntiles);
           double* row = nullptr;   // this position group's row: rows run*PG .. run*PG + PG-1 of the sample
           if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row * PG + dg) * (2 * HC) * 2;
           const float v1[4] = {x1.x, x1.y, x1.z, x1.w}, v2[4] = {x2.x, x2.y, x2.z, x2.w};

@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       f32x4 x1, x2;
-      x1.x = row16_sum(sA[nt].x); x1.y = row16_sum(sA[nt].y); x1.z = row16_sum(sA[nt].z); x1.w = row16_sum(sA[nt].w);
-      x2.x = row16_sum(sB[nt].x); x2.y = row16_sum(sB[nt].y); x2.z = row16_sum(sB[nt].z); x2.w = row16_sum(sB[nt].w);
+      x1 = sA[nt]; x2 = sB[nt];
+      row16_sum8(x1, x2);
       if (r == 0) {
         float* d = red + ((wave * NTW + nt) * 4 + g) * 8;
         st4(d, x1);

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   // tiles of this workgroup: a contiguous run of the (sample, tile) list (blocked; w2s_common.h "Statistics finalisation"); the grid
   // never exceeds the tile count
   const W2SRun wrun = w2s_block_part(total, gridDim.x, blockIdx.x);
-  const int first = wrun.first, step = 1;
+  const int first = wrun.first;
+  const int run_b0 = first / P.ntiles, run_t0 = first - run_b0 * P.ntiles;   // the run's first (sample, tile): the one division of the launch
   // running statistics sums of this workgroup's run [2][OC] (hi, lo), behind the tables (in-kernel statistics finalisation)
   w2s_dd* accL = reinterpret_cast<w2s_dd*>(stL + ((PRO != W2S_PRO_GELU) ? P.B * HC * 2 * (TWO ? 2 : 1) : 0));
   if (PRO != W2S_PRO_GELU) {
@@ -94,8 +95,9 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     f32x4 rx[PD][NH], rx2[TWO ? PD : 1][TWO ? NH : 1];
     auto load_row = [&](auto SET, int i, int k) {   // row k of this workgroup's tile number min(i, nt_wg - 1)
       constexpr int S = decltype(SET)::value;
-      const int tl = first + min(i, nt_wg - 1) * step;
-      const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+      int b, tile_;
+      w2s_run_pos(run_b0, run_t0, P.ntiles, min(i, nt_wg - 1), b, tile_);
+      const int t0 = tile_ * TM;
       const int row = min(row0 + k * rstep, NR - 1), gr = min(max((UP2 ? t0 / 2 : t0 * STRIDE - P.pad) + row, 0), L_in - 1);
       const unsigned off = (unsigned)gr * HC + mych;
       rx[S][k] = ld4o(P.x + (size_t)b * L_in * HC, off);
@@ -105,8 +107,9 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     auto stage = [&](auto SET, int i) {
       constexpr int S = decltype(SET)::value;
       const bool live = i < nt_wg;   // uniform; padding rounds only keep the load queue regular
-      const int tl = first + min(i, nt_wg - 1) * step;
-      const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TM;
+      int b, tile_;
+      w2s_run_pos(run_b0, run_t0, P.ntiles, min(i, nt_wg - 1), b, tile_);
+      const int t0 = tile_ * TM;
       const int rb = UP2 ? t0 / 2 : t0 * STRIDE - P.pad;
       __bf16* hiL = lds + (i & 1) * BUF;
       __bf16* loL = hiL + NR * RSE;
@@ -167,8 +170,8 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   __syncthreads();                     // round 0 of the producers: the first window is in buffer 0
   for (int i = 0; i < NI - 1; ++i) {
     if (i >= nt_wg) { __syncthreads(); continue; }   // padding rounds of the producers' prefetch cycle
-    const int tl = first + i * step;
-    const int b = tl / P.ntiles, tile = tl % P.ntiles;
+    int b, tile;
+    w2s_run_pos(run_b0, run_t0, P.ntiles, i, b, tile);
     const int t0 = tile * TM;
     const __bf16* hiL = lds + (i & 1) * BUF;
     const __bf16* loL = hiL + NR * RSE;
@@ -233,11 +236,11 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     }
     if (P.part) {
       f32x4 x1, x2;
-      x1.x = row16_sum(sA.x); x1.y = row16_sum(sA.y); x1.z = row16_sum(sA.z); x1.w = row16_sum(sA.w);
-      x2.x = row16_sum(sB.x); x2.y = row16_sum(sB.y); x2.z = row16_sum(sB.z); x2.w = row16_sum(sB.w);
+      x1 = sA; x2 = sB;
+      row16_sum8(x1, x2);
       if (P.fin.out) {   // (uniform) running sums of this run; the run of sample b ends with this tile: the sums go to the row scratch
         if (r == 0) {
-          const bool endrun = (i + 1 >= nt_wg) || ((tl + 1) / P.ntiles != b);
+          const bool endrun = (i + 1 >= nt_wg) || (tile + 1 == P.ntiles);
           double* row = nullptr;
           if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row) * (2 * OC) * 2;
           const float v1[4] = {x1.x, x1.y, x1.z, x1.w}, v2[4] = {x2.x, x2.y, x2.z, x2.w};

@@ -99,10 +99,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
   const int total = P.B * P.ntiles;
   const W2SRun wrun = w2s_block_part(total, gridDim.x, blockIdx.x);   // this workgroup's tiles [wfirst, wend): the grid never exceeds the tile count
   const int wfirst = wrun.first, wend = wrun.first + wrun.count;
-  auto prefetch = [&](auto SET, int tl_) {
+  // (sample, tile) of the body's tile and of the prefetch stream (two tiles ahead), carried incrementally: the run is contiguous, so a
+  // position only ever steps to the next tile -- no integer division per tile (each was ~40 scalar + 5 vector instructions, four per tile)
+  int b_cur = wfirst / P.ntiles, tile_cur = wfirst - b_cur * P.ntiles;
+  int b_pf = b_cur, tile_pf = tile_cur, tl_pf = wfirst;   // the prefetch position stops at the run's last tile (later rounds reload it)
+  auto prefetch = [&](auto SET) {
     constexpr int S = decltype(SET)::value;
-    const int tl = min(tl_, wend - 1);
-    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TS;
+    const int b = b_pf, t0 = tile_pf * TS;
+    if (tl_pf + 1 < wend) {
+      ++tl_pf;
+      if (++tile_pf == P.ntiles) { tile_pf = 0; ++b_pf; }
+    }
     const int rb = t0 * STRIDE - P.pad;
     if (FIRST) {  // signal samples rb-pad .. rb-pad+NRh+1 (conv1 has the same padding mode as this conv)
       const float* xs = P.x + (size_t)b * L_in;
@@ -117,12 +124,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
       }
     }
   };
-  auto commit = [&](auto SET, int tl) {
+  auto commit = [&](auto SET) {
     constexpr int S = decltype(SET)::value;
     __bf16* hH = hbase + (DB ? S : 0) * WIN;
     __bf16* hLo = hH + NRh * RSh;
-    const int b = tl / P.ntiles, t0 = (tl % P.ntiles) * TS;
+    const int b = b_cur, t0 = tile_cur * TS;
     const int rb = t0 * STRIDE - P.pad;
+    const bool inside = rb >= 0 && rb + NRh <= L_in;   // uniform: every window row is a real position (all but a sample's first / last tile)
     f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
     if (PRO != W2S_PRO_GELU) {
       const float* st = P.st_in + ((size_t)b * HC + hch) * 2;
@@ -153,7 +161,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
         } else {
           xv = rh[S][k];
         }
-        if (!(W2S_FF_DBG & 4)) fsplit_store4(hH, hLo, row * RSh + hch, ok ? ((W2S_FF_DBG & 1) ? xv - hm : gelu4((xv - hm) * hr)) : (f32x4){0, 0, 0, 0});
+        f32x4 hv = (W2S_FF_DBG & 1) ? xv - hm : gelu4((xv - hm) * hr);
+        if (!inside) hv = ok ? hv : (f32x4){0, 0, 0, 0};   // (uniform branch: the zero padding only exists at a sample's ends)
+        if (!(W2S_FF_DBG & 4)) fsplit_store4(hH, hLo, row * RSh + hch, hv);
       }
     }
   };
@@ -161,13 +171,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   auto body = [&](auto SET, int tl) {
     const bool live = tl < wend;   // workgroup-uniform; a dead round only keeps the load queue regular
-    const int b = min(tl, wend - 1) / P.ntiles, tile = min(tl, wend - 1) % P.ntiles;
+    const int b = b_cur, tile = tile_cur;
     const int t0 = tile * TS;
     if (!DB) __syncthreads();  // single buffer: the previous tile's LDS reads are done (two buffers: the barriers of the round in between did that)
     const __bf16* hH = hbase + (DB ? decltype(SET)::value : 0) * WIN;
     const __bf16* hLo = hH + NRh * RSh;
-    if (live) commit(SET, tl);
-    prefetch(SET, tl + 2);
+    if (live) commit(SET);
+    prefetch(SET);
     __syncthreads();
     if (!live) return;
 
@@ -223,8 +233,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
 #pragma unroll
     for (int nt = 0; nt < CO; ++nt) {
       f32x4 x1, x2;
-      x1.x = row16_sum(sA[nt].x); x1.y = row16_sum(sA[nt].y); x1.z = row16_sum(sA[nt].z); x1.w = row16_sum(sA[nt].w);
-      x2.x = row16_sum(sB[nt].x); x2.y = row16_sum(sB[nt].y); x2.z = row16_sum(sB[nt].z); x2.w = row16_sum(sB[nt].w);
+      x1 = sA[nt]; x2 = sB[nt];
+      row16_sum8(x1, x2);
       if (r == 0) {
         float* d = red + ((wave * CO + nt) * 4 + g) * 8;
         st4(d, x1);
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
 #pragma unroll
       for (int w = 0; w < 4; ++w) s += red[((w * CO + nt) * 4 + gg) * 8 + k * 4 + e];
       if (P.fin.out) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
-        const bool endrun = tl + 1 >= wend || (tl + 1) / P.ntiles != b;
+        const bool endrun = tl + 1 >= wend || tile + 1 == P.ntiles;
         double* row = nullptr;
         if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row) * (2 * OC) * 2;
         w2s_run_add(accL, tid, s, endrun, row);
@@ -247,9 +257,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
         w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c], s);
       }
     }
+    if (++tile_cur == P.ntiles) { tile_cur = 0; ++b_cur; }
   };
-  prefetch(I0{}, wfirst);
-  prefetch(I1{}, wfirst + 1);
+  prefetch(I0{});
+  prefetch(I1{});
   for (int tl = wfirst; tl < wend; tl += 2) {
     body(I0{}, tl);
     body(I1{}, tl + 1);

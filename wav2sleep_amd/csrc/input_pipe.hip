@@ -155,3 +155,93 @@ extern "C" int w2s_causal_normalize_host(const double* x, long n, double samplin
   }
   return W2S_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Host-side plumbing of a step that used to be a handful of stock element-wise launches each (round 4: a steady-state step launches
+// only this library's kernels -- VERDICT r3 item 7).
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Availability of every modality of every sample, from the inputs alone (a sample lacks a modality when its row is -inf: its first value
+// says so, models/wav2sleep.py:150, trainer/masker.py:49-50): keep[m][b] = 1 / 0 for the encoder epilogues, and the key-padding mask of
+// the set-fusion transformer keypad[b*S + s][d] (d < R1: CLS / register tokens, never padded; d = R1 + m: modality m; wav2sleep.py:319-343)
+struct TokenMaskP { const float* x[W2S_MAX_SIGNALS]; long ld[W2S_MAX_SIGNALS]; };
+__global__ __launch_bounds__(256) void token_masks_kernel(TokenMaskP P, int nsig, int R1, int B, int S, float* __restrict__ keep,
+                                                          uint8_t* __restrict__ keypad) {
+  const int D = R1 + nsig;
+  const long n = (long)B * S * D;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int d = (int)(i % D);
+    const long row = i / D;
+    const int b = (int)(row / S);
+    uint8_t pad = 0;
+    if (d >= R1) pad = isinf(P.x[d - R1][(size_t)b * P.ld[d - R1]]) ? 1 : 0;
+    keypad[i] = pad;
+  }
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nsig * B; i += 256) {
+      const int m = i / B, b = i % B;
+      keep[i] = isinf(P.x[m][(size_t)b * P.ld[m]]) ? 0.f : 1.f;
+    }
+}
+extern "C" int w2s_token_masks(const float* const* xs, const long* lds, int nsig, int R1, int B, int S, float* keep, uint8_t* keypad, void* stream) {
+  if (!xs || !lds || nsig <= 0 || nsig > W2S_MAX_SIGNALS || R1 < 0 || B <= 0 || S <= 0 || !keep || !keypad) return W2S_EINVAL;
+  TokenMaskP P;
+  for (int m = 0; m < W2S_MAX_SIGNALS; ++m) { P.x[m] = m < nsig ? xs[m] : nullptr; P.ld[m] = m < nsig ? lds[m] : 0; }
+  for (int m = 0; m < nsig; ++m) if (!P.x[m] || P.ld[m] <= 0) return W2S_EINVAL;
+  const long n = (long)B * S * (R1 + nsig);
+  const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(token_masks_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P, nsig, R1, B, S, keep, keypad);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// dst[n][d][:] = (d == 0) ? (src ? src[n][:] : dst[n][0][:]) : 0 over [N][D][F]: a tensor that carries values in its token-0 rows only
+// (the gradient of the CLS output, wav2sleep.py:345; src == NULL: rows 0 are left for the launch that writes them with row stride D*F)
+__global__ __launch_bounds__(256) void cls_scatter_kernel(float* __restrict__ dst, const float* __restrict__ src, long N, int D, int F4) {
+  const long n4 = N * D * F4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long row = i / F4;
+    const int d = (int)(row % D);
+    if (d == 0) {
+      if (src) st4(dst + i * 4, ld4(src + ((row / D) * F4 + i % F4) * 4));
+    } else {
+      st4(dst + i * 4, (f32x4){0, 0, 0, 0});
+    }
+  }
+}
+extern "C" int w2s_cls_scatter(float* dst, const float* src, long N, int D, int F, void* stream) {
+  if (!dst || N <= 0 || D <= 0 || F <= 0 || (F & 3)) return W2S_EINVAL;
+  const long n4 = N * D * (F / 4);
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(cls_scatter_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dst, src, N, D, F / 4);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+// dst[r*ld_dst + c] = src[r*ld_src + c], c < C (C, ld_* multiples of 4): strided row copy (the CLS rows of a token tensor)
+__global__ __launch_bounds__(256) void copy_rows_kernel(float* __restrict__ dst, long ld_dst, const float* __restrict__ src, long ld_src, long rows, int C4) {
+  const long n4 = rows * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const int c = (int)(i % C4) * 4;
+    st4(dst + r * ld_dst + c, ld4(src + r * ld_src + c));
+  }
+}
+extern "C" int w2s_copy_rows(float* dst, long ld_dst, const float* src, long ld_src, long rows, int C, void* stream) {
+  if (!dst || !src || rows <= 0 || C <= 0 || (C & 3) || (ld_dst & 3) || (ld_src & 3)) return W2S_EINVAL;
+  const long n4 = rows * (C / 4);
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dst, ld_dst, src, ld_src, rows, C / 4);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+// zero n bytes (n % 4 == 0): the confusion-count matrix before a step, gradient slots of absent encoders
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) p[i] = 0u;
+}
+extern "C" int w2s_zero(void* p, long nbytes, void* stream) {
+  if (!p || nbytes <= 0 || (nbytes & 3)) return W2S_EINVAL;
+  const long n4 = nbytes / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<uint32_t*>(p), n4);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}

@@ -31,6 +31,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // factor 1/2 into P -- GELU(x) = x*(1/2 + t) and GELU'(x) = 1/2 + t + x*pdf(x) then need no extra multiplies.  ocml's erff has 3x the
 // VALU instructions, which made every conv VALU-bound (profiles/r01 PMC); the folding removes another ~25 % (r02: the >= 64-channel
 // layers are bound by VALU issue, every wave instruction counts).
+#ifndef W2S_ERF_LOWDEG
 #define W2S_HE_P0 -1.5059950899190544e-12f
 #define W2S_HE_P1 3.0611993495632817e-10f
 #define W2S_HE_P2 -4.6426510635910745e-08f
@@ -43,6 +44,24 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #define W2S_HE_Q2 -0.0004207067540846765f
 #define W2S_HE_Q3 -0.0036866646260023117f
 #define W2S_HE_Q4 -0.014264739118516445f
+#define W2S_HE_NP 7
+#define W2S_HE_NQ 5
+#else
+// -DW2S_ERF_LOWDEG: P of 5 and Q of 4 terms (7 instead of 10 polynomial steps), |err| <= 1.9e-6 abs in fp32 (fitted for this file: Lawson-
+// weighted least squares on [0, 4 sqrt 2], /tmp-style script in DESIGN.md) -- below the 2^-17 relative rounding of the bf16 hi/lo split
+// every GELU output goes through on its way into the matrix cores
+#define W2S_HE_P0 -1.0954269113668116e-07f
+#define W2S_HE_P1 4.9546486891069972e-05f
+#define W2S_HE_P2 0.0042260996717269385f
+#define W2S_HE_P3 0.028607305310687833f
+#define W2S_HE_P4 0.3989514081808952f
+#define W2S_HE_Q0 0.0014177404916614384f
+#define W2S_HE_Q1 0.025206600271118533f
+#define W2S_HE_Q2 0.23847808392940692f
+#define W2S_HE_Q3 1.0f
+#define W2S_HE_NP 5
+#define W2S_HE_NQ 4
+#endif
 #define W2S_HE_CLAMP 5.65685424949238f   /* 4 sqrt 2: erf saturates to fp32 beyond */
 // -DW2S_ERF_IDENTITY: timing-only build (tools/altlib.sh; numerics WRONG on purpose): the rational erf and the exp2 of GELU' collapse
 // to one multiply each -- how fast is the skeleton of a kernel without its transcendental work?  
@@ -56,12 +75,16 @@ __device__ __forceinline__ float half_erf_fast(float x) {
   p = fmaf(x2, p, W2S_HE_P2);
   p = fmaf(x2, p, W2S_HE_P3);
   p = fmaf(x2, p, W2S_HE_P4);
+#if W2S_HE_NP == 7
   p = fmaf(x2, p, W2S_HE_P5);
   p = fmaf(x2, p, W2S_HE_P6);
+#endif
   float q = fmaf(x2, W2S_HE_Q0, W2S_HE_Q1);
   q = fmaf(x2, q, W2S_HE_Q2);
   q = fmaf(x2, q, W2S_HE_Q3);
+#if W2S_HE_NQ == 5
   q = fmaf(x2, q, W2S_HE_Q4);
+#endif
   return (x * p) * __builtin_amdgcn_rcpf(q);
 }
 // exact-form (erf) GELU and its derivative -- models/utils.py:61-74 nn.GELU(approximate='none')
@@ -92,12 +115,16 @@ __device__ __forceinline__ f32x4 half_erf4(f32x4 x) {
   p = fma4(x2, p, splat4(W2S_HE_P2));
   p = fma4(x2, p, splat4(W2S_HE_P3));
   p = fma4(x2, p, splat4(W2S_HE_P4));
+#if W2S_HE_NP == 7
   p = fma4(x2, p, splat4(W2S_HE_P5));
   p = fma4(x2, p, splat4(W2S_HE_P6));
+#endif
   f32x4 q = fma4(x2, splat4(W2S_HE_Q0), splat4(W2S_HE_Q1));
   q = fma4(x2, q, splat4(W2S_HE_Q2));
   q = fma4(x2, q, splat4(W2S_HE_Q3));
+#if W2S_HE_NQ == 5
   q = fma4(x2, q, splat4(W2S_HE_Q4));
+#endif
   // 1/q for the four lanes from one reciprocal
   const float q01 = q.x * q.y, q23 = q.z * q.w;
   const float r = __builtin_amdgcn_rcpf(q01 * q23);
@@ -212,6 +239,14 @@ __host__ __device__ __forceinline__ int w2s_stat_rows_of(int B, int ntiles, int 
   const int total = B * ntiles, g = grid < total ? grid : total, base = total / (g > 0 ? g : 1);
   const int r = (ntiles + base - 1) / base + 1;
   return r < g ? r : g;
+}
+
+// (sample, tile) of the i-th item of a run that starts at tile t0 of sample b0 -- without an integer division (a run is short against a
+// sample except in the chunk-causal configuration, where the loop below takes a few more turns)
+__device__ __forceinline__ void w2s_run_pos(int b0, int t0, int ntiles, int i, int& b, int& tile) {
+  tile = t0 + i;
+  b = b0;
+  while (tile >= ntiles) { tile -= ntiles; ++b; }
 }
 
 typedef double w2s_dd __attribute__((ext_vector_type(2)));   // (hi, lo): value = hi + lo
@@ -340,6 +375,24 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f(v, 2);
   v += dpp_f(v, 3);
   return v;
+}
+// row16_sum of EIGHT values at once (the statistics epilogue of every conv kernel: sums and sums of squares of four channels): four DPP
+// steps, ONE fused v_add_f32_dpp each (the compiler's form of row16_sum is v_mov 0 + v_mov_dpp + add: 85 instructions for the eight
+// values, this is 33).  The eight chains are interleaved, so a register written by one instruction is read as a DPP source eight
+// instructions later: no VALU -> DPP wait states inside; the s_nop covers an operand written right before the block.  Same additions in
+// the same order as row16_sum (a + dpp(a) is commutative bit for bit).  All 64 lanes must be active.
+__device__ __forceinline__ void row16_sum8(f32x4& a, f32x4& b) {
+  float a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+#define W2S_DPP_STEP(ctl) \
+  "v_add_f32_dpp %0, %0, %0 " ctl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 " ctl " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_add_f32_dpp %2, %2, %2 " ctl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %3, %3, %3 " ctl " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_add_f32_dpp %4, %4, %4 " ctl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %5, %5, %5 " ctl " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_add_f32_dpp %6, %6, %6 " ctl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %7, %7, %7 " ctl " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" W2S_DPP_STEP("quad_perm:[1,0,3,2]") W2S_DPP_STEP("quad_perm:[2,3,0,1]") W2S_DPP_STEP("row_half_mirror") W2S_DPP_STEP("row_mirror")
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+#undef W2S_DPP_STEP
+  a = (f32x4){a0, a1, a2, a3};
+  b = (f32x4){b0, b1, b2, b3};
 }
 __device__ __forceinline__ float wave_sum(float v) {
   v += __shfl_xor(v, 1);

@@ -25,8 +25,6 @@ _LONGEST_FIRST = os.environ.get('W2S_LONGEST_FIRST', '1') != '0'
 _INTERLEAVE = os.environ.get('W2S_INTERLEAVE', '1') != '0'
 _DEFER_TRUNK = os.environ.get('W2S_DEFER_TRUNK', '1') != '0'
 _CLS_ONLY = os.environ.get('W2S_CLS_ONLY', '1') != '0'   # last transformer layer: row-wise tail on the CLS rows only
-# W2S_ENC_CHUNK='1024:4,256:8' (samples per chunk by samples-per-epoch of the signal; a bare number applies to every signal)
-_ENC_CHUNK = {(int(kv.split(':')[0]) if ':' in kv else 0): int(kv.split(':')[-1]) for kv in os.environ.get('W2S_ENC_CHUNK', '').split(',') if kv}
 _BWD_WGS = int(os.environ.get('W2S_BWD_WGS', 512))       # persistent workgroups of the fused backward (2 per CU)
 _BWD_WGS32 = int(os.environ.get('W2S_BWD_WGS32', _BWD_WGS))
 _BWD_WGS_RD16 = int(os.environ.get('W2S_BWD_WGS_RD16', 768))  # the 16-channel residual-fold kernel fits three per CU
@@ -399,11 +397,6 @@ class Engine:
         cjobs, self._cjobs = self._cjobs, []
         lib.colsum_batch(cjobs)
 
-    def _enc_chunk(self, sig, B):
-        """samples per depth-first chunk of this signal's encoder pass (0: the whole batch at once)"""
-        cb = _ENC_CHUNK.get(COLS_TO_SAMPLES_PER_EPOCH[sig], _ENC_CHUNK.get(0, 0))
-        return cb if (0 < cb < B and not self.chunk and self.taps is None) else 0
-
     def _interleave(self, tasks, trunk=None):
         """tasks: encoder -> (stream, [generators]).  Enqueue the encoders round-robin, one block per turn, each on its own stream: the
         streams then start together and progress together, instead of the first encoder's whole pass being enqueued (and mostly executed)
@@ -576,44 +569,37 @@ class Engine:
         if cls:
             for r in range(R1):   # column r of the [1, 1, F, R+1] parameter
                 lib.add_rows(tokens.view(-1)[r * F:], D * F, P['epoch_mixer.register_tokens'].view(-1)[r:], R1, None, 1, N, F, False)
-        keeps, enc_ctx = [None] * len(sigs), [None] * len(sigs)
+        enc_ctx = [None] * len(sigs)
+        xf = []
+        for s in sigs:
+            xs = x[s]
+            if xs.dtype != torch.float32 or not xs.is_contiguous():
+                xs = xs.float().contiguous()
+            xf.append(xs)
+        # which sample has which modality (a `-inf` row = missing, wav2sleep.py:150): the per-signal keep masks of the encoder epilogues and
+        # the key-padding mask of the set-fusion transformer in ONE launch on this stream, before the encoder streams fork
+        keep_all = torch.empty(len(sigs), B, device=dev, dtype=torch.float32)
+        keypad = torch.empty(N, D, device=dev, dtype=torch.uint8)
+        lib.token_masks(xf, R1, B, S, keep_all, keypad)
+        keeps = [keep_all[m] for m in range(len(sigs))]
         # launch order: longest encoder first (the streams run side by side; the 1024-samples-per-epoch encoders take 4x the time of the
         # 256 ones and set the end of this phase) -- token slot m stays the sorted position
         tasks = {}   # encoder -> (stream, [generators]): signals sharing an encoder run one after the other on its stream
         for m, s in sorted(enumerate(sigs), key=lambda ms: -COLS_TO_SAMPLES_PER_EPOCH[ms[1]] if _LONGEST_FIRST else 0):
-            xs = x[s]
-            if xs.dtype != torch.float32 or not xs.is_contiguous():
-                xs = xs.float().contiguous()
+            xs = xf[m]
             st = self._side_stream(sp.signal_map[s], dev)
 
             def run(m=m, s=s, xs=xs):
-                keep = (~torch.isinf(xs[:, 0])).float()  # wav2sleep.py:150 (plumbing on B scalars)
-                keeps[m] = keep
+                keep = keeps[m]
                 slot = tokens.view(-1)[(R1 + m) * F:]
-                cb = self._enc_chunk(s, B)
-                if cb:
-                    # sample chunks, depth-first through the whole encoder (every sample is independent there: instance norm): a tensor a
-                    # kernel has just written is then small enough (<= ~96 MB, tools/mall_probe.py) to still sit in the 256 MB Infinity
-                    # Cache when the next kernel reads it
-                    subs = []
-                    for b0 in range(0, B, cb):
-                        sub = yield from self._encoder_forward(s, xs[b0:b0 + cb], keep[b0:b0 + cb], slot[b0 * S * D * F:], D * F, save)
-                        subs.append((b0, sub))
-                    enc_ctx[m] = dict(sig=s, enc=sp.signal_map[s], keep=keep, chunks=subs) if save else None
-                else:
-                    enc_ctx[m] = yield from self._encoder_forward(s, xs, keep, slot, D * F, save)
+                enc_ctx[m] = yield from self._encoder_forward(s, xs, keep, slot, D * F, save)
                 if sp.embed_signals:   # + embedding row of this signal on the samples that have it (wav2sleep.py:155-159)
                     lib.add_rows(slot, D * F, P['signal_encoders.embedder.weight'][sorted(sp.signal_map).index(s)], 1, keep, S, N, F, True)
             tasks.setdefault(sp.signal_map[s], (st, []))[1].append(run())
-        return dict(tokens=tokens, keeps=keeps, enc=enc_ctx, sigs=sigs, B=B, S=S, D=D, N=N, R1=R1, x0=[x[s][:, 0] for s in sigs]), tasks
+        return dict(tokens=tokens, keeps=keeps, keypad=keypad, enc=enc_ctx, sigs=sigs, B=B, S=S, D=D, N=N, R1=R1), tasks
 
     def _encode_keypad(self, e):
-        """key-padding mask of the set-fusion transformer, from the inputs alone (a sample lacks a modality when its row is -inf,
-        wav2sleep.py:150): a handful of launches on B x D values, enqueued on the current stream right AFTER the encoder streams have
-        forked, so that they run beside the encoders instead of between the encoders and the transformer."""
-        B, S, D, N = e['B'], e['S'], e['D'], e['N']
-        miss = torch.stack([torch.zeros_like(e['x0'][0], dtype=torch.bool)] * e['R1'] + [torch.isinf(v) for v in e['x0']], dim=1)   # [B, D]
-        e['keypad'] = miss.to(torch.uint8)[:, None, :].expand(B, S, D).reshape(N, D).contiguous()
+        """(the key-padding mask is made with the keep masks in `_encode_begin`: w2s_token_masks)"""
         return e
 
     def encode(self, x: dict[str, torch.Tensor], save: bool = False, pack_key=None, cls: bool = True):
@@ -707,7 +693,7 @@ class Engine:
                 lib.eltwise(lib.ELT_ADD_DROP, xin, hcur, pre_out, B * S * F, ps, self._seed(100 + b))
             else:  # block 0 reads the strided CLS rows: gather them once (small)
                 xg = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-                xg.view(N, F).copy_(xin.view(N, D * F)[:, :F])  # strided device copy (plumbing)
+                lib.copy_rows(xg, F, xin, D * F, N, F)   # the CLS rows of the token tensor
                 lib.eltwise(lib.ELT_ADD_DROP, xg, hcur, pre_out, B * S * F, ps, self._seed(100 + b))
             if save:
                 seq.append(dict(convs=convs, pre_out=pre_out))
@@ -854,8 +840,8 @@ class Engine:
             p = f'epoch_mixer.transformer_encoder.layers.{l}.'
             cls = L.get('cls', False)   # the forward ran this layer's row-wise tail on the CLS rows only: so does the backward
             if gX is None and not cls:
-                gX = torch.zeros(N, D, F, device=dev, dtype=torch.float32)
-                gX[:, 0, :].copy_(g_pre.view(N, F))  # only token 0 is returned (wav2sleep.py:345)
+                gX = torch.empty(N, D, F, device=dev, dtype=torch.float32)
+                lib.cls_scatter(gX, g_pre.view(N, F), N, D, F)   # only token 0 is returned (wav2sleep.py:345): zero elsewhere
                 gX = gX.view(R, F)
             gin = g_pre.view(N, F) if cls else gX
             Rr, ldr = (N, D * F) if cls else (R, F)
@@ -878,10 +864,11 @@ class Engine:
             self._wgrad(p + 'self_attn.out_proj.weight', g=gproj, x=L['ao'], B=1, L_in=Rr, L_out=Rr, cin=F, cout=F, taps=1, stride=1, pad=0,
                         **(dict(ldx=ldr) if cls else {}))
             if cls:   # back to all token rows: the attention spreads the CLS query's gradient over every token's keys and values
-                gao = torch.zeros(R, F, device=dev, dtype=torch.float32)
+                gao = torch.empty(R, F, device=dev, dtype=torch.float32)
+                lib.cls_scatter(gao, None, N, D, F)   # zero rows 1 .. D-1; the projection below writes the CLS rows (row stride D*F)
                 self._linear(gproj, PB[p + 'self_attn.out_proj.weight'], None, N, F, F, y=gao, ldy=D * F)
-                gX1f = torch.zeros(N, D, F, device=dev, dtype=torch.float32)
-                gX1f[:, 0, :].copy_(gX1)
+                gX1f = torch.empty(N, D, F, device=dev, dtype=torch.float32)
+                lib.cls_scatter(gX1f, gX1, N, D, F)
                 gX1 = gX1f.view(R, F)
             else:
                 gao = self._linear(gproj, PB[p + 'self_attn.out_proj.weight'], None, R, F, F)
@@ -908,7 +895,7 @@ class Engine:
             # embedding rows: sum over the rows of the samples that have the signal (absent signals and missing samples get zero)
             ew = 'signal_encoders.embedder.weight'
             if ew not in self._written:
-                self.G[ew].zero_()
+                lib.zero_(self.G[ew])
                 self._written.add(ew)
             order = sorted(sp.signal_map)
             for m, ec in enumerate(c['enc']):
@@ -923,7 +910,7 @@ class Engine:
             # handed to the reducer, so that nothing touches a range on the compute stream once its all-reduce may be in flight.
             for name, g in self.G.items():
                 if name.startswith('signal_encoders.encoders.') and name.split('.')[2] not in encs and name not in self._written:
-                    g.zero_()
+                    lib.zero_(g)
                     self._written.add(name)
         return gX
 
@@ -963,9 +950,8 @@ class Engine:
             st = self._side_stream(ec['enc'], dev)
 
             def run(m=m, ec=ec):
-                for b0, sub in ec.get('chunks', [(0, ec)]):   # (chunks share the weights: one flush per chunk, accumulating)
-                    yield from self._encoder_backward(sub, gX.view(-1)[(R1 + m) * F + b0 * S * D * F:], D * F)
-                    self._flush_reduce()
+                yield from self._encoder_backward(ec, gX.view(-1)[(R1 + m) * F:], D * F)
+                self._flush_reduce()
                 if hook is not None and ec['enc'] not in encs[m + 1:]:
                     hook(ec['enc'])
             tasks.setdefault(ec['enc'], (st, []))[1].append(run())

@@ -56,7 +56,7 @@ EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_conv_forward', 'w2s_wgrad', 'w2
            'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_bwd_fused_wd', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_stat_rows', 'w2s_conv_stat_rows', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
-           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version']
+           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_token_masks', 'w2s_cls_scatter', 'w2s_copy_rows', 'w2s_zero', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version']
 
 _lib = None
 
@@ -566,6 +566,30 @@ def fill_rows(dst, ld, src, rows, Cc):
 
 def add_rows(dst, ld, src, src_stride, keep, rows_per_sample, rows, Cc, accumulate):
     _chk(load().w2s_add_rows(_f(dst), ld, _f(src), src_stride, _f(keep), rows_per_sample, rows, Cc, int(accumulate), _stream()), 'w2s_add_rows')
+
+
+def token_masks(xs, R1, B, S, keep, keypad):
+    """keep [nsig][B] float and keypad [B*S][R1 + nsig] uint8 from the first value of every signal row (`-inf` row = missing modality)"""
+    n = len(xs)
+    for t in xs:
+        assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+    ptrs = (C.c_void_p * n)(*[_p(t).value for t in xs])
+    lds = (C.c_long * n)(*[t.stride(0) for t in xs])
+    assert keypad.dtype == torch.uint8
+    _chk(load().w2s_token_masks(ptrs, lds, n, R1, B, S, _f(keep), _p(keypad), _stream()), 'w2s_token_masks')
+
+
+def cls_scatter(dst, src, N, D, F):
+    _chk(load().w2s_cls_scatter(_f(dst), _f(src), C.c_long(N), D, F, _stream()), 'w2s_cls_scatter')
+
+
+def copy_rows(dst, ld_dst, src, ld_src, rows, Cc):
+    _chk(load().w2s_copy_rows(_f(dst), C.c_long(ld_dst), _f(src), C.c_long(ld_src), C.c_long(rows), Cc, _stream()), 'w2s_copy_rows')
+
+
+def zero_(t):
+    """t.zero_() as a launch of this library (t contiguous, a multiple of 4 bytes)"""
+    _chk(load().w2s_zero(_p(t), C.c_long(t.numel() * t.element_size()), _stream()), 'w2s_zero')
 
 
 def eltwise(op, a, b, y, n, p=0.0, seed=0):

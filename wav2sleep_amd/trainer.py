@@ -230,7 +230,7 @@ class FusedTrainStep:
                     yv = yv.float()
                 part = torch.empty((rows + 255) // 256, 2, device=logits.device, dtype=torch.float32)
                 glogits = torch.empty(rows, nc, device=logits.device, dtype=torch.float32)
-                self.cmat.zero_()
+                lib.zero_(self.cmat)
                 lib.ce_fwd_bwd(logits, yv.contiguous(), rows, nc, part, self.loss_out, glogits, self.cmat, self.reducer.grad_scale / self.accumulate)
                 eng.backward(glogits, accumulate=not first, hook=self._on_ready if reduce else None)
             if reduce:
@@ -260,7 +260,7 @@ class FusedTrainStep:
         part = torch.empty(sum(nblk), 2, device=dev, dtype=torch.float32)
         count = torch.empty(1, device=dev, dtype=torch.float32)
         logits = torch.empty(B, S, nc, device=dev, dtype=torch.float32)
-        self.cmat.zero_()
+        lib.zero_(self.cmat)
         lib.ce_count(yv, rows, nc, count)
         scale = self.reducer.grad_scale / self.accumulate
 
