@@ -29,7 +29,12 @@ MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak
 
 
 def pmc_key(name):
-    """rocprofv3 kernel name -> the LaunchTimer key (conv_wide: <CI, NW, NP, STRIDE, PRO, EPI, MT, PD> -> <CI, NW, STRIDE, PRO, EPI>)."""
+    """rocprofv3 kernel name -> the LaunchTimer key (conv_wide: <CI, NW, NP, STRIDE, PRO, EPI, MT, PD> -> <CI, NW, STRIDE, PRO, EPI>).
+    Since round 4 the four persistent statistics producers carry a trailing FIN template argument (1: the instantiation with the in-kernel
+    statistics finalisation); the keys do not."""
+    m = re.match(r'(conv_fwd_bf|bwd_fused_bf|bwd_fused|conv_wide|bwd_wide)_kernel<(.*), [01]>$', name)
+    if m and m[2].count(',') + 2 == {'conv_fwd_bf': 6, 'bwd_fused_bf': 8, 'bwd_fused': 6, 'conv_wide': 11, 'bwd_wide': 11}[m[1]]:   # (names of this round: drop FIN)
+        name = f'{m[1]}_kernel<{m[2]}>'
     m = re.match(r'conv_wide_kernel<(\d+), (\d+), \d+, (\d+), (\d+), (\d+), .*>', name)   # <CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ>
     if m:
         return f'conv_wide_kernel<{m[1]}, {m[2]}, {m[3]}, {m[4]}, {m[5]}>'

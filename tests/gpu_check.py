@@ -476,7 +476,10 @@ def t_fused_split_precision():
                 lib.wgrad_reduce(slab, ns, grad, cg, ch, 3, 1, accumulate=False, layout=0)
                 outs.append((gout, part, grad))
             for nm, a, b in zip(('gout', 'part', 'wgrad'), outs[1], outs[0]):
-                report(f'fused bf16x3 {cg}->{ch} s{stride} L{Lh} {nm}', a, b, tol=2e-4)
+                # 32 input-side channels (round 4): the kernel keeps n of the tile in an fp16 LDS plane (the GELU' plane stays fp32): the
+                # per-tile sums of gout * n carry 2^-11 of sum |gout * n| -- a per-tile bar of 5e-4 of the scale; the finalised statistics
+                # average it over thousands of tiles (full-size gradient checks: unchanged 4.3e-4 / 8.3e-4 worst tensor)
+                report(f'fused bf16x3 {cg}->{ch} s{stride} L{Lh} {nm}', a, b, tol=5e-4 if (nm == 'part' and ch == 32) else 2e-4)
 
 def t_fused_residual_fold():
     """conv1 fused backward with the residual branch folded in vs (1x1 conv + add_even) and the separate downsample wgrad."""
@@ -569,8 +572,7 @@ def t_bwd_wide():
     B = 3
     for (cg, ch, L, hst, add_even, stride) in [(64, 64, 1000, True, False, 1), (64, 64, 777, False, True, 1), (64, 32, 500, False, True, 1), (64, 64, 64, True, False, 1),
                                                (64, 32, 130, False, True, 1), (64, 64, 4098, True, False, 1), (64, 32, 2050, True, False, 1),
-                                               (64, 64, 1000, True, False, 2), (64, 64, 64, True, False, 2), (64, 64, 4098, True, False, 2), (64, 64, 130, True, False, 2),
-                                               (32, 32, 1000, True, False, 1), (32, 32, 130, False, True, 1), (32, 32, 4098, True, False, 1), (32, 32, 2050, False, True, 1)]:   # (W2S_BWD_WIDE32: vs the generic kernels)
+                                               (64, 64, 1000, True, False, 2), (64, 64, 64, True, False, 2), (64, 64, 4098, True, False, 2), (64, 64, 130, True, False, 2)]:
         Lg = L // stride
         g = torch.randn(B, Lg, cg, device=dev) * 0.1; y = torch.randn(B, Lg, cg, device=dev) * 2 + 0.2; x = torch.randn(B, L, ch, device=dev) * 1.3 - 0.1
         st = torch.stack([torch.randn(B, cg, device=dev) * 0.1, torch.rand(B, cg, device=dev) + 0.5], dim=-1).contiguous()
@@ -580,21 +582,15 @@ def t_bwd_wide():
         w = torch.randn(cg, ch, 3) / math.sqrt(3 * ch)
         wb = w.permute(1, 2, 0).contiguous().to(dev); wh, wl = lib.frag_major_planes(wb.view(ch, 3 * cg))
         pro_g = lib.PRO_INBWD if stride == 1 else lib.PRO_INBWD_GP
-        # the separate kernels (32 channels: the fused <= 32-channel kernel is the reference arm)
+        # the separate kernels
         gout0 = torch.zeros(B, L, ch, device=dev)
-        if cg == 32:
-            t0 = lib.bwd_fused_tile(cg, ch, 1); nt0 = (L + t0 - 1) // t0; ns0 = min(5, B * nt0)
-            part0 = torch.zeros(B, nt0, 2, ch, device=dev); slab0 = torch.zeros(ns0 * cg * ch * 3, device=dev)
-            lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=pro_g, xin=x, st_in=sti, add_even=ev, wb=wb, gout=gout0, part=part0, slab=slab0, nslab=ns0, B=B,
-                          Lg=L, Lh=L, cg=cg, ch=ch, stride=1, split_precision=True)
-            gw0 = torch.zeros(cg, ch, 3, device=dev); lib.wgrad_reduce(slab0, ns0, gw0, cg, ch, 3, 1)
-        elif stride == 1:
+        if stride == 1:
             a = lib.conv_args(x=g, x2=y, w=wb, w_hi=wh, w_lo=wl, y=gout0, B=B, L_in=L, L_out=L, cin=cg, cout=ch, taps=3, stride=1, pad=1, flip=1, pro=pro_g,
                               pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=x, aux_stats=sti, add_even=ev)
         else:
             a = lib.conv_args(x=g, x2=y, w=wb, w_hi=wh, w_lo=wl, y=gout0, B=B, L_in=Lg, L_out=L, cin=cg, cout=ch, taps=3, stride=2, pad=1, mode=lib.MODE_UP2,
                               pro=pro_g, pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=x, aux_stats=sti)
-        if cg != 32:
+        if True:
             t0 = lib.conv_tile_of(a); nt0 = (L + t0 - 1) // t0
             part0 = torch.zeros(B, nt0, 2, ch, device=dev); lib.set_part(a, part0)
             lib.conv_forward(a)
@@ -614,7 +610,7 @@ def t_bwd_wide():
                          cg=cg, ch=ch, stride=stride)
             gw = torch.zeros(cg, ch, 3, device=dev); lib.wgrad_reduce(slab, ns, gw, cg, ch, 3, 1)
             tag = f'bwd_wide {cg}->{ch} s{stride} L{L} hst{int(hst)} ev{int(add_even)} wgs{ns}'
-            loose = 5 if cg == 32 else 1   # 32 channels: the reference arm (w2s_bwd_fused) packs its K steps differently
+            loose = 1
             report(tag + ' gout', gout, gout0, tol=2e-6 * loose)
             report(tag + ' statistics sums', part.sum(1), part0.sum(1), tol=2e-5 * loose)
             report(tag + ' wgrad', gw, gw0, tol=2e-5 * loose)
@@ -1050,7 +1046,40 @@ def t_inkernel_finalize():
     RES.append(('in-kernel finalize: every counter re-armed', int(cnt.abs().sum()) == 0))
 
 
-STAGES = dict(bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+def t_plumbing():
+    """w2s_token_masks / w2s_cls_scatter / w2s_copy_rows / w2s_zero (round 4: the stock element-wise launches of a step as library kernels)
+    against the torch expressions they replace (models/wav2sleep.py:150,319-345)."""
+    B, S, R1 = 5, 7, 2
+    Ts = [S * 8, S * 16, S * 4]
+    xs = [torch.randn(B, T, device=dev) for T in Ts]
+    xs[0][1] = float('-inf'); xs[2][3] = float('-inf'); xs[1][4, 0] = float('inf'); xs[1][2, 5] = float('-inf')   # (only the FIRST value of a row decides)
+    D = R1 + len(xs)
+    keep = torch.full((len(xs), B), float('nan'), device=dev); keypad = torch.full((B * S, D), 77, device=dev, dtype=torch.uint8)
+    lib.token_masks(xs, R1, B, S, keep, keypad)
+    want_keep = torch.stack([(~torch.isinf(x[:, 0])).float() for x in xs])
+    miss = torch.stack([torch.zeros(B, dtype=torch.bool, device=dev)] * R1 + [torch.isinf(x[:, 0]) for x in xs], dim=1)
+    want_pad = miss.to(torch.uint8)[:, None, :].expand(B, S, D).reshape(B * S, D)
+    RES.append(('token_masks keep', torch.equal(keep, want_keep)))
+    RES.append(('token_masks key padding', torch.equal(keypad, want_pad)))
+    N, F_ = 37, 128
+    src = torch.randn(N, F_, device=dev)
+    dst = torch.full((N, D, F_), float('nan'), device=dev)
+    lib.cls_scatter(dst, src, N, D, F_)
+    want = torch.zeros(N, D, F_, device=dev); want[:, 0] = src
+    RES.append(('cls_scatter with source', torch.equal(dst, want)))
+    dst2 = torch.randn(N, D, F_, device=dev); keep0 = dst2[:, 0].clone()
+    lib.cls_scatter(dst2, None, N, D, F_)
+    want2 = torch.zeros(N, D, F_, device=dev); want2[:, 0] = keep0
+    RES.append(('cls_scatter without source leaves the CLS rows', torch.equal(dst2, want2)))
+    tok = torch.randn(N, D * F_, device=dev); out = torch.zeros(N, F_, device=dev)
+    lib.copy_rows(out, F_, tok, D * F_, N, F_)
+    RES.append(('copy_rows gathers the CLS rows', torch.equal(out, tok[:, :F_])))
+    cm = torch.randint(1, 9, (5, 5), device=dev, dtype=torch.int64); g = torch.randn(1001 * 4, device=dev)[:1000 * 4 + 4]
+    lib.zero_(cm); lib.zero_(g)
+    RES.append(('zero_', int(cm.abs().sum()) == 0 and float(g.abs().sum()) == 0.0))
+
+
+STAGES = dict(plumb=t_plumbing, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

@@ -85,6 +85,12 @@ def test_bench_bookkeeping_helpers():
     assert bench.pmc_key('conv_wide_kernel<8, 8, 4, 1, 3, 1, 4, 2, 0, 0>') == 'conv_wide_kernel<8, 8, 1, 3, 1>'
     assert bench.pmc_key('wgrad_wide_kernel<4, 4, 2, 5, 3, 2, 4, 2, 2, 2>') == 'wgrad_wide_kernel<4, 4, 2, 5, 3>'
     assert bench.pmc_key('bwd_fused_bf_kernel<1, 1, 4, 1, 0, 0>') == 'bwd_fused_bf_kernel<1, 1, 4, 1, 0, 0>'
+    # round 4: the persistent statistics producers carry a trailing FIN template argument that the timer keys do not
+    assert bench.pmc_key('bwd_fused_bf_kernel<1, 1, 4, 1, 0, 0, 0, 0>') == 'bwd_fused_bf_kernel<1, 1, 4, 1, 0, 0, 0>'
+    assert bench.pmc_key('bwd_fused_bf_kernel<1, 1, 4, 1, 0, 0, 0>') == 'bwd_fused_bf_kernel<1, 1, 4, 1, 0, 0, 0>'
+    assert bench.pmc_key('conv_fwd_bf_kernel<1, 1, 4, 1, 3, 1>') == 'conv_fwd_bf_kernel<1, 1, 4, 1, 3>'
+    assert bench.pmc_key('conv_wide_kernel<8, 8, 4, 1, 3, 1, 4, 2, 0, 0, 0>') == 'conv_wide_kernel<8, 8, 1, 3, 1>'
+    assert bench.pmc_key('bwd_wide_kernel<4, 4, 1, 4, 4, 2, 2, 2, 0, 0, 1>') == bench.pmc_key('bwd_wide_kernel<4, 4, 1, 4, 4, 2, 2, 2, 0, 0>')
     fams = {bench.family_of(k) for k in ('bwd_fused_bf_kernel<1, 1, 4, 1, 0, 0>', 'conv_fwd_bf_kernel<1, 1, 4, 1, 3>', 'conv_wide_kernel<4, 4, 1, 3, 1>',
                                          'wgrad_wide_kernel<4, 4, 1, 4, 3>', 'wgrad_bf_kernel<8, 1, 8, 8, 1, -1, -1>', 'conv_cl_kernel<8, 4, 1, 1, 0, 4, 0, 3, 1>')}
     assert len(fams) == 5 and 'other' not in fams

@@ -52,7 +52,7 @@ struct BwdP {
 __host__ __device__ constexpr int bwd_rs(int c) { return (c > 16 || !W2S_BF_OCC3) ? c + 4 : c; }
 __host__ __device__ constexpr int bwd_redn(int ch) { return 4 * ch * 4 * 8; }  // floats of the statistics scratch
 
-template <int CG, int CH, int MT, int UP2, int PF>
+template <int CG, int CH, int MT, int UP2, int PF, int FIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CG == 1 && CH == 1 && W2S_BF_OCC3) ? 3 : 2)))
 void bwd_fused_kernel(BwdP P) {
   extern __shared__ f32x4 smem4[];
@@ -69,6 +69,7 @@ void bwd_fused_kernel(BwdP P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int Lg = P.Lg, Lh = P.Lh;
+  const int G = (int)gridDim.x;
 
   f32x4 accw[CG][3][CH];
 #pragma unroll
@@ -153,7 +154,7 @@ void bwd_fused_kernel(BwdP P) {
 
   // tiles of this workgroup: a contiguous run of the (sample, tile) list (blocked; see w2s_common.h "Statistics finalisation")
   const int total = P.B * P.ntiles;
-  const W2SRun wrun = w2s_block_part(total, gridDim.x, blockIdx.x);   // the grid never exceeds the tile count
+  const W2SRun wrun = w2s_block_part(total, G, blockIdx.x);   // the producers never exceed the tile count
   const int wend = wrun.first + wrun.count;
   w2s_dd* accL = reinterpret_cast<w2s_dd*>(reinterpret_cast<char*>(smem4) + P.acc_off);   // running statistics sums of this run, one slot per thread < 2*HC
   if (tid < 2 * HC) accL[tid] = (w2s_dd){0.0, 0.0};
@@ -244,10 +245,10 @@ void bwd_fused_kernel(BwdP P) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
-        if (P.fin.out) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
+        if ((FIN && P.fin.out)) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
           const bool endrun = tl + 1 >= wend || tile + 1 == P.ntiles;
           double* row = nullptr;
-          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row) * (2 * HC) * 2;
+          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, G, P.ntiles, b, blockIdx.x).row) * (2 * HC) * 2;
           w2s_run_add(accL, tid, s, endrun, row);
         } else {
           w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
@@ -297,7 +298,7 @@ void bwd_fused_kernel(BwdP P) {
         }
       }
   // tickets of the samples this run touched; the last arriver of a sample finalises its statistics (w2s_common.h)
-  if (P.fin.out && wrun.count > 0) w2s_rows_tail(P.fin, total, gridDim.x, P.ntiles, blockIdx.x, wrun.first / P.ntiles, (wend - 1) / P.ntiles, HC, 1, 256, smem4);
+  if ((FIN && P.fin.out) && wrun.count > 0) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, wrun.first / P.ntiles, (wend - 1) / P.ntiles, HC, 1, 256, smem4);
 }
 
 template <int CG, int CH, int MT, int UP2, int PF>
@@ -309,11 +310,11 @@ static int launch_bwd(const BwdP& P0, int nslab, hipStream_t s) {
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = UP2 ? TM + 1 : TM + 2;
   size_t lds = (size_t)(NRg * bwd_rs(CG * 16) + NRh * bwd_rs(CH * 16) + TM * bwd_rs(CH * 16)) * 4;
   lds += (size_t)bwd_redn(CH) * 4 + (size_t)(CH * 16) * (3 * CG * 16 + 4) * 4;
-  if (lds < 256 * 16 + 16) lds = 256 * 16 + 16;   // w2s_rows_tail's scratch aliases the windows
+  if (lds < 256 * 16 + 16) lds = 256 * 16 + 16;   // a finaliser workgroup's scratch aliases the windows
   lds = (lds + 15) & ~(size_t)15;
   P.acc_off = (int)lds;
   lds += (size_t)2 * CH * 16 * 16;
-  auto kern = bwd_fused_kernel<CG, CH, MT, UP2, PF>;
+  auto kern = P.fin.out ? bwd_fused_kernel<CG, CH, MT, UP2, PF, 1> : bwd_fused_kernel<CG, CH, MT, UP2, PF, 0>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -356,6 +357,12 @@ __device__ __forceinline__ f32x4 mfma_bf3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x
 // already staged.  Replaces a 1x1 conv launch (+ its output tensor, written and re-read) and a weight-gradient launch that
 // re-read both gpre and the block input.
 __host__ __device__ constexpr int bf_rs(int c) { return c == 16 ? 16 : c + 8; }  // 32-B rows are conflict-free as they are
+// XOR swizzles of the unpadded 32-channel planes of the fused backward (GPS == 2): column (a multiple of 4) of channel `col` in row `row`.
+// fp32 GELU' plane, 128-B rows read with ds_read_b128 by the epilogue's D-fragment lanes (position = lane & 15, channels 4*(lane >> 4)):
+// 16-B unit ^= (row >> 1) & 7 makes the sixteen lanes of a read group hit sixteen different units; fp16 n plane, 64-B rows read with
+// ds_read_b64: 8-B unit ^= ((row >> 2) & 3) << 1.
+__device__ __forceinline__ int bwd_gp_col(int row, int col) { return (((col >> 2) ^ ((row >> 1) & 7)) << 2); }
+__device__ __forceinline__ int bwd_n_col(int row, int col) { return (((col >> 2) ^ (((row >> 2) & 3) << 1)) << 2); }
 // FIRST = 1 (conv2 of block 0): the input side is block 0's conv1 output, which is never stored -- it is recomputed from
 // the raw 1-channel signal while the window is staged (3 FMAs per element instead of a 64-B row per position).
 // Occupancy: the kernels take what their registers allow (2 waves per SIMD; measured: forcing 2 on the variants that land on 1 changes
@@ -368,7 +375,7 @@ __host__ __device__ constexpr int bf_rs(int c) { return c == 16 ? 16 : c + 8; } 
 #define W2S_BF_OCC22 1   // tuning: the same for the 32-channel kernels ((32,32) both strides, (32,16) fold)
 #endif
 __host__ __device__ constexpr int bfk_occ(int cg, int ch, int rd) { return (cg == 1 && ch == 1 && rd) ? 3 : (cg == 1 && ch == 1) ? W2S_BF_OCC11 : W2S_BF_OCC22; }
-template <int CG, int CH, int MT, int UP2, int RD, int FIRST, int GM = 0>
+template <int CG, int CH, int MT, int UP2, int RD, int FIRST, int GM, int FIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bfk_occ(CG, CH, RD))))
 void bwd_fused_bf_kernel(BwdP P) {
   static_assert(GM != 1 || !RD, "a residual-fold kernel reads the chain from both sides: all fp32 or all fp16");
@@ -397,10 +404,15 @@ void bwd_fused_bf_kernel(BwdP P) {
   constexpr int WROW = KD + 8;
   // GPS (16 input-side channels: the LDS budget allows it): GELU'(n) of the centre rows is computed once, together with
   // GELU(n), while the window is staged, instead of a second erf evaluation in the epilogue
-  constexpr int GPS = (HC == 16) ? 1 : 0;
-  float* nL = reinterpret_cast<float*>(smem4);              // [TM][RSn] normalised input of the centre rows
-  float* gpL = nL + TM * RSn;                               // [TM][RSn] GELU'(n) of the centre rows (GPS)
-  float* red = gpL + (GPS ? TM * RSn : 0);                  // [4][CH][4][8] stats scratch
+  // 32 input-side channels (GPS == 2, round 4): the same, inside the LDS budget of two workgroups per CU -- the GELU' plane stays fp32
+  // (it multiplies the data gradient), the n plane (only the backward statistics sum gout * n read it) is fp16, and both are stored
+  // UNPADDED (128-B / 64-B rows) with an XOR swizzle of their 16-B / 8-B units instead of the pad (bwd_gp_col / bwd_n_col).  The second
+  // erf evaluation per element in the epilogue was ~30 % of these kernels' vector instructions.
+  constexpr int GPS = (HC == 16) ? 1 : 2;
+  float* nL = reinterpret_cast<float*>(smem4);              // GPS 1: [TM][RSn] normalised input of the centre rows;  GPS 2: the GELU' plane [TM][32]
+  float* gpL = (GPS == 2) ? nL : nL + TM * RSn;             // [TM][RSn] GELU'(n) of the centre rows (GPS 2: [TM][32], swizzled)
+  _Float16* nH = reinterpret_cast<_Float16*>(nL + TM * 32); // GPS 2: n of the centre rows as fp16 [TM][32], swizzled
+  float* red = (GPS == 2) ? reinterpret_cast<float*>(nH + TM * 32) : gpL + TM * RSn;   // [4][CH][4][8] stats scratch
   __bf16* gyH = reinterpret_cast<__bf16*>(red + bwd_redn(CH));
   __bf16* gyLo = gyH + NRg * RSg;
   __bf16* hH = gyLo + NRg * RSg;
@@ -418,6 +430,7 @@ void bwd_fused_bf_kernel(BwdP P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4, q4 = r >> 2, p4 = r & 3;
   const int Lg = P.Lg, Lh = P.Lh;
+  const int G = (int)gridDim.x;
   if (WDFC && tid >= 112 && tid < 128) accD[tid - 112] = 0.f;
 
   // weight-gradient ownership: the CG*CH (cout tile, cin tile) pairs are spread over the 4 waves; KW waves share a
@@ -564,14 +577,20 @@ void bwd_fused_bf_kernel(BwdP P) {
           xv = rh[k];
         }
         const f32x4 nv = (xv - hm) * hr;
-        if (GPS) {
+        {
           f32x4 hv, gpv;
           gelu_both4(nv, hv, gpv);
           split_store4(hH, hLo, row * RSh + hch, ok ? hv : (f32x4){0, 0, 0, 0});
-          if (row >= PL && row < TM + PL) { st4(nL + (row - PL) * RSn + hch, nv); st4(gpL + (row - PL) * RSn + hch, gpv); }
-        } else {
-          split_store4(hH, hLo, row * RSh + hch, ok ? gelu4(nv) : (f32x4){0, 0, 0, 0});
-          if (row >= PL && row < TM + PL) st4(nL + (row - PL) * RSn + hch, nv);
+          if (row >= PL && row < TM + PL) {
+            const int rr = row - PL;
+            if (GPS == 2) {
+              st4(gpL + rr * 32 + bwd_gp_col(rr, hch), gpv);
+              st4h(nH, (unsigned)(rr * 32 + bwd_n_col(rr, hch)), f2h4(nv));
+            } else {
+              st4(nL + rr * RSn + hch, nv);
+              st4(gpL + rr * RSn + hch, gpv);
+            }
+          }
         }
       }
     }
@@ -588,7 +607,7 @@ void bwd_fused_bf_kernel(BwdP P) {
 
   // tiles of this workgroup: a contiguous run of the (sample, tile) list (blocked; see w2s_common.h "Statistics finalisation")
   const int total = P.B * P.ntiles;
-  const W2SRun wrun = w2s_block_part(total, gridDim.x, blockIdx.x);   // the grid never exceeds the tile count
+  const W2SRun wrun = w2s_block_part(total, G, blockIdx.x);   // the producers never exceed the tile count
   const int wend = wrun.first + wrun.count;
   w2s_dd* accL = reinterpret_cast<w2s_dd*>(reinterpret_cast<char*>(smem4) + P.acc_off);   // running statistics sums of this run, one slot per thread < 2*HC
   if (tid < 2 * HC) accL[tid] = (w2s_dd){0.0, 0.0};
@@ -736,10 +755,11 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
       for (int nt = 0; nt < CH; ++nt) {
         const int ch = nt * 16 + 4 * g;
-        const f32x4 n = *reinterpret_cast<const f32x4*>(nL + (pos - t0) * RSn + ch);
+        const int mrow = pos - t0;
+        const f32x4 n = (GPS == 2) ? h2f4(ld4h(nH, (unsigned)(mrow * 32 + bwd_n_col(mrow, ch)))) : *reinterpret_cast<const f32x4*>(nL + mrow * RSn + ch);
         f32x4 v = acc[mt][nt];
         if (P.add_even && !(pos & 1)) v += ld4o(P.add_even + (size_t)b * (Lh >> 1) * HC, (unsigned)(pos >> 1) * HC + ch);
-        v = v * (GPS ? *reinterpret_cast<const f32x4*>(gpL + (pos - t0) * RSn + ch) : gelu_grad4(n));
+        v = v * ((GPS == 2) ? *reinterpret_cast<const f32x4*>(gpL + mrow * 32 + bwd_gp_col(mrow, ch)) : *reinterpret_cast<const f32x4*>(gpL + mrow * RSn + ch));
         if (RD && P.y3p) {  // statistics of the previous block's conv3 backward: gn = gout * GELU'(n3), n3 = IN(y3)
           const float* st = P.st3p + ((size_t)b * HC + ch) * 2;
           const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
@@ -822,10 +842,10 @@ void bwd_fused_bf_kernel(BwdP P) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
-        if (P.fin.out) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
+        if ((FIN && P.fin.out)) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
           const bool endrun = tl + 1 >= wend || tile + 1 == P.ntiles;
           double* row = nullptr;
-          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row) * (2 * HC) * 2;
+          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, G, P.ntiles, b, blockIdx.x).row) * (2 * HC) * 2;
           w2s_run_add(accL, tid, s, endrun, row);
         } else {
           w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
@@ -922,7 +942,7 @@ void bwd_fused_bf_kernel(BwdP P) {
     }
   }
   // tickets of the samples this run touched; the last arriver of a sample finalises its statistics (w2s_common.h)
-  if (P.fin.out && wrun.count > 0) w2s_rows_tail(P.fin, total, gridDim.x, P.ntiles, blockIdx.x, wrun.first / P.ntiles, (wend - 1) / P.ntiles, HC, 1, 256, smem4);
+  if ((FIN && P.fin.out) && wrun.count > 0) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, wrun.first / P.ntiles, (wend - 1) / P.ntiles, HC, 1, 256, smem4);
 }
 
 template <int CG, int CH, int MT, int UP2, int RD, int FIRST = 0, int GM = 0>
@@ -932,15 +952,15 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   P.ntiles = (P.Lh + TM - 1) / TM;
   P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, nslab);
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = TM + 2, NRp = RD ? TM / 2 + 1 : 0;
-  size_t lds = (size_t)TM * bwd_rs(HC) * 4 * (HC == 16 ? 2 : 1) + (size_t)bwd_redn(CH) * 4 +
+  size_t lds = (HC == 16 ? (size_t)TM * bwd_rs(HC) * 4 * 2 : (size_t)TM * 32 * (4 + 2)) + (size_t)bwd_redn(CH) * 4 +   // n + GELU' planes (32 ch: fp32 + fp16, unpadded)
                (size_t)2 * 2 * ((NRg + NRp) * bf_rs(GC) + NRh * bf_rs(HC) + HC * (KD + 8));
   if (FIRST) lds += (size_t)(TM + 4) * 4 + 4 * 4 * 12 * 4;
   if (RD) lds += (4 * 4 * 4 + 16) * 4;
-  if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4] (and w2s_rows_tail's)
+  if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4] (and a finaliser workgroup's)
   lds = (lds + 15) & ~(size_t)15;
   P.acc_off = (int)lds;
   lds += (size_t)2 * HC * 16;
-  auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST, GM>;
+  auto kern = P.fin.out ? bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST, GM, 1> : bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST, GM, 0>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;

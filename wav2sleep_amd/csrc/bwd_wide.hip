@@ -57,7 +57,7 @@ __device__ __forceinline__ bf16x8 wb_tr8(const __bf16* p0, const __bf16* p1) {
 
 // CO / CI: 16-channel tiles on the gradient / input side; HST: xin carries statistics (conv2); MT: 16-position m-tiles per tile;
 // NWC consumer waves = (CO / IB) x (CI / CB) weight-gradient owners = CI x (NWC / CI) data-gradient owners; PD: producer prefetch depth
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0, int RD = 0>
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD, int FIN>
 __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
   static_assert(!RD || (!UP2 && !HST && MT % 2 == 0), "residual fold: the stride-1 conv1 (its input is a stored pre-activation)");
   extern __shared__ f32x4 smem4[];
@@ -78,8 +78,9 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
   float* stL = reinterpret_cast<float*>(lds + 2 * BUFB);   // [B][OC][2] (mean, rstd), [B][OC][2] backward sums, then [B][HC][2] (HST)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int total = P.B * P.ntiles;
+  const int G = (int)gridDim.x;
   // tiles of this workgroup: a contiguous run of the (sample, tile) list (blocked; w2s_common.h "Statistics finalisation")
-  const W2SRun wrun = w2s_block_part(total, gridDim.x, blockIdx.x);
+  const W2SRun wrun = w2s_block_part(total, G, blockIdx.x);
   const int first = wrun.first;
   const int run_b0 = first / P.ntiles, run_t0 = first - run_b0 * P.ntiles;   // the run's first (sample, tile): the one division of the launch
   // running statistics sums of this workgroup's run [PG][2][HC] (hi, lo), behind the tables (in-kernel statistics finalisation)
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
   }
   const int ch0 = dn * 16 + 4 * g;   // this lane's 4 consecutive output channels (D fragment: position r, channels 4g .. 4g+3)
   w2s_dd* accW = accL + dg * 2 * HC; // this position group's running sums
-  if (P.fin.out && r == 0) {
+  if ((FIN && P.fin.out) && r == 0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { accW[ch0 + e] = (w2s_dd){0.0, 0.0}; accW[HC + ch0 + e] = (w2s_dd){0.0, 0.0}; }
   }
@@ -351,11 +352,11 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       f32x4 x1, x2;
       x1 = sA; x2 = sB;
       row16_sum8(x1, x2);
-      if (P.fin.out) {   // (uniform) running sums of this run; the run of sample b ends with this tile: the sums go to the row scratch
+      if ((FIN && P.fin.out)) {   // (uniform) running sums of this run; the run of sample b ends with this tile: the sums go to the row scratch
         if (r == 0) {
           const bool endrun = (it + 1 >= nt_wg) || (tile + 1 == P.ntiles);
           double* row = nullptr;   // this position group's row: rows run*PG .. run*PG + PG-1 of the sample
-          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row * PG + dg) * (2 * HC) * 2;
+          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, G, P.ntiles, b, blockIdx.x).row * PG + dg) * (2 * HC) * 2;
           const float v1[4] = {x1.x, x1.y, x1.z, x1.w}, v2[4] = {x2.x, x2.y, x2.z, x2.w};
 #pragma unroll 1
           for (int e = 0; e < 4; ++e) {
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       for (int c = 0; c < CB; ++c) st4(out + (size_t)(((wi * IB + i) * 3 + j) * CI + wc * CB + c) * 256, accw[i][j][c]);
   // tickets of the samples this run touched (the consumer waves; the producers have passed their last barrier and end): the last
   // arriver of a sample finalises its statistics (w2s_common.h).  Scratch: the window buffers, dead now.
-  if (P.fin.out) w2s_rows_tail(P.fin, total, gridDim.x, P.ntiles, blockIdx.x, first / P.ntiles, (first + nt_wg - 1) / P.ntiles, HC, PG, 64 * NWC, smem4);
+  if (FIN && P.fin.out) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, run_b0, (first + nt_wg - 1) / P.ntiles, HC, PG, 64 * NWC, smem4);
 }
 
 template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0, int RD = 0>
@@ -455,7 +456,7 @@ static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
   if (dry) return 0;
   if (nslab <= 0 || (long)nslab > (long)P.B * P.ntiles) return W2S_EINVAL;   // every workgroup writes a slab: it needs a tile
   P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, nslab) * (NWC / CI);
-  auto kern = bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>;
+  auto kern = P.fin.out ? bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 1> : bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 0>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -466,7 +467,6 @@ static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
 
 // positions (input side) per tile and statistics-partial rows per tile of the (cg, ch, stride) instance; 0: no instance
 extern "C" int w2s_bwd_wide_tile(int cg, int ch, int stride) {
-  if (cg == 32 && ch == 32 && stride == 1) return 64;   // (the 32-channel stride-1 convs: an alternative to w2s_bwd_fused, W2S_BWD_WIDE32)
   return (cg == 64 && ((ch == 64 && (stride == 1 || stride == 2)) || (ch == 32 && stride == 1))) ? 64 : 0;
 }
 extern "C" int w2s_bwd_wide_groups(int cg, int ch, int stride) { return !w2s_bwd_wide_tile(cg, ch, stride) ? 0 : (ch == 32) ? 2 : 1; }
@@ -498,8 +498,6 @@ extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, c
              static_cast<const __bf16*>(wd_hi), static_cast<const __bf16*>(wd_lo), slab_d, B, L, L / stride, 0,
              StatFin{stat_out, stat_cnt, reinterpret_cast<double*>(part), 0, 1.0 / (double)L, 0.f, 1}};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (cg == 32 && rd) return launch_bww<2, 2, 0, 4, 4, 1, 1, 3, 0, 1>(P, nslab, s, dry);
-  if (cg == 32) return st_in ? launch_bww<2, 2, 1, 4, 4, 1, 1, 3>(P, nslab, s, dry) : launch_bww<2, 2, 0, 4, 4, 1, 1, 3>(P, nslab, s, dry);
   if (stride == 2) return launch_bww<4, 4, 1, 4, 4, 2, 2, 2, 1>(P, nslab, s, dry);
   if (rd) return ch == 64 ? launch_bww<4, 4, 0, 4, 4, 2, 2, 2, 0, 1>(P, nslab, s, dry) : launch_bww<4, 2, 0, 4, 4, 2, 1, 2, 0, 1>(P, nslab, s, dry);
   if (ch == 64) return st_in ? launch_bww<4, 4, 1, 4, 4, 2, 2, 2>(P, nslab, s, dry) : launch_bww<4, 4, 0, 4, 4, 2, 2, 2>(P, nslab, s, dry);

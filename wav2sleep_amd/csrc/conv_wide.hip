@@ -44,7 +44,7 @@ __device__ __forceinline__ void wsplit_store4(__bf16* hi, __bf16* lo, int off, f
 // UP2 = 1: the transposed stride-2 form (data gradient of the stride-2 conv3, w2s_conv_forward's W2S_MODE_UP2): output position
 // t' = 2u + phase reads the gradient rows u, u+1; m-tiles alternate phase (mt & 1), their row block is mt >> 1.  Symmetric padding:
 // even outputs W_1^T g[u], odd outputs W_2^T g[u] + W_0^T g[u+1]; causal (pad 2): even W_2^T g[u] + W_0^T g[u+1], odd W_1^T g[u+1].
-template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2 = 0, int CZ = 0>   // CZ: UP2 with causal padding
+template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2, int CZ, int FIN>   // CZ: UP2 with causal padding
 __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 16 * MT;                            // output positions per tile (all consumer waves share them)
@@ -63,9 +63,10 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L_in = P.L_in, L_out = P.L_out;
   const int total = P.B * P.ntiles;
-  // tiles of this workgroup: a contiguous run of the (sample, tile) list (blocked; w2s_common.h "Statistics finalisation"); the grid
-  // never exceeds the tile count
-  const W2SRun wrun = w2s_block_part(total, gridDim.x, blockIdx.x);
+  const int G = (int)gridDim.x;
+  // tiles of this workgroup: a contiguous run of the (sample, tile) list (blocked; w2s_common.h "Statistics finalisation"); the producers
+  // never exceed the tile count
+  const W2SRun wrun = w2s_block_part(total, G, blockIdx.x);
   const int first = wrun.first;
   const int run_b0 = first / P.ntiles, run_t0 = first - run_b0 * P.ntiles;   // the run's first (sample, tile): the one division of the launch
   // running statistics sums of this workgroup's run [2][OC] (hi, lo), behind the tables (in-kernel statistics finalisation)
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     al[ks] = *reinterpret_cast<const bf16x8*>(P.w_lo + wo);
   }
   const int ch0 = wave * 16 + 4 * g;   // this lane's 4 consecutive output channels (D fragment: position r, channels 4g..4g+3)
-  if (P.fin.out && r == 0) {           // this lane's eight running sums (nobody else touches them)
+  if ((FIN && P.fin.out) && r == 0) {           // this lane's eight running sums (nobody else touches them)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { accL[ch0 + e] = (w2s_dd){0.0, 0.0}; accL[OC + ch0 + e] = (w2s_dd){0.0, 0.0}; }
   }
@@ -238,11 +239,11 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
       f32x4 x1, x2;
       x1 = sA; x2 = sB;
       row16_sum8(x1, x2);
-      if (P.fin.out) {   // (uniform) running sums of this run; the run of sample b ends with this tile: the sums go to the row scratch
+      if ((FIN && P.fin.out)) {   // (uniform) running sums of this run; the run of sample b ends with this tile: the sums go to the row scratch
         if (r == 0) {
           const bool endrun = (i + 1 >= nt_wg) || (tile + 1 == P.ntiles);
           double* row = nullptr;
-          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row) * (2 * OC) * 2;
+          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, G, P.ntiles, b, blockIdx.x).row) * (2 * OC) * 2;
           const float v1[4] = {x1.x, x1.y, x1.z, x1.w}, v2[4] = {x2.x, x2.y, x2.z, x2.w};
 #pragma unroll 1
           for (int e = 0; e < 4; ++e) {
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
   }
   // tickets of the samples this run touched (the consumer waves; the producers have passed their last barrier and end): the last
   // arriver of a sample finalises its statistics (w2s_common.h).  Scratch: the window buffers, dead now.
-  if (P.fin.out) w2s_rows_tail(P.fin, total, gridDim.x, P.ntiles, blockIdx.x, first / P.ntiles, (first + nt_wg - 1) / P.ntiles, OC, 1, 64 * NW, smem4);
+  if (FIN && P.fin.out) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, run_b0, (first + nt_wg - 1) / P.ntiles, OC, 1, 64 * NW, smem4);
 }
 
 template <int CI, int NW, int STRIDE, int PRO, int EPI, int MT, int NP = 4, int UP2 = 0, int CZ = 0>
@@ -280,7 +281,7 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s, int* rows_only = n
   constexpr int SETV = NHr * 4 * (TWO ? 2 : 1);
   // bytes in flight per CU ~ PD x tile bytes x workgroups per CU >= ~64 KB; register sets beyond that only cost occupancy / spills
   constexpr int PD = NW >= 8 ? (SETV <= 36 ? 2 : 1) : (SETV <= 12 ? 3 : SETV <= 24 ? 2 : 1);
-  auto kern = conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ>;
+  auto kern = P.fin.out ? conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 1> : conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 0>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;

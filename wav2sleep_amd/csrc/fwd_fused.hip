@@ -47,7 +47,7 @@ __host__ __device__ constexpr bool ff_db(int hc, int stride) { return hc == 16 &
 #define W2S_FF_OCC2 1
 #endif
 __host__ __device__ constexpr int ffk_occ(int ci, int co, int stride) { return (ci == 1 && co == 1 && stride == 1) ? 1 : W2S_FF_OCC2; }
-template <int CI, int CO, int MT, int STRIDE, int PRO>
+template <int CI, int CO, int MT, int STRIDE, int PRO, int FIN>   // FIN: with the in-kernel statistics finalisation (its own instantiation: the default path carries none of its code)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI, CO, STRIDE)))) void conv_fwd_bf_kernel(FwdP P) {
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 64 * MT;                            // output rows the matrix cores compute per tile ...
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int L_in = P.L_in, L_out = P.L_out;
+  const int G = (int)gridDim.x;
 
   // ---- weights [OC][3][HC] (forward packing) -> LDS planes once per launch; 16 channels: k = tap*16 + c, zero tail
   for (int i = tid; i < OC * (KD / 4); i += 256) {
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
       for (int j = 0; j < 3; ++j) w1r[i][j] = P.w1[(hch + i) * 3 + j];
   }
   const int total = P.B * P.ntiles;
-  const W2SRun wrun = w2s_block_part(total, gridDim.x, blockIdx.x);   // this workgroup's tiles [wfirst, wend): the grid never exceeds the tile count
+  const W2SRun wrun = w2s_block_part(total, G, blockIdx.x);   // this workgroup's tiles [wfirst, wend): the producers never exceed the tile count
   const int wfirst = wrun.first, wend = wrun.first + wrun.count;
   // (sample, tile) of the body's tile and of the prefetch stream (two tiles ahead), carried incrementally: the run is contiguous, so a
   // position only ever steps to the next tile -- no integer division per tile (each was ~40 scalar + 5 vector instructions, four per tile)
@@ -248,10 +249,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) s += red[((w * CO + nt) * 4 + gg) * 8 + k * 4 + e];
-      if (P.fin.out) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
+      if ((FIN && P.fin.out)) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
         const bool endrun = tl + 1 >= wend || tile + 1 == P.ntiles;
         double* row = nullptr;
-        if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, gridDim.x, P.ntiles, b, blockIdx.x).row) * (2 * OC) * 2;
+        if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, G, P.ntiles, b, blockIdx.x).row) * (2 * OC) * 2;
         w2s_run_add(accL, tid, s, endrun, row);
       } else {
         w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c], s);
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
     body(I1{}, tl + 1);
   }
   // tickets of the samples this run touched; the last arriver of a sample finalises its statistics (w2s_common.h)
-  if (P.fin.out) w2s_rows_tail(P.fin, total, gridDim.x, P.ntiles, blockIdx.x, wfirst / P.ntiles, (wend - 1) / P.ntiles, OC, 1, 256, smem4);
+  if (FIN && P.fin.out) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, wfirst / P.ntiles, (wend - 1) / P.ntiles, OC, 1, 256, smem4);
 }
 
 template <int CI, int CO, int MT, int STRIDE, int PRO>
@@ -279,7 +280,7 @@ static int launch_fwd(const FwdP& P0, int nwg, hipStream_t s) {
   lds = (lds + 15) & ~(size_t)15;
   P.acc_off = (int)lds;
   lds += (size_t)2 * OC * 16;
-  auto kern = conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO>;
+  auto kern = P.fin.out ? conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO, 1> : conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO, 0>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;

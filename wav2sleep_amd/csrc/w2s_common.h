@@ -217,7 +217,9 @@ __device__ __forceinline__ float w2s_dropscale(uint64_t seed, uint64_t idx, floa
 // also re-arms the counter.  Protocol = MI355X_MICROARCH.md, "Valid forms": sc1 payload stores, drained by every storing wave, a
 // workgroup barrier, ONE lane's agent-scope atomic add; the workgroup whose add returned last loads with sc1 loads behind an agent-scope
 // acquire (several workgroups share a CU here).  The round-1 form of this took a ticket per TILE and stalled the persistent workgroups on
-// every one of them (47 ms vs 38.5 ms per step); this one costs a workgroup one or two tickets per launch, after its work.
+// every one of them (47 ms vs 38.5 ms per step); this one costs a workgroup one or two tickets per launch, after its work.  (A third form
+// -- producers only add to the counter, extra finaliser workgroups of the same launch poll it -- was built in round 4 and measured
+// 0.7 ms per step SLOWER than this one: docs/lab_notes_r4.md.)
 // ------------------------------------------------------------------------------------------------------------------
 struct StatFin { float* out; int* cnt; double* rows; int rows_cap; double inv_count; float eps; int kind; };   // out == NULL: per-tile partials only
 

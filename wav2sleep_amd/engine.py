@@ -118,9 +118,7 @@ class Engine:
         # OFF by default: 2.5 x the gradient error for 1.6 % is a trade a user should choose, not inherit
         self.grad_fp16 = os.environ.get('W2S_GRAD_FP16', '0') == '1'
         self.bwd_wide = os.environ.get('W2S_BWD_WIDE', '1') != '0'   # one-pass backward of the 64-channel stride-1 convs (csrc/bwd_wide.hip)
-        self.bwd_wide32 = os.environ.get('W2S_BWD_WIDE32', '0') == '1'   # ... and of the 32 -> 32 stride-1 convs in the same role-split form (experiment)
         self.bwd_wide_rd = os.environ.get('W2S_BWD_WIDE_RD', '1') != '0'   # 64-channel conv1: residual branch folded into the one-pass kernel
-        self.bwd_wide_rd32 = os.environ.get('W2S_BWD_WIDE_RD32', '0') == '1'   # ... and the 32 -> 32 conv1 (block 3) the same way (experiment)
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
         if not spec.use_residual:
@@ -366,7 +364,7 @@ class Engine:
         dev = g.device
         tile, groups = lib.bwd_wide_tile(cg, ch, stride), lib.bwd_wide_groups(cg, ch, stride)
         nt = _cdiv(L, tile)
-        nslab = max(1, min(B * nt, 256 if cg == 64 else int(os.environ.get('W2S_BWD_WIDE32_WGS', 512))))   # one / two workgroups per CU (LDS)
+        nslab = max(1, min(B * nt, 256))   # one workgroup per CU (LDS)
         slab = self._slab(dev, nslab, cg * ch * 3)
         so, sc, rows = self._fin(B, ch, dev, lib.stat_rows(B, nt, nslab) * groups) if want_part else (None, None, None)
         part = (rows if so is not None else torch.empty(B, nt * groups, 2, ch, device=dev, dtype=torch.float32)) if want_part else None
@@ -1155,16 +1153,12 @@ class Engine:
                                       xin=blk['y2'], st_in=blk['st2'], add_even=None, gout=gn2, want_part=True, B=B, Lg=Lh, Lh=L, cg=c, ch=c, stride=2,
                                       gmode=(2 if ghalf else 1) if h16 else 0, hdr_g=gpre_hdr, hdr_o=h2)
                 first = i == 0 and blk['y1'] is None   # block 0's conv1 output is recomputed from the raw signal
-                if self.bwd_wide32 and c == 32 and not h16 and self._bwd_wide_ok(B, L, c, c):
-                    bs1 = self._bwd_wide(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, xin=blk['y1'], st_in=blk['st1'],
-                                         add_even=None, gout=gn1, want_part=True, B=B, L=L, cg=c, ch=c)
-                else:
-                    if fold_w1:
-                        part_w1 = torch.empty(B, _cdiv(L, lib.bwd_fused_tile(c, c, 1, False)), 48, device=dev, dtype=torch.float32)
-                    bs1 = self._bwd_fused(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, pro=lib.PRO_INBWD,
-                                          xin=ec['x'] if first else blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B,
-                                          Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None,
-                                          gmode=2 if h16 else 0, hdr_g=h2, hdr_o=h1, part_w1=part_w1 if fold_w1 else None)
+                if fold_w1:
+                    part_w1 = torch.empty(B, _cdiv(L, lib.bwd_fused_tile(c, c, 1, False)), 48, device=dev, dtype=torch.float32)
+                bs1 = self._bwd_fused(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, pro=lib.PRO_INBWD,
+                                      xin=ec['x'] if first else blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B,
+                                      Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None,
+                                      gmode=2 if h16 else 0, hdr_g=h2, hdr_o=h1, part_w1=part_w1 if fold_w1 else None)
             else:
                 if not (L & 1) and self._bwd_wide_ok(B, L, c, c, stride=2):
                     bs2 = self._bwd_wide(p + 'conv3.conv.weight', g=gpre, y=blk['y3'], st_k=blk['st3'], bst_k=bs3, xin=blk['y2'], st_in=blk['st2'],
@@ -1205,7 +1199,7 @@ class Engine:
                     bs3_folded = None
                 gpre, gpre_hdr = gprev, hp
             elif (i > 0 and self.bwd_wide_rd and self.bwd_wide and self.split_precision and self.kpad == 1 and not (L & 1) and (p + 'downsample.weight') in self.G
-                  and (c >= 64 or (self.bwd_wide_rd32 and not h16)) and self.PB[p + 'downsample.weight'].data_ptr() in self._bf
+                  and c >= 64 and self.PB[p + 'downsample.weight'].data_ptr() in self._bf
                   and self.PB[p + 'conv1.conv.weight'].data_ptr() in self._bf and lib.bwd_wide_takes(B, L, c, cin, 1, False, rd=True)):
                 # 64-channel conv1: the whole residual branch (Wd^T gpre into the data gradient, the downsample weight gradient) and the
                 # previous block's conv3-backward statistics in the one-pass kernel -- no R tensor, no 1x1 conv launch, no separate weight gradient
