@@ -128,3 +128,21 @@ def test_causal_normalisation_matches_reference(name):
     y, m = O.causal_rolling_normalize(g[name + '.x'], sampling_freq=int(g[name + '.spe']) / 30.0, **kw)
     assert np.array_equal(m, g[name + '.mask'])
     np.testing.assert_allclose(y, g[name + '.y'].astype(np.float64), rtol=1e-5, atol=1e-6)
+
+
+def test_confusion_matrix_against_scikit_learn():
+    """`confusion_matrix` is "parity unpinned" (the reference uses torchmetrics' MulticlassConfusionMatrix(ignore_index=-1), trainer/main.py:
+    49-59, and torchmetrics is not installable here).  Short of that pin: the same well-defined function from an independent third party --
+    scikit-learn -- on random labels with ignored entries, 4 and 5 classes, rows = true, columns = predicted."""
+    import numpy as np
+    sk = pytest.importorskip('sklearn.metrics')
+    rng = np.random.default_rng(7)
+    for nc in (4, 5):
+        for n in (1, 37, 5000):
+            true = rng.integers(-1, nc, size=n)
+            pred = rng.integers(0, nc, size=n)
+            got = O.confusion_matrix(torch.from_numpy(pred), torch.from_numpy(true), nc).numpy()
+            keep = true != -1
+            want = sk.confusion_matrix(true[keep], pred[keep], labels=list(range(nc))) if keep.any() else np.zeros((nc, nc), dtype=np.int64)
+            assert np.array_equal(got, want), (nc, n)
+            assert got.sum() == int(keep.sum())

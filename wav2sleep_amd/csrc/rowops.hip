@@ -507,7 +507,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     case 5: hipLaunchKernelGGL(KERN<5>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
     case 6: hipLaunchKernelGGL(KERN<6>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
     case 7: hipLaunchKernelGGL(KERN<7>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
-    default: return W2S_EINVAL;                                                                      \
+    case 8: hipLaunchKernelGGL(KERN<8>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
+    case 9: hipLaunchKernelGGL(KERN<9>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
+    case 10: hipLaunchKernelGGL(KERN<10>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;        \
+    case 11: hipLaunchKernelGGL(KERN<11>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;        \
+    case 12: hipLaunchKernelGGL(KERN<12>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;        \
+    default: return W2S_EINVAL;   /* 2 .. 12 tokens: six signals + CLS + five register tokens is all the reference's maps can ask for */ \
   }
 
 extern "C" int w2s_attn_fwd(const float* qkv, const uint8_t* keypad, float* out, int N, int D, int H, float p_drop, uint64_t seed,

@@ -32,15 +32,16 @@ __all__ = ['ParquetDataset', 'load_dataset', 'save_predictions', 'predict_on_fol
 
 
 def try_read_parquet(fp: str, columns: list[str] | None = None, max_retries: int = 3):
-    """data/dataset.py:188-198."""
+    """`pd.read_parquet` that survives a flaky filesystem: up to `max_retries` further attempts, every failure logged, then a
+    ValueError naming the file -- the contract of the reference's helper of the same name (data/dataset.py:188-198), as a loop."""
     import pandas as pd
-    try:
-        return pd.read_parquet(fp, columns=columns)
-    except Exception as e:  # noqa: BLE001 (the reference retries on anything)
-        logger.error(f'Failed to read parquet {fp=} - {e}')
-        if max_retries > 0:
-            return try_read_parquet(fp, columns=columns, max_retries=max_retries - 1)
-        raise ValueError(f'Failed to read parquet {fp=}')
+    attempts = max_retries + 1
+    for left in range(attempts, 0, -1):
+        try:
+            return pd.read_parquet(fp, columns=columns)
+        except Exception as e:  # noqa: BLE001 (anything the reader raises counts as a failed attempt, as in the reference)
+            logger.error(f'Failed to read parquet {fp=} - {e}')
+    raise ValueError(f'Failed to read parquet {fp=}')
 
 
 class ParquetDataset(torch.utils.data.Dataset):

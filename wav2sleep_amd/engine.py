@@ -68,7 +68,7 @@ class EngineSpec:
         if self.feature_dim != 128 or self.mixer_nhead * 16 != self.feature_dim:
             raise ValueError('kernels are built for feature_dim=128, head_dim=16 (scripts/config/model/wav2sleep.yaml)')
         if not 0 <= self.register_tokens <= 5:
-            raise ValueError('register_tokens must be in 0..5 (the attention kernels hold up to 7 tokens per epoch)')
+            raise ValueError('register_tokens must be in 0..5 (the attention kernels hold up to 12 tokens per epoch: 6 signals + CLS + 5)')
         if self.mixer_dim_ff not in (384, 512) or self.seq_kernel != 7 or self.initial_channels != 16 or self.max_channels not in (16, 32, 64, 128):
             raise ValueError('unsupported hyper-parameters for the fused gfx950 kernels (dim_ff 384 / 512, kernel_size 7, channels 16 -> 128): '
                              'other configurations run on the generic inference path (wav2sleep_amd/generic.py)')
@@ -548,8 +548,8 @@ class Engine:
                 raise ValueError(f'Input length {tuple(v.shape)} of {s} must be [B, T] with T divisible by samples_per_epoch={spe}.')
         if len({(v.shape[0], v.shape[1] // COLS_TO_SAMPLES_PER_EPOCH[s]) for s, v in x.items()}) != 1:
             raise ValueError('all signals must share batch size and number of epochs')
-        if len(x) + sp.register_tokens + 1 > 7:
-            raise ValueError(f'{len(x)} signals + {sp.register_tokens + 1} CLS/register tokens: the attention kernels hold at most 7 tokens per epoch')
+        if len(x) + sp.register_tokens + 1 > 12:
+            raise ValueError(f'{len(x)} signals + {sp.register_tokens + 1} CLS/register tokens: the attention kernels hold at most 12 tokens per epoch')
 
     def _encode_begin(self, x: dict[str, torch.Tensor], save: bool, cls: bool = True):
         """Token tensor (CLS / register rows written on the current stream) and the encoder passes as generators, one list per encoder

@@ -397,8 +397,8 @@ class MultiModalAttentionEmbedder(_HandWritten, nn.Module):
         from . import lib
         R1 = self.num_register_tokens + 1
         N, D = B * S, len(signals) + R1
-        if D > 7:
-            raise ValueError(f'{len(signals)} signals + {R1} CLS/register tokens: the attention kernels hold at most 7 tokens per epoch')
+        if D > 12:
+            raise ValueError(f'{len(signals)} signals + {R1} CLS/register tokens: the attention kernels hold at most 12 tokens per epoch')
         tokens = torch.empty(N, D, F, device=first.device, dtype=torch.float32)
         with torch.cuda.device(first.device):
             for r in range(R1):
