@@ -183,12 +183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
   // two prefetch slots: the fragments of K steps n + 1 and n + 2 are in flight while step n runs (the taps are visited in order, so
   // the K-step index is simply linear: n = tap * (cin/32) + q).  One step ahead left the k=7 SequenceCNN conv at 30 us = 28 steps x
   // one exposed L2 round trip; cin = 32 (one K step per tap) keeps the single slot.
-#ifdef W2S_WPF4   // experiment: four slots (steps n + 1 ... n + 4 in flight) where a wave owns <= 32 output channels
-  constexpr int WSL = (NTW <= 2) ? 4 : 2;
-#else
-  constexpr int WSL = 2;
-#endif
-  bf16x8 pah[WSL][NTW], pal[WSL][NTW];
+  bf16x8 pah[2][NTW], pal[2][NTW];
   const int NSTEP = TAPS * (cin >> 5);
   auto load_frag = [&](auto SLOT, int kidx_) {
     constexpr int SL = decltype(SLOT)::value;
@@ -201,10 +196,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
     }
   };
   using WS0 = std::integral_constant<int, 0>; using WS1 = std::integral_constant<int, 1>;
-  using WS2 = std::integral_constant<int, WSL == 4 ? 2 : 0>; using WS3 = std::integral_constant<int, WSL == 4 ? 3 : 1>;
-  const bool four = (WSL == 4) && !((cin >> 5) & 3);
   if constexpr (WPF) {
-    if (cin >= 32) { load_frag(WS0{}, 0); load_frag(WS1{}, 1); if (four) { load_frag(WS2{}, 2); load_frag(WS3{}, 3); } }
+    if (cin >= 32) { load_frag(WS0{}, 0); load_frag(WS1{}, 1); }
   }
 
   auto mma_tap = [&](int jw, int rowoff, int mtmask, int jw_next = -1) {
@@ -235,8 +228,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
       };
       if (QN & 1) {   // one K step per tap (cin = 32): slot 0 only, one step ahead
         for (int q = 0; q < QN; ++q) step(WS0{}, q, 1);
-      } else if (four) {
-        for (int q = 0; q < QN; q += 4) { step(WS0{}, q, 4); step(WS1{}, q + 1, 4); step(WS2{}, q + 2, 4); step(WS3{}, q + 3, 4); }
       } else {
         for (int q = 0; q < QN; q += 2) { step(WS0{}, q, 2); step(WS1{}, q + 1, 2); }
       }
