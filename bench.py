@@ -32,6 +32,7 @@ def pmc_key(name):
     """rocprofv3 kernel name -> the LaunchTimer key (conv_wide: <CI, NW, NP, STRIDE, PRO, EPI, MT, PD> -> <CI, NW, STRIDE, PRO, EPI>).
     Since round 4 the four persistent statistics producers carry a trailing FIN template argument (1: the instantiation with the in-kernel
     statistics finalisation); the keys do not."""
+    name = name.replace('conv_wide_np_kernel', 'conv_wide_kernel')   # (the forward instances' entry point without packed-fp32 selection)
     m = re.match(r'(conv_fwd_bf|bwd_fused_bf|bwd_fused|conv_wide|bwd_wide)_kernel<(.*), [01]>$', name)
     if m and m[2].count(',') + 2 == {'conv_fwd_bf': 6, 'bwd_fused_bf': 8, 'bwd_fused': 6, 'conv_wide': 11, 'bwd_wide': 11}[m[1]]:   # (names of this round: drop FIN)
         name = f'{m[1]}_kernel<{m[2]}>'

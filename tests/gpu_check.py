@@ -146,7 +146,7 @@ def t_conv_wide():
         lib.conv_forward(a)
         tag = f'wide dgrad {cg}->{ch} L{L} norm{int(aux_norm)} even{int(add_even)}'
         report(tag + f' (tile {tile})', gout, cl(want), tol=5e-5)
-        RES.append((tag + ' uses the persistent wide kernel', tile in (64, 128)))
+        RES.append((tag + ' uses the persistent wide kernel', tile in (32, 64, 128)))   # (128 -> 128: 32-position tiles since round 4)
         out = torch.zeros(B, ch, 2, device=dev); lib.stats_finalize(part, B, nt, ch, L, 0.0, 1, out)
         report(tag + ' sum g', out[..., 0], want.mean(2), tol=2e-5); report(tag + ' sum g*n', out[..., 1], (want * na).mean(2), tol=2e-5)
 

@@ -83,6 +83,7 @@ def test_encoder_ranges_are_one_contiguous_slice_next_to_the_trunk():
 def test_bench_bookkeeping_helpers():
     import bench
     assert bench.pmc_key('conv_wide_kernel<8, 8, 4, 1, 3, 1, 4, 2, 0, 0>') == 'conv_wide_kernel<8, 8, 1, 3, 1>'
+    assert bench.pmc_key('conv_wide_np_kernel<8, 8, 4, 1, 3, 1, 4, 2, 0, 0, 0>') == 'conv_wide_kernel<8, 8, 1, 3, 1>'   # (forward entry point, round 4)
     assert bench.pmc_key('wgrad_wide_kernel<4, 4, 2, 5, 3, 2, 4, 2, 2, 2>') == 'wgrad_wide_kernel<4, 4, 2, 5, 3>'
     assert bench.pmc_key('bwd_fused_bf_kernel<1, 1, 4, 1, 0, 0>') == 'bwd_fused_bf_kernel<1, 1, 4, 1, 0, 0>'
     # round 4: the persistent statistics producers carry a trailing FIN template argument that the timer keys do not

@@ -34,6 +34,8 @@ def conv_case(cin, cout, L, stride=1, pro=lib.PRO_IN_GELU, epi=lib.EPI_STATS, B=
     if epi in (lib.EPI_STATS, lib.EPI_GP):
         lib.set_part(a, part)
     keep = (x, x2, w, y, st, bst, ost, aux, part, wh, wl)   # the descriptor holds raw pointers
+    global LAST_PART
+    LAST_PART = part
     nbytes = 4 * (B * L * cin * (2 if pro >= lib.PRO_INBWD else 1) + B * Lo * cout * (2 if aux is not None else 1))
     flops = 2 * B * Lo * cout * cin * (1.5 if mode == lib.MODE_UP2 else taps)
     return (lambda keep=keep: lib.conv_forward(a)), nbytes, flops
@@ -102,6 +104,7 @@ def ffirst_case(L=983040, B=16):
     fn = lambda: lib.conv_fwd_fused(x=x, w=w, st_in=st, w1=w1, y=y, part=part, B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1, pro=lib.PRO_FIRST, nwg=nwg)
     return fn, 4 * (B * L + B * L * c), 2 * B * L * c * c * 3
 
+LAST_PART = None
 CASES = {
     'bfirst': bfirst_case,
     'ffirst': ffirst_case,
@@ -163,3 +166,7 @@ if __name__ == '__main__':
         fn, nb, fl = CASES[n]()
         ms = timeit(fn, a.iters)
         print(f'{n:8s} {ms*1e3:9.1f} us  {nb/ms/1e6:8.0f} GB/s  {fl/ms/1e9:7.1f} TF/s', flush=True)
+        if os.environ.get('W2S_STAMP') and LAST_PART is not None:   # diagnostic builds (-DW2S_WIDE_STAMP): cycle stamps of workgroup 0 in part[0..7]
+            v = LAST_PART.view(-1)[:8].tolist()
+            print(f'   stamps (cycles of workgroup 0): consumer K loop {v[0]:.0f}, epilogue {v[1]:.0f}, barrier {v[2]:.0f}, tiles {v[3]:.0f}; '
+                  f'producer stage {v[4]:.0f}, barrier {v[5]:.0f}, rounds {v[6]:.0f}', flush=True)

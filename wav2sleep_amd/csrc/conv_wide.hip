@@ -16,6 +16,9 @@
 //   * workgroups are persistent (grid-stride over (sample, tile)), one barrier per tile.
 #include <type_traits>
 #include "conv_cl.inl"
+#ifndef W2S_WIDE_AE_LATE
+#define W2S_WIDE_AE_LATE 1
+#endif
 
 struct WideP {
   const float* x; const float* x2; const float* st; const float* bst;
@@ -45,7 +48,7 @@ __device__ __forceinline__ void wsplit_store4(__bf16* hi, __bf16* lo, int off, f
 // t' = 2u + phase reads the gradient rows u, u+1; m-tiles alternate phase (mt & 1), their row block is mt >> 1.  Symmetric padding:
 // even outputs W_1^T g[u], odd outputs W_2^T g[u] + W_0^T g[u+1]; causal (pad 2): even W_2^T g[u] + W_0^T g[u+1], odd W_1^T g[u+1].
 template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2, int CZ, int FIN>   // CZ: UP2 with causal padding
-__global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
+__device__ __forceinline__ void conv_wide_body(const WideP& P) {
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 16 * MT;                            // output positions per tile (all consumer waves share them)
   constexpr int HC = CI * 16, OC = NW * 16, NPT = 64 * NP;
@@ -90,6 +93,10 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     // only control flow around vector-memory instructions is the loop itself: with the loads under `ok ? load : 0` branches hipcc
     // waited vmcnt(0) before every row -- it drained the whole prefetch queue each time, i.e. one load in flight per wave (measured:
     // producers alone 165 us for the 64-channel conv2, 3 us per tile round trip).
+#ifndef W2S_WIDE_PPRIO
+#define W2S_WIDE_PPRIO 1   // tuning: issue priority of the forward instances' producer waves
+#endif
+    if (EPI == W2S_EPI_STATS && W2S_WIDE_PPRIO) __builtin_amdgcn_s_setprio(W2S_WIDE_PPRIO);
     const int pt = tid - 64 * NW;
     constexpr int c4n = HC / 4, rstep = NPT / c4n, NH = (NR + rstep - 1) / rstep;
     const int myc4 = pt % c4n, row0 = pt / c4n, mych = myc4 * 4;
@@ -145,6 +152,21 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
       if constexpr (PD > 1) load_row(I1{}, 1, k);
       if constexpr (PD > 2) load_row(I2{}, 2, k);
     }
+#ifdef W2S_WIDE_STAMP   // diagnostic build only (tools/altlib.sh): cycles of block 0's first producer wave in stage / at the barrier -> part[4..7]
+    unsigned long long ts = 0, tb = 0;
+    for (int it = 0; it < NI; it += PD) {
+      unsigned long long c0 = __builtin_amdgcn_s_memtime();
+      stage(I0{}, it);
+      unsigned long long c1 = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+      unsigned long long c2 = __builtin_amdgcn_s_memtime();
+      ts += c1 - c0; tb += c2 - c1;
+      if constexpr (PD > 1) { c0 = __builtin_amdgcn_s_memtime(); stage(I1{}, it + 1); c1 = __builtin_amdgcn_s_memtime(); __syncthreads(); c2 = __builtin_amdgcn_s_memtime(); ts += c1 - c0; tb += c2 - c1; }
+      if constexpr (PD > 2) { c0 = __builtin_amdgcn_s_memtime(); stage(I2{}, it + 2); c1 = __builtin_amdgcn_s_memtime(); __syncthreads(); c2 = __builtin_amdgcn_s_memtime(); ts += c1 - c0; tb += c2 - c1; }
+    }
+    if (blockIdx.x == 0 && tid == 64 * NW) { P.part[4] = (float)ts; P.part[5] = (float)tb; P.part[6] = (float)NI; P.part[7] = (float)nt_wg; }
+    return;
+#endif
     for (int it = 0; it < NI; it += PD) {
       stage(I0{}, it);
       __syncthreads();
@@ -169,23 +191,30 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
     for (int e = 0; e < 4; ++e) { accL[ch0 + e] = (w2s_dd){0.0, 0.0}; accL[OC + ch0 + e] = (w2s_dd){0.0, 0.0}; }
   }
   __syncthreads();                     // round 0 of the producers: the first window is in buffer 0
+#ifdef W2S_WIDE_STAMP
+  unsigned long long tk = 0, te = 0, tw = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#endif
   for (int i = 0; i < NI - 1; ++i) {
     if (i >= nt_wg) { __syncthreads(); continue; }   // padding rounds of the producers' prefetch cycle
+#ifdef W2S_WIDE_STAMP
+    c0 = __builtin_amdgcn_s_memtime();
+#endif
     int b, tile;
     w2s_run_pos(run_b0, run_t0, P.ntiles, i, b, tile);
     const int t0 = tile * TM;
     const __bf16* hiL = lds + (i & 1) * BUF;
     const __bf16* loL = hiL + NR * RSE;
     // epilogue operands of THIS tile, issued now so that their latency hides behind the K loop
+    constexpr bool AE_LATE = W2S_WIDE_AE_LATE && NW >= 8 && UP2;
     f32x4 ax[EPI == W2S_EPI_GP ? MT : 1], ae[(EPI == W2S_EPI_GP && !UP2) ? MT : 1];
-    if (EPI == W2S_EPI_GP) {
+    if (EPI == W2S_EPI_GP && !AE_LATE) {
       const float* ab = P.aux + (size_t)b * L_out * OC;
       const float* eb = P.add_even ? P.add_even + (size_t)b * (L_out >> 1) * OC : nullptr;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int pos = UP2 ? t0 + 2 * ((mt >> 1) * 16 + r) + (mt & 1) : t0 + mt * 16 + r;
         ax[mt] = (pos < L_out) ? ld4o(ab, (unsigned)pos * OC + ch0) : (f32x4){0, 0, 0, 0};
-        if constexpr (!UP2) ae[mt] = (eb && !(pos & 1) && (pos >> 1) < (L_out >> 1)) ? ld4o(eb, (unsigned)(pos >> 1) * OC + ch0) : (f32x4){0, 0, 0, 0};
+        if constexpr (!UP2 && !AE_LATE) ae[mt] = (eb && !(pos & 1) && (pos >> 1) < (L_out >> 1)) ? ld4o(eb, (unsigned)(pos >> 1) * OC + ch0) : (f32x4){0, 0, 0, 0};
       }
     }
     f32x4 acc[MT];
@@ -201,15 +230,41 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
       for (int mt = 0; mt < MT; ++mt) {
         if (UP2 && (mt & 1) != phase) continue;
         const int row = UP2 ? (mt >> 1) * 16 + r + rowoff : (mt * 16 + r) * STRIDE + rowoff;
+#ifdef W2S_WIDE_NOLDS   // diagnostic builds (numerics wrong on purpose): the K loop without its LDS reads / without its MFMAs
+        const bf16x8 bh = ah[(ks + mt) % KS], bl = al[(ks + mt) % KS];
+#else
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hiL + row * RSE + q * 32 + 8 * g);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(loL + row * RSE + q * 32 + 8 * g);
+#endif
+#ifdef W2S_WIDE_NOMFMA
+        { typedef float f4 __attribute__((ext_vector_type(4))); f4 t1, t2; __builtin_memcpy(&t1, &bh, 16); __builtin_memcpy(&t2, &bl, 16); acc[mt] += t1 * t2; }
+#else
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh, acc[mt], 0, 0, 0);
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl, acc[mt], 0, 0, 0);
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh, acc[mt], 0, 0, 0);
+#endif
       }
     }
 
+    if constexpr (EPI == W2S_EPI_GP && AE_LATE) {
+      // 128 channels: 96 weight registers + accumulators + activation fragments leave no room for 16-32 epilogue operands across the K
+      // loop.  Prefetched before it they spilled weight fragments, and every reload in the loop carried `s_waitcnt vmcnt(0)` -- i.e. the K
+      // loop of each tile began by waiting for these very HBM loads, and ran with `lgkmcnt(0)` after every LDS read (3.7 x the cycles
+      // of the forward kernel's identical K loop, in-kernel stamps).  Issued here their latency is exposed once per tile instead.
+      const float* ab = P.aux + (size_t)b * L_out * OC;
+      const float* eb = P.add_even ? P.add_even + (size_t)b * (L_out >> 1) * OC : nullptr;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int pos = UP2 ? t0 + 2 * ((mt >> 1) * 16 + r) + (mt & 1) : t0 + mt * 16 + r;
+        ax[mt] = (pos < L_out) ? ld4o(ab, (unsigned)pos * OC + ch0) : (f32x4){0, 0, 0, 0};
+        if constexpr (!UP2) ae[mt] = (eb && !(pos & 1) && (pos >> 1) < (L_out >> 1)) ? ld4o(eb, (unsigned)(pos >> 1) * OC + ch0) : (f32x4){0, 0, 0, 0};
+      }
+    }
     // ---- epilogue
+#ifdef W2S_WIDE_STAMP
+    asm volatile("" :: "v"(acc[0]), "v"(acc[MT - 1]));
+    c1 = __builtin_amdgcn_s_memtime();
+#endif
     f32x4 sA = {0, 0, 0, 0}, sB = {0, 0, 0, 0};
     float* yb = P.y + (size_t)b * L_out * OC;
     f32x4 am = {0, 0, 0, 0}, ar = {1, 1, 1, 1};
@@ -257,11 +312,34 @@ __global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) {
         st4(d + OC, x2);
       }
     }
+#ifdef W2S_WIDE_STAMP
+    c2 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();   // the producers have staged the next window; this one may be overwritten
+#ifdef W2S_WIDE_STAMP
+    c3 = __builtin_amdgcn_s_memtime();
+    tk += c1 - c0; te += c2 - c1; tw += c3 - c2;
+#endif
   }
+#ifdef W2S_WIDE_STAMP
+  if (blockIdx.x == 0 && tid == 0) { P.part[0] = (float)tk; P.part[1] = (float)te; P.part[2] = (float)tw; P.part[3] = (float)nt_wg; }
+#endif
   // tickets of the samples this run touched (the consumer waves; the producers have passed their last barrier and end): the last
   // arriver of a sample finalises its statistics (w2s_common.h).  Scratch: the window buffers, dead now.
   if (FIN && P.fin.out) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, run_b0, (first + nt_wg - 1) / P.ntiles, OC, 1, 64 * NW, smem4);
+}
+
+// Two entry points over one body.  The forward instances (statistics epilogue) are PRODUCER-bound (in-kernel stamps, docs/lab_notes_r4.md
+// section 11): their four producer waves issue ~700 vector instructions per tile beside the consumers' MFMAs, and a packed-fp32
+// instruction issued beside a busy matrix pipe costs ~20 cycles more than the two plain ones it replaces (MI355X_MICROARCH.md, "price of
+// one filler beside MFMAs").  `conv_wide_np_kernel` is the same code compiled without packed-fp32 selection, with the producers at
+// s_setprio 1 (they are the younger waves and lose every issue arbitration otherwise).  The data-gradient instances are consumer-bound
+// (GELU' epilogue, no MFMA beside it) and keep the packed form.
+template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2, int CZ, int FIN>
+__global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) { conv_wide_body<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, FIN>(P); }
+template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2, int CZ, int FIN>
+__global__ __launch_bounds__(64 * (NW + NP)) __attribute__((target("no-packed-fp32-ops"))) void conv_wide_np_kernel(WideP P) {
+  conv_wide_body<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, FIN>(P);
 }
 
 template <int CI, int NW, int STRIDE, int PRO, int EPI, int MT, int NP = 4, int UP2 = 0, int CZ = 0>
@@ -280,8 +358,21 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s, int* rows_only = n
   constexpr int NHr = (NR + (64 * NP) / (HC / 4) - 1) / ((64 * NP) / (HC / 4));
   constexpr int SETV = NHr * 4 * (TWO ? 2 : 1);
   // bytes in flight per CU ~ PD x tile bytes x workgroups per CU >= ~64 KB; register sets beyond that only cost occupancy / spills
-  constexpr int PD = NW >= 8 ? (SETV <= 36 ? 2 : 1) : (SETV <= 12 ? 3 : SETV <= 24 ? 2 : 1);
-  auto kern = P.fin.out ? conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 1> : conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 0>;
+#ifndef W2S_WIDE_PD_A   // tuning: prefetch depths (A: 128-channel stride 1 forward, B: its stride-2 form, C / D: the 64-channel ones)
+#define W2S_WIDE_PD_A 2
+#define W2S_WIDE_PD_B 1
+#define W2S_WIDE_PD_C 2
+#define W2S_WIDE_PD_D 1
+#endif
+  constexpr int PD = TWO ? (NW >= 8 ? (SETV <= 36 ? 2 : 1) : (SETV <= 12 ? 3 : SETV <= 24 ? 2 : 1))
+                         : NW >= 8 ? (SETV <= 36 ? W2S_WIDE_PD_A : SETV <= 68 ? W2S_WIDE_PD_B : 1) : (SETV <= 12 ? 3 : SETV <= 24 ? W2S_WIDE_PD_C : SETV <= 36 ? W2S_WIDE_PD_D : 1);
+#ifndef W2S_WIDE_NP
+#define W2S_WIDE_NP 1   // tuning: 0 = every instance in the packed form
+#endif
+  constexpr bool NPK = W2S_WIDE_NP && EPI == W2S_EPI_STATS;
+  void (*kern)(WideP);
+  if constexpr (NPK) kern = P.fin.out ? conv_wide_np_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 1> : conv_wide_np_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 0>;
+  else kern = P.fin.out ? conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 1> : conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 0>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -320,27 +411,35 @@ static int wide_mt() { return 4; }   // 64-position tiles (128 were tried: no ga
 int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry, int* rows) {
   if (!wide_shape(a)) return 1;
   const int mt = wide_mt();
-#define W2S_WIDE(CI_, NW_, ST_, PRO_, EPI_) \
+#define W2S_WIDE_M(CI_, NW_, ST_, PRO_, EPI_, MT_) \
   if (a.mode == W2S_MODE_CONTIG && a.cin == 16 * CI_ && a.cout == 16 * NW_ && a.stride == ST_ && a.pro == PRO_ && a.epi == EPI_) { \
-    if (dry && rows) launch_wide<CI_, NW_, ST_, PRO_, EPI_, 4>(a, s, rows); \
-    if (dry) return 16 * mt; \
-    return launch_wide<CI_, NW_, ST_, PRO_, EPI_, 4>(a, s); \
+    if (dry && rows) launch_wide<CI_, NW_, ST_, PRO_, EPI_, MT_>(a, s, rows); \
+    if (dry) return 16 * MT_; \
+    return launch_wide<CI_, NW_, ST_, PRO_, EPI_, MT_>(a, s); \
   }
+#define W2S_WIDE(CI_, NW_, ST_, PRO_, EPI_) W2S_WIDE_M(CI_, NW_, ST_, PRO_, EPI_, 4)
+#ifndef W2S_WIDE_MT_D128
+#define W2S_WIDE_MT_D128 2   // tuning: m-tiles of the 128 -> 128 stride-1 data gradient
+#endif
+#ifndef W2S_UP2_MT128
+#define W2S_UP2_MT128 4   // tuning: m-tiles of the 128-channel transposed data gradient
+#endif
   W2S_WIDE(2, 4, 1, W2S_PRO_GELU, W2S_EPI_STATS) W2S_WIDE(4, 4, 1, W2S_PRO_GELU, W2S_EPI_STATS)
   W2S_WIDE(4, 8, 1, W2S_PRO_GELU, W2S_EPI_STATS) W2S_WIDE(8, 8, 1, W2S_PRO_GELU, W2S_EPI_STATS)
   W2S_WIDE(4, 4, 1, W2S_PRO_IN_GELU, W2S_EPI_STATS) W2S_WIDE(8, 8, 1, W2S_PRO_IN_GELU, W2S_EPI_STATS)
   W2S_WIDE(4, 4, 2, W2S_PRO_IN_GELU, W2S_EPI_STATS) W2S_WIDE(8, 8, 2, W2S_PRO_IN_GELU, W2S_EPI_STATS)
-  W2S_WIDE(4, 4, 1, W2S_PRO_INBWD, W2S_EPI_GP) W2S_WIDE(8, 8, 1, W2S_PRO_INBWD, W2S_EPI_GP)
+  W2S_WIDE(4, 4, 1, W2S_PRO_INBWD, W2S_EPI_GP) W2S_WIDE_M(8, 8, 1, W2S_PRO_INBWD, W2S_EPI_GP, W2S_WIDE_MT_D128)
   W2S_WIDE(4, 2, 1, W2S_PRO_INBWD, W2S_EPI_GP) W2S_WIDE(8, 4, 1, W2S_PRO_INBWD, W2S_EPI_GP)
 #undef W2S_WIDE
+#undef W2S_WIDE_M
   if (a.mode == W2S_MODE_UP2) {   // 64-position tiles = 32 gradient rows + 1 (128-position tiles spill)
 #ifndef W2S_UP2_MT
 #define W2S_UP2_MT 8
 #endif
     if (a.cin == 64 && a.pad == 1) { if (dry && rows) launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s, rows); return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s); }
     if (a.cin == 64 && a.pad == 2) { if (dry && rows) launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s, rows); return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s); }
-    if (a.cin == 128 && a.pad == 1) { if (dry && rows) launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s, rows); return dry ? 16 * W2S_UP2_MT : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s); }
-    if (a.cin == 128 && a.pad == 2) { if (dry && rows) launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s, rows); return dry ? 16 * W2S_UP2_MT : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s); }
+    if (a.cin == 128 && a.pad == 1) { if (dry && rows) launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT128, 4, 1, 0>(a, s, rows); return dry ? 16 * W2S_UP2_MT128 : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT128, 4, 1, 0>(a, s); }
+    if (a.cin == 128 && a.pad == 2) { if (dry && rows) launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT128, 4, 1, 1>(a, s, rows); return dry ? 16 * W2S_UP2_MT128 : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT128, 4, 1, 1>(a, s); }
   }
   return 1;
 }

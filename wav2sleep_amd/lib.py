@@ -237,7 +237,7 @@ def conv_forward(a: ConvArgs):
     taps_eff = 1.5 if a.mode == MODE_UP2 else a.taps
     flops = int(2 * out_el * a.cin * taps_eff)
     wide_up2 = a.mode == MODE_UP2 and a.w_hi and a.cin >= 64 and a.cin == a.cout and a.epi == EPI_GP and a.pro == PRO_INBWD_GP and not a.add_even
-    if a.taps == 3 and a.w_hi and load().w2s_conv_tile(C.byref(a)) in (64, 128) and a.cout >= 32 and max(a.cin, a.cout) >= 64 \
+    if a.taps == 3 and a.w_hi and load().w2s_conv_tile(C.byref(a)) in (32, 64, 128) and a.cout >= 32 and max(a.cin, a.cout) >= 64 \
             and ((a.mode == MODE_CONTIG and (a.epi, bool(a.flip)) in ((EPI_STATS, False), (EPI_GP, True))) or wide_up2):
         key = f'conv_wide_kernel<{a.cin // 16}, {a.cout // 16}, {1 if wide_up2 else a.stride}, {a.pro}, {a.epi}>'
         if DETAIL:
