@@ -104,8 +104,39 @@ def ffirst_case(L=983040, B=16):
     fn = lambda: lib.conv_fwd_fused(x=x, w=w, st_in=st, w1=w1, y=y, part=part, B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1, pro=lib.PRO_FIRST, nwg=nwg)
     return fn, 4 * (B * L + B * L * c), 2 * B * L * c * c * 3
 
+def bwd_wide_case(L, stride=1, hst=True, rd=False, ch=64, B=16):
+    """one-pass backward of a 64-channel k=3 conv (w2s_bwd_wide) at the benchmark's shapes: stride 1 (conv2: hst, conv1: not, optionally with the
+    residual fold) or the block's stride-2 conv3"""
+    cg = 64
+    Lg = L // stride
+    g = torch.randn(B, Lg, cg, device=dev); y = torch.randn(B, Lg, cg, device=dev); xin = torch.randn(B, L, ch, device=dev)
+    st = torch.rand(B, cg, 2, device=dev) + 0.5; bst = torch.rand(B, cg, 2, device=dev) * 0.01; sti = torch.rand(B, ch, 2, device=dev) + 0.5
+    w = torch.randn(ch, 3 * cg, device=dev) / (3 * cg) ** 0.5
+    wh, wl = lib.frag_major_planes(w)
+    gout = torch.empty(B, L, ch, device=dev)
+    tile = lib.bwd_wide_tile(cg, ch, stride); nt = (L + tile - 1) // tile; grp = lib.bwd_wide_groups(cg, ch, stride)
+    part = torch.empty(B, nt, grp, 2, ch, device=dev)
+    ns = min(256, B * nt)
+    slab = torch.empty(ns, cg * 3 * ch, device=dev)
+    kw = {}
+    if rd:
+        wd = torch.randn(ch, cg, device=dev) / cg ** 0.5
+        dh, dl = lib.frag_major_planes(wd)
+        kw = dict(gpre=torch.randn(B, L // 2, cg, device=dev), wd_hi=dh, wd_lo=dl, slab_d=torch.empty(ns, cg * ch, device=dev))
+    global LAST_PART
+    LAST_PART = part
+    fn = lambda: lib.bwd_wide(g=g, y=y, st_k=st, bst_k=bst, xin=xin, st_in=sti if hst else None, add_even=None, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab,
+                              nslab=ns, B=B, L=L, cg=cg, ch=ch, stride=stride, **kw)
+    nbytes = 4 * (2 * B * Lg * cg + 2 * B * L * ch + (B * L * cg // 2 if rd else 0))
+    return fn, nbytes, 2 * B * Lg * cg * ch * 3 * 2
+
+
 LAST_PART = None
 CASES = {
+    'bw64': lambda: bwd_wide_case(61440),
+    'bw64c1': lambda: bwd_wide_case(61440, hst=False),
+    'bw64rd': lambda: bwd_wide_case(61440, hst=False, rd=True),
+    'bw64u': lambda: bwd_wide_case(61440, stride=2),
     'bfirst': bfirst_case,
     'ffirst': ffirst_case,
     'ff16': lambda: ffwd_case(16, 16, 983040),
@@ -168,5 +199,5 @@ if __name__ == '__main__':
         print(f'{n:8s} {ms*1e3:9.1f} us  {nb/ms/1e6:8.0f} GB/s  {fl/ms/1e9:7.1f} TF/s', flush=True)
         if os.environ.get('W2S_STAMP') and LAST_PART is not None:   # diagnostic builds (-DW2S_WIDE_STAMP): cycle stamps of workgroup 0 in part[0..7]
             v = LAST_PART.view(-1)[:8].tolist()
-            print(f'   stamps (cycles of workgroup 0): consumer K loop {v[0]:.0f}, epilogue {v[1]:.0f}, barrier {v[2]:.0f}, tiles {v[3]:.0f}; '
+            print(f'   stamps (cycles of workgroup 0): consumer K loop {v[0]:.0f}, epilogue {v[1]:.0f}, barrier {v[2]:.0f}, tiles (bwd_wide: weight-gradient loop) {v[3]:.0f}; '
                   f'producer stage {v[4]:.0f}, barrier {v[5]:.0f}, rounds {v[6]:.0f}', flush=True)

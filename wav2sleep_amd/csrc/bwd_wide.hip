@@ -58,7 +58,7 @@ __device__ __forceinline__ bf16x8 wb_tr8(const __bf16* p0, const __bf16* p1) {
 // CO / CI: 16-channel tiles on the gradient / input side; HST: xin carries statistics (conv2); MT: 16-position m-tiles per tile;
 // NWC consumer waves = (CO / IB) x (CI / CB) weight-gradient owners = CI x (NWC / CI) data-gradient owners; PD: producer prefetch depth
 template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD, int FIN>
-__global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
+__device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
   static_assert(!RD || (!UP2 && !HST && MT % 2 == 0), "residual fold: the stride-1 conv1 (its input is a stored pre-activation)");
   extern __shared__ f32x4 smem4[];
   static_assert((CO / IB) * (CI / CB) == NWC && NWC % CI == 0 && MT % (NWC / CI) == 0, "consumer wave grid");
@@ -106,6 +106,10 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
 
   if (wave >= NWC) {
     // ================================================= producer waves =================================================
+#ifndef W2S_BWW_PPRIO
+#define W2S_BWW_PPRIO 1   // issue priority of the producer waves (the kernel is producer-bound: in-kernel stamps, docs/lab_notes_r4.md section 11)
+#endif
+    if (W2S_BWW_PPRIO) __builtin_amdgcn_s_setprio(W2S_BWW_PPRIO);
     const int pt = tid - 64 * NWC;
     constexpr int c4g = OC / 4, rsg = NPT / c4g, NG = (NRG + rsg - 1) / rsg;
     constexpr int c4h = HC / 4, rsh = NPT / c4h, NH = (NR + rsh - 1) / rsh;
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     const int hch = (pt % c4h) * 4, hrow0 = pt / c4h;
     constexpr int NP = RD ? (TM / 2 + rsg - 1) / rsg : 1;
     f32x4 rg[PD][NG] = {}, ry[PD][NG] = {}, rh[PD][NH] = {}, rp[RD ? PD : 1][NP] = {};
+    // (the run position is looked up per row: hoisting it to once per tile was measured 5 % SLOWER here -- the scalar work spaces the loads)
     auto load_p = [&](auto SET, int i, int k) {
       constexpr int S = decltype(SET)::value;
       int b, tile_;
@@ -167,8 +172,16 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
         const f32x4 v1 = rg[S][k], v2 = ry[S][k];
         load_g(SET, i + PD, k);
         if (live && row < NRG) {
+#ifdef W2S_BWW_NOARITH   // diagnostic builds (numerics wrong on purpose): the producers without their transform arithmetic
+          const f32x4 tv = v1 + v2 * pm;
+#else
           const f32x4 tv = pro_apply(UP2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD, v1, v2, pm, pr, ps1, ps2);
+#endif
+#ifndef W2S_BWW_NOLDSW
           wb_split_store4(gH, gL, row * RSg + gch, (gr >= 0 && gr < Lg) ? tv : (f32x4){0, 0, 0, 0});
+#else
+          if (tv.x == 123.f) wb_split_store4(gH, gL, row * RSg + gch, tv);
+#endif
         }
       }
       f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
@@ -184,9 +197,17 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
         load_h(SET, i + PD, k);
         if (live && row < NR) {
           f32x4 hv, gpv;
+#ifdef W2S_BWW_NOARITH
+          hv = (v - hm) * hr; gpv = hv;
+#else
           gelu_both4((v - hm) * hr, hv, gpv);
+#endif
+#ifndef W2S_BWW_NOLDSW
           wb_split_store4(hH, hL, row * RSh + hch, (gr >= 0 && gr < L) ? hv : (f32x4){0, 0, 0, 0});
           if (row >= 1 && row <= TM) st4(gpL + (row - 1) * RSp + hch, gpv);
+#else
+          if (hv.x == 123.f) { wb_split_store4(hH, hL, row * RSh + hch, hv); st4(gpL + (row - 1) * RSp + hch, gpv); }
+#endif
         }
       }
       if constexpr (RD) {
@@ -220,6 +241,18 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
         if constexpr (PD > 2) load_p(I2{}, 2, k);
       }
     }
+#ifdef W2S_WIDE_STAMP   // diagnostic build only (tools/altlib.sh): cycles of block 0's first producer wave in stage / at the barrier -> part[4..7]
+    {
+      unsigned long long ts = 0, tb = 0, c0, c1, c2;
+      for (int it = 0; it < NI; it += PD) {
+        c0 = __builtin_amdgcn_s_memtime(); stage(I0{}, it); c1 = __builtin_amdgcn_s_memtime(); __syncthreads(); c2 = __builtin_amdgcn_s_memtime(); ts += c1 - c0; tb += c2 - c1;
+        if constexpr (PD > 1) { c0 = __builtin_amdgcn_s_memtime(); stage(I1{}, it + 1); c1 = __builtin_amdgcn_s_memtime(); __syncthreads(); c2 = __builtin_amdgcn_s_memtime(); ts += c1 - c0; tb += c2 - c1; }
+        if constexpr (PD > 2) { c0 = __builtin_amdgcn_s_memtime(); stage(I2{}, it + 2); c1 = __builtin_amdgcn_s_memtime(); __syncthreads(); c2 = __builtin_amdgcn_s_memtime(); ts += c1 - c0; tb += c2 - c1; }
+      }
+      if (blockIdx.x == 0 && tid == 64 * NWC && P.part) { P.part[4] = (float)ts; P.part[5] = (float)tb; P.part[6] = (float)NI; P.part[7] = (float)nt_wg; }
+      return;
+    }
+#endif
     for (int it = 0; it < NI; it += PD) {
       stage(I0{}, it);
       __syncthreads();
@@ -268,8 +301,14 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
     for (int e = 0; e < 4; ++e) { accW[ch0 + e] = (w2s_dd){0.0, 0.0}; accW[HC + ch0 + e] = (w2s_dd){0.0, 0.0}; }
   }
   __syncthreads();                   // round 0 of the producers: the first windows are in buffer 0
+#ifdef W2S_WIDE_STAMP
+  unsigned long long tk = 0, te = 0, tg = 0, tw = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+#endif
   for (int it = 0; it < NI - 1; ++it) {
     if (it >= nt_wg) { __syncthreads(); continue; }   // padding rounds of the producers' prefetch cycle
+#ifdef W2S_WIDE_STAMP
+    c0 = __builtin_amdgcn_s_memtime();
+#endif
     int b, tile;
     w2s_run_pos(run_b0, run_t0, P.ntiles, it, b, tile);
     const int t0 = tile * TM;
@@ -325,6 +364,10 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
         }
     }
     // ---- epilogue: * GELU'(n_in), statistics partials, store
+#ifdef W2S_WIDE_STAMP
+    asm volatile("" :: "v"(acc[0]), "v"(acc[MTW - 1]));
+    c1 = __builtin_amdgcn_s_memtime();
+#endif
     f32x4 sA = {0, 0, 0, 0}, sB = {0, 0, 0, 0};
     f32x4 am = {0, 0, 0, 0}, ar = {1, 1, 1, 1};
     if (P.y3p) {
@@ -371,6 +414,9 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
       }
     }
     // ---- weight gradient: k-step = 32 positions; gradient-side position p <-> gy window row p + 1, h[t + j - 1] <-> window row p + j
+#ifdef W2S_WIDE_STAMP
+    c2 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int s = 0; s < TG / 32; ++s) {
       const int p0 = 32 * s + 8 * g + q4;   // this lane's address row (gradient-side position) of the first 4-position block
@@ -424,8 +470,19 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
         }
       }
     }
+#ifdef W2S_WIDE_STAMP
+    asm volatile("" :: "v"(accw[0][0][0]), "v"(accw[IB - 1][2][CB - 1]));
+    c3 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();   // the producers have staged the next windows; these may be overwritten
+#ifdef W2S_WIDE_STAMP
+    c4 = __builtin_amdgcn_s_memtime();
+    tk += c1 - c0; te += c2 - c1; tg += c3 - c2; tw += c4 - c3;
+#endif
   }
+#ifdef W2S_WIDE_STAMP
+  if (blockIdx.x == 0 && tid == 0 && P.part) { P.part[0] = (float)tk; P.part[1] = (float)te; P.part[2] = (float)tw; P.part[3] = (float)tg; }
+#endif
   if (RD) {
     float* outd = P.slab_d + (size_t)blockIdx.x * (CO * CI) * 256 + lane * 4;
 #pragma unroll
@@ -445,6 +502,14 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) {
   if (FIN && P.fin.out) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, run_b0, (first + nt_wg - 1) / P.ntiles, HC, PG, 64 * NWC, smem4);
 }
 
+// (two entry points over one body, as conv_wide.hip: the second without packed-fp32 instruction selection)
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD, int FIN>
+__global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) { bwd_wide_body<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, FIN>(P); }
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD, int FIN>
+__global__ __launch_bounds__(64 * (NWC + 4)) __attribute__((target("no-packed-fp32-ops"))) void bwd_wide_np_kernel(BwdWideP P) {
+  bwd_wide_body<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, FIN>(P);
+}
+
 template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0, int RD = 0>
 static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
   constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NR = TM + 2, NRG = UP2 ? TM / 2 + 1 : TM + 2, NRP = RD ? TM / 2 + 1 : 0;
@@ -456,7 +521,12 @@ static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
   if (dry) return 0;
   if (nslab <= 0 || (long)nslab > (long)P.B * P.ntiles) return W2S_EINVAL;   // every workgroup writes a slab: it needs a tile
   P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, nslab) * (NWC / CI);
-  auto kern = P.fin.out ? bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 1> : bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 0>;
+#ifndef W2S_BWW_NP
+#define W2S_BWW_NP 0   // tuning: 1 = the entry point without packed-fp32 selection
+#endif
+  void (*kern)(BwdWideP);
+  if constexpr (W2S_BWW_NP) kern = P.fin.out ? bwd_wide_np_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 1> : bwd_wide_np_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 0>;
+  else kern = P.fin.out ? bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 1> : bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 0>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;

@@ -101,15 +101,22 @@ __device__ __forceinline__ void conv_wide_body(const WideP& P) {
     constexpr int c4n = HC / 4, rstep = NPT / c4n, NH = (NR + rstep - 1) / rstep;
     const int myc4 = pt % c4n, row0 = pt / c4n, mych = myc4 * 4;
     f32x4 rx[PD][NH], rx2[TWO ? PD : 1][TWO ? NH : 1];
-    auto load_row = [&](auto SET, int i, int k) {   // row k of this workgroup's tile number min(i, nt_wg - 1)
-      constexpr int S = decltype(SET)::value;
+    // (sample base, first window row) of this workgroup's tile number min(i, nt_wg - 1): ONCE per tile -- looked up per row, the run
+    // position (a scalar loop) and the 64-bit base were recomputed NH times per stage and not merged by the compiler
+    struct TileAt { const float* x; const float* x2; int rb; };
+    auto tile_at = [&](int i) {
       int b, tile_;
       w2s_run_pos(run_b0, run_t0, P.ntiles, min(i, nt_wg - 1), b, tile_);
       const int t0 = tile_ * TM;
-      const int row = min(row0 + k * rstep, NR - 1), gr = min(max((UP2 ? t0 / 2 : t0 * STRIDE - P.pad) + row, 0), L_in - 1);
+      const size_t sb = (size_t)b * L_in * HC;
+      return TileAt{P.x + sb, TWO ? P.x2 + sb : nullptr, UP2 ? t0 / 2 : t0 * STRIDE - P.pad};
+    };
+    auto load_row = [&](auto SET, const TileAt& ta, int k) {   // window row k of that tile
+      constexpr int S = decltype(SET)::value;
+      const int row = min(row0 + k * rstep, NR - 1), gr = min(max(ta.rb + row, 0), L_in - 1);
       const unsigned off = (unsigned)gr * HC + mych;
-      rx[S][k] = ld4o(P.x + (size_t)b * L_in * HC, off);
-      if constexpr (TWO) rx2[S][k] = ld4o(P.x2 + (size_t)b * L_in * HC, off);
+      rx[S][k] = ld4o(ta.x, off);
+      if constexpr (TWO) rx2[S][k] = ld4o(ta.x2, off);
     };
     // stage tile i (its raw rows are in register set SET) into LDS buffer i & 1, refilling the set with tile i + PD
     auto stage = [&](auto SET, int i) {
@@ -132,12 +139,13 @@ __device__ __forceinline__ void conv_wide_body(const WideP& P) {
           ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z}; ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
         }
       }
+      const TileAt nxt = tile_at(i + PD);
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
         const int row = row0 + k * rstep, gr = rb + row;
         f32x4 v1 = rx[S][k], v2 = rx[S][k];
         if constexpr (TWO) v2 = rx2[S][k];
-        load_row(SET, i + PD, k);   // the register is free again: the load of the tile PD rounds ahead goes out at once
+        load_row(SET, nxt, k);   // the register is free again: the load of the tile PD rounds ahead goes out at once
         if (live && row < NR && !(P.dbg & 4)) {
           const bool ok = gr >= 0 && gr < L_in;
           const f32x4 tv = (P.dbg & 1) ? v1 + v2 : pro_apply(PRO, v1, v2, pm, pr, ps1, ps2);
@@ -146,11 +154,14 @@ __device__ __forceinline__ void conv_wide_body(const WideP& P) {
       }
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    {
+      const TileAt a0 = tile_at(0), a1 = tile_at(1), a2 = tile_at(2);
 #pragma unroll
-    for (int k = 0; k < NH; ++k) {
-      load_row(I0{}, 0, k);
-      if constexpr (PD > 1) load_row(I1{}, 1, k);
-      if constexpr (PD > 2) load_row(I2{}, 2, k);
+      for (int k = 0; k < NH; ++k) {
+        load_row(I0{}, a0, k);
+        if constexpr (PD > 1) load_row(I1{}, a1, k);
+        if constexpr (PD > 2) load_row(I2{}, a2, k);
+      }
     }
 #ifdef W2S_WIDE_STAMP   // diagnostic build only (tools/altlib.sh): cycles of block 0's first producer wave in stage / at the barrier -> part[4..7]
     unsigned long long ts = 0, tb = 0;
