@@ -71,6 +71,10 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void wgrad_wide_kernel(WgWideP P) {
 
   if (wave >= NWC) {
     // ================================================= producer waves =================================================
+#ifndef W2S_WGW_PPRIO
+#define W2S_WGW_PPRIO 1   // issue priority of the producer waves (128 -> 128: -4 %, the other shapes neutral)
+#endif
+    if (W2S_WGW_PPRIO) __builtin_amdgcn_s_setprio(W2S_WGW_PPRIO);
     const int pt = tid - 64 * NWC;
     constexpr int c4g = OC / 4, rsg = NPT / c4g, NG = (TM + rsg - 1) / rsg;
     constexpr int c4h = HC / 4, rsh = NPT / c4h, NH = (NRh + rsh - 1) / rsh;
