@@ -65,6 +65,8 @@ def fused_case(cg, ch, L, stride=1, B=16, nslab=None):
     part = torch.empty(B, nt, 2, ch, device=dev)
     ns = nslab or int(os.environ.get('NSLAB', 1024))
     slab = torch.empty(ns * cg * ch * 3, device=dev)
+    global LAST_PART
+    LAST_PART = part
     fn = lambda: lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=lib.PRO_INBWD if stride == 1 else lib.PRO_INBWD_GP, xin=xin, st_in=sti, add_even=None,
                                wb=wb, gout=gout, part=part, slab=slab, nslab=ns, B=B, Lg=Lg, Lh=L, cg=cg, ch=ch, stride=stride, split_precision=os.environ.get('BF') == '1')
     return fn, 4 * (2 * B * Lg * cg + 2 * B * L * ch), 2 * B * Lg * cg * ch * 3 * 2
@@ -197,7 +199,11 @@ if __name__ == '__main__':
         fn, nb, fl = CASES[n]()
         ms = timeit(fn, a.iters)
         print(f'{n:8s} {ms*1e3:9.1f} us  {nb/ms/1e6:8.0f} GB/s  {fl/ms/1e9:7.1f} TF/s', flush=True)
-        if os.environ.get('W2S_STAMP') and LAST_PART is not None:   # diagnostic builds (-DW2S_WIDE_STAMP): cycle stamps of workgroup 0 in part[0..7]
+        if os.environ.get('W2S_STAMP') and LAST_PART is not None and n.startswith('b') and not n.startswith('bw') and n != 'bfirst':
+            v = LAST_PART.view(-1)[:8].tolist()   # bwd_fused_bf (-DW2S_WIDE_STAMP): phases of workgroup 0's first wave
+            print(f'   stamps (cycles, {v[6]:.0f} tiles): barrier A {v[0]:.0f}, wait for the prefetched loads {v[1]:.0f}, commit {v[2]:.0f}, prefetch issue + barrier B {v[3]:.0f}, '
+                  f'data gradient + epilogue {v[4]:.0f}, weight gradient {v[5]:.0f}; in-kernel clock {v[7]:.0f} MHz', flush=True)
+        elif os.environ.get('W2S_STAMP') and LAST_PART is not None:   # diagnostic builds (-DW2S_WIDE_STAMP): cycle stamps of workgroup 0 in part[0..7]
             v = LAST_PART.view(-1)[:8].tolist()
             print(f'   stamps (cycles of workgroup 0): consumer K loop {v[0]:.0f}, epilogue {v[1]:.0f}, barrier {v[2]:.0f}, tiles (bwd_wide: weight-gradient loop) {v[3]:.0f}; '
                   f'producer stage {v[4]:.0f}, barrier {v[5]:.0f}, rounds {v[6]:.0f}', flush=True)

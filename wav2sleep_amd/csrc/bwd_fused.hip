@@ -613,18 +613,37 @@ void bwd_fused_bf_kernel(BwdP P) {
   if (tid < 2 * HC) accL[tid] = (w2s_dd){0.0, 0.0};
   int b = wrun.first / P.ntiles, tile = wrun.first - b * P.ntiles;   // one division per launch; the run is contiguous
   if (wrun.count > 0) prefetch(b, tile);
+#ifdef W2S_WIDE_STAMP   // diagnostic build only (tools/altlib.sh; W2S_STAMP=1 tools/kbench.py): cycles of workgroup 0's first wave per phase -> part[0..7]
+  unsigned long long sA_ = 0, sW_ = 0, sC_ = 0, sB_ = 0, sD_ = 0, sG_ = 0, k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, k6 = 0;
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();   // (100 MHz / shader clock)
+#endif
   for (int tl = wrun.first; tl < wend; ++tl) {
     const int t0 = tile * TM;
     const int tile_n = tile + 1 == P.ntiles ? 0 : tile + 1, b_n = tile + 1 == P.ntiles ? b + 1 : b;   // the next tile of the run
+#ifdef W2S_WIDE_STAMP
+    k0 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef W2S_WIDE_STAMP
+    k1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    k2 = __builtin_amdgcn_s_memtime();
+#endif
     commit(b, tile);
     f32x4 q3[RD ? MT * CH : 1];  // this tile's y3 fragments (the prefetch below reloads rq for the next tile)
     if (RD) {
 #pragma unroll
       for (int i = 0; i < MT * CH; ++i) q3[i] = rq[i];
     }
+#ifdef W2S_WIDE_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    k3 = __builtin_amdgcn_s_memtime();
+#endif
     if (tl + 1 < wend) prefetch(b_n, tile_n);
     __syncthreads();
+#ifdef W2S_WIDE_STAMP
+    k4 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- data gradient
     f32x4 acc[MT][CH];
@@ -870,6 +889,9 @@ void bwd_fused_bf_kernel(BwdP P) {
     }
 
     // ---- weight gradient: k-step = 32 gradient-side positions; lane group g covers positions 8g..8g+7 of the step
+#ifdef W2S_WIDE_STAMP
+    k5 = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int KS = (UP2 ? TM / 2 : TM) / 32;
 #pragma unroll
     for (int s0 = 0; s0 < KS; s0 += KW) {
@@ -904,8 +926,20 @@ void bwd_fused_bf_kernel(BwdP P) {
         accd = mfma_bf3(ah, al, bh, bl, accd);
       }
     }
+#ifdef W2S_WIDE_STAMP
+    asm volatile("" :: "v"(accw[0]), "v"(accw[2]));
+    k6 = __builtin_amdgcn_s_memtime();
+    sA_ += k1 - k0; sW_ += k2 - k1; sC_ += k3 - k2; sB_ += k4 - k3; sD_ += k5 - k4; sG_ += k6 - k5;
+#endif
     b = b_n; tile = tile_n;
   }
+#ifdef W2S_WIDE_STAMP
+  if (blockIdx.x == 0 && tid == 0 && P.part) {
+    P.part[0] = (float)sA_; P.part[1] = (float)sW_; P.part[2] = (float)sC_; P.part[3] = (float)sB_; P.part[4] = (float)sD_; P.part[5] = (float)sG_;
+    P.part[6] = (float)wrun.count;
+    P.part[7] = (float)(__builtin_amdgcn_s_memtime() - ct0) / (float)(__builtin_amdgcn_s_memrealtime() - rt0) * 100.f;   // in-kernel clock, MHz
+  }
+#endif
 
   if (OH) w2s_amax_commit(P.hdr_o, amax, s_out);
   if (WDFC && P.part_wd && tid >= 112 && tid < 128) P.part_wd[(size_t)blockIdx.x * 16 + (tid - 112)] = accD[tid - 112];
