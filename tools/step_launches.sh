@@ -2,6 +2,7 @@
 # Launch census of ONE steady-state train step (run on the GPU box): tools/step_launches.sh  -> gpurun_out/step_launches.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export W2S_MULTI_STREAM=0
+rm -rf gpurun_out/steptrace   # (a second run in one session must not pick up the first run's trace)
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/steptrace -- python3 bench.py --steps 3 --warmup 2 --no-cpu --no-roofline > gpurun_out/steptrace.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Phase / stream timeline of ONE steady-state train step as bench.py runs it (multi-stream): tools/step_timeline.sh -> gpurun_out/step_timeline.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/tl   # (a second run in one session must not pick up the first run's trace)
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 3 --warmup 2 --no-cpu --no-roofline > gpurun_out/tl.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
