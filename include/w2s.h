@@ -170,7 +170,8 @@ int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const
  * split_precision != 0: both products run as bf16x3 (hi/lo planes in LDS, fp32 accumulate).
  * Replaces aten::convolution_backward + native_batch_norm_backward + gelu_backward of blocks.py:173-186.
  */
-int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd);   /* rd: the residual-fold form (gpre != NULL) */
+int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd, int split_precision);   /* rd: the residual-fold form (gpre != NULL); split_precision: the
+ * split-precision kernels' tiles are two positions short of 256 / 128 (254 / 126: their staged windows are whole passes) */
 int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                   const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
                   int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const float* gpre, const float* wd,
@@ -212,7 +213,7 @@ int w2s_enc_first_bwd_h(const float* x, const void* gn1, const float* hdr_n, con
                         void* stream);
 /* Block 0's conv1 weight gradient without its gradient tensor.  w2s_bwd_fused_w1 = w2s_bwd_fused for conv2 of block 0 in the first-layer
  * recompute form (x = raw signal [B][L], w1 = conv1 weight [16][3], 16 -> 16 channels, stride 1, split precision) that ALSO leaves
- * part_w1 [B][ceil(L / w2s_bwd_fused_tile(16,16,1,0))][16][3] = per-tile sums of gout[t][o] * xs[t + j - pad]; gout may be NULL (the folded
+ * part_w1 [B][ceil(L / w2s_bwd_fused_tile(16,16,1,0,1))][16][3] = per-tile sums of gout[t][o] * xs[t + j - pad]; gout may be NULL (the folded
  * sums were its only reader: 1 GB per 1024-samples-per-epoch signal at batch 16 neither written nor read back).  w2s_enc_first_wgrad turns
  * the partials into out [B][48] = each sample's contribution to dW1[o][j] (instance-norm backward applied through the signal's nine
  * moments xmom [B][ntx][9] from w2s_enc_first_stats; stats1 / bstats1 [B][16][2] as for w2s_enc_first_bwd); sum over B with

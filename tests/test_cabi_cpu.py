@@ -64,7 +64,7 @@ def test_argument_validation_without_gpu(built_lib):
     assert dll.w2s_stats_finalize(None, 1, 1, 16, ctypes.c_long(1), ctypes.c_float(0.01), 0, None, None) == -1
     assert L.conv_tile(16, 16, 3, 1) == 256 and L.conv_tile(128, 128, 3, 1) == 64
     assert L.wgrad_grid_y(128, 128, 3) == 1 and L.wgrad_grid_y(128, 128, 7, 2) == 7 and L.wgrad_grid_y(16, 16, 3) == 1
-    assert L.wgrad_slabs_per_block(128, 128, 3) == 1 and L.wgrad_slabs_per_block(16, 16, 3) == 4 and L.bwd_fused_tile(16, 16) == 256 and L.bwd_fused_tile(16, 16, 1, True) == 128
+    assert L.wgrad_slabs_per_block(128, 128, 3) == 1 and L.wgrad_slabs_per_block(16, 16, 3) == 4 and L.bwd_fused_tile(16, 16) == 254 and L.bwd_fused_tile(16, 16, 1, True) == 126 and L.bwd_fused_tile(16, 16, 1, False, False) == 256
     assert L.conv_fwd_fused_tile(16, 16, 1) == 254 and L.conv_fwd_fused_tile(32, 32, 2) == 127 and L.conv_fwd_fused_tile(64, 64, 1) == 0
     assert L.bwd_fused_folds_residual(16, 16) and L.bwd_fused_folds_residual(32, 16) and not L.bwd_fused_folds_residual(32, 32)
     assert dll.w2s_wgrad_reduce_batch(None, 1, None) == -1 and dll.w2s_repack_batch(None, 0, None) == -1 and dll.w2s_colsum_batch(None, 3, None) == -1

@@ -61,7 +61,7 @@ def fused_case(cg, ch, L, stride=1, B=16, nslab=None):
     g = torch.randn(B, Lg, cg, device=dev); y = torch.randn(B, Lg, cg, device=dev); xin = torch.randn(B, L, ch, device=dev)
     st = torch.rand(B, cg, 2, device=dev) + 0.5; bst = torch.rand(B, cg, 2, device=dev) * 0.01; sti = torch.rand(B, ch, 2, device=dev) + 0.5
     wb = torch.randn(ch, 3, cg, device=dev) / 7; gout = torch.empty(B, L, ch, device=dev)
-    tile = lib.bwd_fused_tile(cg, ch, stride); nt = (L + tile - 1) // tile
+    tile = lib.bwd_fused_tile(cg, ch, stride, False, os.environ.get('BF') == '1'); nt = (L + tile - 1) // tile
     part = torch.empty(B, nt, 2, ch, device=dev)
     ns = nslab or int(os.environ.get('NSLAB', 1024))
     slab = torch.empty(ns * cg * ch * 3, device=dev)
@@ -200,7 +200,8 @@ if __name__ == '__main__':
         ms = timeit(fn, a.iters)
         print(f'{n:8s} {ms*1e3:9.1f} us  {nb/ms/1e6:8.0f} GB/s  {fl/ms/1e9:7.1f} TF/s', flush=True)
         if os.environ.get('W2S_STAMP') and LAST_PART is not None and n.startswith('b') and not n.startswith('bw') and n != 'bfirst':
-            v = LAST_PART.view(-1)[:8].tolist()   # bwd_fused_bf (-DW2S_WIDE_STAMP): phases of workgroup 0's first wave
+            v = LAST_PART.view(-1)[:16].tolist()   # bwd_fused_bf (-DW2S_WIDE_STAMP): phases of workgroup 0's first wave
+            print('   per wave (commit, prefetch issue + second barrier): ' + ', '.join(f'w{w}: {v[8 + 2 * w]:.0f} / {v[9 + 2 * w]:.0f}' for w in range(4)), flush=True)
             print(f'   stamps (cycles, {v[6]:.0f} tiles): barrier A {v[0]:.0f}, wait for the prefetched loads {v[1]:.0f}, commit {v[2]:.0f}, prefetch issue + barrier B {v[3]:.0f}, '
                   f'data gradient + epilogue {v[4]:.0f}, weight gradient {v[5]:.0f}; in-kernel clock {v[7]:.0f} MHz', flush=True)
         elif os.environ.get('W2S_STAMP') and LAST_PART is not None:   # diagnostic builds (-DW2S_WIDE_STAMP): cycle stamps of workgroup 0 in part[0..7]

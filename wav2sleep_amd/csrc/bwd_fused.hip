@@ -394,8 +394,14 @@ void bwd_fused_bf_kernel(BwdP P) {
   constexpr int RSg = bf_rs(GC), RSh = bf_rs(HC), RSn = bwd_rs(HC);   // bf16 / bf16 / float elements per row
   static_assert(!(RD && UP2), "the residual fold belongs to the stride-1 conv1");
   static_assert(!FIRST || (HC == 16 && !UP2 && !RD), "first-layer recompute: conv2 of block 0");
-  constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2;
-  constexpr int NRh = TM + 2;                               // h window rows; row 0 = position t0 - pad (stride 2, symmetric: TM + 1 used)
+  // A tile is TS = TM - 2 positions: its two windows (the positions and one halo row on each side) are then exactly TM rows -- a whole
+  // number of staging passes (64 or 32 rows each).  With TM-position tiles the TM + 2 rows cost every tile a fifth pass for two rows,
+  // executed by wave 0 alone at the price of a full one while the other three waited at the barrier (in-kernel stamps, lab notes r4
+  // section 13: wave 0's commit 11-16 % longer than its siblings').  The MFMA tiles still cover TM positions; the last two are computed
+  // on rows past the window (finite LDS contents) and neither stored nor summed, and the weight gradient masks them out of its K axis.
+  constexpr int TS = TM - 2;
+  constexpr int NRg = UP2 ? TM / 2 : TM;
+  constexpr int NRh = TM;                                   // h window rows; row 0 = position t0 - pad
   const int PL = P.pad;                                     // 1: symmetric padding; 2: causal (left pad 2)
   // data-gradient K axis of the LDS weight image.  32 gradient channels: k = tap*32 + o (one tap per MFMA).
   // 16 gradient channels: two taps share one K = 32 step: stride 1: [tap0 | tap1] [tap2 | 0];
@@ -474,7 +480,7 @@ void bwd_fused_bf_kernel(BwdP P) {
       for (int j = 0; j < 3; ++j) w1r[i][j] = P.w1[(hch + i) * 3 + j];
   }
   auto prefetch = [&](int b, int tile) {   // (sample, tile): carried incrementally by the tile loop, no division per tile
-    const int t0 = tile * TM;
+    const int t0 = tile * TS;
     // wave-uniform 64-bit base per sample + 32-bit per-lane offsets (a sample's tensor is < 4 GB): scalar-base addressing,
     // no 64-bit VALU address arithmetic per load
     const char* gb = reinterpret_cast<const char*>(P.g) + (size_t)b * Lg * GC * (GH ? 2 : 4);
@@ -528,7 +534,7 @@ void bwd_fused_bf_kernel(BwdP P) {
     }
   };
   auto commit = [&](int b, int tile) {
-    const int t0 = tile * TM;
+    const int t0 = tile * TS;
     f32x4 pm, pr, ps1, ps2;
     {
       const float* st = P.st_k + ((size_t)b * GC + gch) * 2;
@@ -618,7 +624,7 @@ void bwd_fused_bf_kernel(BwdP P) {
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();   // (100 MHz / shader clock)
 #endif
   for (int tl = wrun.first; tl < wend; ++tl) {
-    const int t0 = tile * TM;
+    const int t0 = tile * TS;
     const int tile_n = tile + 1 == P.ntiles ? 0 : tile + 1, b_n = tile + 1 == P.ntiles ? b + 1 : b;   // the next tile of the run
 #ifdef W2S_WIDE_STAMP
     k0 = __builtin_amdgcn_s_memtime();
@@ -770,7 +776,7 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int pos = UP2 ? t0 + 2 * (wave * (8 * MT) + (mt >> 1) * 16 + r) + (mt & 1) : t0 + wave * (16 * MT) + mt * 16 + r;
-      if (pos >= Lh) continue;
+      if (pos >= Lh || pos - t0 >= TS) continue;   // (the last two positions of the MFMA tiles belong to the next tile)
 #pragma unroll
       for (int nt = 0; nt < CH; ++nt) {
         const int ch = nt * 16 + 4 * g;
@@ -900,8 +906,12 @@ void bwd_fused_bf_kernel(BwdP P) {
       const int p0 = 32 * s + 8 * g + q4;         // this lane's address row (gradient-side position) of the first 4-block
       const int gr0 = UP2 ? p0 : p0 + 2 - PL;     // window row of gradient-side position p0
       const int gcol = wi * 16 + 4 * p4;
-      const bf16x8 ah = lds_tr8(gyH + gr0 * RSg + gcol, gyH + (gr0 + 4) * RSg + gcol);
-      const bf16x8 al = lds_tr8(gyLo + gr0 * RSg + gcol, gyLo + (gr0 + 4) * RSg + gcol);
+      bf16x8 ah = lds_tr8(gyH + gr0 * RSg + gcol, gyH + (gr0 + 4) * RSg + gcol);
+      bf16x8 al = lds_tr8(gyLo + gr0 * RSg + gcol, gyLo + (gr0 + 4) * RSg + gcol);
+      if (s == KS - 1 && g == 3) {   // element e of the fragment is gradient-side position 32 s + 8 g + e: those past the tile's TS (TS / 2) are the next tile's
+        ah[7] = (__bf16)0.f; al[7] = (__bf16)0.f;
+        if (!UP2) { ah[6] = (__bf16)0.f; al[6] = (__bf16)0.f; }
+      }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int h0 = UP2 ? 2 * p0 + j : p0 + j, h1 = UP2 ? 2 * (p0 + 4) + j : p0 + 4 + j;
@@ -919,8 +929,9 @@ void bwd_fused_bf_kernel(BwdP P) {
         if (KSD % KW != 0 && s >= KSD) break;
         const int p0 = 32 * s + 8 * g + q4;
         const int gcol = wi * 16 + 4 * p4, hcol = wc * 16 + 4 * p4;
-        const bf16x8 ah = lds_tr8(pH + p0 * RSg + gcol, pH + (p0 + 4) * RSg + gcol);
-        const bf16x8 al = lds_tr8(pLo + p0 * RSg + gcol, pLo + (p0 + 4) * RSg + gcol);
+        bf16x8 ah = lds_tr8(pH + p0 * RSg + gcol, pH + (p0 + 4) * RSg + gcol);
+        bf16x8 al = lds_tr8(pLo + p0 * RSg + gcol, pLo + (p0 + 4) * RSg + gcol);
+        if (s == KSD - 1 && g == 3) { ah[7] = (__bf16)0.f; al[7] = (__bf16)0.f; }   // gpre row TM/2 - 1 = position t0 + TS: the next tile's
         const bf16x8 bh = lds_tr8(hH + (2 * p0 + PL) * RSh + hcol, hH + (2 * (p0 + 4) + PL) * RSh + hcol);
         const bf16x8 bl = lds_tr8(hLo + (2 * p0 + PL) * RSh + hcol, hLo + (2 * (p0 + 4) + PL) * RSh + hcol);
         accd = mfma_bf3(ah, al, bh, bl, accd);
@@ -934,6 +945,9 @@ void bwd_fused_bf_kernel(BwdP P) {
     b = b_n; tile = tile_n;
   }
 #ifdef W2S_WIDE_STAMP
+  if (blockIdx.x == 0 && (tid & 63) == 0 && P.part) {   // every wave: its commit and its wait at the second barrier
+    P.part[8 + 2 * (tid >> 6)] = (float)sC_; P.part[9 + 2 * (tid >> 6)] = (float)sB_;
+  }
   if (blockIdx.x == 0 && tid == 0 && P.part) {
     P.part[0] = (float)sA_; P.part[1] = (float)sW_; P.part[2] = (float)sC_; P.part[3] = (float)sB_; P.part[4] = (float)sD_; P.part[5] = (float)sG_;
     P.part[6] = (float)wrun.count;
@@ -981,11 +995,11 @@ void bwd_fused_bf_kernel(BwdP P) {
 
 template <int CG, int CH, int MT, int UP2, int RD, int FIRST = 0, int GM = 0>
 static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
-  constexpr int TM = 64 * MT, GC = CG * 16, HC = CH * 16, KD = (GC == 32) ? (RD ? 128 : 96) : 64;
+  constexpr int TM = 64 * MT, TS = TM - 2, GC = CG * 16, HC = CH * 16, KD = (GC == 32) ? (RD ? 128 : 96) : 64;
   BwdP P = P0;
-  P.ntiles = (P.Lh + TM - 1) / TM;
+  P.ntiles = (P.Lh + TS - 1) / TS;
   P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, nslab);
-  constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = TM + 2, NRp = RD ? TM / 2 + 1 : 0;
+  constexpr int NRg = UP2 ? TM / 2 : TM, NRh = TM, NRp = RD ? TM / 2 + 1 : 0;
   size_t lds = (HC == 16 ? (size_t)TM * bwd_rs(HC) * 4 * 2 : (size_t)TM * 32 * (4 + 2)) + (size_t)bwd_redn(CH) * 4 +   // n + GELU' planes (32 ch: fp32 + fp16, unpadded)
                (size_t)2 * 2 * ((NRg + NRp) * bf_rs(GC) + NRh * bf_rs(HC) + HC * (KD + 8));
   if (FIRST) lds += (size_t)(TM + 4) * 4 + 4 * 4 * 12 * 4;
@@ -1020,7 +1034,10 @@ constexpr int bf_mt(int cg, int ch, int up2, int rd) {
 // (cg, ch) pairs whose conv1 kernel can fold the residual branch (LDS budget: two workgroups per CU)
 extern "C" int w2s_bwd_fused_folds_residual(int cg, int ch) { return (cg == 16 && ch == 16) || (cg == 32 && ch == 16); }
 // positions of the input side per tile (= rows of `part` per sample: ceil(Lh / tile)); rd: the residual-fold form (gpre != NULL)
-extern "C" int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd) { return 64 * bf_mt(cg, ch, stride == 2, rd); }
+// split_precision: the split-precision kernels' tiles are two positions short of the MFMA tile (whole staging passes, see the kernel)
+extern "C" int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd, int split_precision) {
+  return 64 * bf_mt(cg, ch, stride == 2, rd) - (split_precision ? 2 : 0);
+}
 
 // cg = channels of the gradient side (the forward conv's cout), ch = channels of the input side (its cin).
 static int bwd_fused_impl(const void* gv, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,

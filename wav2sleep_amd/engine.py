@@ -330,7 +330,7 @@ class Engine:
         """dgrad + wgrad of one k=3 encoder conv in one pass (<= 32 channels); returns the backward statistics or None.
         gpre / down (conv1 of a residual block): fold the 1x1/stride-2 residual branch `down` in as well."""
         dev = g.device
-        tile = lib.bwd_fused_tile(cg, ch, stride, gpre is not None)
+        tile = lib.bwd_fused_tile(cg, ch, stride, gpre is not None, self.split_precision)
         nt = _cdiv(Lh, tile)
         nslab = max(1, min(B * nt, _BWD_WGS_RD16 if (cg == 16 and ch == 16 and gpre is not None) else _BWD_WGS32 if (cg == 32 and ch == 32) else _BWD_WGS))
         slab = self._slab(dev, nslab, cg * ch * 3)
@@ -1154,7 +1154,7 @@ class Engine:
                                       gmode=(2 if ghalf else 1) if h16 else 0, hdr_g=gpre_hdr, hdr_o=h2)
                 first = i == 0 and blk['y1'] is None   # block 0's conv1 output is recomputed from the raw signal
                 if fold_w1:
-                    part_w1 = torch.empty(B, _cdiv(L, lib.bwd_fused_tile(c, c, 1, False)), 48, device=dev, dtype=torch.float32)
+                    part_w1 = torch.empty(B, _cdiv(L, lib.bwd_fused_tile(c, c, 1, False, True)), 48, device=dev, dtype=torch.float32)
                 bs1 = self._bwd_fused(p + 'conv2.conv.weight', g=gn2, y=blk['y2'], st_k=blk['st2'], bst_k=bs2, pro=lib.PRO_INBWD,
                                       xin=ec['x'] if first else blk['y1'], st_in=blk['st1'], add_even=None, gout=gn1, want_part=True, B=B,
                                       Lg=L, Lh=L, cg=c, ch=c, stride=1, w1=P[p + 'conv1.conv.weight'] if first else None,

@@ -342,8 +342,8 @@ def bwd_fused_supported(cg, ch) -> bool:
     return (cg, ch) in ((16, 16), (32, 16), (32, 32))
 
 
-def bwd_fused_tile(cg, ch, stride=1, rd=False) -> int:
-    return load().w2s_bwd_fused_tile(cg, ch, stride, int(bool(rd)))
+def bwd_fused_tile(cg, ch, stride=1, rd=False, split_precision=True) -> int:
+    return load().w2s_bwd_fused_tile(cg, ch, stride, int(bool(rd)), int(bool(split_precision)))
 
 
 def bwd_fused_folds_residual(cg, ch) -> bool:
@@ -385,10 +385,10 @@ def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, s
               + (wg * B * Lh * cg // 2 if gpre is not None else 0) + (4 * B * Lh * ch if y3p is not None else 0))
     flops = 2 * B * Lg * cg * ch * 3 * 2
     if split_precision or gmode:
-        key = (f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch, stride, gpre is not None) // 64}, {1 if stride == 2 else 0}, '
+        key = (f'bwd_fused_bf_kernel<{cg // 16}, {ch // 16}, {(bwd_fused_tile(cg, ch, stride, gpre is not None) + 2) // 64}, {1 if stride == 2 else 0}, '
                f'{1 if gpre is not None else 0}, {1 if w1 is not None else 0}, {gmode}>')
     else:
-        key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch, stride) // 64}, {1 if stride == 2 else 0}, 1>'
+        key = f'bwd_fused_kernel<{cg // 16}, {ch // 16}, {bwd_fused_tile(cg, ch, stride, False, False) // 64}, {1 if stride == 2 else 0}, 1>'
     if DETAIL:
         key += f' L{Lh}'
     _timed(key, nbytes, flops, run)
