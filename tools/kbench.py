@@ -68,7 +68,8 @@ def fused_case(cg, ch, L, stride=1, B=16, nslab=None):
     global LAST_PART
     LAST_PART = part
     fn = lambda: lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=lib.PRO_INBWD if stride == 1 else lib.PRO_INBWD_GP, xin=xin, st_in=sti, add_even=None,
-                               wb=wb, gout=gout, part=part, slab=slab, nslab=ns, B=B, Lg=Lg, Lh=L, cg=cg, ch=ch, stride=stride, split_precision=os.environ.get('BF') == '1')
+                               wb=wb, gout=gout, part=None if os.environ.get('NOPART') else part, slab=slab, nslab=ns, B=B, Lg=Lg, Lh=L, cg=cg, ch=ch, stride=stride,
+                               split_precision=os.environ.get('BF') == '1')   # NOPART=1: without the statistics partials (their per-tile reduction + barrier)
     return fn, 4 * (2 * B * Lg * cg + 2 * B * L * ch), 2 * B * Lg * cg * ch * 3 * 2
 
 def ffwd_case(cin, cout, L, stride=1, B=16, pro=lib.PRO_IN_GELU):
