@@ -106,6 +106,45 @@ def b16_fullsize_grad():
 
 
 @check
+def eog_b16_consistency():
+    """BASELINE configs[3] at the batch the metric is quoted on (EOG-L + EOG-R, 16 recordings x 960 epochs = 3.9 M samples each): the 16
+    recordings as ONE batch against the same 16 one by one.  Logits bit for bit (batch invariance at this length); the batch's flat
+    gradient = sum_b (valid_b / valid_total) * (gradient of recording b alone) -- together with eog_fullsize_grad (B = 1 against the
+    oracle's autograd) that pins the B = 16 step the bench's `extra.configs3_eog_b16` leg times."""
+    import wav2sleep_amd as W
+    from oracle import wav2sleep_oracle as O
+    torch.manual_seed(42)
+    model = build(W, EOG, 5).to(DEV).train()   # dropout 0: train mode only selects the saved-forward path
+    cfg = O.ModelConfig(signal_map=EOG, num_classes=5)
+    B = 16
+    x, y = O.make_inputs(cfg, B, 960, seed=1616, missing={'EOG-R': [2, 9], 'EOG-L': [13]})
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    yd = y.to(DEV)
+
+    def fwd_bwd(xs, ys):
+        model.zero_grad(set_to_none=True)
+        logits = model(xs)
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, 5), ys.reshape(-1).long(), ignore_index=-1)
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), float(loss), model._flat_grad.detach().double().clone()
+
+    lb, loss_b, gb = fwd_bwd(xd, yd)
+    total = int((y >= 0).sum())
+    acc = torch.zeros_like(gb)
+    singles, wl = [], 0.0
+    for i in range(B):
+        li, lo, gi = fwd_bwd({k: v[i:i + 1] for k, v in xd.items()}, yd[i:i + 1])
+        w = int((y[i] >= 0).sum()) / total
+        acc += w * gi
+        wl += w * lo
+        singles.append(li)
+    ls = torch.cat(singles)
+    return dict(logits_equal=torch.equal(lb, ls), logits_max_diff=float((lb - ls).abs().max()), loss_batch=loss_b, loss_singles=wl,
+                grad_rel_l2=float((gb - acc).norm() / (acc.norm() + 1e-300)), grad_norm=float(acc.norm()), finite=bool(torch.isfinite(gb).all()))
+
+
+@check
 def batch_invariance():
     """A recording's logits must not depend on its batch neighbours (instance / layer norms only): B = 32 vs two halves of 16, B = 5 vs
     single recordings; full length, bit for bit."""

@@ -56,6 +56,16 @@ def test_configs3_eog_full_size_gradients_match_oracle_and_are_bit_reproducible(
     assert r['worst_rel_l2'] <= 2e-3, (r['worst_tensor'], r['worst_rel_l2'])
 
 
+def test_configs3_eog_batch16_equals_its_sixteen_recordings_one_by_one(tmp_path):
+    """configs[3] at B = 16 (what `extra.configs3_eog_b16` times): logits bit-equal to the sixteen B = 1 runs, flat gradient = their
+    valid-label-weighted mean within 1e-5 relative L2 (fp32 summation order is all that differs).  The B = 1 run is pinned to the oracle by
+    test_configs3_eog_full_size_gradients_match_oracle_and_are_bit_reproducible."""
+    r = run_check('eog_b16_consistency', tmp_path, 1200)
+    assert r['finite'] and r['logits_equal'], r
+    assert r['loss_batch'] == pytest.approx(r['loss_singles'], rel=1e-6)
+    assert r['grad_rel_l2'] <= 1e-5, r
+
+
 def test_benchmark_shape_batch16_gradients_match_oracle(tmp_path):
     """4 modalities x 960 epochs, B = 16, ragged: one backward pass vs the oracle over 8 micro-batches of 2."""
     r = run_check('b16_fullsize_grad', tmp_path, 1500)

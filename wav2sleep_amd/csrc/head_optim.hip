@@ -317,4 +317,5 @@ extern "C" int w2s_swap(float* a, float* b, long n, void* stream) {
   return W2S_OK;
 }
 
-extern "C" const char* w2s_version(void) { return "w2s-hip 0.1 (gfx950; bf16x3 split-precision and fp32 MFMA)"; }
+extern "C" const char* w2s_version(void) { return "w2s-hip 0.5 (gfx950; bf16x3 split-precision and fp32 MFMA)"; }
+extern "C" int w2s_abi_version(void) { return W2S_ABI_VERSION; }

@@ -434,8 +434,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 // row16_sum of EIGHT values at once (the statistics epilogue of every conv kernel: sums and sums of squares of four channels): four DPP
 // steps, ONE fused v_add_f32_dpp each (the compiler's form of row16_sum is v_mov 0 + v_mov_dpp + add: 85 instructions for the eight
 // values, this is 33).  The eight chains are interleaved, so a register written by one instruction is read as a DPP source eight
-// instructions later: no VALU -> DPP wait states inside; the s_nop covers an operand written right before the block.  Same additions in
-// the same order as row16_sum (a + dpp(a) is commutative bit for bit).  All 64 lanes must be active.
+// instructions later: no VALU -> DPP wait states inside; the s_nop 4 (5 wait states, once per tile) covers an operand written right before the block AND a VALU write of EXEC (v_cmpx) the
+// compiler might place there -- its hazard recogniser does not look into inline asm.  Same additions in
+// the same order as row16_sum (a + dpp(a) is commutative bit for bit).  All 64 lanes must be active: call it from wave-uniform control flow only.
 __device__ __forceinline__ void row16_sum8(f32x4& a, f32x4& b) {
   float a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
 #define W2S_DPP_STEP(ctl) \
@@ -443,7 +444,7 @@ __device__ __forceinline__ void row16_sum8(f32x4& a, f32x4& b) {
   "v_add_f32_dpp %2, %2, %2 " ctl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %3, %3, %3 " ctl " row_mask:0xf bank_mask:0xf\n\t" \
   "v_add_f32_dpp %4, %4, %4 " ctl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %5, %5, %5 " ctl " row_mask:0xf bank_mask:0xf\n\t" \
   "v_add_f32_dpp %6, %6, %6 " ctl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %7, %7, %7 " ctl " row_mask:0xf bank_mask:0xf\n\t"
-  asm volatile("s_nop 1\n\t" W2S_DPP_STEP("quad_perm:[1,0,3,2]") W2S_DPP_STEP("quad_perm:[2,3,0,1]") W2S_DPP_STEP("row_half_mirror") W2S_DPP_STEP("row_mirror")
+  asm volatile("s_nop 4\n\t" W2S_DPP_STEP("quad_perm:[1,0,3,2]") W2S_DPP_STEP("quad_perm:[2,3,0,1]") W2S_DPP_STEP("row_half_mirror") W2S_DPP_STEP("row_mirror")
                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
 #undef W2S_DPP_STEP
   a = (f32x4){a0, a1, a2, a3};

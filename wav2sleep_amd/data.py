@@ -35,8 +35,7 @@ def try_read_parquet(fp: str, columns: list[str] | None = None, max_retries: int
     """`pd.read_parquet` that survives a flaky filesystem: up to `max_retries` further attempts, every failure logged, then a
     ValueError naming the file -- the contract of the reference's helper of the same name (data/dataset.py:188-198), as a loop."""
     import pandas as pd
-    attempts = max_retries + 1
-    for left in range(attempts, 0, -1):
+    for _ in range(max_retries + 1):
         try:
             return pd.read_parquet(fp, columns=columns)
         except Exception as e:  # noqa: BLE001 (anything the reader raises counts as a failed attempt, as in the reference)

@@ -56,8 +56,9 @@ EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_conv_forward', 'w2s_wgrad', 'w2
            'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_bwd_fused_wd', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_stat_rows', 'w2s_conv_stat_rows', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
-           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_token_masks', 'w2s_cls_scatter', 'w2s_copy_rows', 'w2s_zero', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version']
+           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_token_masks', 'w2s_cls_scatter', 'w2s_copy_rows', 'w2s_zero', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version', 'w2s_abi_version']
 
+ABI_VERSION = 5   # include/w2s.h W2S_ABI_VERSION
 _lib = None
 
 
@@ -93,6 +94,9 @@ def load():
             if not hasattr(lib, name):
                 raise RuntimeError(f'{LIB_PATH} does not export {name}')
         lib.w2s_version.restype = C.c_char_p
+        lib.w2s_abi_version.restype = C.c_int
+        if lib.w2s_abi_version() != ABI_VERSION:   # a stale W2S_LIB / build_alt library would be called with shifted arguments
+            raise RuntimeError(f'{LIB_PATH} has ABI {lib.w2s_abi_version()}, this host was written against {ABI_VERSION} (include/w2s.h): rebuild it')
         _lib = lib
     return _lib
 
@@ -589,6 +593,7 @@ def copy_rows(dst, ld_dst, src, ld_src, rows, Cc):
 
 def zero_(t):
     """t.zero_() as a launch of this library (t contiguous, a multiple of 4 bytes)"""
+    assert t.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0, 'w2s_zero: contiguous storage, a multiple of 4 bytes'
     _chk(load().w2s_zero(_p(t), C.c_long(t.numel() * t.element_size()), _stream()), 'w2s_zero')
 
 
