@@ -476,10 +476,10 @@ def t_fused_split_precision():
                 lib.wgrad_reduce(slab, ns, grad, cg, ch, 3, 1, accumulate=False, layout=0)
                 outs.append((gout, part.sum(1), grad))   # (the two kernels' tiles differ: the partials are compared as sums over a sample's tiles)
             for nm, a, b in zip(('gout', 'part', 'wgrad'), outs[1], outs[0]):
-                # 32 input-side channels (round 4): the kernel keeps n of the tile in an fp16 LDS plane (the GELU' plane stays fp32): the
+                # the kernel keeps n of the tile's positions as fp16 (round 4: an LDS plane of the 32-channel kernels; round 5: registers, every width): the
                 # per-tile sums of gout * n carry 2^-11 of sum |gout * n| -- a per-tile bar of 5e-4 of the scale; the finalised statistics
                 # average it over thousands of tiles (full-size gradient checks: unchanged 4.3e-4 / 8.3e-4 worst tensor)
-                report(f'fused bf16x3 {cg}->{ch} s{stride} L{Lh} {nm}', a, b, tol=5e-4 if (nm == 'part' and ch == 32) else 2e-4)
+                report(f'fused bf16x3 {cg}->{ch} s{stride} L{Lh} {nm}', a, b, tol=5e-4 if nm == 'part' else 2e-4)
 
 def t_fused_residual_fold():
     """conv1 fused backward with the residual branch folded in vs (1x1 conv + add_even) and the separate downsample wgrad."""

@@ -338,12 +338,6 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
   bf16x4t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p1));
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-__device__ __forceinline__ void split_store4(__bf16* hi, __bf16* lo, int off, f32x4 t) {
-  bf16x4 h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
-  bf16x4 l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
-  *reinterpret_cast<bf16x4*>(hi + off) = h;
-  *reinterpret_cast<bf16x4*>(lo + off) = l;
-}
 __device__ __forceinline__ f32x4 mfma_bf3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 c) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
@@ -357,12 +351,15 @@ __device__ __forceinline__ f32x4 mfma_bf3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x
 // already staged.  Replaces a 1x1 conv launch (+ its output tensor, written and re-read) and a weight-gradient launch that
 // re-read both gpre and the block input.
 __host__ __device__ constexpr int bf_rs(int c) { return c == 16 ? 16 : c + 8; }  // 32-B rows are conflict-free as they are
-// XOR swizzles of the unpadded 32-channel planes of the fused backward (GPS == 2): column (a multiple of 4) of channel `col` in row `row`.
-// fp32 GELU' plane, 128-B rows read with ds_read_b128 by the epilogue's D-fragment lanes (position = lane & 15, channels 4*(lane >> 4)):
-// 16-B unit ^= (row >> 1) & 7 makes the sixteen lanes of a read group hit sixteen different units; fp16 n plane, 64-B rows read with
-// ds_read_b64: 8-B unit ^= ((row >> 2) & 3) << 1.
-__device__ __forceinline__ int bwd_gp_col(int row, int col) { return (((col >> 2) ^ ((row >> 1) & 7)) << 2); }
-__device__ __forceinline__ int bwd_n_col(int row, int col) { return (((col >> 2) ^ (((row >> 2) & 3) << 1)) << 2); }
+// row stride (bf16 elements) of the h planes: stride 1 as the gy planes; stride 2: a lane's sixteen-lane store group covers EVERY OTHER row
+// (the even / odd outputs are separate M tiles), so 32-B rows would put eight lanes on one bank pair -- 40-B / 72-B rows leave 2-way
+__host__ __device__ constexpr int bf_rsh(int c, int up2) { return up2 ? (c == 16 ? 20 : 36) : bf_rs(c); }
+#ifndef W2S_BF_LATEH
+#define W2S_BF_LATEH 1   // the input-side prefetch of the next tile is issued after the epilogue (see `prefetch`)
+#endif
+#ifndef W2S_BF_HLO
+#define W2S_BF_HLO 1   // 1: h = GELU(n) staged as bf16 hi + lo planes (three MFMAs per weight-gradient product); 0: hi plane only (two)
+#endif
 // FIRST = 1 (conv2 of block 0): the input side is block 0's conv1 output, which is never stored -- it is recomputed from
 // the raw 1-channel signal while the window is staged (3 FMAs per element instead of a 64-B row per position).
 // Occupancy: the kernels take what their registers allow (2 waves per SIMD; measured: forcing 2 on the variants that land on 1 changes
@@ -374,7 +371,7 @@ __device__ __forceinline__ int bwd_n_col(int row, int col) { return (((col >> 2)
 #ifndef W2S_BF_OCC22
 #define W2S_BF_OCC22 1   // tuning: the same for the 32-channel kernels ((32,32) both strides, (32,16) fold)
 #endif
-__host__ __device__ constexpr int bfk_occ(int cg, int ch, int rd) { return (cg == 1 && ch == 1 && rd) ? 3 : (cg == 1 && ch == 1) ? W2S_BF_OCC11 : W2S_BF_OCC22; }
+__host__ __device__ constexpr int bfk_occ(int cg, int ch, int rd) { return (cg == 1 && ch == 1) ? W2S_BF_OCC11 : W2S_BF_OCC22; }
 template <int CG, int CH, int MT, int UP2, int RD, int FIRST, int GM, int FIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bfk_occ(CG, CH, RD))))
 void bwd_fused_bf_kernel(BwdP P) {
@@ -391,7 +388,7 @@ void bwd_fused_bf_kernel(BwdP P) {
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 64 * MT;
   constexpr int GC = CG * 16, HC = CH * 16;
-  constexpr int RSg = bf_rs(GC), RSh = bf_rs(HC), RSn = bwd_rs(HC);   // bf16 / bf16 / float elements per row
+  constexpr int RSg = bf_rs(GC), RSh = bf_rsh(HC, UP2);   // bf16 elements per row of the gy / h planes
   static_assert(!(RD && UP2), "the residual fold belongs to the stride-1 conv1");
   static_assert(!FIRST || (HC == 16 && !UP2 && !RD), "first-layer recompute: conv2 of block 0");
   // A tile is TS = TM - 2 positions: its two windows (the positions and one halo row on each side) are then exactly TM rows -- a whole
@@ -408,22 +405,19 @@ void bwd_fused_bf_kernel(BwdP P) {
   // stride 2 (even outputs use tap 1, odd outputs taps 2 and 0): [tap1 | 0] [tap2 | tap0].
   constexpr int KD = (GC == 32) ? (RD ? 128 : 96) : 64;   // RD: [tap2 | Wd] (16 ch) / a fourth K step = Wd (32 ch)
   constexpr int WROW = KD + 8;
-  // GPS (16 input-side channels: the LDS budget allows it): GELU'(n) of the centre rows is computed once, together with
-  // GELU(n), while the window is staged, instead of a second erf evaluation in the epilogue
-  // 32 input-side channels (GPS == 2, round 4): the same, inside the LDS budget of two workgroups per CU -- the GELU' plane stays fp32
-  // (it multiplies the data gradient), the n plane (only the backward statistics sum gout * n read it) is fp16, and both are stored
-  // UNPADDED (128-B / 64-B rows) with an XOR swizzle of their 16-B / 8-B units instead of the pad (bwd_gp_col / bwd_n_col).  The second
-  // erf evaluation per element in the epilogue was ~30 % of these kernels' vector instructions.
-  constexpr int GPS = (HC == 16) ? 1 : 2;
-  float* nL = reinterpret_cast<float*>(smem4);              // GPS 1: [TM][RSn] normalised input of the centre rows;  GPS 2: the GELU' plane [TM][32]
-  float* gpL = (GPS == 2) ? nL : nL + TM * RSn;             // [TM][RSn] GELU'(n) of the centre rows (GPS 2: [TM][32], swizzled)
-  _Float16* nH = reinterpret_cast<_Float16*>(nL + TM * 32); // GPS 2: n of the centre rows as fp16 [TM][32], swizzled
-  float* red = (GPS == 2) ? reinterpret_cast<float*>(nH + TM * 32) : gpL + TM * RSn;   // [4][CH][4][8] stats scratch
+  // Round 5: the input-side window is staged by the lane that OWNS the position in the data gradient's D fragment (position = lane & 15 of
+  // the wave's 16-position M tile, channels 4 * (lane >> 4) ...: bwd_hrow below), so n = IN(x) and GELU'(n) of the tile's positions never
+  // leave their registers between the staging pass (one erf for GELU and GELU') and the epilogue (gout = d * GELU'(n), sum gout * n).
+  // Rounds 3-4 kept them in two fp32 LDS planes (32 KB of the 16-channel kernels' 70 KB: two workgroups per CU): a ds_write_b128 + ds_read_b128
+  // pair per plane and 4 elements.  Without them the 16 -> 16 kernels hold 31 KB and the register file sets the occupancy.
+  // HLO: the lo plane of h = GELU(n), which only the weight gradient reads (dW = gy * h: gy_hi h_hi + gy_lo h_hi [+ gy_hi h_lo]).
+  constexpr bool HLO = W2S_BF_HLO != 0;
+  float* red = reinterpret_cast<float*>(smem4);             // [4][CH][4][8] stats scratch
   __bf16* gyH = reinterpret_cast<__bf16*>(red + bwd_redn(CH));
   __bf16* gyLo = gyH + NRg * RSg;
   __bf16* hH = gyLo + NRg * RSg;
-  __bf16* hLo = hH + NRh * RSh;
-  __bf16* wH = hLo + NRh * RSh;                             // [HC][WROW]
+  __bf16* hLo = hH + NRh * RSh;                             // (HLO == 0: not there -- the weight planes follow hH)
+  __bf16* wH = hH + (HLO ? 2 : 1) * NRh * RSh;              // [HC][WROW]
   __bf16* wLo = wH + HC * WROW;
   constexpr int NRp = RD ? TM / 2 + 1 : 0;                  // gpre rows of the tile + one all-zero row (odd output positions)
   __bf16* pH = wLo + HC * WROW;
@@ -466,101 +460,128 @@ void bwd_fused_bf_kernel(BwdP P) {
   }
 
   constexpr int c4g = GC / 4, rstep_g = 256 / c4g, NG = (NRg + rstep_g - 1) / rstep_g;
-  constexpr int c4h = HC / 4, rstep_h = 256 / c4h, NH = (NRh + rstep_h - 1) / rstep_h;
+  constexpr int NH = MT * CH;   // float4s of the h window per thread: one per (M tile, channel tile) of this lane's D fragments
   const int gc4 = tid % c4g, grow0 = tid / c4g, gch = gc4 * 4;
-  const int hc4 = tid % c4h, hrow0 = tid / c4h, hch = hc4 * 4;
+  // tile-local position index of this lane in M tile mt (what the data gradient's D fragment holds), and the window row it stages: the
+  // window's row i is position t0 - pad + i, so index m lives in row m + pad; the pad rows in front of the tile are staged by the lanes
+  // of the last `pad` indices (>= TS: they own no output), i.e. row = (m + pad) mod TM -- every lane stages exactly MT * CH float4s
+  auto bwd_hm = [&](int mt) { return UP2 ? 2 * (wave * (8 * MT) + (mt >> 1) * 16 + r) + (mt & 1) : wave * (16 * MT) + mt * 16 + r; };
   constexpr int NP = RD ? (TM / 2 + rstep_g - 1) / rstep_g : 1;
   GRaw rg[NG], rp[NP];
   f32x4 ry[NG], rh[FIRST ? 1 : NH], rq[RD ? MT * CH : 1];  // rq: previous block's y3 in the D-fragment layout
+  f32x4 nR[NH], gR[NH];   // n = IN(x) and GELU'(n) of this lane's positions, from the staging pass to the epilogue
   float rxs[2], w1r[4][3];
   if (FIRST) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) w1r[i][j] = P.w1[(hch + i) * 3 + j];
+      for (int j = 0; j < 3; ++j) w1r[i][j] = P.w1[(4 * g + i) * 3 + j];
   }
-  auto prefetch = [&](int b, int tile) {   // (sample, tile): carried incrementally by the tile loop, no division per tile
+  // PART 0: the gradient side (g, y_k; the residual fold's gpre; the first-layer form's signal samples) -- issued right after the commit,
+  // in flight during the matrix phase.  PART 1: the input side (x_in, and the previous block's y3 fragments of the statistics fold): with
+  // W2S_BF_LATEH issued AFTER the epilogue (n / GELU' of the current tile are dead by then: 16 registers less at the peak, which is what
+  // lets the 16 -> 16 kernels keep three waves per SIMD without spilling); those loads have the weight-gradient phase and the next
+  // commit's gradient half to land
+  auto prefetch = [&](int b, int tile, auto PART) {   // (sample, tile): carried incrementally by the tile loop, no division per tile
+    constexpr int PT = decltype(PART)::value;
     const int t0 = tile * TS;
     // wave-uniform 64-bit base per sample + 32-bit per-lane offsets (a sample's tensor is < 4 GB): scalar-base addressing,
     // no 64-bit VALU address arithmetic per load
-    const char* gb = reinterpret_cast<const char*>(P.g) + (size_t)b * Lg * GC * (GH ? 2 : 4);
-    const float* yb = P.y + (size_t)b * Lg * GC;
-    const int rb = UP2 ? t0 / 2 : t0 - 2 + PL;   // gy window: the data gradient reads gy[t' + pad - j] at window row (t' - t0) + 2 - j
+    if constexpr (PT == 0) {
+      const char* gb = reinterpret_cast<const char*>(P.g) + (size_t)b * Lg * GC * (GH ? 2 : 4);
+      const float* yb = P.y + (size_t)b * Lg * GC;
+      const int rb = UP2 ? t0 / 2 : t0 - 2 + PL;   // gy window: the data gradient reads gy[t' + pad - j] at window row (t' - t0) + 2 - j
 #pragma unroll
-    for (int k = 0; k < NG; ++k) {
-      const int row = grow0 + k * rstep_g, gr = rb + row;
-      const bool ok = row < NRg && gr >= 0 && gr < Lg;
-      const unsigned off = (unsigned)gr * GC + gch;
-      if constexpr (GH) rg[k] = ok ? ld4h(gb, off) : (h16x4){0, 0, 0, 0};
-      else rg[k] = ok ? ld4o(reinterpret_cast<const float*>(gb), off) : (f32x4){0, 0, 0, 0};
-      ry[k] = ok ? ld4o(yb, off) : (f32x4){0, 0, 0, 0};
-    }
-    if (FIRST) {  // TM + 4 signal samples t0-2pad .. : one per thread (+4), exchanged through LDS at commit time (conv1 pads like this conv)
-      const float* xs = P.xin + (size_t)b * Lh;
+      for (int k = 0; k < NG; ++k) {   // unconditional loads from clamped rows (rows outside the sample: zeroed in LDS by `zero_oob`)
+        const int row = grow0 + k * rstep_g, gr = min(max(rb + row, 0), Lg - 1);
+        const unsigned off = (unsigned)gr * GC + gch;
+        if constexpr (GH) rg[k] = ld4h(gb, off);
+        else rg[k] = ld4o(reinterpret_cast<const float*>(gb), off);
+        ry[k] = ld4o(yb, off);
+      }
+      if (FIRST) {  // TM + 4 signal samples t0-2pad .. : one per thread (+4), exchanged through LDS at commit time (conv1 pads like this conv)
+        const float* xs = P.xin + (size_t)b * Lh;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int i = tid + 256 * k, gr = t0 - 2 * PL + i;
-        const float xv = xs[min(max(gr, 0), Lh - 1)];
-        rxs[k] = (i < TM + 4 && gr >= 0 && gr < Lh && !isinf(xv)) ? xv : 0.f;
+        for (int k = 0; k < 2; ++k) {
+          const int i = tid + 256 * k, gr = t0 - 2 * PL + i;
+          const float xv = xs[min(max(gr, 0), Lh - 1)];
+          rxs[k] = (i < TM + 4 && gr >= 0 && gr < Lh && !isinf(xv)) ? xv : 0.f;
+        }
+      }
+      if (RD) {
+        const char* pb = reinterpret_cast<const char*>(P.gpre) + (size_t)b * (Lh >> 1) * GC * (GH ? 2 : 4);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const int row = grow0 + k * rstep_g, gr = min(t0 / 2 + row, (Lh >> 1) - 1);
+          if constexpr (GH) rp[k] = ld4h(pb, (unsigned)gr * GC + gch);
+          else rp[k] = ld4o(reinterpret_cast<const float*>(pb), (unsigned)gr * GC + gch);
+        }
       }
     } else {
-      const float* xb = P.xin + (size_t)b * Lh * HC;
+      if (!FIRST) {
+        const float* xb = P.xin + (size_t)b * Lh * HC;
 #pragma unroll
-      for (int k = 0; k < NH; ++k) {
-        const int row = hrow0 + k * rstep_h, gr = t0 - PL + row;
-        const bool ok = row < NRh && gr >= 0 && gr < Lh;
-        rh[k] = ok ? ld4o(xb, (unsigned)gr * HC + hch) : (f32x4){0, 0, 0, 0};
-      }
-    }
-    if (RD && P.y3p) {
-      const float* qb = P.y3p + (size_t)b * Lh * HC;
+        for (int mt = 0; mt < MT; ++mt) {
+          const int row = (bwd_hm(mt) + PL) & (TM - 1), gr = min(max(t0 - PL + row, 0), Lh - 1);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < CH; ++nt) {
-          const int pos = t0 + wave * (16 * MT) + mt * 16 + r;
-          rq[mt * CH + nt] = (pos < Lh) ? ld4o(qb, (unsigned)pos * HC + nt * 16 + 4 * g) : (f32x4){0, 0, 0, 0};
+          for (int nt = 0; nt < CH; ++nt) rh[mt * CH + nt] = ld4o(xb, (unsigned)gr * HC + nt * 16 + 4 * g);
         }
-    }
-    if (RD) {
-      const char* pb = reinterpret_cast<const char*>(P.gpre) + (size_t)b * (Lh >> 1) * GC * (GH ? 2 : 4);
+      }
+      if (RD && P.y3p) {
+        const float* qb = P.y3p + (size_t)b * Lh * HC;
 #pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        const int row = grow0 + k * rstep_g, gr = t0 / 2 + row;
-        const bool ok = row < TM / 2 && gr < (Lh >> 1);
-        if constexpr (GH) rp[k] = ok ? ld4h(pb, (unsigned)gr * GC + gch) : (h16x4){0, 0, 0, 0};
-        else rp[k] = ok ? ld4o(reinterpret_cast<const float*>(pb), (unsigned)gr * GC + gch) : (f32x4){0, 0, 0, 0};
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < CH; ++nt) {
+            const int pos = min(t0 + wave * (16 * MT) + mt * 16 + r, Lh - 1);   // (positions past the sample are not summed)
+            rq[mt * CH + nt] = ld4o(qb, (unsigned)pos * HC + nt * 16 + 4 * g);
+          }
       }
     }
   };
+  static_assert(NRg % rstep_g == 0 && (TM / 2) % rstep_g == 0, "whole staging passes");
   auto commit = [&](int b, int tile) {
     const int t0 = tile * TS;
-    f32x4 pm, pr, ps1, ps2;
+    // instance-norm backward of the gradient side as TWO fused multiply-adds per element: with n = (y - m) r,
+    //   gy = r (g - s1 - n s2) = r g + (-r^2 s2) y + r (r s2 m - s1)
+    // (stride 2, where g passes through GELU'(n) first: gy = (r g) GELU'(n) + n (-r s2) + (-r s1), n = r y + (-m r)).  The per-channel
+    // coefficients are formed once per tile (a dozen operations); rounds 1-4 evaluated the textbook form: 5 (6) operations per element.
+    f32x4 cA, cB, cC, cD;
     {
       const float* st = P.st_k + ((size_t)b * GC + gch) * 2;
       f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-      pm = (f32x4){s01.x, s01.z, s23.x, s23.z}; pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+      const f32x4 pm = {s01.x, s01.z, s23.x, s23.z}, pr = {s01.y, s01.w, s23.y, s23.w};
       const float* bs = P.bst_k + ((size_t)b * GC + gch) * 2;
       f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
-      ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z}; ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
+      const f32x4 ps1 = {b01.x, b01.z, b23.x, b23.z}, ps2 = {b01.y, b01.w, b23.y, b23.w};
+      cA = pr;
+      if (UP2) { cB = -(pm * pr); cC = -(pr * ps2); cD = -(pr * ps1); }
+      else { cB = -(pr * pr * ps2); cC = pr * (pr * ps2 * pm - ps1); cD = cC; }
     }
-    const int rb = UP2 ? t0 / 2 : t0 - 2 + PL;
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
-      const int row = grow0 + k * rstep_g, gr = rb + row;
-      if (row < NRg) {
-        const bool ok = gr >= 0 && gr < Lg;
-        f32x4 gv;
-        if constexpr (GH) gv = h2f4(rg[k]) * inv_g; else gv = rg[k];
-        split_store4(gyH, gyLo, row * RSg + gch,
-                     ok ? pro_apply(UP2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD, gv, ry[k], pm, pr, ps1, ps2) : (f32x4){0, 0, 0, 0});
+      const int row = grow0 + k * rstep_g;
+      f32x4 gv;
+      if constexpr (GH) gv = h2f4(rg[k]) * inv_g; else gv = rg[k];
+      f32x4 gy;
+      if (UP2) {
+        const f32x4 n = fma4(ry[k], cA, cB);
+        gy = fma4(gv * cA, gelu_grad4(n), fma4(n, cC, cD));
+      } else {
+        gy = fma4(cA, gv, fma4(cB, ry[k], cC));
       }
+      split_store4(gyH, gyLo, row * RSg + gch, gy);
     }
-    f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
-    if (P.st_in) {
-      const float* st = P.st_in + ((size_t)b * HC + hch) * 2;
-      f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-      hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+    f32x4 hr[CH], hb[CH];   // n = x * rstd + (-mean * rstd)
+#pragma unroll
+    for (int nt = 0; nt < CH; ++nt) {
+      hr[nt] = (f32x4){1, 1, 1, 1}; hb[nt] = (f32x4){0, 0, 0, 0};
+      if (P.st_in) {
+        const float* st = P.st_in + ((size_t)b * HC + nt * 16 + 4 * g) * 2;
+        f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+        hr[nt] = (f32x4){s01.y, s01.w, s23.y, s23.w};
+        hb[nt] = -((f32x4){s01.x, s01.z, s23.x, s23.z} * hr[nt]);
+      }
     }
     if (FIRST) {
       if (tid < TM + 4) xsL[tid] = rxs[0];
@@ -568,10 +589,11 @@ void bwd_fused_bf_kernel(BwdP P) {
       __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < NH; ++k) {
-      const int row = hrow0 + k * rstep_h, gr = t0 - PL + row;
-      if (row < NRh) {
-        const bool ok = gr >= 0 && gr < Lh;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = (bwd_hm(mt) + PL) & (TM - 1);
+#pragma unroll
+      for (int nt = 0; nt < CH; ++nt) {
+        const int k = mt * CH + nt, ch = nt * 16 + 4 * g;
         f32x4 xv;
         if (FIRST) {  // window row <-> position t0-pad+row; xsL[i] <-> position t0-2pad+i: conv1 taps at p-1,p,p+1 or p-2,p-1,p
           const float xm = xsL[row], xc = xsL[row + 1], xp = xsL[row + 2];
@@ -582,21 +604,16 @@ void bwd_fused_bf_kernel(BwdP P) {
         } else {
           xv = rh[k];
         }
-        const f32x4 nv = (xv - hm) * hr;
-        {
-          f32x4 hv, gpv;
-          gelu_both4(nv, hv, gpv);
-          split_store4(hH, hLo, row * RSh + hch, ok ? hv : (f32x4){0, 0, 0, 0});
-          if (row >= PL && row < TM + PL) {
-            const int rr = row - PL;
-            if (GPS == 2) {
-              st4(gpL + rr * 32 + bwd_gp_col(rr, hch), gpv);
-              st4h(nH, (unsigned)(rr * 32 + bwd_n_col(rr, hch)), f2h4(nv));
-            } else {
-              st4(nL + rr * RSn + hch, nv);
-              st4(gpL + rr * RSn + hch, gpv);
-            }
-          }
+        const f32x4 nv = fma4(xv, hr[nt], hb[nt]);
+        f32x4 hv;
+        gelu_both4(nv, hv, gR[k]);
+        nR[k] = nv;
+        if (HLO) split_store4(hH, hLo, row * RSh + ch, hv);
+        else {
+          u32x2 h2;
+          h2.x = __builtin_bit_cast(unsigned, (bf16x2){(__bf16)hv.x, (__bf16)hv.y});
+          h2.y = __builtin_bit_cast(unsigned, (bf16x2){(__bf16)hv.z, (__bf16)hv.w});
+          *reinterpret_cast<u32x2*>(hH + row * RSh + ch) = h2;
         }
       }
     }
@@ -606,7 +623,34 @@ void bwd_fused_bf_kernel(BwdP P) {
         const int row = grow0 + k * rstep_g;
         f32x4 pv;
         if constexpr (GH) pv = h2f4(rp[k]) * inv_p; else pv = rp[k];
-        if (row < TM / 2) split_store4(pH, pLo, row * RSg + gch, pv);
+        split_store4(pH, pLo, row * RSg + gch, pv);
+      }
+    }
+    // rows outside the sample (the zero padding of the conv; only a sample's first and last tiles have any -- a uniform branch): the passes
+    // above loaded them from clamped addresses and transformed them like any other row; the lanes that own them now overwrite them with
+    // zeros (the same thread stored the row: LDS keeps a thread's stores in order).  Rounds 1-4 predicated every load and every row of
+    // every tile instead: ~120 of a tile's ~1250 instructions per wave.
+    const int rbg = UP2 ? t0 / 2 : t0 - 2 + PL;
+    if (rbg < 0 || rbg + NRg > Lg || t0 - PL < 0 || t0 - PL + TM > Lh) {
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        const int row = grow0 + k * rstep_g, gr = rbg + row;
+        if (gr < 0 || gr >= Lg) { zero_store4(gyH, row * RSg + gch); zero_store4(gyLo, row * RSg + gch); }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = (bwd_hm(mt) + PL) & (TM - 1), gr = t0 - PL + row;
+        if (gr < 0 || gr >= Lh) {
+#pragma unroll
+          for (int nt = 0; nt < CH; ++nt) { zero_store4(hH, row * RSh + nt * 16 + 4 * g); if (HLO) zero_store4(hLo, row * RSh + nt * 16 + 4 * g); }
+        }
+      }
+      if (RD) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const int row = grow0 + k * rstep_g;
+          if (t0 / 2 + row >= (Lh >> 1)) { zero_store4(pH, row * RSg + gch); zero_store4(pLo, row * RSg + gch); }
+        }
       }
     }
   };
@@ -618,7 +662,8 @@ void bwd_fused_bf_kernel(BwdP P) {
   w2s_dd* accL = reinterpret_cast<w2s_dd*>(reinterpret_cast<char*>(smem4) + P.acc_off);   // running statistics sums of this run, one slot per thread < 2*HC
   if (tid < 2 * HC) accL[tid] = (w2s_dd){0.0, 0.0};
   int b = wrun.first / P.ntiles, tile = wrun.first - b * P.ntiles;   // one division per launch; the run is contiguous
-  if (wrun.count > 0) prefetch(b, tile);
+  using PT0 = std::integral_constant<int, 0>; using PT1 = std::integral_constant<int, 1>;
+  if (wrun.count > 0) { prefetch(b, tile, PT0{}); prefetch(b, tile, PT1{}); }
 #ifdef W2S_WIDE_STAMP   // diagnostic build only (tools/altlib.sh; W2S_STAMP=1 tools/kbench.py): cycles of workgroup 0's first wave per phase -> part[0..7]
   unsigned long long sA_ = 0, sW_ = 0, sC_ = 0, sB_ = 0, sD_ = 0, sG_ = 0, k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, k6 = 0;
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();   // (100 MHz / shader clock)
@@ -636,16 +681,20 @@ void bwd_fused_bf_kernel(BwdP P) {
     k2 = __builtin_amdgcn_s_memtime();
 #endif
     commit(b, tile);
+#if !W2S_BF_LATEH
     f32x4 q3[RD ? MT * CH : 1];  // this tile's y3 fragments (the prefetch below reloads rq for the next tile)
     if (RD) {
 #pragma unroll
       for (int i = 0; i < MT * CH; ++i) q3[i] = rq[i];
     }
+#else
+    f32x4 (&q3)[RD ? MT * CH : 1] = rq;   // (reloaded after the epilogue)
+#endif
 #ifdef W2S_WIDE_STAMP
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     k3 = __builtin_amdgcn_s_memtime();
 #endif
-    if (tl + 1 < wend) prefetch(b_n, tile_n);
+    if (tl + 1 < wend) { prefetch(b_n, tile_n, PT0{}); if (!W2S_BF_LATEH) prefetch(b_n, tile_n, PT1{}); }
     __syncthreads();
 #ifdef W2S_WIDE_STAMP
     k4 = __builtin_amdgcn_s_memtime();
@@ -757,6 +806,7 @@ void bwd_fused_bf_kernel(BwdP P) {
     }
 
     // ---- epilogue: * GELU'(n_in), statistics, store
+    const int elim = min(TS, Lh - t0);   // uniform: tile-local positions below it are this tile's outputs
     f32x4 sA[CH], sB[CH];
 #pragma unroll
     for (int nt = 0; nt < CH; ++nt) { sA[nt] = (f32x4){0, 0, 0, 0}; sB[nt] = (f32x4){0, 0, 0, 0}; }
@@ -776,15 +826,14 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int pos = UP2 ? t0 + 2 * (wave * (8 * MT) + (mt >> 1) * 16 + r) + (mt & 1) : t0 + wave * (16 * MT) + mt * 16 + r;
-      if (pos >= Lh || pos - t0 >= TS) continue;   // (the last two positions of the MFMA tiles belong to the next tile)
+      if (pos - t0 >= elim) continue;   // (the last two positions of the MFMA tiles belong to the next tile; positions past the sample)
 #pragma unroll
       for (int nt = 0; nt < CH; ++nt) {
         const int ch = nt * 16 + 4 * g;
-        const int mrow = pos - t0;
-        const f32x4 n = (GPS == 2) ? h2f4(ld4h(nH, (unsigned)(mrow * 32 + bwd_n_col(mrow, ch)))) : *reinterpret_cast<const f32x4*>(nL + mrow * RSn + ch);
+        const f32x4 n = nR[mt * CH + nt];
         f32x4 v = acc[mt][nt];
         if (P.add_even && !(pos & 1)) v += ld4o(P.add_even + (size_t)b * (Lh >> 1) * HC, (unsigned)(pos >> 1) * HC + ch);
-        v = v * ((GPS == 2) ? *reinterpret_cast<const f32x4*>(gpL + mrow * 32 + bwd_gp_col(mrow, ch)) : *reinterpret_cast<const f32x4*>(gpL + mrow * RSn + ch));
+        v = v * gR[mt * CH + nt];
         if (RD && P.y3p) {  // statistics of the previous block's conv3 backward: gn = gout * GELU'(n3), n3 = IN(y3)
           const float* st = P.st3p + ((size_t)b * HC + ch) * 2;
           const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
@@ -898,6 +947,7 @@ void bwd_fused_bf_kernel(BwdP P) {
 #ifdef W2S_WIDE_STAMP
     k5 = __builtin_amdgcn_s_memtime();
 #endif
+    if (W2S_BF_LATEH && tl + 1 < wend) prefetch(b_n, tile_n, PT1{});
     constexpr int KS = (UP2 ? TM / 2 : TM) / 32;
 #pragma unroll
     for (int s0 = 0; s0 < KS; s0 += KW) {
@@ -917,8 +967,13 @@ void bwd_fused_bf_kernel(BwdP P) {
         const int h0 = UP2 ? 2 * p0 + j : p0 + j, h1 = UP2 ? 2 * (p0 + 4) + j : p0 + 4 + j;
         const int hcol = wc * 16 + 4 * p4;
         const bf16x8 bh = lds_tr8(hH + h0 * RSh + hcol, hH + h1 * RSh + hcol);
-        const bf16x8 bl = lds_tr8(hLo + h0 * RSh + hcol, hLo + h1 * RSh + hcol);
-        accw[j] = mfma_bf3(ah, al, bh, bl, accw[j]);
+        if (HLO) {
+          const bf16x8 bl = lds_tr8(hLo + h0 * RSh + hcol, hLo + h1 * RSh + hcol);
+          accw[j] = mfma_bf3(ah, al, bh, bl, accw[j]);
+        } else {
+          accw[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, accw[j], 0, 0, 0);
+          accw[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, accw[j], 0, 0, 0);
+        }
       }
     }
     if (RD) {  // dWd[o][c] += sum_u gpre[u][o] * h[2u][c]   (window row of position t0 + 2u is 2u + pad)
@@ -933,8 +988,13 @@ void bwd_fused_bf_kernel(BwdP P) {
         bf16x8 al = lds_tr8(pLo + p0 * RSg + gcol, pLo + (p0 + 4) * RSg + gcol);
         if (s == KSD - 1 && g == 3) { ah[7] = (__bf16)0.f; al[7] = (__bf16)0.f; }   // gpre row TM/2 - 1 = position t0 + TS: the next tile's
         const bf16x8 bh = lds_tr8(hH + (2 * p0 + PL) * RSh + hcol, hH + (2 * (p0 + 4) + PL) * RSh + hcol);
-        const bf16x8 bl = lds_tr8(hLo + (2 * p0 + PL) * RSh + hcol, hLo + (2 * (p0 + 4) + PL) * RSh + hcol);
-        accd = mfma_bf3(ah, al, bh, bl, accd);
+        if (HLO) {
+          const bf16x8 bl = lds_tr8(hLo + (2 * p0 + PL) * RSh + hcol, hLo + (2 * (p0 + 4) + PL) * RSh + hcol);
+          accd = mfma_bf3(ah, al, bh, bl, accd);
+        } else {
+          accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, accd, 0, 0, 0);
+          accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, accd, 0, 0, 0);
+        }
       }
     }
 #ifdef W2S_WIDE_STAMP
@@ -1000,8 +1060,7 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   P.ntiles = (P.Lh + TS - 1) / TS;
   P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, nslab);
   constexpr int NRg = UP2 ? TM / 2 : TM, NRh = TM, NRp = RD ? TM / 2 + 1 : 0;
-  size_t lds = (HC == 16 ? (size_t)TM * bwd_rs(HC) * 4 * 2 : (size_t)TM * 32 * (4 + 2)) + (size_t)bwd_redn(CH) * 4 +   // n + GELU' planes (32 ch: fp32 + fp16, unpadded)
-               (size_t)2 * 2 * ((NRg + NRp) * bf_rs(GC) + NRh * bf_rs(HC) + HC * (KD + 8));
+  size_t lds = (size_t)bwd_redn(CH) * 4 + (size_t)2 * (2 * (NRg + NRp) * bf_rs(GC) + (W2S_BF_HLO ? 2 : 1) * NRh * bf_rsh(HC, UP2) + 2 * HC * (KD + 8));
   if (FIRST) lds += (size_t)(TM + 4) * 4 + 4 * 4 * 12 * 4;
   if (RD) lds += (4 * 4 * 4 + 16) * 4;
   if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4] (and a finaliser workgroup's)

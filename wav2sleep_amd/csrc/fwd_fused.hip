@@ -24,13 +24,6 @@ struct FwdP {
   StatFin fin;   // in-kernel statistics finalisation (fin.out == NULL: partials only)
 };
 
-typedef __bf16 bf16x4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void fsplit_store4(__bf16* hi, __bf16* lo, int off, f32x4 t) {
-  bf16x4f h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
-  bf16x4f l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
-  *reinterpret_cast<bf16x4f*>(hi + off) = h;
-  *reinterpret_cast<bf16x4f*>(lo + off) = l;
-}
 __host__ __device__ constexpr int ff_rs(int c) { return c == 16 ? 16 : c + 8; }  // 32-B rows are conflict-free as they are
 // Output positions per tile.  The window of a TM-position tile has TM*stride + 2 (stride 1) / + 1 (stride 2) rows; 256 threads stage
 // 64 rows of 16 channels (32 rows of 32) per pass, so the two halo rows cost wave 0 a whole extra pass of prologue arithmetic (erf-GELU,
@@ -79,7 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
     const int row = i / (KD / 4), k = (i % (KD / 4)) * 4;
     f32x4 v = {0, 0, 0, 0};
     if (k < 3 * HC) v = ld4(P.w + (size_t)row * (3 * HC) + k);
-    fsplit_store4(wH, wLo, row * WROW + k, v);
+    split_store4(wH, wLo, row * WROW + k, v);
   }
 
   constexpr int c4h = HC / 4, rstep = 256 / c4h, NH = (NRh + rstep - 1) / rstep;
@@ -132,11 +125,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
     const int b = b_cur, t0 = tile_cur * TS;
     const int rb = t0 * STRIDE - P.pad;
     const bool inside = rb >= 0 && rb + NRh <= L_in;   // uniform: every window row is a real position (all but a sample's first / last tile)
-    f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
+    f32x4 hb = {0, 0, 0, 0}, hr = {1, 1, 1, 1};   // n = x * rstd + (-mean * rstd): one fused multiply-add per element
     if (PRO != W2S_PRO_GELU) {
       const float* st = P.st_in + ((size_t)b * HC + hch) * 2;
       f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-      hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+      hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+      hb = -((f32x4){s01.x, s01.z, s23.x, s23.z} * hr);
     }
     if (FIRST) {
 #pragma unroll
@@ -149,9 +143,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
     }
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
-      const int row = hrow0 + k * rstep, gr = rb + row;
+      const int row = hrow0 + k * rstep;
       if (row < NRh) {
-        const bool ok = gr >= 0 && gr < L_in;
         f32x4 xv;
         if (FIRST) {  // window row <-> position rb+row; xsL[i] <-> position rb-pad+i: taps at p-1,p,p+1 (pad 1) or p-2,p-1,p (pad 2)
           const float xm = xsL[row], xc = xsL[row + 1], xp = xsL[row + 2];
@@ -162,9 +155,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
         } else {
           xv = rh[S][k];
         }
-        f32x4 hv = (W2S_FF_DBG & 1) ? xv - hm : gelu4((xv - hm) * hr);
-        if (!inside) hv = ok ? hv : (f32x4){0, 0, 0, 0};   // (uniform branch: the zero padding only exists at a sample's ends)
-        if (!(W2S_FF_DBG & 4)) fsplit_store4(hH, hLo, row * RSh + hch, hv);
+        const f32x4 hv = (W2S_FF_DBG & 1) ? xv + hb : gelu4(fma4(xv, hr, hb));
+        if (!(W2S_FF_DBG & 4)) split_store4(hH, hLo, row * RSh + hch, hv);
+      }
+    }
+    if (!inside) {   // (uniform: the zero padding only exists at a sample's ends) rows outside the sample were loaded from clamped addresses
+                     // and transformed like the others; the lanes that stored them now overwrite them with zeros
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const int row = hrow0 + k * rstep, gr = rb + row;
+        if (row < NRh && (gr < 0 || gr >= L_in)) { zero_store4(hH, row * RSh + hch); zero_store4(hLo, row * RSh + hch); }
       }
     }
   };

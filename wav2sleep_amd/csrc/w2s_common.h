@@ -200,6 +200,27 @@ __device__ __forceinline__ void gelu_both4(f32x4 v, f32x4& h, f32x4& gp) {
   h = v * cdf;
   gp = fma4(v * 0.39894228040143267794f, pdf, cdf);
 }
+// x = hi + lo as two bf16 (round 5: written on the bits -- hipcc's own lowering of `(__bf16)(x - (float)(__bf16)x)` converted half of the
+// elements one by one: 14 instructions per four elements, this is 10): hi pair = ONE v_cvt_pk_bf16_f32, its two values back as fp32 are a
+// shift and a mask of that word, lo pair = ONE v_cvt_pk_bf16_f32 of the two remainders
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& hi2, unsigned& lo2) {
+  const bf16x2 h = {(__bf16)x, (__bf16)y};
+  const unsigned u = __builtin_bit_cast(unsigned, h);
+  const float xh = __builtin_bit_cast(float, u << 16), yh = __builtin_bit_cast(float, u & 0xffff0000u);
+  const bf16x2 l = {(__bf16)(x - xh), (__bf16)(y - yh)};
+  hi2 = u;
+  lo2 = __builtin_bit_cast(unsigned, l);
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_store4(__bf16* hi, __bf16* lo, int off, f32x4 t) {
+  unsigned h0, h1, l0, l1;
+  split_pair(t.x, t.y, h0, l0);
+  split_pair(t.z, t.w, h1, l1);
+  *reinterpret_cast<u32x2*>(hi + off) = (u32x2){h0, h1};
+  *reinterpret_cast<u32x2*>(lo + off) = (u32x2){l0, l1};
+}
+__device__ __forceinline__ void zero_store4(__bf16* pl, int off) { *reinterpret_cast<u32x2*>(pl + off) = (u32x2){0u, 0u}; }
 __device__ __forceinline__ float sanitize_f(float x) { return isinf(x) ? 0.0f : x; }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
