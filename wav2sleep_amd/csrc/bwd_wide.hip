@@ -40,14 +40,8 @@ struct BwdWideP {
   StatFin fin;            // in-kernel statistics finalisation (fin.out == NULL: per-tile partials in `part`)
 };
 
-typedef __bf16 wbbf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 wbbf16x4v __attribute__((__vector_size__(4 * sizeof(__bf16))));
-__device__ __forceinline__ void wb_split_store4(__bf16* hi, __bf16* lo, int off, f32x4 t) {
-  wbbf16x4 h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
-  wbbf16x4 l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
-  *reinterpret_cast<wbbf16x4*>(hi + off) = h;
-  *reinterpret_cast<wbbf16x4*>(lo + off) = l;
-}
+#define wb_split_store4 split_store4   /* w2s_common.h: the explicit bit form (10 instead of 14 instructions per four elements) */
 __device__ __forceinline__ bf16x8 wb_tr8(const __bf16* p0, const __bf16* p1) {
   typedef __attribute__((address_space(3))) wbbf16x4v* lds_p;
   wbbf16x4v a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p0));
@@ -157,53 +151,65 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
       __bf16* pH = hL + NR * RSh;
       __bf16* pL = pH + NRP * RSg;
       float* gpL = reinterpret_cast<float*>(pL + NRP * RSg);
-      f32x4 pm, pr, ps1, ps2;
+      // instance-norm backward as two fused multiply-adds per element (coefficients per tile; see bwd_fused.hip `commit`):
+      //   stride 1: gy = r g + (-r^2 s2) y + r (r s2 m - s1);   stride 2: n = r y + (-m r), gy = (r g) GELU'(n) + n (-r s2) + (-r s1)
+      f32x4 cA, cB, cC, cD;
       {
         const float* st = stL + (b * OC + gch) * 2;
         const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-        pm = (f32x4){s01.x, s01.z, s23.x, s23.z}; pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+        const f32x4 pm = {s01.x, s01.z, s23.x, s23.z}, pr = {s01.y, s01.w, s23.y, s23.w};
         const float* bs = stL + ((P.B + b) * OC + gch) * 2;
         const f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
-        ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z}; ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
+        const f32x4 ps1 = {b01.x, b01.z, b23.x, b23.z}, ps2 = {b01.y, b01.w, b23.y, b23.w};
+        cA = pr;
+        if (UP2) { cB = -(pm * pr); cC = -(pr * ps2); cD = -(pr * ps1); }
+        else { cB = -(pr * pr * ps2); cC = pr * (pr * ps2 * pm - ps1); cD = cC; }
       }
 #pragma unroll
       for (int k = 0; k < NG; ++k) {
-        const int row = grow0 + k * rsg, gr = (UP2 ? t0 / 2 : t0 - 1) + row;
+        const int row = grow0 + k * rsg;
         const f32x4 v1 = rg[S][k], v2 = ry[S][k];
         load_g(SET, i + PD, k);
         if (live && row < NRG) {
+          f32x4 tv;
 #ifdef W2S_BWW_NOARITH   // diagnostic builds (numerics wrong on purpose): the producers without their transform arithmetic
-          const f32x4 tv = v1 + v2 * pm;
+          tv = v1 + v2 * cA;
 #else
-          const f32x4 tv = pro_apply(UP2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD, v1, v2, pm, pr, ps1, ps2);
+          if (UP2) {
+            const f32x4 n = fma4(v2, cA, cB);
+            tv = fma4(v1 * cA, gelu_grad4(n), fma4(n, cC, cD));
+          } else {
+            tv = fma4(cA, v1, fma4(cB, v2, cC));
+          }
 #endif
 #ifndef W2S_BWW_NOLDSW
-          wb_split_store4(gH, gL, row * RSg + gch, (gr >= 0 && gr < Lg) ? tv : (f32x4){0, 0, 0, 0});
+          wb_split_store4(gH, gL, row * RSg + gch, tv);
 #else
           if (tv.x == 123.f) wb_split_store4(gH, gL, row * RSg + gch, tv);
 #endif
         }
       }
-      f32x4 hm = {0, 0, 0, 0}, hr = {1, 1, 1, 1};
+      f32x4 hb = {0, 0, 0, 0}, hr = {1, 1, 1, 1};   // n = x rstd + (-mean rstd)
       if (HST) {
         const float* st = stL + P.B * OC * 4 + (b * HC + hch) * 2;
         const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-        hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+        hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+        hb = -((f32x4){s01.x, s01.z, s23.x, s23.z} * hr);
       }
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
-        const int row = hrow0 + k * rsh, gr = t0 - 1 + row;
+        const int row = hrow0 + k * rsh;
         const f32x4 v = rh[S][k];
         load_h(SET, i + PD, k);
         if (live && row < NR) {
           f32x4 hv, gpv;
 #ifdef W2S_BWW_NOARITH
-          hv = (v - hm) * hr; gpv = hv;
+          hv = fma4(v, hr, hb); gpv = hv;
 #else
-          gelu_both4((v - hm) * hr, hv, gpv);
+          gelu_both4(fma4(v, hr, hb), hv, gpv);
 #endif
 #ifndef W2S_BWW_NOLDSW
-          wb_split_store4(hH, hL, row * RSh + hch, (gr >= 0 && gr < L) ? hv : (f32x4){0, 0, 0, 0});
+          wb_split_store4(hH, hL, row * RSh + hch, hv);
           if (row >= 1 && row <= TM) st4(gpL + (row - 1) * RSp + hch, gpv);
 #else
           if (hv.x == 123.f) { wb_split_store4(hH, hL, row * RSh + hch, hv); st4(gpL + (row - 1) * RSp + hch, gpv); }
@@ -213,10 +219,32 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
       if constexpr (RD) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-          const int row = grow0 + k * rsg, gr = t0 / 2 + row;
+          const int row = grow0 + k * rsg;
           const f32x4 v = rp[S][k];
           load_p(SET, i + PD, k);
-          if (live && row < TM / 2) wb_split_store4(pH, pL, row * RSg + gch, (gr < (L >> 1)) ? v : (f32x4){0, 0, 0, 0});
+          if (live && row < TM / 2) wb_split_store4(pH, pL, row * RSg + gch, v);
+        }
+      }
+      // rows outside the sample (the conv's zero padding; a sample's first / last tile only -- uniform branch): loaded from clamped
+      // addresses and transformed like any row above, now overwritten with zeros by the lanes that stored them (bwd_fused.hip `commit`)
+      const int rbg = UP2 ? t0 / 2 : t0 - 1;
+      if (live && (rbg < 0 || rbg + NRG > Lg || t0 - 1 < 0 || t0 - 1 + NR > L)) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+          const int row = grow0 + k * rsg, gr = rbg + row;
+          if (row < NRG && (gr < 0 || gr >= Lg)) { zero_store4(gH, row * RSg + gch); zero_store4(gL, row * RSg + gch); }
+        }
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+          const int row = hrow0 + k * rsh, gr = t0 - 1 + row;
+          if (row < NR && (gr < 0 || gr >= L)) { zero_store4(hH, row * RSh + hch); zero_store4(hL, row * RSh + hch); }
+        }
+        if constexpr (RD) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            const int row = grow0 + k * rsg;
+            if (row < TM / 2 && t0 / 2 + row >= (L >> 1)) { zero_store4(pH, row * RSg + gch); zero_store4(pL, row * RSg + gch); }
+          }
         }
       }
     };

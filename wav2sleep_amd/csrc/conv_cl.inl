@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
       ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
     }
   }
+  const ProCoef kc = pro_coef(pro, pm, pr, ps1, ps2);
   // wave-uniform per-sample bases + 32-bit lane offsets: scalar-base addressing (a sample's tensor is < 4 GB)
   const float* xb = ((PRO == W2S_PRO_FIRST)) ? a.x + (size_t)b * L_in : a.x + (size_t)b * L_in * a.ldx;
   const float* x2b = (pro == W2S_PRO_INBWD || pro == W2S_PRO_INBWD_GP) ? a.x2 + (size_t)b * L_in * a.ldx : nullptr;
@@ -154,12 +155,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
         const int rr = row + u * rstep, gr = rb + rr * rowmul;
         if (rr < NR) {
           const bool ok = (gr >= 0) && (gr < L_in);
-          f32x4 t = ok ? pro_apply(pro, v[u], v2[u], pm, pr, ps1, ps2) : (f32x4){0, 0, 0, 0};
+          f32x4 t = ok ? pro_apply_k(pro, v[u], v2[u], kc) : (f32x4){0, 0, 0, 0};
           if constexpr (BF) {
-            bf16x4 h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
-            bf16x4 l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
-            *reinterpret_cast<bf16x4*>(hiL + rr * RSE + myc4 * 4) = h;
-            *reinterpret_cast<bf16x4*>(loL + rr * RSE + myc4 * 4) = l;
+            split_store4(hiL, loL, rr * RSE + myc4 * 4, t);
           } else {
             st4(smem + rr * RS + myc4 * 4, t);
           }

@@ -30,13 +30,7 @@ struct WideP {
   StatFin fin;   // in-kernel statistics finalisation (fin.out == NULL: per-tile partials in `part`)
 };
 
-typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void wsplit_store4(__bf16* hi, __bf16* lo, int off, f32x4 t) {
-  wbf16x4 h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
-  wbf16x4 l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
-  *reinterpret_cast<wbf16x4*>(hi + off) = h;
-  *reinterpret_cast<wbf16x4*>(lo + off) = l;
-}
+#define wsplit_store4 split_store4   /* w2s_common.h: the explicit bit form */
 
 // NW consumer waves (wave w: output channels [16w, 16w+16), weights in registers, MFMA + epilogue) and NP producer waves (global
 // loads of the raw window, on-load transform, bf16 hi/lo split, LDS writes of the NEXT tile into the other buffer).  A SIMD hosts
@@ -121,35 +115,52 @@ __device__ __forceinline__ void conv_wide_body(const WideP& P) {
     // stage tile i (its raw rows are in register set SET) into LDS buffer i & 1, refilling the set with tile i + PD
     auto stage = [&](auto SET, int i) {
       constexpr int S = decltype(SET)::value;
-      const bool live = i < nt_wg;   // uniform; padding rounds only keep the load queue regular
-      int b, tile_;
+      int b, tile_;   // (padding rounds i >= nt_wg only keep the load queue regular)
       w2s_run_pos(run_b0, run_t0, P.ntiles, min(i, nt_wg - 1), b, tile_);
       const int t0 = tile_ * TM;
       const int rb = UP2 ? t0 / 2 : t0 * STRIDE - P.pad;
       __bf16* hiL = lds + (i & 1) * BUF;
       __bf16* loL = hiL + NR * RSE;
-      f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, ps1 = {0, 0, 0, 0}, ps2 = {0, 0, 0, 0};
+      // per-channel coefficients of the on-load transform, formed once per tile so that the per-element work is fused multiply-adds:
+      //   IN + GELU: n = x r + (-m r);  IN backward: gy = r g + (-r^2 s2) y + r (r s2 m - s1)  (with GELU': n = r y + (-m r),
+      //   gy = (r g) GELU'(n) + n (-r s2) + (-r s1)) -- bwd_fused.hip `commit`
+      f32x4 cA = {1, 1, 1, 1}, cB = {0, 0, 0, 0}, cC = {0, 0, 0, 0}, cD = {0, 0, 0, 0};
       if (PRO != W2S_PRO_GELU) {   // statistics from the LDS copy made at kernel start (lgkmcnt: does not touch the vector-memory queue)
         const float* st = stL + (b * HC + mych) * 2;
         const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-        pm = (f32x4){s01.x, s01.z, s23.x, s23.z}; pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+        const f32x4 pm = {s01.x, s01.z, s23.x, s23.z}, pr = {s01.y, s01.w, s23.y, s23.w};
+        cA = pr; cB = -(pm * pr);
         if (TWO) {
           const float* bs = stL + ((P.B + b) * HC + mych) * 2;
           const f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
-          ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z}; ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
+          const f32x4 ps1 = {b01.x, b01.z, b23.x, b23.z}, ps2 = {b01.y, b01.w, b23.y, b23.w};
+          if (PRO == W2S_PRO_INBWD_GP) { cC = -(pr * ps2); cD = -(pr * ps1); }
+          else { cB = -(pr * pr * ps2); cC = pr * (pr * ps2 * pm - ps1); }
         }
       }
       const TileAt nxt = tile_at(i + PD);
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
-        const int row = row0 + k * rstep, gr = rb + row;
+        const int row = row0 + k * rstep;
         f32x4 v1 = rx[S][k], v2 = rx[S][k];
         if constexpr (TWO) v2 = rx2[S][k];
         load_row(SET, nxt, k);   // the register is free again: the load of the tile PD rounds ahead goes out at once
-        if (live && row < NR && !(P.dbg & 4)) {
-          const bool ok = gr >= 0 && gr < L_in;
-          const f32x4 tv = (P.dbg & 1) ? v1 + v2 : pro_apply(PRO, v1, v2, pm, pr, ps1, ps2);
-          wsplit_store4(hiL, loL, row * RSE + mych, ok ? tv : (f32x4){0, 0, 0, 0});
+        if (row < NR && !(P.dbg & 4)) {   // (a padding round stages its clamped tile again, into the buffer nobody reads: no `live` branch)
+          f32x4 tv;   // (no run-time branch in here: control flow around the vector-memory queue makes hipcc drain it -- see above)
+          if constexpr (PRO == W2S_PRO_GELU) tv = gelu4(v1);
+          else if constexpr (PRO == W2S_PRO_IN_GELU) tv = gelu4(fma4(v1, cA, cB));
+          else if constexpr (PRO == W2S_PRO_INBWD) tv = fma4(cA, v1, fma4(cB, v2, cC));
+          else if constexpr (PRO == W2S_PRO_INBWD_GP) { const f32x4 n = fma4(v2, cA, cB); tv = fma4(v1 * cA, gelu_grad4(n), fma4(n, cC, cD)); }
+          else tv = pro_apply(PRO, v1, v2, cA, cA, cA, cA);   // (not instantiated)
+          wsplit_store4(hiL, loL, row * RSE + mych, (P.dbg & 1) ? v1 + v2 : tv);
+        }
+      }
+      // rows outside the sample (zero padding; a sample's first / last tile only -- uniform): zeroed after the fact by the lanes that stored them
+      if (!(P.dbg & 4) && (rb < 0 || rb + NR > L_in)) {
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+          const int row = row0 + k * rstep, gr = rb + row;
+          if (row < NR && (gr < 0 || gr >= L_in)) { zero_store4(hiL, row * RSE + mych); zero_store4(loL, row * RSE + mych); }
         }
       }
     };

@@ -223,6 +223,39 @@ __device__ __forceinline__ void split_store4(__bf16* hi, __bf16* lo, int off, f3
 __device__ __forceinline__ void zero_store4(__bf16* pl, int off) { *reinterpret_cast<u32x2*>(pl + off) = (u32x2){0u, 0u}; }
 __device__ __forceinline__ float sanitize_f(float x) { return isinf(x) ? 0.0f : x; }
 
+// The on-load transforms (conv_cl.inl pro_apply) with the per-channel coefficients formed ONCE (per tile / per staging pass) so that an element costs fused
+// multiply-adds only (round 5; the textbook forms above are 2 + 3 (+1) dependent operations per element):
+//   IN(+GELU):    n  = x r + (-m r)
+//   IN backward:  gy = r (g - s1 - n s2) = r g + (-r^2 s2) y + r (r s2 m - s1)
+//   ... + GELU':  n  = r y + (-m r),  gy = (r g) GELU'(n) + n (-r s2) + (-r s1)
+struct ProCoef { f32x4 a, b, c, d; };
+__device__ __forceinline__ ProCoef pro_coef(int pro, f32x4 mean, f32x4 rstd, f32x4 s1, f32x4 s2) {
+  ProCoef k{rstd, -(mean * rstd), {0, 0, 0, 0}, {0, 0, 0, 0}};
+  if (pro == W2S_PRO_INBWD) { k.b = -(rstd * rstd * s2); k.c = rstd * (rstd * s2 * mean - s1); }
+  else if (pro == W2S_PRO_INBWD_GP) { k.c = -(rstd * s2); k.d = -(rstd * s1); }
+  return k;
+}
+__device__ __forceinline__ f32x4 pro_apply_k(int pro, f32x4 v, f32x4 v2, const ProCoef& k) {
+  switch (pro) {
+    case W2S_PRO_SANITIZE:
+      v.x = sanitize_f(v.x); v.y = sanitize_f(v.y); v.z = sanitize_f(v.z); v.w = sanitize_f(v.w);
+      return v;
+    case W2S_PRO_GELU:
+      return gelu4(v);
+    case W2S_PRO_IN_GELU:
+    case W2S_PRO_FIRST:
+      return gelu4(fma4(v, k.a, k.b));
+    case W2S_PRO_INBWD:
+      return fma4(k.a, v, fma4(k.b, v2, k.c));
+    case W2S_PRO_INBWD_GP: {
+      const f32x4 n = fma4(v2, k.a, k.b);
+      return fma4(v * k.a, gelu_grad4(n), fma4(n, k.c, k.d));
+    }
+    default:
+      return v;
+  }
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 // wave-uniform base + 32-bit BYTE offset per lane: selects the scalar-base addressing mode (no 64-bit VALU address arithmetic)

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP P) {
         load_chan_params(a.g_stats, b, a.cout, ch, pm, pr);
         if (a.pro_g >= W2S_PRO_INBWD) load_chan_params(a.g_bstats, b, a.cout, ch, ps1, ps2);
       }
+      const ProCoef kg = pro_coef(a.pro_g, pm, pr, ps1, ps2);
       const float* gb = a.g + (size_t)b * a.L_out * a.ldg;   // uniform base, 32-bit lane offsets (scalar-base addressing)
       const float* g2b = (a.pro_g >= W2S_PRO_INBWD) ? a.g2 + (size_t)b * a.L_out * a.ldg : nullptr;
       for (int row = row0; row < TM; row += rstep) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP P) {
           const unsigned go = (unsigned)t * (unsigned)a.ldg + ch;
           f32x4 x = ld4o(gb, go);
           f32x4 x2 = g2b ? ld4o(g2b, go) : (f32x4){0, 0, 0, 0};
-          v = pro4(a.pro_g, x, x2, pm, pr, ps1, ps2);
+          v = pro_apply_k(a.pro_g, x, x2, kg);
         }
         st4(gyL + row * RSg + myc4 * 4, v);
       }
@@ -94,13 +95,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP P) {
       const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
       f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, z = {0, 0, 0, 0};
       if (a.pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
+      const ProCoef kh = pro_coef(a.pro_h, pm, pr, z, z);
       const float* xb = a.x + (size_t)b * a.L_in * a.ldx;
       const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
       const int rowmul = (TAPS_T == 1) ? STRIDE : 1;
       for (int row = row0; row < NRh; row += rstep) {
         const int gr = rb + row * rowmul;
         f32x4 v = {0, 0, 0, 0};
-        if (gr >= 0 && gr < a.L_in) v = pro4(a.pro_h, ld4o(xb, (unsigned)gr * (unsigned)a.ldx + ch), z, pm, pr, z, z);
+        if (gr >= 0 && gr < a.L_in) v = pro_apply_k(a.pro_h, ld4o(xb, (unsigned)gr * (unsigned)a.ldx + ch), z, kh);
         st4(hL + row * RSh + ch, v);
       }
     }
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
           load_chan_params(a.g_stats, b, a.cout, o0 + ch, pm, pr);
           if (pro_g >= W2S_PRO_INBWD) load_chan_params(a.g_bstats, b, a.cout, o0 + ch, ps1, ps2);
         }
+        const ProCoef kg = pro_coef(pro_g, pm, pr, ps1, ps2);
         for (int row = row0; row < TM; row += rstep) {
           const int t = t0 + row;
           f32x4 v = {0, 0, 0, 0};
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
             const unsigned go = (unsigned)t * (unsigned)a.ldg + ch;
             f32x4 x = ld4o(gb, go);
             f32x4 x2 = g2b ? ld4o(g2b, go) : (f32x4){0, 0, 0, 0};
-            v = pro4(pro_g, x, x2, pm, pr, ps1, ps2);
+            v = pro_apply_k(pro_g, x, x2, kg);
           }
           st4(gyL + row * RSg + ch, v);
         }
@@ -211,13 +214,14 @@ __global__ __launch_bounds__(NW * 64) void wgrad_ts_kernel(WgradP P) {
       const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
       f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, z = {0, 0, 0, 0};
       if (pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
+      const ProCoef kh = pro_coef(pro_h, pm, pr, z, z);
       const float* xb = a.x + (size_t)b * a.L_in * a.ldx;
       const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
       const int rowmul = (JT == 1) ? STRIDE : 1;
       for (int row = row0; row < NRh; row += rstep) {
         const int gr = rb + row * rowmul;
         f32x4 v = {0, 0, 0, 0};
-        if (gr >= 0 && gr < a.L_in) v = pro4(pro_h, ld4o(xb, (unsigned)gr * (unsigned)a.ldx + ch), z, pm, pr, z, z);
+        if (gr >= 0 && gr < a.L_in) v = pro_apply_k(pro_h, ld4o(xb, (unsigned)gr * (unsigned)a.ldx + ch), z, kh);
         st4(hL + row * RSh + ch, v);
       }
     }
@@ -294,12 +298,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
 #pragma unroll
     for (int j = 0; j < JT; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
 
-  auto split_store = [&](__bf16* hi, __bf16* lo, int off, f32x4 t) {
-    bf16x4 h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
-    bf16x4 l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
-    *reinterpret_cast<bf16x4*>(hi + off) = h;
-    *reinterpret_cast<bf16x4*>(lo + off) = l;
-  };
+  auto split_store = [&](__bf16* hi, __bf16* lo, int off, f32x4 t) { split_store4(hi, lo, off, t); };
 
   const int total = a.B * P.ntiles;
   for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
@@ -318,6 +317,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
           load_chan_params(a.g_stats, b, a.cout, o0 + ch, pm, pr);
           if (pro_g >= W2S_PRO_INBWD) load_chan_params(a.g_bstats, b, a.cout, o0 + ch, ps1, ps2);
         }
+        const ProCoef kg = pro_coef(pro_g, pm, pr, ps1, ps2);
         for (int row = row0; row < TM; row += rstep) {
           const int t = t0 + row;
           f32x4 v = {0, 0, 0, 0};
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
             const unsigned go = (unsigned)t * (unsigned)a.ldg + ch;
             f32x4 x = ld4o(gb, go);
             f32x4 x2 = g2b ? ld4o(g2b, go) : (f32x4){0, 0, 0, 0};
-            v = pro4(pro_g, x, x2, pm, pr, ps1, ps2);
+            v = pro_apply_k(pro_g, x, x2, kg);
           }
           split_store(gH, gL, row * RSg + ch, v);
         }
@@ -341,13 +341,14 @@ __global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
       const int myc4 = tid % c4n, row0 = tid / c4n, ch = myc4 * 4;
       f32x4 pm = {0, 0, 0, 0}, pr = {1, 1, 1, 1}, z = {0, 0, 0, 0};
       if (pro_h >= W2S_PRO_IN_GELU) load_chan_params(a.x_stats, b, cin, ch, pm, pr);
+      const ProCoef kh = pro_coef(pro_h, pm, pr, z, z);
       const float* xb = a.x + (size_t)b * a.L_in * a.ldx;
       const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
       const int rowmul = (JT == 1) ? STRIDE : 1;
       for (int row = row0; row < NRh; row += rstep) {
         const int gr = rb + row * rowmul;
         f32x4 v = {0, 0, 0, 0};
-        if (gr >= 0 && gr < a.L_in) v = pro4(pro_h, ld4o(xb, (unsigned)gr * (unsigned)a.ldx + ch), z, pm, pr, z, z);
+        if (gr >= 0 && gr < a.L_in) v = pro_apply_k(pro_h, ld4o(xb, (unsigned)gr * (unsigned)a.ldx + ch), z, kh);
         split_store(hH, hL, row * RSh + ch, v);
       }
     }

@@ -26,14 +26,8 @@ struct WgWideP {
   int dbg;   // tuning only (W2S_WGW_DBG): 1 = no on-load arithmetic, 2 = no MFMA loop, 4 = no LDS staging
 };
 
-typedef __bf16 gbf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 gbf16x4v __attribute__((__vector_size__(4 * sizeof(__bf16))));
-__device__ __forceinline__ void gsplit_store4(__bf16* hi, __bf16* lo, int off, f32x4 t) {
-  gbf16x4 h = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
-  gbf16x4 l = {(__bf16)(t.x - (float)h.x), (__bf16)(t.y - (float)h.y), (__bf16)(t.z - (float)h.z), (__bf16)(t.w - (float)h.w)};
-  *reinterpret_cast<gbf16x4*>(hi + off) = h;
-  *reinterpret_cast<gbf16x4*>(lo + off) = l;
-}
+#define gsplit_store4 split_store4   /* w2s_common.h: the explicit bit form */
 // 8 consecutive positions (rows) of 16 channels for the 16x16x32 operand: two transposing reads of 4 rows each
 __device__ __forceinline__ bf16x8 gtr_read8(const __bf16* p0, const __bf16* p1) {
   typedef __attribute__((address_space(3))) gbf16x4v* lds_p;
@@ -106,14 +100,14 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void wgrad_wide_kernel(WgWideP P) {
       __bf16* gL = gH + TM * RSg;
       __bf16* hH = gL + TM * RSg;
       __bf16* hL = hH + NRh * RSh;
-      f32x4 pm, pr, ps1, ps2;
+      ProCoef kg;
       {
         const float* st = gstL + (b * OC + gch) * 2;
         const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
-        pm = (f32x4){s01.x, s01.z, s23.x, s23.z}; pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
+        const f32x4 pm = {s01.x, s01.z, s23.x, s23.z}, pr = {s01.y, s01.w, s23.y, s23.w};
         const float* bs = gstL + ((P.B + b) * OC + gch) * 2;
         const f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
-        ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z}; ps2 = (f32x4){b01.y, b01.w, b23.y, b23.w};
+        kg = pro_coef(PG, pm, pr, (f32x4){b01.x, b01.z, b23.x, b23.z}, (f32x4){b01.y, b01.w, b23.y, b23.w});
       }
 #pragma unroll
       for (int k = 0; k < NG; ++k) {
@@ -121,7 +115,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void wgrad_wide_kernel(WgWideP P) {
         const f32x4 v1 = rg[S][k], v2 = ry[S][k];
         load_g(SET, i + PD, k);
         if (live && row < TM && !(P.dbg & 4)) {
-          const f32x4 tv = (P.dbg & 1) ? v1 + v2 : pro_apply(PG, v1, v2, pm, pr, ps1, ps2);
+          const f32x4 tv = (P.dbg & 1) ? v1 + v2 : pro_apply_k(PG, v1, v2, kg);
           gsplit_store4(gH, gL, row * RSg + gch, (t0 + row < P.Lg) ? tv : (f32x4){0, 0, 0, 0});
         }
       }
@@ -131,6 +125,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void wgrad_wide_kernel(WgWideP P) {
         const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
         hm = (f32x4){s01.x, s01.z, s23.x, s23.z}; hr = (f32x4){s01.y, s01.w, s23.y, s23.w};
       }
+      const ProCoef kh = pro_coef(PH, hm, hr, hm, hm);
       const int rb = t0 * STRIDE - P.pad;
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
@@ -139,7 +134,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void wgrad_wide_kernel(WgWideP P) {
         load_h(SET, i + PD, k);
         if (live && row < NRh && !(P.dbg & 4)) {
           const f32x4 z = {0, 0, 0, 0};
-          const f32x4 tv = (P.dbg & 1) ? v + hm : pro_apply(PH, v, z, hm, hr, z, z);
+          const f32x4 tv = (P.dbg & 1) ? v + hm : pro_apply_k(PH, v, z, kh);
           gsplit_store4(hH, hL, row * RSh + hch, (gr >= 0 && gr < P.Lh) ? tv : z);
         }
       }
