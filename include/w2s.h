@@ -76,12 +76,9 @@ typedef struct w2s_conv_args {
   float* part;             /* EPI_STATS / EPI_GP: [B][ntiles][2][cout] partial sums, or NULL */
   const void* w_hi;        /* optional bf16 planes of w (w = hi + lo, layout as w; see w2s_repack_bf16): enables the split-  */
   const void* w_lo;        /* precision matrix-core path for cin >= 32 and cout >= 64; NULL = exact fp32 MFMA               */
-  float* stat_out;         /* optional: [B][cout][2] finalised IN the kernel (EPI_STATS: mean, rstd with stat_eps; EPI_GP: sums /   */
-  int32_t* stat_cnt;       /* L_out); `part` is then the row scratch sized by w2s_conv_stat_rows; stat_cnt: [B] zeroed once          */
   int32_t B, L_in, L_out, cin, cout, taps, stride, dil, pad, flip, mode;
   int32_t ldx, ldy, ldy2, ld_aux;
   int32_t pro, epi;
-  float stat_eps;          /* variance epsilon of the in-kernel finalisation (models/wav2sleep.py:213-215: 1e-2) */
   int32_t reserved;        /* bit 0: y += result instead of y = result (a contraction split over several launches: cin > 128) */
                            /* EPI_BIAS fusions of the set-fusion transformer (TransformerEncoderLayer, wav2sleep.py:286-296; W2S_FUSE_*):      */
                            /* bit 1: y = aux + drop(result)            (residual add + dropout: x + Dropout(sublayer(x)))                       */
@@ -158,8 +155,7 @@ int w2s_repack_bf16(const float* w, void* fwd_hi, void* fwd_lo, void* bwd_hi, vo
  */
 int w2s_conv_fwd_fused_tile(int cin, int cout, int stride);
 int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const float* w1, float* y, float* part, int B, int L_in,
-                       int L_out, int cin, int cout, int stride, int pad, int pro, int nwg, float* stat_out, int32_t* stat_cnt, float eps,
-                       void* stream);   /* pad: 1 = symmetric, 2 = causal (left pad k-1, blocks.py:150-152) */
+                       int L_out, int cin, int cout, int stride, int pad, int pro, int nwg, void* stream);   /* pad: 1 = symmetric, 2 = causal (left pad k-1, blocks.py:150-152) */
 
 /*
  * Fused backward of one encoder ConvLayer1D (k=3, pad=1, stride 1 or 2) for the bandwidth-bound <=32-channel layers:
@@ -175,7 +171,7 @@ int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd, int split_precision);
 int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                   const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
                   int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const float* gpre, const float* wd,
-                  float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int32_t* stat_cnt, void* stream);
+                  float* slab_d, const float* w1, const float* y3p, const float* st3p, void* stream);
 /* pad: the forward conv's left padding: 1 = symmetric, 2 = causal (blocks.py:150-152; split_precision only) */
 /* gpre != NULL (conv1 of a residual block; stride 1, split_precision, add_even NULL, w2s_bwd_fused_folds_residual(cg, ch)): the
  * block's 1x1/stride-2 residual branch (blocks.py:44-47,68) is folded in -- gout additionally receives Wd^T gpre[t/2] at even t
@@ -221,20 +217,19 @@ int w2s_enc_first_bwd_h(const float* x, const void* gn1, const float* hdr_n, con
  * weight gradient alone: slab [nslab][16].  Replaces trainer-side autograd of models/wav2sleep.py:96-110 (block 0). */
 int w2s_bwd_fused_w1(const float* g, const float* y, const float* st_k, const float* bst_k, const float* x, const float* st_in,
                      const float* wb, float* gout, float* part, float* part_w1, float* slab, int nslab, int B, int L, int pad,
-                     const float* w1, float* stat_out, int32_t* stat_cnt, void* stream);   /* stat_out: as for w2s_bwd_fused */
+                     const float* w1, void* stream);
 int w2s_enc_first_wgrad(const float* xmom, int ntx, const float* w1, const float* part_w1, const float* stats1, const float* bstats1,
                         float* out, int B, int ntiles, void* stream);
 /* w2s_enc_first_fwd's statistics-only form (y == NULL) that also keeps the nine raw moments of every signal tile:
  * xmom [B][ceil(L / tile)][9] (may be NULL) -- the sums w2s_enc_first_wgrad needs */
-int w2s_enc_first_stats(const float* x, const float* w, float* part, float* xmom, int B, int L, int tile, float* stat_out, int32_t* stat_cnt,
-                        float eps, int causal, void* stream);
+int w2s_enc_first_stats(const float* x, const float* w, float* part, float* xmom, int B, int L, int tile, int causal, void* stream);
 int w2s_enc_first_dwd(const float* x, const float* gpre, float* slab, int nslab, int B, int L, void* stream);
 /* ... or folded as well: w2s_bwd_fused_wd = w2s_bwd_fused for conv1 of block 1 in its residual-fold form (16 -> 16; gpre / wd / slab_d /
  * y3p / st3p as there) whose gout IS block 0's gpre; part_wd [nslab][16] = per-workgroup sums of gout[u][o] * san(x0[2u]), x0 = the raw
  * signal [B][2 L].  Sum the rows with w2s_colsum_batch; w2s_enc_first_dwd is then not needed. */
 int w2s_bwd_fused_wd(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* wb, float* gout,
                      float* part, float* slab, int nslab, int B, int L, int pad, const float* gpre, const float* wd, float* slab_d,
-                     const float* y3p, const float* st3p, const float* x0, float* part_wd, float* stat_out, int32_t* stat_cnt, void* stream);
+                     const float* y3p, const float* st3p, const float* x0, float* part_wd, void* stream);
 
 /*
  * Fused backward of one k=3 / symmetric-padding encoder conv with cg = 64 gradient-side channels (round 3, csrc/bwd_wide.hip): data
@@ -253,9 +248,7 @@ int w2s_bwd_wide_groups(int cg, int ch, int stride);   /* statistics-partial row
 int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                  const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B, int L,
                  int cg, int ch, int stride, const float* y3p, const float* st3p, const float* gpre, const void* wd_hi, const void* wd_lo,
-                 float* slab_d, float* stat_out, int32_t* stat_cnt, int dry, void* stream);
-/* stat_out / stat_cnt: in-kernel statistics finalisation (below); `part` is then the row scratch of B * w2s_stat_rows(B, ntiles, nslab) *
- * w2s_bwd_wide_groups rows. */
+                 float* slab_d, int dry, void* stream);
 /* gpre != NULL (conv1 of a residual block: stride 1, st_in and add_even NULL, L even): the block's 1x1/stride-2 residual branch
  * (blocks.py:44-47,68) folded in as in w2s_bwd_fused -- gout additionally receives Wd^T gpre[t/2] at even t before the GELU' factor (gpre:
  * [B][L/2][cg], wd_hi / wd_lo: w2s_repack_batch bwd planes of the downsample weight) and slab_d receives nslab raw-fragment slabs of the
@@ -264,27 +257,17 @@ int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float*
  * does: y3p = that block's pre-norm conv3 output [B][L][ch], st3p = its (mean, rstd) [B][ch][2]; `part` then holds the partial sums of
  * gout*GELU'(n3) and gout*GELU'(n3)*n3, n3 = IN(y3p). */
 
-/* In-kernel finalisation (stat_out / stat_cnt arguments of the producers above; round 4: per WORKGROUP, not per tile).  The persistent
- * producers take their tiles blocked (a workgroup owns a contiguous run of the (sample, tile) list), keep exact (double-double) running
- * sums of their run, and at the end of their run of a sample store ONE row and take ONE ticket from stat_cnt[b]; the workgroup that draws a
- * sample's last ticket sums its rows in row order and writes stat_out[b][C][2] -- same result contract as w2s_stats_finalize, no launch.
- * With stat_out set, `part` is NOT the per-tile partials but the ROW SCRATCH: [B][rows][2][C] pairs of doubles (hi, lo), 16-byte aligned,
- * rows = w2s_stat_rows(B, ntiles, grid) for w2s_conv_fwd_fused (grid = min(nwg, B * ntiles)), w2s_bwd_fused (grid = nslab) and
- * w2s_bwd_wide (grid = nslab; times w2s_bwd_wide_groups), w2s_conv_stat_rows(&a) for w2s_conv_forward (0: that descriptor's kernel has
- * no in-kernel finalisation -- leave stat_out NULL), ntiles for the tile-per-workgroup kernels (w2s_gp_stats, w2s_enc_first_*).
- * stat_cnt is a caller-owned int32 [B] buffer, zero before first use; the kernels re-arm it.  One buffer per stream.
+/* Statistics leave every producer above as per-tile fp32 partial sums `part` (rounds 1 and 4 also built finalisation INSIDE the producers:
+ * correct, 168 launches fewer per step and slower every time it was measured -- removed in round 5, docs/lab_notes_r5.md).
  * w2s_stats_finalize: partial sums [B][ntiles][2][C] -> per-(b,c) pairs [B][C][2]: kind 0 = (mean, rstd) with biased variance + eps
  * (nn.InstanceNorm1d, models/utils.py:89-92), kind 1 = (sum1, sum2)/count.  fp64 accumulation, fixed order. */
-int w2s_stat_rows(int B, int ntiles, int grid);
-int w2s_conv_stat_rows(const w2s_conv_args* a);
 int w2s_stats_finalize(const float* part, int B, int ntiles, int C, long count, float eps, int kind, float* out, void* stream);
 
 /* First encoder layer, Cin = 1 (blocks.py:46, conv1 of block 0): y[b,t,o] = sum_j w[o][j]*san(x[b,t+j-1]);
  * part [B][ceil(L/tile)][2][16] = partial sum / sum-of-squares.  w is the torch tensor [16][1][3]. */
 /* y may be NULL (statistics only: the W2S_PRO_FIRST consumers recompute the values).
  * causal != 0: the causal padding of ConvLayer1D (blocks.py:150-152,178-182), taps x[t-2], x[t-1], x[t]; needs y. */
-int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, float* stat_out, int32_t* stat_cnt,
-                      float eps, int causal, void* stream);
+int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, int causal, void* stream);
 /* Block-0 residual join (blocks.py:67-69): pre[b,u,o] = GELU(IN(y3[b,u,o])) + wd[o]*san(x[b,2u]) */
 int w2s_enc_first_join(const float* x, const float* wd, const float* y3, const float* stats3, float* pre, int B, int L, int cout, void* stream);
 /* weight grads of block-0 conv1 / downsample; slab[nslab][64] = {dW1[o][j] (48), dWd[o] (16)}; sum with w2s_colsum */
@@ -292,8 +275,7 @@ int w2s_enc_first_bwd(const float* x, const float* gn1, const float* y1, const f
                       const float* gpre, float* slab, int nslab, int B, int L, int cout, const float* w1, int causal, void* stream);
 /* y1 == NULL: the conv1 output is recomputed from x and w1 = conv1 weight [16][3] (the W2S_PRO_FIRST flow) */
 /* pre-pass of conv3's backward: part [B][ceil(L/tile)][2][C] = partial sums of g*GELU'(n) and g*GELU'(n)*n, n = IN(y) */
-int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, float* stat_out, int32_t* stat_cnt,
-                 void* stream);
+int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, void* stream);
 
 /* ---- row-wise ops on [rows][C] (nn.LayerNorm of the transformer; ConvLayerNorm models/utils.py:17-23) ---- */
 int w2s_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* rstat, int rows, int C,

@@ -910,30 +910,12 @@ def t_fwd_fused():
     report('fwd fused first-layer recompute stats', p2.sum(1), p1.sum(1), tol=2e-4)
 
 
-def t_inkernel_finalize():
-    """Statistics finalised INSIDE the six producer kernels (round 4: per-workgroup rows + one ticket per workgroup and sample, the last
-    arriver reduces; csrc/w2s_common.h) against the per-tile partials + w2s_stats_finalize path of the same kernel on the same inputs,
-    and against torch.  Few / many / uneven workgroup counts (a sample covered by 1 .. many runs, runs that straddle samples), several
-    passes on one counter buffer (re-arming), a second stream keeping the CUs busy (the hand-off must not depend on an idle chip), NaN-
-    poisoned row scratch (a row that is read before it is written shows)."""
+def t_stats_partition():
+    """The persistent statistics producers take their tiles BLOCKED (a workgroup owns a contiguous run of the (sample, tile) list): the
+    per-tile partials -- and everything else they write -- must not depend on how many workgroups share the list (1 ... more than there are
+    tiles; runs that straddle samples), and the finalised statistics must agree with torch.  (Rounds 1 and 4 also finalised inside the
+    producers; removed in round 5 -- docs/lab_notes_r5.md.)"""
     B = 5
-    cnt = torch.zeros(B, device=dev, dtype=torch.int32)
-    side = torch.cuda.Stream()
-    hog_a = torch.randn(1 << 26, device=dev); hog_b = torch.empty_like(hog_a)
-
-    def scratch(rows, C):
-        return torch.full((B * max(rows, 1) * 2 * C * 2,), float('nan'), device=dev, dtype=torch.float64)
-
-    def under_load(fn):
-        ev = torch.cuda.Event(); ev.record()
-        with torch.cuda.stream(side):
-            side.wait_event(ev)
-            for _ in range(3):
-                hog_b.copy_(hog_a)
-        fn()
-        torch.cuda.current_stream().wait_stream(side)
-
-    # ---- persistent forward <= 32 channels
     for (cin, cout, L, stride) in ((16, 16, 5000, 1), (32, 32, 3001, 1), (16, 32, 2560, 1), (32, 32, 4096, 2), (16, 16, 300, 1)):
         Lo = L // stride
         if L % stride:
@@ -942,51 +924,16 @@ def t_inkernel_finalize():
         w = torch.randn(cout, 3, cin, device=dev) / math.sqrt(3 * cin)
         st = torch.stack([torch.randn(B, cin, device=dev) * 0.1, torch.rand(B, cin, device=dev) + 0.5], dim=-1).contiguous()
         tile = lib.conv_fwd_fused_tile(cin, cout, stride); nt = (Lo + tile - 1) // tile
-        y0 = torch.zeros(B, Lo, cout, device=dev); part = torch.zeros(B, nt, 2, cout, device=dev)
-        lib.conv_fwd_fused(x=x, w=w, st_in=st, w1=None, y=y0, part=part, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, stride=stride, pro=lib.PRO_IN_GELU, nwg=7)
-        ref = torch.zeros(B, cout, 2, device=dev); lib.stats_finalize(part, B, nt, cout, Lo, 1e-2, 0, ref)
-        want = torch.stack([y0.mean(1), 1 / torch.sqrt(y0.var(1, unbiased=False) + 1e-2)], dim=-1)
+        outs = []
         for nwg in (1, 3, 7, 64, 1024):
-            grid = min(nwg, B * nt)
-            rows = lib.stat_rows(B, nt, grid)
-            y = torch.zeros(B, Lo, cout, device=dev); so = torch.full((B, cout, 2), float('nan'), device=dev); sc = scratch(rows, cout)
-            under_load(lambda: lib.conv_fwd_fused(x=x, w=w, st_in=st, w1=None, y=y, part=sc, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, stride=stride,
-                                                  pro=lib.PRO_IN_GELU, nwg=nwg, stat_out=so, stat_cnt=cnt, eps=1e-2))
-            tag = f'in-kernel finalize fwd {cin}->{cout} L{L} s{stride} wgs{grid}'
-            RES.append((tag + ' same y', torch.equal(y, y0)))
-            report(tag + ' vs finalize launch', so, ref, tol=1e-6)
-            report(tag + ' vs torch', so, want, tol=2e-5)
-    # ---- persistent wide kernel through the generic descriptor (forward statistics and the data gradient's backward sums)
-    for (cin, cout, L, stride) in ((64, 64, 2000, 1), (128, 128, 777, 2), (64, 128, 640, 1), (128, 128, 64, 1)):
-        Lo = (L + 2 - 3) // stride + 1
-        x = torch.randn(B, L, cin, device=dev) * 2 + 0.3
-        w = torch.randn(cout, 3, cin, device=dev) / math.sqrt(3 * cin); wh, wl = lib.frag_major_planes(w.view(cout, 3 * cin))
-        st = torch.stack([torch.randn(B, cin, device=dev) * 0.1, torch.rand(B, cin, device=dev) + 0.5], dim=-1).contiguous()
-        pro = lib.PRO_IN_GELU if cin == cout else lib.PRO_GELU
-        kw = dict(x=x, w=w, w_hi=wh, w_lo=wl, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, taps=3, stride=stride, pad=1, pro=pro, pro_stats=st if pro == lib.PRO_IN_GELU else None,
-                  epi=lib.EPI_STATS, stat_eps=1e-2)
-        y0 = torch.zeros(B, Lo, cout, device=dev)
-        a0 = lib.conv_args(y=y0, **kw); tile = lib.conv_tile_of(a0); nt = (Lo + tile - 1) // tile
-        part = torch.zeros(B, nt, 2, cout, device=dev); lib.set_part(a0, part); lib.conv_forward(a0)
-        ref = torch.zeros(B, cout, 2, device=dev); lib.stats_finalize(part, B, nt, cout, Lo, 1e-2, 0, ref)
-        rows = lib.conv_stat_rows(lib.conv_args(y=y0, **kw))
-        RES.append((f'in-kernel finalize wide {cin}->{cout} L{L} s{stride}: the wide kernel takes it', rows > 0 and tile == 64))
-        for rep in range(3):   # the counters must have been re-armed by the kernel
-            y = torch.zeros(B, Lo, cout, device=dev); so = torch.full((B, cout, 2), float('nan'), device=dev); sc = scratch(rows, cout)
-            under_load(lambda: lib.conv_forward(lib.conv_args(y=y, part=sc, stat_out=so, stat_cnt=cnt, **kw)))
-            tag = f'in-kernel finalize wide {cin}->{cout} L{L} s{stride} pass {rep}'
-            RES.append((tag + ' same y', torch.equal(y, y0)))
-            report(tag + ' vs finalize launch', so, ref, tol=1e-6)
-    # the generic kernel has no in-kernel finalisation: the library says so and refuses the descriptor
-    xg = torch.randn(B, 500, 16, device=dev); wg = torch.randn(16, 3, 16, device=dev); yg = torch.zeros(B, 500, 16, device=dev)
-    ag = dict(x=xg, w=wg, y=yg, B=B, L_in=500, L_out=500, cin=16, cout=16, taps=3, stride=1, pad=1, epi=lib.EPI_STATS)
-    ok = lib.conv_stat_rows(lib.conv_args(**ag)) == 0
-    try:
-        lib.conv_forward(lib.conv_args(part=scratch(4, 16), stat_out=torch.zeros(B, 16, 2, device=dev), stat_cnt=cnt, **ag)); ok = False
-    except lib.W2SError:
-        pass
-    RES.append(('in-kernel finalize: generic conv kernel refuses stat_out', ok))
-    # ---- fused backward <= 32 channels and the 64-channel one-pass backward (kind 1: plain means of gout, gout * n_in)
+            y = torch.zeros(B, Lo, cout, device=dev); part = torch.full((B, nt, 2, cout), float('nan'), device=dev)
+            lib.conv_fwd_fused(x=x, w=w, st_in=st, w1=None, y=y, part=part, B=B, L_in=L, L_out=Lo, cin=cin, cout=cout, stride=stride, pro=lib.PRO_IN_GELU, nwg=nwg)
+            outs.append((y, part))
+        tag = f'blocked partition fwd {cin}->{cout} L{L} s{stride}'
+        RES.append((tag + ': y and partials independent of the grid', all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])))
+        ref = torch.zeros(B, cout, 2, device=dev); lib.stats_finalize(outs[0][1], B, nt, cout, Lo, 1e-2, 0, ref)
+        y0 = outs[0][0]
+        report(tag + ' statistics vs torch', ref, torch.stack([y0.mean(1), 1 / torch.sqrt(y0.var(1, unbiased=False) + 1e-2)], dim=-1), tol=2e-5)
     for (cg, ch, L, stride, wide) in ((16, 16, 3000, 1, False), (32, 32, 2050, 2, False), (32, 16, 1000, 1, False), (64, 64, 1000, 1, True), (64, 64, 1026, 2, True), (64, 32, 500, 1, True)):
         Lg = L // stride
         g = torch.randn(B, Lg, cg, device=dev) * 0.1; y = torch.randn(B, Lg, cg, device=dev) * 2 + 0.2; xi = torch.randn(B, L, ch, device=dev) * 1.3 - 0.1
@@ -1000,50 +947,21 @@ def t_inkernel_finalize():
         else:
             tile, groups = lib.bwd_fused_tile(cg, ch, stride, False, True), 1
         nt = (L + tile - 1) // tile
-
-        def launch(ns, gout, part, slab, so=None):
+        outs = []
+        for ns in (1, 4, min(37, B * nt), min(256, B * nt)):
+            gout = torch.zeros(B, L, ch, device=dev); part = torch.full((B, nt * groups, 2, ch), float('nan'), device=dev); slab = torch.zeros(ns * cg * ch * 3, device=dev)
             if wide:
                 lib.bwd_wide(g=g, y=y, st_k=st, bst_k=bst, xin=xi, st_in=sti, add_even=None, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab, nslab=ns, B=B, L=L,
-                             cg=cg, ch=ch, stride=stride, stat_out=so, stat_cnt=cnt if so is not None else None)
+                             cg=cg, ch=ch, stride=stride)
             else:
                 lib.bwd_fused(g=g, y=y, st_k=st, bst_k=bst, pro=pro_g, xin=xi, st_in=sti, add_even=None, wb=wb, gout=gout, part=part, slab=slab, nslab=ns, B=B,
-                              Lg=Lg, Lh=L, cg=cg, ch=ch, stride=stride, split_precision=True, stat_out=so, stat_cnt=cnt if so is not None else None)
-        for ns in (1, 4, min(37, B * nt), min(256, B * nt)):
-            gout0 = torch.zeros(B, L, ch, device=dev); part = torch.zeros(B, nt * groups, 2, ch, device=dev); slab0 = torch.zeros(ns * cg * ch * 3, device=dev)
-            launch(ns, gout0, part, slab0)
-            ref = torch.zeros(B, ch, 2, device=dev); lib.stats_finalize(part, B, nt * groups, ch, L, 0.0, 1, ref)
-            rows = lib.stat_rows(B, nt, ns) * groups
-            gout = torch.zeros(B, L, ch, device=dev); slab = torch.zeros(ns * cg * ch * 3, device=dev); so = torch.full((B, ch, 2), float('nan'), device=dev); sc = scratch(rows, ch)
-            under_load(lambda: launch(ns, gout, sc, slab, so))
-            tag = f'in-kernel finalize {"bwd_wide" if wide else "bwd_fused"} {cg}->{ch} L{L} s{stride} wgs{ns}'
-            RES.append((tag + ' same gout / slabs', torch.equal(gout, gout0) and torch.equal(slab, slab0)))
-            report(tag + ' vs finalize launch', so, ref, tol=1e-6)
-    # ---- tile-per-workgroup kernels: gp_stats, the Cin = 1 statistics
-    for (C, L, tile) in ((32, 3333, 512), (128, 700, 64), (16, 40000, 1024)):
-        g = torch.randn(B, L, C, device=dev); yv = torch.randn(B, L, C, device=dev)
-        st = torch.stack([torch.randn(B, C, device=dev) * 0.1, torch.rand(B, C, device=dev) + 0.5], dim=-1).contiguous()
-        nt = (L + tile - 1) // tile
-        part = torch.zeros(B, nt, 2, C, device=dev); lib.gp_stats(g, yv, st, part, B, L, C, tile)
-        ref = torch.zeros(B, C, 2, device=dev); lib.stats_finalize(part, B, nt, C, L, 0.0, 1, ref)
-        for rep in range(2):
-            so = torch.full((B, C, 2), float('nan'), device=dev); sc = scratch(nt, C)
-            under_load(lambda: lib.gp_stats(g, yv, st, sc, B, L, C, tile, stat_out=so, stat_cnt=cnt))
-            report(f'in-kernel finalize gp_stats C{C} L{L} tile{tile} pass {rep}', so, ref, tol=1e-6)
-    for (L, tile) in ((5000, 1024), (70000, 4096)):
-        x = torch.randn(B, L, device=dev); x[1, 7] = float('inf'); w1 = torch.randn(16, 1, 3, device=dev) / 2
-        nt = (L + tile - 1) // tile
-        part = torch.zeros(B, nt, 2, 16, device=dev); xm0 = torch.zeros(B, nt, 9, device=dev)
-        lib.enc_first_stats(x, w1, part, xm0, B, L, tile)
-        ref = torch.zeros(B, 16, 2, device=dev); lib.stats_finalize(part, B, nt, 16, L, 1e-2, 0, ref)
-        so = torch.full((B, 16, 2), float('nan'), device=dev); sc = scratch(nt, 16); xm = torch.zeros(B, nt, 9, device=dev)
-        under_load(lambda: lib.enc_first_stats(x, w1, sc, xm, B, L, tile, stat_out=so, stat_cnt=cnt, eps=1e-2))
-        report(f'in-kernel finalize enc_first_stats L{L} tile{tile}', so, ref, tol=1e-6)
-        RES.append((f'in-kernel finalize enc_first_stats L{L}: same moments', torch.equal(xm, xm0)))
-        y1 = torch.zeros(B, L, 16, device=dev); so2 = torch.full((B, 16, 2), float('nan'), device=dev); sc2 = scratch(nt, 16)
-        lib.enc_first_fwd(x, w1, y1, sc2, B, L, 16, tile, stat_out=so2, stat_cnt=cnt, eps=1e-2)
-        report(f'in-kernel finalize enc_first_fwd L{L} tile{tile}', so2, ref, tol=2e-5)
-    torch.cuda.synchronize()
-    RES.append(('in-kernel finalize: every counter re-armed', int(cnt.abs().sum()) == 0))
+                              Lg=Lg, Lh=L, cg=cg, ch=ch, stride=stride, split_precision=True)
+            outs.append((gout, part))
+        tag = f'blocked partition {"bwd_wide" if wide else "bwd_fused"} {cg}->{ch} L{L} s{stride}'
+        RES.append((tag + ': gout and partials independent of the grid', all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])))
+        n_in = (xi - sti[:, None, :, 0]) * sti[:, None, :, 1]
+        ref = torch.zeros(B, ch, 2, device=dev); lib.stats_finalize(outs[0][1], B, nt * groups, ch, L, 0.0, 1, ref)
+        report(tag + ' backward sums vs torch', ref, torch.stack([outs[0][0].mean(1), (outs[0][0] * n_in).mean(1)], dim=-1), tol=2e-4)
 
 
 def t_plumbing():
@@ -1079,7 +997,7 @@ def t_plumbing():
     RES.append(('zero_', int(cm.abs().sum()) == 0 and float(g.abs().sum()) == 0.0))
 
 
-STAGES = dict(plumb=t_plumbing, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, fin=t_inkernel_finalize, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(plumb=t_plumbing, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, part=t_stats_partition, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

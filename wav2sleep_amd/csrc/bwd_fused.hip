@@ -30,8 +30,6 @@ struct BwdP {
   // previous block's conv3 backward statistics folded into this block's conv1 (RD) kernel: y3p = that block's pre-norm conv3
   // output [B][Lh][HC] (same positions as gout), st3p = its (mean, rstd); part then receives sums of gn = gout*GELU'(n3) and gn*n3
   const float* y3p; const float* st3p;
-  StatFin fin;   // in-kernel finalisation of `part` into the backward statistics (fin.out == NULL: partials only)
-  int acc_off;   // byte offset of the running statistics sums [2][HC] (hi, lo) in the dynamic LDS
   // fp16 gradient chain (split-precision kernels; w2s_common.h): gmode 0 = g / gpre / gout are fp32; 1 = g fp32 (header hdr_g: scale 1,
   // max from w2s_gp_stats), gout fp16; 2 = g, gpre and gout fp16.  hdr_o[1] must be zero at launch.
   int gmode; const float* hdr_g; const float* hdr_p; float* hdr_o;
@@ -52,7 +50,7 @@ struct BwdP {
 __host__ __device__ constexpr int bwd_rs(int c) { return (c > 16 || !W2S_BF_OCC3) ? c + 4 : c; }
 __host__ __device__ constexpr int bwd_redn(int ch) { return 4 * ch * 4 * 8; }  // floats of the statistics scratch
 
-template <int CG, int CH, int MT, int UP2, int PF, int FIN>
+template <int CG, int CH, int MT, int UP2, int PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CG == 1 && CH == 1 && W2S_BF_OCC3) ? 3 : 2)))
 void bwd_fused_kernel(BwdP P) {
   extern __shared__ f32x4 smem4[];
@@ -156,8 +154,6 @@ void bwd_fused_kernel(BwdP P) {
   const int total = P.B * P.ntiles;
   const W2SRun wrun = w2s_block_part(total, G, blockIdx.x);   // the producers never exceed the tile count
   const int wend = wrun.first + wrun.count;
-  w2s_dd* accL = reinterpret_cast<w2s_dd*>(reinterpret_cast<char*>(smem4) + P.acc_off);   // running statistics sums of this run, one slot per thread < 2*HC
-  if (tid < 2 * HC) accL[tid] = (w2s_dd){0.0, 0.0};
   int b = wrun.first / P.ntiles, tile = wrun.first - b * P.ntiles;   // one division per launch; the run is contiguous
   if (PF && wrun.count > 0) prefetch(b, tile);
   for (int tl = wrun.first; tl < wend; ++tl) {
@@ -245,14 +241,7 @@ void bwd_fused_kernel(BwdP P) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
-        if ((FIN && P.fin.out)) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
-          const bool endrun = tl + 1 >= wend || tile + 1 == P.ntiles;
-          double* row = nullptr;
-          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, G, P.ntiles, b, blockIdx.x).row) * (2 * HC) * 2;
-          w2s_run_add(accL, tid, s, endrun, row);
-        } else {
-          w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
-        }
+        w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
       }
     }
 
@@ -297,8 +286,6 @@ void bwd_fused_kernel(BwdP P) {
           st4(out + ((i * 3 + j) * CH + c) * 256 + lane * 4, v);
         }
       }
-  // tickets of the samples this run touched; the last arriver of a sample finalises its statistics (w2s_common.h)
-  if ((FIN && P.fin.out) && wrun.count > 0) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, wrun.first / P.ntiles, (wend - 1) / P.ntiles, HC, 1, 256, smem4);
 }
 
 template <int CG, int CH, int MT, int UP2, int PF>
@@ -306,15 +293,11 @@ static int launch_bwd(const BwdP& P0, int nslab, hipStream_t s) {
   constexpr int TM = 64 * MT;
   BwdP P = P0;
   P.ntiles = (P.Lh + TM - 1) / TM;
-  P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, nslab);
   constexpr int NRg = UP2 ? TM / 2 + 1 : TM + 2, NRh = UP2 ? TM + 1 : TM + 2;
   size_t lds = (size_t)(NRg * bwd_rs(CG * 16) + NRh * bwd_rs(CH * 16) + TM * bwd_rs(CH * 16)) * 4;
   lds += (size_t)bwd_redn(CH) * 4 + (size_t)(CH * 16) * (3 * CG * 16 + 4) * 4;
-  if (lds < 256 * 16 + 16) lds = 256 * 16 + 16;   // a finaliser workgroup's scratch aliases the windows
   lds = (lds + 15) & ~(size_t)15;
-  P.acc_off = (int)lds;
-  lds += (size_t)2 * CH * 16 * 16;
-  auto kern = P.fin.out ? bwd_fused_kernel<CG, CH, MT, UP2, PF, 1> : bwd_fused_kernel<CG, CH, MT, UP2, PF, 0>;
+  auto kern = bwd_fused_kernel<CG, CH, MT, UP2, PF>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -372,7 +355,7 @@ __host__ __device__ constexpr int bf_rsh(int c, int up2) { return up2 ? (c == 16
 #define W2S_BF_OCC22 1   // tuning: the same for the 32-channel kernels ((32,32) both strides, (32,16) fold)
 #endif
 __host__ __device__ constexpr int bfk_occ(int cg, int ch, int rd) { return (cg == 1 && ch == 1) ? W2S_BF_OCC11 : W2S_BF_OCC22; }
-template <int CG, int CH, int MT, int UP2, int RD, int FIRST, int GM, int FIN>
+template <int CG, int CH, int MT, int UP2, int RD, int FIRST, int GM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bfk_occ(CG, CH, RD))))
 void bwd_fused_bf_kernel(BwdP P) {
   static_assert(GM != 1 || !RD, "a residual-fold kernel reads the chain from both sides: all fp32 or all fp16");
@@ -659,8 +642,6 @@ void bwd_fused_bf_kernel(BwdP P) {
   const int total = P.B * P.ntiles;
   const W2SRun wrun = w2s_block_part(total, G, blockIdx.x);   // the producers never exceed the tile count
   const int wend = wrun.first + wrun.count;
-  w2s_dd* accL = reinterpret_cast<w2s_dd*>(reinterpret_cast<char*>(smem4) + P.acc_off);   // running statistics sums of this run, one slot per thread < 2*HC
-  if (tid < 2 * HC) accL[tid] = (w2s_dd){0.0, 0.0};
   int b = wrun.first / P.ntiles, tile = wrun.first - b * P.ntiles;   // one division per launch; the run is contiguous
   using PT0 = std::integral_constant<int, 0>; using PT1 = std::integral_constant<int, 1>;
   if (wrun.count > 0) { prefetch(b, tile, PT0{}); prefetch(b, tile, PT1{}); }
@@ -916,14 +897,7 @@ void bwd_fused_bf_kernel(BwdP P) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
-        if ((FIN && P.fin.out)) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
-          const bool endrun = tl + 1 >= wend || tile + 1 == P.ntiles;
-          double* row = nullptr;
-          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, G, P.ntiles, b, blockIdx.x).row) * (2 * HC) * 2;
-          w2s_run_add(accL, tid, s, endrun, row);
-        } else {
-          w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
-        }
+        w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
       }
       if (wdf && tid >= 112 && tid < 128) {
         const int o = tid - 112;
@@ -1049,8 +1023,6 @@ void bwd_fused_bf_kernel(BwdP P) {
       }
     }
   }
-  // tickets of the samples this run touched; the last arriver of a sample finalises its statistics (w2s_common.h)
-  if ((FIN && P.fin.out) && wrun.count > 0) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, wrun.first / P.ntiles, (wend - 1) / P.ntiles, HC, 1, 256, smem4);
 }
 
 template <int CG, int CH, int MT, int UP2, int RD, int FIRST = 0, int GM = 0>
@@ -1058,16 +1030,13 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   constexpr int TM = 64 * MT, TS = TM - 2, GC = CG * 16, HC = CH * 16, KD = (GC == 32) ? (RD ? 128 : 96) : 64;
   BwdP P = P0;
   P.ntiles = (P.Lh + TS - 1) / TS;
-  P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, nslab);
   constexpr int NRg = UP2 ? TM / 2 : TM, NRh = TM, NRp = RD ? TM / 2 + 1 : 0;
   size_t lds = (size_t)bwd_redn(CH) * 4 + (size_t)2 * (2 * (NRg + NRp) * bf_rs(GC) + (W2S_BF_HLO ? 2 : 1) * NRh * bf_rsh(HC, UP2) + 2 * HC * (KD + 8));
   if (FIRST) lds += (size_t)(TM + 4) * 4 + 4 * 4 * 12 * 4;
   if (RD) lds += (4 * 4 * 4 + 16) * 4;
-  if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4] (and a finaliser workgroup's)
+  if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4]
   lds = (lds + 15) & ~(size_t)15;
-  P.acc_off = (int)lds;
-  lds += (size_t)2 * HC * 16;
-  auto kern = P.fin.out ? bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST, GM, 1> : bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST, GM, 0>;
+  auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST, GM>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -1102,7 +1071,7 @@ extern "C" int w2s_bwd_fused_tile(int cg, int ch, int stride, int rd, int split_
 static int bwd_fused_impl(const void* gv, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                           const float* st_in, const float* add_even, const float* wb, void* goutv, float* part, float* slab, int nslab,
                           int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const void* gprev, const float* wd,
-                          float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt,
+                          float* slab_d, const float* w1, const float* y3p, const float* st3p,
                           int gmode, const float* hdr_g, const float* hdr_p, float* hdr_o, void* stream, float* part_w1 = nullptr,
                           const float* x0 = nullptr, float* part_wd = nullptr) {
   const float* g = static_cast<const float*>(gv);
@@ -1115,10 +1084,9 @@ static int bwd_fused_impl(const void* gv, const float* y, const float* st_k, con
   if (!((stride == 1 && Lg == Lh) || (stride == 2 && 2 * Lg == Lh))) return W2S_EINVAL;
   if (pro != (stride == 2 ? W2S_PRO_INBWD_GP : W2S_PRO_INBWD)) return W2S_EINVAL;  // the kernels bake the mode in
   if (pad != 1 && !(pad == 2 && split_precision)) return W2S_EINVAL;                // causal padding: split-precision kernels only
-  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, pad, gpre, wd, slab_d, w1, y3p, st3p, StatFin{stat_out, stat_cnt, reinterpret_cast<double*>(part), 0, 1.0 / (double)Lh, 0.f, 1}, 0,
+  BwdP P{g, y, st_k, bst_k, xin, st_in, add_even, wb, gout, part, slab, B, Lg, Lh, 0, pro, pad, gpre, wd, slab_d, w1, y3p, st3p,
          gmode, hdr_g, hdr_p, hdr_o, part_w1, x0, part_wd};
   if ((x0 != nullptr) != (part_wd != nullptr) || (part_wd && (!gpre || cg != 16 || ch != 16 || gmode))) return W2S_EINVAL;
-  if (stat_out && (!stat_cnt || !part || ((uintptr_t)part & 15))) return W2S_EINVAL;   // stat_out: `part` is the ROW scratch (w2s_stat_rows)
   if (y3p && (!gpre || !st3p || !part)) return W2S_EINVAL;
   const bool rd = gpre != nullptr;
   if (rd && (!wd || !slab_d || add_even || stride != 1 || !split_precision || !w2s_bwd_fused_folds_residual(cg, ch) || (Lh & 1))) return W2S_EINVAL;
@@ -1157,28 +1125,28 @@ static int bwd_fused_impl(const void* gv, const float* y, const float* st_k, con
 extern "C" int w2s_bwd_fused(const float* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
                              const float* st_in, const float* add_even, const float* wb, float* gout, float* part, float* slab, int nslab,
                              int B, int Lg, int Lh, int cg, int ch, int stride, int pad, int split_precision, const float* gpre, const float* wd,
-                             float* slab_d, const float* w1, const float* y3p, const float* st3p, float* stat_out, int* stat_cnt, void* stream) {
+                             float* slab_d, const float* w1, const float* y3p, const float* st3p, void* stream) {
   return bwd_fused_impl(g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, pad, split_precision, gpre,
-                        wd, slab_d, w1, y3p, st3p, stat_out, stat_cnt, 0, nullptr, nullptr, nullptr, stream);
+                        wd, slab_d, w1, y3p, st3p, 0, nullptr, nullptr, nullptr, stream);
 }
 // conv2 of block 0 (first-layer recompute form: w1 != NULL) with the first layer's weight gradient folded in: per-tile partial sums into
 // part_w1 [B][ceil(L / tile)][16][3]; gout may be NULL (nothing else reads it).  w2s_enc_first_wgrad finishes the job.
 extern "C" int w2s_bwd_fused_w1(const float* g, const float* y, const float* st_k, const float* bst_k, const float* x, const float* st_in,
                                 const float* wb, float* gout, float* part, float* part_w1, float* slab, int nslab, int B, int L, int pad,
-                                const float* w1, float* stat_out, int* stat_cnt, void* stream) {
+                                const float* w1, void* stream) {
   if (!part_w1) return W2S_EINVAL;
   return bwd_fused_impl(g, y, st_k, bst_k, W2S_PRO_INBWD, x, st_in, nullptr, wb, gout, part, slab, nslab, B, L, L, 16, 16, 1, pad, 1, nullptr, nullptr,
-                        nullptr, w1, nullptr, nullptr, stat_out, stat_cnt, 0, nullptr, nullptr, nullptr, stream, part_w1);
+                        nullptr, w1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream, part_w1);
 }
 // conv1 of block 1 (residual-fold form, 16 -> 16) with block 0's downsample weight gradient folded in: this kernel's gout is block 0's
 // gpre, so part_wd [nslab][16] = per-workgroup sums of gout[u][o] * san(x0[2u]) (x0 = the raw signal [B][2 Lh]) replaces a pass over
 // that tensor.  Sum the rows with w2s_colsum_batch.
 extern "C" int w2s_bwd_fused_wd(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* wb, float* gout,
                                 float* part, float* slab, int nslab, int B, int L, int pad, const float* gpre, const float* wd, float* slab_d,
-                                const float* y3p, const float* st3p, const float* x0, float* part_wd, float* stat_out, int* stat_cnt, void* stream) {
+                                const float* y3p, const float* st3p, const float* x0, float* part_wd, void* stream) {
   if (!x0 || !part_wd) return W2S_EINVAL;
   return bwd_fused_impl(g, y, st_k, bst_k, W2S_PRO_INBWD, xin, nullptr, nullptr, wb, gout, part, slab, nslab, B, L, L, 16, 16, 1, pad, 1, gpre, wd, slab_d,
-                        nullptr, y3p, st3p, stat_out, stat_cnt, 0, nullptr, nullptr, nullptr, stream, nullptr, x0, part_wd);
+                        nullptr, y3p, st3p, 0, nullptr, nullptr, nullptr, stream, nullptr, x0, part_wd);
 }
 // the same launch with the gradient chain stored as fp16 (include/w2s.h, "fp16 gradient chain")
 extern "C" int w2s_bwd_fused_h(const void* g, const float* y, const float* st_k, const float* bst_k, int pro, const float* xin,
@@ -1187,5 +1155,5 @@ extern "C" int w2s_bwd_fused_h(const void* g, const float* y, const float* st_k,
                                const float* w1, const float* y3p, const float* st3p, int gmode, const float* hdr_g, const float* hdr_p,
                                float* hdr_o, void* stream) {
   return bwd_fused_impl(g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, pad, 1, gpre, wd, slab_d, w1,
-                        y3p, st3p, nullptr, nullptr, gmode, hdr_g, hdr_p, hdr_o, stream);
+                        y3p, st3p, gmode, hdr_g, hdr_p, hdr_o, stream);
 }

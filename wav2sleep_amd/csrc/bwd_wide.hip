@@ -37,7 +37,6 @@ struct BwdWideP {
   // sum_u gpre[u] x h[2u].  gpre = dL/d(block pre-activation) [B][L/2][OC]; wd_hi / wd_lo = data-gradient planes of the downsample weight
   const float* gpre; const __bf16* wd_hi; const __bf16* wd_lo; float* slab_d;
   int B, L, Lg, ntiles;   // L: input-side length; Lg: gradient-side length (L, or L / 2 for the stride-2 form)
-  StatFin fin;            // in-kernel statistics finalisation (fin.out == NULL: per-tile partials in `part`)
 };
 
 typedef __bf16 wbbf16x4v __attribute__((__vector_size__(4 * sizeof(__bf16))));
@@ -51,7 +50,7 @@ __device__ __forceinline__ bf16x8 wb_tr8(const __bf16* p0, const __bf16* p1) {
 
 // CO / CI: 16-channel tiles on the gradient / input side; HST: xin carries statistics (conv2); MT: 16-position m-tiles per tile;
 // NWC consumer waves = (CO / IB) x (CI / CB) weight-gradient owners = CI x (NWC / CI) data-gradient owners; PD: producer prefetch depth
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD, int FIN>
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD>
 __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
   static_assert(!RD || (!UP2 && !HST && MT % 2 == 0), "residual fold: the stride-1 conv1 (its input is a stored pre-activation)");
   extern __shared__ f32x4 smem4[];
@@ -77,8 +76,6 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
   const W2SRun wrun = w2s_block_part(total, G, blockIdx.x);
   const int first = wrun.first;
   const int run_b0 = first / P.ntiles, run_t0 = first - run_b0 * P.ntiles;   // the run's first (sample, tile): the one division of the launch
-  // running statistics sums of this workgroup's run [PG][2][HC] (hi, lo), behind the tables (in-kernel statistics finalisation)
-  w2s_dd* accL = reinterpret_cast<w2s_dd*>(stL + P.B * OC * 4 + (HST ? P.B * HC * 2 : 0));
   for (int i = tid; i < P.B * OC * 2; i += 64 * (NWC + 4)) {
     stL[i] = P.st_k[i];
     stL[P.B * OC * 2 + i] = P.bst_k[i];
@@ -323,11 +320,6 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
       for (int c = 0; c < CB; ++c) accd[i][c] = (f32x4){0, 0, 0, 0};
   }
   const int ch0 = dn * 16 + 4 * g;   // this lane's 4 consecutive output channels (D fragment: position r, channels 4g .. 4g+3)
-  w2s_dd* accW = accL + dg * 2 * HC; // this position group's running sums
-  if ((FIN && P.fin.out) && r == 0) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { accW[ch0 + e] = (w2s_dd){0.0, 0.0}; accW[HC + ch0 + e] = (w2s_dd){0.0, 0.0}; }
-  }
   __syncthreads();                   // round 0 of the producers: the first windows are in buffer 0
 #ifdef W2S_WIDE_STAMP
   unsigned long long tk = 0, te = 0, tg = 0, tw = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
@@ -423,19 +415,7 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
       f32x4 x1, x2;
       x1 = sA; x2 = sB;
       row16_sum8(x1, x2);
-      if ((FIN && P.fin.out)) {   // (uniform) running sums of this run; the run of sample b ends with this tile: the sums go to the row scratch
-        if (r == 0) {
-          const bool endrun = (it + 1 >= nt_wg) || (tile + 1 == P.ntiles);
-          double* row = nullptr;   // this position group's row: rows run*PG .. run*PG + PG-1 of the sample
-          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, G, P.ntiles, b, blockIdx.x).row * PG + dg) * (2 * HC) * 2;
-          const float v1[4] = {x1.x, x1.y, x1.z, x1.w}, v2[4] = {x2.x, x2.y, x2.z, x2.w};
-#pragma unroll 1
-          for (int e = 0; e < 4; ++e) {
-            w2s_run_add(accW, ch0 + e, v1[e], endrun, row);
-            w2s_run_add(accW, HC + ch0 + e, v2[e], endrun, row);
-          }
-        }
-      } else if (r == 0) {
+      if (r == 0) {
         float* d = P.part + ((((size_t)b * P.ntiles + tile) * PG + dg) * 2) * HC + ch0;
         st4(d, x1);
         st4(d + HC, x2);
@@ -525,17 +505,14 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int c = 0; c < CB; ++c) st4(out + (size_t)(((wi * IB + i) * 3 + j) * CI + wc * CB + c) * 256, accw[i][j][c]);
-  // tickets of the samples this run touched (the consumer waves; the producers have passed their last barrier and end): the last
-  // arriver of a sample finalises its statistics (w2s_common.h).  Scratch: the window buffers, dead now.
-  if (FIN && P.fin.out) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, run_b0, (first + nt_wg - 1) / P.ntiles, HC, PG, 64 * NWC, smem4);
 }
 
 // (two entry points over one body, as conv_wide.hip: the second without packed-fp32 instruction selection)
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD, int FIN>
-__global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) { bwd_wide_body<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, FIN>(P); }
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD, int FIN>
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD>
+__global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) { bwd_wide_body<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>(P); }
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD>
 __global__ __launch_bounds__(64 * (NWC + 4)) __attribute__((target("no-packed-fp32-ops"))) void bwd_wide_np_kernel(BwdWideP P) {
-  bwd_wide_body<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, FIN>(P);
+  bwd_wide_body<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>(P);
 }
 
 template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0, int RD = 0>
@@ -543,18 +520,16 @@ static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
   constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NR = TM + 2, NRG = UP2 ? TM / 2 + 1 : TM + 2, NRP = RD ? TM / 2 + 1 : 0;
   BwdWideP P = P0;
   P.ntiles = (P.L + TM - 1) / TM;
-  const size_t lds = (size_t)2 * ((2 * (NRG + NRP) * (OC + 16) + 2 * NR * (HC + 8)) * 2 + TM * (HC + 4) * 4) + (size_t)P.B * OC * 4 * 4 + (HST ? (size_t)P.B * HC * 2 * 4 : 0) +
-                     (size_t)((NWC / CI) * 2 * HC) * 16;   // ... + running statistics sums [PG][2][HC] (hi, lo)
+  const size_t lds = (size_t)2 * ((2 * (NRG + NRP) * (OC + 16) + 2 * NR * (HC + 8)) * 2 + TM * (HC + 4) * 4) + (size_t)P.B * OC * 4 * 4 + (HST ? (size_t)P.B * HC * 2 * 4 : 0);
   if (lds > 160 * 1024) return 1;   // (batch too large for the LDS statistics tables: the caller runs the separate kernels)
   if (dry) return 0;
   if (nslab <= 0 || (long)nslab > (long)P.B * P.ntiles) return W2S_EINVAL;   // every workgroup writes a slab: it needs a tile
-  P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, nslab) * (NWC / CI);
 #ifndef W2S_BWW_NP
 #define W2S_BWW_NP 0   // tuning: 1 = the entry point without packed-fp32 selection
 #endif
   void (*kern)(BwdWideP);
-  if constexpr (W2S_BWW_NP) kern = P.fin.out ? bwd_wide_np_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 1> : bwd_wide_np_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 0>;
-  else kern = P.fin.out ? bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 1> : bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, 0>;
+  if constexpr (W2S_BWW_NP) kern = bwd_wide_np_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>;
+  else kern = bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -581,20 +556,18 @@ extern "C" int w2s_bwd_wide_groups(int cg, int ch, int stride) { return !w2s_bwd
 extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                             const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B,
                             int L, int cg, int ch, int stride, const float* y3p, const float* st3p, const float* gpre, const void* wd_hi,
-                            const void* wd_lo, float* slab_d, float* stat_out, int* stat_cnt, int dry, void* stream) {
+                            const void* wd_lo, float* slab_d, int dry, void* stream) {
   if (!w2s_bwd_wide_tile(cg, ch, stride)) return 1;
   const bool rd = gpre != nullptr;
   if (rd && (stride != 1 || st_in || add_even || (L & 1) || (!dry && (!wd_hi || !wd_lo || !slab_d)))) return dry ? 1 : W2S_EINVAL;
   if (stride == 2 && (!st_in || add_even || (L & 1) || y3p)) return dry ? 1 : W2S_EINVAL;
   if (y3p && (!st3p || !part)) return W2S_EINVAL;
-  if (stat_out && (!stat_cnt || !part || ((uintptr_t)part & 15))) return W2S_EINVAL;   // stat_out: `part` is the ROW scratch (w2s_stat_rows x groups)
   if (!dry && (!g || !y || !st_k || !bst_k || !xin || !w_hi || !w_lo || !gout || !slab)) return W2S_EINVAL;
   if ((size_t)L * 64 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;   // 32-bit lane offsets inside one sample
   static const char* off = getenv("W2S_NO_BWD_WIDE");   // tuning only
   if (off) return 1;
   BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, y3p, st3p, gpre,
-             static_cast<const __bf16*>(wd_hi), static_cast<const __bf16*>(wd_lo), slab_d, B, L, L / stride, 0,
-             StatFin{stat_out, stat_cnt, reinterpret_cast<double*>(part), 0, 1.0 / (double)L, 0.f, 1}};
+             static_cast<const __bf16*>(wd_hi), static_cast<const __bf16*>(wd_lo), slab_d, B, L, L / stride, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (stride == 2) return launch_bww<4, 4, 1, 4, 4, 2, 2, 2, 1>(P, nslab, s, dry);
   if (rd) return ch == 64 ? launch_bww<4, 4, 0, 4, 4, 2, 2, 2, 0, 1>(P, nslab, s, dry) : launch_bww<4, 2, 0, 4, 4, 2, 1, 2, 0, 1>(P, nslab, s, dry);

@@ -14,7 +14,7 @@ int w2s_conv_dispatch_44d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_33d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_up2(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_tile_impl(int cin, int cout, int taps, int stride, int mode, int B, int L_out);
-int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry, int* rows = nullptr);   // conv_wide.hip: 1 = not a wide-kernel shape
+int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry);   // conv_wide.hip: 1 = not a wide-kernel shape
 void w2s_conv_cfg_impl(int cin, int cout, int taps, int stride, int mode, int B, int L_out, int dil, int* out3);
 
 // (NT, MT, WN) template arguments and the effective MODE of the conv_cl_kernel instance w2s_conv_forward(a) launches (profiling keys)
@@ -35,18 +35,6 @@ extern "C" int w2s_conv_tile(const w2s_conv_args* a) {
   return w2s_conv_tile_impl(a->cin, a->cout, a->taps, a->stride, a->mode, a->B, a->L_out);
 }
 
-// rows per sample of the row scratch that w2s_conv_forward(a) needs in `part` when a->stat_out is set: part = [B][rows][2][cout] (hi, lo)
-// pairs of doubles, 16-byte aligned.  0: the kernel that takes this descriptor has no in-kernel finalisation (leave stat_out NULL, use
-// the per-tile partials + w2s_stats_finalize).  `a` filled as for the launch; y / part / stat_* may be NULL.
-extern "C" int w2s_conv_stat_rows(const w2s_conv_args* a) {
-  if (!a) return 0;
-  int rows = 0;
-  return w2s_conv_wide_try(*a, nullptr, 1, &rows) > 1 ? rows : 0;
-}
-// rows per sample of the persistent producers that take `grid` workgroups over B * ntiles tiles (w2s_conv_fwd_fused: grid = min(nwg, B *
-// ntiles); w2s_bwd_fused / w2s_bwd_wide: grid = nslab, times w2s_bwd_wide_groups for the latter)
-extern "C" int w2s_stat_rows(int B, int ntiles, int grid) { return (B > 0 && ntiles > 0 && grid > 0) ? w2s_stat_rows_of(B, ntiles, grid) : 0; }
-
 extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
   if (!ap) return W2S_EINVAL;
   const w2s_conv_args& a = *ap;
@@ -60,10 +48,6 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
     if ((size_t)a.L_in * ldx * 4 >= lim || (size_t)a.L_out * (size_t)a.ldy * 4 >= lim) return W2S_EINVAL;
     if (a.y2 && (size_t)a.L_out * (size_t)(a.ldy2 ? a.ldy2 : a.cout) * 4 >= lim) return W2S_EINVAL;
     if (a.aux && (size_t)a.L_out * (size_t)(a.ld_aux ? a.ld_aux : a.cout) * 4 >= lim) return W2S_EINVAL;
-  }
-  if (a.stat_out) {   // in-kernel statistics finalisation: only the persistent wide kernel does it (`part` = its row scratch, w2s_conv_stat_rows)
-    int rows = 0;
-    if (!a.stat_cnt || !a.part || ((uintptr_t)a.part & 15) || w2s_conv_wide_try(a, nullptr, 1, &rows) <= 1 || rows <= 0) return W2S_EINVAL;
   }
   if (a.pro >= W2S_PRO_IN_GELU && !a.pro_stats) return W2S_EINVAL;
   if ((a.pro == W2S_PRO_INBWD || a.pro == W2S_PRO_INBWD_GP) && (!a.pro_bstats || !a.x2)) return W2S_EINVAL;

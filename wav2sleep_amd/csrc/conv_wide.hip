@@ -27,7 +27,6 @@ struct WideP {
   float* y; float* part;
   int B, L_in, L_out, ntiles, flip, pad;   // window row 0 = input position t0*STRIDE - pad (1: symmetric; forward 2 / data gradient 0: causal)
   int dbg;   // tuning only (W2S_WIDE_DBG): 1 = no prologue arithmetic, 2 = no MFMA loop, 4 = no LDS staging, 8 = no stores, 16 = no loads
-  StatFin fin;   // in-kernel statistics finalisation (fin.out == NULL: per-tile partials in `part`)
 };
 
 #define wsplit_store4 split_store4   /* w2s_common.h: the explicit bit form */
@@ -41,7 +40,7 @@ struct WideP {
 // UP2 = 1: the transposed stride-2 form (data gradient of the stride-2 conv3, w2s_conv_forward's W2S_MODE_UP2): output position
 // t' = 2u + phase reads the gradient rows u, u+1; m-tiles alternate phase (mt & 1), their row block is mt >> 1.  Symmetric padding:
 // even outputs W_1^T g[u], odd outputs W_2^T g[u] + W_0^T g[u+1]; causal (pad 2): even W_2^T g[u] + W_0^T g[u+1], odd W_1^T g[u+1].
-template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2, int CZ, int FIN>   // CZ: UP2 with causal padding
+template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2, int CZ>   // CZ: UP2 with causal padding
 __device__ __forceinline__ void conv_wide_body(const WideP& P) {
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 16 * MT;                            // output positions per tile (all consumer waves share them)
@@ -66,8 +65,6 @@ __device__ __forceinline__ void conv_wide_body(const WideP& P) {
   const W2SRun wrun = w2s_block_part(total, G, blockIdx.x);
   const int first = wrun.first;
   const int run_b0 = first / P.ntiles, run_t0 = first - run_b0 * P.ntiles;   // the run's first (sample, tile): the one division of the launch
-  // running statistics sums of this workgroup's run [2][OC] (hi, lo), behind the tables (in-kernel statistics finalisation)
-  w2s_dd* accL = reinterpret_cast<w2s_dd*>(stL + ((PRO != W2S_PRO_GELU) ? P.B * HC * 2 * (TWO ? 2 : 1) : 0));
   if (PRO != W2S_PRO_GELU) {
     for (int i = tid; i < P.B * HC * 2; i += 64 * (NW + NP)) {
       stL[i] = P.st[i];
@@ -208,10 +205,6 @@ __device__ __forceinline__ void conv_wide_body(const WideP& P) {
     al[ks] = *reinterpret_cast<const bf16x8*>(P.w_lo + wo);
   }
   const int ch0 = wave * 16 + 4 * g;   // this lane's 4 consecutive output channels (D fragment: position r, channels 4g..4g+3)
-  if ((FIN && P.fin.out) && r == 0) {           // this lane's eight running sums (nobody else touches them)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { accL[ch0 + e] = (w2s_dd){0.0, 0.0}; accL[OC + ch0 + e] = (w2s_dd){0.0, 0.0}; }
-  }
   __syncthreads();                     // round 0 of the producers: the first window is in buffer 0
 #ifdef W2S_WIDE_STAMP
   unsigned long long tk = 0, te = 0, tw = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -316,19 +309,7 @@ __device__ __forceinline__ void conv_wide_body(const WideP& P) {
       f32x4 x1, x2;
       x1 = sA; x2 = sB;
       row16_sum8(x1, x2);
-      if ((FIN && P.fin.out)) {   // (uniform) running sums of this run; the run of sample b ends with this tile: the sums go to the row scratch
-        if (r == 0) {
-          const bool endrun = (i + 1 >= nt_wg) || (tile + 1 == P.ntiles);
-          double* row = nullptr;
-          if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, G, P.ntiles, b, blockIdx.x).row) * (2 * OC) * 2;
-          const float v1[4] = {x1.x, x1.y, x1.z, x1.w}, v2[4] = {x2.x, x2.y, x2.z, x2.w};
-#pragma unroll 1
-          for (int e = 0; e < 4; ++e) {
-            w2s_run_add(accL, ch0 + e, v1[e], endrun, row);
-            w2s_run_add(accL, OC + ch0 + e, v2[e], endrun, row);
-          }
-        }
-      } else if (r == 0) {
+      if (r == 0) {
         float* d = P.part + (((size_t)b * P.ntiles + tile) * 2) * OC + ch0;
         st4(d, x1);
         st4(d + OC, x2);
@@ -346,9 +327,6 @@ __device__ __forceinline__ void conv_wide_body(const WideP& P) {
 #ifdef W2S_WIDE_STAMP
   if (blockIdx.x == 0 && tid == 0) { P.part[0] = (float)tk; P.part[1] = (float)te; P.part[2] = (float)tw; P.part[3] = (float)nt_wg; }
 #endif
-  // tickets of the samples this run touched (the consumer waves; the producers have passed their last barrier and end): the last
-  // arriver of a sample finalises its statistics (w2s_common.h).  Scratch: the window buffers, dead now.
-  if (FIN && P.fin.out) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, run_b0, (first + nt_wg - 1) / P.ntiles, OC, 1, 64 * NW, smem4);
 }
 
 // Two entry points over one body.  The forward instances (statistics epilogue) are PRODUCER-bound (in-kernel stamps, docs/lab_notes_r4.md
@@ -357,24 +335,22 @@ __device__ __forceinline__ void conv_wide_body(const WideP& P) {
 // one filler beside MFMAs").  `conv_wide_np_kernel` is the same code compiled without packed-fp32 selection, with the producers at
 // s_setprio 1 (they are the younger waves and lose every issue arbitration otherwise).  The data-gradient instances are consumer-bound
 // (GELU' epilogue, no MFMA beside it) and keep the packed form.
-template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2, int CZ, int FIN>
-__global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) { conv_wide_body<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, FIN>(P); }
-template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2, int CZ, int FIN>
+template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2, int CZ>
+__global__ __launch_bounds__(64 * (NW + NP)) void conv_wide_kernel(WideP P) { conv_wide_body<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ>(P); }
+template <int CI, int NW, int NP, int STRIDE, int PRO, int EPI, int MT, int PD, int UP2, int CZ>
 __global__ __launch_bounds__(64 * (NW + NP)) __attribute__((target("no-packed-fp32-ops"))) void conv_wide_np_kernel(WideP P) {
-  conv_wide_body<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, FIN>(P);
+  conv_wide_body<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ>(P);
 }
 
 template <int CI, int NW, int STRIDE, int PRO, int EPI, int MT, int NP = 4, int UP2 = 0, int CZ = 0>
-static int launch_wide(const w2s_conv_args& a, hipStream_t s, int* rows_only = nullptr) {   // rows_only: answer the row count of the in-kernel finalisation, launch nothing
+static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
   constexpr int TM = 16 * MT, HC = CI * 16, NR = UP2 ? TM / 2 + 1 : (TM - 1) * STRIDE + 3, RSE = HC + (STRIDE == 1 ? 16 : 8);
   WideP P{a.x, a.x2, a.pro_stats, a.pro_bstats, static_cast<const __bf16*>(a.w_hi), static_cast<const __bf16*>(a.w_lo), a.aux, a.aux_stats,
-          a.add_even, a.y, a.part, a.B, a.L_in, a.L_out, (a.L_out + TM - 1) / TM, a.flip, a.pad, 0,
-          StatFin{a.stat_out, a.stat_cnt, reinterpret_cast<double*>(a.part), 0, 1.0 / (double)a.L_out, a.stat_eps, a.epi == W2S_EPI_STATS ? 0 : 1}};
+          a.add_even, a.y, a.part, a.B, a.L_in, a.L_out, (a.L_out + TM - 1) / TM, a.flip, a.pad, 0};
   { static const char* d = getenv("W2S_WIDE_DBG"); if (d) P.dbg = atoi(d); }
   size_t lds = (size_t)2 * 2 * NR * RSE * 2;   // two window buffers x (hi, lo) planes, bf16
   constexpr bool TWO = (PRO == W2S_PRO_INBWD || PRO == W2S_PRO_INBWD_GP);
   if (PRO != W2S_PRO_GELU) lds += (size_t)a.B * HC * 2 * 4 * (TWO ? 2 : 1);   // the statistics tables
-  lds += (size_t)2 * 16 * NW * 16;                                              // running statistics sums [2][OC] (hi, lo)
   // producer prefetch depth: three tiles in flight where the register budget allows (kernel-wide allocation: 64-channel workgroups
   // of 8 waves run two per CU = 128 VGPRs; 128-channel workgroups of 12 waves run one per CU = 168 VGPRs)
   constexpr int NHr = (NR + (64 * NP) / (HC / 4) - 1) / ((64 * NP) / (HC / 4));
@@ -393,8 +369,8 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s, int* rows_only = n
 #endif
   constexpr bool NPK = W2S_WIDE_NP && EPI == W2S_EPI_STATS;
   void (*kern)(WideP);
-  if constexpr (NPK) kern = P.fin.out ? conv_wide_np_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 1> : conv_wide_np_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 0>;
-  else kern = P.fin.out ? conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 1> : conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ, 0>;
+  if constexpr (NPK) kern = conv_wide_np_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ>;
+  else kern = conv_wide_kernel<CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -402,8 +378,6 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s, int* rows_only = n
   static const char* e = getenv("W2S_WIDE_WGS");   // tuning only: workgroups per CU
   const int per_cu = e ? atoi(e) : ((NW >= 8 || UP2) ? 1 : 2);   // (the transposed form needs 166 registers: one 8-wave workgroup per CU)
   const int nwg = 256 * (per_cu > 0 ? per_cu : 1), grid = nwg < total ? nwg : total;
-  P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, grid);
-  if (rows_only) { *rows_only = P.fin.rows_cap; return W2S_OK; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NW + NP)), lds, s, P);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
@@ -413,7 +387,6 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s, int* rows_only = n
 static bool wide_shape(const w2s_conv_args& a) {
   if (!a.w_hi || !a.w_lo || (a.mode != W2S_MODE_CONTIG && a.mode != W2S_MODE_UP2) || a.taps != 3 || a.dil != 1 || a.pad < 0 || a.pad > 2) return false;
   if (a.y2 || a.rowkeep || a.bias || a.reserved) return false;
-  if (a.stat_out && (!a.stat_cnt || !a.part || ((uintptr_t)a.part & 15))) return false;
   if ((size_t)a.B * a.cin * 16 > 32 * 1024) return false;   // the per-sample statistics tables live in LDS
   if (a.ldx != a.cin || a.ldy != a.cout || (a.aux && a.ld_aux != a.cout)) return false;
   if (a.cin < 32 || a.cout < 32 || (a.cin < 64 && a.cout < 64)) return false;
@@ -427,15 +400,13 @@ static bool wide_shape(const w2s_conv_args& a) {
   return !off;
 }
 // dry != 0: only answer which tile an instance would use for this launch (> 0) or that none takes it (1 -> the caller's generic kernel);
-// w2s_conv_tile sizes the statistics partials with it.  rows != NULL (with dry): also the rows per sample of the in-kernel statistics
-// finalisation's scratch (w2s_conv_stat_rows)
+// w2s_conv_tile sizes the statistics partials with it.
 static int wide_mt() { return 4; }   // 64-position tiles (128 were tried: no gain, more registers)
-int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry, int* rows) {
+int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry) {
   if (!wide_shape(a)) return 1;
   const int mt = wide_mt();
 #define W2S_WIDE_M(CI_, NW_, ST_, PRO_, EPI_, MT_) \
   if (a.mode == W2S_MODE_CONTIG && a.cin == 16 * CI_ && a.cout == 16 * NW_ && a.stride == ST_ && a.pro == PRO_ && a.epi == EPI_) { \
-    if (dry && rows) launch_wide<CI_, NW_, ST_, PRO_, EPI_, MT_>(a, s, rows); \
     if (dry) return 16 * MT_; \
     return launch_wide<CI_, NW_, ST_, PRO_, EPI_, MT_>(a, s); \
   }
@@ -458,10 +429,10 @@ int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry, int* rows)
 #ifndef W2S_UP2_MT
 #define W2S_UP2_MT 8
 #endif
-    if (a.cin == 64 && a.pad == 1) { if (dry && rows) launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s, rows); return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s); }
-    if (a.cin == 64 && a.pad == 2) { if (dry && rows) launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s, rows); return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s); }
-    if (a.cin == 128 && a.pad == 1) { if (dry && rows) launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT128, 4, 1, 0>(a, s, rows); return dry ? 16 * W2S_UP2_MT128 : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT128, 4, 1, 0>(a, s); }
-    if (a.cin == 128 && a.pad == 2) { if (dry && rows) launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT128, 4, 1, 1>(a, s, rows); return dry ? 16 * W2S_UP2_MT128 : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT128, 4, 1, 1>(a, s); }
+    if (a.cin == 64 && a.pad == 1) { return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 0>(a, s); }
+    if (a.cin == 64 && a.pad == 2) { return dry ? 16 * W2S_UP2_MT : launch_wide<4, 4, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT, 4, 1, 1>(a, s); }
+    if (a.cin == 128 && a.pad == 1) { return dry ? 16 * W2S_UP2_MT128 : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT128, 4, 1, 0>(a, s); }
+    if (a.cin == 128 && a.pad == 2) { return dry ? 16 * W2S_UP2_MT128 : launch_wide<8, 8, 1, W2S_PRO_INBWD_GP, W2S_EPI_GP, W2S_UP2_MT128, 4, 1, 1>(a, s); }
   }
   return 1;
 }

@@ -12,7 +12,7 @@
 // => 6 multiply-adds per sample instead of 16 channels x 5, then a 32-thread expansion per tile.  fp32 partials per tile, fp64 in
 // w2s_stats_finalize as for every other layer.
 __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
-                                                             int L, int tile, int ntiles, StatFin fin, int shift, float* __restrict__ xmom) {
+                                                             int L, int tile, int ntiles, int shift, float* __restrict__ xmom) {
   __shared__ float red[4][9];
   __shared__ float tot[9];
   const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -37,23 +37,20 @@ __global__ __launch_bounds__(256) void enc_first_stats_kernel(const float* __res
   if (tid < 9) tot[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   __syncthreads();
   if (xmom && tid >= 32 && tid < 41) xmom[((size_t)b * ntiles + tl) * 9 + (tid - 32)] = tot[tid - 32];   // the tile's nine raw moments (w2s_enc_first_wgrad)
-  float sown = 0.f;
   if (tid < 32) {
     const int k = tid >> 4, o = tid & 15;
     const float w0 = w[o * 3], w1 = w[o * 3 + 1], w2 = w[o * 3 + 2];
     float s;
     if (k == 0) s = w0 * tot[0] + w1 * tot[1] + w2 * tot[2];
     else s = w0 * w0 * tot[3] + w1 * w1 * tot[4] + w2 * w2 * tot[5] + 2.f * (w0 * w1 * tot[6] + w1 * w2 * tot[7] + w0 * w2 * tot[8]);
-    sown = s;
-    if (!fin.out) w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + o], s);
+    w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + o], s);
   }
-  if (fin.out) w2s_row_per_workgroup(fin, b, tl, ntiles, 16, sown);   // uniform
 }
 
 // launcher for w2s_enc_first_fwd (enc_misc.hip)
-int w2s_enc_first_stats_launch(const float* x, const float* w, float* part, int B, int L, int tile, int ntiles, StatFin fin, int shift, hipStream_t s,
+int w2s_enc_first_stats_launch(const float* x, const float* w, float* part, int B, int L, int tile, int ntiles, int shift, hipStream_t s,
                                float* xmom) {
-  hipLaunchKernelGGL(enc_first_stats_kernel, dim3(ntiles, B), dim3(256), 0, s, x, w, part, L, tile, ntiles, fin, shift, xmom);
+  hipLaunchKernelGGL(enc_first_stats_kernel, dim3(ntiles, B), dim3(256), 0, s, x, w, part, L, tile, ntiles, shift, xmom);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

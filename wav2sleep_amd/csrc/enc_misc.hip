@@ -8,7 +8,7 @@
 // (16-B store; 4 lanes cover a 64-B row; a wave writes 1 KiB contiguous).  blocks.py:46 with Cin = 1.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                                                            float* __restrict__ part, int L, int tile, int ntiles, StatFin fin, int shift) {
+                                                            float* __restrict__ part, int L, int tile, int ntiles, int shift) {
   __shared__ float red[4][4][8];
   const int b = blockIdx.y, tl = blockIdx.x, tid = threadIdx.x;
   const int og = tid & 3, lane = tid & 63, wave = tid >> 6;
@@ -51,44 +51,37 @@ __global__ __launch_bounds__(256) void enc_first_fwd_kernel(const float* __restr
     for (int k = 0; k < 8; ++k) red[wave][lane][k] = a[k];
   }
   __syncthreads();
-  float sown = 0.f;
   if (tid < 32) {
     const int k = tid >> 4, c = tid & 15;  // k: 0 sum, 1 sumsq
     float s = 0.f;
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv) s += red[wv][c >> 2][k * 4 + (c & 3)];
-    sown = s;
-    if (!fin.out) w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + c], s);
+    w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * 16 + c], s);
   }
-  if (fin.out) w2s_row_per_workgroup(fin, b, tl, ntiles, 16, sown);   // uniform
 }
 
-int w2s_enc_first_stats_launch(const float* x, const float* w, float* part, int B, int L, int tile, int ntiles, StatFin fin, int shift, hipStream_t s,
+int w2s_enc_first_stats_launch(const float* x, const float* w, float* part, int B, int L, int tile, int ntiles, int shift, hipStream_t s,
                                float* xmom = nullptr);   // enc_first_stats.hip
 
-extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, float* stat_out,
-                                 int* stat_cnt, float eps, int causal, void* stream) {
+extern "C" int w2s_enc_first_fwd(const float* x, const float* w, float* y, float* part, int B, int L, int cout, int tile, int causal,
+                                 void* stream) {
   if (!x || !w || !part || cout != 16 || tile < 64 || (tile & 63)) return W2S_EINVAL;  // y == NULL: statistics only
   const int ntiles = (L + tile - 1) / tile;
-  if (stat_out && (!stat_cnt || ((uintptr_t)part & 15))) return W2S_EINVAL;   // stat_out: `part` is the ROW scratch [B][ntiles][2][16] of (hi, lo) doubles
-  const StatFin fin{stat_out, stat_cnt, reinterpret_cast<double*>(part), ntiles, 1.0 / (double)L, eps, 0};
   if (!y) {
-    return w2s_enc_first_stats_launch(x, w, part, B, L, tile, ntiles, fin, causal ? 1 : 0, reinterpret_cast<hipStream_t>(stream));
+    return w2s_enc_first_stats_launch(x, w, part, B, L, tile, ntiles, causal ? 1 : 0, reinterpret_cast<hipStream_t>(stream));
   }
   hipLaunchKernelGGL(enc_first_fwd_kernel, dim3(ntiles, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, y, part, L, tile,
-                     ntiles, fin, causal ? 1 : 0);
+                     ntiles, causal ? 1 : 0);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
 
 // statistics-only form that also keeps the nine raw moments of every tile of the signal: xmom [B][ceil(L/tile)][9] (S0,S1,S2, A00,A11,A22,
 // A01,A12,A02 of enc_first_stats.hip) -- w2s_enc_first_wgrad needs their sums and this kernel has them anyway
-extern "C" int w2s_enc_first_stats(const float* x, const float* w, float* part, float* xmom, int B, int L, int tile, float* stat_out, int* stat_cnt,
-                                   float eps, int causal, void* stream) {
+extern "C" int w2s_enc_first_stats(const float* x, const float* w, float* part, float* xmom, int B, int L, int tile, int causal,
+                                   void* stream) {
   if (!x || !w || !part || tile < 64 || (tile & 63)) return W2S_EINVAL;
-  if (stat_out && (!stat_cnt || ((uintptr_t)part & 15))) return W2S_EINVAL;   // stat_out: `part` is the ROW scratch [B][ntiles][2][16] of (hi, lo) doubles
-  const StatFin fin{stat_out, stat_cnt, reinterpret_cast<double*>(part), (L + tile - 1) / tile, 1.0 / (double)L, eps, 0};
-  return w2s_enc_first_stats_launch(x, w, part, B, L, tile, (L + tile - 1) / tile, fin, causal ? 1 : 0, reinterpret_cast<hipStream_t>(stream), xmom);
+  return w2s_enc_first_stats_launch(x, w, part, B, L, tile, (L + tile - 1) / tile, causal ? 1 : 0, reinterpret_cast<hipStream_t>(stream), xmom);
 }
 
 // pre[b,u,o] = GELU(IN(y3[b,u,o])) + wd[o] * san(x[b,2u])     (blocks.py:67-69, stored pre-activation)
@@ -446,7 +439,7 @@ extern "C" int w2s_stats_finalize(const float* part, int B, int ntiles, int C, l
 template <int GH>
 __global__ __launch_bounds__(256) void gp_stats_kernel(const void* __restrict__ gv, const float* __restrict__ y,
                                                        const float* __restrict__ stats, float* __restrict__ part, int L, int C, int tile,
-                                                       int ntiles, StatFin fin, const float* __restrict__ hdr_g, float* __restrict__ hdr_amax) {
+                                                       int ntiles, const float* __restrict__ hdr_g, float* __restrict__ hdr_amax) {
   const float* g = static_cast<const float*>(gv);
   const float inv_g = GH ? 1.f / hdr_g[0] : 1.f;
   float amax = 0.f;
@@ -484,39 +477,33 @@ __global__ __launch_bounds__(256) void gp_stats_kernel(const void* __restrict__ 
   st4(sm + tid * 8, a1);
   st4(sm + tid * 8 + 4, a2);
   __syncthreads();
-  float sown = 0.f;
   if (tid < 2 * C) {
     const int k = tid / C, c = tid % C;
     float s = 0.f;
     for (int rl = 0; rl < rstep; ++rl) s += sm[(rl * c4n + (c >> 2)) * 8 + k * 4 + (c & 3)];
-    sown = s;
-    if (!fin.out) w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * C + c], s);
+    w2s_part_store(&part[(((size_t)b * ntiles + tl) * 2 + k) * C + c], s);
   }
   if (!GH && hdr_amax) w2s_amax_commit(hdr_amax, amax, 1.f);   // uniform
-  if (fin.out) w2s_row_per_workgroup(fin, b, tl, ntiles, C, sown);   // uniform
 }
 
 static int gp_stats_impl(const void* g, int g_half, const float* hdr_g, float* hdr_amax, const float* y, const float* stats, float* part, int B, int L,
-                         int C, int tile, float* stat_out, int* stat_cnt, void* stream) {
+                         int C, int tile, void* stream) {
   if (!g || !y || !stats || !part || C < 16 || C > 128 || (C & (C - 1)) || tile <= 0) return W2S_EINVAL;
   if (g_half ? (!hdr_g || hdr_amax) : (hdr_g != nullptr)) return W2S_EINVAL;
   const int ntiles = (L + tile - 1) / tile;
-  if (stat_out && (!stat_cnt || ((uintptr_t)part & 15))) return W2S_EINVAL;   // stat_out: `part` is the ROW scratch [B][ntiles][2][C] of (hi, lo) doubles
-  const StatFin fin{stat_out, stat_cnt, reinterpret_cast<double*>(part), ntiles, 1.0 / (double)L, 0.f, 1};
   if (g_half)
     hipLaunchKernelGGL(gp_stats_kernel<1>, dim3(ntiles, B), dim3(256), 256 * 8 * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y,
-                       stats, part, L, C, tile, ntiles, fin, hdr_g, hdr_amax);
+                       stats, part, L, C, tile, ntiles, hdr_g, hdr_amax);
   else
     hipLaunchKernelGGL(gp_stats_kernel<0>, dim3(ntiles, B), dim3(256), 256 * 8 * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y,
-                       stats, part, L, C, tile, ntiles, fin, hdr_g, hdr_amax);
+                       stats, part, L, C, tile, ntiles, hdr_g, hdr_amax);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
-extern "C" int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, float* stat_out,
-                            int* stat_cnt, void* stream) {
-  return gp_stats_impl(g, 0, nullptr, nullptr, y, stats, part, B, L, C, tile, stat_out, stat_cnt, stream);
+extern "C" int w2s_gp_stats(const float* g, const float* y, const float* stats, float* part, int B, int L, int C, int tile, void* stream) {
+  return gp_stats_impl(g, 0, nullptr, nullptr, y, stats, part, B, L, C, tile, stream);
 }
 extern "C" int w2s_gp_stats_h(const void* g, int g_half, const float* hdr_g, float* hdr_amax, const float* y, const float* stats, float* part, int B,
                               int L, int C, int tile, void* stream) {
-  return gp_stats_impl(g, g_half, hdr_g, hdr_amax, y, stats, part, B, L, C, tile, nullptr, nullptr, stream);
+  return gp_stats_impl(g, g_half, hdr_g, hdr_amax, y, stats, part, B, L, C, tile, stream);
 }

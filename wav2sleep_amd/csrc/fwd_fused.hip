@@ -20,8 +20,6 @@ struct FwdP {
   const float* x; const float* w; const float* st_in; const float* w1;
   float* y; float* part;
   int B, L_in, L_out, ntiles, pro, pad;
-  int acc_off;   // byte offset of the running statistics sums in the dynamic LDS
-  StatFin fin;   // in-kernel statistics finalisation (fin.out == NULL: partials only)
 };
 
 __host__ __device__ constexpr int ff_rs(int c) { return c == 16 ? 16 : c + 8; }  // 32-B rows are conflict-free as they are
@@ -40,7 +38,7 @@ __host__ __device__ constexpr bool ff_db(int hc, int stride) { return hc == 16 &
 #define W2S_FF_OCC2 1
 #endif
 __host__ __device__ constexpr int ffk_occ(int ci, int co, int stride) { return (ci == 1 && co == 1 && stride == 1) ? 1 : W2S_FF_OCC2; }
-template <int CI, int CO, int MT, int STRIDE, int PRO, int FIN>   // FIN: with the in-kernel statistics finalisation (its own instantiation: the default path carries none of its code)
+template <int CI, int CO, int MT, int STRIDE, int PRO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI, CO, STRIDE)))) void conv_fwd_bf_kernel(FwdP P) {
   extern __shared__ f32x4 smem4[];
   constexpr int TM = 64 * MT;                            // output rows the matrix cores compute per tile ...
@@ -59,9 +57,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
   __bf16* wH = hbase + (DB ? 2 : 1) * WIN;               // [OC][WROW]
   __bf16* wLo = wH + OC * WROW;
   float* xsL = reinterpret_cast<float*>(wLo + OC * WROW);  // FIRST: NRh + 2 signal samples
-  // running (double-double) sums of this workgroup's run [2][OC], one slot per thread < 2*OC (in-kernel statistics finalisation)
-  w2s_dd* accL = reinterpret_cast<w2s_dd*>(reinterpret_cast<char*>(smem4) + P.acc_off);
-  if (threadIdx.x < 2 * OC) accL[threadIdx.x] = (w2s_dd){0.0, 0.0};
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int L_in = P.L_in, L_out = P.L_out;
@@ -249,14 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) s += red[((w * CO + nt) * 4 + gg) * 8 + k * 4 + e];
-      if ((FIN && P.fin.out)) {   // running sum of this run; the run of sample b ends with this tile (uniform): the sum goes to the row scratch
-        const bool endrun = tl + 1 >= wend || tile + 1 == P.ntiles;
-        double* row = nullptr;
-        if (endrun) row = P.fin.rows + ((size_t)b * P.fin.rows_cap + w2s_row_pos(total, G, P.ntiles, b, blockIdx.x).row) * (2 * OC) * 2;
-        w2s_run_add(accL, tid, s, endrun, row);
-      } else {
-        w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c], s);
-      }
+      w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c], s);
     }
     if (++tile_cur == P.ntiles) { tile_cur = 0; ++b_cur; }
   };
@@ -266,8 +254,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
     body(I0{}, tl);
     body(I1{}, tl + 1);
   }
-  // tickets of the samples this run touched; the last arriver of a sample finalises its statistics (w2s_common.h)
-  if (FIN && P.fin.out) w2s_rows_tail(P.fin, total, G, P.ntiles, blockIdx.x, wfirst / P.ntiles, (wend - 1) / P.ntiles, OC, 1, 256, smem4);
 }
 
 template <int CI, int CO, int MT, int STRIDE, int PRO>
@@ -278,14 +264,11 @@ static int launch_fwd(const FwdP& P0, int nwg, hipStream_t s) {
   size_t lds = (size_t)4 * CO * 4 * 8 * 4 + (size_t)2 * 2 * ((ff_db(HC, STRIDE) ? 2 : 1) * NRh * ff_rs(HC) + OC * (KD + 8));
   if (PRO == W2S_PRO_FIRST) lds += (size_t)(NRh + 2) * 4;
   lds = (lds + 15) & ~(size_t)15;
-  P.acc_off = (int)lds;
-  lds += (size_t)2 * OC * 16;
-  auto kern = P.fin.out ? conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO, 1> : conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO, 0>;
+  auto kern = conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
   const int total = P.B * P.ntiles, grid = nwg < total ? nwg : total;
-  P.fin.rows_cap = w2s_stat_rows_of(P.B, P.ntiles, grid);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, P);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
@@ -299,18 +282,14 @@ extern "C" int w2s_conv_fwd_fused_tile(int cin, int cout, int stride) {
 }
 
 extern "C" int w2s_conv_fwd_fused(const float* x, const float* w, const float* st_in, const float* w1, float* y, float* part, int B,
-                                  int L_in, int L_out, int cin, int cout, int stride, int pad, int pro, int nwg, float* stat_out, int* stat_cnt,
-                                  float eps, void* stream) {
-  // stat_out given: the statistics are finalised in the kernel and `part` is its ROW scratch instead of the per-tile partials --
-  // B * w2s_stat_rows(B, ntiles, min(nwg, B * ntiles)) * 2 * cout (hi, lo) pairs of doubles, 16-byte aligned (w2s_common.h)
+                                  int L_in, int L_out, int cin, int cout, int stride, int pad, int pro, int nwg, void* stream) {
   if (!x || !w || !y || !part || B <= 0 || L_out <= 0 || nwg <= 0) return W2S_EINVAL;
   if (!w2s_conv_fwd_fused_tile(cin, cout, stride)) return W2S_EINVAL;
   if (pro != W2S_PRO_GELU && pro != W2S_PRO_IN_GELU && pro != W2S_PRO_FIRST) return W2S_EINVAL;
   if ((pro != W2S_PRO_GELU && !st_in) || (pro == W2S_PRO_FIRST && (!w1 || cin != 16 || stride != 1))) return W2S_EINVAL;
   if ((stride == 1 && L_out != L_in) || (stride == 2 && 2 * L_out != L_in) || (pad != 1 && pad != 2)) return W2S_EINVAL;
   if ((size_t)L_in * 32 * 4 >= ((size_t)1 << 32)) return W2S_EINVAL;
-  if (stat_out && (!stat_cnt || ((uintptr_t)part & 15))) return W2S_EINVAL;
-  FwdP P{x, w, st_in, w1, y, part, B, L_in, L_out, 0, pro, pad, 0, StatFin{stat_out, stat_cnt, reinterpret_cast<double*>(part), 0, 1.0 / (double)L_out, eps, 0}};
+  FwdP P{x, w, st_in, w1, y, part, B, L_in, L_out, 0, pro, pad};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define W2S_FF(CI_, CO_, MT_, ST_) \
   if (cin == 16 * CI_ && cout == 16 * CO_ && stride == ST_) { \

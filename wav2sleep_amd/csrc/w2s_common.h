@@ -312,24 +312,14 @@ __device__ __forceinline__ float w2s_dropscale(uint64_t seed, uint64_t idx, floa
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Statistics finalisation inside the PRODUCER kernel, per WORKGROUP (round 4; replaces the w2s_stats_finalize launch between every two
-// encoder layers: 168 launches per train step).  The persistent producers take their tiles BLOCKED -- workgroup w owns a contiguous run of
-// the flattened (sample, tile) list (w2s_block_part) -- so a workgroup meets one or two samples and a sample is covered by a handful of
-// workgroups.  In its tile loop a workgroup only keeps running sums of its tiles' per-tile fp32 sums in a small LDS table (double-double:
-// the total is exact to ~2^-100, so the finalised fp32 values do not depend on how batch size / grid happened to cut a sample into runs)
-// and, when its run of sample b ends, stores ONE row [2][C] of (hi, lo) pairs with agent-scope write-through stores.  AFTER the loop
-// (w2s_rows_tail: nothing of the loop is live any more, so none of this counts against the loop's register budget) it waits for the
-// acknowledgement of its stores and takes ONE ticket per sample of its run from cnt[b]; the workgroup whose ticket is a sample's last sums
-// that sample's rows -- all its threads, a fixed partition and order -- and writes out[b][C][2] = (mean, rstd) or (sum1, sum2)/count; it
-// also re-arms the counter.  Protocol = MI355X_MICROARCH.md, "Valid forms": sc1 payload stores, drained by every storing wave, a
-// workgroup barrier, ONE lane's agent-scope atomic add; the workgroup whose add returned last loads with sc1 loads behind an agent-scope
-// acquire (several workgroups share a CU here).  The round-1 form of this took a ticket per TILE and stalled the persistent workgroups on
-// every one of them (47 ms vs 38.5 ms per step); this one costs a workgroup one or two tickets per launch, after its work.  (A third form
-// -- producers only add to the counter, extra finaliser workgroups of the same launch poll it -- was built in round 4 and measured
-// 0.7 ms per step SLOWER than this one: docs/lab_notes_r4.md.)
+// Blocked tile assignment of the persistent producers: workgroup w owns a contiguous run of the flattened (sample, tile) list, so it meets
+// one or two samples and carries (sample, tile) incrementally -- no integer division per tile.  Statistics leave the producers as per-tile
+// fp32 partial sums [B][ntiles][2][C] that w2s_stats_finalize combines in fp64 in a fixed order (exact enough that the finalised values do
+// not depend on how batch size and grid cut a sample).  Rounds 1 and 4 built three forms of finalising INSIDE the producer (ticket per
+// tile; running double-double sums + one ticket per sample after the tile loop; extra finaliser workgroups polling a counter): correct,
+// 168 launches fewer per step, and 0.3-0.9 ms per step SLOWER at four streams every time they were measured (docs/lab_notes_r4.md section 3,
+// docs/lab_notes_r5.md) -- removed in round 5.
 // ------------------------------------------------------------------------------------------------------------------
-struct StatFin { float* out; int* cnt; double* rows; int rows_cap; double inv_count; float eps; int kind; };   // out == NULL: per-tile partials only
-
 // balanced blocked partition of `total` items over `grid` workgroups: the first total % grid runs are one longer (surplus workgroups: empty)
 struct W2SRun { int first, count; };
 __host__ __device__ __forceinline__ W2SRun w2s_block_part(int total, int grid, int w) {
@@ -338,18 +328,6 @@ __host__ __device__ __forceinline__ W2SRun w2s_block_part(int total, int grid, i
   const int base = total / grid, rem = total % grid;
   return W2SRun{w * base + (w < rem ? w : rem), base + (w < rem ? 1 : 0)};
 }
-__host__ __device__ __forceinline__ int w2s_block_owner(int total, int grid, int t) {
-  if (grid > total) grid = total;
-  const int base = total / grid, rem = total % grid, cut = rem * (base + 1);
-  return t < cut ? t / (base + 1) : rem + (t - cut) / base;
-}
-// rows a sample can have (sizes the row scratch [B][rows][2][C] of (hi, lo) pairs): the runs that can intersect ntiles consecutive items
-__host__ __device__ __forceinline__ int w2s_stat_rows_of(int B, int ntiles, int grid) {
-  const int total = B * ntiles, g = grid < total ? grid : total, base = total / (g > 0 ? g : 1);
-  const int r = (ntiles + base - 1) / base + 1;
-  return r < g ? r : g;
-}
-
 // (sample, tile) of the i-th item of a run that starts at tile t0 of sample b0 -- without an integer division (a run is short against a
 // sample except in the chunk-causal configuration, where the loop below takes a few more turns)
 __device__ __forceinline__ void w2s_run_pos(int b0, int t0, int ntiles, int i, int& b, int& tile) {
@@ -357,114 +335,8 @@ __device__ __forceinline__ void w2s_run_pos(int b0, int t0, int ntiles, int i, i
   b = b0;
   while (tile >= ntiles) { tile -= ntiles; ++b; }
 }
-
-typedef double w2s_dd __attribute__((ext_vector_type(2)));   // (hi, lo): value = hi + lo
-__device__ __forceinline__ void w2s_dd_add(w2s_dd& a, double x) {   // a += x, error-free in the high word (Knuth TwoSum)
-  const double s = a.x + x, bb = s - a.x;
-  a.y += (a.x - (s - bb)) + (x - bb);
-  a.x = s;
-}
-__device__ __forceinline__ void w2s_dd_add2(w2s_dd& a, w2s_dd b) { w2s_dd_add(a, b.x); a.y += b.y; }
-// agent-scope write-through store / L1-bypassing load of one (hi, lo) pair (two 8-byte accesses: the guide's table covers 8-B sc1 forms)
-__device__ __forceinline__ void w2s_row_store(double* p, w2s_dd v) {
-  __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ w2s_dd w2s_row_load(const double* p) {
-  return (w2s_dd){__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
-}
-// per-tile partial sums of the partials-only mode (F.out == NULL): plain stores, read by a later launch (w2s_stats_finalize)
+// per-tile partial sums: plain stores, read by a later launch (w2s_stats_finalize)
 __device__ __forceinline__ void w2s_part_store(float* p, float v) { *p = v; }
-
-// Which row of sample b workgroup w writes, and how many workgroups write rows of b
-struct W2SRowPos { int row, expected; };
-__device__ __forceinline__ W2SRowPos w2s_row_pos(int total, int grid, int ntiles, int b, int w) {
-  const int w0 = w2s_block_owner(total, grid, b * ntiles), w1 = w2s_block_owner(total, grid, (b + 1) * ntiles - 1);
-  return W2SRowPos{w - w0, w1 - w0 + 1};
-}
-// In the tile loop, thread-private: running sum `idx` (a value of the row [groups][2][C], owned by exactly one thread) += the tile's fp32 sum;
-// with `endrun` (the workgroup's run of sample b ends with this tile) the sum goes to the row and the slot is cleared.  acc: LDS table.
-__device__ __forceinline__ void w2s_run_add(w2s_dd* acc, int idx, float s, bool endrun, double* row) {
-  w2s_dd a = acc[idx];
-  w2s_dd_add(a, (double)s);
-  if (endrun) { w2s_row_store(row + 2 * idx, a); a = (w2s_dd){0.0, 0.0}; }
-  acc[idx] = a;
-}
-// After the tile loop; reached by the NT threads (tid 0 .. NT-1, whole waves) that stored rows or share a barrier with those that did --
-// every thread of the workgroup, or the consumer waves of a role-split kernel once its producer waves have ended.  Workgroup w's run
-// covered samples b0 .. b1 (b1 < b0: empty run).  `lds`: >= NT * 16 + 16 bytes of LDS nobody else uses any more, 16-byte aligned.
-// rows: [B][rows_cap][2][C] pairs; a workgroup wrote `groups` consecutive rows per sample (position groups of a tile: row*groups + g).
-__device__ __forceinline__ void w2s_rows_tail(const StatFin& F, int total, int grid, int ntiles, int w, int b0, int b1, int C, int groups, int NT, void* lds) {
-  const int tid = threadIdx.x;
-  w2s_dd* red = reinterpret_cast<w2s_dd*>(lds);
-  int* flag = reinterpret_cast<int*>(red + NT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its row stores are acknowledged (write-through: at the memory side)
-  __syncthreads();
-  const int V = 2 * C, slots = NT / V;   // thread = (row slot, value of the row); NT >= 2C in every caller (C = 128 with 256 threads: one slot)
-  for (int b = b0; b <= b1; ++b) {
-    const W2SRowPos rp = w2s_row_pos(total, grid, ntiles, b, w);
-    if (tid == 0) {
-      const int lastw = (__hip_atomic_fetch_add(&F.cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rp.expected - 1) ? 1 : 0;
-#ifndef W2S_FIN_NOFENCE   // (tuning builds: without the acquire -- every load of the rows is an sc1 load, which bypasses L1 by itself)
-      if (lastw) {   // ONE lane's agent-scope acquire (drops this CU's L1 copies: several workgroups share a CU), complete before the barrier
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-#endif
-      *flag = lastw;
-    }
-    __syncthreads();
-    const bool last = *flag != 0;
-    if (last) {   // uniform
-      const int nrows = rp.expected * groups;
-      const double* base = F.rows + ((size_t)b * F.rows_cap) * V * 2;
-      const int v = tid % V, slot = tid / V;
-      w2s_dd a = {0.0, 0.0};
-      if (slot < slots) {
-        int r = slot;
-        for (; r + 3 * slots < nrows; r += 4 * slots) {   // four rows in flight per thread
-          w2s_dd x[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) x[u] = w2s_row_load(base + ((size_t)(r + u * slots) * V + v) * 2);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) w2s_dd_add2(a, x[u]);
-        }
-        for (; r < nrows; r += slots) w2s_dd_add2(a, w2s_row_load(base + ((size_t)r * V + v) * 2));
-      }
-      red[tid] = a;
-      __syncthreads();
-      if (tid < C) {
-        w2s_dd s1 = {0.0, 0.0}, s2 = {0.0, 0.0};
-        for (int sl = 0; sl < slots; ++sl) { w2s_dd_add2(s1, red[sl * V + tid]); w2s_dd_add2(s2, red[sl * V + C + tid]); }
-        const double t1 = s1.x + s1.y, t2 = s2.x + s2.y;
-        float o0, o1;
-        if (F.kind == 0) {
-          const double mean = t1 * F.inv_count;
-          double var = t2 * F.inv_count - mean * mean;
-          if (var < 0.0) var = 0.0;
-          o0 = (float)mean;
-          o1 = (float)(1.0 / sqrt(var + (double)F.eps));
-        } else {
-          o0 = (float)(t1 * F.inv_count);
-          o1 = (float)(t2 * F.inv_count);
-        }
-        F.out[((size_t)b * C + tid) * 2] = o0;
-        F.out[((size_t)b * C + tid) * 2 + 1] = o1;
-      }
-      if (tid == 0) __hip_atomic_store(&F.cnt[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch on this stream
-    }
-    __syncthreads();   // flag / red are reused by the next sample of the run
-  }
-}
-
-// Tile-per-workgroup kernels (w2s_gp_stats, the Cin = 1 statistics kernels; grid (ntiles, B), 256 threads): workgroup (tile tl of sample b)
-// is row tl of its sample's ntiles rows; threads < 2C hold the row's values.  Reached by every thread of the workgroup.
-__device__ __forceinline__ void w2s_row_per_workgroup(const StatFin& F, int b, int tl, int ntiles, int C, float s) {
-  __shared__ __attribute__((aligned(16))) char fin_lds[256 * 16 + 16];
-  if ((int)threadIdx.x < 2 * C) w2s_row_store(F.rows + (((size_t)b * F.rows_cap + tl) * (2 * C) + threadIdx.x) * 2, (w2s_dd){(double)s, 0.0});
-  // (as a blocked partition: B * ntiles items over as many workgroups, this one is number b * ntiles + tl)
-  w2s_rows_tail(F, gridDim.y * ntiles, gridDim.y * ntiles, ntiles, b * ntiles + tl, b, b, C, 1, 256, fin_lds);
-}
 
 // sum over the 16 lanes that share (lane >> 4)  [row of the MFMA output fragment]
 // DPP lane permutes inside a 16-lane row (no LDS traffic, unlike the ds_bpermute behind __shfl_xor): pair swap, quad-pair

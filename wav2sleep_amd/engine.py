@@ -108,9 +108,6 @@ class Engine:
         self._deferred = None
         self.fused_forward = os.environ.get('W2S_FUSED_FORWARD', '1') != '0'
         self.fold_gp = os.environ.get('W2S_FOLD_GP', '1') == '1'   # conv3-backward statistics of the previous block ride in the residual-fold conv1 kernel
-        # instance-norm statistics finalised inside their producer kernels (per-workgroup rows + one ticket per workgroup and sample,
-        # csrc/w2s_common.h): no w2s_stats_finalize launch between two encoder layers.  W2S_FUSED_FINALIZE=0: per-tile partials + that launch
-        self.fused_finalize = os.environ.get('W2S_FUSED_FINALIZE', '0') != '0'
         self.fold_w1 = os.environ.get('W2S_FOLD_W1', '1') != '0'   # block 0: conv1's weight gradient inside conv2's backward kernel, gn1 never stored
         # W2S_GRAD_FP16=1: fp16 storage (one power-of-two scale per tensor, fp32 arithmetic) of the gradient tensors between the fused-backward
         # launches of the <= 32-channel blocks.  Measured round 3, full suite green with it: -14 GB of traffic,
@@ -226,25 +223,6 @@ class Engine:
         lib.stats_finalize(part, B, ntiles, C, count, self.spec.instance_eps, kind, out)
         return out
 
-    def _fin(self, B, C, dev, rows):
-        """(stat_out, stat_cnt, row scratch) of an in-kernel statistics finalisation with `rows` rows per sample (0 / disabled: three Nones):
-        the producer's workgroups leave per-run rows in the scratch and the one that draws a sample's last ticket reduces them, so no
-        w2s_stats_finalize launch sits between two layers.  One self-re-arming counter buffer per stream and batch size."""
-        if not self.fused_finalize or rows <= 0:
-            return None, None, None
-        key = (torch.cuda.current_stream(dev).cuda_stream, B)
-        cnt = self._cnt.get(key)
-        if cnt is None:
-            cnt = self._cnt[key] = torch.zeros(B, device=dev, dtype=torch.int32)
-        return (torch.empty(B, C, 2, device=dev, dtype=torch.float32), cnt,
-                torch.empty(B * rows * 2 * C * 2, device=dev, dtype=torch.float64))
-
-    @staticmethod
-    def _row_tile(L, tile):
-        """tile of a tile-per-workgroup statistics kernel (w2s_gp_stats, the Cin = 1 kernels) when it finalises in the kernel: every
-        workgroup is one row of its sample, so at most 64 of them per sample (a multiple of the requested tile)"""
-        return max(tile, _cdiv(_cdiv(L, 64), tile) * tile)
-
     def _conv(self, **kw):
         planes = self._bf.get(kw['w'].data_ptr()) if self.split_precision else None
         if planes is not None:
@@ -252,19 +230,13 @@ class Engine:
         lib.conv_forward(lib.conv_args(**kw))
 
     def _conv_part(self, *, B, L_out, cout, kind, **kw):
-        """A conv launch that also produces instance-norm statistics: asks the library which kernel takes THIS descriptor -- the persistent
-        wide kernel finalises them itself (row scratch), the generic kernel leaves per-tile partials for w2s_stats_finalize.
-        -> finalised statistics [B][cout][2] (kind 0: mean/rstd, 1: backward sums)."""
+        """A conv launch that also produces instance-norm statistics (per-tile partials, sized by the tile of the kernel that takes THIS
+        descriptor) -> finalised statistics [B][cout][2] (kind 0: mean/rstd, 1: backward sums)."""
         planes = self._bf.get(kw['w'].data_ptr()) if self.split_precision else None
         if planes is not None:
             kw['w_hi'], kw['w_lo'] = planes
         dev = kw['x'].device
-        a = lib.conv_args(B=B, L_out=L_out, cout=cout, part=None, stat_eps=self.spec.instance_eps, **kw)
-        so, sc, rows = self._fin(B, cout, dev, lib.conv_stat_rows(a) if self.fused_finalize else 0)
-        if so is not None:
-            a = lib.conv_args(B=B, L_out=L_out, cout=cout, part=rows, stat_out=so, stat_cnt=sc, stat_eps=self.spec.instance_eps, **kw)
-            lib.conv_forward(a)
-            return so
+        a = lib.conv_args(B=B, L_out=L_out, cout=cout, part=None, **kw)
         nt = _cdiv(L_out, lib.conv_tile_of(a))
         part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
         lib.set_part(a, part)
@@ -280,11 +252,10 @@ class Engine:
             # <= 32 channels: persistent split-precision forward kernel (prefetch + LDS-resident weights)
             nt = _cdiv(L_out, ftile)
             nwg = _FWD_WGS16 if cin == 16 else _FWD_WGS
-            so, sc, rows = self._fin(B, cout, dev, lib.stat_rows(B, nt, min(nwg, B * nt)))
-            part = rows if so is not None else torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
+            part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
             lib.conv_fwd_fused(x=x, w=w, st_in=pro_stats, w1=x2, y=y, part=part, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, stride=stride,
-                               pro=pro, pad=self.kpad, nwg=nwg, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps)
-            return y, (so if so is not None else self._finalize(part, B, nt, cout, L_out, 0))
+                               pro=pro, pad=self.kpad, nwg=nwg)
+            return y, self._finalize(part, B, nt, cout, L_out, 0)
         return y, self._conv_part(x=x, x2=x2, w=w, y=y, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=3, stride=stride, pad=self.kpad, pro=pro,
                                   pro_stats=pro_stats, epi=lib.EPI_STATS, kind=0, **({'ldx': 4} if pro == lib.PRO_FIRST else {}))
 
@@ -335,12 +306,11 @@ class Engine:
         nslab = max(1, min(B * nt, _BWD_WGS_RD16 if (cg == 16 and ch == 16 and gpre is not None) else _BWD_WGS32 if (cg == 32 and ch == 32) else _BWD_WGS))
         slab = self._slab(dev, nslab, cg * ch * 3)
         slab_d = self._slab(dev, nslab, cg * ch) if gpre is not None else None
-        so, sc, rows = self._fin(B, ch, dev, lib.stat_rows(B, nt, nslab)) if (want_part and not gmode) else (None, None, None)
-        part = (rows if so is not None else torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32)) if want_part else None
+        part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         part_wd = torch.empty(nslab, 16, device=dev, dtype=torch.float32) if x0 is not None else None   # block 0's downsample weight gradient (down0)
         lib.bwd_fused(g=g, y=y, st_k=st_k, bst_k=bst_k, pro=pro, xin=xin, st_in=st_in, add_even=add_even, wb=self.PB[name], gout=gout,
                       part=part, slab=slab, nslab=nslab, B=B, Lg=Lg, Lh=Lh, cg=cg, ch=ch, stride=stride, pad=self.kpad, split_precision=self.split_precision,
-                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1, y3p=y3p, st3p=st3p, stat_out=so, stat_cnt=sc,
+                      gpre=gpre, wd=self.PB[down] if gpre is not None else None, slab_d=slab_d, w1=w1, y3p=y3p, st3p=st3p,
                       gmode=gmode, hdr_g=hdr_g, hdr_p=hdr_p, hdr_o=hdr_o, part_w1=part_w1, x0=x0, part_wd=part_wd)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
@@ -352,7 +322,7 @@ class Engine:
             self._written.add(down0)
         if not want_part:
             return None
-        return so if so is not None else self._bstats(part, B, nt, ch, Lh)
+        return self._bstats(part, B, nt, ch, Lh)
 
     def _bwd_wide_ok(self, B, L, cg, ch, stride=1, hst=True):
         """the one-pass backward of a 64-channel conv (csrc/bwd_wide.hip): split precision, symmetric padding; L = input-side length"""
@@ -366,21 +336,17 @@ class Engine:
         nt = _cdiv(L, tile)
         nslab = max(1, min(B * nt, 256))   # one workgroup per CU (LDS)
         slab = self._slab(dev, nslab, cg * ch * 3)
-        so, sc, rows = self._fin(B, ch, dev, lib.stat_rows(B, nt, nslab) * groups) if want_part else (None, None, None)
-        part = (rows if so is not None else torch.empty(B, nt * groups, 2, ch, device=dev, dtype=torch.float32)) if want_part else None
+        part = torch.empty(B, nt * groups, 2, ch, device=dev, dtype=torch.float32) if want_part else None
         wh, wl = self._bf[self.PB[name].data_ptr()]
         dh, dl = self._bf[self.PB[down].data_ptr()] if gpre is not None else (None, None)
         slab_d = self._slab(dev, nslab, cg * ch) if gpre is not None else None
         lib.bwd_wide(g=g, y=y, st_k=st_k, bst_k=bst_k, xin=xin, st_in=st_in, add_even=add_even, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab,
-                     nslab=nslab, B=B, L=L, cg=cg, ch=ch, stride=stride, y3p=y3p, st3p=st3p, gpre=gpre, wd_hi=dh, wd_lo=dl, slab_d=slab_d,
-                     stat_out=so, stat_cnt=sc)
+                     nslab=nslab, B=B, L=L, cg=cg, ch=ch, stride=stride, y3p=y3p, st3p=st3p, gpre=gpre, wd_hi=dh, wd_lo=dl, slab_d=slab_d)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         if gpre is not None:
             self._rjobs.append((slab_d, nslab, self.G[down], cg, ch, 1, 1, down in self._written, 0))
             self._written.add(down)
-        if so is not None:
-            return so
         return self._bstats(part, B, nt * groups, ch, L) if want_part else None
 
     def _colsum(self, part, nparts, C, out, accumulate=False, ld=None):
@@ -474,16 +440,15 @@ class Engine:
         recompute = self.split_precision and self.taps is None and c == 16
         w1 = P[pfx + 'cnn.0.conv1.conv.weight']
         y1 = None if recompute else torch.empty(B, L, c, device=dev, dtype=torch.float32)
-        ft = self._row_tile(L, FIRST_TILE) if self.fused_finalize else FIRST_TILE   # (in-kernel finalisation: one row per workgroup, <= 64 per sample)
+        ft = FIRST_TILE
         nt = _cdiv(L, ft)
-        so, sc, rows = self._fin(B, c, dev, nt)
-        part = rows if so is not None else torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
+        part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
         xmom = torch.empty(B, nt, 9, device=dev, dtype=torch.float32) if (recompute and save and self.fold_w1) else None
         if xmom is not None:   # (the signal's raw moments per tile: what the folded first-layer weight gradient needs in backward)
-            lib.enc_first_stats(x, w1, part, xmom, B, L, ft, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps, causal=self.causal)
+            lib.enc_first_stats(x, w1, part, xmom, B, L, ft, causal=self.causal)
         else:
-            lib.enc_first_fwd(x, w1, y1, part, B, L, c, ft, stat_out=so, stat_cnt=sc, eps=self.spec.instance_eps, causal=self.causal)
-        st1 = so if so is not None else self._finalize(part, B, nt, c, L, 0)
+            lib.enc_first_fwd(x, w1, y1, part, B, L, c, ft, causal=self.causal)
+        st1 = self._finalize(part, B, nt, c, L, 0)
         if recompute:
             y2, st2 = self._conv_stats(x=x, x2=w1, w=PF[pfx + 'cnn.0.conv2.conv.weight'], B=B, L_in=L, L_out=L, cin=c, cout=c, stride=1,
                                        pro=lib.PRO_FIRST, pro_stats=st1)
@@ -1133,13 +1098,10 @@ class Engine:
                     lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile, hdr_g=gpre_hdr if ghalf else None, hdr_amax=None if ghalf else gpre_hdr)
                     bs3 = self._bstats(part, B, nt, c, Lh)
                 else:
-                    if self.fused_finalize:
-                        tile = self._row_tile(Lh, tile)
                     nt = _cdiv(Lh, tile)
-                    so, sc, rows = self._fin(B, c, dev, nt)
-                    part = rows if so is not None else torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
-                    lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile, stat_out=so, stat_cnt=sc)
-                    bs3 = so if so is not None else self._bstats(part, B, nt, c, Lh)
+                    part = torch.empty(B, nt, 2, c, device=dev, dtype=torch.float32)
+                    lib.gp_stats(gpre, blk['y3'], blk['st3'], part, B, Lh, c, tile)
+                    bs3 = self._bstats(part, B, nt, c, Lh)
             # block 0 in the first-layer recompute flow: conv1's weight gradient rides in conv2's backward kernel (per-tile sums of gn1 x signal
             # taps), so gn1 -- which only that weight gradient would read -- is never stored (fp32 chain, split-precision kernels)
             fold_w1 = (i == 0 and blk['y1'] is None and ec.get('xmom') is not None and not h16 and self.split_precision and c == 16

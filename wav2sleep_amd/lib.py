@@ -28,9 +28,9 @@ _i32 = C.c_int32
 
 class ConvArgs(C.Structure):
     _fields_ = [(n, _fp) for n in ('x', 'x2', 'w', 'y', 'y2', 'pro_stats', 'pro_bstats', 'aux', 'aux_stats', 'add_even', 'bias',
-                                   'rowkeep', 'part', 'w_hi', 'w_lo', 'stat_out', 'stat_cnt')] + \
+                                   'rowkeep', 'part', 'w_hi', 'w_lo')] + \
                [(n, _i32) for n in ('B', 'L_in', 'L_out', 'cin', 'cout', 'taps', 'stride', 'dil', 'pad', 'flip', 'mode',
-                                    'ldx', 'ldy', 'ldy2', 'ld_aux', 'pro', 'epi')] + [('stat_eps', C.c_float), ('reserved', _i32), ('drop_p', C.c_float),
+                                    'ldx', 'ldy', 'ldy2', 'ld_aux', 'pro', 'epi')] + [('reserved', _i32), ('drop_p', C.c_float),
                                                                                             ('drop_seed', C.c_uint64)]
 
 
@@ -53,7 +53,7 @@ class WgradArgs(C.Structure):
 
 
 EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
-           'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_bwd_fused_wd', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_stat_rows', 'w2s_conv_stat_rows', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
+           'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_bwd_fused_wd', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_token_masks', 'w2s_cls_scatter', 'w2s_copy_rows', 'w2s_zero', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version', 'w2s_abi_version']
@@ -146,32 +146,18 @@ def _f(t):
 
 
 def _fp(t):
-    """the `part` argument of a statistics producer: fp32 per-tile partials, or (with stat_out) the fp64 row scratch of the in-kernel
-    finalisation (include/w2s.h "In-kernel finalisation")"""
-    assert t is None or t.dtype in (torch.float32, torch.float64), 'fp32 partials or fp64 row scratch'
-    return _p(t)
+    """the `part` argument of a statistics producer: fp32 per-tile partial sums"""
+    return _f(t)
 
 
-def stat_rows(B, ntiles, grid) -> int:
-    """rows per sample of the row scratch [B][rows][2][C][2] (fp64) of a persistent producer that runs `grid` workgroups over B * ntiles tiles"""
-    return load().w2s_stat_rows(B, ntiles, grid)
-
-
-def conv_stat_rows(a: 'ConvArgs') -> int:
-    """rows per sample of the row scratch conv_forward(a) needs with stat_out set; 0 = that kernel has no in-kernel finalisation"""
-    return load().w2s_conv_stat_rows(C.byref(a))
-
-
-# ------------------------------------------------------------------------------------------------
 def conv_args(*, x, w, y, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, flip=0, mode=MODE_CONTIG, ldx=None, ldy=None,
               pro=PRO_NONE, epi=EPI_PLAIN, x2=None, pro_stats=None, pro_bstats=None, aux=None, aux_stats=None, add_even=None,
-              bias=None, rowkeep=None, part=None, y2=None, ldy2=0, ld_aux=0, w_hi=None, w_lo=None, stat_out=None, stat_cnt=None,
-              stat_eps=1e-2, accumulate=False, fuse=0, drop_p=0.0, drop_seed=0) -> ConvArgs:
+              bias=None, rowkeep=None, part=None, y2=None, ldy2=0, ld_aux=0, w_hi=None, w_lo=None,
+              accumulate=False, fuse=0, drop_p=0.0, drop_seed=0) -> ConvArgs:
     a = ConvArgs()
     a.reserved = (1 if accumulate else 0) | fuse   # fuse: FUSE_* bits (EPI_BIAS only)
     a.drop_p, a.drop_seed = drop_p, drop_seed
     a.w_hi, a.w_lo = _p(w_hi), _p(w_lo)
-    a.stat_out, a.stat_cnt, a.stat_eps = _f(stat_out), _p(stat_cnt), stat_eps
     a.x, a.x2, a.w, a.y, a.y2 = _f(x), _f(x2), _f(w), _f(y), _f(y2)
     a.pro_stats, a.pro_bstats, a.aux, a.aux_stats = _f(pro_stats), _f(pro_bstats), _f(aux), _f(aux_stats)
     a.add_even, a.bias, a.rowkeep, a.part = _f(add_even), _f(bias), _f(rowkeep), _fp(part)
@@ -333,10 +319,9 @@ def conv_fwd_fused_tile(cin, cout, stride) -> int:
     return load().w2s_conv_fwd_fused_tile(cin, cout, stride)
 
 
-def conv_fwd_fused(*, x, w, st_in, w1, y, part, B, L_in, L_out, cin, cout, stride, pro, nwg, pad=1, stat_out=None, stat_cnt=None, eps=1e-2):
+def conv_fwd_fused(*, x, w, st_in, w1, y, part, B, L_in, L_out, cin, cout, stride, pro, nwg, pad=1):
     def run():
-        _chk(load().w2s_conv_fwd_fused(_f(x), _f(w), _f(st_in), _f(w1), _f(y), _fp(part), B, L_in, L_out, cin, cout, stride, pad, pro, nwg, _f(stat_out),
-                                       _p(stat_cnt), C.c_float(eps), _stream()),
+        _chk(load().w2s_conv_fwd_fused(_f(x), _f(w), _f(st_in), _f(w1), _f(y), _fp(part), B, L_in, L_out, cin, cout, stride, pad, pro, nwg, _stream()),
              f'w2s_conv_fwd_fused(cin={cin},cout={cout},stride={stride},pro={pro})')
     nbytes = 4 * (B * L_in * (1 if pro == PRO_FIRST else cin) + B * L_out * cout)
     mt = (conv_fwd_fused_tile(cin, cout, stride) + 2) // 64   # tiles are 64*MT - 2 (stride 1) or - 1 (stride 2) positions
@@ -364,7 +349,7 @@ def _h(t):
 
 
 def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, slab, nslab, B, Lg, Lh, cg, ch, stride, split_precision=False, pad=1,
-              gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None, stat_out=None, stat_cnt=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None,
+              gpre=None, wd=None, slab_d=None, w1=None, y3p=None, st3p=None, gmode=0, hdr_g=None, hdr_p=None, hdr_o=None,
               part_w1=None, x0=None, part_wd=None):
     """part_w1 (conv2 of block 0, w1 given): also leave the first layer's weight-gradient partials; gout may then be None.
     gmode 1 / 2: the fp16 gradient chain (include/w2s.h): gout (and, gmode 2, g / gpre) are fp16 tensors with the headers hdr_*."""
@@ -379,14 +364,14 @@ def bwd_fused(*, g, y, st_k, bst_k, pro, xin, st_in, add_even, wb, gout, part, s
             return
         if part_wd is not None:
             _chk(load().w2s_bwd_fused_wd(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(wb), _f(gout), _fp(part), _f(slab), nslab, B, Lh, pad, _f(gpre), _f(wd),
-                                         _f(slab_d), _f(y3p), _f(st3p), _f(x0), _f(part_wd), _f(stat_out), _p(stat_cnt), _stream()), 'w2s_bwd_fused_wd')
+                                         _f(slab_d), _f(y3p), _f(st3p), _f(x0), _f(part_wd), _stream()), 'w2s_bwd_fused_wd')
             return
         if part_w1 is not None:
             _chk(load().w2s_bwd_fused_w1(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(st_in), _f(wb), _f(gout), _fp(part), _f(part_w1), _f(slab), nslab, B, Lh,
-                                         pad, _f(w1), _f(stat_out), _p(stat_cnt), _stream()), 'w2s_bwd_fused_w1')
+                                         pad, _f(w1), _stream()), 'w2s_bwd_fused_w1')
             return
         _chk(load().w2s_bwd_fused(_f(g), _f(y), _f(st_k), _f(bst_k), pro, _f(xin), _f(st_in), _f(add_even), _f(wb), _f(gout), _fp(part),
-                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, pad, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p), _f(stat_out), _p(stat_cnt), _stream()),
+                                  _f(slab), nslab, B, Lg, Lh, cg, ch, stride, pad, int(bool(split_precision)), _f(gpre), _f(wd), _f(slab_d), _f(w1), _f(y3p), _f(st3p), _stream()),
              f'w2s_bwd_fused(cg={cg},ch={ch},stride={stride})')
     wg, wo = (2 if gmode == 2 else 4), (2 if gmode else 4)   # bytes per stored gradient element in / out
     nbytes = (B * Lg * cg * (wg + 4) + (B * Lh * (4 * 1 + (wo * ch if gout is not None else 0)) if w1 is not None else B * Lh * ch * (4 + wo)) + (4 * B * Lh * ch // 2 if add_even is not None else 0)
@@ -415,14 +400,14 @@ def bwd_wide_takes(B, L, cg, ch, stride=1, hst=True, rd=False) -> bool:
     rd: with the residual branch folded in (gpre given)."""
     one = C.c_void_p(1)
     return load().w2s_bwd_wide(None, None, None, None, None, one if hst else None, None, None, None, None, None, None, 0, B, L, cg, ch, stride,
-                               None, None, one if rd else None, None, None, None, None, None, 1, None) == 0
+                               None, None, one if rd else None, None, None, None, 1, None) == 0
 
 
 def bwd_wide(*, g, y, st_k, bst_k, xin, st_in, add_even, w_hi, w_lo, gout, part, slab, nslab, B, L, cg, ch, stride=1, y3p=None, st3p=None,
-             gpre=None, wd_hi=None, wd_lo=None, slab_d=None, stat_out=None, stat_cnt=None):
+             gpre=None, wd_hi=None, wd_lo=None, slab_d=None):
     def run():
         _chk(load().w2s_bwd_wide(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(st_in), _f(add_even), _p(w_hi), _p(w_lo), _f(gout), _fp(part), _f(slab), nslab,
-                                 B, L, cg, ch, stride, _f(y3p), _f(st3p), _f(gpre), _p(wd_hi), _p(wd_lo), _f(slab_d), _f(stat_out), _p(stat_cnt), 0, _stream()),
+                                 B, L, cg, ch, stride, _f(y3p), _f(st3p), _f(gpre), _p(wd_hi), _p(wd_lo), _f(slab_d), 0, _stream()),
              f'w2s_bwd_wide(cg={cg},ch={ch},stride={stride})')
     nbytes = 4 * (2 * B * (L // stride) * cg + 2 * B * L * ch + (B * L * ch // 2 if add_even is not None else 0) + (B * L * ch if y3p is not None else 0)
                   + (B * L * cg // 2 if gpre is not None else 0))
@@ -494,8 +479,8 @@ def stats_finalize(part, B, ntiles, Cc, count, eps, kind, out):
     _chk(load().w2s_stats_finalize(_f(part), B, ntiles, Cc, C.c_long(count), C.c_float(eps), kind, _f(out), _stream()), 'w2s_stats_finalize')
 
 
-def enc_first_fwd(x, w, y, part, B, L, cout, tile, stat_out=None, stat_cnt=None, eps=1e-2, causal=False):
-    _chk(load().w2s_enc_first_fwd(_f(x), _f(w), _f(y), _fp(part), B, L, cout, tile, _f(stat_out), _p(stat_cnt), C.c_float(eps), int(causal), _stream()),
+def enc_first_fwd(x, w, y, part, B, L, cout, tile, causal=False):
+    _chk(load().w2s_enc_first_fwd(_f(x), _f(w), _f(y), _fp(part), B, L, cout, tile, int(causal), _stream()),
          'w2s_enc_first_fwd')
 
 
@@ -516,8 +501,8 @@ def enc_first_wgrad(xmom, ntx, w1, part_w1, stats1, bstats1, out, B, ntiles):
     _chk(load().w2s_enc_first_wgrad(_f(xmom), ntx, _f(w1), _f(part_w1), _f(stats1), _f(bstats1), _f(out), B, ntiles, _stream()), 'w2s_enc_first_wgrad')
 
 
-def enc_first_stats(x, w, part, xmom, B, L, tile, stat_out=None, stat_cnt=None, eps=1e-2, causal=False):
-    _chk(load().w2s_enc_first_stats(_f(x), _f(w), _fp(part), _f(xmom), B, L, tile, _f(stat_out), _p(stat_cnt), C.c_float(eps), int(causal), _stream()),
+def enc_first_stats(x, w, part, xmom, B, L, tile, causal=False):
+    _chk(load().w2s_enc_first_stats(_f(x), _f(w), _fp(part), _f(xmom), B, L, tile, int(causal), _stream()),
          'w2s_enc_first_stats')
 
 
@@ -525,14 +510,14 @@ def enc_first_dwd(x, gpre, slab, nslab, B, L):
     _chk(load().w2s_enc_first_dwd(_f(x), _f(gpre), _f(slab), nslab, B, L, _stream()), 'w2s_enc_first_dwd')
 
 
-def gp_stats(g, y, stats, part, B, L, Cc, tile, stat_out=None, stat_cnt=None, hdr_g=None, hdr_amax=None):
+def gp_stats(g, y, stats, part, B, L, Cc, tile, hdr_g=None, hdr_amax=None):
     """hdr_g: g is an fp16 chain tensor with that header; hdr_amax (fp32 g): also publish {1, max |g|} there (the chain's entry)."""
     if hdr_g is not None or hdr_amax is not None:
         half = g.dtype == torch.float16
         _chk(load().w2s_gp_stats_h(_h(g) if half else _f(g), int(half), _f(hdr_g), _f(hdr_amax), _f(y), _f(stats), _f(part), B, L, Cc, tile, _stream()),
              'w2s_gp_stats_h')
         return
-    _chk(load().w2s_gp_stats(_f(g), _f(y), _f(stats), _fp(part), B, L, Cc, tile, _f(stat_out), _p(stat_cnt), _stream()), 'w2s_gp_stats')
+    _chk(load().w2s_gp_stats(_f(g), _f(y), _f(stats), _fp(part), B, L, Cc, tile, _stream()), 'w2s_gp_stats')
 
 
 def layernorm_fwd(x, ldx, gamma, beta, y, ldy, rstat, rows, Cc, eps, gelu=False):
