@@ -320,9 +320,12 @@ int w2s_zero(void* p, long nbytes, void* stream);   /* nbytes % 4 == 0 */
 int w2s_eltwise(int op, const float* a, const float* b, float* y, long n, float p_drop, uint64_t seed, void* stream);
 
 /* ---- set-fusion attention core: SDPA inside nn.MultiheadAttention (wav2sleep.py:286-296), D = 1+C tokens (2..7),
- * head_dim 16, qkv [N*D][3*H*16], keypad [N][D] (1 = missing modality), out [N*D][H*16] ---- */
-int w2s_attn_fwd(const float* qkv, const uint8_t* keypad, float* out, int N, int D, int H, float p_drop, uint64_t seed, void* stream);
-int w2s_attn_bwd(const float* qkv, const uint8_t* keypad, const float* gout, float* gqkv, int N, int D, int H, float p_drop, uint64_t seed, void* stream);
+ * head_dim 16, qkv [N*D][3*H*16], keypad [N][D] (1 = missing modality), out [N*D][H*16].  nq = D, or 1: only token 0 of every epoch is a
+ * QUERY (the last layer of the stack: wav2sleep.py:345 returns the CLS token alone) -- the other out rows are not written, and the
+ * backward reads gout row 0 only and writes zeros to the other rows' query gradients ---- */
+int w2s_attn_fwd(const float* qkv, const uint8_t* keypad, float* out, int N, int D, int H, int nq, float p_drop, uint64_t seed, void* stream);
+int w2s_attn_bwd(const float* qkv, const uint8_t* keypad, const float* gout, float* gqkv, int N, int D, int H, int nq, float p_drop, uint64_t seed,
+                 void* stream);
 
 /* ---- classifier (wav2sleep.py:41,66), masked cross-entropy + confusion matrix (trainer/main.py:162-172) ---- */
 int w2s_head_fwd(const float* pre, int ld, const float* w, const float* bias, float* logits, int rows, int F, int nc, int gelu_in, void* stream);

@@ -379,6 +379,18 @@ def t_attn():
     gq = torch.zeros(N * D, 3 * Fd, device=dev)
     lib.attn_bwd(qkv.detach().to(dev), kp, go.to(dev), gq, N, D, H)
     report('attn bwd', gq, qkv.grad)
+    # token 0 as the only query (nq = 1; the last layer of the stack): its output row as before, the other rows untouched; backward = the full
+    # kernel on a gradient that is zero off the CLS rows, with dropout on (same counter-based masks in both)
+    for pdrop in (0.0, 0.1):
+        full = torch.zeros(N * D, Fd, device=dev); lib.attn_fwd(qkv.detach().to(dev), kp, full, N, D, H, pdrop, 77)
+        o1 = torch.full((N * D, Fd), 7.0, device=dev); lib.attn_fwd(qkv.detach().to(dev), kp, o1, N, D, H, pdrop, 77, nq=1)
+        RES.append((f'attn fwd nq=1 p={pdrop}: CLS rows bit-equal, other rows untouched',
+                    torch.equal(o1.view(N, D, Fd)[:, 0], full.view(N, D, Fd)[:, 0]) and bool((o1.view(N, D, Fd)[:, 1:] == 7.0).all())))
+        gcls = torch.zeros(N, D, Fd, device=dev); gcls[:, 0] = go.view(N, D, Fd)[:, 0].to(dev)
+        g_full = torch.zeros(N * D, 3 * Fd, device=dev); lib.attn_bwd(qkv.detach().to(dev), kp, gcls.view(N * D, Fd), g_full, N, D, H, pdrop, 77)
+        gcls[:, 1:] = float('nan')   # nq = 1 must not read the other rows
+        g1 = torch.full((N * D, 3 * Fd), float('nan'), device=dev); lib.attn_bwd(qkv.detach().to(dev), kp, gcls.view(N * D, Fd), g1, N, D, H, pdrop, 77, nq=1)
+        RES.append((f'attn bwd nq=1 p={pdrop}: equals the full kernel on a CLS-only gradient', torch.equal(g1, g_full)))
 
 def t_head_optim():
     rows, Fd, nc = 700, 128, 5

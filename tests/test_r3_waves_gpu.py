@@ -90,7 +90,9 @@ def test_wave_step_equals_one_pass_step(signal_map, nc, B, S, missing, waves, ca
         if scale == 0.0:
             assert float(g2.abs().max()) == 0.0, k
             continue
-        assert float((g1 - g2).abs().max()) <= 2e-5 * scale, (k, float((g1 - g2).abs().max()), scale)
+        # (fp32 accumulation order: the waves cut the (sample, tile) list differently, so other workgroups sum other tiles -- measured up to
+        #  2.3e-5 of the tensor's scale in the chunk-causal case, whose 'samples' are single epochs)
+        assert float((g1 - g2).abs().max()) <= 4e-5 * scale, (k, float((g1 - g2).abs().max()), scale)
     # (the parameters after the step are not compared element-wise: AdamW's first update is lr * sign(g) wherever |g| >> eps, so a gradient
     # that is zero to rounding may move its weight by +-lr in either run; the goldens test above bounds the parameters after two steps)
 

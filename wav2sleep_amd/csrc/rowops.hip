@@ -400,7 +400,7 @@ extern "C" int w2s_eltwise(int op, const float* a, const float* b, float* y, lon
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ keypad,
-                                                       float* __restrict__ out, int N, int H, float p, uint64_t seed) {
+                                                       float* __restrict__ out, int N, int H, int nq, float p, uint64_t seed) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t pair = gid >> 4;  // (n, h)
   const int e = threadIdx.x & 15;
@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int dq = 0; dq < D; ++dq) {
+    if (dq >= nq) break;   // (uniform) nq = 1: only token 0's output is read downstream (the last layer: wav2sleep.py:345 returns the CLS token)
     float s[D];
     float mx = -INFINITY;
 #pragma unroll
@@ -441,8 +442,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ keypad,
-                                                       const float* __restrict__ gout, float* __restrict__ gqkv, int N, int H, float p,
-                                                       uint64_t seed) {
+                                                       const float* __restrict__ gout, float* __restrict__ gqkv, int N, int H, int nq,
+                                                       float p, uint64_t seed) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t pair = gid >> 4;
   const int e = threadIdx.x & 15;
@@ -461,6 +462,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int dq = 0; dq < D; ++dq) {
+    if (dq >= nq) {   // (uniform) a token whose output nobody read: its query gets no gradient and it adds nothing to the keys / values
+      gqkv[((size_t)n * D + dq) * ld + h * 16 + e] = 0.f;
+      continue;
+    }
     float pr[D], dp[D];
     float mx = -INFINITY;
 #pragma unroll
@@ -515,21 +520,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     default: return W2S_EINVAL;   /* 2 .. 12 tokens: six signals + CLS + five register tokens is all the reference's maps can ask for */ \
   }
 
-extern "C" int w2s_attn_fwd(const float* qkv, const uint8_t* keypad, float* out, int N, int D, int H, float p_drop, uint64_t seed,
+extern "C" int w2s_attn_fwd(const float* qkv, const uint8_t* keypad, float* out, int N, int D, int H, int nq, float p_drop, uint64_t seed,
                             void* stream) {
-  if (!qkv || !keypad || !out || N <= 0 || H <= 0) return W2S_EINVAL;
+  if (!qkv || !keypad || !out || N <= 0 || H <= 0 || (nq != D && nq != 1)) return W2S_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned blocks = (unsigned)(((size_t)N * H * 16 + 255) / 256);
-  W2S_ATTN_DISPATCH(attn_fwd_kernel, qkv, keypad, out, N, H, p_drop, seed)
+  W2S_ATTN_DISPATCH(attn_fwd_kernel, qkv, keypad, out, N, H, nq, p_drop, seed)
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
-extern "C" int w2s_attn_bwd(const float* qkv, const uint8_t* keypad, const float* gout, float* gqkv, int N, int D, int H, float p_drop,
+extern "C" int w2s_attn_bwd(const float* qkv, const uint8_t* keypad, const float* gout, float* gqkv, int N, int D, int H, int nq, float p_drop,
                             uint64_t seed, void* stream) {
-  if (!qkv || !keypad || !gout || !gqkv || N <= 0 || H <= 0) return W2S_EINVAL;
+  if (!qkv || !keypad || !gout || !gqkv || N <= 0 || H <= 0 || (nq != D && nq != 1)) return W2S_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned blocks = (unsigned)(((size_t)N * H * 16 + 255) / 256);
-  W2S_ATTN_DISPATCH(attn_bwd_kernel, qkv, keypad, gout, gqkv, N, H, p_drop, seed)
+  W2S_ATTN_DISPATCH(attn_bwd_kernel, qkv, keypad, gout, gqkv, N, H, nq, p_drop, seed)
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

@@ -600,12 +600,13 @@ class Engine:
             rs1 = torch.empty(R, 2, device=dev, dtype=torch.float32)
             lib.layernorm_fwd(X, F, P[p + 'norm1.weight'], P[p + 'norm1.bias'], h, F, rs1, R, F, sp.layer_eps)
             qkv = self._linear(h, P[p + 'self_attn.in_proj_weight'], P[p + 'self_attn.in_proj_bias'], R, F, 3 * F)
-            ao = torch.empty(R, F, device=dev, dtype=torch.float32)
-            lib.attn_fwd(qkv, keypad, ao, N, D, sp.mixer_nhead, pm, self._seed(10 * l + 1))
             # Only token 0 of the LAST layer's output is read (wav2sleep.py:345 returns the CLS token): behind that layer's attention, every
             # row-wise op -- out_proj, the residual adds, norm2, the feed-forward block -- runs on the N CLS rows instead of all N x D token
-            # rows (row stride D*F in, compact [N][F] out); the other tokens' outputs were never used and their gradients are exactly zero
+            # rows (row stride D*F in, compact [N][F] out); the other tokens' outputs were never used and their gradients are exactly zero.
+            # Round 5: so is the attention itself -- token 0 is the only QUERY of that layer (keys and values still come from every token)
             cls = _CLS_ONLY and l == sp.mixer_layers - 1 and D > 1
+            ao = torch.empty(R, F, device=dev, dtype=torch.float32)
+            lib.attn_fwd(qkv, keypad, ao, N, D, sp.mixer_nhead, pm, self._seed(10 * l + 1), nq=1 if cls else D)
             Rr, ldr = (N, D * F) if cls else (R, F)
             # x + Dropout(out_proj(attention)): the residual add and the dropout ride in the projection's epilogue (no `proj` tensor)
             X1 = self._linear(ao, P[p + 'self_attn.out_proj.weight'], P[p + 'self_attn.out_proj.bias'], Rr, F, F, ldx=ldr, fuse=lib.FUSE_ADD_DROP, aux=X,
@@ -836,7 +837,7 @@ class Engine:
             else:
                 gao = self._linear(gproj, PB[p + 'self_attn.out_proj.weight'], None, R, F, F)
             gqkv = torch.empty(R, 3 * F, device=dev, dtype=torch.float32)
-            lib.attn_bwd(L['qkv'], c['keypad'], gao, gqkv, N, D, sp.mixer_nhead, pm, self._seed(10 * l + 1))
+            lib.attn_bwd(L['qkv'], c['keypad'], gao, gqkv, N, D, sp.mixer_nhead, pm, self._seed(10 * l + 1), nq=1 if cls else D)
             self._colgrad(p + 'self_attn.in_proj_bias', gqkv, R, 3 * F)
             self._wgrad(p + 'self_attn.in_proj_weight', g=gqkv, x=L['h'], B=1, L_in=R, L_out=R, cin=F, cout=3 * F, taps=1, stride=1, pad=0)
             gh = self._linear(gqkv, PB[p + 'self_attn.in_proj_weight'], None, R, 3 * F, F)

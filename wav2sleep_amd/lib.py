@@ -590,12 +590,12 @@ def eltwise(op, a, b, y, n, p=0.0, seed=0):
     _chk(load().w2s_eltwise(op, _f(a), _f(b), _f(y), C.c_long(n), C.c_float(p), C.c_uint64(seed), _stream()), 'w2s_eltwise')
 
 
-def attn_fwd(qkv, keypad, out, N, D, H, p=0.0, seed=0):
-    _chk(load().w2s_attn_fwd(_f(qkv), _p(keypad), _f(out), N, D, H, C.c_float(p), C.c_uint64(seed), _stream()), 'w2s_attn_fwd')
+def attn_fwd(qkv, keypad, out, N, D, H, p=0.0, seed=0, nq=None):
+    _chk(load().w2s_attn_fwd(_f(qkv), _p(keypad), _f(out), N, D, H, D if nq is None else nq, C.c_float(p), C.c_uint64(seed), _stream()), 'w2s_attn_fwd')
 
 
-def attn_bwd(qkv, keypad, gout, gqkv, N, D, H, p=0.0, seed=0):
-    _chk(load().w2s_attn_bwd(_f(qkv), _p(keypad), _f(gout), _f(gqkv), N, D, H, C.c_float(p), C.c_uint64(seed), _stream()), 'w2s_attn_bwd')
+def attn_bwd(qkv, keypad, gout, gqkv, N, D, H, p=0.0, seed=0, nq=None):
+    _chk(load().w2s_attn_bwd(_f(qkv), _p(keypad), _f(gout), _f(gqkv), N, D, H, D if nq is None else nq, C.c_float(p), C.c_uint64(seed), _stream()), 'w2s_attn_bwd')
 
 
 def head_fwd(pre, ld, w, bias, logits, rows, F, nc, gelu_in):
