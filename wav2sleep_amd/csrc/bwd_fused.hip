@@ -395,8 +395,8 @@ void bwd_fused_bf_kernel(BwdP P) {
   // pair per plane and 4 elements.  Without them the 16 -> 16 kernels hold 31 KB and the register file sets the occupancy.
   // HLO: the lo plane of h = GELU(n), which only the weight gradient reads (dW = gy * h: gy_hi h_hi + gy_lo h_hi [+ gy_hi h_lo]).
   constexpr bool HLO = W2S_BF_HLO != 0;
-  float* red = reinterpret_cast<float*>(smem4);             // [2][4][CH][4][8] stats scratch, double-buffered (see `flush_stats`)
-  __bf16* gyH = reinterpret_cast<__bf16*>(red + 2 * bwd_redn(CH));
+  float* red = reinterpret_cast<float*>(smem4);             // [4][CH][4][8] stats scratch
+  __bf16* gyH = reinterpret_cast<__bf16*>(red + bwd_redn(CH));
   __bf16* gyLo = gyH + NRg * RSg;
   __bf16* hH = gyLo + NRg * RSg;
   __bf16* hLo = hH + NRh * RSh;                             // (HLO == 0: not there -- the weight planes follow hH)
@@ -406,9 +406,9 @@ void bwd_fused_bf_kernel(BwdP P) {
   __bf16* pH = wLo + HC * WROW;
   __bf16* pLo = pH + NRp * RSg;
   float* xsL = reinterpret_cast<float*>(pLo + NRp * RSg);   // FIRST: TM + 4 signal samples
-  float* redA = xsL + TM + 4;                               // FIRST: [2][4 waves][4 lane groups][12] scratch of the folded first-layer weight gradient
-  float* redD = xsL;                                        // RD + part_wd: [2][4 waves][4 lane groups][4] scratch of the folded downsample weight gradient
-  float* accD = redD + 2 * 64;                              //               [16] running sums of this workgroup (thread 112 + o owns entry o)
+  float* redA = xsL + TM + 4;                               // FIRST: [4 waves][4 lane groups][12] scratch of the folded first-layer weight gradient
+  float* redD = xsL;                                        // RD + part_wd: [4 waves][4 lane groups][4] scratch of the folded downsample weight gradient
+  float* accD = redD + 64;                                  //               [16] running sums of this workgroup (thread 112 + o owns entry o)
   constexpr bool WDFC = RD && CG == 1 && CH == 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4, q4 = r >> 2, p4 = r & 3;
@@ -643,42 +643,6 @@ void bwd_fused_bf_kernel(BwdP P) {
   const W2SRun wrun = w2s_block_part(total, G, blockIdx.x);   // the producers never exceed the tile count
   const int wend = wrun.first + wrun.count;
   int b = wrun.first / P.ntiles, tile = wrun.first - b * P.ntiles;   // one division per launch; the run is contiguous
-  // The cross-wave sums of a tile (backward statistics; the folded first-layer / downsample weight-gradient partials) used to cost a barrier
-  // of their own per tile.  Round 5: the waves leave their row sums in one of two LDS buffers and the combination of tile i runs behind the
-  // FIRST barrier of tile i + 1 (every wave has finished tile i by then); tile i + 2 rewrites the buffer behind the next such barrier.
-  int st_b = 0, st_tile = 0, st_par = 0;
-  bool st_have = false;
-  const bool wdf_u = WDFC && P.part_wd;
-  auto flush_stats = [&]() {   // uniform; call directly behind a workgroup barrier
-    if (!st_have) return;
-    if (P.part && tid < CH * 32) {
-      const float* rd = red + st_par * bwd_redn(CH);
-      const int k = tid / HC, c = tid % HC;
-      const int nt = c >> 4, gg = (c >> 2) & 3, e = c & 3;
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) s += rd[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
-      w2s_part_store(&P.part[(((size_t)st_b * P.ntiles + st_tile) * 2 + k) * HC + c], s);
-    }
-    if (wdf_u && tid >= 112 && tid < 128) {
-      const int o = tid - 112;
-      float sd = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) sd += redD[st_par * 64 + (w * 4 + (o >> 2)) * 4 + (o & 3)];
-      accD[o] += sd;
-    }
-    if constexpr (FIRST) {
-      if (P.part_w1 && tid >= 64 && tid < 112) {   // (o, j) = ((tid - 64) / 3, (tid - 64) % 3); channel o sits in lane group o >> 2, slot o & 3
-        const int idx = tid - 64, o = idx / 3, j = idx % 3;
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) s += redA[st_par * 192 + (w * 4 + (o >> 2)) * 12 + (o & 3) * 3 + j];
-        P.part_w1[((size_t)st_b * P.ntiles + st_tile) * 48 + idx] = s;
-      }
-    }
-    st_par ^= 1;
-    st_have = false;
-  };
   using PT0 = std::integral_constant<int, 0>; using PT1 = std::integral_constant<int, 1>;
   if (wrun.count > 0) { prefetch(b, tile, PT0{}); prefetch(b, tile, PT1{}); }
 #ifdef W2S_WIDE_STAMP   // diagnostic build only (tools/altlib.sh; W2S_STAMP=1 tools/kbench.py): cycles of workgroup 0's first wave per phase -> part[0..7]
@@ -692,7 +656,6 @@ void bwd_fused_bf_kernel(BwdP P) {
     k0 = __builtin_amdgcn_s_memtime();
 #endif
     __syncthreads();
-    flush_stats();   // the previous tile's
 #ifdef W2S_WIDE_STAMP
     k1 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -896,7 +859,7 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
           const float sk = row16_sum(aw[k]);
-          if (r == 0) redA[st_par * 192 + (wave * 4 + g) * 12 + k] = sk;
+          if (r == 0) redA[(wave * 4 + g) * 12 + k] = sk;
         }
       }
     }
@@ -904,8 +867,16 @@ void bwd_fused_bf_kernel(BwdP P) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float se = row16_sum(ad[e]);
-        if (r == 0) redD[st_par * 64 + (wave * 4 + g) * 4 + e] = se;
+        if (r == 0) redD[(wave * 4 + g) * 4 + e] = se;
       }
+      if (!P.part) __syncthreads();
+    }
+    if (wdf && tid >= 112 && tid < 128 && !P.part) {
+      const int o = tid - 112;
+      float sd = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sd += redD[(w * 4 + (o >> 2)) * 4 + (o & 3)];
+      accD[o] += sd;
     }
     if (P.part) {
 #pragma unroll
@@ -914,14 +885,37 @@ void bwd_fused_bf_kernel(BwdP P) {
         x1 = sA[nt]; x2 = sB[nt];
         row16_sum8(x1, x2);
         if (r == 0) {
-          float* d = red + st_par * bwd_redn(CH) + ((wave * CH + nt) * 4 + g) * 8;
+          float* d = red + ((wave * CH + nt) * 4 + g) * 8;
           st4(d, x1);
           st4(d + 4, x2);
         }
       }
+      __syncthreads();
+      if (tid < CH * 32) {
+        const int k = tid / HC, c = tid % HC;
+        const int nt = c >> 4, gg = (c >> 2) & 3, e = c & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[((w * CH + nt) * 4 + gg) * 8 + k * 4 + e];
+        w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * HC + c], s);
+      }
+      if (wdf && tid >= 112 && tid < 128) {
+        const int o = tid - 112;
+        float sd = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sd += redD[(w * 4 + (o >> 2)) * 4 + (o & 3)];
+        accD[o] += sd;
+      }
+      if constexpr (FIRST) {
+        if (P.part_w1 && tid >= 64 && tid < 112) {   // (o, j) = ((tid - 64) / 3, (tid - 64) % 3); channel o sits in lane group o >> 2, slot o & 3
+          const int idx = tid - 64, o = idx / 3, j = idx % 3;
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) s += redA[(w * 4 + (o >> 2)) * 12 + (o & 3) * 3 + j];
+          P.part_w1[((size_t)b * P.ntiles + tile) * 48 + idx] = s;
+        }
+      }
     }
-    // (no barrier here: the cross-wave sums of this tile's partials ride behind the next tile's first barrier -- flush_stats)
-    st_b = b; st_tile = tile; st_have = true;
 
     // ---- weight gradient: k-step = 32 gradient-side positions; lane group g covers positions 8g..8g+7 of the step
 #ifdef W2S_WIDE_STAMP
@@ -995,8 +989,6 @@ void bwd_fused_bf_kernel(BwdP P) {
   }
 #endif
 
-  __syncthreads();
-  flush_stats();   // the run's last tile
   if (OH) w2s_amax_commit(P.hdr_o, amax, s_out);
   if (WDFC && P.part_wd && tid >= 112 && tid < 128) P.part_wd[(size_t)blockIdx.x * 16 + (tid - 112)] = accD[tid - 112];
   // ---- one slab per workgroup, raw-fragment layout [tile(i,j,c)][lane][4]; waves sharing a tile pair sum in wave order
@@ -1039,9 +1031,9 @@ static int launch_bwd_bf(const BwdP& P0, int nslab, hipStream_t s) {
   BwdP P = P0;
   P.ntiles = (P.Lh + TS - 1) / TS;
   constexpr int NRg = UP2 ? TM / 2 : TM, NRh = TM, NRp = RD ? TM / 2 + 1 : 0;
-  size_t lds = (size_t)2 * bwd_redn(CH) * 4 + (size_t)2 * (2 * (NRg + NRp) * bf_rs(GC) + (W2S_BF_HLO ? 2 : 1) * NRh * bf_rsh(HC, UP2) + 2 * HC * (KD + 8));
-  if (FIRST) lds += (size_t)(TM + 4) * 4 + 2 * 4 * 4 * 12 * 4;
-  if (RD) lds += (2 * 4 * 4 * 4 + 16) * 4;
+  size_t lds = (size_t)bwd_redn(CH) * 4 + (size_t)2 * (2 * (NRg + NRp) * bf_rs(GC) + (W2S_BF_HLO ? 2 : 1) * NRh * bf_rsh(HC, UP2) + 2 * HC * (KD + 8));
+  if (FIRST) lds += (size_t)(TM + 4) * 4 + 4 * 4 * 12 * 4;
+  if (RD) lds += (4 * 4 * 4 + 16) * 4;
   if (lds < 4 * 4 * 64 * 4 * 4) lds = 4 * 4 * 64 * 4 * 4;  // end-of-kernel scratch [wave][4][64][4]
   lds = (lds + 15) & ~(size_t)15;
   auto kern = bwd_fused_bf_kernel<CG, CH, MT, UP2, RD, FIRST, GM>;

@@ -48,12 +48,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
   constexpr int NRh = (TS - 1) * STRIDE + 3;             // window rows; row 0 = input position t0*STRIDE - pad
   constexpr int KSP = (HC == 16) ? 2 : 3;                // K = 32 steps: [tap0|tap1] [tap2|0]  or one tap each
   constexpr int KD = KSP * 32, WROW = KD + 8;
-  float* red = reinterpret_cast<float*>(smem4);          // [2][4][CO][4][8] statistics scratch, double-buffered (see `flush_stats`)
+  float* red = reinterpret_cast<float*>(smem4);          // [4][CO][4][8] statistics scratch
   // 16 input channels, stride 1: TWO window buffers (the LDS budget keeps four workgroups per CU), so a wave that is done with a tile's
   // MFMAs / stores starts transforming the next window at once instead of waiting at a barrier for the slowest wave
   constexpr bool DB = ff_db(HC, STRIDE);
   constexpr int WIN = 2 * NRh * RSh;                     // one window: hi plane, lo plane
-  __bf16* hbase = reinterpret_cast<__bf16*>(red + 2 * 4 * CO * 4 * 8);
+  __bf16* hbase = reinterpret_cast<__bf16*>(red + 4 * CO * 4 * 8);
   __bf16* wH = hbase + (DB ? 2 : 1) * WIN;               // [OC][WROW]
   __bf16* wLo = wH + OC * WROW;
   float* xsL = reinterpret_cast<float*>(wLo + OC * WROW);  // FIRST: NRh + 2 signal samples
@@ -164,25 +164,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
     }
   };
 
-  // Statistics of a tile = the four waves' row sums, combined by 32 * CO threads.  Round 5: instead of a barrier of its own per tile, the
-  // waves leave their sums in one of two LDS buffers and the combination of tile i runs right after the window barrier of tile i + 1
-  // (which every wave passes after its epilogue of tile i); the buffer is written again by tile i + 2, i.e. behind the next such barrier.
-  int st_b = 0, st_tile = 0, st_par = 0;
-  bool st_have = false;
-  auto flush_stats = [&]() {   // uniform; call directly behind a workgroup barrier
-    if (!st_have) return;
-    if (tid < CO * 32) {
-      const float* rd = red + st_par * (4 * CO * 4 * 8);
-      const int k = tid / OC, c = tid % OC;
-      const int nt = c >> 4, gg = (c >> 2) & 3, e = c & 3;
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) s += rd[((w * CO + nt) * 4 + gg) * 8 + k * 4 + e];
-      w2s_part_store(&P.part[(((size_t)st_b * P.ntiles + st_tile) * 2 + k) * OC + c], s);
-    }
-    st_par ^= 1;
-    st_have = false;
-  };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   auto body = [&](auto SET, int tl) {
     const bool live = tl < wend;   // workgroup-uniform; a dead round only keeps the load queue regular
@@ -194,7 +175,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
     if (live) commit(SET);
     prefetch(SET);
     __syncthreads();
-    flush_stats();   // the PREVIOUS tile's statistics: its four waves' sums are in LDS since before this barrier
     if (!live) return;
 
     f32x4 acc[MT][CO];
@@ -252,13 +232,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
       x1 = sA[nt]; x2 = sB[nt];
       row16_sum8(x1, x2);
       if (r == 0) {
-        float* d = red + st_par * (4 * CO * 4 * 8) + ((wave * CO + nt) * 4 + g) * 8;
+        float* d = red + ((wave * CO + nt) * 4 + g) * 8;
         st4(d, x1);
         st4(d + 4, x2);
       }
     }
-    // (no barrier here: the cross-wave sum of these partials rides behind the NEXT tile's window barrier -- flush_stats)
-    st_b = b; st_tile = tile; st_have = true;
+    __syncthreads();
+    if (tid < CO * 32) {
+      const int k = tid / OC, c = tid % OC;
+      const int nt = c >> 4, gg = (c >> 2) & 3, e = c & 3;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[((w * CO + nt) * 4 + gg) * 8 + k * 4 + e];
+      w2s_part_store(&P.part[(((size_t)b * P.ntiles + tile) * 2 + k) * OC + c], s);
+    }
     if (++tile_cur == P.ntiles) { tile_cur = 0; ++b_cur; }
   };
   prefetch(I0{});
@@ -267,8 +254,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ffk_occ(CI,
     body(I0{}, tl);
     body(I1{}, tl + 1);
   }
-  __syncthreads();
-  flush_stats();   // the run's last tile
 }
 
 template <int CI, int CO, int MT, int STRIDE, int PRO>
@@ -276,7 +261,7 @@ static int launch_fwd(const FwdP& P0, int nwg, hipStream_t s) {
   constexpr int TM = 64 * MT, TS = ff_ts(TM, STRIDE), HC = CI * 16, OC = CO * 16, NRh = (TS - 1) * STRIDE + 3, KD = (HC == 16 ? 2 : 3) * 32;
   FwdP P = P0;
   P.ntiles = (P.L_out + TS - 1) / TS;
-  size_t lds = (size_t)2 * 4 * CO * 4 * 8 * 4 + (size_t)2 * 2 * ((ff_db(HC, STRIDE) ? 2 : 1) * NRh * ff_rs(HC) + OC * (KD + 8));
+  size_t lds = (size_t)4 * CO * 4 * 8 * 4 + (size_t)2 * 2 * ((ff_db(HC, STRIDE) ? 2 : 1) * NRh * ff_rs(HC) + OC * (KD + 8));
   if (PRO == W2S_PRO_FIRST) lds += (size_t)(NRh + 2) * 4;
   lds = (lds + 15) & ~(size_t)15;
   auto kern = conv_fwd_bf_kernel<CI, CO, MT, STRIDE, PRO>;
