@@ -336,10 +336,7 @@ __device__ __forceinline__ f32x4 mfma_bf3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x
 __host__ __device__ constexpr int bf_rs(int c) { return c == 16 ? 16 : c + 8; }  // 32-B rows are conflict-free as they are
 // row stride (bf16 elements) of the h planes: stride 1 as the gy planes; stride 2: a lane's sixteen-lane store group covers EVERY OTHER row
 // (the even / odd outputs are separate M tiles), so 32-B rows would put eight lanes on one bank pair -- 40-B / 72-B rows leave 2-way
-__host__ __device__ constexpr int bf_rsh(int c, int up2) { return up2 ? (c == 16 ? 20 : 36) : bf_rs(c); }
-#ifndef W2S_BF_LATEH
-#define W2S_BF_LATEH 1   // the input-side prefetch of the next tile is issued after the epilogue (see `prefetch`)
-#endif
+__host__ __device__ constexpr int bf_rsh(int c, int up2) { return up2 ? (c == 16 ? 20 : 36) : bf_rs(c); }   // (16 / 40 and 24 / 44 measured the same)
 #ifndef W2S_BF_HLO
 #define W2S_BF_HLO 1   // 1: h = GELU(n) staged as bf16 hi + lo planes (three MFMAs per weight-gradient product); 0: hi plane only (two)
 #endif
@@ -461,8 +458,8 @@ void bwd_fused_bf_kernel(BwdP P) {
       for (int j = 0; j < 3; ++j) w1r[i][j] = P.w1[(4 * g + i) * 3 + j];
   }
   // PART 0: the gradient side (g, y_k; the residual fold's gpre; the first-layer form's signal samples) -- issued right after the commit,
-  // in flight during the matrix phase.  PART 1: the input side (x_in, and the previous block's y3 fragments of the statistics fold): with
-  // W2S_BF_LATEH issued AFTER the epilogue (n / GELU' of the current tile are dead by then: 16 registers less at the peak, which is what
+  // in flight during the matrix phase.  PART 1: the input side (x_in, and the previous block's y3 fragments of the statistics fold): in the
+  // stride-1 forms issued AFTER the epilogue (n / GELU' of the current tile are dead by then: 16 registers less at the peak, which is what
   // lets the 16 -> 16 kernels keep three waves per SIMD without spilling); those loads have the weight-gradient phase and the next
   // commit's gradient half to land
   auto prefetch = [&](int b, int tile, auto PART) {   // (sample, tile): carried incrementally by the tile loop, no division per tile
@@ -662,20 +659,17 @@ void bwd_fused_bf_kernel(BwdP P) {
     k2 = __builtin_amdgcn_s_memtime();
 #endif
     commit(b, tile);
-#if !W2S_BF_LATEH
+    constexpr bool LATEH = !UP2;   // stride 1: -3 %; stride 2 (half the gradient-side registers in flight): +2 % -- measured per form
     f32x4 q3[RD ? MT * CH : 1];  // this tile's y3 fragments (the prefetch below reloads rq for the next tile)
     if (RD) {
 #pragma unroll
       for (int i = 0; i < MT * CH; ++i) q3[i] = rq[i];
     }
-#else
-    f32x4 (&q3)[RD ? MT * CH : 1] = rq;   // (reloaded after the epilogue)
-#endif
 #ifdef W2S_WIDE_STAMP
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     k3 = __builtin_amdgcn_s_memtime();
 #endif
-    if (tl + 1 < wend) { prefetch(b_n, tile_n, PT0{}); if (!W2S_BF_LATEH) prefetch(b_n, tile_n, PT1{}); }
+    if (tl + 1 < wend) { prefetch(b_n, tile_n, PT0{}); if (!LATEH) prefetch(b_n, tile_n, PT1{}); }
     __syncthreads();
 #ifdef W2S_WIDE_STAMP
     k4 = __builtin_amdgcn_s_memtime();
@@ -921,7 +915,7 @@ void bwd_fused_bf_kernel(BwdP P) {
 #ifdef W2S_WIDE_STAMP
     k5 = __builtin_amdgcn_s_memtime();
 #endif
-    if (W2S_BF_LATEH && tl + 1 < wend) prefetch(b_n, tile_n, PT1{});
+    if (LATEH && tl + 1 < wend) prefetch(b_n, tile_n, PT1{});
     constexpr int KS = (UP2 ? TM / 2 : TM) / 32;
 #pragma unroll
     for (int s0 = 0; s0 < KS; s0 += KW) {
