@@ -21,9 +21,9 @@ void w2s_conv_cfg_impl(int cin, int cout, int taps, int stride, int mode, int B,
 extern "C" int w2s_conv_cfg(const w2s_conv_args* a, int* out4) {
   if (!a || !out4) return W2S_EINVAL;
   int mode = a->mode, dil = a->dil > 0 ? a->dil : 1;
-  if (mode == W2S_MODE_DILATED && a->taps == 7 && a->stride == 1 && (size_t)(64 + 6 * dil) * (a->cin + 16) * 4 <= 150 * 1024 && !getenv("W2S_SEQ_PER_TAP"))
+  if (mode == W2S_MODE_DILATED && a->taps == 7 && a->stride == 1 && (size_t)(64 + 6 * dil) * (a->cin + 16) * 4 <= 150 * 1024)
     mode = W2S_MODE_CONTIG;   // single staging of the whole dilated window (w2s_conv_forward)
-  if (mode == W2S_MODE_CONTIG && a->taps == 1 && a->stride == 2 && a->cin >= 32 && !getenv("W2S_DS_CONTIG")) mode = W2S_MODE_DILATED;   // (w2s_conv_forward)
+  if (mode == W2S_MODE_CONTIG && a->taps == 1 && a->stride == 2 && a->cin >= 32) mode = W2S_MODE_DILATED;   // (w2s_conv_forward)
   w2s_conv_cfg_impl(a->cin, a->cout, a->taps, a->stride, mode, a->B, a->L_out, mode == W2S_MODE_CONTIG ? dil : 1, out4);
   out4[3] = mode;
   return W2S_OK;
@@ -68,7 +68,7 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
   if (a.mode == W2S_MODE_DILATED) {
     if (a.taps == 7 && a.stride == 1) {
       // whole dilated window (64-position tile + 6*dil halo rows, hi/lo planes or fp32) in LDS: single staging
-      if (a.dil >= 1 && (size_t)(64 + 6 * a.dil) * (a.cin + 16) * 4 <= 150 * 1024 && !getenv("W2S_SEQ_PER_TAP")) {
+      if (a.dil >= 1 && (size_t)(64 + 6 * a.dil) * (a.cin + 16) * 4 <= 150 * 1024) {
         w2s_conv_args b = a;
         b.mode = W2S_MODE_CONTIG;
         return w2s_conv_dispatch_71(b, s);
@@ -90,8 +90,7 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
     // the 1x1 / stride-2 residual conv reads every other input row: stage exactly those (the per-tap window form: TM rows at row stride 2)
     // instead of the contiguous 2 TM - 1 row window -- half the loads and half the on-load GELU work, and for >= 32 channels (rows of whole
     // cache lines) half the HBM traffic of that operand
-    static const char* contig = getenv("W2S_DS_CONTIG");   // tuning only
-    if (!contig && a.cin >= 32) {   // (16 channels: 64-B rows share their cache line with the skipped row, and the two-taps-per-K-step
+    if (a.cin >= 32) {   // (16 channels: 64-B rows share their cache line with the skipped row, and the two-taps-per-K-step
       w2s_conv_args b = a;          //  split-precision packing of that width exists for the contiguous window only)
       b.mode = W2S_MODE_DILATED;
       return w2s_conv_dispatch_12d(b, s);

@@ -476,11 +476,6 @@ static inline TileCfg pick_cfg(int cin, int cout, int taps, int stride, int mode
   // every wave owns 32 output channels for all 64 positions, so each weight fragment is fetched ONCE per workgroup (the 2 x 2 grid
   // fetched it from both position halves: the K loop of these layers waits on L2 weight fetches, 12 TB/s aggregate)  -9 ... -14 %
   if (c.nt >= 8) { c.mt = 4; c.wn = 4; }
-  { static const char* e = getenv("W2S_WN2"); if (e && c.nt >= 8) { c.mt = 2; c.wn = 2; } }  // tuning only: the 2 x 2 grid
-  { static const char* e = getenv("W2S_WN4"); if (e && c.nt >= atoi(e)) { c.wn = 4; c.mt = 4; } }  // tuning only: 1 x 4 wave grid
-  { static const char* e = getenv("W2S_FORCE_MT"); if (e && c.nt >= 4) c.mt = atoi(e); }  // tuning only
-  { static const char* e = getenv("W2S_FORCE_NT"); if (e && c.nt >= 8) c.nt = atoi(e); }  // tuning only
-  { static const char* e = getenv("W2S_NO_SHRINK"); if (e) return c; }                    // tuning only
   // short problems (SequenceCNN: 16 x 960 rows): shrink the tile until the grid covers the 256 CUs about twice
   auto wgs = [&](const TileCfg& t) {
     const long tm = 16 * t.mt * (4 / t.wn);

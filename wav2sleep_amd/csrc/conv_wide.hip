@@ -375,8 +375,7 @@ static int launch_wide(const w2s_conv_args& a, hipStream_t s) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
   const int total = P.B * P.ntiles;
-  static const char* e = getenv("W2S_WIDE_WGS");   // tuning only: workgroups per CU
-  const int per_cu = e ? atoi(e) : ((NW >= 8 || UP2) ? 1 : 2);   // (the transposed form needs 166 registers: one 8-wave workgroup per CU)
+  const int per_cu = (NW >= 8 || UP2) ? 1 : 2;   // (the transposed form needs 166 registers: one 8-wave workgroup per CU)
   const int nwg = 256 * (per_cu > 0 ? per_cu : 1), grid = nwg < total ? nwg : total;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NW + NP)), lds, s, P);
   W2S_CHECK_LAUNCH();

@@ -21,15 +21,15 @@ import torch
 from . import lib
 from .settings import COLS_TO_SAMPLES_PER_EPOCH
 
-_LONGEST_FIRST = os.environ.get('W2S_LONGEST_FIRST', '1') != '0'
-_INTERLEAVE = os.environ.get('W2S_INTERLEAVE', '1') != '0'
-_DEFER_TRUNK = os.environ.get('W2S_DEFER_TRUNK', '1') != '0'
-_CLS_ONLY = os.environ.get('W2S_CLS_ONLY', '1') != '0'   # last transformer layer: row-wise tail on the CLS rows only
-_BWD_WGS = int(os.environ.get('W2S_BWD_WGS', 512))       # persistent workgroups of the fused backward (2 per CU)
-_BWD_WGS32 = int(os.environ.get('W2S_BWD_WGS32', _BWD_WGS))
-_BWD_WGS_RD16 = int(os.environ.get('W2S_BWD_WGS_RD16', 768))  # the 16-channel residual-fold kernel fits three per CU
-_FWD_WGS16 = int(os.environ.get('W2S_FWD_WGS16', 1024))    # persistent workgroups of the forward kernel: 16 input channels (four per CU) ...
-_FWD_WGS = int(os.environ.get('W2S_FWD_WGS', 512))        # ... and the other forms
+# Settled scheduling choices (each was an environment switch while its A/B ran: docs/lab_notes_r1-3.md, r4): the encoder with the longest signal is
+# enqueued first, the encoder streams are fed round-robin (one block per turn), the trunk's weight gradients are deferred to run beside the
+# encoder backward.  _CLS_ONLY stays a module attribute because tests/test_r3_parity_gpu.py checks the all-rows form against it.
+_CLS_ONLY = True      # last transformer layer: attention queries and the row-wise tail on the CLS rows only
+_BWD_WGS = 512        # persistent workgroups of the fused backward (2 per CU)
+_BWD_WGS32 = 512
+_BWD_WGS_RD16 = 768   # the 16-channel residual-fold kernel fits three per CU
+_FWD_WGS16 = 1024     # persistent workgroups of the forward kernel: 16 input channels (four per CU) ...
+_FWD_WGS = 512        # ... and the other forms
 
 FIRST_TILE = 1024  # positions per statistics partial of the Cin=1 layer
 
@@ -106,16 +106,17 @@ class Engine:
         self._streams = {}
         self._rjobs = []
         self._deferred = None
-        self.fused_forward = os.environ.get('W2S_FUSED_FORWARD', '1') != '0'
-        self.fold_gp = os.environ.get('W2S_FOLD_GP', '1') == '1'   # conv3-backward statistics of the previous block ride in the residual-fold conv1 kernel
-        self.fold_w1 = os.environ.get('W2S_FOLD_W1', '1') != '0'   # block 0: conv1's weight gradient inside conv2's backward kernel, gn1 never stored
+        # structural choices that won their A/B (attributes, not environment switches: a test may flip one to check the other form)
+        self.fused_forward = True   # <= 32-channel forward convs on the persistent kernel
+        self.fold_gp = True         # conv3-backward statistics of the previous block ride in the residual-fold conv1 kernel
+        self.fold_w1 = True         # block 0: conv1's weight gradient inside conv2's backward kernel, gn1 never stored
         # W2S_GRAD_FP16=1: fp16 storage (one power-of-two scale per tensor, fp32 arithmetic) of the gradient tensors between the fused-backward
         # launches of the <= 32-channel blocks.  Measured round 3, full suite green with it: -14 GB of traffic,
         # 33.3 -> 32.8 ms per step (-1.6 %); worst full-size gradient tensor 4.4e-4 -> 1.1e-3 relative L2 (EOG 8.3e-4 -> 1.25e-3; bar 2e-3).
         # OFF by default: 2.5 x the gradient error for 1.6 % is a trade a user should choose, not inherit
         self.grad_fp16 = os.environ.get('W2S_GRAD_FP16', '0') == '1'
-        self.bwd_wide = os.environ.get('W2S_BWD_WIDE', '1') != '0'   # one-pass backward of the 64-channel stride-1 convs (csrc/bwd_wide.hip)
-        self.bwd_wide_rd = os.environ.get('W2S_BWD_WIDE_RD', '1') != '0'   # 64-channel conv1: residual branch folded into the one-pass kernel
+        self.bwd_wide = True        # one-pass backward of the 64-channel convs (csrc/bwd_wide.hip)
+        self.bwd_wide_rd = True     # 64-channel conv1: residual branch folded into the one-pass kernel
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
         if not spec.use_residual:
@@ -366,16 +367,6 @@ class Engine:
         streams then start together and progress together, instead of the first encoder's whole pass being enqueued (and mostly executed)
         before the second one's first kernel.  Signals that share an encoder share its stream and run one after the other.  The
         queues of pending slab / column reductions are per encoder (they are flushed on that encoder's stream)."""
-        if not _INTERLEAVE:
-            for g in ([trunk[1]] if trunk else []):
-                for _ in g:
-                    pass
-            for st, gens in tasks.values():
-                with torch.cuda.stream(st):
-                    for g in gens:
-                        for _ in g:
-                            pass
-            return
         live = {e: [st, list(gens), [], []] for e, (st, gens) in tasks.items()}
         if trunk is not None:   # (stream, generator): the trunk's deferred leaf work; it inherits the reductions queued so far
             live['_trunk'] = [trunk[0], [trunk[1]], self._rjobs, self._cjobs]
@@ -548,7 +539,7 @@ class Engine:
         # launch order: longest encoder first (the streams run side by side; the 1024-samples-per-epoch encoders take 4x the time of the
         # 256 ones and set the end of this phase) -- token slot m stays the sorted position
         tasks = {}   # encoder -> (stream, [generators]): signals sharing an encoder run one after the other on its stream
-        for m, s in sorted(enumerate(sigs), key=lambda ms: -COLS_TO_SAMPLES_PER_EPOCH[ms[1]] if _LONGEST_FIRST else 0):
+        for m, s in sorted(enumerate(sigs), key=lambda ms: -COLS_TO_SAMPLES_PER_EPOCH[ms[1]]):
             xs = xf[m]
             st = self._side_stream(sp.signal_map[s], dev)
 
@@ -735,7 +726,7 @@ class Engine:
         self._cjobs = []
         # weight / bias gradients of the trunk are leaves of the backward graph: they are queued here and enqueued on this stream AFTER the
         # encoder streams have been forked, so that these small-grid kernels run beside the encoder backward instead of before it
-        self._deferred = [] if (_DEFER_TRUNK and self.multi_stream) else None
+        self._deferred = [] if self.multi_stream else None
 
     def _backward_end(self, accumulate):
         if not accumulate:
@@ -910,7 +901,7 @@ class Engine:
         dev = gX.device
         encs = [ec['enc'] for ec in c['enc']]
         tasks = {}
-        for m, ec in sorted(enumerate(c['enc']), key=lambda me: -COLS_TO_SAMPLES_PER_EPOCH[me[1]['sig']] if _LONGEST_FIRST else 0):
+        for m, ec in sorted(enumerate(c['enc']), key=lambda me: -COLS_TO_SAMPLES_PER_EPOCH[me[1]['sig']]):
             st = self._side_stream(ec['enc'], dev)
 
             def run(m=m, ec=ec):

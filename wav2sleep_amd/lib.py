@@ -90,14 +90,10 @@ def load():
             raise RuntimeError(f'{LIB_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"` '
                                f'(or `make -C wav2sleep_amd/csrc`). wav2sleep_amd has no CPU fallback.')
         lib = C.CDLL(LIB_PATH)
-        any_abi = bool(os.environ.get('W2S_LIB')) and os.environ.get('W2S_ABI_ANY') == '1'   # tuning only: an older library known to match
         for name in EXPORTS:
-            if not hasattr(lib, name) and not (any_abi and name == 'w2s_abi_version'):
+            if not hasattr(lib, name):
                 raise RuntimeError(f'{LIB_PATH} does not export {name}')
         lib.w2s_version.restype = C.c_char_p
-        if any_abi:
-            _lib = lib
-            return _lib
         lib.w2s_abi_version.restype = C.c_int
         if lib.w2s_abi_version() != ABI_VERSION:   # a stale W2S_LIB / build_alt library would be called with shifted arguments
             raise RuntimeError(f'{LIB_PATH} has ABI {lib.w2s_abi_version()}, this host was written against {ABI_VERSION} (include/w2s.h): rebuild it')
