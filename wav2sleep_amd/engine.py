@@ -25,11 +25,6 @@ from .settings import COLS_TO_SAMPLES_PER_EPOCH
 # enqueued first, the encoder streams are fed round-robin (one block per turn), the trunk's weight gradients are deferred to run beside the
 # encoder backward.  _CLS_ONLY stays a module attribute because tests/test_r3_parity_gpu.py checks the all-rows form against it.
 _CLS_ONLY = True      # last transformer layer: attention queries and the row-wise tail on the CLS rows only
-_BWD_WGS = 512        # persistent workgroups of the fused backward (2 per CU)
-_BWD_WGS32 = 512
-_BWD_WGS_RD16 = 768   # the 16-channel residual-fold kernel fits three per CU
-_FWD_WGS16 = 1024     # persistent workgroups of the forward kernel: 16 input channels (four per CU) ...
-_FWD_WGS = 512        # ... and the other forms
 
 FIRST_TILE = 1024  # positions per statistics partial of the Cin=1 layer
 
@@ -252,7 +247,8 @@ class Engine:
         if ftile and pro in (lib.PRO_GELU, lib.PRO_IN_GELU, lib.PRO_FIRST):
             # <= 32 channels: persistent split-precision forward kernel (prefetch + LDS-resident weights)
             nt = _cdiv(L_out, ftile)
-            nwg = _FWD_WGS16 if cin == 16 else _FWD_WGS
+            # persistent workgroups (grid sweep of round 5, `gpurun_out/r5p`): first-layer form 1024, 16 -> 16 stride 2 768, everything else 512
+            nwg = 1024 if pro == lib.PRO_FIRST else 768 if (cin == 16 and stride == 2) else 512
             part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
             lib.conv_fwd_fused(x=x, w=w, st_in=pro_stats, w1=x2, y=y, part=part, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, stride=stride,
                                pro=pro, pad=self.kpad, nwg=nwg)
@@ -304,7 +300,8 @@ class Engine:
         dev = g.device
         tile = lib.bwd_fused_tile(cg, ch, stride, gpre is not None, self.split_precision)
         nt = _cdiv(Lh, tile)
-        nslab = max(1, min(B * nt, _BWD_WGS_RD16 if (cg == 16 and ch == 16 and gpre is not None) else _BWD_WGS32 if (cg == 32 and ch == 32) else _BWD_WGS))
+        # persistent workgroups = what fits a CU x 256 (round 5: the stride-2 forms and the 16-channel residual-fold form fit three)
+        nslab = max(1, min(B * nt, 768 if ((cg == 16 and ch == 16 and gpre is not None) or (stride == 2 and cg == ch)) else 512))
         slab = self._slab(dev, nslab, cg * ch * 3)
         slab_d = self._slab(dev, nslab, cg * ch) if gpre is not None else None
         part = torch.empty(B, nt, 2, ch, device=dev, dtype=torch.float32) if want_part else None
