@@ -62,7 +62,8 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #define W2S_HE_NP 5
 #define W2S_HE_NQ 4
 #endif
-// The backward's erf (GELU' and the GELU recomputed beside it: gelu_grad4 / gelu_both4 / gelu_grad_f -- gradients only, never a logit):
+// The backward's erf (GELU' and the GELU recomputed beside it -- the weight-gradient operand h of the fused backward kernels sees an
+// activation that differs from the forward's by up to ~2e-6 |x| --: gelu_grad4 / gelu_both4 / gelu_grad_f -- gradients only, never a logit):
 // P of 5 and Q of 4 terms, |err| <= 1.9e-6 abs (7 instead of 10 polynomial steps).  The same fit flipped arg-max labels when the FORWARD
 // used it (near-tied logits at the default initialisation, docs/lab_notes_r4.md section 7); in the backward it moves the gradients by
 // ~1e-6 relative against a 2e-3 bar (measured 4.3e-4, dominated by the split-precision products).  -DW2S_BWD_ERF_LOWDEG=0: the forward's erf.
@@ -79,6 +80,10 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #define W2S_HL_Q2 0.23847808392940692f
 #define W2S_HL_Q3 1.0f
 #define W2S_HE_CLAMP 5.65685424949238f   /* 4 sqrt 2: erf saturates to fp32 beyond */
+// The backward's fit overshoots 1/2 beyond x = 4.69 (up to 0.5000017 at the forward's clamp): clamped at 4.6 instead, where it reads
+// 0.4999995 (true value 0.4999979; beyond, the true value approaches 1/2 from below), so |half_erf_bwd| < 1/2 everywhere -- cdf stays in
+// (0, 1) and GELU' keeps its sign for strongly negative inputs -- at no extra instruction and inside the same 1.9e-6 error bound
+#define W2S_HL_CLAMP 4.6f
 // -DW2S_ERF_IDENTITY: timing-only build (tools/altlib.sh; numerics WRONG on purpose): the rational erf and the exp2 of GELU' collapse
 // to one multiply each -- how fast is the skeleton of a kernel without its transcendental work?  
 __device__ __forceinline__ float half_erf_fast(float x) {
@@ -109,7 +114,7 @@ __device__ __forceinline__ float half_erf_bwd(float x) {
 #if !W2S_BWD_ERF_LOWDEG || defined(W2S_ERF_IDENTITY)
   return half_erf_fast(x);
 #else
-  x = __builtin_amdgcn_fmed3f(x, -W2S_HE_CLAMP, W2S_HE_CLAMP);
+  x = __builtin_amdgcn_fmed3f(x, -W2S_HL_CLAMP, W2S_HL_CLAMP);
   const float x2 = x * x;
   float p = fmaf(x2, W2S_HL_P0, W2S_HL_P1);
   p = fmaf(x2, p, W2S_HL_P2);
@@ -168,8 +173,8 @@ __device__ __forceinline__ f32x4 half_erf4_bwd(f32x4 x) {
 #if !W2S_BWD_ERF_LOWDEG || defined(W2S_ERF_IDENTITY)
   return half_erf4(x);
 #else
-  x.x = __builtin_amdgcn_fmed3f(x.x, -W2S_HE_CLAMP, W2S_HE_CLAMP); x.y = __builtin_amdgcn_fmed3f(x.y, -W2S_HE_CLAMP, W2S_HE_CLAMP);
-  x.z = __builtin_amdgcn_fmed3f(x.z, -W2S_HE_CLAMP, W2S_HE_CLAMP); x.w = __builtin_amdgcn_fmed3f(x.w, -W2S_HE_CLAMP, W2S_HE_CLAMP);
+  x.x = __builtin_amdgcn_fmed3f(x.x, -W2S_HL_CLAMP, W2S_HL_CLAMP); x.y = __builtin_amdgcn_fmed3f(x.y, -W2S_HL_CLAMP, W2S_HL_CLAMP);
+  x.z = __builtin_amdgcn_fmed3f(x.z, -W2S_HL_CLAMP, W2S_HL_CLAMP); x.w = __builtin_amdgcn_fmed3f(x.w, -W2S_HL_CLAMP, W2S_HL_CLAMP);
   const f32x4 x2 = x * x;
   f32x4 p = fma4(x2, splat4(W2S_HL_P0), splat4(W2S_HL_P1));
   p = fma4(x2, p, splat4(W2S_HL_P2));
@@ -364,6 +369,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 // compiler might place there -- its hazard recogniser does not look into inline asm.  Same additions in
 // the same order as row16_sum (a + dpp(a) is commutative bit for bit).  All 64 lanes must be active: call it from wave-uniform control flow only.
 __device__ __forceinline__ void row16_sum8(f32x4& a, f32x4& b) {
+#ifdef W2S_NO_DPP8   // fallback: the compiler's form of the same additions (bitwise the same results; tools/altlib.sh nodpp8 "-DW2S_NO_DPP8=1" ...)
+  a = (f32x4){row16_sum(a.x), row16_sum(a.y), row16_sum(a.z), row16_sum(a.w)};
+  b = (f32x4){row16_sum(b.x), row16_sum(b.y), row16_sum(b.z), row16_sum(b.w)};
+  return;
+#endif
   float a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
 #define W2S_DPP_STEP(ctl) \
   "v_add_f32_dpp %0, %0, %0 " ctl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 " ctl " row_mask:0xf bank_mask:0xf\n\t" \
