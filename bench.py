@@ -40,7 +40,7 @@ def pmc_key(name):
     m = re.match(r'conv_wide_kernel<(\d+), (\d+), \d+, (\d+), (\d+), (\d+), .*>', name)   # <CI, NW, NP, STRIDE, PRO, EPI, MT, PD, UP2, CZ>
     if m:
         return f'conv_wide_kernel<{m[1]}, {m[2]}, {m[3]}, {m[4]}, {m[5]}>'
-    m = re.match(r'bwd_wide_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+, \d+, \d+, (\d+), (\d+)>', name)   # <CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>
+    m = re.match(r'bwd_wide_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+, \d+, \d+, (\d+), (\d+)(?:, \d+)?>', name)   # <CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD[, CZ]>
     if m:
         return f'bwd_wide_kernel<{m[1]}, {m[2]}, {m[3]}, {int(m[4]) + 1}{", rd" if m[5] == "1" else ""}>'
     m = re.match(r'wgrad_wide_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), .*>', name)   # <CO, CI, STRIDE, PG, PH, MT, NWC, IB, CB, PD>

@@ -232,7 +232,7 @@ int w2s_bwd_fused_wd(const float* g, const float* y, const float* st_k, const fl
                      const float* y3p, const float* st3p, const float* x0, float* part_wd, void* stream);
 
 /*
- * Fused backward of one k=3 / symmetric-padding encoder conv with cg = 64 gradient-side channels (round 3, csrc/bwd_wide.hip): data
+ * Fused backward of one k=3 encoder conv (symmetric or causal padding) with cg = 64 gradient-side channels (round 3, csrc/bwd_wide.hip): data
  * gradient + weight gradient + GELU' + backward statistics in one persistent role-split pass -- the >= 64-channel counterpart of
  * w2s_bwd_fused (same formulas).  stride 1: ch = 64 or 32 input-side channels, gy = instance-norm backward of g with (st_k, bst_k), h =
  * GELU(IN(xin)) with st_in or GELU(xin) when st_in == NULL.  stride 2 (the block's conv3; ch = 64, st_in required): g = dL/d(block
@@ -248,7 +248,7 @@ int w2s_bwd_wide_groups(int cg, int ch, int stride);   /* statistics-partial row
 int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                  const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B, int L,
                  int cg, int ch, int stride, const float* y3p, const float* st3p, const float* gpre, const void* wd_hi, const void* wd_lo,
-                 float* slab_d, int dry, void* stream);
+                 float* slab_d, int pad, int dry, void* stream);   /* pad: the forward conv's left padding (1 symmetric, 2 causal) */
 /* gpre != NULL (conv1 of a residual block: stride 1, st_in and add_even NULL, L even): the block's 1x1/stride-2 residual branch
  * (blocks.py:44-47,68) folded in as in w2s_bwd_fused -- gout additionally receives Wd^T gpre[t/2] at even t before the GELU' factor (gpre:
  * [B][L/2][cg], wd_hi / wd_lo: w2s_repack_batch bwd planes of the downsample weight) and slab_d receives nslab raw-fragment slabs of the

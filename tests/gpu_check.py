@@ -558,7 +558,7 @@ def Rr_fp64(gpre, wd):
     """data gradient of the 1x1 / stride-2 residual conv at the even input rows: R[u] = Wd^T gpre[u]  (wd: [ch][cg], the kernels' layout)"""
     return torch.einsum('buc,oc->buo', gpre.double().cpu(), wd.double().cpu())
 
-def _bwd_wide_fp64(g, y, st, bst, x, sti, ev, w, stride):
+def _bwd_wide_fp64(g, y, st, bst, x, sti, ev, w, stride, pad=1):
     """fp64 restatement of one encoder conv's backward as blocks.py:174-183 + autograd define it (channels-last device tensors in, CPU out):
     gy = IN-backward of g (x GELU'(n) first for the stride-2 conv3) with the GIVEN statistics / backward sums; H = GELU(IN(x)) (or GELU(x));
     dH, dW = autograd of F.conv1d(H, W, stride, padding=1); gout = (dH + ev at the even rows) x GELU'; sums = means of gout, gout x n_in."""
@@ -569,7 +569,8 @@ def _bwd_wide_fp64(g, y, st, bst, x, sti, ev, w, stride):
     hn = (x - sti[:, None, :, 0].double().cpu()) * sti[:, None, :, 1].double().cpu() if sti is not None else x
     H = (0.5 * hn * (1 + torch.erf(hn / 2 ** 0.5))).transpose(1, 2).contiguous().requires_grad_(True)
     W = w.double().cpu().clone().requires_grad_(True)   # [cg][ch][3]
-    F.conv1d(H, W, stride=stride, padding=1).backward(GY.transpose(1, 2)[:, :, :x.shape[1] // stride].contiguous())
+    Hp = F.pad(H, (pad, 2 - pad))   # pad = 2: causal (blocks.py's left-only padding)
+    F.conv1d(Hp, W, stride=stride)[:, :, :x.shape[1] // stride].backward(GY.transpose(1, 2)[:, :, :x.shape[1] // stride].contiguous())
     dH = H.grad.transpose(1, 2).clone()
     if ev is not None:
         dH[:, 0:2 * ev.shape[1]:2, :] += ev.double().cpu()
@@ -582,9 +583,11 @@ def t_bwd_wide():
     same tensors: the conv_wide data gradient (instance-norm-backward prologue, GELU' epilogue, residual add, backward statistics) and the
     wgrad_wide weight gradient.  Same split-precision products in the same order: the bars are tight."""
     B = 3
-    for (cg, ch, L, hst, add_even, stride) in [(64, 64, 1000, True, False, 1), (64, 64, 777, False, True, 1), (64, 32, 500, False, True, 1), (64, 64, 64, True, False, 1),
-                                               (64, 32, 130, False, True, 1), (64, 64, 4098, True, False, 1), (64, 32, 2050, True, False, 1),
-                                               (64, 64, 1000, True, False, 2), (64, 64, 64, True, False, 2), (64, 64, 4098, True, False, 2), (64, 64, 130, True, False, 2)]:
+    cases = [(64, 64, 1000, True, False, 1), (64, 64, 777, False, True, 1), (64, 32, 500, False, True, 1), (64, 64, 64, True, False, 1),
+             (64, 32, 130, False, True, 1), (64, 64, 4098, True, False, 1), (64, 32, 2050, True, False, 1),
+             (64, 64, 1000, True, False, 2), (64, 64, 64, True, False, 2), (64, 64, 4098, True, False, 2), (64, 64, 130, True, False, 2)]
+    # pad = 2: the causal variant (left-only padding), every case again
+    for (cg, ch, L, hst, add_even, stride), pad in [(c, 1) for c in cases] + [(c, 2) for c in cases]:
         Lg = L // stride
         g = torch.randn(B, Lg, cg, device=dev) * 0.1; y = torch.randn(B, Lg, cg, device=dev) * 2 + 0.2; x = torch.randn(B, L, ch, device=dev) * 1.3 - 0.1
         st = torch.stack([torch.randn(B, cg, device=dev) * 0.1, torch.rand(B, cg, device=dev) + 0.5], dim=-1).contiguous()
@@ -597,16 +600,16 @@ def t_bwd_wide():
         # the separate kernels
         gout0 = torch.zeros(B, L, ch, device=dev)
         if stride == 1:
-            a = lib.conv_args(x=g, x2=y, w=wb, w_hi=wh, w_lo=wl, y=gout0, B=B, L_in=L, L_out=L, cin=cg, cout=ch, taps=3, stride=1, pad=1, flip=1, pro=pro_g,
+            a = lib.conv_args(x=g, x2=y, w=wb, w_hi=wh, w_lo=wl, y=gout0, B=B, L_in=L, L_out=L, cin=cg, cout=ch, taps=3, stride=1, pad=2 - pad, flip=1, pro=pro_g,
                               pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=x, aux_stats=sti, add_even=ev)
         else:
-            a = lib.conv_args(x=g, x2=y, w=wb, w_hi=wh, w_lo=wl, y=gout0, B=B, L_in=Lg, L_out=L, cin=cg, cout=ch, taps=3, stride=2, pad=1, mode=lib.MODE_UP2,
+            a = lib.conv_args(x=g, x2=y, w=wb, w_hi=wh, w_lo=wl, y=gout0, B=B, L_in=Lg, L_out=L, cin=cg, cout=ch, taps=3, stride=2, pad=pad, mode=lib.MODE_UP2,
                               pro=pro_g, pro_stats=st, pro_bstats=bst, epi=lib.EPI_GP, aux=x, aux_stats=sti)
         if True:
             t0 = lib.conv_tile_of(a); nt0 = (L + t0 - 1) // t0
             part0 = torch.zeros(B, nt0, 2, ch, device=dev); lib.set_part(a, part0)
             lib.conv_forward(a)
-            kw = dict(g=g, g2=y, g_stats=st, g_bstats=bst, x=x, x_stats=sti, B=B, L_in=L, L_out=Lg, cin=ch, cout=cg, taps=3, stride=stride, pad=1, pro_g=pro_g,
+            kw = dict(g=g, g2=y, g_stats=st, g_bstats=bst, x=x, x_stats=sti, B=B, L_in=L, L_out=Lg, cin=ch, cout=cg, taps=3, stride=stride, pad=pad, pro_g=pro_g,
                       pro_h=lib.PRO_IN_GELU if hst else lib.PRO_GELU, split_precision=True)
             ns0 = min(5, (B * Lg + 255) // 256)
             slab0 = torch.zeros(ns0 * cg * ch * 3, device=dev); lib.wgrad(slab=slab0, nslab=ns0, **kw)
@@ -614,21 +617,21 @@ def t_bwd_wide():
         # the fused kernel, with few and with many workgroups
         tile, groups = lib.bwd_wide_tile(cg, ch, stride), lib.bwd_wide_groups(cg, ch, stride)
         nt = (L + tile - 1) // tile
-        RES.append((f'bwd_wide {cg}->{ch} s{stride} L{L} is taken', lib.bwd_wide_takes(B, L, cg, ch, stride, hst) and tile == 64))
+        RES.append((f'bwd_wide {cg}->{ch} s{stride} pad{pad} L{L} is taken', lib.bwd_wide_takes(B, L, cg, ch, stride, hst) and tile == 64))
         for ns in (min(5, B * nt), min(256, B * nt)):
             gout = torch.full((B, L, ch), float('nan'), device=dev); part = torch.full((B, nt * groups, 2, ch), float('nan'), device=dev)
             slab = torch.full((ns * cg * ch * 3,), float('nan'), device=dev)
             lib.bwd_wide(g=g, y=y, st_k=st, bst_k=bst, xin=x, st_in=sti, add_even=ev, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab, nslab=ns, B=B, L=L,
-                         cg=cg, ch=ch, stride=stride)
+                         cg=cg, ch=ch, stride=stride, pad=pad)
             gw = torch.zeros(cg, ch, 3, device=dev); lib.wgrad_reduce(slab, ns, gw, cg, ch, 3, 1)
-            tag = f'bwd_wide {cg}->{ch} s{stride} L{L} hst{int(hst)} ev{int(add_even)} wgs{ns}'
+            tag = f'bwd_wide {cg}->{ch} s{stride} pad{pad} L{L} hst{int(hst)} ev{int(add_even)} wgs{ns}'
             loose = 1
             report(tag + ' gout', gout, gout0, tol=2e-6 * loose)
             report(tag + ' statistics sums', part.sum(1), part0.sum(1), tol=2e-5 * loose)
             report(tag + ' wgrad', gw, gw0, tol=2e-5 * loose)
         if (cg, ch, L, stride) in ((64, 64, 1000, 1), (64, 64, 1000, 2), (64, 32, 500, 1)):
             # CPU arm (round-3 verdict): the same outputs against fp64 autograd of F.conv1d, independent of every sibling HIP kernel
-            want_gout, want_gw, want_s = _bwd_wide_fp64(g, y, st, bst, x, sti, ev, w, stride)
+            want_gout, want_gw, want_s = _bwd_wide_fp64(g, y, st, bst, x, sti, ev, w, stride, pad)
             report(tag + ' gout vs fp64 autograd', gout, want_gout, tol=1e-4)
             report(tag + ' wgrad vs fp64 autograd', gw, want_gw, tol=3e-4)
             if hst:
@@ -639,12 +642,12 @@ def t_bwd_wide():
             gout2 = torch.full((B, L, ch), float('nan'), device=dev); part2 = torch.full((B, nt * groups, 2, ch), float('nan'), device=dev)
             slab2 = torch.zeros(ns * cg * ch * 3, device=dev)
             lib.bwd_wide(g=g, y=y, st_k=st, bst_k=bst, xin=x, st_in=sti, add_even=ev, w_hi=wh, w_lo=wl, gout=gout2, part=part2, slab=slab2, nslab=ns, B=B, L=L,
-                         cg=cg, ch=ch, stride=1, y3p=y3p, st3p=st3)
+                         cg=cg, ch=ch, stride=1, y3p=y3p, st3p=st3, pad=pad)
             ntg = (L + 511) // 512
             pg = torch.zeros(B, ntg, 2, ch, device=dev)
             lib.gp_stats(gout2, y3p, st3, pg, B, L, ch, 512)
-            report(f'bwd_wide {cg}->{ch} L{L} gout with the statistics fold', gout2, gout, tol=0)
-            report(f'bwd_wide {cg}->{ch} L{L} folded conv3 statistics', part2.sum(1), pg.sum(1), tol=2e-5)
+            report(f'bwd_wide {cg}->{ch} pad{pad} L{L} gout with the statistics fold', gout2, gout, tol=0)
+            report(f'bwd_wide {cg}->{ch} pad{pad} L{L} folded conv3 statistics', part2.sum(1), pg.sum(1), tol=2e-5)
         if stride == 1 and not hst and not (L & 1):   # ... and the block's residual branch folded in vs (1x1 conv -> add_even) + downsample wgrad
             gpre = torch.randn(B, L // 2, cg, device=dev) * 0.1
             wd = (torch.randn(ch, cg) / math.sqrt(cg)).to(dev); dh, dl = lib.frag_major_planes(wd)
@@ -655,7 +658,7 @@ def t_bwd_wide():
                 go = torch.full((B, L, ch), float('nan'), device=dev); pt = torch.full((B, nt * groups, 2, ch), float('nan'), device=dev)
                 sl = torch.zeros(ns * cg * ch * 3, device=dev); sd = torch.zeros(ns * cg * ch, device=dev) if fold else None
                 lib.bwd_wide(g=g, y=y, st_k=st, bst_k=bst, xin=x, st_in=None, add_even=None if fold else Rr, w_hi=wh, w_lo=wl, gout=go, part=pt, slab=sl, nslab=ns,
-                             B=B, L=L, cg=cg, ch=ch, stride=1, gpre=gpre if fold else None, wd_hi=dh if fold else None, wd_lo=dl if fold else None, slab_d=sd)
+                             B=B, L=L, cg=cg, ch=ch, stride=1, gpre=gpre if fold else None, wd_hi=dh if fold else None, wd_lo=dl if fold else None, slab_d=sd, pad=pad)
                 gwf = torch.zeros(cg, ch, 3, device=dev); lib.wgrad_reduce(sl, ns, gwf, cg, ch, 3, 1)
                 gd = torch.zeros(cg, ch, 1, device=dev)
                 if fold:
@@ -663,15 +666,15 @@ def t_bwd_wide():
                 outs.append((go, pt, gwf, gd))
             hcl = F.gelu(x)[:, 0:2 * (L // 2):2, :]
             want_gd = torch.einsum('buo,buc->oc', gpre.double().cpu(), hcl.double().cpu()).float().view(cg, ch, 1)
-            RES.append((f'bwd_wide {cg}->{ch} L{L} residual fold is taken', lib.bwd_wide_takes(B, L, cg, ch, 1, False, rd=True)))
-            report(f'bwd_wide {cg}->{ch} L{L} residual fold gout', outs[1][0], outs[0][0], tol=2e-5)
-            report(f'bwd_wide {cg}->{ch} L{L} residual fold statistics', outs[1][1].sum(1), outs[0][1].sum(1), tol=2e-4)
-            report(f'bwd_wide {cg}->{ch} L{L} residual fold conv wgrad identical', outs[1][2], outs[0][2], tol=0)
-            report(f'bwd_wide {cg}->{ch} L{L} residual fold downsample wgrad', outs[1][3], want_gd, tol=3e-4)
+            RES.append((f'bwd_wide {cg}->{ch} pad{pad} L{L} residual fold is taken', lib.bwd_wide_takes(B, L, cg, ch, 1, False, rd=True)))
+            report(f'bwd_wide {cg}->{ch} pad{pad} L{L} residual fold gout', outs[1][0], outs[0][0], tol=2e-5)
+            report(f'bwd_wide {cg}->{ch} pad{pad} L{L} residual fold statistics', outs[1][1].sum(1), outs[0][1].sum(1), tol=2e-4)
+            report(f'bwd_wide {cg}->{ch} pad{pad} L{L} residual fold conv wgrad identical', outs[1][2], outs[0][2], tol=0)
+            report(f'bwd_wide {cg}->{ch} pad{pad} L{L} residual fold downsample wgrad', outs[1][3], want_gd, tol=3e-4)
             if (cg, ch, L) == (64, 32, 500):   # CPU arm of the residual-fold form: (W^T gy + Wd^T gpre at the even rows) x GELU'(pin), fp64
-                want_gout, want_gw, _ = _bwd_wide_fp64(g, y, st, bst, x, None, Rr_fp64(gpre, wd), w, 1)
-                report(f'bwd_wide {cg}->{ch} L{L} residual fold gout vs fp64 autograd', outs[1][0], want_gout, tol=1e-4)
-                report(f'bwd_wide {cg}->{ch} L{L} residual fold wgrad vs fp64 autograd', outs[1][2], want_gw, tol=3e-4)
+                want_gout, want_gw, _ = _bwd_wide_fp64(g, y, st, bst, x, None, Rr_fp64(gpre, wd), w, 1, pad)
+                report(f'bwd_wide {cg}->{ch} pad{pad} L{L} residual fold gout vs fp64 autograd', outs[1][0], want_gout, tol=1e-4)
+                report(f'bwd_wide {cg}->{ch} pad{pad} L{L} residual fold wgrad vs fp64 autograd', outs[1][2], want_gw, tol=3e-4)
     RES.append(('bwd_wide refuses a batch whose statistics tables do not fit its LDS', not lib.bwd_wide_takes(48, 640, 64, 64, 1, True) and lib.bwd_wide_takes(40, 640, 64, 64, 1, False)))
 
 def t_grad_fp16_chain():

@@ -37,6 +37,7 @@ struct BwdWideP {
   // sum_u gpre[u] x h[2u].  gpre = dL/d(block pre-activation) [B][L/2][OC]; wd_hi / wd_lo = data-gradient planes of the downsample weight
   const float* gpre; const __bf16* wd_hi; const __bf16* wd_lo; float* slab_d;
   int B, L, Lg, ntiles;   // L: input-side length; Lg: gradient-side length (L, or L / 2 for the stride-2 form)
+  int pad;                // the forward conv's left padding: 1 = symmetric, 2 = causal (blocks.py:150-152,178-182)
 };
 
 typedef __bf16 wbbf16x4v __attribute__((__vector_size__(4 * sizeof(__bf16))));
@@ -50,13 +51,14 @@ __device__ __forceinline__ bf16x8 wb_tr8(const __bf16* p0, const __bf16* p1) {
 
 // CO / CI: 16-channel tiles on the gradient / input side; HST: xin carries statistics (conv2); MT: 16-position m-tiles per tile;
 // NWC consumer waves = (CO / IB) x (CI / CB) weight-gradient owners = CI x (NWC / CI) data-gradient owners; PD: producer prefetch depth
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD>
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD, int CZ>
 __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
   static_assert(!RD || (!UP2 && !HST && MT % 2 == 0), "residual fold: the stride-1 conv1 (its input is a stored pre-activation)");
   extern __shared__ f32x4 smem4[];
   static_assert((CO / IB) * (CI / CB) == NWC && NWC % CI == 0 && MT % (NWC / CI) == 0, "consumer wave grid");
   static_assert(!UP2 || (NWC == CI && MT % 2 == 0 && (8 * MT) % 32 == 0), "stride-2 form: one position group, even / odd m-tiles");
-  constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NPT = 256, NR = TM + 2;   // h window rows: positions t0 - 1 .. t0 + TM
+  static_assert(!CZ || UP2, "CZ: the stride-2 form with causal padding (stride 1 takes the padding at run time)");
+  constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NPT = 256, NR = TM + 2;   // h window rows: positions t0 - pad .. t0 - pad + TM + 1
   constexpr int NRG = UP2 ? TM / 2 + 1 : TM + 2;                                     // gy window rows: t0 - 1 .. t0 + TM (UP2: t0/2 .. t0/2 + TM/2)
   constexpr int TG = UP2 ? TM / 2 : TM;                                              // gradient-side positions per tile
   constexpr int RSg = OC + 16, RSh = HC + 8;                                         // bf16 elements per LDS row
@@ -94,6 +96,7 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
   const int nt_wg = wrun.count;                                   // >= 1 (the grid never exceeds the tile count)
   const int NI = ((nt_wg + 1 + PD - 1) / PD) * PD;                // barrier rounds, padded to whole prefetch cycles
   const int L = P.L, Lg = P.Lg;
+  const int PL = P.pad;   // window row 0: h position t0 - pad, gy position t0 + pad - 2 (stride 1; stride 2: t0 / 2)
 
   if (wave >= NWC) {
     // ================================================= producer waves =================================================
@@ -122,7 +125,7 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
       int b, tile_;
       w2s_run_pos(run_b0, run_t0, P.ntiles, min(i, nt_wg - 1), b, tile_);
       const int t0 = tile_ * TM;
-      const int row = min(grow0 + k * rsg, NRG - 1), gr = min(max((UP2 ? t0 / 2 : t0 - 1) + row, 0), Lg - 1);
+      const int row = min(grow0 + k * rsg, NRG - 1), gr = min(max((UP2 ? t0 / 2 : t0 + PL - 2) + row, 0), Lg - 1);
       const unsigned off = (unsigned)gr * OC + gch;
       rg[S][k] = ld4o(P.g + (size_t)b * Lg * OC, off);
       ry[S][k] = ld4o(P.y + (size_t)b * Lg * OC, off);
@@ -132,7 +135,7 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
       int b, tile_;
       w2s_run_pos(run_b0, run_t0, P.ntiles, min(i, nt_wg - 1), b, tile_);
       const int t0 = tile_ * TM;
-      const int row = min(hrow0 + k * rsh, NR - 1), gr = min(max(t0 - 1 + row, 0), L - 1);
+      const int row = min(hrow0 + k * rsh, NR - 1), gr = min(max(t0 - PL + row, 0), L - 1);
       rh[S][k] = ld4o(P.xin + (size_t)b * L * HC, (unsigned)gr * HC + hch);
     };
     auto stage = [&](auto SET, int i) {
@@ -207,9 +210,9 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
 #endif
 #ifndef W2S_BWW_NOLDSW
           wb_split_store4(hH, hL, row * RSh + hch, hv);
-          if (row >= 1 && row <= TM) st4(gpL + (row - 1) * RSp + hch, gpv);
+          if (row >= PL && row < TM + PL) st4(gpL + (row - PL) * RSp + hch, gpv);
 #else
-          if (hv.x == 123.f) { wb_split_store4(hH, hL, row * RSh + hch, hv); st4(gpL + (row - 1) * RSp + hch, gpv); }
+          if (hv.x == 123.f) { wb_split_store4(hH, hL, row * RSh + hch, hv); st4(gpL + (row - PL) * RSp + hch, gpv); }
 #endif
         }
       }
@@ -224,8 +227,8 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
       }
       // rows outside the sample (the conv's zero padding; a sample's first / last tile only -- uniform branch): loaded from clamped
       // addresses and transformed like any row above, now overwritten with zeros by the lanes that stored them (bwd_fused.hip `commit`)
-      const int rbg = UP2 ? t0 / 2 : t0 - 1;
-      if (live && (rbg < 0 || rbg + NRG > Lg || t0 - 1 < 0 || t0 - 1 + NR > L)) {
+      const int rbg = UP2 ? t0 / 2 : t0 + PL - 2;
+      if (live && (rbg < 0 || rbg + NRG > Lg || t0 - PL < 0 || t0 - PL + NR > L)) {
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
           const int row = grow0 + k * rsg, gr = rbg + row;
@@ -233,7 +236,7 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
         }
 #pragma unroll
         for (int k = 0; k < NH; ++k) {
-          const int row = hrow0 + k * rsh, gr = t0 - 1 + row;
+          const int row = hrow0 + k * rsh, gr = t0 - PL + row;
           if (row < NR && (gr < 0 || gr >= L)) { zero_store4(hH, row * RSh + hch); zero_store4(hL, row * RSh + hch); }
         }
         if constexpr (RD) {
@@ -360,8 +363,10 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
       const int j = ks / QN, q = ks % QN;
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
-        if (UP2 && (mt & 1) != (j == 1 ? 0 : 1)) continue;   // even outputs: tap 1; odd outputs: taps 2 (row u) and 0 (row u + 1)
-        const int row = UP2 ? (mt >> 1) * 16 + r + (j == 0 ? 1 : 0) : (dg * MTW + mt) * 16 + r + 2 - j;
+        // stride 2, symmetric padding: even outputs tap 1 (row u), odd outputs taps 2 (row u) and 0 (row u + 1); causal padding (forward taps
+        // at 2u + j - 2): even outputs taps 2 (row u) and 0 (row u + 1), odd outputs tap 1 (row u + 1)
+        if (UP2 && (mt & 1) != ((j == 1) != (CZ != 0) ? 0 : 1)) continue;
+        const int row = UP2 ? (mt >> 1) * 16 + r + ((j == 0 || (CZ && j == 1)) ? 1 : 0) : (dg * MTW + mt) * 16 + r + 2 - j;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(gH + row * RSg + q * 32 + 8 * g);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(gL + row * RSg + q * 32 + 8 * g);
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, acc[mt], 0, 0, 0);
@@ -428,7 +433,7 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
 #pragma unroll
     for (int s = 0; s < TG / 32; ++s) {
       const int p0 = 32 * s + 8 * g + q4;   // this lane's address row (gradient-side position) of the first 4-position block
-      const int gr0 = UP2 ? p0 : p0 + 1;    // its gy window row
+      const int gr0 = UP2 ? p0 : p0 + 2 - PL;   // its gy window row (row 0 = position t0 + pad - 2)
       bf16x8 ah[IB], al[IB];
 #pragma unroll
       for (int i = 0; i < IB; ++i) {
@@ -453,7 +458,7 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
         }
       }
     }
-    if constexpr (RD) {   // dWd[o][c] += sum_u gpre[u][o] h[2u][c]: window row of position t0 + 2u is 2u + 1
+    if constexpr (RD) {   // dWd[o][c] += sum_u gpre[u][o] h[2u][c]: window row of position t0 + 2u is 2u + pad
 #pragma unroll
       for (int s = 0; s < TM / 64; ++s) {
         const int p0 = 32 * s + 8 * g + q4;
@@ -467,8 +472,8 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
           const int col = (wc * CB + c) * 16 + 4 * p4;
-          const bf16x8 bh = wb_tr8(hH + (2 * p0 + 1) * RSh + col, hH + (2 * (p0 + 4) + 1) * RSh + col);
-          const bf16x8 bl = wb_tr8(hL + (2 * p0 + 1) * RSh + col, hL + (2 * (p0 + 4) + 1) * RSh + col);
+          const bf16x8 bh = wb_tr8(hH + (2 * p0 + PL) * RSh + col, hH + (2 * (p0 + 4) + PL) * RSh + col);
+          const bf16x8 bl = wb_tr8(hL + (2 * p0 + PL) * RSh + col, hL + (2 * (p0 + 4) + PL) * RSh + col);
 #pragma unroll
           for (int i = 0; i < IB; ++i) {
             accd[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, accd[i][c], 0, 0, 0);
@@ -508,14 +513,14 @@ __device__ __forceinline__ void bwd_wide_body(const BwdWideP& P) {
 }
 
 // (two entry points over one body, as conv_wide.hip: the second without packed-fp32 instruction selection)
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD>
-__global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) { bwd_wide_body<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>(P); }
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD>
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD, int CZ>
+__global__ __launch_bounds__(64 * (NWC + 4)) void bwd_wide_kernel(BwdWideP P) { bwd_wide_body<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, CZ>(P); }
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2, int RD, int CZ>
 __global__ __launch_bounds__(64 * (NWC + 4)) __attribute__((target("no-packed-fp32-ops"))) void bwd_wide_np_kernel(BwdWideP P) {
-  bwd_wide_body<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>(P);
+  bwd_wide_body<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, CZ>(P);
 }
 
-template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0, int RD = 0>
+template <int CO, int CI, int HST, int MT, int NWC, int IB, int CB, int PD, int UP2 = 0, int RD = 0, int CZ = 0>
 static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
   constexpr int OC = CO * 16, HC = CI * 16, TM = 16 * MT, NR = TM + 2, NRG = UP2 ? TM / 2 + 1 : TM + 2, NRP = RD ? TM / 2 + 1 : 0;
   BwdWideP P = P0;
@@ -528,8 +533,8 @@ static int launch_bww(const BwdWideP& P0, int nslab, hipStream_t s, int dry) {
 #define W2S_BWW_NP 0   // tuning: 1 = the entry point without packed-fp32 selection
 #endif
   void (*kern)(BwdWideP);
-  if constexpr (W2S_BWW_NP) kern = bwd_wide_np_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>;
-  else kern = bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD>;
+  if constexpr (W2S_BWW_NP) kern = bwd_wide_np_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, CZ>;
+  else kern = bwd_wide_kernel<CO, CI, HST, MT, NWC, IB, CB, PD, UP2, RD, CZ>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return W2S_ELAUNCH;
@@ -544,7 +549,7 @@ extern "C" int w2s_bwd_wide_tile(int cg, int ch, int stride) {
 }
 extern "C" int w2s_bwd_wide_groups(int cg, int ch, int stride) { return !w2s_bwd_wide_tile(cg, ch, stride) ? 0 : (ch == 32) ? 2 : 1; }
 
-// One pass for the backward of a k=3 / symmetric-padding encoder conv with cg = 64 gradient-side channels: stride 1 with ch = 64 or 32
+// One pass for the backward of a k=3 encoder conv (pad: 1 = symmetric, 2 = causal left padding) with cg = 64 gradient-side channels: stride 1 with ch = 64 or 32
 // input-side channels, or stride 2 (the block's conv3: g = dL/d(block pre-activation), [B][L/2][cg]) with ch = 64.  L: input-side length.
 // w_hi / w_lo: the data-gradient operand planes (w2s_repack_batch bwd_hi / bwd_lo of the conv's weight).  part: [B][ntiles][groups][2][ch]
 // partial sums of gout and gout * n_in (rows = ntiles * groups for w2s_stats_finalize), or NULL.  slab: nslab slabs of cg * 3 * ch floats
@@ -556,8 +561,9 @@ extern "C" int w2s_bwd_wide_groups(int cg, int ch, int stride) { return !w2s_bwd
 extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, const float* bst_k, const float* xin, const float* st_in,
                             const float* add_even, const void* w_hi, const void* w_lo, float* gout, float* part, float* slab, int nslab, int B,
                             int L, int cg, int ch, int stride, const float* y3p, const float* st3p, const float* gpre, const void* wd_hi,
-                            const void* wd_lo, float* slab_d, int dry, void* stream) {
+                            const void* wd_lo, float* slab_d, int pad, int dry, void* stream) {
   if (!w2s_bwd_wide_tile(cg, ch, stride)) return 1;
+  if (pad != 1 && pad != 2) return dry ? 1 : W2S_EINVAL;
   const bool rd = gpre != nullptr;
   if (rd && (stride != 1 || st_in || add_even || (L & 1) || (!dry && (!wd_hi || !wd_lo || !slab_d)))) return dry ? 1 : W2S_EINVAL;
   if (stride == 2 && (!st_in || add_even || (L & 1) || y3p)) return dry ? 1 : W2S_EINVAL;
@@ -567,9 +573,9 @@ extern "C" int w2s_bwd_wide(const float* g, const float* y, const float* st_k, c
   static const char* off = getenv("W2S_NO_BWD_WIDE");   // tuning only
   if (off) return 1;
   BwdWideP P{g, y, st_k, bst_k, xin, st_in, add_even, static_cast<const __bf16*>(w_hi), static_cast<const __bf16*>(w_lo), gout, part, slab, y3p, st3p, gpre,
-             static_cast<const __bf16*>(wd_hi), static_cast<const __bf16*>(wd_lo), slab_d, B, L, L / stride, 0};
+             static_cast<const __bf16*>(wd_hi), static_cast<const __bf16*>(wd_lo), slab_d, B, L, L / stride, 0, pad};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (stride == 2) return launch_bww<4, 4, 1, 4, 4, 2, 2, 2, 1>(P, nslab, s, dry);
+  if (stride == 2) return pad == 2 ? launch_bww<4, 4, 1, 4, 4, 2, 2, 2, 1, 0, 1>(P, nslab, s, dry) : launch_bww<4, 4, 1, 4, 4, 2, 2, 2, 1>(P, nslab, s, dry);
   if (rd) return ch == 64 ? launch_bww<4, 4, 0, 4, 4, 2, 2, 2, 0, 1>(P, nslab, s, dry) : launch_bww<4, 2, 0, 4, 4, 2, 1, 2, 0, 1>(P, nslab, s, dry);
   if (ch == 64) return st_in ? launch_bww<4, 4, 1, 4, 4, 2, 2, 2>(P, nslab, s, dry) : launch_bww<4, 4, 0, 4, 4, 2, 2, 2>(P, nslab, s, dry);
   return st_in ? launch_bww<4, 2, 1, 4, 4, 2, 1, 2>(P, nslab, s, dry) : launch_bww<4, 2, 0, 4, 4, 2, 1, 2>(P, nslab, s, dry);

@@ -323,8 +323,8 @@ class Engine:
         return self._bstats(part, B, nt, ch, Lh)
 
     def _bwd_wide_ok(self, B, L, cg, ch, stride=1, hst=True):
-        """the one-pass backward of a 64-channel conv (csrc/bwd_wide.hip): split precision, symmetric padding; L = input-side length"""
-        return self.bwd_wide and self.split_precision and self.kpad == 1 and lib.bwd_wide_takes(B, L, cg, ch, stride, hst)
+        """the one-pass backward of a 64-channel conv (csrc/bwd_wide.hip): split precision, symmetric or causal padding; L = input-side length"""
+        return self.bwd_wide and self.split_precision and lib.bwd_wide_takes(B, L, cg, ch, stride, hst)
 
     def _bwd_wide(self, name, *, g, y, st_k, bst_k, xin, st_in, add_even, gout, want_part, B, L, cg, ch, stride=1, y3p=None, st3p=None,
                   gpre=None, down=None):
@@ -339,7 +339,7 @@ class Engine:
         dh, dl = self._bf[self.PB[down].data_ptr()] if gpre is not None else (None, None)
         slab_d = self._slab(dev, nslab, cg * ch) if gpre is not None else None
         lib.bwd_wide(g=g, y=y, st_k=st_k, bst_k=bst_k, xin=xin, st_in=st_in, add_even=add_even, w_hi=wh, w_lo=wl, gout=gout, part=part, slab=slab,
-                     nslab=nslab, B=B, L=L, cg=cg, ch=ch, stride=stride, y3p=y3p, st3p=st3p, gpre=gpre, wd_hi=dh, wd_lo=dl, slab_d=slab_d)
+                     nslab=nslab, B=B, L=L, cg=cg, ch=ch, stride=stride, y3p=y3p, st3p=st3p, gpre=gpre, wd_hi=dh, wd_lo=dl, slab_d=slab_d, pad=self.kpad)
         self._rjobs.append((slab, nslab, self.G[name], cg, ch, 3, 1, name in self._written, 0))
         self._written.add(name)
         if gpre is not None:
@@ -1149,7 +1149,7 @@ class Engine:
                 if not self.fold_gp:
                     bs3_folded = None
                 gpre, gpre_hdr = gprev, hp
-            elif (i > 0 and self.bwd_wide_rd and self.bwd_wide and self.split_precision and self.kpad == 1 and not (L & 1) and (p + 'downsample.weight') in self.G
+            elif (i > 0 and self.bwd_wide_rd and self.bwd_wide and self.split_precision and not (L & 1) and (p + 'downsample.weight') in self.G
                   and c >= 64 and self.PB[p + 'downsample.weight'].data_ptr() in self._bf
                   and self.PB[p + 'conv1.conv.weight'].data_ptr() in self._bf and lib.bwd_wide_takes(B, L, c, cin, 1, False, rd=True)):
                 # 64-channel conv1: the whole residual branch (Wd^T gpre into the data gradient, the downsample weight gradient) and the

@@ -396,14 +396,14 @@ def bwd_wide_takes(B, L, cg, ch, stride=1, hst=True, rd=False) -> bool:
     rd: with the residual branch folded in (gpre given)."""
     one = C.c_void_p(1)
     return load().w2s_bwd_wide(None, None, None, None, None, one if hst else None, None, None, None, None, None, None, 0, B, L, cg, ch, stride,
-                               None, None, one if rd else None, None, None, None, 1, None) == 0
+                               None, None, one if rd else None, None, None, None, 1, 1, None) == 0
 
 
 def bwd_wide(*, g, y, st_k, bst_k, xin, st_in, add_even, w_hi, w_lo, gout, part, slab, nslab, B, L, cg, ch, stride=1, y3p=None, st3p=None,
-             gpre=None, wd_hi=None, wd_lo=None, slab_d=None):
+             gpre=None, wd_hi=None, wd_lo=None, slab_d=None, pad=1):
     def run():
         _chk(load().w2s_bwd_wide(_f(g), _f(y), _f(st_k), _f(bst_k), _f(xin), _f(st_in), _f(add_even), _p(w_hi), _p(w_lo), _f(gout), _fp(part), _f(slab), nslab,
-                                 B, L, cg, ch, stride, _f(y3p), _f(st3p), _f(gpre), _p(wd_hi), _p(wd_lo), _f(slab_d), 0, _stream()),
+                                 B, L, cg, ch, stride, _f(y3p), _f(st3p), _f(gpre), _p(wd_hi), _p(wd_lo), _f(slab_d), pad, 0, _stream()),
              f'w2s_bwd_wide(cg={cg},ch={ch},stride={stride})')
     nbytes = 4 * (2 * B * (L // stride) * cg + 2 * B * L * ch + (B * L * ch // 2 if add_even is not None else 0) + (B * L * ch if y3p is not None else 0)
                   + (B * L * cg // 2 if gpre is not None else 0))
