@@ -287,6 +287,10 @@ class Engine:
         args = dict(g=g, x=x, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad, dil=dil,
                     split_precision=self.split_precision, **kw)
         gx = max(1, min(work, max(1, lib.wgrad_max_blocks(slab=None, nslab=0, **args) // gy)))
+        if cin >= 64 and cout >= 128 and L_out >= 1024:
+            # 128-channel encoder convs: a slab is 100-200 KB, written once and read once by the reduce -- at 256 workgroups that is 40-80 % on top
+            # of the kernel's own input.  128 workgroups halve it; the other streams use the CUs left over (docs/lab_notes_r5.md section 11)
+            gx = min(gx, 128)
         nslab = gx * lib.wgrad_slabs_per_block_of(slab=None, nslab=0, **args)
         slab = self._slab(g.device, nslab, cout * cin * taps)
         lib.wgrad(slab=slab, nslab=nslab, **args)
