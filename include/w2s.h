@@ -372,7 +372,7 @@ const char* w2s_version(void);
 /* Integer ABI number of this header: bumped whenever a signature or the meaning of an argument changes (round 5: 5).  The host refuses a
  * library whose number differs from the one it was written against (wav2sleep_amd/lib.py), so a stale build_alt/ or W2S_LIB library is
  * an error at load time instead of shifted arguments at call time. */
-#define W2S_ABI_VERSION 5
+#define W2S_ABI_VERSION 6
 int w2s_abi_version(void);
 
 /* ---- generic (untuned, inference) path: module variants outside the shipped production model (models/utils.py:26-96, ppgnet.py) ---- */

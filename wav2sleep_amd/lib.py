@@ -58,7 +58,7 @@ EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_conv_forward', 'w2s_wgrad', 'w2
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_token_masks', 'w2s_cls_scatter', 'w2s_copy_rows', 'w2s_zero', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version', 'w2s_abi_version']
 
-ABI_VERSION = 5   # include/w2s.h W2S_ABI_VERSION
+ABI_VERSION = 6   # include/w2s.h W2S_ABI_VERSION
 _lib = None
 
 
