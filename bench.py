@@ -422,9 +422,25 @@ def main():
         # BASELINE.json configs[3] (wav2sleep-eog: EOG-L + EOG-R at 4096 samples per epoch, ten-block encoders, 5 classes; hub.py:17-22,
         # settings.py:19-26) and the `causal: True` variant of the headline shape (scripts/config/main.yaml:22), each at batch 16 x 8 h on a
         # model of its own, after the headline's model has been released.  Driver-visible perf for the configs the suite only checks for parity
+        # inference forward of the headline model (api.predict -> model(x), api.py:179-183; eval mode, nothing saved), same batch
+        model.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                model(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(6):
+                model(x)
+            torch.cuda.synchronize()
+            dti = (time.perf_counter() - t0) / 6
+        fwd_bytes = 4 * sum(ELEMS_FWD[s] for s in SIGNAL_MAP) * (args.epochs / 960) * args.batch
+        inference = {'workload': f'{"+".join(SIGNAL_MAP)} {args.epochs}-epoch synthetic, batch {args.batch}, inference forward (eval mode)',
+                     'ms_per_batch': round(1000 * dti, 3), 'value': round(args.batch / dti, 3), 'unit': 'recordings/s', 'steps': 6, 'warmup': 2,
+                     'frac_of_hbm_peak': round(fwd_bytes / dti / 1e9 / HBM_PEAK_GBS, 4)}
         del trainer, model, x, y, out
         torch.cuda.empty_cache()
         line['extra'] = {
+            'inference_b16': inference,
             'configs3_eog_b16': extra_config(W, {'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, {'EOG-L': 4096, 'EOG-R': 4096}, 5, False, args.batch, args.epochs, dev, 2, 6),
             'causal_b16': extra_config(W, dict(SIGNAL_MAP), dict(SPE), 4, True, args.batch, args.epochs, dev, 3, 8)}
     if rank == 0 and world == 1 and not args.no_cpu:
