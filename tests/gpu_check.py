@@ -364,9 +364,13 @@ def t_rowops():
         report(f'layernorm bwd dgamma gelu={gelu}', dg, g.grad, tol=3e-4); report(f'layernorm bwd dbeta gelu={gelu}', db, b.grad, tol=3e-4)
 
 def t_attn():
-    N, D, H = 50, 5, 8; Fd = 128
+    for D in (5, 2, 3, 6, 7, 12):   # 2 .. 6: four lanes per (n, head); 7 .. 12: the sixteen-lane form (rowops.hip)
+        _attn_case(D)
+
+def _attn_case(D):
+    N, H = 50, 8; Fd = 128
     qkv = torch.randn(N * D, 3 * Fd, requires_grad=True)
-    pad = torch.zeros(N, D, dtype=torch.bool); pad[::3, 2] = True; pad[1::4, 4] = True
+    pad = torch.zeros(N, D, dtype=torch.bool); pad[::3, min(2, D - 1)] = True; pad[1::4, D - 1] = True
     q, k, v = qkv.view(N, D, 3, H, 16).permute(2, 0, 3, 1, 4)
     s = (q @ k.transpose(-1, -2)) / 4
     s = s.masked_fill(pad[:, None, None, :], float('-inf'))
@@ -375,22 +379,22 @@ def t_attn():
     od = torch.zeros(N * D, Fd, device=dev)
     kp = pad.to(torch.uint8).to(dev)
     lib.attn_fwd(qkv.detach().to(dev), kp, od, N, D, H)
-    report('attn fwd', od, o)
+    report(f'attn fwd D={D}', od, o)
     gq = torch.zeros(N * D, 3 * Fd, device=dev)
     lib.attn_bwd(qkv.detach().to(dev), kp, go.to(dev), gq, N, D, H)
-    report('attn bwd', gq, qkv.grad)
+    report(f'attn bwd D={D}', gq, qkv.grad)
     # token 0 as the only query (nq = 1; the last layer of the stack): its output row as before, the other rows untouched; backward = the full
     # kernel on a gradient that is zero off the CLS rows, with dropout on (same counter-based masks in both)
     for pdrop in (0.0, 0.1):
         full = torch.zeros(N * D, Fd, device=dev); lib.attn_fwd(qkv.detach().to(dev), kp, full, N, D, H, pdrop, 77)
         o1 = torch.full((N * D, Fd), 7.0, device=dev); lib.attn_fwd(qkv.detach().to(dev), kp, o1, N, D, H, pdrop, 77, nq=1)
-        RES.append((f'attn fwd nq=1 p={pdrop}: CLS rows bit-equal, other rows untouched',
+        RES.append((f'attn fwd D={D} nq=1 p={pdrop}: CLS rows bit-equal, other rows untouched',
                     torch.equal(o1.view(N, D, Fd)[:, 0], full.view(N, D, Fd)[:, 0]) and bool((o1.view(N, D, Fd)[:, 1:] == 7.0).all())))
         gcls = torch.zeros(N, D, Fd, device=dev); gcls[:, 0] = go.view(N, D, Fd)[:, 0].to(dev)
         g_full = torch.zeros(N * D, 3 * Fd, device=dev); lib.attn_bwd(qkv.detach().to(dev), kp, gcls.view(N * D, Fd), g_full, N, D, H, pdrop, 77)
         gcls[:, 1:] = float('nan')   # nq = 1 must not read the other rows
         g1 = torch.full((N * D, 3 * Fd), float('nan'), device=dev); lib.attn_bwd(qkv.detach().to(dev), kp, gcls.view(N * D, Fd), g1, N, D, H, pdrop, 77, nq=1)
-        RES.append((f'attn bwd nq=1 p={pdrop}: equals the full kernel on a CLS-only gradient', torch.equal(g1, g_full)))
+        RES.append((f'attn bwd D={D} nq=1 p={pdrop}: equals the full kernel on a CLS-only gradient', torch.equal(g1, g_full)))
 
 def t_head_optim():
     rows, Fd, nc = 700, 128, 5

@@ -9,6 +9,9 @@
 //   wgrad :  dW[o][j][c] = sum_t gy[t][o] h[t+j-1][c]
 // UP2 (the stride-2 conv3, g = dL/d(block pre-activation) at half the length): gy = instance-norm backward of g * GELU'(n_k) (W2S_PRO_INBWD_GP);
 //   dgrad: gout[2u] = W_1^T gy[u], gout[2u+1] = W_2^T gy[u] + W_0^T gy[u+1];  wgrad: dW[o][j][c] = sum_u gy[u][o] h[2u+j-1][c]
+// (written for symmetric padding, pad = 1.  Causal padding, pad = 2 -- the forward taps at t+j-2 / 2u+j-2, blocks.py:150-152,178-182 --
+//  shifts the windows: gy[t+2-j] and h[t+j-2] in the stride-1 form; stride 2 (template CZ): gout[2u] = W_2^T gy[u] + W_0^T gy[u+1],
+//  gout[2u+1] = W_1^T gy[u+1], dW from h[2u+j-2])
 //
 // Before: conv_wide (dgrad) and wgrad_wide each streamed g, y_k and xin, each ran the instance-norm backward on g, one evaluated GELU'
 // and the other GELU of the same n_in (two erf's) -- 7 tensor passes and twice the producer arithmetic for 4 passes' worth of work

@@ -177,19 +177,34 @@ __global__ void head_bwd_kernel(const float* __restrict__ pre, int ld, const flo
   float wf[W2S_MAXC], dw[W2S_MAXC], db[W2S_MAXC];
 #pragma unroll
   for (int c = 0; c < W2S_MAXC; ++c) { wf[c] = (c < nc) ? w[(size_t)c * F + f] : 0.f; dw[c] = 0.f; db[c] = 0.f; }
-  for (int r = r0; r < r1; ++r) {
-    const float p = pre[(size_t)r * ld + f];
-    const float feat = gelu_in ? gelu_f(p) : p;
-    float gf = 0.f;
+  // eight rows in flight (one dependent load pair per iteration left this kernel at 41 us for 8 MB: 64 L2 round trips in a row);
+  // the sums run over the rows in the same order as the plain loop
+  constexpr int U = 8;
+  for (int rb = r0; rb < r1; rb += U) {
+    float pv[U], gl[U][W2S_MAXC];
 #pragma unroll
-    for (int c = 0; c < W2S_MAXC; ++c)
-      if (c < nc) {
-        const float gl = glogits[(size_t)r * nc + c];
-        gf += gl * wf[c];
-        dw[c] += gl * feat;
-        db[c] += gl;
-      }
-    gpre[(size_t)r * ldg + f] = gelu_in ? gf * gelu_grad_f(p) : gf;
+    for (int u = 0; u < U; ++u) {
+      const int r = min(rb + u, r1 - 1);
+      pv[u] = pre[(size_t)r * ld + f];
+#pragma unroll
+      for (int c = 0; c < W2S_MAXC; ++c) gl[u][c] = (c < nc) ? glogits[(size_t)r * nc + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = rb + u;
+      if (r >= r1) break;
+      const float p = pv[u];
+      const float feat = gelu_in ? gelu_f(p) : p;
+      float gf = 0.f;
+#pragma unroll
+      for (int c = 0; c < W2S_MAXC; ++c)
+        if (c < nc) {
+          gf += gl[u][c] * wf[c];
+          dw[c] += gl[u][c] * feat;
+          db[c] += gl[u][c];
+        }
+      gpre[(size_t)r * ldg + f] = gelu_in ? gf * gelu_grad_f(p) : gf;
+    }
   }
   float* out = part + (size_t)blockIdx.x * (nc * F + nc);
 #pragma unroll

@@ -398,8 +398,129 @@ extern "C" int w2s_eltwise(int op, const float* a, const float* b, float* y, lon
 // attention-probability dropout (p) regenerated from (seed, index) in the backward.
 // Replaces F.scaled_dot_product_attention inside nn.MultiheadAttention (wav2sleep.py:286-296).
 // ------------------------------------------------------------------------------------------------
+// ---- D <= 6 tokens (every shipped map: 4 signals + CLS = 5, EOG pair = 3, single signal = 2): FOUR lanes per (n, head), four head
+// dimensions each -- 16-byte loads / stores, a dot product is 4 FMAs + two quad DPP steps.  The 16-lane form below (one dimension per lane:
+// dword accesses, four DPP steps per dot product) issued 4-5 x the wave instructions for the same bytes and ran at 2.2 TB/s; it stays
+// for 7 .. 12 tokens, where six [D] float4 arrays no longer fit the register file.  Same dropout indices, same masks.
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_f(v, 0);
+  v += dpp_f(v, 1);
+  return v;
+}
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
+
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ keypad,
+                                                       float* __restrict__ out, int N, int H, int nq, float p, uint64_t seed) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t pair = gid >> 2;  // (n, h); the four lanes of a quad share it, so a quad leaves together
+  const int e = (threadIdx.x & 3) * 4;
+  if (pair >= (size_t)N * H) return;
+  const int n = (int)(pair / H), h = (int)(pair % H);
+  const int F = H * 16, ld = 3 * F;
+  f32x4 q[D], k[D], v[D];
+  bool pad[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float* row = qkv + ((size_t)n * D + d) * ld + h * 16 + e;
+    q[d] = (d < nq) ? ld4(row) : (f32x4){0, 0, 0, 0};
+    k[d] = ld4(row + F); v[d] = ld4(row + 2 * F);
+    pad[d] = keypad[(size_t)n * D + d] != 0;
+  }
+#pragma unroll
+  for (int dq = 0; dq < D; ++dq) {
+    if (dq >= nq) break;   // (uniform) nq = 1: only token 0's output is read downstream (the last layer: wav2sleep.py:345 returns the CLS token)
+    float s[D];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int dk = 0; dk < D; ++dk) {
+      s[dk] = pad[dk] ? -INFINITY : quad_sum(dot4(q[dq], k[dk])) * 0.25f;
+      mx = fmaxf(mx, s[dk]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int dk = 0; dk < D; ++dk) { s[dk] = __expf(s[dk] - mx); den += s[dk]; }
+    const float inv = 1.0f / den;
+    f32x4 o = {0, 0, 0, 0};
+#pragma unroll
+    for (int dk = 0; dk < D; ++dk) {
+      float pr = s[dk] * inv;
+      if (p > 0.f) pr *= w2s_dropscale(seed, ((pair * D + dq) * D + dk), p);
+      o += pr * v[dk];
+    }
+    st4(out + ((size_t)n * D + dq) * F + h * 16 + e, o);
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ keypad,
+                                                       const float* __restrict__ gout, float* __restrict__ gqkv, int N, int H, int nq,
+                                                       float p, uint64_t seed) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t pair = gid >> 2;
+  const int e = (threadIdx.x & 3) * 4;
+  if (pair >= (size_t)N * H) return;
+  const int n = (int)(pair / H), h = (int)(pair % H);
+  const int F = H * 16, ld = 3 * F;
+  f32x4 q[D], k[D], v[D], go[D], dk_[D], dv_[D];
+  bool pad[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float* row = qkv + ((size_t)n * D + d) * ld + h * 16 + e;
+    const bool live = d < nq;   // (uniform) rows nobody read have no query gradient and their gout is never looked at
+    q[d] = live ? ld4(row) : (f32x4){0, 0, 0, 0};
+    k[d] = ld4(row + F); v[d] = ld4(row + 2 * F);
+    go[d] = live ? ld4(gout + ((size_t)n * D + d) * F + h * 16 + e) : (f32x4){0, 0, 0, 0};
+    pad[d] = keypad[(size_t)n * D + d] != 0;
+    dk_[d] = (f32x4){0, 0, 0, 0}; dv_[d] = (f32x4){0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int dq = 0; dq < D; ++dq) {
+    if (dq >= nq) {   // (uniform) a token whose output nobody read: its query gets no gradient and it adds nothing to the keys / values
+      st4(gqkv + ((size_t)n * D + dq) * ld + h * 16 + e, (f32x4){0, 0, 0, 0});
+      continue;
+    }
+    float pr[D], dp[D];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int d2 = 0; d2 < D; ++d2) {
+      pr[d2] = pad[d2] ? -INFINITY : quad_sum(dot4(q[dq], k[d2])) * 0.25f;
+      mx = fmaxf(mx, pr[d2]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int d2 = 0; d2 < D; ++d2) { pr[d2] = __expf(pr[d2] - mx); den += pr[d2]; }
+    const float inv = 1.0f / den;
+    float dot = 0.f;
+#pragma unroll
+    for (int d2 = 0; d2 < D; ++d2) {
+      pr[d2] *= inv;
+      const float m = (p > 0.f) ? w2s_dropscale(seed, ((pair * D + dq) * D + d2), p) : 1.0f;
+      // O = sum (P*m) V  =>  dV += (P*m) gO ; dP = m * (gO . V)
+      dv_[d2] += (pr[d2] * m) * go[dq];
+      dp[d2] = m * quad_sum(dot4(go[dq], v[d2]));
+      dot += pr[d2] * dp[d2];
+    }
+    f32x4 dqv = {0, 0, 0, 0};
+#pragma unroll
+    for (int d2 = 0; d2 < D; ++d2) {
+      const float ds = pr[d2] * (dp[d2] - dot) * 0.25f;  // dS (scaled)
+      dqv += ds * k[d2];
+      dk_[d2] += ds * q[dq];
+    }
+    st4(gqkv + ((size_t)n * D + dq) * ld + h * 16 + e, dqv);
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    float* row = gqkv + ((size_t)n * D + d) * ld + h * 16 + e;
+    st4(row + F, dk_[d]);
+    st4(row + 2 * F, dv_[d]);
+  }
+}
+
+// ---- 7 .. 12 tokens: sixteen lanes per (n, head), one head dimension each
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd16_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ keypad,
                                                        float* __restrict__ out, int N, int H, int nq, float p, uint64_t seed) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t pair = gid >> 4;  // (n, h)
@@ -441,7 +562,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ keypad,
+__global__ __launch_bounds__(256) void attn_bwd16_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ keypad,
                                                        const float* __restrict__ gout, float* __restrict__ gqkv, int N, int H, int nq,
                                                        float p, uint64_t seed) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -504,19 +625,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
-#define W2S_ATTN_DISPATCH(KERN, ...)                                                                 \
+#define W2S_ATTN_DISPATCH(KERN, KERN16, ...)                                                         \
   switch (D) {                                                                                       \
-    case 2: hipLaunchKernelGGL(KERN<2>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
-    case 3: hipLaunchKernelGGL(KERN<3>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
-    case 4: hipLaunchKernelGGL(KERN<4>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
-    case 5: hipLaunchKernelGGL(KERN<5>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
-    case 6: hipLaunchKernelGGL(KERN<6>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
-    case 7: hipLaunchKernelGGL(KERN<7>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
-    case 8: hipLaunchKernelGGL(KERN<8>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
-    case 9: hipLaunchKernelGGL(KERN<9>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;          \
-    case 10: hipLaunchKernelGGL(KERN<10>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;        \
-    case 11: hipLaunchKernelGGL(KERN<11>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;        \
-    case 12: hipLaunchKernelGGL(KERN<12>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;        \
+    case 2: hipLaunchKernelGGL(KERN<2>, dim3(blocks4), dim3(256), 0, s, __VA_ARGS__); break;         \
+    case 3: hipLaunchKernelGGL(KERN<3>, dim3(blocks4), dim3(256), 0, s, __VA_ARGS__); break;         \
+    case 4: hipLaunchKernelGGL(KERN<4>, dim3(blocks4), dim3(256), 0, s, __VA_ARGS__); break;         \
+    case 5: hipLaunchKernelGGL(KERN<5>, dim3(blocks4), dim3(256), 0, s, __VA_ARGS__); break;         \
+    case 6: hipLaunchKernelGGL(KERN<6>, dim3(blocks4), dim3(256), 0, s, __VA_ARGS__); break;         \
+    case 7: hipLaunchKernelGGL(KERN16<7>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;        \
+    case 8: hipLaunchKernelGGL(KERN16<8>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;        \
+    case 9: hipLaunchKernelGGL(KERN16<9>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;        \
+    case 10: hipLaunchKernelGGL(KERN16<10>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;      \
+    case 11: hipLaunchKernelGGL(KERN16<11>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;      \
+    case 12: hipLaunchKernelGGL(KERN16<12>, dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;      \
     default: return W2S_EINVAL;   /* 2 .. 12 tokens: six signals + CLS + five register tokens is all the reference's maps can ask for */ \
   }
 
@@ -524,8 +645,8 @@ extern "C" int w2s_attn_fwd(const float* qkv, const uint8_t* keypad, float* out,
                             void* stream) {
   if (!qkv || !keypad || !out || N <= 0 || H <= 0 || (nq != D && nq != 1)) return W2S_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const unsigned blocks = (unsigned)(((size_t)N * H * 16 + 255) / 256);
-  W2S_ATTN_DISPATCH(attn_fwd_kernel, qkv, keypad, out, N, H, nq, p_drop, seed)
+  const unsigned blocks = (unsigned)(((size_t)N * H * 16 + 255) / 256), blocks4 = (unsigned)(((size_t)N * H * 4 + 255) / 256);
+  W2S_ATTN_DISPATCH(attn_fwd_kernel, attn_fwd16_kernel, qkv, keypad, out, N, H, nq, p_drop, seed)
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
@@ -533,8 +654,8 @@ extern "C" int w2s_attn_bwd(const float* qkv, const uint8_t* keypad, const float
                             uint64_t seed, void* stream) {
   if (!qkv || !keypad || !gout || !gqkv || N <= 0 || H <= 0 || (nq != D && nq != 1)) return W2S_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const unsigned blocks = (unsigned)(((size_t)N * H * 16 + 255) / 256);
-  W2S_ATTN_DISPATCH(attn_bwd_kernel, qkv, keypad, gout, gqkv, N, H, nq, p_drop, seed)
+  const unsigned blocks = (unsigned)(((size_t)N * H * 16 + 255) / 256), blocks4 = (unsigned)(((size_t)N * H * 4 + 255) / 256);
+  W2S_ATTN_DISPATCH(attn_bwd_kernel, attn_bwd16_kernel, qkv, keypad, gout, gqkv, N, H, nq, p_drop, seed)
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
