@@ -749,7 +749,7 @@ class Engine:
 
         # ---- classifier
         g_pre = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-        nparts = max(1, min(256, _cdiv(rows, 64)))
+        nparts = max(1, min(1024, _cdiv(rows, 16)))   # 16 rows per block: two batches of eight rows in flight (head_optim.hip)
         part = torch.empty(nparts, nc * F + nc, device=dev, dtype=torch.float32)
         lib.head_bwd(c['pre_out'], F, P['classifier.weight'], glogits, g_pre, F, part, nparts, rows, F, nc, True)
         self._colsum(part, nparts, nc * F, self.G['classifier.weight'], accumulate='classifier.weight' in self._written, ld=nc * F + nc)
