@@ -72,6 +72,37 @@ def eog_fullsize_grad():
 
 
 @check
+def causal_fullsize_grad():
+    """`causal: True` (scripts/config/main.yaml:22; causal-padded convolutions, chunk_causal=False) at the benchmark's full length: 4 modalities x
+    960 epochs, B = 2, one missing (sample, modality) pair -- loss, arg-max labels and every gradient tensor vs the oracle.  Since round 5 the
+    64-channel layers of this variant run on the one-pass backward kernel (w2s_bwd_wide, pad = 2): this is its full-length case (61 440 / 30 720
+    positions per sample; the stage checks and goldens stop at a few thousand)."""
+    import wav2sleep_amd as W
+    from oracle import wav2sleep_oracle as O
+    torch.manual_seed(42)
+    model = W.Wav2Sleep(W.SignalEncoders(SM4, 128, 'gelu', norm='instance', causal=True, chunk_causal=False),
+                        W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.0, dim_ff=512, nhead=8),
+                        W.SequenceCNN(128, dropout=0.0, norm='layer', causal=True, num_layers=2, kernel_size=7, num_dilations=6), 4).to(DEV).train()
+    cfg = O.ModelConfig(signal_map=SM4, num_classes=4, causal=True)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x, y = O.make_inputs(cfg, 2, 960, seed=99, missing={'THX': [1]})
+    runs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        logits = model({k: v.to(DEV) for k, v in x.items()})
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, 4), y.to(DEV).reshape(-1).long(), ignore_index=-1)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append(model._flat_grad.clone())
+    want_loss, want_logits, want = O.loss_and_grads(sd, cfg, x, y)
+    worst, over = _grad_errors(model, want)
+    agree = float((logits.argmax(-1).cpu() == want_logits.argmax(-1)).float().mean())
+    return dict(bit_reproducible=torch.equal(runs[0], runs[1]), loss=float(loss), want_loss=float(want_loss), worst_tensor=worst[0],
+                worst_rel_l2=worst[1], over_1e3=over, argmax_agreement=agree,
+                max_abs_logit_err=float((logits.detach().cpu() - want_logits).abs().max()), max_abs_logit=float(want_logits.abs().max()))
+
+
+@check
 def b16_fullsize_grad():
     """The benchmark's own shape (4 modalities x 960 epochs, B = 16, default init, 6 missing (sample, modality) pairs): every gradient tensor of
     ONE backward pass vs the oracle accumulated over 8 micro-batches of 2 (sum_mb (valid_mb / valid_total) * grad(mean loss of mb))."""

@@ -74,6 +74,17 @@ def test_benchmark_shape_batch16_gradients_match_oracle(tmp_path):
     assert r['argmax_agreement'] >= 0.9999
 
 
+def test_causal_variant_full_length_gradients_match_oracle(tmp_path):
+    """`causal: True` at 4 modalities x 960 epochs, B = 2: the full-length case of the causal convolutions (their 64-channel layers on the
+    one-pass backward kernel with causal padding)."""
+    r = run_check('causal_fullsize_grad', tmp_path, 1200)
+    assert r['bit_reproducible'], r
+    assert r['loss'] == pytest.approx(r['want_loss'], rel=1e-4)
+    assert r['worst_rel_l2'] <= 2e-3, (r['worst_tensor'], r['worst_rel_l2'], r['over_1e3'])
+    assert r['max_abs_logit_err'] <= 1e-3 * r['max_abs_logit'], r
+    assert r['argmax_agreement'] >= 0.999, r
+
+
 def test_logits_do_not_depend_on_batch_neighbours_full_length(tmp_path):
     r = run_check('batch_invariance', tmp_path, 600)
     assert r['b32_vs_halves_equal'] and r['b5_vs_singles_equal'], r
