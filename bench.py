@@ -245,8 +245,8 @@ def extra_config(W, signal_map, spe, nc, causal, batch, epochs, dev, warmup=3, s
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)   # >= 20 timed steps after >= 5 warm-up
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--epochs', type=int, default=960)
     ap.add_argument('--no-cpu', action='store_true')
