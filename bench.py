@@ -58,6 +58,10 @@ def family_of(key):
     return 'other'
 
 
+FAMILY_KEYS = {'fused backward <=32ch (dgrad+wgrad)': 'bwd_le32', 'persistent forward <=32ch': 'fwd_le32', 'wide conv >=64ch (fwd + dgrad)': 'wide_ge64',
+               'fused backward 64ch (dgrad+wgrad)': 'bwd64_onepass', 'weight gradient >=64ch / k1 / dilated': 'wgrad', 'generic conv (1x1, dilated, downsample, UP2 dgrad)': 'generic_conv'}
+
+
 def step_traffic(profiles):
     """HBM bytes one step moves: the committed PMC bytes/launch x the committed kernel-trace launch counts (all kernels, not only the
     GEMM-shaped ones).  None when the two files are not both there."""
@@ -171,36 +175,66 @@ def cpu_baseline(epochs, num_classes, signal_map, budget_s=60.0):
                       f'oracle/wav2sleep_oracle.py on stock torch CPU ops'}
 
 
-def kappa_parity(model, signal_map, num_classes, epochs, dev):
+def kappa_parity(model, signal_map, num_classes, epochs, dev, causal=False):
     """Cohen's kappa between the HIP path's and the CPU oracle's stage predictions on ONE synthetic overnight recording (inference
     forward, same weights, same input), plus the logit errors: BASELINE.json's metric names kappa parity.  Checker use of oracle/."""
     from oracle import wav2sleep_oracle as O
     from wav2sleep_amd.stats import cohens_kappa
-    cfg = O.ModelConfig(signal_map=signal_map, num_classes=num_classes)
+    cfg = O.ModelConfig(signal_map=signal_map, num_classes=num_classes, causal=causal)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     x, _ = O.make_inputs(cfg, 1, epochs, seed=4321)
     was_training = model.training
     model.eval()
+    xd = {k: v.to(dev) for k, v in x.items()}
     with torch.no_grad():
-        got = model({k: v.to(dev) for k, v in x.items()}).cpu()
+        got = model(xd).cpu()
     model.train(was_training)
     want = O.forward(sd, cfg, x)
-    pg, pw = got.argmax(-1).flatten(), want.argmax(-1).flatten()
-    cm = torch.zeros(num_classes, num_classes, dtype=torch.int64)
-    cm.index_put_((pw, pg), torch.ones_like(pw), accumulate=True)
-    err = (got - want).abs()
-    # the label margin: how close the oracle's own top-2 logits are, in units of this build's logit error -- an epoch whose gap is within
-    # 10 x the error is one the next forward change could flip (the suite demands identical arg-max labels)
     top2 = want.topk(2, dim=-1).values
     gap = (top2[..., 0] - top2[..., 1]).flatten()
-    emax = float(err.max())
-    agree = pg == pw
-    margin = {'near_ties': int((gap < 10.0 * emax).sum()), 'near_tie_threshold': 10.0 * emax,
-              'min_top2_gap_among_agreeing': float(gap[agree].min()) if bool(agree.any()) else None,
-              'min_top2_gap': float(gap.min()), 'median_top2_gap': float(gap.median())}
-    return {**margin, 'kappa_build_vs_oracle': round(float(cohens_kappa(cm.numpy(), num_classes)), 6), 'argmax_agreement': round(float((pg == pw).float().mean()), 6),
-            'epochs_compared': int(pg.numel()), 'max_abs_logit_err': float(err.max()), 'max_abs_logit': float(want.abs().max()),
-            'max_rel_logit_err_elementwise': float((err / want.abs().clamp_min(1e-3 * float(want.abs().max()))).max()),
+    pw = want.argmax(-1).flatten()
+
+    def figures(got):
+        pg = got.argmax(-1).flatten()
+        cm = torch.zeros(num_classes, num_classes, dtype=torch.int64)
+        cm.index_put_((pw, pg), torch.ones_like(pw), accumulate=True)
+        err = (got - want).abs()
+        # the label margin: how close the oracle's own top-2 logits are, in units of this build's logit error -- an epoch whose gap is within
+        # 10 x the error is one the next forward change could flip (the suite demands identical arg-max labels)
+        emax = float(err.max())
+        agree = pg == pw
+        return {'near_ties': int((gap < 10.0 * emax).sum()), 'near_tie_threshold': 10.0 * emax,
+                'min_top2_gap_among_agreeing': float(gap[agree].min()) if bool(agree.any()) else None,
+                'kappa_build_vs_oracle': round(float(cohens_kappa(cm.numpy(), num_classes)), 6), 'argmax_agreement': round(float(agree.float().mean()), 6),
+                'flips': int((~agree).sum()), 'max_abs_logit_err': emax,
+                'max_rel_logit_err_elementwise': float((err / want.abs().clamp_min(1e-3 * float(want.abs().max()))).max())}
+
+    res = figures(got)
+    # the same weights and recording through the fp32-MFMA kernels (W2S_EXACT_FP32=1 is read when a model's engine is built): the mode whose
+    # error is ~5 x smaller, beside the default one (VERDICT r5 item 3; tests/child_checks.py `argmax_sweep` runs 16 seeds x 2 states of both)
+    import wav2sleep_amd as W
+    prev = os.environ.get('W2S_EXACT_FP32')
+    os.environ['W2S_EXACT_FP32'] = '1'
+    try:
+        m2 = W.Wav2Sleep(W.SignalEncoders(signal_map, 128, 'gelu', norm='instance', causal=causal, chunk_causal=False),
+                         W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.1, dim_ff=512, nhead=8),
+                         W.SequenceCNN(128, dropout=0.1, norm='layer', causal=causal, num_layers=2, kernel_size=7, num_dilations=6), num_classes)
+        m2.load_state_dict(sd)
+        m2.to(dev).eval()
+        with torch.no_grad():
+            got2 = m2(xd).cpu()
+        assert not m2._engine.split_precision
+        exact = figures(got2)
+        del m2
+    except Exception as e:   # (a causal bench model etc.: the default figures stand alone)
+        exact = {'error': repr(e)[:200]}
+    finally:
+        if prev is None:
+            os.environ.pop('W2S_EXACT_FP32', None)
+        else:
+            os.environ['W2S_EXACT_FP32'] = prev
+    return {**res, 'exact_fp32': exact, 'min_top2_gap': float(gap.min()), 'median_top2_gap': float(gap.median()),
+            'epochs_compared': int(pw.numel()), 'max_abs_logit': float(want.abs().max()),
             'weights': 'the bench model (reference default init, seed 42) after the timed steps', 'sample': f'1 recording x {epochs} epochs, inference forward'}
 
 
@@ -304,21 +338,30 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # The timed region: EXACTLY `steps` steps between two barrier + synchronize pairs (the driver's contract), measured twice over the same
+    # steps -- the host clock around the synchronised region (`value` / `ms_per_step`: it contains everything, host enqueue included) and a HIP
+    # event pair on the stream the steps are enqueued on (every step starts and ends on that stream: the encoder streams fork
+    # from it and join it) -- the device's own time for the same steps, reported beside it as a cross-check.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         out = trainer.step(x, y)
+    ev1.record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_ev = ev0.elapsed_time(ev1) * 1e-3
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, dt_ev], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        dt, dt_ev = float(t[0]), float(t[1])
     loss = float(out['loss'])
 
     line = {'metric': 'overnight-recordings/sec (train step, bs=16)', 'value': round(args.batch * world * args.steps / dt, 3), 'unit': 'recordings/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3),
+            'ms_per_step_hip_events': round(1000 * dt_ev / args.steps, 3), 'timing': 'host clock around barrier + synchronize (value, ms_per_step); HIP event pair on the launch stream over the same steps beside it',
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{len(SIGNAL_MAP)}-modality ({"+".join(SIGNAL_MAP)}) {args.epochs}-epoch ({args.epochs // 120} h) synthetic, {nc}-class, per-GPU batch {args.batch}, '
                                    f'full train step fwd+CE+bwd+clip+AdamW' + (', causal convolutions (causal: True)' if args.causal else ''), 'global_batch': args.batch * world, 'epochs': args.epochs,
@@ -395,6 +438,17 @@ def main():
                                 'traffic_over_algorithmic': round(f['traffic'] / f['bytes'], 3) if f['covered'] and pmc else None}
                             for n, f in sorted(fams.items(), key=lambda kv: -kv[1]['ms'])}
         roof['gemm_kernel_ms_per_step'] = round(total_ms, 3)
+        # the same facts as top-level scalars (a parser that drops nested objects keeps these): the family furthest below the HBM roof, the
+        # largest family, and every family's time / fraction / traffic ratio under a flat key
+        named = {n: f for n, f in roof['families'].items() if n != 'other'}
+        if named:
+            wn, wf = min(named.items(), key=lambda kv: kv[1]['frac'])
+            ln, lf = max(named.items(), key=lambda kv: kv[1]['ms'])
+            roof.update({'worst_family': wn, 'worst_family_ms': wf['ms'], 'worst_family_frac': wf['frac'], 'worst_family_traffic_ratio': wf['traffic_over_algorithmic'],
+                         'largest_family': ln, 'largest_family_ms': lf['ms'], 'largest_family_frac': lf['frac'], 'largest_family_traffic_ratio': lf['traffic_over_algorithmic']})
+            for n, f in named.items():
+                k = FAMILY_KEYS.get(n, re.sub(r'[^a-z0-9]+', '_', n.lower()).strip('_'))
+                roof[f'fam_{k}_ms'], roof[f'fam_{k}_frac'], roof[f'fam_{k}_traffic_ratio'] = f['ms'], f['frac'], f['traffic_over_algorithmic']
         # what the memory system gives a plain 1-read : 1-write stream on THIS box (torch's device copy of 1 GiB, HIP events): the
         # practical ceiling for these kernels -- the 8 TB/s `peak` is the spec number
         src = torch.empty(1 << 28, device=dev, dtype=torch.float32).normal_()
@@ -417,7 +471,7 @@ def main():
         with open(os.path.join(ROOT, 'gpurun_out', 'bench_launch_breakdown.json'), 'w') as f:
             json.dump({k: v for k, v in top}, f, indent=1)
     if rank == 0 and world == 1 and not args.no_cpu:
-        line['kappa_parity'] = kappa_parity(model, dict(SIGNAL_MAP), nc, args.epochs, dev)
+        line['kappa_parity'] = kappa_parity(model, dict(SIGNAL_MAP), nc, args.epochs, dev, causal=args.causal)
     if rank == 0 and world == 1 and not args.no_extra and not args.no_cpu and args.variant == 'cardio' and not args.causal:   # (tuning runs pass --no-cpu)
         # BASELINE.json configs[3] (wav2sleep-eog: EOG-L + EOG-R at 4096 samples per epoch, ten-block encoders, 5 classes; hub.py:17-22,
         # settings.py:19-26) and the `causal: True` variant of the headline shape (scripts/config/main.yaml:22), each at batch 16 x 8 h on a

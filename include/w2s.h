@@ -369,7 +369,7 @@ int w2s_causal_normalize_host(const double* x, long n, double sampling_freq, dou
                               double baseline_tau_seconds, double min_sigma, double* out, uint8_t* outlier);
 
 const char* w2s_version(void);
-/* Integer ABI number of this header: bumped whenever a signature or the meaning of an argument changes (round 5: 5).  The host refuses a
+/* Integer ABI number of this header: bumped whenever a signature or the meaning of an argument changes (round 5: 6; round 6: see the define).  The host refuses a
  * library whose number differs from the one it was written against (wav2sleep_amd/lib.py), so a stale build_alt/ or W2S_LIB library is
  * an error at load time instead of shifted arguments at call time. */
 #define W2S_ABI_VERSION 6

@@ -218,6 +218,70 @@ def five_mod_fullsize_forward():
 
 
 @check
+def argmax_sweep():
+    """How much room do the arg-max labels have?    16 seeds -- each its own default initialisation AND its own full-length
+    recording -- at two states of the weights (as initialised; after 10 AdamW steps at lr 1e-3, which move every weight by ~1e-2), in the
+    default split-precision mode and under W2S_EXACT_FP32=1: epochs whose label differs from the oracle's (flips), the oracle's top-2 gap at
+    every flip, epochs within 10 x the error of a tie, max |d logit|.  The oracle's forward is the same for both modes."""
+    import wav2sleep_amd as W
+    from oracle import wav2sleep_oracle as O
+    cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
+    S = 960
+    rows = []
+
+    def run_mode(exact, sd, xd):
+        if exact:
+            os.environ['W2S_EXACT_FP32'] = '1'
+        else:
+            os.environ.pop('W2S_EXACT_FP32', None)
+        m = build(W, SM4, 4)
+        m.load_state_dict(sd)
+        m.to(DEV).eval()
+        with torch.no_grad():
+            out = m(xd).cpu()
+        assert m._engine.split_precision == (not exact)
+        del m
+        return out
+
+    for seed in range(16):
+        torch.manual_seed(1000 + seed)
+        model = build(W, SM4, 4, dropout=0.1).to(DEV).train()
+        x, _ = O.make_inputs(cfg, 1, S, seed=7000 + seed)
+        xd = {k: v.to(DEV) for k, v in x.items()}
+        for state in ('init', 'trained'):
+            if state == 'trained':
+                tr = W.FusedTrainStep(model, lr=1e-3, scheduler=False)
+                xb, yb = O.make_inputs(cfg, 2, S, seed=8000 + seed)
+                xb = {k: v.to(DEV) for k, v in xb.items()}
+                for _ in range(10):
+                    tr.step(xb, yb.to(DEV))
+                torch.cuda.synchronize()
+                del tr
+            sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+            want = O.forward(sd, cfg, x)
+            top2 = want.topk(2, dim=-1).values
+            gap = (top2[..., 0] - top2[..., 1]).flatten()
+            for exact in (False, True):
+                got = run_mode(exact, sd, xd)
+                err = float((got - want).abs().max())
+                flip = (got.argmax(-1) != want.argmax(-1)).flatten()
+                rows.append(dict(seed=seed, state=state, mode='exact_fp32' if exact else 'bf16x3', flips=int(flip.sum()),
+                                 flip_gaps=[float(g) for g in gap[flip]], max_abs_err=err, max_abs_logit=float(want.abs().max()),
+                                 near_ties=int((gap < 10 * err).sum()), min_gap=float(gap.min()), median_gap=float(gap.median())))
+        del model
+    os.environ.pop('W2S_EXACT_FP32', None)
+    agg = {}
+    for mode in ('bf16x3', 'exact_fp32'):
+        for state in ('init', 'trained'):
+            rs = [r for r in rows if r['mode'] == mode and r['state'] == state]
+            agg[f'{mode}/{state}'] = dict(epochs=S * len(rs), flips=sum(r['flips'] for r in rs), near_ties=sum(r['near_ties'] for r in rs),
+                                          max_abs_err=max(r['max_abs_err'] for r in rs), max_rel_err=max(r['max_abs_err'] / r['max_abs_logit'] for r in rs),
+                                          worst_flip_gap_over_err=max([g / r['max_abs_err'] for r in rs for g in r['flip_gaps']], default=0.0),
+                                          min_gap=min(r['min_gap'] for r in rs))
+    return dict(summary=agg, rows=rows)
+
+
+@check
 def nccl_forced_collectives():
     """The RCCL + side-stream path on one GPU: FusedTrainStep with backend 'nccl', world size 1, W2S_FORCE_COLLECTIVES=1 against the same
     steps without any collective: flat gradient and parameters bit for bit (a SUM over one rank is the identity)."""

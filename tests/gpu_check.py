@@ -681,6 +681,75 @@ def t_bwd_wide():
                 report(f'bwd_wide {cg}->{ch} pad{pad} L{L} residual fold wgrad vs fp64 autograd', outs[1][2], want_gw, tol=3e-4)
     RES.append(('bwd_wide refuses a batch whose statistics tables do not fit its LDS', not lib.bwd_wide_takes(48, 640, 64, 64, 1, True) and lib.bwd_wide_takes(40, 640, 64, 64, 1, False)))
 
+def t_offset_channels():
+    """Channels with a large DC offset against their spread.  Since round 5 the on-load transforms use per-tile coefficient
+    forms -- n = x r + (-m r), gy = r g + (-r^2 s2) y + r (r s2 m - s1) -- whose absolute error in n is ~|m| r 2^-24 instead of the textbook
+    (x - m) r's ~|n| 2^-24.  An fp32 MEAN already carries |m| 2^-24, i.e. the same |m| r 2^-24 in n, whatever form follows: the coefficient
+    form can at most double what the fp32 statistics contract costs.  Measured here against fp64 for the forward statistics consumers
+    (persistent <= 32-channel kernel, role-split 64-channel kernel, generic kernel) and the instance-norm backward of the fused backward kernel,
+    beside the textbook fp32 form evaluated by torch on the same fp32 statistics; bar: <= 4 x the textbook form's error + the split-precision floor."""
+    B = 2
+    for ratio, mean, std in ((0, 0.0, 1.0), (30, 3.0, 0.1), (1e3, 100.0, 0.1), (1e4, 1000.0, 0.1)):
+        for (cin, cout, L, kind) in ((16, 16, 1500, 'fused'), (64, 64, 700, 'wide'), (16, 32, 600, 'generic')):
+            sign = torch.where(torch.arange(cin) % 2 == 0, 1.0, -1.0)
+            x = (torch.randn(B, L, cin) * std + mean * sign).to(dev)
+            x64 = x.double().cpu()
+            m64, v64 = x64.mean(1), x64.var(1, unbiased=False)
+            r64 = 1 / torch.sqrt(v64 + 1e-2)
+            st = torch.stack([m64, r64], -1).float().contiguous().to(dev)     # what w2s_stats_finalize hands a consumer: fp32 (mean, rstd)
+            w = torch.randn(cout, cin, 3) / math.sqrt(3 * cin)
+            conv64 = lambda n: cl(F.conv1d(F.gelu(n).transpose(1, 2), w.double(), padding=1))
+            want = conv64((x64 - m64[:, None]) * r64[:, None])
+            text = conv64(((x.cpu() - st[..., 0].cpu()[:, None]) * st[..., 1].cpu()[:, None]).double())   # textbook form in fp32 on the fp32 statistics
+            y = torch.zeros(B, L, cout, device=dev)
+            wp = pack_fwd(w).to(dev)
+            if kind == 'fused':
+                t = lib.conv_fwd_fused_tile(cin, cout, 1); part = torch.zeros(B, (L + t - 1) // t, 2, cout, device=dev)
+                lib.conv_fwd_fused(x=x, w=wp, st_in=st, w1=None, y=y, part=part, B=B, L_in=L, L_out=L, cin=cin, cout=cout, stride=1, pro=lib.PRO_IN_GELU, nwg=7)
+            else:
+                wh, wl = lib.frag_major_planes(wp.view(cout, 3 * cin)) if cin >= 32 else (None, None)
+                a = lib.conv_args(x=x, w=wp, w_hi=wh, w_lo=wl, y=y, B=B, L_in=L, L_out=L, cin=cin, cout=cout, taps=3, stride=1, pad=1, pro=lib.PRO_IN_GELU,
+                                  pro_stats=st, epi=lib.EPI_STATS)
+                t = lib.conv_tile_of(a); part = torch.zeros(B, (L + t - 1) // t, 2, cout, device=dev); lib.set_part(a, part)
+                lib.conv_forward(a)
+            scale = float(want.abs().max())
+            ek, et = float((y.double().cpu() - want).abs().max()), float((text - want).abs().max())
+            ok = ek <= 4 * et + 5e-5 * scale
+            RES.append((f'offset fwd {kind} ratio {ratio:g}', ok))
+            print(f'{"OK  " if ok else "FAIL"} offset |mean|/std {ratio:<6g} forward {kind:8s} {cin}->{cout}: kernel err {ek:.3e}, textbook-fp32 err {et:.3e} (scale {scale:.3e})', flush=True)
+        # instance-norm backward (W2S_PRO_INBWD) + the input-side IN + GELU of the fused backward kernel, both sides offset
+        cg = ch = 16; L = 1500
+        sign = torch.where(torch.arange(cg) % 2 == 0, 1.0, -1.0)
+        g = torch.randn(B, L, cg, device=dev) * 0.1
+        yk = (torch.randn(B, L, cg) * std + mean * sign).to(dev); xin = (torch.randn(B, L, ch) * std - mean * sign).to(dev)
+
+        def stats(t):
+            t64 = t.double().cpu()
+            return torch.stack([t64.mean(1), 1 / torch.sqrt(t64.var(1, unbiased=False) + 1e-2)], -1)
+        st64, sti64 = stats(yk), stats(xin)
+        st, sti = st64.float().contiguous().to(dev), sti64.float().contiguous().to(dev)
+        n64 = (yk.double().cpu() - st64[:, None, :, 0]) * st64[:, None, :, 1]
+        g64 = g.double().cpu()
+        bst64 = torch.stack([g64.mean(1), (g64 * n64).mean(1)], -1)          # the backward sums autograd's instance norm uses
+        bst = bst64.float().contiguous().to(dev)
+        w = torch.randn(cg, ch, 3) / math.sqrt(3 * ch)
+        wb = w.permute(1, 2, 0).contiguous().to(dev)
+        tile = lib.bwd_fused_tile(cg, ch, 1, False, True); nt = (L + tile - 1) // tile
+        gout = torch.zeros(B, L, ch, device=dev); part = torch.zeros(B, nt, 2, ch, device=dev)
+        ns = min(B * nt, 5); slab = torch.zeros(ns * cg * ch * 3, device=dev); gw = torch.zeros(cg, ch, 3, device=dev)
+        lib.bwd_fused(g=g, y=yk, st_k=st, bst_k=bst, pro=lib.PRO_INBWD, xin=xin, st_in=sti, add_even=None, wb=wb, gout=gout, part=part, slab=slab, nslab=ns,
+                      B=B, Lg=L, Lh=L, cg=cg, ch=ch, stride=1, split_precision=True)
+        lib.wgrad_reduce(slab, ns, gw, cg, ch, 3, 1, accumulate=False, layout=0)
+        want_gout, want_gw, _ = _bwd_wide_fp64(g, yk, st64, bst64, xin, sti64, None, w, 1)                          # fp64 statistics: the true values
+        text_gout, text_gw, _ = _bwd_wide_fp64(g, yk, st.cpu(), bst.cpu(), xin, sti.cpu(), None, w, 1)              # fp32-rounded statistics, exact arithmetic
+        for nm, got, want, text in (('gout', gout, want_gout, text_gout), ('wgrad', gw, want_gw, text_gw)):
+            scale = float(want.abs().max())
+            ek, et = float((got.cpu() - want).abs().max()), float((text - want).abs().max())
+            ok = ek <= 4 * et + 3e-4 * scale
+            RES.append((f'offset bwd {nm} ratio {ratio:g}', ok))
+            print(f'{"OK  " if ok else "FAIL"} offset |mean|/std {ratio:<6g} fused backward 16->16 {nm:5s}: kernel err {ek:.3e}, fp32-statistics err {et:.3e} (scale {scale:.3e})', flush=True)
+
+
 def t_grad_fp16_chain():
     """The fp16 gradient-chain forms of the fused backward kernels (gmode 1 / 2, include/w2s.h) against the fp32 kernels: a power-of-two
     scale and fp32 arithmetic make the relation EXACT -- fed with the dequantised fp16 gradient the fp32 kernel must give bit-identical
@@ -1016,7 +1085,7 @@ def t_plumbing():
     RES.append(('zero_', int(cm.abs().sum()) == 0 and float(g.abs().sum()) == 0.0))
 
 
-STAGES = dict(plumb=t_plumbing, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, part=t_stats_partition, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(plumb=t_plumbing, offset=t_offset_channels, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, part=t_stats_partition, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

@@ -101,3 +101,26 @@ def test_library_has_no_packed_fp32_instruction_with_src1_high_half_in_the_low_l
     n, bad = isa_audit.audit(lib.LIB_PATH)
     assert n > 100000, n          # the disassembly really saw the kernels
     assert not bad, bad[:10]
+
+
+def test_abi_number_of_header_and_host_agree():
+    """include/w2s.h's W2S_ABI_VERSION is duplicated by hand in wav2sleep_amd/lib.py (and compiled into the library): the three must move together."""
+    from wav2sleep_amd import lib
+    m = re.search(r'^#define\s+W2S_ABI_VERSION\s+(\d+)', open(HEADER).read(), re.M)
+    assert m, 'W2S_ABI_VERSION not found in include/w2s.h'
+    assert int(m.group(1)) == lib.ABI_VERSION
+    dll = lib.load()
+    assert dll.w2s_abi_version() == lib.ABI_VERSION
+
+
+def test_no_kernel_spills_beyond_the_allowed_list():
+    """Register spills are silent (the units built with `-mllvm -amdgpu-mfma-vgpr-form` hold their accumulators in the 256 architectural
+    VGPRs): every kernel's scratch size from the code-object metadata, against wav2sleep_amd/isa_audit.SCRATCH_ALLOWED."""
+    from wav2sleep_amd import isa_audit, lib
+    if not os.path.exists(isa_audit.READELF):
+        pytest.skip('llvm-readelf not in this image')
+    res = isa_audit.resources(lib.LIB_PATH)
+    assert len(res) > 300, len(res)   # the notes really list the kernels
+    hot = [k for k in res if 'bwd_fused_bf_kernel' in k or 'conv_fwd_bf_kernel' in k]
+    assert hot and all(res[k]['scratch'] == 0 for k in hot), [(k, res[k]) for k in hot if res[k]['scratch']]
+    assert not isa_audit.scratch_violations(lib.LIB_PATH), isa_audit.scratch_violations(lib.LIB_PATH)

@@ -111,6 +111,9 @@ class Engine:
         # OFF by default: 2.5 x the gradient error for 1.6 % is a trade a user should choose, not inherit
         self.grad_fp16 = os.environ.get('W2S_GRAD_FP16', '0') == '1'
         self.bwd_wide = True        # one-pass backward of the 64-channel convs (csrc/bwd_wide.hip)
+        # workgroup (= slab) caps of the weight-gradient launches with >= 64 x 128 channels: encoder convs (k = 3) / trunk linears (k = 1, or 4 strided taps)
+        self.enc_wgrad_cap = int(os.environ.get('W2S_ENC_WGRAD_CAP', '128'))
+        self.trunk_wgrad_cap = int(os.environ.get('W2S_TRUNK_WGRAD_CAP', '128'))
         self.bwd_wide_rd = True     # 64-channel conv1: residual branch folded into the one-pass kernel
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
@@ -289,8 +292,10 @@ class Engine:
         gx = max(1, min(work, max(1, lib.wgrad_max_blocks(slab=None, nslab=0, **args) // gy)))
         if cin >= 64 and cout >= 128 and L_out >= 1024:
             # 128-channel encoder convs: a slab is 100-200 KB, written once and read once by the reduce -- at 256 workgroups that is 40-80 % on top
-            # of the kernel's own input.  128 workgroups halve it; the other streams use the CUs left over (docs/lab_notes_r5.md section 11)
-            gx = min(gx, 128)
+            # of the kernel's own input.  128 workgroups halve it; the other streams use the CUs left over (docs/lab_notes_r5.md section 11).
+            # The same predicate matches the trunk's 76 800-row linears (in_proj, out_proj, linear1, linear2: slabs of 64-256 KB); their cap is
+            # a separate attribute so that the two can be measured apart (docs/lab_notes_r6.md)
+            gx = min(gx, self.enc_wgrad_cap if taps == 3 else self.trunk_wgrad_cap)
         nslab = gx * lib.wgrad_slabs_per_block_of(slab=None, nslab=0, **args)
         slab = self._slab(g.device, nslab, cout * cin * taps)
         lib.wgrad(slab=slab, nslab=nslab, **args)

@@ -90,6 +90,53 @@ def audit(path: str) -> tuple[int, list[tuple[str, str]]]:
     return seen, bad
 
 
+READELF = os.path.join(os.path.dirname(OBJDUMP), 'llvm-readelf')
+# Kernels that are ALLOWED scratch memory (bytes per lane), by mangled-name prefix.  Everything else must have none: several translation units
+# are built with `-mllvm -amdgpu-mfma-vgpr-form` (csrc/Makefile), which moves MFMA accumulators into the 256 architectural VGPRs -- a kernel
+# that outgrows them then spills silently.  The entries: two tile configurations of the generic conv that `pick_cfg` never selects (NT = 8 with
+# WN = 2; dead instantiations), the exact-fp32 16-channel fused backward (W2S_EXACT_FP32=1 only) and the 128-channel transposed data gradient
+# (12 B, measured round 4: the non-spilling tile was slower).
+SCRATCH_ALLOWED = {
+    '_Z14conv_cl_kernelILi8ELi4ELi3ELi3ELi1ELi2E': 320, '_Z14conv_cl_kernelILi8ELi4ELi4ELi4ELi1ELi2E': 320, '_Z14conv_cl_kernelILi8ELi4ELi7ELi1ELi0ELi2E': 320,
+    '_Z14conv_cl_kernelILi8ELi4ELi7ELi1ELi1ELi2E': 320, '_Z16bwd_fused_kernelILi1ELi1ELi4ELi0ELi1EE': 32, '_Z16conv_wide_kernelILi8ELi8ELi4ELi1ELi5ELi4ELi4ELi1ELi1E': 16,
+}
+
+
+def resources(path: str) -> dict[str, dict[str, int]]:
+    """kernel symbol -> {vgpr, agpr, sgpr, scratch (bytes per lane), spill (VGPRs), lds} from the code objects' metadata notes."""
+    if not os.path.exists(READELF):
+        raise RuntimeError(f'{READELF} not found: cannot read kernel resources of {path}')
+    out = {}
+    for _, blob in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix='.co', delete=False) as f:
+            f.write(blob)
+        try:
+            txt = subprocess.run([READELF, '--notes', f.name], capture_output=True, text=True, check=True).stdout
+        finally:
+            os.unlink(f.name)
+        for blk in txt.split('  - .agpr_count')[1:]:
+            blk = '.agpr_count' + blk
+
+            def num(key, blk=blk):
+                m = re.search(r'\.' + key + r':\s+(\d+)', blk)
+                return int(m.group(1)) if m else 0
+            m = re.search(r'^\s+\.name:\s+(\S+)', blk, re.M)
+            if m:
+                out[m.group(1)] = dict(vgpr=num('vgpr_count'), agpr=num('agpr_count'), sgpr=num('sgpr_count'), scratch=num('private_segment_fixed_size'),
+                                       spill=num('vgpr_spill_count'), lds=num('group_segment_fixed_size'))
+    return out
+
+
+def scratch_violations(path: str) -> list[tuple[str, int]]:
+    """[(kernel, scratch bytes)] of every kernel that uses scratch memory beyond SCRATCH_ALLOWED."""
+    bad = []
+    for k, r in resources(path).items():
+        lim = max([v for pfx, v in SCRATCH_ALLOWED.items() if k.startswith(pfx)], default=0)
+        if r['scratch'] > lim:
+            bad.append((k, r['scratch']))
+    return bad
+
+
 if __name__ == '__main__':
     import sys
     from wav2sleep_amd.lib import LIB_PATH
@@ -97,4 +144,8 @@ if __name__ == '__main__':
     print(f'{n} packed-fp32 instructions, {len(bad)} with the low lane reading the high half of src1')
     for sym, ins in bad:
         print(f'  {sym}: {ins}')
-    sys.exit(1 if bad else 0)
+    sv = scratch_violations(sys.argv[1] if len(sys.argv) > 1 else LIB_PATH)
+    print(f'{len(sv)} kernels with scratch memory beyond the allowed list')
+    for k, b in sv:
+        print(f'  {k}: {b} B per lane')
+    sys.exit(1 if (bad or sv) else 0)
