@@ -65,28 +65,8 @@ def test_default_init_forward_matches_reference_golden(mode, tag, B, S, seed, mi
     assert np.array_equal(lg.argmax(-1).numpy(), g[f'pred_{tag}'])
 
 
-def test_default_init_full_size_batch16_matches_oracle(mode):
-    """BASELINE configs[1] at full size: 4 modalities, 960 epochs, batch 16, the weights scripts/train.py starts from.  Oracle per recording
-    (a recording's logits do not depend on its batch neighbours: instance / layer norms only)."""
-    torch.manual_seed(0)
-    model = default_init_model().to(DEV).eval()
-    cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
-    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    B, S = 16, 960
-    x, _ = O.make_inputs(cfg, B, S, seed=99, missing={'ABD': [3], 'PPG': [3, 7], 'ECG': [11]})
-    with torch.no_grad():
-        got = model({k: v.to(DEV) for k, v in x.items()}).cpu()
-    agree, worst = [], dict(max_abs=0.0, max_rel_elementwise=0.0)
-    for b in range(B):
-        want = O.forward(sd, cfg, {k: v[b:b + 1] for k, v in x.items()})
-        e = logit_errors(got[b:b + 1].numpy(), want.numpy())
-        assert e['ok_maxnorm'] and e['ok_elementwise'], (b, e)
-        agree.append(float((got[b].argmax(-1) == want[0].argmax(-1)).float().mean()))
-        worst = {k: max(worst[k], e[k]) for k in worst}
-        srt = want[0].sort(-1).values
-        flips = (got[b].argmax(-1) != want[0].argmax(-1))
-        assert not bool(flips.any()), (b, int(flips.sum()), float((srt[..., -1] - srt[..., -2])[flips].max()))
-    note(f'full-size default-init B=16 [{mode}]: arg-max agreement {min(agree):.6f}, worst logit errors {worst}')
+# (test_default_init_full_size_batch16_matches_oracle[bf16x3 | exact_fp32] lives in tests/test_a_children_gpu.py since round 6: one child process
+#  shares the oracle's eight micro-batches with the B = 16 gradient check)
 
 
 def _flat_of(chunks, layout, total):
@@ -385,36 +365,9 @@ def test_scheduling_does_not_change_a_bit():
         assert torch.equal(grads[0], grads[k]), f'schedule {k} changed {int((grads[0] != grads[k]).sum())} gradient elements'
 
 
-@pytest.mark.parametrize('causal', [False, True])
-def test_full_size_gradients_match_oracle(causal):
-    """One full-size step (4 modalities x 960 epochs, B = 2, one missing modality, the default initialisation, no dropout): loss and EVERY
-    gradient tensor against the oracle's autograd -- the fused / persistent / role-split kernels at the lengths the benchmark runs them
-    (3871 tiles per recording in the first block), with symmetric and with causal padding."""
-    torch.manual_seed(42)
-    model = W.Wav2Sleep(W.SignalEncoders(SM4, 128, 'gelu', norm='instance', causal=causal, chunk_causal=False),
-                        W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.0, dim_ff=512, nhead=8),
-                        W.SequenceCNN(128, dropout=0.0, norm='layer', causal=causal, num_layers=2, kernel_size=7, num_dilations=6), 4).to(DEV).train()
-    cfg = O.ModelConfig(signal_map=SM4, num_classes=4, causal=causal)
-    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    B, S = 2, 960
-    x, y = O.make_inputs(cfg, B, S, seed=123, missing={'THX': [1]})
-    logits = model({k: v.to(DEV) for k, v in x.items()})
-    yl = y.to(DEV)
-    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, 4), yl.reshape(-1).long(), ignore_index=-1)
-    loss.backward()
-    want_loss, want_logits, want = O.loss_and_grads(sd, cfg, x, y)
-    assert float(loss) == pytest.approx(want_loss, rel=1e-4)
-    worst, bad = ('', 0.0), []
-    for name, p in model.named_parameters():
-        g, w = p.grad.detach().cpu(), want[name]
-        rel = float((g - w).norm() / (w.norm() + 1e-20))
-        if rel > worst[1]:
-            worst = (name, rel)
-        if rel > 5e-4:
-            print(f'   {name}: rel-L2 {rel:.2e}  |g| {float(w.norm()):.3e}')
-        bad = bad + [(name, rel)] if rel > 2e-3 else bad
-    assert not bad, bad
-    note(f'full-size gradients B=2 [causal={causal}]: loss {float(loss):.6f} vs oracle {want_loss:.6f}; worst tensor {worst[0]} rel-L2 {worst[1]:.2e}')
+# (round 6: test_full_size_gradients_match_oracle[False | True] -- one full-size step at B = 2 against the oracle's autograd -- removed as duplicates:
+#  the symmetric case is a sub-case of tests/test_a_children_gpu.py::test_benchmark_shape_batch16_gradients_match_oracle (same model and lengths,
+#  B = 16, six missing pairs), the causal case IS ::test_causal_variant_full_length_gradients_match_oracle (same seed, batch and mask))
 
 
 def test_full_size_gradients_are_bit_reproducible():
