@@ -210,6 +210,45 @@ def t_wgrad():
             lib.wgrad_reduce(slab, nslab, gw, cout, cin, taps, dil)
             report(f'wgrad bf16x3 {cin}->{cout} k{taps} s{stride} d{dil}', gw, w.grad, tol=3e-4)
 
+def t_wgrad_pipelined():
+    """Round 6: the software-pipelined form of the split-precision tile-split weight gradient (wgrad_bf_pf_kernel: k = 1 / tap-split launches
+    without a gradient-side transform -- the trunk's linears, the SequenceCNN convs, the encoders' dense layer and 1x1 joins) against the
+    unpipelined kernel (W2S_NO_WGRAD_PF=1, read per launch): same products in the same order => bit for bit; and against fp64."""
+    cases = [  # cin, cout, taps, stride, dil, pad, B, L_out, pro_h, grid.x
+        (128, 384, 1, 1, 1, 0, 1, 3000, lib.PRO_NONE, 7), (128, 512, 1, 1, 1, 0, 1, 2049, lib.PRO_NONE, 5), (128, 128, 1, 1, 1, 0, 1, 4100, lib.PRO_NONE, 9),
+        (128, 128, 4, 4, 1, 0, 1, 1500, lib.PRO_NONE, 6), (128, 128, 7, 1, 4, 12, 3, 333, lib.PRO_NONE, 4), (128, 128, 7, 1, 32, 96, 2, 960, lib.PRO_NONE, 8),
+        (128, 128, 4, 4, 1, 0, 3, 200, lib.PRO_GELU, 3), (64, 128, 1, 2, 1, 0, 2, 700, lib.PRO_GELU, 5), (128, 256, 1, 1, 1, 0, 1, 1000, lib.PRO_NONE, 2),
+        (64, 64, 1, 2, 1, 0, 2, 900, lib.PRO_GELU, 5), (128, 128, 1, 1, 1, 0, 1, 20, lib.PRO_NONE, 1)]
+    for (cin, cout, taps, stride, dil, pad, B, Lo, pro_h, gx) in cases:
+        L_in = Lo * stride
+        g = torch.randn(B, Lo, cout, device=dev); x = torch.randn(B, L_in, cin, device=dev) * 1.5
+        gyd = lib.wgrad_grid_y(cin, cout, taps, dil)
+        nslab = gx * lib.wgrad_slabs_per_block(cin, cout, taps, dil)
+        outs = []
+        for nopf in ('1', None):
+            if nopf:
+                os.environ['W2S_NO_WGRAD_PF'] = nopf
+            else:
+                os.environ.pop('W2S_NO_WGRAD_PF', None)
+            slab = torch.full((nslab * cout * cin * taps,), float('nan'), device=dev)
+            lib.wgrad(g=g, x=x, slab=slab, nslab=nslab, B=B, L_in=L_in, L_out=Lo, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad, dil=dil, pro_h=pro_h,
+                      split_precision=True)
+            gw = torch.zeros(cout, cin, taps, device=dev)
+            lib.wgrad_reduce(slab, nslab, gw, cout, cin, taps, dil)
+            torch.cuda.synchronize()
+            outs.append((slab.clone(), gw))
+        os.environ.pop('W2S_NO_WGRAD_PF', None)
+        tag = f'wgrad pipelined {cin}->{cout} k{taps} s{stride} d{dil} B{B} L{Lo} pro_h{pro_h}'
+        RES.append((tag + ' slabs bit-equal', bool(torch.equal(outs[0][0], outs[1][0]))))
+        print(f'{"OK  " if RES[-1][1] else "FAIL"} {tag} slabs bit-equal to the unpipelined kernel', flush=True)
+        h = (F.gelu(x.double().cpu()) if pro_h == lib.PRO_GELU else x.double().cpu())
+        hp = F.pad(h, (0, 0, pad, pad + taps * dil * stride))
+        want = torch.zeros(cout, cin, taps, dtype=torch.float64)
+        for j in range(taps):
+            rows = torch.arange(Lo) * stride + j * dil        # window row of output position t, tap j (origin -pad)
+            want[:, :, j] = torch.einsum('bto,btc->oc', g.double().cpu(), hp[:, rows, :])
+        report(tag + ' vs fp64', outs[1][1], want.float(), tol=3e-4)
+
 def t_conv_wide_up2():
     """transposed stride-2 form of conv_wide_kernel (data gradient of the stride-2 conv3, >= 64 channels), symmetric and causal padding:
     gout = (W^T (x) gy) * GELU'(IN(aux)), gy = IN-backward(g * GELU'(n3); y3) -- against the autograd of F.conv1d in fp64."""
@@ -1085,7 +1124,7 @@ def t_plumbing():
     RES.append(('zero_', int(cm.abs().sum()) == 0 and float(g.abs().sum()) == 0.0))
 
 
-STAGES = dict(plumb=t_plumbing, offset=t_offset_channels, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, part=t_stats_partition, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(plumb=t_plumbing, offset=t_offset_channels, wgpf=t_wgrad_pipelined, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, part=t_stats_partition, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

@@ -51,6 +51,20 @@ def wgrad_case(cin, cout, L, stride=1, taps=3, B=16, pro_g=lib.PRO_INBWD, pro_h=
                            taps=taps, stride=stride, pad=1 if taps == 3 else 0, pro_g=pro_g, pro_h=pro_h, split_precision=os.environ.get('BF') == '1')
     return fn, 4 * (B * Lo * cout * 2 + B * L * cin), 2 * B * Lo * cout * cin * taps
 
+def wgrad_trunk_case(cin, cout, rows, taps=1, stride=1, B=1, dil=1, pad=0, pro_h=lib.PRO_NONE, cap=None):
+    """weight gradients of the trunk (no gradient-side transform): the transformer's linears over `rows` token rows (taps = 1, or the 512-wide
+    input of linear2 as 4 strided taps), the SequenceCNN's dilated convs (B x rows, 7 taps)"""
+    L_in = rows * stride if taps == stride and taps > 1 else rows
+    g = torch.randn(B, rows, cout, device=dev); x = torch.randn(B, L_in, cin, device=dev)
+    gy = lib.wgrad_grid_y(cin, cout, taps, dil)
+    cap = int(os.environ.get('WGCAP', 128 if cap is None else cap))
+    gx = max(1, min((B * rows + 255) // 256, max(1, 512 // gy), cap)); nslab = gx * lib.wgrad_slabs_per_block(cin, cout, taps, dil)
+    slab = torch.empty(nslab * cout * cin * taps, device=dev)
+    fn = lambda: lib.wgrad(g=g, x=x, slab=slab, nslab=nslab, B=B, L_in=L_in, L_out=rows, cin=cin, cout=cout, taps=taps, stride=stride, pad=pad, dil=dil,
+                           pro_h=pro_h, split_precision=True)
+    return fn, 4 * (B * rows * cout + B * L_in * cin), 2 * B * rows * cout * cin * taps
+
+
 def elt_case(op, n=16 * 983040 * 16):
     a = torch.randn(n, device=dev); b = torch.randn(n, device=dev); y = torch.empty(n, device=dev)
     nb = 4 * n * (3 if op == lib.ELT_ADD else 2)
@@ -183,6 +197,14 @@ CASES = {
     'w128': lambda: wgrad_case(128, 128, 15360),
     'w64s2': lambda: wgrad_case(64, 64, 61440, stride=2, pro_g=lib.PRO_INBWD_GP),
     'w128s2': lambda: wgrad_case(128, 128, 15360, stride=2, pro_g=lib.PRO_INBWD_GP),
+    'wqkv': lambda: wgrad_trunk_case(128, 384, 76800),
+    'wff1': lambda: wgrad_trunk_case(128, 512, 76800),
+    'wproj': lambda: wgrad_trunk_case(128, 128, 76800),
+    'wff2': lambda: wgrad_trunk_case(128, 128, 76800, taps=4, stride=4),
+    'wff1c': lambda: wgrad_trunk_case(128, 512, 15360),
+    'wseq1': lambda: wgrad_trunk_case(128, 128, 960, taps=7, B=16, dil=1, pad=3, cap=512),
+    'wseq32': lambda: wgrad_trunk_case(128, 128, 960, taps=7, B=16, dil=32, pad=96, cap=512),
+    'wdense': lambda: wgrad_trunk_case(128, 128, 960, taps=4, stride=4, B=16, pro_h=lib.PRO_GELU, cap=512),
     'qkv': lambda: conv_case(128, 384, 76800, B=1, taps=1, pro=lib.PRO_NONE, epi=lib.EPI_BIAS),
     'ff1': lambda: conv_case(128, 512, 76800, B=1, taps=1, pro=lib.PRO_NONE, epi=lib.EPI_BIAS),
     'proj': lambda: conv_case(128, 128, 76800, B=1, taps=1, pro=lib.PRO_NONE, epi=lib.EPI_BIAS),

@@ -8,6 +8,7 @@
 // its own quarter of the positions.  Every wave then writes its accumulators as one raw-fragment slab;
 // w2s_wgrad_reduce sums the slabs in a fixed order (deterministic) and scatters to torch layout [o][c][j].
 // blockIdx.y enumerates (output-channel tile, tap group) so accumulators stay <= 32 tiles (128 VGPRs).
+#include <cstdlib>
 #include "w2s_common.h"
 
 struct WgradP {
@@ -387,6 +388,105 @@ __global__ __launch_bounds__(NW * 64) void wgrad_bf_kernel(WgradP P) {
     for (int j = 0; j < JT; ++j) st4(out + (((ogrp * OW + i) * JT + j) * CT + ctile) * 256, acc[i][j]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 6: the same kernel SOFTWARE-PIPELINED for the k = 1 / tap-split weight gradients without a gradient-side transform (the set-fusion
+// transformer's linears over 76 800 token rows, the SequenceCNN's dilated convs, the encoders' dense layer and 1x1 joins): wgrad_bf_kernel
+// above runs  load -> wait -> split -> LDS -> barrier -> MFMA -> barrier  per tile, and with 384-512 gradient channels a tile is ONE 32-position
+// K step -- every 1500-cycle matrix phase waited for its own HBM round trip first (in_proj's weight gradient: 110 us for 157 MB).  Here the
+// raw rows of tile i + 1 are requested (unconditional loads from clamped rows: no branch around the vector-memory queue) right after tile
+// i's windows have been committed to LDS, and land while tile i runs through the matrix cores.  TM is a compile-time constant (register
+// arrays); same products in the same order, same slab layout: results are bit-identical to wgrad_bf_kernel's.
+// ------------------------------------------------------------------------------------------------------------------
+template <int OW, int CT, int NW, int STRIDE, int TM>
+__global__ __launch_bounds__(NW * 64) void wgrad_bf_pf_kernel(WgradP P) {
+  extern __shared__ f32x4 smem4[];
+  const w2s_wgrad_args& a = P.a;
+  constexpr int NT = NW * 64, OGR = NW / CT, WG = OGR * OW * 16, HC = CT * 16;
+  constexpr int RSg = WG + 8, RSh = HC + 8;
+  constexpr int c4g = WG / 4, c4h = HC / 4;
+  constexpr int NG = (TM * c4g + NT - 1) / NT, NH = (TM * c4h + NT - 1) / NT;   // float4s per thread and tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+  const int oy = blockIdx.y / P.ntg, tg = blockIdx.y % P.ntg;
+  const int o0 = oy * WG, j0 = tg;
+  __bf16* gH = reinterpret_cast<__bf16*>(smem4);
+  __bf16* gL = gH + TM * RSg;
+  __bf16* hH = gL + TM * RSg;
+  __bf16* hL = hH + TM * RSh;
+  const int ctile = wave % CT, ogrp = wave / CT;
+  const int pro_h = a.pro_h;   // NONE or GELU (no statistics): uniform
+
+  f32x4 acc[OW];
+#pragma unroll
+  for (int i = 0; i < OW; ++i) acc[i] = (f32x4){0, 0, 0, 0};
+
+  f32x4 rg[NG], rh[NH];
+  const int total = a.B * P.ntiles;
+  auto prefetch = [&](int tl) {
+    const int b = tl / P.ntiles, t0 = (tl - b * P.ntiles) * TM;
+    const float* gb = a.g + (size_t)b * a.L_out * a.ldg + o0;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int f = min(tid + k * NT, TM * c4g - 1), row = f / c4g, ch = (f - row * c4g) * 4;
+      rg[k] = ld4o(gb, (unsigned)min(t0 + row, a.L_out - 1) * (unsigned)a.ldg + ch);
+    }
+    const float* xb = a.x + (size_t)b * a.L_in * a.ldx;
+    const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int f = min(tid + k * NT, TM * c4h - 1), row = f / c4h, ch = (f - row * c4h) * 4;
+      rh[k] = ld4o(xb, (unsigned)min(max(rb + row * STRIDE, 0), a.L_in - 1) * (unsigned)a.ldx + ch);
+    }
+  };
+  auto commit = [&](int tl) {
+    const int b = tl / P.ntiles, t0 = (tl - b * P.ntiles) * TM;
+    const f32x4 z = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int f = tid + k * NT, row = f / c4g, ch = (f - row * c4g) * 4;
+      if (f < TM * c4g) split_store4(gH, gL, row * RSg + ch, (t0 + row < a.L_out) ? rg[k] : z);
+    }
+    const int rb = t0 * STRIDE - a.pad + j0 * a.dil;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int f = tid + k * NT, row = f / c4h, ch = (f - row * c4h) * 4, gr = rb + row * STRIDE;
+      if (f < TM * c4h) {
+        const f32x4 v = (pro_h == W2S_PRO_GELU) ? gelu4(rh[k]) : rh[k];
+        split_store4(hH, hL, row * RSh + ch, (gr >= 0 && gr < a.L_in) ? v : z);
+      }
+    }
+  };
+
+  int tl = blockIdx.x;
+  if (tl < total) prefetch(tl);
+  for (; tl < total; tl += gridDim.x) {
+    __syncthreads();   // the previous tile's fragment reads are done
+    commit(tl);
+    if (tl + (int)gridDim.x < total) prefetch(tl + gridDim.x);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TM / 32; ++s) {
+      const int p0 = 32 * s + 8 * g + q4;
+      const int hcol = ctile * 16 + 4 * p4;
+      const bf16x8 bh = tr_read8(hH + p0 * RSh + hcol, hH + (p0 + 4) * RSh + hcol);
+      const bf16x8 bl = tr_read8(hL + p0 * RSh + hcol, hL + (p0 + 4) * RSh + hcol);
+#pragma unroll
+      for (int i = 0; i < OW; ++i) {
+        const int col = (ogrp * OW + i) * 16 + 4 * p4;
+        const bf16x8 ah = tr_read8(gH + p0 * RSg + col, gH + (p0 + 4) * RSg + col);
+        const bf16x8 al = tr_read8(gL + p0 * RSg + col, gL + (p0 + 4) * RSg + col);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[i], 0, 0, 0);
+      }
+    }
+  }
+  constexpr int TILES = OGR * OW * CT;
+  float* out = a.slab + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * TILES) * 256 + lane * 4;
+#pragma unroll
+  for (int i = 0; i < OW; ++i) st4(out + ((ogrp * OW + i) * CT + ctile) * 256, acc[i]);
+}
+
 // sum slabs in a fixed order (16 slab-lanes x sequential chunks, then a fixed LDS tree); decode the fragment
 // index to (o, j, c); write torch layout grad[o][c][j] (layout 0) or [o][j][c] (layout 1).  Deterministic.
 // One block = 256 consecutive slab elements (64 lanes x float4: a wave reads 1 KB contiguous runs of ONE slab; the earlier
@@ -497,6 +597,13 @@ static int launch_wgrad_ts(const w2s_wgrad_args& a, hipStream_t s) {
   return W2S_OK;
 }
 
+// positions per tile of wgrad_bf_kernel with one tap per block: the largest of 128 / 64 / 32 whose two windows (bf16 hi + lo) fit 76 KB
+__host__ __device__ constexpr int wgbf_tm(int wg, int cin) {
+  return (128 * (wg + 8 + cin + 8) * 4 <= 76 * 1024) ? 128 : (64 * (wg + 8 + cin + 8) * 4 <= 76 * 1024) ? 64 : 32;
+}
+#ifndef W2S_WGRAD_PF
+#define W2S_WGRAD_PF 1   // tuning: 0 = every launch on the unpipelined kernel
+#endif
 template <int OW, int JT, int CT, int NW, int STRIDE, int PG, int PH>
 static int launch_wgrad_bf(const w2s_wgrad_args& a, hipStream_t s) {
   WgradP P;
@@ -515,6 +622,20 @@ static int launch_wgrad_bf(const w2s_wgrad_args& a, hipStream_t s) {
   P.ntg = a.taps / JT;
   dim3 grid(a.nslab, (a.cout / WG) * P.ntg);
   size_t lds = lds_of(TM);
+  if constexpr (JT == 1 && PG < 0 && W2S_WGRAD_PF) {
+    // no gradient-side transform, input side plain or GELU (no statistics): the software-pipelined form (same results bit for bit)
+    constexpr int TMC = wgbf_tm(WG, CT * 16);
+    const char* off = getenv("W2S_NO_WGRAD_PF");   // tuning / the bit-equality check of tests/gpu_check.py `wgrad` (read per launch on purpose)
+    if (!off && a.pro_g == W2S_PRO_NONE && (a.pro_h == W2S_PRO_NONE || a.pro_h == W2S_PRO_GELU) && TM == TMC) {
+      auto kpf = wgrad_bf_pf_kernel<OW, CT, NW, STRIDE, TMC>;
+      if (lds > 64 * 1024 &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(kpf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return W2S_ELAUNCH;
+      hipLaunchKernelGGL(kpf, grid, dim3(NW * 64), lds, s, P);
+      W2S_CHECK_LAUNCH();
+      return W2S_OK;
+    }
+  }
   auto kern = wgrad_bf_kernel<OW, JT, CT, NW, STRIDE, PG, PH>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
