@@ -277,17 +277,42 @@ def five_mod_fullsize_forward():
                 worst_floored_rel=float((err / (want.abs() + 0.2 * scale)).max()))
 
 
+def _oracle_forward(job):
+    """Runs in a spawned worker process that never touches the GPU: the oracle's inference forward of one recording."""
+    sd, cfg, x, threads = job
+    torch.set_num_threads(threads)
+    from oracle import wav2sleep_oracle as O
+    return O.forward(sd, cfg, x)
+
+
 @check
 def argmax_sweep():
     """How much room do the arg-max labels have?    16 seeds -- each its own default initialisation AND its own full-length
     recording -- at two states of the weights (as initialised; after 10 AdamW steps at lr 1e-3, which move every weight by ~1e-2), in the
     default split-precision mode and under W2S_EXACT_FP32=1: epochs whose label differs from the oracle's (flips), the oracle's top-2 gap at
-    every flip, epochs within 10 x the error of a tie, max |d logit|.  The oracle's forward is the same for both modes."""
+    every flip, epochs within 10 x the error of a tie, max |d logit|.  The oracle's forward is the same for both modes; the 32 oracle
+    forwards run in worker processes (started before this process touches the GPU) beside the GPU work."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
     import wav2sleep_amd as W
     from oracle import wav2sleep_oracle as O
     cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
-    S = 960
-    rows = []
+    S, NSEED = 960, 16
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)
+    workers = max(1, min(4, cores // 8))
+    threads = max(1, min(16, cores // workers))
+    pool = cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn'))
+    # ---- CPU only so far: every seed's default initialisation and recording; their oracle forwards start now (this spawns all the workers)
+    models, xs, futs = [], [], {}
+    for seed in range(NSEED):
+        torch.manual_seed(1000 + seed)
+        models.append(build(W, SM4, 4, dropout=0.1))
+        x, _ = O.make_inputs(cfg, 1, S, seed=7000 + seed)
+        xs.append(x)
+    for seed in range(NSEED):
+        sd = {k: v.detach().clone() for k, v in models[seed].state_dict().items()}
+        futs[(seed, 'init')] = (pool.submit(_oracle_forward, (sd, cfg, xs[seed], threads)), sd)
+    assert len(futs) >= workers   # (every worker process exists before the first GPU call below)
 
     def run_mode(exact, sd, xd):
         if exact:
@@ -303,11 +328,11 @@ def argmax_sweep():
         del m
         return out
 
-    for seed in range(16):
-        torch.manual_seed(1000 + seed)
-        model = build(W, SM4, 4, dropout=0.1).to(DEV).train()
-        x, _ = O.make_inputs(cfg, 1, S, seed=7000 + seed)
-        xd = {k: v.to(DEV) for k, v in x.items()}
+    # ---- GPU side
+    got = {}
+    for seed in range(NSEED):
+        model = models[seed].to(DEV).train()
+        xd = {k: v.to(DEV) for k, v in xs[seed].items()}
         for state in ('init', 'trained'):
             if state == 'trained':
                 tr = W.FusedTrainStep(model, lr=1e-3, scheduler=False)
@@ -317,19 +342,29 @@ def argmax_sweep():
                     tr.step(xb, yb.to(DEV))
                 torch.cuda.synchronize()
                 del tr
-            sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-            want = O.forward(sd, cfg, x)
+                sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+                futs[(seed, state)] = (pool.submit(_oracle_forward, (sd, cfg, xs[seed], threads)), sd)
+            sd = futs[(seed, state)][1]
+            for exact in (False, True):
+                got[(seed, state, exact)] = run_mode(exact, sd, xd)
+        models[seed] = None
+        del model
+    os.environ.pop('W2S_EXACT_FP32', None)
+    # ---- compare
+    rows = []
+    for seed in range(NSEED):
+        for state in ('init', 'trained'):
+            want = futs[(seed, state)][0].result()
             top2 = want.topk(2, dim=-1).values
             gap = (top2[..., 0] - top2[..., 1]).flatten()
             for exact in (False, True):
-                got = run_mode(exact, sd, xd)
-                err = float((got - want).abs().max())
-                flip = (got.argmax(-1) != want.argmax(-1)).flatten()
+                g = got[(seed, state, exact)]
+                err = float((g - want).abs().max())
+                flip = (g.argmax(-1) != want.argmax(-1)).flatten()
                 rows.append(dict(seed=seed, state=state, mode='exact_fp32' if exact else 'bf16x3', flips=int(flip.sum()),
-                                 flip_gaps=[float(g) for g in gap[flip]], max_abs_err=err, max_abs_logit=float(want.abs().max()),
+                                 flip_gaps=[float(v) for v in gap[flip]], max_abs_err=err, max_abs_logit=float(want.abs().max()),
                                  near_ties=int((gap < 10 * err).sum()), min_gap=float(gap.min()), median_gap=float(gap.median())))
-        del model
-    os.environ.pop('W2S_EXACT_FP32', None)
+    pool.shutdown()
     agg = {}
     for mode in ('bf16x3', 'exact_fp32'):
         for state in ('init', 'trained'):
@@ -338,7 +373,7 @@ def argmax_sweep():
                                           max_abs_err=max(r['max_abs_err'] for r in rs), max_rel_err=max(r['max_abs_err'] / r['max_abs_logit'] for r in rs),
                                           worst_flip_gap_over_err=max([g / r['max_abs_err'] for r in rs for g in r['flip_gaps']], default=0.0),
                                           min_gap=min(r['min_gap'] for r in rs))
-    return dict(summary=agg, rows=rows)
+    return dict(summary=agg, rows=rows, oracle_workers=workers, oracle_threads=threads)
 
 
 @check

@@ -113,7 +113,7 @@ class Engine:
         self.bwd_wide = True        # one-pass backward of the 64-channel convs (csrc/bwd_wide.hip)
         # workgroup (= slab) caps of the weight-gradient launches with >= 64 x 128 channels: encoder convs (k = 3) / trunk linears (k = 1, or 4 strided taps)
         self.enc_wgrad_cap = int(os.environ.get('W2S_ENC_WGRAD_CAP', '128'))
-        self.trunk_wgrad_cap = int(os.environ.get('W2S_TRUNK_WGRAD_CAP', '128'))
+        self.trunk_wgrad_cap = int(os.environ.get('W2S_TRUNK_WGRAD_CAP', '256'))   # (256 since the trunk's launches run on the pipelined kernel: lab notes r6)
         self.bwd_wide_rd = True     # 64-channel conv1: residual branch folded into the one-pass kernel
         self._cnt = {}   # measured neutral (its extra read ~ the pre-pass it saves): off
         self._cjobs = []
