@@ -96,6 +96,9 @@ int w2s_conv_tile(const w2s_conv_args* a);
 int w2s_conv_forward(const w2s_conv_args* a, void* stream);
 /* out4 = (NT, MT, WN, effective MODE) of the generic kernel instance that launch would use (profiling / bookkeeping only) */
 int w2s_conv_cfg(const w2s_conv_args* a, int32_t* out4);
+/* 1: w2s_conv_forward(a) runs on the persistent pipelined GEMM of the transformer's row-wise linears (csrc/linear_pf.hip: cin 128 per chunk,
+ * cout 128..512, no on-load transform, bias epilogue with its W2S_FUSE_* fusions; bit-identical to the generic kernel) -- bookkeeping only */
+int w2s_linear_pf_takes(const w2s_conv_args* a);
 
 /*
  * Weight gradient: dW[o][j][c] = sum_{b,t} GY(g)[b,t,o] * H(x)[b, t*stride + j*dil - pad, c]
@@ -369,10 +372,10 @@ int w2s_causal_normalize_host(const double* x, long n, double sampling_freq, dou
                               double baseline_tau_seconds, double min_sigma, double* out, uint8_t* outlier);
 
 const char* w2s_version(void);
-/* Integer ABI number of this header: bumped whenever a signature or the meaning of an argument changes (round 5: 6; round 6: see the define).  The host refuses a
+/* Integer ABI number of this header: bumped whenever a signature or the meaning of an argument changes (round 5: 6; round 6: 7).  The host refuses a
  * library whose number differs from the one it was written against (wav2sleep_amd/lib.py), so a stale build_alt/ or W2S_LIB library is
  * an error at load time instead of shifted arguments at call time. */
-#define W2S_ABI_VERSION 6
+#define W2S_ABI_VERSION 7
 int w2s_abi_version(void);
 
 /* ---- generic (untuned, inference) path: module variants outside the shipped production model (models/utils.py:26-96, ppgnet.py) ---- */

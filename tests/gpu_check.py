@@ -249,6 +249,53 @@ def t_wgrad_pipelined():
             want[:, :, j] = torch.einsum('bto,btc->oc', g.double().cpu(), hp[:, rows, :])
         report(tag + ' vs fp64', outs[1][1], want.float(), tol=3e-4)
 
+def t_linear_pipelined():
+    """Round 6: the persistent pipelined GEMM of the transformer's row-wise linears (csrc/linear_pf.hip) against the generic tile kernel it
+    replaces (W2S_NO_LINEAR_PF=1, read per launch): every fusion of the bias epilogue, the strided CLS-row layouts, K = 384 / 512 as 3 / 4
+    chunks, ragged row counts -- same products in the same order => bit for bit -- and one case against fp64."""
+    cases = [  # rows, K, N, fuse, bias, drop_p, ldx, ldy, ld_aux
+        (3000, 128, 384, 0, True, 0.0, 128, 384, 0),                          # in_proj
+        (2049, 128, 128, lib.FUSE_ADD_DROP, True, 0.1, 128, 128, 128),        # out_proj + residual + dropout
+        (1500, 128, 128, lib.FUSE_ADD_DROP, True, 0.1, 640, 128, 640),        # ... on the CLS rows of a [N, 5, 128] tensor
+        (4100, 128, 512, lib.FUSE_Y2_GELU_DROP, True, 0.1, 128, 512, 0),      # linear1 -> (f1, dropout(GELU))
+        (2500, 512, 128, lib.FUSE_ADD_DROP, True, 0.0, 128, 128, 128),        # linear2 (four 128-wide chunks) + residual
+        (2500, 128, 512, lib.FUSE_GELU_BWD_DROP, False, 0.1, 128, 512, 512),  # data gradient of linear2 x GELU'(f1) x mask
+        (1000, 512, 128, 0, False, 0.0, 128, 128, 0),                         # data gradient of linear1
+        (1300, 384, 128, 0, False, 0.0, 128, 128, 0),                         # data gradient of in_proj (three chunks)
+        (700, 128, 128, 0, False, 0.0, 128, 640, 0),                          # data gradient of out_proj into the CLS rows (strided output)
+        (257, 128, 256, 0, True, 0.0, 128, 256, 0)]
+    for (rows, K, N, fuse, bias, drop_p, ldx, ldy, ld_aux) in cases:
+        taps = K // 128
+        x = torch.randn(rows * taps, ldx, device=dev) if taps > 1 else torch.randn(rows, ldx, device=dev)
+        w = (torch.randn(N, K, device=dev) / math.sqrt(K)).contiguous()
+        wh, wl = lib.frag_major_planes(w)
+        b = torch.randn(N, device=dev) if bias else None
+        aux = torch.randn(rows, ld_aux, device=dev) if ld_aux else None
+        outs = []
+        for nopf in ('1', None):
+            if nopf:
+                os.environ['W2S_NO_LINEAR_PF'] = nopf
+            else:
+                os.environ.pop('W2S_NO_LINEAR_PF', None)
+            y = torch.full((rows, ldy), float('nan'), device=dev)
+            y2 = torch.full((rows, N), float('nan'), device=dev) if fuse & lib.FUSE_Y2_GELU_DROP else None
+            a = lib.conv_args(x=x, w=w, w_hi=wh, w_lo=wl, y=y, y2=y2, ldy2=N, B=1, L_in=rows * taps, L_out=rows, cin=128, cout=N, taps=taps, stride=taps, pad=0,
+                              mode=lib.MODE_DILATED if taps > 1 else lib.MODE_CONTIG, ldx=ldx, ldy=ldy, epi=lib.EPI_BIAS, bias=b, aux=aux, ld_aux=ld_aux,
+                              fuse=fuse, drop_p=drop_p, drop_seed=12345)
+            takes = bool(lib.load().w2s_linear_pf_takes(__import__('ctypes').byref(a)))
+            lib.conv_forward(a)
+            torch.cuda.synchronize()
+            outs.append((y[:, :N].clone(), None if y2 is None else y2.clone(), takes))
+        os.environ.pop('W2S_NO_LINEAR_PF', None)
+        tag = f'linear pipelined rows {rows} K {K} N {N} fuse {fuse} ldx {ldx} ldy {ldy}'
+        RES.append((tag + ' is taken', outs[1][2] and not outs[0][2]))
+        ok = bool(torch.equal(outs[0][0], outs[1][0])) and (outs[0][1] is None or bool(torch.equal(outs[0][1], outs[1][1]))) and not bool(torch.isnan(outs[1][0]).any())
+        RES.append((tag + ' bit-equal', ok))
+        print(f'{"OK  " if ok and RES[-2][1] else "FAIL"} {tag}: bit-equal to the generic kernel (taken: {outs[1][2]})', flush=True)
+        if fuse == 0 and ldx == 128:
+            want = x.double().cpu().view(rows, K) @ w.double().cpu().t() + (b.double().cpu() if bias else 0.0)
+            report(tag + ' vs fp64', outs[1][0], want.float(), tol=1e-4)
+
 def t_conv_wide_up2():
     """transposed stride-2 form of conv_wide_kernel (data gradient of the stride-2 conv3, >= 64 channels), symmetric and causal padding:
     gout = (W^T (x) gy) * GELU'(IN(aux)), gy = IN-backward(g * GELU'(n3); y3) -- against the autograd of F.conv1d in fp64."""
@@ -1124,7 +1171,7 @@ def t_plumbing():
     RES.append(('zero_', int(cm.abs().sum()) == 0 and float(g.abs().sum()) == 0.0))
 
 
-STAGES = dict(plumb=t_plumbing, offset=t_offset_channels, wgpf=t_wgrad_pipelined, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, part=t_stats_partition, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(plumb=t_plumbing, offset=t_offset_channels, wgpf=t_wgrad_pipelined, linpf=t_linear_pipelined, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, part=t_stats_partition, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

@@ -15,6 +15,7 @@ int w2s_conv_dispatch_33d(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_dispatch_up2(const w2s_conv_args& a, hipStream_t s);
 int w2s_conv_tile_impl(int cin, int cout, int taps, int stride, int mode, int B, int L_out);
 int w2s_conv_wide_try(const w2s_conv_args& a, hipStream_t s, int dry);   // conv_wide.hip: 1 = not a wide-kernel shape
+int w2s_linear_pf_try(const w2s_conv_args& a, hipStream_t s, int dry);   // linear_pf.hip: 1 = not one of the transformer's row-wise linears
 void w2s_conv_cfg_impl(int cin, int cout, int taps, int stride, int mode, int B, int L_out, int dil, int* out3);
 
 // (NT, MT, WN) template arguments and the effective MODE of the conv_cl_kernel instance w2s_conv_forward(a) launches (profiling keys)
@@ -60,6 +61,7 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
     if ((a.reserved & (W2S_FUSE_ADD_DROP | W2S_FUSE_GELU_BWD_DROP)) && !a.aux) return W2S_EINVAL;
     if ((a.reserved & W2S_FUSE_Y2_GELU_DROP) && !a.y2) return W2S_EINVAL;
   }
+  { const int rc = w2s_linear_pf_try(a, s, 0); if (rc != 1) return rc; }   // the transformer's linears: persistent pipelined GEMM (linear_pf.hip)
   if (a.mode == W2S_MODE_UP2) {
     if (a.taps != 3 || a.stride != 2 || (a.pad != 1 && a.pad != 2)) return W2S_EINVAL;  // pad 2 = gradient of the causal-padded conv
     { const int rc = w2s_conv_wide_try(a, s, 0); if (rc != 1) return rc; }   // >= 64 channels: persistent role-split kernel

@@ -52,13 +52,13 @@ class WgradArgs(C.Structure):
                                     'pro_g', 'pro_h', 'nslab', 'split_precision')]
 
 
-EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
+EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_linear_pf_takes', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
            'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_bwd_fused_wd', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
            'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_token_masks', 'w2s_cls_scatter', 'w2s_copy_rows', 'w2s_zero', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_version', 'w2s_abi_version']
 
-ABI_VERSION = 6   # include/w2s.h W2S_ABI_VERSION
+ABI_VERSION = 7   # include/w2s.h W2S_ABI_VERSION
 _lib = None
 
 
@@ -238,6 +238,8 @@ def conv_forward(a: ConvArgs):
         if DETAIL:
             key += f' L{a.L_out}'
         return _timed(key, nbytes, flops, run)
+    if load().w2s_linear_pf_takes(C.byref(a)):   # the transformer's row-wise linears (csrc/linear_pf.hip)
+        return _timed('linear_pf_kernel' + (f' {a.cin * a.taps}->{a.cout} L{a.L_out}' if DETAIL else ''), nbytes, flops, run)
     cfg = (C.c_int32 * 4)()
     _chk(load().w2s_conv_cfg(C.byref(a), cfg), 'w2s_conv_cfg')
     nt, mt, wn, mode = cfg[0], cfg[1], cfg[2], cfg[3]
