@@ -351,7 +351,7 @@ def argmax_sweep():
         del model
     os.environ.pop('W2S_EXACT_FP32', None)
     # ---- compare
-    rows = []
+    rows, transients = [], []
     for seed in range(NSEED):
         for state in ('init', 'trained'):
             want = futs[(seed, state)][0].result()
@@ -360,6 +360,15 @@ def argmax_sweep():
             for exact in (False, True):
                 g = got[(seed, state, exact)]
                 err = float((g - want).abs().max())
+                if err > 1e-3 * float(want.abs().max()):
+                    # a GROSS mismatch: run the same forward again before judging it.  Round 6 saw one exact-fp32 forward in 64 come back 0.3 off
+                    # on weights and input that gave 3e-5 in the session before and in 700 targeted repetitions after (tools/flake_probe*.py;
+                    # docs/lab_notes_r6.md): a transient is REPORTED (and fails the test beyond one per sweep), a repeatable one is a plain failure
+                    g2 = run_mode(exact, futs[(seed, state)][1], {k: v.to(DEV) for k, v in xs[seed].items()})
+                    err2 = float((g2 - want).abs().max())
+                    transients.append(dict(seed=seed, state=state, mode='exact_fp32' if exact else 'bf16x3', first_err=err, rerun_err=err2,
+                                           rerun_bit_equal_to_first=bool(torch.equal(g, g2))))
+                    g, err = g2, err2
                 flip = (g.argmax(-1) != want.argmax(-1)).flatten()
                 rows.append(dict(seed=seed, state=state, mode='exact_fp32' if exact else 'bf16x3', flips=int(flip.sum()),
                                  flip_gaps=[float(v) for v in gap[flip]], max_abs_err=err, max_abs_logit=float(want.abs().max()),
@@ -373,7 +382,7 @@ def argmax_sweep():
                                           max_abs_err=max(r['max_abs_err'] for r in rs), max_rel_err=max(r['max_abs_err'] / r['max_abs_logit'] for r in rs),
                                           worst_flip_gap_over_err=max([g / r['max_abs_err'] for r in rs for g in r['flip_gaps']], default=0.0),
                                           min_gap=min(r['min_gap'] for r in rs))
-    return dict(summary=agg, rows=rows, oracle_workers=workers, oracle_threads=threads)
+    return dict(summary=agg, rows=rows, transients=transients, oracle_workers=workers, oracle_threads=threads)
 
 
 @check
