@@ -183,14 +183,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
   // one exposed L2 round trip; cin = 32 (one K step per tap) keeps the single slot.
   bf16x8 pah[2][NTW], pal[2][NTW];
   const int NSTEP = TAPS * (cin >> 5);
+  // (round 6) wave-uniform 64-bit bases of this wave's first fragment row + one 32-bit BYTE offset per lane and K step: the fetch of a
+  // step is `base + (nt * NSTEP + kidx) KB + 16 lane` -- the first cut recomputed a 64-bit element index per load (~10 vector instructions
+  // each, 1100 of the 1500 per wave of a SequenceCNN conv: profiles/r06 counters)
+  const char* wfh = reinterpret_cast<const char*>(static_cast<const __bf16*>(a.w_hi) + (size_t)((n0 + wn0) / 16) * (K >> 5) * 512);
+  const char* wfl = reinterpret_cast<const char*>(static_cast<const __bf16*>(a.w_lo) + (size_t)((n0 + wn0) / 16) * (K >> 5) * 512);
   auto load_frag = [&](auto SLOT, int kidx_) {
     constexpr int SL = decltype(SLOT)::value;
     const int kidx = min(kidx_, NSTEP - 1);   // no branch around the loads (a conditional load makes hipcc wait vmcnt(0) everywhere)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-      const size_t wo = ((size_t)((n0 + wn0) / 16 + nt) * (K >> 5) + (size_t)kidx) * 512 + lane * 8;
-      pah[SL][nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_hi) + wo);
-      pal[SL][nt] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.w_lo) + wo);
+      const unsigned wo = ((unsigned)(nt * (K >> 5) + kidx) << 10) + ((unsigned)lane << 4);
+      pah[SL][nt] = *reinterpret_cast<const bf16x8*>(wfh + wo);
+      pal[SL][nt] = *reinterpret_cast<const bf16x8*>(wfl + wo);
     }
   };
   using WS0 = std::integral_constant<int, 0>; using WS1 = std::integral_constant<int, 1>;

@@ -303,14 +303,33 @@ __device__ __forceinline__ void w2s_amax_commit(float* hdr, float amax, float sc
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hdr[0] = scale;
 }
 
-// counter-based RNG for dropout: splitmix64 of (seed, element index) -> uniform [0,1).  The same
-// (seed, index) regenerates the same mask in the backward pass; nothing is stored.
+// counter-based RNG for dropout: a hash of (seed, element index) -> uniform [0,1).  The same (seed, index) regenerates the same mask in
+// the backward pass; nothing is stored.  Round 6: rounds 1-5 used splitmix64 -- three 64 x 64-bit multiplies per ELEMENT, i.e. ~30 of
+// gfx950's quarter-rate 32-bit integer multiplies; the epilogue of linear1 (39 M masks per step) and of its backward GEMM spent more issue
+// slots on the generator than on GELU.  Now: the element index (< 2^32 for every tensor here: the launchers refuse larger ones) times the
+// golden ratio plus the seed's low word through murmur3's 32-bit finaliser (full avalanche), with the seed's high word (the step counter's
+// upper bits: uniform per launch, folded on the scalar unit) added between its two multiplies -- three multiplies per element.
+// -DW2S_DROPOUT_SPLITMIX=1: the old generator (other masks, same statistics).
+#ifndef W2S_DROPOUT_SPLITMIX
+#define W2S_DROPOUT_SPLITMIX 0
+#endif
 __device__ __forceinline__ float w2s_uniform(uint64_t seed, uint64_t idx) {
+#if W2S_DROPOUT_SPLITMIX
   uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z ^= z >> 31;
   return (float)(z >> 40) * (1.0f / 16777216.0f);
+#else
+  uint32_t h = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h += (uint32_t)(seed >> 32) * 0x27D4EB2Fu;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+#endif
 }
 __device__ __forceinline__ float w2s_dropscale(uint64_t seed, uint64_t idx, float p) {
   return (w2s_uniform(seed, idx) >= p) ? 1.0f / (1.0f - p) : 0.0f;
