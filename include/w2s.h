@@ -101,6 +101,30 @@ int w2s_conv_cfg(const w2s_conv_args* a, int32_t* out4);
 int w2s_linear_pf_takes(const w2s_conv_args* a);
 
 /*
+ * SequenceCNN's dilated convolution with its channel LayerNorm fused into the epilogue (csrc/seq_conv.hip), 128 -> 128 channels, 7 taps:
+ *   DilatedConvBlock.forward (models/blocks.py:115-126: Conv1d(k 7, dilation d, bias False) -> ConvLayerNorm (models/utils.py:9-23) -> GELU)
+ *   and its autograd backward.  v[b,t,:] = sum_j W_j x[b, t + roff(j) dil - pad, :], roff(j) = flip ? 6 - j : j, zero padding per sample.
+ *   mode 0: y = v.
+ *   mode 1: y = v (pre-norm, kept for backward), out = GELU(gamma * LN_c(v) + beta), rs[b*S + t] = (mean_c, rstd_c)   [eps inside the sqrt]
+ *   mode 2: v is the gradient w.r.t. the LOWER layer's GELU(LN(.)) output (x = the gradient w.r.t. this layer's conv output, flip = 1, the
+ *           [cin][7][cout] packing); out = the gradient w.r.t. the lower layer's conv output yl (LayerNorm + GELU backward with that layer's
+ *           gamma / beta / rs), part[b * ntiles + tile][2][128] = per-tile sums over positions of (gn * xhat, gn), gn = v * GELU'(gamma xhat + beta):
+ *           the lower LayerNorm's weight / bias gradients (ntiles = ceil(S / 64)); v itself is not stored (y unused).
+ * w_hi / w_lo: fragment-major bf16 planes of the packed weight (w2s_repack_bf16).  Split precision only (no exact-fp32 form: that mode runs the
+ * generic conv + w2s_layernorm_*).  Returns EINVAL for dil > 32 (the window must fit LDS).
+ */
+typedef struct w2s_seq_conv_args {
+  const float* x;
+  const void* w_hi; const void* w_lo;
+  float* y; float* out; float* rs;
+  const float* gamma; const float* beta; const float* yl;
+  float* part;
+  int32_t B, S, ldx, dil, pad, flip, mode;
+  float eps;
+} w2s_seq_conv_args;
+int w2s_seq_conv(const w2s_seq_conv_args* a, void* stream);
+
+/*
  * Weight gradient: dW[o][j][c] = sum_{b,t} GY(g)[b,t,o] * H(x)[b, t*stride + j*dil - pad, c]
  * GY/H are the same on-load transforms as above (pro_g on the gradient side, pro_h on the input side).
  * Writes per-workgroup partial slabs; w2s_wgrad_reduce sums them deterministically into the torch-layout

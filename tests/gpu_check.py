@@ -296,6 +296,64 @@ def t_linear_pipelined():
             want = x.double().cpu().view(rows, K) @ w.double().cpu().t() + (b.double().cpu() if bias else 0.0)
             report(tag + ' vs fp64', outs[1][0], want.float(), tol=1e-4)
 
+def t_seq_conv():
+    """Round 6: the SequenceCNN kernel with the channel LayerNorm in its epilogue (csrc/seq_conv.hip) against the launches it replaces --
+    generic dilated conv -> w2s_layernorm_fwd(gelu) forward, generic data gradient -> w2s_layernorm_bwd(gelu) backward -- and against fp64:
+    every dilation, symmetric and causal padding, ragged lengths (a last tile of 8 positions, a sample shorter than the halo), the strided
+    CLS-row input of block 0.  The conv part has the same products in the same order: bit for bit; the LayerNorm sums differ in order."""
+    cases = [(2, 960, 1, False, 128), (3, 200, 32, False, 128), (2, 130, 4, True, 128), (2, 64, 8, False, 640), (1, 1000, 16, False, 128), (2, 50, 2, False, 128),
+             (2, 200, 32, True, 128), (1, 72, 16, False, 128)]
+    C = 128
+    for (B, S, d, causal, ldx) in cases:
+        pad = 6 * d if causal else 3 * d
+        xs = torch.randn(B, S, ldx, device=dev)
+        x = xs if ldx == C else None   # (ldx > 128: the kernel reads the first 128 floats of every ldx-wide row)
+        w = torch.randn(C, C, 7) / math.sqrt(7 * C)                      # torch layout [cout][cin][taps]
+        wf = w.permute(0, 2, 1).contiguous().to(dev)                       # forward packing [cout][taps][cin]
+        wb = w.permute(1, 2, 0).contiguous().to(dev)                       # data-gradient packing [cin][taps][cout]
+        fh, fl = lib.frag_major_planes(wf.view(C, 7 * C)); bh, bl = lib.frag_major_planes(wb.view(C, 7 * C))
+        gamma = (torch.rand(C, device=dev) + 0.5); beta = torch.randn(C, device=dev) * 0.1
+        tag = f'seq conv B{B} S{S} d{d} {"causal" if causal else "sym"} ldx{ldx}'
+        # ---- forward
+        y0 = torch.zeros(B, S, C, device=dev); hn0 = torch.zeros(B, S, C, device=dev); rs0 = torch.zeros(B * S, 2, device=dev)
+        lib.conv_forward(lib.conv_args(x=xs, w=wf, w_hi=fh, w_lo=fl, y=y0, B=B, L_in=S, L_out=S, cin=C, cout=C, taps=7, stride=1, dil=d, pad=pad, mode=lib.MODE_DILATED, ldx=ldx))
+        lib.layernorm_fwd(y0, C, gamma, beta, hn0, C, rs0, B * S, C, 1e-5, gelu=True)
+        y1 = torch.full((B, S, C), float('nan'), device=dev); hn1 = torch.full((B, S, C), float('nan'), device=dev); rs1 = torch.full((B * S, 2), float('nan'), device=dev)
+        lib.seq_conv(x=xs, w_hi=fh, w_lo=fl, B=B, S=S, ldx=ldx, dil=d, pad=pad, mode=1, y=y1, out=hn1, rs=rs1, gamma=gamma, beta=beta, eps=1e-5)
+        RES.append((tag + ' y bit-equal', bool(torch.equal(y0, y1))))
+        print(f'{"OK  " if RES[-1][1] else "FAIL"} {tag}: conv output bit-equal to the generic kernel', flush=True)
+        report(tag + ' GELU(LN) vs the LayerNorm kernel', hn1, hn0, tol=3e-6)
+        report(tag + ' row statistics', rs1, rs0, tol=3e-6)
+        x64 = xs[:, :, :C].double().cpu().transpose(1, 2)
+        want_y = F.conv1d(F.pad(x64, (pad, 6 * d - pad)), w.double(), dilation=d).transpose(1, 2)
+        want_hn = F.gelu(F.layer_norm(want_y, (C,), gamma.double().cpu(), beta.double().cpu(), 1e-5))
+        report(tag + ' GELU(LN(conv)) vs fp64', hn1, want_hn.float(), tol=1e-4)
+        # ---- backward: gy = gradient w.r.t. THIS layer's conv output; the layer below has pre-norm output yl, statistics rsl
+        gy = torch.randn(B, S, C, device=dev) * 0.1
+        yl = torch.randn(B, S, C, device=dev) * 0.7 + 0.1
+        rsl = torch.zeros(B * S, 2, device=dev); tmp = torch.zeros(B, S, C, device=dev)
+        lib.layernorm_fwd(yl, C, gamma, beta, tmp, C, rsl, B * S, C, 1e-5, gelu=True)
+        gh0 = torch.zeros(B, S, C, device=dev)
+        lib.conv_forward(lib.conv_args(x=gy, w=wb, w_hi=bh, w_lo=bl, y=gh0, B=B, L_in=S, L_out=S, cin=C, cout=C, taps=7, stride=1, dil=d, pad=6 * d - pad, flip=1, mode=lib.MODE_DILATED))
+        npl = max(1, min(1024, (B * S + 31) // 32))
+        out0 = torch.zeros(B, S, C, device=dev); pg = torch.zeros(npl, C, device=dev); pb = torch.zeros(npl, C, device=dev)
+        lib.layernorm_bwd(gh0, C, yl, C, gamma, beta, rsl, None, out0, C, pg, pb, B * S, C, True, npl)
+        g0 = torch.full((B, S, C), float('nan'), device=dev)
+        lib.seq_conv(x=gy, w_hi=bh, w_lo=bl, B=B, S=S, ldx=C, dil=d, pad=6 * d - pad, flip=1, mode=0, y=g0)
+        RES.append((tag + ' data gradient bit-equal', bool(torch.equal(g0, gh0))))
+        print(f'{"OK  " if RES[-1][1] else "FAIL"} {tag}: plain data gradient bit-equal to the generic kernel', flush=True)
+        nt = B * ((S + 63) // 64)
+        out1 = torch.full((B, S, C), float('nan'), device=dev); part = torch.full((nt, 2, C), float('nan'), device=dev)
+        lib.seq_conv(x=gy, w_hi=bh, w_lo=bl, B=B, S=S, ldx=C, dil=d, pad=6 * d - pad, flip=1, mode=2, out=out1, rs=rsl, gamma=gamma, beta=beta, yl=yl, part=part, eps=1e-5)
+        report(tag + ' LayerNorm backward in the epilogue', out1, out0, tol=2e-5)
+        report(tag + ' LayerNorm weight gradient', part[:, 0].sum(0), pg.sum(0), tol=2e-5)
+        report(tag + ' LayerNorm bias gradient', part[:, 1].sum(0), pb.sum(0), tol=2e-5)
+        # fp64 autograd of GELU(LN(yl)) against the incoming gradient gh0
+        yl64 = yl.double().cpu().requires_grad_(True); gm64 = gamma.double().cpu().requires_grad_(True); bt64 = beta.double().cpu().requires_grad_(True)
+        F.gelu(F.layer_norm(yl64, (C,), gm64, bt64, 1e-5)).backward(gh0.double().cpu())
+        report(tag + ' LayerNorm backward vs fp64 autograd', out1, yl64.grad.float(), tol=1e-4)
+        report(tag + ' LayerNorm weight gradient vs fp64 autograd', part[:, 0].sum(0), gm64.grad.float(), tol=3e-4)
+
 def t_conv_wide_up2():
     """transposed stride-2 form of conv_wide_kernel (data gradient of the stride-2 conv3, >= 64 channels), symmetric and causal padding:
     gout = (W^T (x) gy) * GELU'(IN(aux)), gy = IN-backward(g * GELU'(n3); y3) -- against the autograd of F.conv1d in fp64."""
@@ -1171,7 +1229,7 @@ def t_plumbing():
     RES.append(('zero_', int(cm.abs().sum()) == 0 and float(g.abs().sum()) == 0.0))
 
 
-STAGES = dict(plumb=t_plumbing, offset=t_offset_channels, wgpf=t_wgrad_pipelined, linpf=t_linear_pipelined, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, part=t_stats_partition, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
+STAGES = dict(plumb=t_plumbing, offset=t_offset_channels, wgpf=t_wgrad_pipelined, linpf=t_linear_pipelined, seqconv=t_seq_conv, bwdwide=t_bwd_wide, gradh=t_grad_fp16_chain, wideup2=t_conv_wide_up2, wgwide=t_wgrad_wide, wide=t_conv_wide, causal=t_causal, part=t_stats_partition, fwdfused=t_fwd_fused, first=t_first_layer_recompute, batch=t_batched_entry_points, fusedbf=t_fused_split_precision, fold=t_fused_residual_fold, conv=t_conv_plain, split=t_conv_split_precision, stats=t_conv_stats_pro, dil=t_conv_dilated, dgrad=t_dgrad, wgrad=t_wgrad, rowops=t_rowops, attn=t_attn,
               head=t_head_optim, c1=t_model_c1, c2=t_model_c2, c4=t_model_c4)
 if __name__ == '__main__':
     print(lib.version(), torch.cuda.get_device_name(0))

@@ -47,7 +47,7 @@ def to_dev(x):
     return {k: v.to(DEV) for k, v in x.items()}
 
 
-@pytest.mark.parametrize('stage', ['bwdwide', 'gradh', 'wideup2', 'wgwide', 'wide', 'conv', 'split', 'causal', 'part', 'fwdfused', 'fusedbf', 'fold', 'first', 'batch', 'stats', 'dil', 'dgrad', 'wgrad', 'rowops', 'attn', 'head', 'plumb', 'offset', 'wgpf', 'linpf'])
+@pytest.mark.parametrize('stage', ['bwdwide', 'gradh', 'wideup2', 'wgwide', 'wide', 'conv', 'split', 'causal', 'part', 'fwdfused', 'fusedbf', 'fold', 'first', 'batch', 'stats', 'dil', 'dgrad', 'wgrad', 'rowops', 'attn', 'head', 'plumb', 'offset', 'wgpf', 'linpf', 'seqconv'])
 def test_kernels_against_cpu_torch(stage):
     """Every C-ABI kernel family against the stock CPU op it replaces (tests/gpu_check.py)."""
     from tests import gpu_check as G

@@ -65,6 +65,19 @@ def wgrad_trunk_case(cin, cout, rows, taps=1, stride=1, B=1, dil=1, pad=0, pro_h
     return fn, 4 * (B * rows * cout + B * L_in * cin), 2 * B * rows * cout * cin * taps
 
 
+def seqconv_case(dil, mode, B=16, S=960):
+    """SequenceCNN conv with the LayerNorm in its epilogue (w2s_seq_conv): mode 1 = forward (conv + LN + GELU), 2 = backward (data gradient + LN backward)"""
+    C = 128
+    x = torch.randn(B, S, C, device=dev); w = torch.randn(C, 7 * C, device=dev) / (7 * C) ** 0.5
+    wh, wl = lib.frag_major_planes(w)
+    y = torch.empty(B, S, C, device=dev); out = torch.empty(B, S, C, device=dev); rs = torch.rand(B * S, 2, device=dev) + 0.5
+    gm = torch.rand(C, device=dev) + 0.5; bt = torch.randn(C, device=dev) * 0.1; yl = torch.randn(B, S, C, device=dev)
+    part = torch.empty(B * ((S + 63) // 64), 2, C, device=dev)
+    fn = lambda: lib.seq_conv(x=x, w_hi=wh, w_lo=wl, B=B, S=S, ldx=C, dil=dil, pad=3 * dil, mode=mode, flip=int(mode == 2), y=y, out=out, rs=rs, gamma=gm, beta=bt,
+                              yl=yl, part=part)
+    return fn, 4 * B * S * C * 3, 2 * B * S * C * C * 7
+
+
 def elt_case(op, n=16 * 983040 * 16):
     a = torch.randn(n, device=dev); b = torch.randn(n, device=dev); y = torch.empty(n, device=dev)
     nb = 4 * n * (3 if op == lib.ELT_ADD else 2)
@@ -197,6 +210,7 @@ CASES = {
     'w128': lambda: wgrad_case(128, 128, 15360),
     'w64s2': lambda: wgrad_case(64, 64, 61440, stride=2, pro_g=lib.PRO_INBWD_GP),
     'w128s2': lambda: wgrad_case(128, 128, 15360, stride=2, pro_g=lib.PRO_INBWD_GP),
+    **{f'sq{d}{"f" if m == 1 else "b"}': (lambda d=d, m=m: seqconv_case(d, m)) for d in (1, 2, 4, 8, 16, 32) for m in (1, 2)},
     'wqkv': lambda: wgrad_trunk_case(128, 384, 76800),
     'wff1': lambda: wgrad_trunk_case(128, 512, 76800),
     'wproj': lambda: wgrad_trunk_case(128, 128, 76800),

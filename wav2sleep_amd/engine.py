@@ -111,6 +111,8 @@ class Engine:
         # OFF by default: 2.5 x the gradient error for 1.6 % is a trade a user should choose, not inherit
         self.grad_fp16 = os.environ.get('W2S_GRAD_FP16', '0') == '1'
         self.bwd_wide = True        # one-pass backward of the 64-channel convs (csrc/bwd_wide.hip)
+        # SequenceCNN: dilated conv + channel LayerNorm (+ GELU) in ONE launch, forward and backward (csrc/seq_conv.hip; split precision only)
+        self.seq_fused = os.environ.get('W2S_NO_SEQCONV', '0') != '1'
         # workgroup (= slab) caps of the weight-gradient launches with >= 64 x 128 channels: encoder convs (k = 3) / trunk linears (k = 1, or 4 strided taps)
         self.enc_wgrad_cap = int(os.environ.get('W2S_ENC_WGRAD_CAP', '128'))
         self.trunk_wgrad_cap = int(os.environ.get('W2S_TRUNK_WGRAD_CAP', '256'))   # (256 since the trunk's launches run on the pipelined kernel: lab notes r6)
@@ -641,11 +643,17 @@ class Engine:
                 d = 2 ** j
                 p = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.'
                 y = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-                self._conv(x=hcur, w=self.PF[p + 'conv.weight'], y=y, B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1,
-                           dil=d, pad=(sp.seq_kernel - 1) * d if self.seq_causal else (sp.seq_kernel // 2) * d, mode=lib.MODE_DILATED, ldx=ldh)
                 hn = torch.empty(B, S, F, device=dev, dtype=torch.float32)
                 rs = torch.empty(B * S, 2, device=dev, dtype=torch.float32)
-                lib.layernorm_fwd(y, F, P[p + 'norm.weight'], P[p + 'norm.bias'], hn, F, rs, B * S, F, sp.layer_eps, gelu=True)
+                pad = (sp.seq_kernel - 1) * d if self.seq_causal else (sp.seq_kernel // 2) * d
+                if self._seq_fused_ok(d):   # conv + LayerNorm + GELU in one launch (a tile holds all 128 channels of its positions)
+                    wh, wl = self._bf[self.PF[p + 'conv.weight'].data_ptr()]
+                    lib.seq_conv(x=hcur, w_hi=wh, w_lo=wl, B=B, S=S, ldx=ldh, dil=d, pad=pad, mode=1, y=y, out=hn, rs=rs, gamma=P[p + 'norm.weight'],
+                                 beta=P[p + 'norm.bias'], eps=sp.layer_eps)
+                else:
+                    self._conv(x=hcur, w=self.PF[p + 'conv.weight'], y=y, B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1,
+                               dil=d, pad=pad, mode=lib.MODE_DILATED, ldx=ldh)
+                    lib.layernorm_fwd(y, F, P[p + 'norm.weight'], P[p + 'norm.bias'], hn, F, rs, B * S, F, sp.layer_eps, gelu=True)
                 if save:
                     convs.append(dict(hin=hcur, ldh=ldh, y=y, rs=rs))
                 hcur, ldh = hn, F
@@ -664,6 +672,11 @@ class Engine:
                 xin, ldin = act, F
 
         return pre_out, seq
+
+    def _seq_fused_ok(self, dil: int) -> bool:
+        """the fused SequenceCNN kernel takes this layer: split precision (it has no fp32-MFMA form), 128 channels, 7 taps, a window that fits LDS"""
+        sp = self.spec
+        return self.seq_fused and self.split_precision and sp.feature_dim == 128 and sp.seq_kernel == 7 and 1 <= dil <= 32
 
     def _trunk_forward(self, e, pm, ps, save, logits=None):
         """set-fusion transformer + SequenceCNN + classifier on the tokens of `e`; returns (logits [B, S, nc], saved context or None)"""
@@ -766,24 +779,47 @@ class Engine:
             blk = c['seq'][b]
             gh = torch.empty(B, S, F, device=dev, dtype=torch.float32)
             lib.eltwise(lib.ELT_DROP, g_pre, None, gh, rows * F, ps, self._seed(100 + b))
+            gy = None   # gradient w.r.t. layer j's conv output, when the fused kernel of layer j + 1 has already produced it
             for j in reversed(range(sp.seq_dilations)):
                 d = 2 ** j
                 cv = blk['convs'][j]
                 p = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j}.'
-                gy = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-                npl = max(1, min(1024, _cdiv(rows, 32)))
-                pg = torch.empty(npl, F, device=dev, dtype=torch.float32)
-                pb = torch.empty(npl, F, device=dev, dtype=torch.float32)
-                lib.layernorm_bwd(gh, F, cv['y'], F, P[p + 'norm.weight'], P[p + 'norm.bias'], cv['rs'], None, gy, F, pg, pb, rows, F, True, npl)
-                self._colsum(pg, npl, F, self.G[p + 'norm.weight'], accumulate=(p + 'norm.weight') in self._written)
-                self._colsum(pb, npl, F, self.G[p + 'norm.bias'], accumulate=(p + 'norm.bias') in self._written)
-                self._written.update((p + 'norm.weight', p + 'norm.bias'))
+                if gy is None:   # the block's last layer (or the unfused path): LayerNorm + GELU backward as a launch of its own
+                    gy = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                    npl = max(1, min(1024, _cdiv(rows, 32)))
+                    pg = torch.empty(npl, F, device=dev, dtype=torch.float32)
+                    pb = torch.empty(npl, F, device=dev, dtype=torch.float32)
+                    lib.layernorm_bwd(gh, F, cv['y'], F, P[p + 'norm.weight'], P[p + 'norm.bias'], cv['rs'], None, gy, F, pg, pb, rows, F, True, npl)
+                    self._colsum(pg, npl, F, self.G[p + 'norm.weight'], accumulate=(p + 'norm.weight') in self._written)
+                    self._colsum(pb, npl, F, self.G[p + 'norm.bias'], accumulate=(p + 'norm.bias') in self._written)
+                    self._written.update((p + 'norm.weight', p + 'norm.bias'))
                 pad = (sp.seq_kernel - 1) * d if self.seq_causal else (sp.seq_kernel // 2) * d
                 self._wgrad(p + 'conv.weight', g=gy, x=cv['hin'], ldx=cv['ldh'], B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel,
                             stride=1, pad=pad, dil=d)
-                gh = torch.empty(B, S, F, device=dev, dtype=torch.float32)
-                self._conv(x=gy, w=PB[p + 'conv.weight'], y=gh, B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1, dil=d,
-                           pad=(sp.seq_kernel - 1) * d - pad, flip=1, mode=lib.MODE_DILATED)
+                if self._seq_fused_ok(d):
+                    # data gradient of this conv with the LayerNorm + GELU backward of the layer BELOW in its epilogue (layer 0: the plain
+                    # data gradient w.r.t. the block's input); the lower LayerNorm's weight / bias gradient partials come with it
+                    wh, wl = self._bf[PB[p + 'conv.weight'].data_ptr()]
+                    gnext = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                    if j > 0:
+                        lo = blk['convs'][j - 1]
+                        pl = f'sequence_mixer.dilated_convs.{b}.conv_layers.{j - 1}.'
+                        ntl = B * _cdiv(S, 64)
+                        part = torch.empty(ntl, 2, F, device=dev, dtype=torch.float32)
+                        lib.seq_conv(x=gy, w_hi=wh, w_lo=wl, B=B, S=S, ldx=F, dil=d, pad=(sp.seq_kernel - 1) * d - pad, flip=1, mode=2, out=gnext,
+                                     rs=lo['rs'], gamma=P[pl + 'norm.weight'], beta=P[pl + 'norm.bias'], yl=lo['y'], part=part, eps=sp.layer_eps)
+                        self._colsum(part, ntl, F, self.G[pl + 'norm.weight'], accumulate=(pl + 'norm.weight') in self._written, ld=2 * F)
+                        self._colsum(part.view(-1)[F:], ntl, F, self.G[pl + 'norm.bias'], accumulate=(pl + 'norm.bias') in self._written, ld=2 * F)
+                        self._written.update((pl + 'norm.weight', pl + 'norm.bias'))
+                        gy = gnext
+                    else:
+                        lib.seq_conv(x=gy, w_hi=wh, w_lo=wl, B=B, S=S, ldx=F, dil=d, pad=(sp.seq_kernel - 1) * d - pad, flip=1, mode=0, y=gnext)
+                        gh = gnext
+                else:
+                    gh = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+                    self._conv(x=gy, w=PB[p + 'conv.weight'], y=gh, B=B, L_in=S, L_out=S, cin=F, cout=F, taps=sp.seq_kernel, stride=1, dil=d,
+                               pad=(sp.seq_kernel - 1) * d - pad, flip=1, mode=lib.MODE_DILATED)
+                    gy = None
             gx = torch.empty(B, S, F, device=dev, dtype=torch.float32)
             lib.eltwise(lib.ELT_ADD, g_pre, gh, gx, rows * F)
             if b > 0:

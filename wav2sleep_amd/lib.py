@@ -52,7 +52,7 @@ class WgradArgs(C.Structure):
                                     'pro_g', 'pro_h', 'nslab', 'split_precision')]
 
 
-EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_linear_pf_takes', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
+EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_linear_pf_takes', 'w2s_seq_conv', 'w2s_conv_forward', 'w2s_wgrad', 'w2s_wgrad_max_blocks', 'w2s_wgrad_slabs_per_block_of', 'w2s_wgrad_grid_y', 'w2s_wgrad_slabs_per_block', 'w2s_wgrad_reduce', 'w2s_wgrad_reduce_batch', 'w2s_repack', 'w2s_repack_batch', 'w2s_repack_bf16',
            'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_bwd_fused_wd', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
@@ -258,6 +258,26 @@ def conv_forward(a: ConvArgs):
     if DETAIL:
         key += f' {a.cin}->{a.cout} pro{a.pro} epi{a.epi} L{a.L_out}'
     _timed(key, nbytes, flops, run)
+
+
+class SeqConvArgs(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w_hi', C.c_void_p), ('w_lo', C.c_void_p), ('y', C.c_void_p), ('out', C.c_void_p), ('rs', C.c_void_p),
+                ('gamma', C.c_void_p), ('beta', C.c_void_p), ('yl', C.c_void_p), ('part', C.c_void_p),
+                ('B', C.c_int32), ('S', C.c_int32), ('ldx', C.c_int32), ('dil', C.c_int32), ('pad', C.c_int32), ('flip', C.c_int32), ('mode', C.c_int32),
+                ('eps', C.c_float)]
+
+
+def seq_conv(*, x, w_hi, w_lo, B, S, ldx, dil, pad, mode, flip=0, y=None, out=None, rs=None, gamma=None, beta=None, yl=None, part=None, eps=1e-5):
+    """SequenceCNN dilated conv (128 -> 128, k 7) with the channel LayerNorm in its epilogue (include/w2s.h w2s_seq_conv; csrc/seq_conv.hip)."""
+    a = SeqConvArgs()
+    a.x, a.w_hi, a.w_lo, a.y, a.out, a.rs = _f(x), _p(w_hi), _p(w_lo), _f(y), _f(out), _f(rs)
+    a.gamma, a.beta, a.yl, a.part = _f(gamma), _f(beta), _f(yl), _f(part)
+    a.B, a.S, a.ldx, a.dil, a.pad, a.flip, a.mode, a.eps = B, S, ldx, dil, pad, flip, mode, eps
+
+    def run():
+        _chk(load().w2s_seq_conv(C.byref(a), _stream()), f'w2s_seq_conv(mode={mode},dil={dil})')
+    el = B * S * 128
+    _timed(f'seq_conv_kernel<{mode}>', 4 * el * (2, 3, 3)[mode], 2 * el * 128 * 7, run)
 
 
 def _wgrad_args(*, g, x, slab, nslab, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, ldg=None, ldx=None, pro_g=PRO_NONE,
