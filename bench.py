@@ -57,7 +57,8 @@ def family_of(key):
     for prefix, fam in (('bwd_fused_bf_kernel', 'fused backward <=32ch (dgrad+wgrad)'), ('conv_fwd_bf_kernel', 'persistent forward <=32ch'),
                         ('conv_wide_kernel', 'wide conv >=64ch (fwd + dgrad)'), ('bwd_wide_kernel', 'fused backward 64ch (dgrad+wgrad)'),
                         ('wgrad', 'weight gradient >=64ch / k1 / dilated'),
-                        ('conv_cl_kernel', 'generic conv (1x1, dilated, downsample, UP2 dgrad)'), ('linear_pf_kernel', 'generic conv (1x1, dilated, downsample, UP2 dgrad)')):
+                        ('conv_cl_kernel', 'generic conv (1x1, dilated, downsample, UP2 dgrad)'), ('linear_pf_kernel', 'generic conv (1x1, dilated, downsample, UP2 dgrad)'),
+                        ('seq_conv_kernel', 'generic conv (1x1, dilated, downsample, UP2 dgrad)')):
         if key.startswith(prefix):
             return fam
     return 'other'
