@@ -46,7 +46,10 @@ __global__ __launch_bounds__(512) void seq_conv_kernel(SeqP P) {
   // ---- this wave's weight fragments: K step ks = tap * 4 + q of output-channel tile `wave`, from L2, four steps ahead
   const char* wfh = reinterpret_cast<const char*>(P.w_hi) + ((size_t)wave * KS << 10) + (lane << 4);
   const char* wfl = reinterpret_cast<const char*>(P.w_lo) + ((size_t)wave * KS << 10) + (lane << 4);
-  constexpr int RING = 4;
+#ifndef W2S_SEQ_RING
+#define W2S_SEQ_RING 4   // tuning: K steps of weight fragments in flight (8 registers each); 8 measured 2-4 us SLOWER per launch (lab notes r6)
+#endif
+  constexpr int RING = W2S_SEQ_RING;
   bf16x8 fh[RING], fl[RING];
   auto load_frag = [&](auto SLOT, int ks) {
     constexpr int SL = decltype(SLOT)::value;
@@ -54,6 +57,10 @@ __global__ __launch_bounds__(512) void seq_conv_kernel(SeqP P) {
     fl[SL] = *reinterpret_cast<const bf16x8*>(wfl + ((unsigned)ks << 10));
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>; using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
+  // the first RING steps' fragments go out before anything else (L2 hits: they are back long before the window's HBM rows)
+  load_frag(I0{}, 0); load_frag(I1{}, 1); load_frag(I2{}, 2); load_frag(I3{}, 3);
+  if constexpr (RING == 8) { load_frag(I4{}, 4); load_frag(I5{}, 5); load_frag(I6{}, 6); load_frag(I7{}, 7); }
 
   // ---- stage the window: 32 float4 per row, 16 rows per pass, eight passes of loads in flight; rows outside the sample are zero padding
   {
@@ -74,7 +81,6 @@ __global__ __launch_bounds__(512) void seq_conv_kernel(SeqP P) {
       }
     }
   }
-  load_frag(I0{}, 0); load_frag(I1{}, 1); load_frag(I2{}, 2); load_frag(I3{}, 3);
   // epilogue operands of MODE 2 (the lower layer's conv output in this lane's D-fragment layout, its row statistics): requested now, they
   // land during the K loop (older than every weight fetch the loop waits for)
   const int ch = wave * 16 + 4 * g;
@@ -115,8 +121,16 @@ __global__ __launch_bounds__(512) void seq_conv_kernel(SeqP P) {
       acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[mt], acc[mt], 0, 0, 0);
     }
   };
+  if constexpr (RING == 8) {
 #pragma unroll
-  for (int ks = 0; ks < KS; ks += 4) { step(I0{}, ks); step(I1{}, ks + 1); step(I2{}, ks + 2); step(I3{}, ks + 3); }
+    for (int ks = 0; ks < 24; ks += 8) {
+      step(I0{}, ks); step(I1{}, ks + 1); step(I2{}, ks + 2); step(I3{}, ks + 3); step(I4{}, ks + 4); step(I5{}, ks + 5); step(I6{}, ks + 6); step(I7{}, ks + 7);
+    }
+    step(I0{}, 24); step(I1{}, 25); step(I2{}, 26); step(I3{}, 27);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 4) { step(I0{}, ks); step(I1{}, ks + 1); step(I2{}, ks + 2); step(I3{}, ks + 3); }
+  }
 
   // ---- epilogue.  Lane (r, g) of wave w holds, for mt = 0..3, position t0 + 16 mt + r, channels 16 w + 4 g .. + 3
   // sum over the 128 channels of a row of up to two values per lane at once: 4 channels in the lane -> the wave's 16 (two cross-row
