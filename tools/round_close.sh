@@ -7,7 +7,7 @@
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=gpurun_out/close_$TAG; mkdir -p $O
 {
   echo "# box of this run"; date -u
