@@ -37,8 +37,6 @@ def pmc_key(name):
     m = re.match(r'wgrad_bf_pf_kernel<(\d+), (\d+), (\d+), (\d+), \d+>$', name)   # round 6: the pipelined form <OW, CT, NW, STRIDE, TM> of wgrad_bf_kernel<OW, 1, CT, NW, STRIDE, -1, -1>
     if m:
         return f'wgrad_bf_kernel<{m[1]}, 1, {m[2]}, {m[3]}, {m[4]}, -1, -1>'
-    if name.startswith('linear_pf_kernel<'):   # round 6: the transformer's row-wise linears (csrc/linear_pf.hip), one timer key for its instances
-        return 'linear_pf_kernel'
     m = re.match(r'(conv_fwd_bf|bwd_fused_bf|bwd_fused|conv_wide|bwd_wide)_kernel<(.*), [01]>$', name)
     if m and m[2].count(',') + 2 == {'conv_fwd_bf': 6, 'bwd_fused_bf': 8, 'bwd_fused': 6, 'conv_wide': 11, 'bwd_wide': 11}[m[1]]:   # (names of this round: drop FIN)
         name = f'{m[1]}_kernel<{m[2]}>'

@@ -239,7 +239,7 @@ def conv_forward(a: ConvArgs):
             key += f' L{a.L_out}'
         return _timed(key, nbytes, flops, run)
     if load().w2s_linear_pf_takes(C.byref(a)):   # the transformer's row-wise linears (csrc/linear_pf.hip)
-        return _timed('linear_pf_kernel' + (f' {a.cin * a.taps}->{a.cout} L{a.L_out}' if DETAIL else ''), nbytes, flops, run)
+        return _timed(f'linear_pf_kernel<1, {a.taps}>' + (f' {a.cin * a.taps}->{a.cout} L{a.L_out}' if DETAIL else ''), nbytes, flops, run)   # <NB, KC>: the name rocprofv3 reports
     cfg = (C.c_int32 * 4)()
     _chk(load().w2s_conv_cfg(C.byref(a), cfg), 'w2s_conv_cfg')
     nt, mt, wn, mode = cfg[0], cfg[1], cfg[2], cfg[3]
