@@ -113,7 +113,6 @@ class Engine:
         self.bwd_wide = True        # one-pass backward of the 64-channel convs (csrc/bwd_wide.hip)
         # SequenceCNN: dilated conv + channel LayerNorm (+ GELU) in ONE launch, forward and backward (csrc/seq_conv.hip; split precision only)
         self.seq_fused = os.environ.get('W2S_NO_SEQCONV', '0') != '1'
-        self.flush_early = os.environ.get('W2S_FLUSH_EARLY', '0') == '1'   # A/B (lab notes r6): slab sums of the wide blocks behind those blocks
         # workgroup (= slab) caps of the weight-gradient launches with >= 64 x 128 channels: encoder convs (k = 3) / trunk linears (k = 1, or 4 strided taps)
         self.enc_wgrad_cap = int(os.environ.get('W2S_ENC_WGRAD_CAP', '128'))
         self.trunk_wgrad_cap = int(os.environ.get('W2S_TRUNK_WGRAD_CAP', '256'))   # (256 since the trunk's launches run on the pipelined kernel: lab notes r6)
@@ -1250,9 +1249,4 @@ class Engine:
                 self._colsum(slab, nslab, 48, self.G[n1], accumulate=n1 in self._written, ld=64)
                 self._colsum(slab.view(-1)[48:], nslab, 16, self.G[nd], accumulate=nd in self._written, ld=64)
                 self._written.update((n1, nd))
-            if self.flush_early and c >= 64 and (i == 0 or ch[i - 1] < 64):
-                # the >= 64-channel blocks are done: sum their slabs (100-200 KB each: most of this encoder's slab bytes) NOW, beside the other
-                # streams' long <= 32-channel kernels, instead of at the end of the stream where all encoders finish together (same sums in the
-                # same order: the accumulate flags were fixed when the jobs were queued)
-                self._flush_reduce()
             yield
