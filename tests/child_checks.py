@@ -145,7 +145,9 @@ def b16_fullsize_grad():
     workers = max(1, min(4, int(mem_gb // 40), cores // 8))    # a micro-batch of 2 holds ~25 GB of autograd state at its peak
     threads = max(1, min(16, cores // workers))
     pool = cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn'))
-    futs = [pool.submit(_oracle_microbatch, (sd, cfg, {k: v[b0:b0 + 2].clone() for k, v in x.items()}, y[b0:b0 + 2].clone(), threads)) for b0 in range(0, B, 2)]
+    # (copies: a tensor handed to the pool is moved into shared memory in place by the executor's feeder thread -- never share one this thread still uses)
+    futs = [pool.submit(_oracle_microbatch, ({k: v.clone() for k, v in sd.items()}, cfg, {k: v[b0:b0 + 2].clone() for k, v in x.items()}, y[b0:b0 + 2].clone(), threads))
+            for b0 in range(0, B, 2)]
     # ---- GPU side (the workers are running)
     model.to(DEV).train()
     xd = {k: v.to(DEV) for k, v in x.items()}
@@ -309,9 +311,17 @@ def argmax_sweep():
         models.append(build(W, SM4, 4, dropout=0.1))
         x, _ = O.make_inputs(cfg, 1, S, seed=7000 + seed)
         xs.append(x)
+    # What goes to the pool is a COPY (`_to_pool`): torch registers its tensor reductions with multiprocessing, so a submitted CPU tensor's
+    # storage is MOVED INTO SHARED MEMORY IN PLACE by the executor's feeder thread, some time after submit() returns -- while this thread may be
+    # reading the very same tensor (load_state_dict, .to(device)).  The first version of this check shared `sd` with the pool and then loaded
+    # it into a model at once: 1-3 forwards per sweep came out wrong (docs/lab_notes_r6.md section 10: a harness race, not a kernel's)
+    def _to_pool(sd, x):
+        return {k: v.clone() for k, v in sd.items()}, {k: v.clone() for k, v in x.items()}
+
     for seed in range(NSEED):
         sd = {k: v.detach().clone() for k, v in models[seed].state_dict().items()}
-        futs[(seed, 'init')] = (pool.submit(_oracle_forward, (sd, cfg, xs[seed], threads)), sd)
+        sdj, xj = _to_pool(sd, xs[seed])
+        futs[(seed, 'init')] = (pool.submit(_oracle_forward, (sdj, cfg, xj, threads)), sd)
     assert len(futs) >= workers   # (every worker process exists before the first GPU call below)
 
     def run_mode(exact, sd, xd):
@@ -343,7 +353,8 @@ def argmax_sweep():
                 torch.cuda.synchronize()
                 del tr
                 sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-                futs[(seed, state)] = (pool.submit(_oracle_forward, (sd, cfg, xs[seed], threads)), sd)
+                sdj, xj = _to_pool(sd, xs[seed])
+                futs[(seed, state)] = (pool.submit(_oracle_forward, (sdj, cfg, xj, threads)), sd)
             sd = futs[(seed, state)][1]
             for exact in (False, True):
                 got[(seed, state, exact)] = run_mode(exact, sd, xd)
@@ -361,9 +372,9 @@ def argmax_sweep():
                 g = got[(seed, state, exact)]
                 err = float((g - want).abs().max())
                 if err > 1e-3 * float(want.abs().max()):
-                    # a GROSS mismatch: run the same forward again before judging it.  Round 6 saw one exact-fp32 forward in 64 come back 0.3 off
-                    # on weights and input that gave 3e-5 in the session before and in 700 targeted repetitions after (tools/flake_probe*.py;
-                    # docs/lab_notes_r6.md): a transient is REPORTED (and fails the test beyond one per sweep), a repeatable one is a plain failure
+                    # a GROSS mismatch: run the same forward again before judging it, and REPORT it as a transient if the re-run is right (the test
+                    # then fails either way: round 6's transients were this harness sharing tensors with the pool -- see `_to_pool` above -- and
+                    # none is expected any more)
                     g2 = run_mode(exact, futs[(seed, state)][1], {k: v.to(DEV) for k, v in xs[seed].items()})
                     err2 = float((g2 - want).abs().max())
                     transients.append(dict(seed=seed, state=state, mode='exact_fp32' if exact else 'bf16x3', first_err=err, rerun_err=err2,

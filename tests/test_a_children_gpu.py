@@ -104,11 +104,9 @@ def test_argmax_label_margin_over_sixteen_seeds_two_weight_states_both_modes(tmp
     if os.path.isdir(out):
         json.dump(r, open(os.path.join(out, 'argmax_sweep.json'), 'w'), indent=1)
     print(json.dumps(r['summary'], indent=1))
-    if r.get('transients'):   # a gross mismatch that did NOT repeat when the same forward was run again: reported, tolerated once per sweep
-        import warnings
-        warnings.warn(f'argmax_sweep: transient gross mismatches (re-run passed): {r["transients"]}')
-        print('TRANSIENTS:', json.dumps(r['transients']))
-    assert len(r.get('transients', [])) <= 1, r['transients']
+    # a gross mismatch that did not repeat when the same forward was run again would be a transient (round 6's were the harness's own race with
+    # its worker pool, fixed in child_checks.py `_to_pool`): none is tolerated
+    assert not r.get('transients'), r['transients']
     for key, a in r['summary'].items():
         assert a['max_rel_err'] <= 1e-3, (key, a)
         assert a['worst_flip_gap_over_err'] <= 2.0, (key, a)       # a flip further from a tie than the error allows would be a wrong result, not a tie

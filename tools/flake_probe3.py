@@ -38,6 +38,7 @@ def main():
     ap.add_argument('--no-train', action='store_true')
     ap.add_argument('--repeat', type=int, default=2)
     ap.add_argument('--keep-models', action='store_true', help='build every seed\'s model on the CPU first, as the sweep does')
+    ap.add_argument('--share', action='store_true', help='hand the SAME sd / x tensors to the pool and to the model (the harness race of round 6); default: copies')
     a = ap.parse_args()
     import wav2sleep_amd as W
     from oracle import wav2sleep_oracle as O
@@ -90,7 +91,7 @@ def main():
                 del tr
             sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
             if pool:
-                futs.append(pool.submit(_oracle_forward, (sd, cfg, xs[seed], 16)))
+                futs.append(pool.submit(_oracle_forward, (sd, cfg, xs[seed], 16) if a.share else ({k: v.clone() for k, v in sd.items()}, cfg, {k: v.clone() for k, v in xs[seed].items()}, 16)))
             for exact in (False, True):
                 outs = [run_mode(exact, sd, xd) for _ in range(a.repeat)]
                 total += a.repeat
