@@ -179,11 +179,8 @@ template <int NB, int KC>
 static int launch_linear_pf(const LinP& P, int gy, hipStream_t s) {
   const size_t lds = (size_t)2 * 2 * 64 * (128 + 16) * 2;   // two windows x (hi, lo) x 64 rows x 144 bf16 = 73 728 B
   auto kern = linear_pf_kernel<NB, KC>;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W2S_ELAUNCH;
-    attr = true;
-  }
+  // (per launch, like every launcher of this library: the attribute belongs to the CURRENT device's copy of the function)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W2S_ELAUNCH;
   // one 8-wave workgroup per CU (two where 32 NB KC weight registers leave room: the register file sets it); every workgroup the same
   // number of tiles where the count allows it
   const char* gs = getenv("W2S_LINEAR_PF_GRID");   // tuning only
