@@ -399,7 +399,7 @@ const char* w2s_version(void);
 /* Integer ABI number of this header: bumped whenever a signature or the meaning of an argument changes (round 5: 6; round 6: 7).  The host refuses a
  * library whose number differs from the one it was written against (wav2sleep_amd/lib.py), so a stale build_alt/ or W2S_LIB library is
  * an error at load time instead of shifted arguments at call time. */
-#define W2S_ABI_VERSION 7
+#define W2S_ABI_VERSION 8
 int w2s_abi_version(void);
 
 /* ---- generic (untuned, inference) path: module variants outside the shipped production model (models/utils.py:26-96, ppgnet.py) ---- */
@@ -411,8 +411,31 @@ int w2s_affine_act(const float* x, int ldx, const float* scale, const float* shi
 /* per-position normalisation over C channels + activation: ConvLayerNorm (utils.py:9-23), ConvRMSNorm (rms != 0, beta NULL; :26-38), nn.LayerNorm */
 int w2s_rownorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, long rows, int C, float eps, int rms,
                     int act, float slope, void* stream);
-/* nn.MultiheadAttention's attention core for any head size hd, D <= 16 tokens: qkv [N][D][3*H*hd], keypad [N][D] (1 = padded key), out [N][D][H*hd] */
-int w2s_attn_generic_fwd(const float* qkv, const unsigned char* keypad, float* out, long N, int D, int H, int hd, void* stream);
+/* nn.MultiheadAttention's attention core for any head size hd, D <= 16 tokens: qkv [N][D][3*H*hd], keypad [N][D] (1 = padded key), out [N][D][H*hd];
+ * p_drop > 0: dropout on the attention weights (training; mask from (seed, ((n H + h) D + query) D + key), regenerated by the backward) */
+int w2s_attn_generic_fwd(const float* qkv, const unsigned char* keypad, float* out, long N, int D, int H, int hd, float p_drop, uint64_t seed,
+                         void* stream);
+
+/* ---- generic path, backward (round 6): what autograd runs for ConvLayer1D's norm -> activation (blocks.py:183-185), the row norms and
+ * nn.MultiheadAttention when the reference trains SleepPPGNet (models/ppgnet.py) or a non-production Wav2Sleep configuration.  Data / weight
+ * gradients of the convolutions and GEMMs are w2s_conv_forward (flip / W2S_MODE_UP2) and w2s_wgrad. ---- */
+/* ga = g * act'(z), xh = stats ? (y - mean) * rstd : y, z = gamma ? xh * gamma + beta : xh; stats [.][C][2] = (mean, rstd), stats_stride = floats
+ * between samples (0: one set for the batch).  part [nsamples][ceil(rows_per_sample / tile)][2][C] = per-tile sums of ga and ga * xh
+ * (w2s_stats_finalize kind 1 turns them into the per-(sample, channel) means). */
+int w2s_norm_act_bwd_part(const float* g, int ldg, const float* y, int ldy, const float* stats, int stats_stride, const float* gamma,
+                          const float* beta, int rows_per_sample, int nsamples, int C, int act, float slope, int tile, float* part, void* stream);
+/* gy = coef ? A * ga + B + Cx * xh : ga; coef [.][3][C] = (A, B, Cx), coef_stride = floats between samples (0: one set).  gy may alias g. */
+int w2s_norm_act_bwd_apply(const float* g, int ldg, const float* y, int ldy, const float* stats, int stats_stride, const float* gamma,
+                           const float* beta, const float* coef, int coef_stride, float* gy, int ldgy, int rows_per_sample, long rows, int C,
+                           int act, float slope, void* stream);
+/* backward of w2s_rownorm_fwd: x = the norm's input, g = gradient of the activation's output, gx = gradient of x (may alias g);
+ * part [w2s_rownorm_bwd_blocks(rows)][2][C] = per-block sums for gamma's and beta's gradients (w2s_colsum finishes them).  C <= 1024. */
+int w2s_rownorm_bwd_blocks(long rows);
+int w2s_rownorm_bwd(const float* g, int ldg, const float* x, int ldx, const float* gamma, const float* beta, float* gx, int ldgx, float* part,
+                    long rows, int C, float eps, int rms, int act, float slope, void* stream);
+/* backward of w2s_attn_generic_fwd: gqkv [N][D][3*H*hd] (fully written) from gout [N][D][H*hd] */
+int w2s_attn_generic_bwd(const float* qkv, const unsigned char* keypad, const float* gout, float* gqkv, long N, int D, int H, int hd, float p_drop,
+                         uint64_t seed, void* stream);
 
 #ifdef __cplusplus
 }

@@ -131,3 +131,32 @@ def variant_inputs(name: str):
     for s, rows in (v.get('missing') or {}).items():
         x[s][rows] = float('-inf')
     return x
+
+
+# ---- gradients of the generic-path variants (tests/golden/variants_grad.npz, made by make_goldens_r6.py from the REFERENCE modules) ----
+GRAD_SAMPLE = 2048   # gradient tensors above this size are stored as an evenly strided sample of this many elements (+ their L2 norm)
+
+
+def variant_labels(name: str):
+    """Seeded stage labels [B, S] of a variant with ~15 % unscored (-1) epochs."""
+    v = VARIANTS[name]
+    g = torch.Generator().manual_seed(1900 + sorted(VARIANTS).index(name))
+    y = torch.randint(0, v['nc'], (v['B'], v['S']), generator=g)
+    y[torch.rand(v['B'], v['S'], generator=g) < 0.15] = -1
+    return y
+
+
+def variant_cfg(name: str, train: bool):
+    """The variant's constructor arguments for a gradient run: train=True -> train mode with every dropout at 0 (BatchNorm uses the batch's
+    statistics; nothing random), train=False -> eval mode (BatchNorm uses its running statistics)."""
+    v = dict(VARIANTS[name])
+    if train:
+        v['seq'] = dict(v['seq'], dropout=0.0)
+    return v
+
+
+def grad_sample_index(n: int):
+    """indices of the stored sample of an n-element gradient (all of it up to GRAD_SAMPLE elements)"""
+    if n <= GRAD_SAMPLE:
+        return np.arange(n)
+    return np.linspace(0, n - 1, GRAD_SAMPLE).astype(np.int64)

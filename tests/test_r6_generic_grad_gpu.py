@@ -1,0 +1,222 @@
+"""GPU tests of the generic path's BACKWARD (round 6; wav2sleep_amd/generic.py tape, csrc/generic.hip): gradients of the reference's
+modules in configurations outside the production family -- BatchNorm (batch and running statistics) / GroupNorm / RMS / layer / no norm,
+ReLU / LeakyReLU / SiLU / GELU, feature sizes 16..64, post-norm transformer layers, shared encoders with signal embeddings, a missing
+modality -- and of SleepPPGNet in train mode, against what torch autograd computed on the REFERENCE modules
+(tests/golden/variants_grad.npz, made by tests/golden/make_goldens_r6.py: the reference in float64, with its own float32 deviation as the
+yardstick); and the backward kernels one by one against torch CPU autograd.  Tolerance: relative L2 error 1e-3 per gradient tensor, or
+three times the reference's float32 deviation where BatchNorm on batch statistics makes the gradient ill-conditioned."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import wav2sleep_amd as W  # noqa: E402
+from wav2sleep_amd import lib  # noqa: E402
+from tests.golden_util import VARIANTS, grad_sample_index, load, perturb_state, variant_cfg, variant_inputs, variant_labels  # noqa: E402
+
+DEV = 'cuda'
+
+
+def build(name, train):
+    v = variant_cfg(name, train)
+    torch.manual_seed(4000 + sorted(VARIANTS).index(name))
+    model = W.Wav2Sleep(W.SignalEncoders(**v['enc']), W.MultiModalAttentionEmbedder(**v['mix']), W.SequenceCNN(**v['seq']), num_classes=v['nc'])
+    model.load_state_dict(perturb_state(model.state_dict(), seed=77), strict=True)
+    return model.to(DEV).train(train)
+
+
+def check_grads(model, g, tag, floor=1e-3, k_ref=3.0):
+    """Every parameter's gradient against the reference's FLOAT64 gradient: relative L2 error (on the stored sample) and the L2 norm within
+    max(floor, k_ref x the deviation of the reference's own float32 step from that float64 gradient) -- with BatchNorm on batch statistics
+    some gradients are differences of nearly equal sums and float32 itself is off by up to 3e-2 (make_goldens_r6.py)."""
+    worst = ('', 0.0, 0.0)
+    # ... and ReLU / LeakyReLU gates are discontinuous: a pre-activation within rounding of zero flips its gate, which moves a 384-element
+    # channel sum by 3e-3 -- the float32 reference does it too, at OTHER elements; so no parameter is held tighter than the reference's own
+    # worst parameter of the same step
+    floor = max(floor, max(float(g[f'{tag}.ref32.{k}']) for k, _ in model.named_parameters()))
+    for k, p in model.named_parameters():
+        want = g[f'{tag}.grad.{k}'].astype(np.float64)
+        got_full = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().flatten().double().cpu().numpy()
+        got = got_full[grad_sample_index(got_full.size)]
+        bound = max(floor, k_ref * float(g[f'{tag}.ref32.{k}']))
+        err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+        if err / bound > worst[1]:
+            worst = (k, err / bound, err)
+        assert err <= bound, (tag, k, err, bound)
+        wn = float(g[f'{tag}.norm.{k}'])
+        assert abs(np.linalg.norm(got_full) - wn) <= bound * wn + 1e-9, (tag, k, np.linalg.norm(got_full), wn)
+    return worst
+
+
+@pytest.mark.parametrize('name,train', [('causality', False), ('causality', True), ('leaky_auto_rms', False), ('silu_group', False), ('relu_nonorm', False)])
+def test_variant_gradients_match_reference_autograd(name, train):
+    g = load('variants_grad')
+    tag = f"{name}.{'train' if train else 'eval'}"
+    model = build(name, train)
+    assert not model.fused_ok()
+    x = {k: v.to(DEV) for k, v in variant_inputs(name).items()}
+    y = variant_labels(name).to(DEV)
+    lg = model(x)
+    assert lg.requires_grad and lg.shape == g[f'{tag}.logits'].shape
+    np.testing.assert_allclose(lg.detach().cpu().numpy(), g[f'{tag}.logits'], atol=5e-4 * np.abs(g[f'{tag}.logits']).max())
+    loss = F.cross_entropy(lg.flatten(0, 1), y.flatten().long(), ignore_index=-1)
+    assert abs(float(loss.detach()) - float(g[f'{tag}.loss'])) <= 2e-4 * abs(float(g[f'{tag}.loss']))
+    loss.backward()
+    worst = check_grads(model, g, tag)
+    print(tag, 'worst gradient error / scale', worst)
+    # a second backward through the same node is refused (the tape is consumed), and no_grad keeps the old inference behaviour
+    with torch.no_grad():
+        assert not model(x).requires_grad
+
+
+def test_sleep_ppgnet_train_mode_gradients_match_reference_autograd():
+    """SleepPPGNet as the reference trains it (BatchNorm on batch statistics, LeakyReLU, 256-channel layers; dropout 0 for determinism) on two
+    10-hour inputs: loss, every parameter's gradient, and the running statistics after the step."""
+    g = load('variants_grad')
+    torch.manual_seed(4100)
+    ppg = W.SleepPPGNet(n_classes=4, feature_dim=128, dropout=0.0, activation='leaky', norm='batch')
+    ppg.load_state_dict(perturb_state(ppg.state_dict(), seed=78), strict=True)
+    ppg = ppg.to(DEV).train()
+    x = torch.randn(2, 1228800, generator=torch.Generator().manual_seed(4102)).to(DEV)
+    y = torch.from_numpy(g['ppgnet.train.labels']).to(DEV)
+    lg = ppg(x)
+    want = g['ppgnet.train.logits']
+    np.testing.assert_allclose(lg.detach().cpu().numpy(), want, atol=1e-3 * np.abs(want).max())
+    loss = F.cross_entropy(lg.flatten(0, 1), y.flatten().long(), ignore_index=-1)
+    assert abs(float(loss.detach()) - float(g['ppgnet.train.loss'])) <= 3e-4 * float(g['ppgnet.train.loss'])
+    loss.backward()
+    worst = check_grads(ppg, g, 'ppgnet.train')
+    print('ppgnet worst gradient error / scale', worst)
+    after = ppg.state_dict()
+    for k in ('conv_block.model.0.conv1.norm.running_mean', 'conv_block.model.7.conv3.norm.running_var', 'dilated_convs.1.conv_layers.5.norm.running_var'):
+        np.testing.assert_allclose(after[k].cpu().numpy(), g[f'ppgnet.train.after.{k}'], rtol=5e-4, atol=1e-5, err_msg=k)
+
+
+# ------------------------------------------------------------------ the backward kernels one by one, against torch CPU autograd
+ACTS = {'linear': lambda t: t, 'relu': F.relu, 'leaky': F.leaky_relu, 'gelu': F.gelu, 'silu': F.silu}
+
+
+def rel(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double()
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize('act', ['linear', 'relu', 'leaky', 'gelu', 'silu'])
+@pytest.mark.parametrize('kind', ['none', 'instance', 'batch_train', 'batch_eval', 'group'])
+def test_norm_activation_backward_against_autograd(kind, act):
+    from wav2sleep_amd.generic import GenericForward
+    torch.manual_seed(5)
+    B, L, Cc = 3, 1500, 32
+    layer = W.ConvLayer1D(16, Cc, kernel_size=3, padding=1, activation=act, norm={'none': None, 'instance': 'instance', 'batch_train': 'batch',
+                                                                                 'batch_eval': 'batch', 'group': 'group'}[kind])
+    if kind.startswith('batch') or kind == 'group':
+        n = layer.norm if kind.startswith('batch') else layer.norm.norm
+        with torch.no_grad():
+            n.weight.normal_(1, 0.3); n.bias.normal_(0, 0.3)
+            if kind.startswith('batch'):
+                n.running_mean.normal_(0, 0.3); n.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(B, 16, L)
+    go = torch.randn(B, Cc, L)
+    # torch CPU: the reference's ConvLayer1D.forward (blocks.py:173-186)
+    ref = {k: v.detach().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+    xr = x.clone().requires_grad_(True)
+    o = F.conv1d(xr, ref['conv.weight'], ref.get('conv.bias'), padding=1)
+    if kind == 'instance':
+        o = F.instance_norm(o, eps=layer.norm.eps)
+    elif kind.startswith('batch'):
+        o = F.batch_norm(o, layer.norm.running_mean.clone(), layer.norm.running_var.clone(), ref['norm.weight'], ref['norm.bias'], kind == 'batch_train', 0.1, layer.norm.eps)
+    elif kind == 'group':
+        o = F.group_norm(o, layer.norm.norm.num_groups, ref['norm.norm.weight'], ref['norm.norm.bias'], layer.norm.norm.eps)
+    ACTS[act](o).backward(go)
+    layer = layer.to(DEV).train(kind == 'batch_train')
+    with torch.cuda.device(0):
+        gf = GenericForward(training=kind == 'batch_train', grad=True)
+        xin = x.transpose(1, 2).contiguous().to(DEV)
+        out = gf.conv_layer(layer, xin)
+        # the input's gradient: make it a recorded tensor by giving the tape a root
+        pg = gf.backward(out, go.transpose(1, 2).contiguous().to(DEV))
+    for k, p in layer.named_parameters():
+        assert rel(pg[p], ref[k].grad) < 1e-3, (kind, act, k, rel(pg[p], ref[k].grad))
+
+
+@pytest.mark.parametrize('Cc,rms,act', [(16, False, 'linear'), (48, False, 'gelu'), (128, True, 'silu'), (1000, False, 'relu'), (64, True, 'leaky')])
+def test_rownorm_backward_against_autograd(Cc, rms, act):
+    torch.manual_seed(6)
+    rows = 777
+    x = torch.randn(rows, Cc) * 1.5 + 0.3
+    gam = (1 + 0.3 * torch.randn(Cc)).requires_grad_(True)
+    bet = None if rms else (0.2 * torch.randn(Cc)).requires_grad_(True)
+    go = torch.randn(rows, Cc)
+    xr = x.clone().requires_grad_(True)
+    if rms:
+        o = xr / torch.sqrt(xr.pow(2).mean(1, keepdim=True) + 1e-5) * gam
+    else:
+        o = F.layer_norm(xr, (Cc,), gam, bet, 1e-5)
+    ACTS[act](o).backward(go)
+    code = lib.ACT[act]
+    xd, gd = x.to(DEV), go.to(DEV)
+    nb = lib.rownorm_bwd_blocks(rows)
+    part = torch.empty(nb, 2, Cc, device=DEV)
+    gx = torch.empty_like(xd)
+    lib.rownorm_bwd(gd, Cc, xd, Cc, gam.detach().to(DEV), bet.detach().to(DEV) if bet is not None else None, gx, Cc, part, rows, Cc, 1e-5, rms, code)
+    assert rel(gx, xr.grad) < 2e-4
+    assert rel(part[:, 0].sum(0), gam.grad) < 2e-4
+    if bet is not None:
+        assert rel(part[:, 1].sum(0), bet.grad) < 2e-4
+
+
+@pytest.mark.parametrize('D,H,hd', [(2, 1, 16), (5, 4, 4), (7, 2, 32), (16, 3, 8)])
+def test_generic_attention_backward_against_autograd(D, H, hd):
+    torch.manual_seed(7)
+    N, Fd = 37, H * hd
+    qkv = torch.randn(N, D, 3 * Fd)
+    pad = torch.rand(N, D) < 0.3
+    pad[:, 0] = False
+    go = torch.randn(N, D, Fd)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = (t.view(N, D, H, hd).transpose(1, 2) for t in qr.split(Fd, dim=2))
+    sc = (q @ k.transpose(-1, -2)) / hd ** 0.5
+    sc = sc.masked_fill(pad[:, None, None, :], float('-inf'))
+    o = (sc.softmax(-1) @ v).transpose(1, 2).reshape(N, D, Fd)
+    o.backward(go)
+    qd, kp, gd = qkv.to(DEV), pad.to(torch.uint8).to(DEV), go.to(DEV)
+    out = torch.empty(N, D, Fd, device=DEV)
+    lib.attn_generic_fwd(qd, kp, out, N, D, H, hd)
+    assert rel(out, o) < 1e-5
+    gq = torch.full_like(qd, float('nan'))
+    lib.attn_generic_bwd(qd, kp, gd, gq, N, D, H, hd)
+    assert rel(gq, qr.grad) < 1e-4
+    # dropout on the attention weights: forward and backward draw the same mask -- <go, f(q,k,V)> is linear in V with gradient gV
+    p, seed = 0.3, 1234
+    lib.attn_generic_fwd(qd, kp, out, N, D, H, hd, p, seed)
+    lib.attn_generic_bwd(qd, kp, gd, gq, N, D, H, hd, p, seed)
+    lhs = float((out.double() * gd.double()).sum())
+    rhs = float((gq[..., 2 * Fd:].double() * qd[..., 2 * Fd:].double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+    out0 = torch.empty_like(out)
+    lib.attn_generic_fwd(qd, kp, out0, N, D, H, hd)
+    assert not torch.equal(out0, out)   # some weights were dropped
+
+
+def test_generic_training_step_reduces_the_loss():
+    """SleepPPGNet-style training loop written as the reference's Lightning module does it (criterion on flattened logits, loss.backward(),
+    clip_grad_norm_, AdamW): the gradients come from the tape, the loss falls."""
+    torch.manual_seed(11)
+    model = W.Wav2Sleep(W.SignalEncoders({'ECG': 'ECG', 'THX': 'THX'}, feature_dim=32, activation='leaky', norm='batch'),
+                        W.MultiModalAttentionEmbedder(32, layers=1, nhead=4, dim_ff=64, dropout=0.1, activation='relu'),
+                        W.SequenceCNN(32, norm='batch', activation='leaky', dropout=0.1, num_layers=1, num_dilations=3), 4).to(DEV).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-3)
+    g = torch.Generator().manual_seed(12)
+    x = {'ECG': torch.randn(4, 12 * 1024, generator=g).to(DEV), 'THX': torch.randn(4, 12 * 256, generator=g).to(DEV)}
+    y = torch.randint(0, 4, (4, 12), generator=g).to(DEV)
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        loss = F.cross_entropy(model(x).flatten(0, 1), y.flatten(), ignore_index=-1)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], losses

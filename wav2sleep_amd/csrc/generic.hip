@@ -88,7 +88,8 @@ extern "C" int w2s_rownorm_fwd(const float* x, int ldx, const float* gamma, cons
 // transformer attends over 1 + C modality tokens): qkv [N][D][3 H hd] (q | k | v), keypad [N][D] (1 = padded key), out [N][D][H hd].
 // One thread per (sentence, head, query token); inference (no dropout).  Production (hd = 16, D <= 7) uses w2s_attn_fwd instead.
 __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ keypad,
-                                                               float* __restrict__ out, long N, int D, int H, int hd, float scale) {
+                                                               float* __restrict__ out, long N, int D, int H, int hd, float scale, float p,
+                                                               uint64_t seed) {
   const long total = N * H * D;
   const int F = H * hd;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const float* __re
     float den = 0.f;
     for (int j = 0; j < D; ++j) { sc[j] = __expf(sc[j] - mx); den += sc[j]; }
     const float inv = 1.0f / den;
+    if (p > 0.f)   // dropout on the attention weights (F.multi_head_attention_forward, training): mask index ((n H + h) D + query) D + key
+      for (int j = 0; j < D; ++j) sc[j] *= w2s_dropscale(seed, (uint64_t)(i * D + j), p);
     float* o = out + (n * D + qi) * F + h * hd;
     for (int e = 0; e < hd; ++e) {
       float a = 0.f;
@@ -118,13 +121,263 @@ __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const float* __re
   }
 }
 
-extern "C" int w2s_attn_generic_fwd(const float* qkv, const unsigned char* keypad, float* out, long N, int D, int H, int hd, void* stream) {
-  if (!qkv || !keypad || !out || N <= 0 || D <= 0 || D > 16 || H <= 0 || hd <= 0) return W2S_EINVAL;
+extern "C" int w2s_attn_generic_fwd(const float* qkv, const unsigned char* keypad, float* out, long N, int D, int H, int hd, float p_drop,
+                                    uint64_t seed, void* stream) {
+  if (!qkv || !keypad || !out || N <= 0 || D <= 0 || D > 16 || H <= 0 || hd <= 0 || p_drop < 0.f || p_drop >= 1.f) return W2S_EINVAL;
   const long total = N * H * D;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(attn_generic_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkv, keypad, out, N,
-                     D, H, hd, 1.0f / sqrtf((float)hd));
+                     D, H, hd, 1.0f / sqrtf((float)hd), p_drop, seed);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// ===================================================================================================================
+// Backward kernels of the generic path (round 6): training of the module variants above -- SleepPPGNet (BatchNorm / LeakyReLU, which the
+// reference trains: models/ppgnet.py), feature sizes other than 128, the other norms and activations.  Data and weight gradients of the
+// convolutions / GEMMs are w2s_conv_forward (flip / UP2 forms) and w2s_wgrad; what is left is the backward of norm -> activation
+// (ConvLayer1D.forward, blocks.py:183-185), of the row norms and of the attention core.  HBM-bound elementwise / row kernels like the
+// forward's three; per-(sample, channel) sums leave as per-tile fp32 partials for w2s_stats_finalize (fp64, fixed order).
+// ===================================================================================================================
+__device__ __forceinline__ float act_grad_f(float z, int act, float slope) {
+  switch (act) {
+    case 1: return z > 0.f ? 1.f : 0.f;        // threshold_backward
+    case 2: return z > 0.f ? 1.f : slope;      // leaky_relu_backward
+    case 3: return gelu_grad_f(z);
+    case 4: { const float sg = 1.0f / (1.0f + __expf(-z)); return sg * (1.0f + z * (1.0f - sg)); }
+    default: return 1.f;
+  }
+}
+
+// the normalised value xh and the activation's input z of four channels:  xh = stats ? (y - mean) * rstd : y,   z = gamma ? xh * gamma + beta : xh
+struct NormCh { f32x4 mean, rstd, gamma, beta; int has_stats, has_affine; };
+__device__ __forceinline__ NormCh norm_ch(const float* stats, long soff, const float* gamma, const float* beta, int c) {
+  NormCh k;
+  k.has_stats = stats != nullptr;
+  k.has_affine = gamma != nullptr;
+  k.mean = splat4(0.f); k.rstd = splat4(1.f); k.gamma = splat4(1.f); k.beta = splat4(0.f);
+  if (stats) {
+    const f32x4 a = ld4(stats + soff + 2 * c), b = ld4(stats + soff + 2 * c + 4);   // (mean, rstd) interleaved
+    k.mean = (f32x4){a.x, a.z, b.x, b.z};
+    k.rstd = (f32x4){a.y, a.w, b.y, b.w};
+  }
+  if (gamma) { k.gamma = ld4(gamma + c); if (beta) k.beta = ld4(beta + c); }
+  return k;
+}
+__device__ __forceinline__ void norm_act_grad4(const NormCh& k, f32x4 g, f32x4 y, int act, float slope, f32x4& ga, f32x4& xh) {
+  xh = (y - k.mean) * k.rstd;
+  const f32x4 z = xh * k.gamma + k.beta;
+  ga = (f32x4){g.x * act_grad_f(z.x, act, slope), g.y * act_grad_f(z.y, act, slope), g.z * act_grad_f(z.z, act, slope),
+               g.w * act_grad_f(z.w, act, slope)};
+}
+
+// pass 1: part[s][tile][0][c] = sum_rows ga, part[s][tile][1][c] = sum_rows ga * xh,   ga = g * act'(z)   (rows of sample s in the tile)
+__global__ __launch_bounds__(256) void norm_act_bwd_part_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ y, int ldy,
+                                                                const float* __restrict__ stats, int stats_stride, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int rows_per_sample, int C, int act, float slope,
+                                                                int tile, float* __restrict__ part) {
+  __shared__ float sm[2048];   // [rows in flight][2][C]
+  const int s = blockIdx.y, tl = blockIdx.x, nt = gridDim.x, tid = threadIdx.x;
+  const int c4n = C >> 2, rpb = 256 / c4n, q = tid % c4n, rr = tid / c4n, c = q * 4;
+  f32x4 a1 = splat4(0.f), a2 = splat4(0.f);
+  if (rr < rpb) {
+    const NormCh k = norm_ch(stats, (long)s * stats_stride, gamma, beta, c);
+    const long row0 = (long)s * rows_per_sample;
+    const int t1 = min(rows_per_sample, (tl + 1) * tile);
+    for (int t = tl * tile + rr; t < t1; t += rpb) {
+      f32x4 ga, xh;
+      norm_act_grad4(k, ld4(g + (row0 + t) * ldg + c), ld4(y + (row0 + t) * ldy + c), act, slope, ga, xh);
+      a1 += ga;
+      a2 += ga * xh;
+    }
+    st4(sm + (rr * 2 + 0) * C + c, a1);
+    st4(sm + (rr * 2 + 1) * C + c, a2);
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) {
+    float v = 0.f;
+    for (int r = 0; r < rpb; ++r) v += sm[r * 2 * C + i];
+    part[((size_t)s * nt + tl) * 2 * C + i] = v;
+  }
+}
+
+extern "C" int w2s_norm_act_bwd_part(const float* g, int ldg, const float* y, int ldy, const float* stats, int stats_stride, const float* gamma,
+                                     const float* beta, int rows_per_sample, int nsamples, int C, int act, float slope, int tile, float* part,
+                                     void* stream) {
+  if (!g || !y || !part || rows_per_sample <= 0 || nsamples <= 0 || C < 4 || C > 1024 || (C & 3) || (ldg & 3) || (ldy & 3) || (stats_stride & 3) ||
+      act < 0 || act > 4 || tile <= 0 || (beta && !gamma))
+    return W2S_EINVAL;
+  const int nt = (rows_per_sample + tile - 1) / tile;
+  hipLaunchKernelGGL(norm_act_bwd_part_kernel, dim3(nt, nsamples), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, ldg, y, ldy, stats,
+                     stats_stride, gamma, beta, rows_per_sample, C, act, slope, tile, part);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// pass 2: gy = coef ? A * ga + B + Cx * xh : ga     coef [.][3][C] = (A, B, Cx) per (sample, channel) (coef_stride 0: one set for all samples):
+// every statistics-based norm's backward has this shape -- instance (A = rstd, B = -rstd mean(ga), Cx = -rstd mean(ga xh)), BatchNorm in
+// training (the same with the means over the batch and gamma folded), GroupNorm (means over the group), eval-mode BatchNorm (A only).
+__global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ y, int ldy,
+                                                                 const float* __restrict__ stats, int stats_stride, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ coef, int coef_stride,
+                                                                 float* __restrict__ gy, int ldgy, int rows_per_sample, long rows, int C, int act,
+                                                                 float slope) {
+  const int c4n = C >> 2;
+  const long total = rows * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    const long s = row / rows_per_sample;
+    const NormCh k = norm_ch(stats, s * stats_stride, gamma, beta, c);
+    f32x4 ga, xh;
+    norm_act_grad4(k, ld4(g + row * ldg + c), ld4(y + row * ldy + c), act, slope, ga, xh);
+    if (coef) {
+      const float* cf = coef + s * coef_stride + c;
+      ga = ld4(cf) * ga + ld4(cf + C) + ld4(cf + 2 * C) * xh;
+    }
+    st4(gy + row * ldgy + c, ga);
+  }
+}
+
+extern "C" int w2s_norm_act_bwd_apply(const float* g, int ldg, const float* y, int ldy, const float* stats, int stats_stride, const float* gamma,
+                                      const float* beta, const float* coef, int coef_stride, float* gy, int ldgy, int rows_per_sample, long rows,
+                                      int C, int act, float slope, void* stream) {
+  if (!g || !y || !gy || rows_per_sample <= 0 || rows <= 0 || C < 4 || (C & 3) || (ldg & 3) || (ldy & 3) || (ldgy & 3) || (stats_stride & 3) ||
+      (coef_stride & 3) || act < 0 || act > 4 || (beta && !gamma))
+    return W2S_EINVAL;
+  const long total = rows * (C >> 2);
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(norm_act_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, ldg, y, ldy, stats,
+                     stats_stride, gamma, beta, coef, coef_stride, gy, ldgy, rows_per_sample, rows, C, act, slope);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// Backward of w2s_rownorm_fwd (norm over the channels of a row, affine, activation): x = the norm's INPUT, g = gradient of the activation's
+// output.  gx = rstd (gh - mean_c(gh) - xh mean_c(gh xh)), gh = g act'(z) gamma  (RMS: no mean term);  part[block][0][c] = sum_rows
+// g act'(z) xh (gamma's gradient), part[block][1][c] = sum_rows g act'(z) (beta's).  One wave per row, any C <= 1024; gx may alias g.
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ gx,
+                                                          int ldgx, float* __restrict__ part, long rows, int C, float eps, int rms, int act,
+                                                          float slope) {
+  extern __shared__ float sm[];   // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* sg = sm + wave * 2 * C;
+  float* sb = sg + C;
+  for (int c = lane; c < C; c += 64) { sg[c] = 0.f; sb[c] = 0.f; }
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float* xr = x + row * ldx;
+    const float* gr = g + row * ldg;
+    float s = 0.f;
+    if (!rms) { for (int c = lane; c < C; c += 64) s += xr[c]; }
+    const float mean = rms ? 0.f : wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (xr[c] - mean) * rstd;
+      const float z = xh * gamma[c] + (beta ? beta[c] : 0.f);
+      const float ga = gr[c] * act_grad_f(z, act, slope);
+      const float gh = ga * gamma[c];
+      s1 += gh;
+      s2 += gh * xh;
+      sg[c] += ga * xh;
+      sb[c] += ga;
+    }
+    const float m1 = rms ? 0.f : wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (xr[c] - mean) * rstd;
+      const float z = xh * gamma[c] + (beta ? beta[c] : 0.f);
+      const float gh = gr[c] * act_grad_f(z, act, slope) * gamma[c];
+      gx[row * ldgx + c] = rstd * (gh - m1 - xh * m2);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) part[(size_t)blockIdx.x * 2 * C + i] = sm[i] + sm[2 * C + i] + sm[4 * C + i] + sm[6 * C + i];
+}
+
+extern "C" int w2s_rownorm_bwd_blocks(long rows) {
+  long blocks = (rows + 3) / 4;
+  return (int)(blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks));
+}
+
+extern "C" int w2s_rownorm_bwd(const float* g, int ldg, const float* x, int ldx, const float* gamma, const float* beta, float* gx, int ldgx,
+                               float* part, long rows, int C, float eps, int rms, int act, float slope, void* stream) {
+  if (!g || !x || !gamma || !gx || !part || rows <= 0 || C <= 0 || C > 1024 || act < 0 || act > 4) return W2S_EINVAL;
+  const int blocks = w2s_rownorm_bwd_blocks(rows);
+  hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(blocks), dim3(256), (size_t)8 * C * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, ldg, x,
+                     ldx, gamma, beta, gx, ldgx, part, rows, C, eps, rms, act, slope);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// Backward of w2s_attn_generic_fwd: gqkv [N][D][3 H hd] from gout [N][D][H hd]; one thread per (sentence, head) walks the queries, so the
+// key / value gradients it accumulates (in gqkv itself) are its own -- no atomics, fixed order.  The softmax (and the dropout mask of the
+// forward, same seed) is recomputed per query.
+__global__ __launch_bounds__(256) void attn_generic_bwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ keypad,
+                                                               const float* __restrict__ gout, float* __restrict__ gqkv, long N, int D, int H,
+                                                               int hd, float scale, float p, uint64_t seed) {
+  const long total = N * H;
+  const int F = H * hd;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int h = (int)(i % H);
+    const long n = i / H;
+    const float* base = qkv + n * D * 3 * F + h * hd;
+    float* gbase = gqkv + n * D * 3 * F + h * hd;
+    for (int j = 0; j < D; ++j)
+      for (int e = 0; e < hd; ++e) { gbase[(long)j * 3 * F + F + e] = 0.f; gbase[(long)j * 3 * F + 2 * F + e] = 0.f; }
+    for (int qi = 0; qi < D; ++qi) {
+      const float* q = base + (long)qi * 3 * F;
+      const float* go = gout + (n * D + qi) * F + h * hd;
+      float pr[16], dp[16];
+      float mx = -INFINITY;
+      for (int j = 0; j < D; ++j) {
+        const float* k = base + (long)j * 3 * F + F;
+        float s = 0.f;
+        for (int e = 0; e < hd; ++e) s += q[e] * k[e];
+        s = keypad[n * D + j] ? -INFINITY : s * scale;
+        pr[j] = s;
+        mx = fmaxf(mx, s);
+      }
+      float den = 0.f;
+      for (int j = 0; j < D; ++j) { pr[j] = __expf(pr[j] - mx); den += pr[j]; }
+      const float inv = 1.0f / den;
+      float delta = 0.f;
+      for (int j = 0; j < D; ++j) {
+        const float m = p > 0.f ? w2s_dropscale(seed, (uint64_t)((i * D + qi) * D + j), p) : 1.f;
+        const float pj = pr[j] * inv;
+        const float* v = base + (long)j * 3 * F + 2 * F;
+        float* gv = gbase + (long)j * 3 * F + 2 * F;
+        float d = 0.f;
+        for (int e = 0; e < hd; ++e) { d += go[e] * v[e]; gv[e] += pj * m * go[e]; }
+        d *= m;           // gradient of the pre-dropout weight
+        pr[j] = pj;
+        dp[j] = d;
+        delta += pj * d;
+      }
+      float* gq = gbase + (long)qi * 3 * F;
+      for (int e = 0; e < hd; ++e) gq[e] = 0.f;
+      for (int j = 0; j < D; ++j) {
+        const float ds = pr[j] * (dp[j] - delta) * scale;
+        const float* k = base + (long)j * 3 * F + F;
+        float* gk = gbase + (long)j * 3 * F + F;
+        for (int e = 0; e < hd; ++e) { gq[e] += ds * k[e]; gk[e] += ds * q[e]; }
+      }
+    }
+  }
+}
+
+extern "C" int w2s_attn_generic_bwd(const float* qkv, const unsigned char* keypad, const float* gout, float* gqkv, long N, int D, int H, int hd,
+                                    float p_drop, uint64_t seed, void* stream) {
+  if (!qkv || !keypad || !gout || !gqkv || N <= 0 || D <= 0 || D > 16 || H <= 0 || hd <= 0 || p_drop < 0.f || p_drop >= 1.f) return W2S_EINVAL;
+  const long total = N * H;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(attn_generic_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkv, keypad, gout, gqkv,
+                     N, D, H, hd, 1.0f / sqrtf((float)hd), p_drop, seed);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

@@ -676,6 +676,7 @@ static int launch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
 template <int STRIDE>
 static int dispatch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
   const WgCfg c = wg_cfg(a.cin, a.cout, a.taps, a.dil);
+  if (c.ts && a.cout % (c.nto * 16)) return W2S_EINVAL;   // the tile-split grid covers whole blocks of nw * ot o-tiles only (callers split cout)
   if (c.ts && a.split_precision && c.nw >= c.ntc && c.nw % c.ntc == 0) {
     // (OW = o-tiles per wave) = nto / (nw / ntc);  same slab layout / reduce as the fp32 tile-split kernel
     const int ow = c.nto / (c.nw / c.ntc);
@@ -707,7 +708,7 @@ static int dispatch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
     if constexpr (STRIDE == 2) {
       W2S_TS3(8, 8, W2S_PRO_INBWD_GP, W2S_PRO_IN_GELU) W2S_TS3(4, 4, W2S_PRO_INBWD_GP, W2S_PRO_IN_GELU)
     }
-    if constexpr (STRIDE <= 2) { W2S_TS(1, 3, 8, 8) W2S_TS(1, 3, 4, 4) W2S_TS(1, 3, 4, 8) }
+    if constexpr (STRIDE <= 2) { W2S_TS(1, 3, 8, 8) W2S_TS(1, 3, 4, 4) W2S_TS(1, 3, 4, 8) W2S_TS(1, 3, 8, 4) }
     W2S_TS(1, 1, 8, 8) W2S_TS(1, 1, 4, 8) W2S_TS(1, 1, 4, 4) W2S_TS(3, 1, 8, 8) W2S_TS(4, 1, 8, 8) W2S_TS(2, 1, 8, 8) W2S_TS(1, 1, 8, 4)
 #undef W2S_TS
 #undef W2S_TS3
@@ -717,6 +718,9 @@ static int dispatch_wgrad(const w2s_wgrad_args& a, hipStream_t s) {
   if (c.nto == NTO_ && c.ntc == NTC_ && c.tapst == TT_) return launch_wgrad<NTO_, NTC_, TT_, STRIDE>(a, s);
   if constexpr (STRIDE <= 2) {
     W2S_WG(1, 1, 3) W2S_WG(2, 1, 3) W2S_WG(2, 2, 3) W2S_WG(4, 2, 3) W2S_WG(2, 4, 3)
+    // shapes only the generic training path reaches (generic.py: feature sizes 16 / 32 / 64, SleepPPGNet's pieces): the rest of wg_cfg's range
+    W2S_WG(4, 1, 3) W2S_WG(8, 1, 3) W2S_WG(1, 2, 3) W2S_WG(1, 4, 3)
+    W2S_WG(4, 1, 1) W2S_WG(8, 1, 1) W2S_WG(1, 2, 1) W2S_WG(8, 2, 1) W2S_WG(1, 4, 1) W2S_WG(2, 4, 1) W2S_WG(1, 8, 1) W2S_WG(2, 8, 1)
   }
   W2S_WG(1, 1, 1) W2S_WG(2, 1, 1) W2S_WG(2, 2, 1) W2S_WG(4, 2, 1) W2S_WG(4, 4, 1) W2S_WG(8, 4, 1) W2S_WG(4, 8, 1)
 #undef W2S_WG

@@ -1,4 +1,4 @@
-"""Generic (untuned) inference path: every module variant the reference can be configured into besides its shipped production model.
+"""Generic (untuned) path: every module variant the reference can be configured into besides its shipped production model.
 
 `models/utils.py:26-96` offers batch / layer / rms / group / instance / no normalisation and ReLU / LeakyReLU / GELU / SiLU / linear
 activations; `MultiModalAttentionEmbedder` and `SequenceCNN` take any feature size and head count (the reference's own
@@ -6,8 +6,12 @@ tests/model/test_causality.py builds feature_dim 16, ReLU, BatchNorm, 4 layers x
 from the same blocks.  The production model (GELU, instance / layer norm, 128 features, 16-wide heads) runs on the fused kernels
 (engine.py); everything else runs here: the reference's call graph, layer by layer, on channels-last device tensors, every convolution and
 GEMM through `w2s_conv_forward` (no prologue; contractions wider than 128 channels as accumulating launches) and the norms / activations /
-attention core through the three kernels of csrc/generic.hip.  Forward only: these variants have no backward kernels, the result carries
-no autograd graph.  Host-side torch is used for plumbing only: folding per-(sample, channel) statistics and affine parameters into
+attention core through the kernels of csrc/generic.hip.  With `grad=True` the walker also records a TAPE -- one entry per launch group
+(output, inputs, backward closure) -- and `backward()` replays it in reverse: data gradients are `w2s_conv_forward` again (flipped taps,
+W2S_MODE_UP2 for the stride-2 convs, transposed weights for the GEMMs), weight gradients `w2s_wgrad` (cut into the channel blocks its
+kernels take), norm / activation / attention backward the kernels of csrc/generic.hip; that is what `SleepPPGNet` (which the reference
+trains, models/ppgnet.py) and the non-production `Wav2Sleep` configurations train on (ops.py wraps it as one autograd node).  Nothing of
+torch's autograd runs underneath.  Host-side torch is used for plumbing only: folding per-(sample, channel) statistics and affine parameters into
 (scale, shift) vectors -- [B, C] scalars --, zero-padding the one-channel input, slicing weights.
 
 Reference call sites mirrored: ConvLayer1D.forward (blocks.py:173-186), ConvBlock1D.forward (:57-71), DilatedConvBlock.forward (:115-126),
@@ -35,54 +39,171 @@ def _act_code(name: str) -> int:
     return lib.ACT[name]
 
 
-def _pow2_chunk(c: int) -> int:
-    """Contraction width of one launch: the kernels take a power-of-two channel count in [16, 128]."""
-    if c > 128:
-        if c % 128:
-            raise NotImplementedError(f'{c} input channels: widths above 128 must be multiples of 128')
-        return 128
-    if c < 16 or c & (c - 1):
-        raise NotImplementedError(f'{c} input channels: the generic kernels take powers of two in [16, 128] (or multiples of 128)')
-    return c
-
-
-def act_(x: torch.Tensor, name: str, slope: float = 0.01) -> torch.Tensor:
-    """In-place activation of a contiguous [..., C] tensor."""
-    code = _act_code(name)
-    if code:
-        Cc = x.shape[-1]
-        lib.affine_act(x, Cc, None, None, 0, x, Cc, 1, x.numel() // Cc, Cc, code, slope)
-    return x
+def _chunks(c: int):
+    """Contraction widths of the launches that cover c channels: the kernels take a power-of-two channel count in [16, 128], so c (a
+    multiple of 16) is cut greedily -- 256 -> 128 + 128, 48 -> 32 + 16 -- and the launches after the first accumulate.  [(offset, width)]"""
+    if c < 16 or c % 16:
+        raise NotImplementedError(f'{c} input channels: the generic kernels contract over multiples of 16')
+    out, o = [], 0
+    while o < c:
+        w = 128
+        while w > c - o:
+            w >>= 1
+        out.append((o, w))
+        o += w
+    return out
 
 
 class GenericForward:
-    """Stateless walker over the parameter containers of wav2sleep.py (same attribute names as the reference modules)."""
+    """Stateless walker over the parameter containers of wav2sleep.py (same attribute names as the reference modules).
+    grad=True: every launch group is recorded on a tape and nothing is overwritten in place; `backward(out, g)` then returns
+    {parameter: gradient}."""
 
-    def __init__(self, training: bool = False, seed: int = 0):
+    def __init__(self, training: bool = False, seed: int = 0, grad: bool = False):
         self.training = training
         self.seed = seed
+        self.grad = grad
         self._site = 0
+        self.tape = []      # (output tensor, input tensors, fn: gradient of the output -> gradients of the inputs)
+        self.pgrads = {}    # nn.Parameter -> gradient (the parameter's shape)
         lib.load()
 
+    # ------------------------------------------------------------------ tape
+    def _rec(self, out, inputs, fn):
+        if self.grad:
+            self.tape.append((out, tuple(inputs), fn))
+
+    def _add(self, a, b):
+        o = torch.empty_like(a)
+        lib.eltwise(lib.ELT_ADD, a, b.contiguous(), o, a.numel())
+        return o
+
+    def _pgrad(self, param, g):
+        g = g.reshape(param.shape)
+        self.pgrads[param] = self._add(self.pgrads[param], g) if param in self.pgrads else g.contiguous()
+
+    def _view(self, t, *shape):
+        v = t.view(*shape)
+        self._rec(v, (t,), lambda g: (g.reshape(t.shape),))
+        return v
+
+    def backward(self, out, g_out) -> dict:
+        """Replay the tape in reverse from d(loss)/d(out); returns {parameter: gradient} (a parameter used twice: the sum)."""
+        if not self.grad:
+            raise RuntimeError('GenericForward(grad=False) keeps no tape')
+        grads = {id(out): g_out.contiguous().float()}
+        for o, inputs, fn in reversed(self.tape):
+            g = grads.pop(id(o), None)
+            if g is None:
+                continue
+            for t, gi in zip(inputs, fn(g)):
+                if gi is None:
+                    continue
+                k = id(t)
+                grads[k] = self._add(grads[k], gi) if k in grads else gi
+        self.tape = []
+        return self.pgrads
+
+    def _rowsum(self, g, rows, Cc, ld):
+        """sum over `rows` rows of a [rows][ld] gradient -> [Cc] (two fixed-order stages)"""
+        nparts = max(1, min(1024, _cdiv(rows, 64)))
+        part = torch.empty(nparts, Cc, device=g.device, dtype=torch.float32)
+        lib.bias_grad(g, rows, Cc, ld, part, nparts)
+        out = torch.empty(Cc, device=g.device, dtype=torch.float32)
+        lib.colsum(part, nparts, Cc, out)
+        return out
+
+    # ------------------------------------------------------------------ weight / data gradients of a convolution
+    def _wgrad(self, g, x, *, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1):
+        """dW [cout][cin][taps] = sum_{b,t} g[b,t,:] (x) x[b, t*stride + j*dil - pad, :]: w2s_wgrad per (<= 128 input channels) x
+        (128 / 64 / 32 / 16 output channels) block -- the shapes its kernels are instantiated for -- then the deterministic slab sum."""
+        dev = g.device
+        dW = torch.empty(cout, cin, taps, device=dev, dtype=torch.float32)
+        for ci0, ck in _chunks(cin):
+            co0 = 0
+            while co0 < cout:
+                cp = next(c for c in (128, 64, 32, 16) if c <= cout - co0)
+                kw = dict(g=g if co0 == 0 else g[..., co0:], x=x if ci0 == 0 else x[..., ci0:], B=B, L_in=L_in, L_out=L_out, cin=ck, cout=cp,
+                          taps=taps, stride=stride, pad=pad, dil=dil, ldg=cout, ldx=cin, split_precision=True)
+                gy = lib.wgrad_grid_y(ck, cp, taps, dil)
+                gx = max(1, min(_cdiv(B * L_out, 256), max(1, lib.wgrad_max_blocks(slab=None, nslab=0, **kw) // gy)))
+                nslab = gx * lib.wgrad_slabs_per_block_of(slab=None, nslab=0, **kw)
+                slab = torch.empty(nslab * cp * ck * taps, device=dev, dtype=torch.float32)
+                lib.wgrad(slab=slab, nslab=nslab, **kw)
+                piece = dW if (cp == cout and ck == cin) else torch.empty(cp, ck, taps, device=dev, dtype=torch.float32)
+                lib.wgrad_reduce(slab, nslab, piece, cp, ck, taps, dil, False, 0)
+                if piece is not dW:
+                    dW[co0:co0 + cp, ci0:ci0 + ck] = piece
+                co0 += cp
+        return dW
+
+    def _dgrad(self, gy, w, *, B, L_x, L_out, stride, pad, dil):
+        """gradient of the conv input: gy [B, L_out, cout], w [cout, cin, k] -> gx [B, L_x, cin] (w2s_conv_forward on the transposed weights:
+        flipped taps for stride 1, W2S_MODE_UP2 for the k=3 / stride-2 conv, the even rows of gx for the 1x1 / stride-2 residual conv)."""
+        cout, cin, k = w.shape
+        dev = gy.device
+        if cin % 16:
+            raise NotImplementedError(f'data gradient towards {cin} channels: multiples of 16')
+        wb = w.permute(1, 2, 0).contiguous()   # [cin][k][cout]
+        chunks = _chunks(cout)
+        nchunk = len(chunks)
+        if stride == 2 and k == 1:
+            if pad != 0:
+                raise NotImplementedError('1x1 / stride-2 conv with padding')
+            gx = torch.zeros(B, L_x, cin, device=dev, dtype=torch.float32)
+            samples = [(gy, gx, B)] if L_x == 2 * L_out else [(gy[b], gx[b], 1) for b in range(B)]
+            for gs, xs, nb in samples:   # row t of the gradient lands on row 2t of gx: a GEMM whose output row stride is two rows of gx
+                for q, (c0, ck) in enumerate(chunks):
+                    wq = wb if nchunk == 1 else wb[:, :, c0:c0 + ck].contiguous()
+                    lib.conv_forward(lib.conv_args(x=gs if q == 0 else gs[..., c0:], w=wq, y=xs, B=1, L_in=nb * L_out, L_out=nb * L_out, cin=ck, cout=cin,
+                                                   taps=1, stride=1, pad=0, ldx=cout, ldy=2 * cin, accumulate=q > 0))
+            return gx
+        gx = torch.empty(B, L_x, cin, device=dev, dtype=torch.float32)
+        for q, (c0, ck) in enumerate(chunks):
+            wq = wb if nchunk == 1 else wb[:, :, c0:c0 + ck].contiguous()
+            xq = gy if q == 0 else gy[..., c0:]
+            if stride == 1:
+                mode = lib.MODE_DILATED if k == 7 else lib.MODE_CONTIG
+                a = lib.conv_args(x=xq, w=wq, y=gx, B=B, L_in=L_out, L_out=L_x, cin=ck, cout=cin, taps=k, stride=1, pad=(k - 1) * dil - pad, dil=dil,
+                                  flip=1, mode=mode, ldx=cout, accumulate=q > 0)
+            elif stride == 2 and k == 3 and dil == 1:
+                a = lib.conv_args(x=xq, w=wq, y=gx, B=B, L_in=L_out, L_out=L_x, cin=ck, cout=cin, taps=3, stride=2, pad=pad, mode=lib.MODE_UP2,
+                                  ldx=cout, accumulate=q > 0)
+            else:
+                raise NotImplementedError(f'data gradient of kernel_size={k}, stride={stride}, dilation={dil}')
+            lib.conv_forward(a)
+        return gx
+
     # ------------------------------------------------------------------ convolution + normalisation + activation
-    def _conv(self, x, w, bias, L_out, *, stride, pad, dil, want_stats=None, eps=1e-5):
+    def _col_stats(self, y, B, L, Cc, eps, kind):
+        """per-(sample, channel) statistics of y [B, L, C] in a pass of their own (layers whose contraction is split over several launches)"""
+        tile = 1024
+        nt = _cdiv(L, tile)
+        part = torch.empty(B, nt, 2, Cc, device=y.device, dtype=torch.float32)
+        lib.norm_act_bwd_part(y, Cc, y, Cc, None, 0, None, None, L, B, Cc, 0, 0.0, tile, part)   # (sum y, sum y*y): g = y, no norm, linear
+        stats = torch.empty(B, Cc, 2, device=y.device, dtype=torch.float32)
+        lib.stats_finalize(part, B, nt, Cc, L, eps, kind, stats)
+        return stats
+
+    def _conv(self, x, wp, bp, L_out, *, stride, pad, dil, want_stats=None, eps=1e-5, x_needs_grad=True):
         """x [B, L_in, Cin] -> y [B, L_out, Cout]; left padding `pad` (zeros), taps j read x[t*stride + j*dil - pad].
-        want_stats: None | 0 (mean, rstd) | 1 (E[y], E[y^2]) -> [B, Cout, 2]."""
+        wp / bp: the weight / bias PARAMETERS ([cout, cin, k] / [cout] or None).  want_stats: None | 0 (mean, rstd) | 1 (E[y], E[y^2]) -> [B, Cout, 2]."""
+        w = wp.detach()
+        bias = bp.detach() if bp is not None else None
         B, L_in, cin = x.shape
-        cout, _, k = w.shape
+        cout, cin_w, k = w.shape
         if cout % 16:
             raise NotImplementedError(f'{cout} output channels: the generic kernels produce multiples of 16')
         dev = x.device
+        x_in = x
         if cin == 1:   # zero-pad the one-channel input to the narrowest tile the matrix path takes
             x16 = torch.zeros(B, L_in, 16, device=dev, dtype=torch.float32)
             x16[..., 0] = x[..., 0]
             w16 = torch.zeros(cout, 16, k, device=dev, dtype=torch.float32)
             w16[:, 0] = w[:, 0]
             x, w, cin = x16, w16, 16
-        ck = _pow2_chunk(cin)
-        nchunk = cin // ck
-        if want_stats is not None and nchunk > 1:
-            raise NotImplementedError('statistics-based norms on layers wider than 128 input channels')
+        chunks = _chunks(cin)
+        nchunk = len(chunks)
         y = torch.empty(B, L_out, cout, device=dev, dtype=torch.float32)
         if k == 7 and stride == 1:
             mode = lib.MODE_DILATED
@@ -93,13 +214,14 @@ class GenericForward:
         else:
             raise NotImplementedError(f'kernel_size={k}, stride={stride}, dilation={dil}: no generic kernel')
         stats = None
-        for q in range(nchunk):
-            wq = w[:, q * ck:(q + 1) * ck, :].permute(0, 2, 1).contiguous()   # [cout][k][ck]
-            xq = x if nchunk == 1 else x[..., q * ck:]                          # pointer offset; row stride stays the full width
+        fused_stats = want_stats is not None and nchunk == 1
+        for q, (c0, ck) in enumerate(chunks):
+            wq = w[:, c0:c0 + ck, :].permute(0, 2, 1).contiguous()             # [cout][k][ck]
+            xq = x if q == 0 else x[..., c0:]                                   # pointer offset; row stride stays the full width
             a = lib.conv_args(x=xq, w=wq, y=y, B=B, L_in=L_in, L_out=L_out, cin=ck, cout=cout, taps=k, stride=stride, pad=pad, dil=dil, mode=mode,
-                              ldx=cin, epi=lib.EPI_BIAS if (bias is not None and q == 0) else (lib.EPI_STATS if want_stats is not None else lib.EPI_PLAIN),
+                              ldx=cin, epi=lib.EPI_BIAS if (bias is not None and q == 0) else (lib.EPI_STATS if fused_stats else lib.EPI_PLAIN),
                               bias=bias if q == 0 else None, accumulate=q > 0)
-            if want_stats is not None:
+            if fused_stats:
                 nt = _cdiv(L_out, lib.conv_tile_of(a))
                 part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
                 lib.set_part(a, part)
@@ -108,23 +230,89 @@ class GenericForward:
                 lib.stats_finalize(part, B, nt, cout, L_out, eps, want_stats, stats)
             else:
                 lib.conv_forward(a)
+        if want_stats is not None and not fused_stats:
+            stats = self._col_stats(y, B, L_out, cout, eps, want_stats)
+        if self.grad:
+            xs = x   # the (padded) operand of the weight gradient
+
+            def bw(gy):
+                if bp is not None:
+                    self._pgrad(bp, self._rowsum(gy, B * L_out, cout, cout))
+                dW = self._wgrad(gy, xs, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=k, stride=stride, pad=pad, dil=dil)
+                self._pgrad(wp, dW[:, :cin_w] if cin_w != cin else dW)
+                if not x_needs_grad or cin_w == 1:
+                    return (None,)
+                return (self._dgrad(gy, wp.detach(), B=B, L_x=L_in, L_out=L_out, stride=stride, pad=pad, dil=dil),)
+            self._rec(y, (x_in,), bw)
         return y, stats
 
+    def _act(self, x, name: str, slope: float = 0.01):
+        """activation of a contiguous [..., C] tensor (in place unless a gradient is wanted)"""
+        code = _act_code(name)
+        if not code:
+            return x
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        if not self.grad:
+            lib.affine_act(x, Cc, None, None, 0, x, Cc, 1, rows, Cc, code, slope)
+            return x
+        out = torch.empty_like(x)
+        lib.affine_act(x, Cc, None, None, 0, out, Cc, 1, rows, Cc, code, slope)
+
+        def bw(g):
+            gx = torch.empty_like(g)
+            lib.norm_act_bwd_apply(g, Cc, x, Cc, None, 0, None, None, None, 0, gx, Cc, rows, rows, Cc, code, slope)
+            return (gx,)
+        self._rec(out, (x,), bw)
+        return out
+
+    def _stat_norm_bwd(self, g, y, stats, stride_s, gamma, beta, act, B, L, Cc, pool):
+        """backward of (statistics-based norm -> affine -> activation) over y [B, L, C]: per-(sample, channel) means of ga and ga * xh, pooled
+        by `pool` (means [B, C, 2] -> (m1, m2) broadcastable to [B, C]: what the norm averaged over), then gy = A ga + B + Cx xh.
+        Returns gy, sum(ga * xh) [C], sum(ga) [C] (the affine parameters' gradients)."""
+        dev = y.device
+        tile = 1024
+        nt = _cdiv(L, tile)
+        part = torch.empty(B, nt, 2, Cc, device=dev, dtype=torch.float32)
+        lib.norm_act_bwd_part(g, Cc, y, Cc, stats, stride_s, gamma, beta, L, B, Cc, act, 0.01, tile, part)
+        means = torch.empty(B, Cc, 2, device=dev, dtype=torch.float32)
+        lib.stats_finalize(part, B, nt, Cc, L, 0.0, 1, means)
+        rstd = stats.view(-1, Cc, 2)[..., 1]                                   # [B or 1, C]
+        gam = gamma[None, :] if gamma is not None else torch.ones(1, Cc, device=dev)
+        m1, m2 = pool(means[..., 0] * gam, means[..., 1] * gam)               # means of gh = ga * gamma and of gh * xh over the normalised set
+        coef = torch.stack(((rstd * gam).expand(B, Cc), (-rstd * m1).expand(B, Cc), (-rstd * m2).expand(B, Cc)), dim=1).contiguous()   # [B, 3, C]
+        gy = torch.empty_like(y)
+        lib.norm_act_bwd_apply(g, Cc, y, Cc, stats, stride_s, gamma, beta, coef, 3 * Cc, gy, Cc, L, B * L, Cc, act, 0.01)
+        return gy, means[..., 1].sum(0) * L, means[..., 0].sum(0) * L
+
     def _norm_act(self, layer, y, stats, act_name):
-        """norm -> activation of one ConvLayer1D output y [B, L, C], in place (blocks.py:183-185)."""
+        """norm -> activation of one ConvLayer1D output y [B, L, C] (blocks.py:183-185); in place unless a gradient is wanted."""
         B, L, Cc = y.shape
         rows = B * L
         act = _act_code(act_name)
         norm = layer.norm
         kind = layer.norm_name
+        out = torch.empty_like(y) if self.grad else y
+        bw = None
         if kind is None or kind == 'weight':
-            lib.affine_act(y, Cc, None, None, 0, y, Cc, L, rows, Cc, act, 0.01)
+            lib.affine_act(y, Cc, None, None, 0, out, Cc, L, rows, Cc, act, 0.01)
+
+            def bw(g):
+                gy = torch.empty_like(g)
+                lib.norm_act_bwd_apply(g, Cc, y, Cc, None, 0, None, None, None, 0, gy, Cc, L, rows, Cc, act, 0.01)
+                return (gy,)
         elif kind == 'instance':   # stats = (mean, rstd) per (b, c)
             scale = stats[..., 1].contiguous()
             shift = (-stats[..., 0] * stats[..., 1]).contiguous()
-            lib.affine_act(y, Cc, scale, shift, Cc, y, Cc, L, rows, Cc, act, 0.01)
+            lib.affine_act(y, Cc, scale, shift, Cc, out, Cc, L, rows, Cc, act, 0.01)
+            if getattr(norm, 'affine', False):
+                raise NotImplementedError('InstanceNorm1d(affine=True)')
+
+            def bw(g):
+                return (self._stat_norm_bwd(g, y, stats, 2 * Cc, None, None, act, B, L, Cc, lambda a, b: (a, b))[0],)
         elif kind == 'batch':
-            if self.training and norm.training:   # batch statistics over (B, L) + running-statistics update (nn.BatchNorm1d)
+            batch_stats = self.training and norm.training
+            if batch_stats:   # batch statistics over (B, L) + running-statistics update (nn.BatchNorm1d)
                 m = stats[..., 0].mean(0)
                 var = (stats[..., 1].mean(0) - m * m).clamp_min(0)
                 with torch.no_grad():
@@ -134,34 +322,99 @@ class GenericForward:
                     norm.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
                     norm.num_batches_tracked += 1
             else:
-                m, var = norm.running_mean, norm.running_var
-            scale = (norm.weight.detach() / torch.sqrt(var + norm.eps)).contiguous()
-            shift = (norm.bias.detach() - m * scale).contiguous()
-            lib.affine_act(y, Cc, scale, shift, 0, y, Cc, L, rows, Cc, act, 0.01)
+                m, var = norm.running_mean.detach().clone(), norm.running_var.detach().clone()
+            gam, bet = norm.weight.detach(), norm.bias.detach()
+            rstd = 1.0 / torch.sqrt(var + norm.eps)
+            scale = (gam * rstd).contiguous()
+            shift = (bet - m * scale).contiguous()
+            lib.affine_act(y, Cc, scale, shift, 0, out, Cc, L, rows, Cc, act, 0.01)
+
+            def bw(g):
+                st = torch.stack((m, rstd), dim=1).contiguous()   # [C, 2], one set for the batch
+                if batch_stats:
+                    pool = lambda a, b: (a.mean(0, keepdim=True), b.mean(0, keepdim=True))
+                else:                                             # running statistics are constants: gy = ga * gamma * rstd
+                    pool = lambda a, b: (torch.zeros_like(a[:1]), torch.zeros_like(b[:1]))
+                gy, dgam, dbet = self._stat_norm_bwd(g, y, st, 0, gam, bet, act, B, L, Cc, pool)
+                self._pgrad(norm.weight, dgam)
+                self._pgrad(norm.bias, dbet)
+                return (gy,)
         elif kind == 'group':      # stats = (E[y], E[y^2]) per (b, c): pool over the channels of a group (equal lengths)
             gn = norm.norm
             G = gn.num_groups
             e1 = stats[..., 0].view(B, G, Cc // G).mean(2, keepdim=True)
             e2 = stats[..., 1].view(B, G, Cc // G).mean(2, keepdim=True)
             rstd = 1.0 / torch.sqrt((e2 - e1 * e1).clamp_min(0) + gn.eps)
-            scale = (rstd.expand(B, G, Cc // G).reshape(B, Cc) * gn.weight.detach()[None, :]).contiguous()
-            shift = (gn.bias.detach()[None, :] - e1.expand(B, G, Cc // G).reshape(B, Cc) * scale).contiguous()
-            lib.affine_act(y, Cc, scale, shift, Cc, y, Cc, L, rows, Cc, act, 0.01)
-        elif kind == 'layer':
-            lib.rownorm_fwd(y, Cc, norm.weight.detach().reshape(Cc), norm.bias.detach().reshape(Cc), y, Cc, rows, Cc, norm.eps, False, act, 0.01)
-        elif kind == 'rms':
-            lib.rownorm_fwd(y, Cc, norm.weight.detach().reshape(Cc), None, y, Cc, rows, Cc, norm.eps, True, act, 0.01)
+            gam, bet = gn.weight.detach(), gn.bias.detach()
+            scale = (rstd.expand(B, G, Cc // G).reshape(B, Cc) * gam[None, :]).contiguous()
+            shift = (bet[None, :] - e1.expand(B, G, Cc // G).reshape(B, Cc) * scale).contiguous()
+            lib.affine_act(y, Cc, scale, shift, Cc, out, Cc, L, rows, Cc, act, 0.01)
+
+            def bw(g):
+                st = torch.stack((e1.expand(B, G, Cc // G).reshape(B, Cc), rstd.expand(B, G, Cc // G).reshape(B, Cc)), dim=2).contiguous()   # [B, C, 2]
+                grp = lambda t: t.view(B, G, Cc // G).mean(2, keepdim=True).expand(B, G, Cc // G).reshape(B, Cc)
+                gy, dgam, dbet = self._stat_norm_bwd(g, y, st, 2 * Cc, gam, bet, act, B, L, Cc, lambda a, b: (grp(a), grp(b)))
+                self._pgrad(gn.weight, dgam)
+                self._pgrad(gn.bias, dbet)
+                return (gy,)
+        elif kind in ('layer', 'rms'):
+            rms = kind == 'rms'
+            gam = norm.weight.detach().reshape(Cc)
+            bet = None if rms else norm.bias.detach().reshape(Cc)
+            lib.rownorm_fwd(y, Cc, gam, bet, out, Cc, rows, Cc, norm.eps, rms, act, 0.01)
+
+            def bw(g):
+                return (self._rownorm_bwd(g, y, norm.weight, None if rms else norm.bias, rows, Cc, norm.eps, rms, act),)
         else:
             raise ValueError(f'Normalisation with name={kind} unknown.')
-        return y
+        self._rec(out, (y,), bw)
+        return out
+
+    def _rownorm_bwd(self, g, x, wp, bp, rows, Cc, eps, rms, act):
+        nb = lib.rownorm_bwd_blocks(rows)
+        part = torch.empty(nb, 2, Cc, device=g.device, dtype=torch.float32)
+        gx = torch.empty_like(g)
+        lib.rownorm_bwd(g, Cc, x, Cc, wp.detach().reshape(Cc), bp.detach().reshape(Cc) if bp is not None else None, gx, Cc, part, rows, Cc, eps, rms, act, 0.01)
+        dg = torch.empty(Cc, device=g.device, dtype=torch.float32)
+        lib.colsum(part, nb, Cc, dg, ld=2 * Cc)
+        self._pgrad(wp, dg)
+        if bp is not None:
+            db = torch.empty(Cc, device=g.device, dtype=torch.float32)
+            lib.colsum(part.view(-1)[Cc:], nb, Cc, db, ld=2 * Cc)
+            self._pgrad(bp, db)
+        return gx
+
+    def _rownorm(self, t, wp, bp, eps, rms=False, act=0):
+        """LayerNorm / RMS norm over the last dimension of t [rows, C] (out of place)"""
+        rows, Cc = t.shape
+        o = torch.empty_like(t)
+        lib.rownorm_fwd(t, Cc, wp.detach().reshape(Cc), bp.detach().reshape(Cc) if bp is not None else None, o, Cc, rows, Cc, eps, rms, act, 0.01)
+        self._rec(o, (t,), lambda g: (self._rownorm_bwd(g, t, wp, bp, rows, Cc, eps, rms, act),))
+        return o
 
     def _dropout_(self, x, p):
-        if self.training and p > 0.0:
-            self._site += 1
-            lib.eltwise(lib.ELT_DROP, x, None, x, x.numel(), p, ((self.seed & 0xFFFFFFFF) << 16) ^ (self._site * 0x9E3779B1 & 0xFFFFFFFF))
-        return x
+        if not (self.training and p > 0.0):
+            return x
+        self._site += 1
+        seed = ((self.seed & 0xFFFFFFFF) << 16) ^ (self._site * 0x9E3779B1 & 0xFFFFFFFF)
+        out = torch.empty_like(x) if self.grad else x
+        lib.eltwise(lib.ELT_DROP, x, None, out, x.numel(), p, seed)
 
-    def conv_layer(self, layer, x):
+        def bw(g):
+            gx = torch.empty_like(g)
+            lib.eltwise(lib.ELT_DROP, g, None, gx, g.numel(), p, seed)   # the same (seed, element) mask
+            return (gx,)
+        self._rec(out, (x,), bw)
+        return out
+
+    def _sum(self, a, b):
+        """a + b (in place into a unless a gradient is wanted)"""
+        out = torch.empty_like(a) if self.grad else a
+        lib.eltwise(lib.ELT_ADD, a, b, out, a.numel())
+        self._rec(out, (a, b), lambda g: (g, g))
+        return out
+
+    def conv_layer(self, layer, x, x_needs_grad=True):
         """ConvLayer1D.forward on channels-last x [B, L, Cin] (blocks.py:173-186)."""
         conv = layer.conv
         k, stride, dil = conv.kernel_size[0], conv.stride[0], conv.dilation[0]
@@ -179,21 +432,18 @@ class GenericForward:
         if kind == 'batch' and self.training and layer.norm.training:
             want = 1
         eps = layer.norm.eps if kind == 'instance' else 0.0
-        bias = conv.bias.detach() if conv.bias is not None else None
-        if bias is not None and want is not None:
+        if conv.bias is not None and want is not None:
             raise NotImplementedError('a convolution bias in front of a statistics-based norm')
-        y, stats = self._conv(x, conv.weight.detach(), bias, L_out, stride=stride, pad=pad, dil=dil, want_stats=want, eps=eps)
-        self._norm_act(layer, y, stats, layer.activation_name)
-        return self._dropout_(y, layer.dropout_p)
+        y, stats = self._conv(x, conv.weight, conv.bias, L_out, stride=stride, pad=pad, dil=dil, want_stats=want, eps=eps, x_needs_grad=x_needs_grad)
+        return self._dropout_(self._norm_act(layer, y, stats, layer.activation_name), layer.dropout_p)
 
-    def conv_block(self, block, x):
+    def conv_block(self, block, x, x_needs_grad=True):
         """ConvBlock1D.forward (blocks.py:57-71)."""
-        out = self.conv_layer(block.conv3, self.conv_layer(block.conv2, self.conv_layer(block.conv1, x)))
+        out = self.conv_layer(block.conv3, self.conv_layer(block.conv2, self.conv_layer(block.conv1, x, x_needs_grad)))
         if block.use_residual:
-            B, L, _ = x.shape
-            r, _ = self._conv(x, block.downsample.weight.detach(), None, out.shape[1], stride=2, pad=0, dil=1)
-            lib.eltwise(lib.ELT_ADD, out, r, out, out.numel())
-        return act_(out, block.activation_name)
+            r, _ = self._conv(x, block.downsample.weight, None, out.shape[1], stride=2, pad=0, dil=1, x_needs_grad=x_needs_grad)
+            out = self._sum(out, r)
+        return self._act(out, block.activation_name)
 
     def dilated_block(self, block, x):
         """DilatedConvBlock.forward (blocks.py:115-126) on [B, S, F]."""
@@ -203,26 +453,33 @@ class GenericForward:
         out = self._dropout_(out, block.dropout.p)
         if out is x:
             out = x.clone()
-        lib.eltwise(lib.ELT_ADD, out, x, out, out.numel())
-        return act_(out, block.activation_name)
+        return self._act(self._sum(out, x), block.activation_name)
 
     # ------------------------------------------------------------------ dense layers / GEMMs
-    def linear(self, x_rows, weight, bias, act_name='linear'):
-        """y[rows, cout] = x[rows, cin] @ W^T + b, then the activation (any cin that is a power of two <= 128 or a multiple of 128)."""
+    def linear(self, x_rows, wp, bp, act_name='linear'):
+        """y[rows, cout] = x[rows, cin] @ W^T + b, then the activation (any cin that is a power of two <= 128 or a multiple of 128).
+        wp / bp: the weight [cout, cin] / bias [cout] parameters (or tensors, when no gradient is recorded)."""
         rows, cin = x_rows.shape
-        cout = weight.shape[0]
+        cout = wp.shape[0]
         if cout % 16:
             raise NotImplementedError(f'{cout} output features: multiples of 16')
-        ck = _pow2_chunk(cin)
         y = torch.empty(rows, cout, device=x_rows.device, dtype=torch.float32)
-        w = weight.detach()
-        for q in range(cin // ck):
-            wq = w[:, q * ck:(q + 1) * ck].contiguous()
-            xq = x_rows if cin == ck else x_rows[:, q * ck:]
+        w = wp.detach()
+        bias = bp.detach() if bp is not None else None
+        for q, (c0, ck) in enumerate(_chunks(cin)):
+            wq = w[:, c0:c0 + ck].contiguous()
+            xq = x_rows if q == 0 else x_rows[:, c0:]
             lib.conv_forward(lib.conv_args(x=xq, w=wq, y=y, B=1, L_in=rows, L_out=rows, cin=ck, cout=cout, taps=1, stride=1, pad=0, ldx=cin,
                                            epi=lib.EPI_BIAS if (bias is not None and q == 0) else lib.EPI_PLAIN,
-                                           bias=bias.detach() if (bias is not None and q == 0) else None, accumulate=q > 0))
-        return act_(y, act_name)
+                                           bias=bias if q == 0 else None, accumulate=q > 0))
+
+        def bw(gy):
+            if bp is not None:
+                self._pgrad(bp, self._rowsum(gy, rows, cout, cout))
+            self._pgrad(wp, self._wgrad(gy, x_rows, B=1, L_in=rows, L_out=rows, cin=cin, cout=cout, taps=1, stride=1, pad=0))
+            return (self._dgrad(gy.view(1, rows, cout), w.view(cout, cin, 1), B=1, L_x=rows, L_out=rows, stride=1, pad=0, dil=1).view(rows, cin),)
+        self._rec(y, (x_rows,), bw)
+        return self._act(y, act_name)
 
     # ------------------------------------------------------------------ the modules
     def signal_encoder(self, enc, x_BT):
@@ -234,15 +491,14 @@ class GenericForward:
         S = T // spe
         x = x_BT.contiguous().float()
         y = x.view(B * S, spe, 1) if (enc.causal and enc.chunk_causal) else x.view(B, T, 1)
-        for block in enc.cnn:
-            y = self.conv_block(block, y)
+        for i, block in enumerate(enc.cnn):
+            y = self.conv_block(block, y, x_needs_grad=i > 0)
         # [B(*S), 4(*S), C] -> [B, S, 4C]: feature index = t_local * C + c, which in channels-last layout is the memory order
-        feat = y.reshape(B * S, enc.epoch_dim)
+        feat = self._view(y, B * S, enc.epoch_dim)
         z = self.linear(feat, enc.linear.weight, enc.linear.bias, enc.activation_name)
         if isinstance(enc.output_norm, nn.LayerNorm):
-            F_ = enc.feature_dim
-            lib.rownorm_fwd(z, F_, enc.output_norm.weight.detach(), enc.output_norm.bias.detach(), z, F_, B * S, F_, enc.output_norm.eps, False, 0, 0.01)
-        return z.view(B, S, enc.feature_dim)
+            z = self._rownorm(z, enc.output_norm.weight, enc.output_norm.bias, enc.output_norm.eps)
+        return self._view(z, B, S, enc.feature_dim)
 
     def signal_encoders(self, mod, x: dict) -> dict:
         """SignalEncoders.forward (wav2sleep.py:146-161)."""
@@ -252,10 +508,22 @@ class GenericForward:
                 raise ValueError(f'Unknown signal {name}')
             mask_B = torch.isinf(x_BT[:, 0])
             xs = torch.where(torch.isinf(x_BT), torch.zeros_like(x_BT), x_BT)
-            z_BSF = self.signal_encoder(mod.get_encoder(name), xs)
-            z_BSF = torch.where(mask_B[:, None, None], float('-inf'), z_BSF)
+            z_enc = self.signal_encoder(mod.get_encoder(name), xs)
+            z_BSF = torch.where(mask_B[:, None, None], float('-inf'), z_enc)
+            self._rec(z_BSF, (z_enc,), lambda g, mask_B=mask_B: (g.masked_fill(mask_B[:, None, None], 0.0),))
             if mod.embed_signals:
-                z_BSF = z_BSF + mod.embedder.weight.detach()[mod.sig_to_embedding_idx[name]][None, None, :]
+                idx = mod.sig_to_embedding_idx[name]
+                z_in = z_BSF
+                z_BSF = z_in + mod.embedder.weight.detach()[idx][None, None, :]
+
+                def bw(g, idx=idx, mask_B=mask_B):
+                    Bq, Sq, Fq = g.shape
+                    gm = g.masked_fill(mask_B[:, None, None], 0.0)   # -inf rows stay -inf whatever the embedding is
+                    ge = torch.zeros_like(mod.embedder.weight)
+                    ge[idx] = self._rowsum(gm, Bq * Sq, Fq, Fq)
+                    self._pgrad(mod.embedder.weight, ge)
+                    return (g,)
+                self._rec(z_BSF, (z_in,), bw)
             z[name] = z_BSF
         return z
 
@@ -285,27 +553,54 @@ class GenericForward:
         H = mod.nhead
         hd = F_ // H
         X = tokens.view(N * D, F_)
+
+        def bw_tokens(gX):
+            g3 = gX.view(N, D, F_)
+            greg = torch.empty(F_, R1, device=dev, dtype=torch.float32)
+            for r in range(R1):   # CLS / register tokens are broadcast over the N sentences: their gradient is the column sum of slot r
+                col = torch.empty(F_, device=dev, dtype=torch.float32)
+                lib.colsum(gX.view(-1)[r * F_:], N, F_, col, ld=D * F_)
+                greg[:, r] = col
+            self._pgrad(mod.register_tokens, greg)
+            outs = []
+            for m in range(len(signals)):
+                gz = g3[:, R1 + m, :].reshape(B, S, F_)
+                outs.append(gz.masked_fill(pads[R1 + m][:, None, None], 0.0))
+            return outs
+        self._rec(X, [z_dict[sig] for sig in signals], bw_tokens)
+        p_attn = 0.0
         for layer in mod.transformer_encoder.layers:
             sa = layer.self_attn
+            if self.training and sa.dropout > 0.0:
+                p_attn = float(sa.dropout)
 
-            def attn(h):
+            def attn(h, sa=sa, layer=layer):
                 qkv = self.linear(h, sa.in_proj_weight, sa.in_proj_bias)
                 ao = torch.empty(N * D, F_, device=dev, dtype=torch.float32)
-                lib.attn_generic_fwd(qkv, keypad, ao, N, D, H, hd)
+                seed = 0
+                if p_attn > 0.0:
+                    self._site += 1
+                    seed = ((self.seed & 0xFFFFFFFF) << 16) ^ (self._site * 0x9E3779B1 & 0xFFFFFFFF)
+                lib.attn_generic_fwd(qkv, keypad, ao, N, D, H, hd, p_attn, seed)
+
+                def bw(g):
+                    gqkv = torch.empty_like(qkv)
+                    lib.attn_generic_bwd(qkv, keypad, g, gqkv, N, D, H, hd, p_attn, seed)
+                    return (gqkv,)
+                self._rec(ao, (qkv,), bw)
                 return self._dropout_(self.linear(ao, sa.out_proj.weight, sa.out_proj.bias), layer.dropout1.p)
 
-            def ff(h):
+            def ff(h, layer=layer):
                 a1 = self._dropout_(self.linear(h, layer.linear1.weight, layer.linear1.bias, mod.activation_name), layer.dropout.p)
                 return self._dropout_(self.linear(a1, layer.linear2.weight, layer.linear2.bias), layer.dropout2.p)
 
             def ln(norm, t):
-                o = torch.empty_like(t)
-                lib.rownorm_fwd(t, F_, norm.weight.detach(), norm.bias.detach(), o, F_, N * D, F_, norm.eps, False, 0, 0.01)
-                return o
+                return self._rownorm(t, norm.weight, norm.bias, norm.eps)
 
             def add(a_, b_):
                 o = torch.empty_like(a_)
                 lib.eltwise(lib.ELT_ADD, a_, b_, o, a_.numel())
+                self._rec(o, (a_, b_), lambda g: (g, g))
                 return o
 
             if layer.norm_first:
@@ -314,11 +609,18 @@ class GenericForward:
             else:
                 X = ln(layer.norm1, add(X, attn(X)))
                 X = ln(layer.norm2, add(X, ff(X)))
-        return X.view(N, D, F_)[:, 0, :].reshape(B, S, F_).contiguous()
+        cls = X.view(N, D, F_)[:, 0, :].reshape(B, S, F_).contiguous()
+
+        def bw_cls(g):
+            gX = torch.zeros(N, D, F_, device=dev, dtype=torch.float32)
+            gX[:, 0, :] = g.reshape(N, F_)
+            return (gX.view(N * D, F_),)
+        self._rec(cls, (X,), bw_cls)
+        return cls
 
     def sequence_cnn(self, mod, x_BSF):
         """SequenceCNN.forward (wav2sleep.py:379-390); channels-last [B, S, F] is already the layout the blocks run on."""
-        x = x_BSF.contiguous().float()
+        x = x_BSF if (x_BSF.is_contiguous() and x_BSF.dtype == torch.float32) else x_BSF.contiguous().float()
         for block in mod.dilated_convs:
             x = self.dilated_block(block, x)
         return x
@@ -326,8 +628,25 @@ class GenericForward:
     def classifier(self, lin: nn.Linear, x_BSF):
         B, S, F_ = x_BSF.shape
         nc = lin.out_features
+        rows = B * S
         logits = torch.empty(B, S, nc, device=x_BSF.device, dtype=torch.float32)
-        lib.head_fwd(x_BSF.contiguous(), F_, lin.weight.detach(), lin.bias.detach(), logits, B * S, F_, nc, False)
+        xc = x_BSF if x_BSF.is_contiguous() else x_BSF.contiguous()
+        lib.head_fwd(xc, F_, lin.weight.detach(), lin.bias.detach(), logits, rows, F_, nc, False)
+
+        def bw(g):
+            gl = g.reshape(rows, nc).contiguous()
+            gx = torch.empty(B, S, F_, device=g.device, dtype=torch.float32)
+            nparts = max(1, min(1024, _cdiv(rows, 16)))
+            part = torch.empty(nparts, nc * F_ + nc, device=g.device, dtype=torch.float32)
+            lib.head_bwd(xc, F_, lin.weight.detach(), gl, gx, F_, part, nparts, rows, F_, nc, False)
+            dw = torch.empty(nc * F_, device=g.device, dtype=torch.float32)
+            db = torch.empty(nc, device=g.device, dtype=torch.float32)
+            lib.colsum(part, nparts, nc * F_, dw, ld=nc * F_ + nc)
+            lib.colsum(part.view(-1)[nc * F_:], nparts, nc, db, ld=nc * F_ + nc)
+            self._pgrad(lin.weight, dw)
+            self._pgrad(lin.bias, db)
+            return (gx,)
+        self._rec(logits, (x_BSF,), bw)
         return logits
 
     def wav2sleep(self, model, x: dict) -> torch.Tensor:
@@ -343,10 +662,36 @@ class GenericForward:
             raise ValueError(f'Input tensor had unexpected shape: {x_BT.size()}')
         B = x_BT.shape[0]
         y = x_BT.contiguous().float().view(B, -1, 1)
-        for block in model.conv_block.model:
-            y = self.conv_block(block, y)                      # [B, 4800, 256]
-        feat = y.reshape(B * 1200, 1024)                       # transpose(-1, -2).reshape(-1, 1200, 1024): memory order in channels-last
-        z = self.linear(feat, model.dense.linear.weight, model.dense.linear.bias, model.dense.activation_name).view(B, 1200, model.feature_dim)
+        for i, block in enumerate(model.conv_block.model):
+            y = self.conv_block(block, y, x_needs_grad=i > 0)  # [B, 4800, 256]
+        feat = self._view(y, B * 1200, 1024)                   # transpose(-1, -2).reshape(-1, 1200, 1024): memory order in channels-last
+        z = self._view(self.linear(feat, model.dense.linear.weight, model.dense.linear.bias, model.dense.activation_name), B, 1200, model.feature_dim)
         for block in model.dilated_convs:
             z = self.dilated_block(block, z)
         return self.classifier(model.classifier, z)
+
+
+class _GenericFn(torch.autograd.Function):
+    """One autograd node around a generic-path forward: logits = run(walker); the backward replays the walker's tape (HIP kernels only) and
+    hands torch the parameter gradients.  The inputs (signals) get no gradient, as in training."""
+
+    @staticmethod
+    def forward(ctx, run, training, seed, device, *params):
+        with torch.cuda.device(device):
+            gf = GenericForward(training=training, seed=seed, grad=True)
+            out = run(gf)
+        ctx.gf, ctx.out, ctx.params, ctx.device = gf, out, params, device
+        return out.detach().clone()   # the tape keys tensors by identity: keep the walker's own output out of the caller's hands
+
+    @staticmethod
+    def backward(ctx, g):
+        with torch.cuda.device(ctx.device):
+            pg = ctx.gf.backward(ctx.out, g)
+        ctx.gf = ctx.out = None
+        return (None, None, None, None) + tuple(pg.get(p) if p.requires_grad else None for p in ctx.params)
+
+
+def differentiable(model: nn.Module, run, training: bool, seed: int = 0) -> torch.Tensor:
+    """run(walker) -> logits as ONE autograd node over model.parameters() (ppgnet.py / wav2sleep.py call this when a gradient is wanted)."""
+    params = [p for p in model.parameters()]
+    return _GenericFn.apply(run, training, seed, params[0].device, *params)

@@ -1,6 +1,6 @@
 """SleepPPG-Net (reference models/ppgnet.py:19-134; Kotzen et al. 2023): eight ConvBlock1D's down to 4800 x 256, a time-distributed
 dense layer 1024 -> feature_dim, two DilatedConvBlocks, a linear classifier.  Same constructor, attribute names and state-dict keys as
-the reference; the forward runs on the generic path (generic.py: BatchNorm / LeakyReLU, 256-channel layers as accumulating launches)."""
+the reference; forward AND backward run on the generic path (generic.py: BatchNorm / LeakyReLU, 256-channel layers as accumulating launches)."""
 from __future__ import annotations
 
 import torch
@@ -50,13 +50,16 @@ class SleepPPGNet(nn.Module):
         )
         self.classifier = nn.Linear(in_features=feature_dim, out_features=n_classes)
 
-    @torch.no_grad()
     def forward(self, x_BT: Tensor) -> Tensor:
-        """[N, 1 228 800] -> logits [N, 1200, n_classes] (inference)."""
-        from .generic import GenericForward
+        """[N, 1 228 800] -> logits [N, 1200, n_classes].  With gradients enabled the result is ONE autograd node whose backward is the
+        generic path's tape (generic.py: HIP kernels only), so `loss.backward()` fills `.grad` as the reference's training loop expects."""
+        from .generic import GenericForward, differentiable
         from .lib import W2SError
         dev = next(self.parameters()).device
         if dev.type != 'cuda' or x_BT.device.type != 'cuda':
             raise W2SError('wav2sleep_amd runs on MI355X only: move the model and its input to a cuda device (there is no CPU fallback)')
-        with torch.cuda.device(dev):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            self._seed = getattr(self, '_seed', 0) + 1
+            return differentiable(self, lambda gf: gf.ppgnet(self, x_BT), self.training, self._seed)
+        with torch.no_grad(), torch.cuda.device(dev):
             return GenericForward(training=self.training).ppgnet(self, x_BT)

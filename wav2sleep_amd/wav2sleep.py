@@ -488,15 +488,21 @@ class Wav2Sleep(_HandWritten, nn.Module):
 
     def forward(self, x: dict[str, Tensor]) -> Tensor:
         """dict[str -> [B, T_sig]] -> logits [B, S, num_classes].  The production family runs on the fused kernels (one autograd node);
-        any other configuration of the reference's modules on the generic path (generic.py): forward only, no autograd graph."""
+        any other configuration of the reference's modules on the generic path (generic.py), also one autograd node when a gradient is wanted."""
         if not self.fused_ok():
             from .generic import GenericForward
             from .lib import W2SError
             dev = next(self.parameters()).device
             if dev.type != 'cuda':
                 raise W2SError('wav2sleep_amd runs on MI355X only: move the model to a cuda device (there is no CPU fallback)')
+            if any(v.device.type != 'cuda' for v in x.values()):
+                raise W2SError('wav2sleep_amd runs on MI355X only: move the inputs to a cuda device (there is no CPU fallback)')
+            seed = self._next_seed() if self.training else 0
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):   # one autograd node; backward = the walker's tape
+                from .generic import differentiable
+                return differentiable(self, lambda gf: gf.wav2sleep(self, x), self.training, seed)
             with torch.no_grad(), torch.cuda.device(dev):
-                return GenericForward(training=self.training, seed=self._next_seed() if self.training else 0).wav2sleep(self, x)
+                return GenericForward(training=self.training, seed=seed).wav2sleep(self, x)
         # ONE custom operator (ops.py: fake + autograd registered), so a caller's torch.compile traces through this forward
         params = list(self.parameters())
         if params[0].device.type != 'cuda' or any(v.device.type != 'cuda' for v in x.values()):
