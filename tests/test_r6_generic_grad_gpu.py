@@ -220,3 +220,41 @@ def test_generic_training_step_reduces_the_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], losses
+
+
+def test_generic_train_step_matches_torch_adamw_on_the_tape_gradients():
+    """GenericTrainStep (HIP loss + clip + AdamW on the flat buffers) = the same model stepped with torch's cross_entropy / clip_grad_norm_ /
+    AdamW on the gradients of the autograd node; and SleepModule drives a SleepPPGNet-style unimodal model through it."""
+    from wav2sleep_amd.trainer import GenericTrainStep, SleepModule
+
+    def make():
+        torch.manual_seed(21)
+        return W.Wav2Sleep(W.SignalEncoders({'ECG': 'ECG'}, feature_dim=32, activation='leaky', norm='group'),
+                           W.MultiModalAttentionEmbedder(32, layers=1, nhead=2, dim_ff=64, activation='gelu'),
+                           W.SequenceCNN(32, norm='layer', activation='silu', dropout=0.0, num_layers=1, num_dilations=2), 5).to(DEV).train()
+    g = torch.Generator().manual_seed(22)
+    x = {'ECG': torch.randn(3, 8 * 1024, generator=g).to(DEV)}
+    y = torch.randint(0, 5, (3, 8), generator=g).float()
+    y[0, :3] = -1
+    y = y.to(DEV)
+    a, b = make(), make()
+    opt = torch.optim.AdamW(a.parameters(), lr=1e-3, weight_decay=1e-4)
+    step = GenericTrainStep(b, lr=1e-3, weight_decay=1e-4, scheduler=False)
+    for k in range(3):
+        opt.zero_grad()
+        loss = F.cross_entropy(a(x).flatten(0, 1), y.flatten().long(), ignore_index=-1)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0)
+        opt.step()
+        out = step.step(x, y)
+        assert abs(float(out['loss']) - float(loss.detach())) <= 1e-5 * abs(float(loss.detach())), k
+    # three AdamW steps move a parameter by up to 3e-3; an element whose gradient is within rounding of zero gets m / sqrt(v) of either sign
+    # (the fused clip + AdamW kernel itself is pinned by tests/golden/optim.npz), so: a tenth of the movement, and the losses above
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert float((pa.detach() - pb.detach()).abs().max()) <= 3e-4, n
+    mod = SleepModule(make(), num_classes=5)
+    l0 = float(mod.training_step((x, y)))
+    for _ in range(10):
+        l1 = float(mod.training_step((x, y)))
+    assert np.isfinite(l1) and l1 < l0
+    assert float(mod.eval_step((x, y))) > 0

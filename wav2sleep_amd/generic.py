@@ -74,6 +74,8 @@ class GenericForward:
             self.tape.append((out, tuple(inputs), fn))
 
     def _add(self, a, b):
+        if a.numel() & 3:   # (a classifier bias of 5 classes: the elementwise kernel works on quads)
+            return a + b
         o = torch.empty_like(a)
         lib.eltwise(lib.ELT_ADD, a, b.contiguous(), o, a.numel())
         return o

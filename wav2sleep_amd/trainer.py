@@ -284,6 +284,109 @@ class FusedTrainStep:
         return reduce_metrics(self.loss_out, self.cmat, self.reducer.group)
 
 
+class GenericTrainStep:
+    """FusedTrainStep's recipe -- CE (mean over labels != -1), DDP mean of per-rank gradients, global-norm clip, AdamW, ExpWarmUp, gradient
+    accumulation -- for the models that run on the generic path: `SleepPPGNet` (trainer/main.py:72,109-113 feeds it the one signal of the
+    batch) and `Wav2Sleep` configurations outside the production family.  Forward and backward are generic.py's walker and tape (HIP
+    kernels), the loss / clip / AdamW kernels are the fused step's own, on one flat parameter and one flat gradient buffer."""
+
+    def __init__(self, model: nn.Module, lr: float = 1e-3, weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_norm: float = 1.0, warmup_steps: int = 2000, tau: float = 10000.0, process_group=None, scheduler: bool = True,
+                 accumulate: int = 1, num_classes: int | None = None):
+        from .ddp import flat_layout
+        self.model = model
+        named = list(model.named_parameters())
+        dev = named[0][1].device
+        if dev.type != 'cuda':
+            raise lib.W2SError('wav2sleep_amd runs on MI355X only: move the model to a cuda device (there is no CPU fallback)')
+        self.device = dev
+        layout, off = flat_layout([p.shape for _, p in named])
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.views = {}
+        with torch.no_grad():
+            for (o, n, shape), (name, p) in zip(layout, named):   # parameters become views of ONE buffer: one clip reduction, one AdamW launch
+                v = self.flat[o:o + n].view(shape)
+                v.copy_(p.detach().float())
+                p.data = v
+                self.views[p] = self.flat_grad[o:o + n].view(shape)
+        self.n = off
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.lr_max, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.warmup_steps, self.tau, self.use_sched = warmup_steps, tau, scheduler
+        if accumulate < 1:
+            raise ValueError(f'accumulate must be >= 1, got {accumulate}')
+        self.accumulate, self.micro, self.step_count = int(accumulate), 0, 0
+        self.nparts = 256
+        self.sumsq = torch.empty(self.nparts, device=dev, dtype=torch.float32)
+        self.hyper = torch.zeros(8, device=dev, dtype=torch.float32)
+        self.normcoef = torch.zeros(2, device=dev, dtype=torch.float32)
+        self.loss_out = torch.zeros(2, device=dev, dtype=torch.float32)
+        nc = num_classes if num_classes is not None else model.classifier.out_features
+        self.num_classes = nc
+        self.cmat = torch.zeros(nc, nc, device=dev, dtype=torch.int64)
+        self.reducer = FlatGradReducer(self.flat_grad, group=process_group)
+        self._seed = 0
+        if self.reducer.world > 1:   # rank 0's initialisation everywhere (Lightning DDP broadcasts the module at construction)
+            import torch.distributed as dist
+            dist.broadcast(self.flat, src=dist.get_global_rank(self.reducer.group, 0) if self.reducer.group is not None else 0, group=self.reducer.group)
+
+    lr_at = FusedTrainStep.lr_at
+
+    def _run(self, gf, x):
+        if isinstance(self.model, Wav2Sleep):
+            return gf.wav2sleep(self.model, x)
+        if isinstance(x, dict):   # trainer/main.py:109-113
+            if len(x) != 1:
+                raise ValueError(f'{x.keys()=} but expected unimodal input!')
+            x = x[list(x.keys())[0]]
+        return gf.ppgnet(self.model, x)
+
+    def step(self, x, y: torch.Tensor) -> dict:
+        from .generic import GenericForward
+        first = self.micro == 0
+        self.micro += 1
+        last = self.micro == self.accumulate
+        self._seed += 1
+        with torch.cuda.device(self.device), torch.no_grad():
+            gf = GenericForward(training=True, seed=self._seed, grad=True)
+            logits = self._run(gf, x)
+            B, S, nc = logits.shape
+            rows = B * S
+            yv = y.reshape(rows).float().contiguous()
+            part = torch.empty((rows + 255) // 256, 2, device=self.device, dtype=torch.float32)
+            glogits = torch.empty(rows, nc, device=self.device, dtype=torch.float32)
+            lib.zero_(self.cmat)
+            lib.ce_fwd_bwd(logits, yv, rows, nc, part, self.loss_out, glogits, self.cmat, self.reducer.grad_scale / self.accumulate)
+            pg = gf.backward(logits, glogits.view(B, S, nc))
+            if first:
+                lib.zero_(self.flat_grad)
+            for p, g in pg.items():
+                lib.eltwise(lib.ELT_ADD, self.views[p], g, self.views[p], g.numel()) if g.numel() % 4 == 0 else self.views[p].add_(g)
+            if last and (self.reducer.world > 1 or self.reducer.force):
+                self.reducer.reduce_range(0, self.n)
+                self.reducer.wait()
+        out = dict(loss=self.loss_out[0], count=self.loss_out[1], cmat=self.cmat, logits=logits, stepped=last)
+        if last:
+            self.micro = 0
+            self.step_count += 1
+            k = self.step_count
+            b1, b2 = self.betas
+            h = torch.tensor([self.lr_at(k), self.wd, b1, b2, self.eps, 1 - b1 ** k, 1 - b2 ** k, self.max_norm if self.max_norm else 0.0],
+                             dtype=torch.float32).pin_memory()
+            with torch.cuda.device(self.device):
+                self.hyper.copy_(h, non_blocking=True)
+                lib.sumsq_partial(self.flat_grad, self.n, self.sumsq, self.nparts)
+                lib.clip_coef(self.sumsq, self.nparts, self.hyper, self.normcoef)
+                lib.adamw(self.flat, self.flat_grad, self.m, self.v, self.n, self.hyper, self.normcoef)
+            out['lr'] = float(h[0])
+            out['grad_norm'] = self.normcoef[0]
+        return out
+
+    def metrics(self):
+        return reduce_metrics(self.loss_out, self.cmat, self.reducer.group)
+
+
 def _loss_and_counts(logits: torch.Tensor, labels: torch.Tensor, num_classes: int):
     """(loss_out [mean CE over labels != -1, count], confusion matrix [C, C] int64: rows true, cols pred) of one batch, on the device."""
     rows = logits.numel() // num_classes
@@ -317,10 +420,25 @@ class SleepModule:
         self.masker = masker if isinstance(model, Wav2Sleep) else None
         self.flip_polarity = flip_polarity
         self.causal = causal
-        self.unified = len(model.signal_encoders) > 1
+        self.unified = isinstance(model, Wav2Sleep) and len(model.signal_encoders) > 1   # trainer/main.py:106
         self.aux_outputs = {mode: defaultdict(lambda: defaultdict(lambda: 0)) for mode in ('train', 'val', 'test')}
-        self.trainer = FusedTrainStep(model, lr=lr, weight_decay=weight_decay, max_norm=max_norm, process_group=process_group,
-                                      accumulate=accumulate_grad_batches)   # Trainer(accumulate_grad_batches=...), scripts/train.py:59-76
+        fused = isinstance(model, Wav2Sleep) and model.fused_ok()
+        kw = dict(lr=lr, weight_decay=weight_decay, max_norm=max_norm, process_group=process_group, accumulate=accumulate_grad_batches)
+        # Trainer(accumulate_grad_batches=...), scripts/train.py:59-76; SleepPPGNet and the non-production configurations: the generic path
+        self.trainer = FusedTrainStep(model, **kw) if fused else GenericTrainStep(model, num_classes=num_classes, **kw)
+
+    def forward(self, x):
+        """trainer/main.py:108-114: SleepPPGNet takes the batch's one signal as a tensor."""
+        if not isinstance(self.model, Wav2Sleep):
+            if len(x) != 1:
+                raise ValueError(f'{x.keys()=} but expected unimodal input!')
+            x = x[list(x.keys())[0]]
+        return self.model(x)
+
+    def _forward_subsets(self, x, subsets) -> dict:
+        if isinstance(self.trainer, FusedTrainStep):
+            return self.model.forward_subsets(x, subsets)   # every encoder once for all subsets
+        return {(tuple(sub) if sub is not None else None): self.forward(x if sub is None else {s: x[s] for s in sub}) for sub in subsets}
 
     def on_after_batch_transfer(self, batch, training: bool = True):
         x, y = batch
@@ -343,7 +461,7 @@ class SleepModule:
         if signals is not None:
             x = {s: x[s] for s in signals}
         self.model.eval()
-        logits = self.model(x)
+        logits = self.forward(x)
         out, cm = _loss_and_counts(logits, y, self.num_classes)
         _, _, cm = reduce_metrics(out, cm, self.trainer.reducer.group)
         prefix = '_'.join(signals) if signals is not None else (None if self.unified else '_'.join(x.keys()))
@@ -357,7 +475,7 @@ class SleepModule:
         x, y = batch
         self.model.eval()
         subsets = [None]
-        valid = self.model.valid_signals
+        valid = self.model.valid_signals if self.unified else []
         if self.unified and not combined:
             if 'ECG' in x and 'ECG' in valid:
                 subsets.append(('ECG',))
@@ -367,7 +485,7 @@ class SleepModule:
                 subsets.append(('PPG',))
                 if 'THX' in x and 'THX' in valid and ds_name in ('mesa',):
                     subsets.append(('PPG', 'THX'))
-        logits = self.model.forward_subsets(x, subsets)
+        logits = self._forward_subsets(x, subsets)
         losses = {}
         for sub, lg in logits.items():
             out, cm = _loss_and_counts(lg, y, self.num_classes)
