@@ -17,6 +17,7 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
     ap.add_argument('--train-folder'); ap.add_argument('--val-folder'); ap.add_argument('--out', required=True)
     ap.add_argument('--signals', default='ABD,THX,ECG,PPG'); ap.add_argument('--num-classes', type=int, default=4)
+    ap.add_argument('--model', default='wav2sleep', choices=['wav2sleep', 'ppgnet'], help='ppgnet: SleepPPGNet on the one signal given (scripts/config/model/ppgnet.yaml)')
     ap.add_argument('--epochs', type=int, default=30); ap.add_argument('--batch-size', type=int, default=16)      # scripts/config/main.yaml
     ap.add_argument('--accumulate', type=int, default=1); ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--synthetic', type=int, default=0, help='train on this many synthetic recordings (no folders needed)')
@@ -35,10 +36,15 @@ def main(argv=None) -> int:
     torch.manual_seed(a.seed)   # utils.fix_seeds: every rank the same initialisation (rank 0's is broadcast anyway)
     sig = [s.strip() for s in a.signals.split(',')]
     smap = {s: s for s in sig}
-    model = W.Wav2Sleep(W.SignalEncoders(smap, 128, 'gelu', norm='instance', chunk_causal=False), W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.1, dim_ff=512, nhead=8),
-                        W.SequenceCNN(128, dropout=0.1, norm='layer', num_layers=2, kernel_size=7, num_dilations=6), a.num_classes).to('cuda')
+    if a.model == 'ppgnet':   # 10-h inputs only (SleepPPGNet.INPUT_LENGTH); trained on the generic path's tape (wav2sleep_amd/generic.py)
+        if len(sig) != 1:
+            ap.error('--model ppgnet takes exactly one signal (--signals PPG)')
+        model = W.SleepPPGNet(n_classes=a.num_classes).to('cuda')
+    else:
+        model = W.Wav2Sleep(W.SignalEncoders(smap, 128, 'gelu', norm='instance', chunk_causal=False), W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.1, dim_ff=512, nhead=8),
+                            W.SequenceCNN(128, dropout=0.1, norm='layer', num_layers=2, kernel_size=7, num_dilations=6), a.num_classes).to('cuda')
     drop = {'ABD': 0.7, 'THX': 0.7, 'ECG': 0.5, 'PPG': 0.1}   # scripts/config/inputs/cardiorespiratory/all.yaml:9-18 (other signal sets: no masking)
-    masker = W.SignalMasker({s: drop[s] for s in sig}, backups=[s for s in ('ECG', 'PPG') if s in sig]) if set(sig) <= set(drop) and len(sig) > 1 else None
+    masker = W.SignalMasker({s: drop[s] for s in sig}, backups=[s for s in ('ECG', 'PPG') if s in sig]) if set(sig) <= set(drop) and len(sig) > 1 and a.model == 'wav2sleep' else None
     mod = W.SleepModule(model, num_classes=a.num_classes, masker=masker, lr=a.lr, accumulate_grad_batches=a.accumulate)
 
     def loader(folder, train):

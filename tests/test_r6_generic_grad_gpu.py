@@ -238,23 +238,58 @@ def test_generic_train_step_matches_torch_adamw_on_the_tape_gradients():
     y[0, :3] = -1
     y = y.to(DEV)
     a, b = make(), make()
+    p0 = torch.cat([p.detach().flatten().clone() for p in a.parameters()])
     opt = torch.optim.AdamW(a.parameters(), lr=1e-3, weight_decay=1e-4)
     step = GenericTrainStep(b, lr=1e-3, weight_decay=1e-4, scheduler=False)
     for k in range(3):
         opt.zero_grad()
         loss = F.cross_entropy(a(x).flatten(0, 1), y.flatten().long(), ignore_index=-1)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0)
+        ga = torch.cat([p.grad.flatten() for p in a.parameters()]).clone()
+        tn = torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0)
         opt.step()
         out = step.step(x, y)
         assert abs(float(out['loss']) - float(loss.detach())) <= 1e-5 * abs(float(loss.detach())), k
-    # three AdamW steps move a parameter by up to 3e-3; an element whose gradient is within rounding of zero gets m / sqrt(v) of either sign
-    # (the fused clip + AdamW kernel itself is pinned by tests/golden/optim.npz), so: a tenth of the movement, and the losses above
-    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        assert float((pa.detach() - pb.detach()).abs().max()) <= 3e-4, n
+        gb = torch.cat([step.views[p].flatten() for p in b.parameters()])   # the flat gradient stays unclipped (the coefficient is folded into AdamW)
+        assert float((ga - gb).norm() / ga.norm()) <= 1e-5, k
+        assert abs(float(out['grad_norm']) - float(tn)) <= 1e-5 * float(tn), k
+        # AdamW's first steps move every element by ~lr whatever its gradient's size, so an element whose gradient is within rounding of zero
+        # may go either way (the fused clip + AdamW kernel itself is pinned by tests/golden/optim.npz): the step's movement agrees in the L2
+        # sense, and the next step starts both models from the same weights
+        pa = torch.cat([p.detach().flatten() for p in a.parameters()])
+        pb = torch.cat([p.detach().flatten() for p in b.parameters()])
+        assert float((pa - pb).norm() / (pa - p0).norm()) <= 0.03, k
+        p0 = pa.clone()
+        with torch.no_grad():
+            for qa, qb in zip(a.parameters(), b.parameters()):
+                qb.copy_(qa)
     mod = SleepModule(make(), num_classes=5)
     l0 = float(mod.training_step((x, y)))
     for _ in range(10):
         l1 = float(mod.training_step((x, y)))
     assert np.isfinite(l1) and l1 < l0
     assert float(mod.eval_step((x, y))) > 0
+
+
+def test_generic_module_checkpoint_round_trip(tmp_path):
+    """A SleepModule around a generic-path model saves and resumes like the fused one: weights, AdamW moments, step count (checkpoint.py)."""
+    from wav2sleep_amd.checkpoint import load_lightning_checkpoint, save_lightning_checkpoint
+    from wav2sleep_amd.trainer import SleepModule
+
+    def make():
+        torch.manual_seed(31)
+        return W.Wav2Sleep(W.SignalEncoders({'THX': 'THX'}, feature_dim=16, activation='relu', norm='batch'), W.MultiModalAttentionEmbedder(16, layers=1, nhead=2, dim_ff=32),
+                           W.SequenceCNN(16, norm='batch', activation='relu', dropout=0.0, num_layers=1, num_dilations=2), 4).to(DEV)
+    g = torch.Generator().manual_seed(32)
+    x = {'THX': torch.randn(2, 6 * 256, generator=g).to(DEV)}
+    y = torch.randint(0, 4, (2, 6), generator=g).float().to(DEV)
+    a = SleepModule(make(), num_classes=4)
+    for _ in range(3):
+        a.training_step((x, y))
+    path = save_lightning_checkpoint(str(tmp_path / 'last.ckpt'), a, epoch=0)
+    la = [float(a.training_step((x, y))) for _ in range(2)]
+    b = SleepModule(make(), num_classes=4)
+    load_lightning_checkpoint(path, b)
+    assert b.trainer.step_count == 3
+    lb = [float(b.training_step((x, y))) for _ in range(2)]
+    assert la == lb, (la, lb)

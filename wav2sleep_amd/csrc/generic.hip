@@ -185,7 +185,20 @@ __global__ __launch_bounds__(256) void norm_act_bwd_part_kernel(const float* __r
     const NormCh k = norm_ch(stats, (long)s * stats_stride, gamma, beta, c);
     const long row0 = (long)s * rows_per_sample;
     const int t1 = min(rows_per_sample, (tl + 1) * tile);
-    for (int t = tl * tile + rr; t < t1; t += rpb) {
+    int t = tl * tile + rr;
+    for (; t + 3 * rpb < t1; t += 4 * rpb) {   // four rows in flight per thread (one dependent load pair per iteration ran at 2 TB/s)
+      f32x4 gv[4], yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { gv[u] = ld4(g + (row0 + t + u * rpb) * ldg + c); yv[u] = ld4(y + (row0 + t + u * rpb) * ldy + c); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 ga, xh;
+        norm_act_grad4(k, gv[u], yv[u], act, slope, ga, xh);
+        a1 += ga;
+        a2 += ga * xh;
+      }
+    }
+    for (; t < t1; t += rpb) {
       f32x4 ga, xh;
       norm_act_grad4(k, ld4(g + (row0 + t) * ldg + c), ld4(y + (row0 + t) * ldy + c), act, slope, ga, xh);
       a1 += ga;

@@ -64,6 +64,7 @@ class GenericForward:
         self.seed = seed
         self.grad = grad
         self._site = 0
+        self._x16 = None    # (the one-channel input, its 16-channel zero-padded copy)
         self.tape = []      # (output tensor, input tensors, fn: gradient of the output -> gradients of the inputs)
         self.pgrads = {}    # nn.Parameter -> gradient (the parameter's shape)
         lib.load()
@@ -198,9 +199,12 @@ class GenericForward:
             raise NotImplementedError(f'{cout} output channels: the generic kernels produce multiples of 16')
         dev = x.device
         x_in = x
-        if cin == 1:   # zero-pad the one-channel input to the narrowest tile the matrix path takes
-            x16 = torch.zeros(B, L_in, 16, device=dev, dtype=torch.float32)
-            x16[..., 0] = x[..., 0]
+        if cin == 1:   # zero-pad the one-channel input to the narrowest tile the matrix path takes (once per input: conv1 and the residual conv share it)
+            if self._x16 is None or self._x16[0] is not x:
+                x16 = torch.zeros(B, L_in, 16, device=dev, dtype=torch.float32)
+                x16[..., 0] = x[..., 0]
+                self._x16 = (x, x16)
+            x16 = self._x16[1]
             w16 = torch.zeros(cout, 16, k, device=dev, dtype=torch.float32)
             w16[:, 0] = w[:, 0]
             x, w, cin = x16, w16, 16

@@ -326,12 +326,31 @@ class GenericTrainStep:
         self.num_classes = nc
         self.cmat = torch.zeros(nc, nc, device=dev, dtype=torch.int64)
         self.reducer = FlatGradReducer(self.flat_grad, group=process_group)
-        self._seed = 0
-        if self.reducer.world > 1:   # rank 0's initialisation everywhere (Lightning DDP broadcasts the module at construction)
-            import torch.distributed as dist
-            dist.broadcast(self.flat, src=dist.get_global_rank(self.reducer.group, 0) if self.reducer.group is not None else 0, group=self.reducer.group)
+        # what checkpoint.py / EMACallback read on a model (the fused models carry these themselves): the storage is settled HERE
+        model._flat, model._flat_grad, model._layout = self.flat, self.flat_grad, layout
+        model._ensure_flat = lambda: None
+        if not hasattr(model, 'mark_params_dirty'):
+            model.mark_params_dirty = lambda: None
+        if not hasattr(model, '_seed_base'):
+            model._seed_base, model._seed_ctr = 0, 0
+        self.sync_parameters()
 
     lr_at = FusedTrainStep.lr_at
+
+    def sync_parameters(self):
+        """Rank 0's weights, moments and scalar optimiser state to every rank (collective; FusedTrainStep.sync_parameters's contract)."""
+        if self.reducer.world > 1:
+            import torch.distributed as dist
+            src = dist.get_global_rank(self.reducer.group, 0) if self.reducer.group is not None else 0
+            for t in (self.flat, self.m, self.v):
+                dist.broadcast(t, src=src, group=self.reducer.group)
+            sc = torch.tensor([self.step_count, self.micro, self.lr_max, self.betas[0], self.betas[1], self.eps, self.wd, self.model._seed_ctr],
+                              dtype=torch.float64, device=self.device)
+            dist.broadcast(sc, src=src, group=self.reducer.group)
+            sc = sc.tolist()
+            self.step_count, self.micro = int(sc[0]), int(sc[1])
+            self.lr_max, self.betas, self.eps, self.wd = sc[2], (sc[3], sc[4]), sc[5], sc[6]
+            self.model._seed_ctr = int(sc[7])
 
     def _run(self, gf, x):
         if isinstance(self.model, Wav2Sleep):
@@ -347,9 +366,9 @@ class GenericTrainStep:
         first = self.micro == 0
         self.micro += 1
         last = self.micro == self.accumulate
-        self._seed += 1
+        self.model._seed_ctr += 1
         with torch.cuda.device(self.device), torch.no_grad():
-            gf = GenericForward(training=True, seed=self._seed, grad=True)
+            gf = GenericForward(training=True, seed=self.model._seed_base * 1000003 + self.model._seed_ctr, grad=True)
             logits = self._run(gf, x)
             B, S, nc = logits.shape
             rows = B * S
