@@ -433,6 +433,16 @@ int w2s_norm_act_bwd_apply(const float* g, int ldg, const float* y, int ldy, con
 int w2s_rownorm_bwd_blocks(long rows);
 int w2s_rownorm_bwd(const float* g, int ldg, const float* x, int ldx, const float* gamma, const float* beta, float* gx, int ldgx, float* part,
                     long rows, int C, float eps, int rms, int act, float slope, void* stream);
+/* the per-(sample, channel) arithmetic around the statistics-based norms in one launch each (fp64 inside).  kind: 0 InstanceNorm1d (stats =
+ * (mean, rstd) per (b, c)), 1 BatchNorm1d training (stats = (E[y], E[y^2]) per (b, c); run_mean / run_var updated in place with `momentum`
+ * and the unbiased variance over `count` = B L elements, or NULL), 2 BatchNorm1d eval (running statistics; stats unused), 3 GroupNorm (stats =
+ * (E[y], E[y^2]); G groups of consecutive channels).  scale / shift [nset][C] feed w2s_affine_act, mr [nset][C][2] = (mean, rstd) feeds the
+ * backward kernels as `stats`; nset = B for kinds 0 and 3, 1 for kinds 1 and 2. */
+int w2s_norm_fold(int kind, const float* stats, int B, int C, int G, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                  float eps, float momentum, double count, float* scale, float* shift, float* mr, void* stream);
+/* means [B][C][2] = per-(sample, channel) means of ga and ga * xh -> coef [nset][3][C] for w2s_norm_act_bwd_apply, dgamma / dbeta [C] (or NULL) */
+int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, int B, int C, int G, const float* gamma, double L, float* coef,
+                      float* dgamma, float* dbeta, void* stream);
 /* backward of w2s_attn_generic_fwd: gqkv [N][D][3*H*hd] (fully written) from gout [N][D][H*hd] */
 int w2s_attn_generic_bwd(const float* qkv, const unsigned char* keypad, const float* gout, float* gqkv, long N, int D, int H, int hd, float p_drop,
                          uint64_t seed, void* stream);

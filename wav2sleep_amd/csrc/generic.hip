@@ -394,3 +394,125 @@ extern "C" int w2s_attn_generic_bwd(const float* qkv, const unsigned char* keypa
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The per-(sample, channel) arithmetic around the statistics-based norms, one launch each instead of ~30 torch launches on [B, C] tensors
+// per layer (a SleepPPGNet step spent 6 of its 32 ms of kernel time in 1300 such launches): fp64 inside, one thread per channel.
+// kind: 0 InstanceNorm1d (stats = (mean, rstd) per (b, c), no affine), 1 BatchNorm1d in training (stats = (E[y], E[y^2]) per (b, c); the
+// running statistics are updated with the unbiased variance as nn.BatchNorm1d does), 2 BatchNorm1d in eval mode (running statistics),
+// 3 GroupNorm (stats = (E[y], E[y^2]); G groups of C / G consecutive channels).
+// out: scale / shift [nset][C] for w2s_affine_act and mr [nset][C][2] = (mean, rstd) for the backward; nset = B (kinds 0, 3) or 1 (1, 2).
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ void norm_fold_kernel(int kind, const float* __restrict__ stats, int B, int C, int G, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ run_mean, float* __restrict__ run_var, float eps, float momentum,
+                                 double count, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mr) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double gm = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+  if (kind == 1 || kind == 2) {
+    double m, var;
+    if (kind == 1) {
+      double e1 = 0.0, e2 = 0.0;
+      for (int b = 0; b < B; ++b) { e1 += (double)stats[((size_t)b * C + c) * 2]; e2 += (double)stats[((size_t)b * C + c) * 2 + 1]; }
+      m = e1 / B;
+      var = e2 / B - m * m;
+      if (var < 0.0) var = 0.0;
+      if (run_mean) {
+        run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * m);
+        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+      }
+    } else {
+      m = run_mean[c];
+      var = run_var[c];
+    }
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    scale[c] = (float)(gm * rstd);
+    shift[c] = (float)(bt - m * gm * rstd);
+    mr[2 * c] = (float)m;
+    mr[2 * c + 1] = (float)rstd;
+    return;
+  }
+  const int cg = C / G, c0 = (c / cg) * cg;
+  for (int b = 0; b < B; ++b) {
+    double m, rstd;
+    if (kind == 0) {
+      m = stats[((size_t)b * C + c) * 2];
+      rstd = stats[((size_t)b * C + c) * 2 + 1];
+    } else {
+      double e1 = 0.0, e2 = 0.0;
+      for (int k = 0; k < cg; ++k) { e1 += (double)stats[((size_t)b * C + c0 + k) * 2]; e2 += (double)stats[((size_t)b * C + c0 + k) * 2 + 1]; }
+      e1 /= cg; e2 /= cg;
+      double var = e2 - e1 * e1;
+      if (var < 0.0) var = 0.0;
+      m = e1;
+      rstd = 1.0 / sqrt(var + (double)eps);
+    }
+    scale[(size_t)b * C + c] = (float)(gm * rstd);
+    shift[(size_t)b * C + c] = (float)(bt - m * gm * rstd);
+    mr[((size_t)b * C + c) * 2] = (float)m;
+    mr[((size_t)b * C + c) * 2 + 1] = (float)rstd;
+  }
+}
+
+extern "C" int w2s_norm_fold(int kind, const float* stats, int B, int C, int G, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                             float eps, float momentum, double count, float* scale, float* shift, float* mr, void* stream) {
+  if (kind < 0 || kind > 3 || B <= 0 || C <= 0 || !scale || !shift || !mr || (kind != 2 && !stats) || (kind == 2 && (!run_mean || !run_var)) ||
+      (kind == 3 && (G <= 0 || C % G)) || (beta && !gamma))
+    return W2S_EINVAL;
+  hipLaunchKernelGGL(norm_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, stats, B, C, kind == 3 ? G : C,
+                     gamma, beta, run_mean, run_var, eps, momentum, count, scale, shift, mr);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// backward counterpart: means [B][C][2] = per-(sample, channel) means over L of ga and ga * xh (w2s_norm_act_bwd_part + w2s_stats_finalize
+// kind 1), mr as written by w2s_norm_fold -> coef [nset][3][C] = (A, B, Cx) of w2s_norm_act_bwd_apply and the affine parameters' gradients
+// dgamma[c] = L sum_b means[b][c][1], dbeta[c] = L sum_b means[b][c][0] (NULL for kind 0).
+__global__ void norm_bwd_coef_kernel(int kind, const float* __restrict__ means, const float* __restrict__ mr, int B, int C, int G,
+                                     const float* __restrict__ gamma, double L, float* __restrict__ coef, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double gm = gamma ? (double)gamma[c] : 1.0;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < B; ++b) { s1 += (double)means[((size_t)b * C + c) * 2]; s2 += (double)means[((size_t)b * C + c) * 2 + 1]; }
+  if (dgamma) dgamma[c] = (float)(s2 * L);
+  if (dbeta) dbeta[c] = (float)(s1 * L);
+  if (kind == 1 || kind == 2) {
+    const double rstd = mr[2 * c + 1];
+    coef[c] = (float)(rstd * gm);
+    coef[C + c] = kind == 1 ? (float)(-rstd * gm * s1 / B) : 0.f;
+    coef[2 * C + c] = kind == 1 ? (float)(-rstd * gm * s2 / B) : 0.f;
+    return;
+  }
+  const int cg = C / G, c0 = (c / cg) * cg;
+  for (int b = 0; b < B; ++b) {
+    const double rstd = mr[((size_t)b * C + c) * 2 + 1];
+    double m1, m2;
+    if (kind == 0) {
+      m1 = means[((size_t)b * C + c) * 2];
+      m2 = means[((size_t)b * C + c) * 2 + 1];
+    } else {
+      m1 = 0.0; m2 = 0.0;
+      for (int k = 0; k < cg; ++k) {
+        const double gk = gamma ? (double)gamma[c0 + k] : 1.0;
+        m1 += gk * (double)means[((size_t)b * C + c0 + k) * 2];
+        m2 += gk * (double)means[((size_t)b * C + c0 + k) * 2 + 1];
+      }
+      m1 /= cg; m2 /= cg;
+    }
+    float* cf = coef + (size_t)b * 3 * C;
+    cf[c] = (float)(rstd * gm);
+    cf[C + c] = (float)(-rstd * m1);
+    cf[2 * C + c] = (float)(-rstd * m2);
+  }
+}
+
+extern "C" int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, int B, int C, int G, const float* gamma, double L, float* coef,
+                                 float* dgamma, float* dbeta, void* stream) {
+  if (kind < 0 || kind > 3 || !means || !mr || !coef || B <= 0 || C <= 0 || (kind == 3 && (G <= 0 || C % G))) return W2S_EINVAL;
+  hipLaunchKernelGGL(norm_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, means, mr, B, C,
+                     kind == 3 ? G : C, gamma, L, coef, dgamma, dbeta);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}

@@ -272,24 +272,25 @@ class GenericForward:
         self._rec(out, (x,), bw)
         return out
 
-    def _stat_norm_bwd(self, g, y, stats, stride_s, gamma, beta, act, B, L, Cc, pool):
-        """backward of (statistics-based norm -> affine -> activation) over y [B, L, C]: per-(sample, channel) means of ga and ga * xh, pooled
-        by `pool` (means [B, C, 2] -> (m1, m2) broadcastable to [B, C]: what the norm averaged over), then gy = A ga + B + Cx xh.
-        Returns gy, sum(ga * xh) [C], sum(ga) [C] (the affine parameters' gradients)."""
+    def _stat_norm_bwd(self, kind, g, y, mr, gamma, beta, act, B, L, Cc, G):
+        """backward of (statistics-based norm -> affine -> activation) over y [B, L, C]: per-(sample, channel) means of ga and ga * xh
+        (two launches), the norm's own averaging + (A, B, Cx) + the affine parameters' gradients (w2s_norm_bwd_coef), gy = A ga + B + Cx xh.
+        Returns gy, dgamma, dbeta (None without affine parameters)."""
         dev = y.device
+        per_sample = kind in (0, 3)
         tile = 1024
         nt = _cdiv(L, tile)
         part = torch.empty(B, nt, 2, Cc, device=dev, dtype=torch.float32)
-        lib.norm_act_bwd_part(g, Cc, y, Cc, stats, stride_s, gamma, beta, L, B, Cc, act, 0.01, tile, part)
+        lib.norm_act_bwd_part(g, Cc, y, Cc, mr, 2 * Cc if per_sample else 0, gamma, beta, L, B, Cc, act, 0.01, tile, part)
         means = torch.empty(B, Cc, 2, device=dev, dtype=torch.float32)
         lib.stats_finalize(part, B, nt, Cc, L, 0.0, 1, means)
-        rstd = stats.view(-1, Cc, 2)[..., 1]                                   # [B or 1, C]
-        gam = gamma[None, :] if gamma is not None else torch.ones(1, Cc, device=dev)
-        m1, m2 = pool(means[..., 0] * gam, means[..., 1] * gam)               # means of gh = ga * gamma and of gh * xh over the normalised set
-        coef = torch.stack(((rstd * gam).expand(B, Cc), (-rstd * m1).expand(B, Cc), (-rstd * m2).expand(B, Cc)), dim=1).contiguous()   # [B, 3, C]
+        coef = torch.empty(B if per_sample else 1, 3, Cc, device=dev, dtype=torch.float32)
+        dgam = torch.empty(Cc, device=dev, dtype=torch.float32) if gamma is not None else None
+        dbet = torch.empty(Cc, device=dev, dtype=torch.float32) if gamma is not None else None
+        lib.norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, float(L), coef, dgam, dbet)
         gy = torch.empty_like(y)
-        lib.norm_act_bwd_apply(g, Cc, y, Cc, stats, stride_s, gamma, beta, coef, 3 * Cc, gy, Cc, L, B * L, Cc, act, 0.01)
-        return gy, means[..., 1].sum(0) * L, means[..., 0].sum(0) * L
+        lib.norm_act_bwd_apply(g, Cc, y, Cc, mr, 2 * Cc if per_sample else 0, gamma, beta, coef, 3 * Cc if per_sample else 0, gy, Cc, L, B * L, Cc, act, 0.01)
+        return gy, dgam, dbet
 
     def _norm_act(self, layer, y, stats, act_name):
         """norm -> activation of one ConvLayer1D output y [B, L, C] (blocks.py:183-185); in place unless a gradient is wanted."""
@@ -298,6 +299,7 @@ class GenericForward:
         act = _act_code(act_name)
         norm = layer.norm
         kind = layer.norm_name
+        dev = y.device
         out = torch.empty_like(y) if self.grad else y
         bw = None
         if kind is None or kind == 'weight':
@@ -307,61 +309,41 @@ class GenericForward:
                 gy = torch.empty_like(g)
                 lib.norm_act_bwd_apply(g, Cc, y, Cc, None, 0, None, None, None, 0, gy, Cc, L, rows, Cc, act, 0.01)
                 return (gy,)
-        elif kind == 'instance':   # stats = (mean, rstd) per (b, c)
-            scale = stats[..., 1].contiguous()
-            shift = (-stats[..., 0] * stats[..., 1]).contiguous()
-            lib.affine_act(y, Cc, scale, shift, Cc, out, Cc, L, rows, Cc, act, 0.01)
-            if getattr(norm, 'affine', False):
-                raise NotImplementedError('InstanceNorm1d(affine=True)')
+        elif kind in ('instance', 'batch', 'group'):
+            # statistics -> (scale, shift) for the forward and (mean, rstd) for the backward, in one launch (w2s_norm_fold)
+            gam = bet = rm = rv = None
+            G, mom, pnorm = 1, 0.0, None
+            if kind == 'instance':   # stats = (mean, rstd) per (b, c)
+                if getattr(norm, 'affine', False):
+                    raise NotImplementedError('InstanceNorm1d(affine=True)')
+                code, eps = 0, norm.eps
+            elif kind == 'batch':    # stats = (E[y], E[y^2]) per (b, c) in training, unused in eval mode
+                pnorm = norm
+                gam, bet, eps = norm.weight.detach(), norm.bias.detach(), norm.eps
+                if self.training and norm.training:
+                    code = 1
+                    if norm.track_running_stats:
+                        rm, rv = norm.running_mean, norm.running_var
+                        mom = norm.momentum if norm.momentum is not None else 1.0 / float(norm.num_batches_tracked + 1)
+                        norm.num_batches_tracked += 1
+                else:
+                    code, rm, rv = 2, norm.running_mean, norm.running_var
+            else:                    # GroupNorm: stats = (E[y], E[y^2]) per (b, c), pooled over the channels of a group
+                pnorm = norm.norm
+                gam, bet, eps, G = pnorm.weight.detach(), pnorm.bias.detach(), pnorm.eps, pnorm.num_groups
+                code = 3
+            nset = B if code in (0, 3) else 1
+            scale = torch.empty(nset, Cc, device=dev, dtype=torch.float32)
+            shift = torch.empty(nset, Cc, device=dev, dtype=torch.float32)
+            mr = torch.empty(nset, Cc, 2, device=dev, dtype=torch.float32)
+            lib.norm_fold(code, stats, B, Cc, G, gam, bet, rm, rv, eps, mom, float(B * L), scale, shift, mr)
+            lib.affine_act(y, Cc, scale, shift, Cc if nset > 1 else 0, out, Cc, L, rows, Cc, act, 0.01)
 
             def bw(g):
-                return (self._stat_norm_bwd(g, y, stats, 2 * Cc, None, None, act, B, L, Cc, lambda a, b: (a, b))[0],)
-        elif kind == 'batch':
-            batch_stats = self.training and norm.training
-            if batch_stats:   # batch statistics over (B, L) + running-statistics update (nn.BatchNorm1d)
-                m = stats[..., 0].mean(0)
-                var = (stats[..., 1].mean(0) - m * m).clamp_min(0)
-                with torch.no_grad():
-                    n = B * L
-                    mom = norm.momentum if norm.momentum is not None else 1.0 / float(norm.num_batches_tracked + 1)
-                    norm.running_mean.mul_(1 - mom).add_(m, alpha=mom)
-                    norm.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
-                    norm.num_batches_tracked += 1
-            else:
-                m, var = norm.running_mean.detach().clone(), norm.running_var.detach().clone()
-            gam, bet = norm.weight.detach(), norm.bias.detach()
-            rstd = 1.0 / torch.sqrt(var + norm.eps)
-            scale = (gam * rstd).contiguous()
-            shift = (bet - m * scale).contiguous()
-            lib.affine_act(y, Cc, scale, shift, 0, out, Cc, L, rows, Cc, act, 0.01)
-
-            def bw(g):
-                st = torch.stack((m, rstd), dim=1).contiguous()   # [C, 2], one set for the batch
-                if batch_stats:
-                    pool = lambda a, b: (a.mean(0, keepdim=True), b.mean(0, keepdim=True))
-                else:                                             # running statistics are constants: gy = ga * gamma * rstd
-                    pool = lambda a, b: (torch.zeros_like(a[:1]), torch.zeros_like(b[:1]))
-                gy, dgam, dbet = self._stat_norm_bwd(g, y, st, 0, gam, bet, act, B, L, Cc, pool)
-                self._pgrad(norm.weight, dgam)
-                self._pgrad(norm.bias, dbet)
-                return (gy,)
-        elif kind == 'group':      # stats = (E[y], E[y^2]) per (b, c): pool over the channels of a group (equal lengths)
-            gn = norm.norm
-            G = gn.num_groups
-            e1 = stats[..., 0].view(B, G, Cc // G).mean(2, keepdim=True)
-            e2 = stats[..., 1].view(B, G, Cc // G).mean(2, keepdim=True)
-            rstd = 1.0 / torch.sqrt((e2 - e1 * e1).clamp_min(0) + gn.eps)
-            gam, bet = gn.weight.detach(), gn.bias.detach()
-            scale = (rstd.expand(B, G, Cc // G).reshape(B, Cc) * gam[None, :]).contiguous()
-            shift = (bet[None, :] - e1.expand(B, G, Cc // G).reshape(B, Cc) * scale).contiguous()
-            lib.affine_act(y, Cc, scale, shift, Cc, out, Cc, L, rows, Cc, act, 0.01)
-
-            def bw(g):
-                st = torch.stack((e1.expand(B, G, Cc // G).reshape(B, Cc), rstd.expand(B, G, Cc // G).reshape(B, Cc)), dim=2).contiguous()   # [B, C, 2]
-                grp = lambda t: t.view(B, G, Cc // G).mean(2, keepdim=True).expand(B, G, Cc // G).reshape(B, Cc)
-                gy, dgam, dbet = self._stat_norm_bwd(g, y, st, 2 * Cc, gam, bet, act, B, L, Cc, lambda a, b: (grp(a), grp(b)))
-                self._pgrad(gn.weight, dgam)
-                self._pgrad(gn.bias, dbet)
+                gy, dgam, dbet = self._stat_norm_bwd(code, g, y, mr, gam, bet, act, B, L, Cc, G)
+                if pnorm is not None:
+                    self._pgrad(pnorm.weight, dgam)
+                    self._pgrad(pnorm.bias, dbet)
                 return (gy,)
         elif kind in ('layer', 'rms'):
             rms = kind == 'rms'

@@ -56,7 +56,7 @@ EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_linear_pf_takes', 'w2s_seq_conv
            'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_bwd_fused_wd', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
-           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_token_masks', 'w2s_cls_scatter', 'w2s_copy_rows', 'w2s_zero', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_norm_act_bwd_part', 'w2s_norm_act_bwd_apply', 'w2s_rownorm_bwd_blocks', 'w2s_rownorm_bwd', 'w2s_attn_generic_bwd', 'w2s_version', 'w2s_abi_version']
+           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_token_masks', 'w2s_cls_scatter', 'w2s_copy_rows', 'w2s_zero', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_norm_act_bwd_part', 'w2s_norm_act_bwd_apply', 'w2s_rownorm_bwd_blocks', 'w2s_rownorm_bwd', 'w2s_attn_generic_bwd', 'w2s_norm_fold', 'w2s_norm_bwd_coef', 'w2s_version', 'w2s_abi_version']
 
 ABI_VERSION = 8   # include/w2s.h W2S_ABI_VERSION
 _lib = None
@@ -711,6 +711,19 @@ def norm_act_bwd_part(g, ldg, y, ldy, stats, stats_stride, gamma, beta, rows_per
 def norm_act_bwd_apply(g, ldg, y, ldy, stats, stats_stride, gamma, beta, coef, coef_stride, gy, ldgy, rows_per_sample, rows, Cc, act, slope=0.01):
     _chk(load().w2s_norm_act_bwd_apply(_f(g), ldg, _f(y), ldy, _f(stats), stats_stride, _f(gamma), _f(beta), _f(coef), coef_stride, _f(gy), ldgy,
                                        rows_per_sample, C.c_long(rows), Cc, act, C.c_float(slope), _stream()), 'w2s_norm_act_bwd_apply')
+
+
+NORM_KIND = {'instance': 0, 'batch_train': 1, 'batch_eval': 2, 'group': 3}
+
+
+def norm_fold(kind, stats, B, Cc, G, gamma, beta, run_mean, run_var, eps, momentum, count, scale, shift, mr):
+    _chk(load().w2s_norm_fold(kind, _f(stats), B, Cc, G, _f(gamma), _f(beta), _f(run_mean), _f(run_var), C.c_float(eps), C.c_float(momentum),
+                              C.c_double(count), _f(scale), _f(shift), _f(mr), _stream()), 'w2s_norm_fold')
+
+
+def norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, L, coef, dgamma, dbeta):
+    _chk(load().w2s_norm_bwd_coef(kind, _f(means), _f(mr), B, Cc, G, _f(gamma), C.c_double(L), _f(coef), _f(dgamma), _f(dbeta), _stream()),
+         'w2s_norm_bwd_coef')
 
 
 def rownorm_bwd_blocks(rows) -> int:
