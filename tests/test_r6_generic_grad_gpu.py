@@ -293,3 +293,36 @@ def test_generic_module_checkpoint_round_trip(tmp_path):
     assert b.trainer.step_count == 3
     lb = [float(b.training_step((x, y))) for _ in range(2)]
     assert la == lb, (la, lb)
+
+
+def test_production_model_fused_and_generic_paths_agree(monkeypatch):
+    """Two independent implementations of the same mathematics: the production model's step on the fused kernels (engine.py) and on the generic
+    path's walker + tape (W2S_FORCE_GENERIC=1) -- logits, loss and every parameter's gradient, with a missing modality, dropout off."""
+    from oracle import wav2sleep_oracle as O
+    cfg = O.ModelConfig(signal_map={'ABD': 'ABD', 'THX': 'THX', 'ECG': 'ECG', 'PPG': 'PPG'}, num_classes=4)
+    x, y = O.make_inputs(cfg, 3, 24, seed=77, missing={'ECG': [1]})
+    xd, yd = {k: v.to(DEV) for k, v in x.items()}, y.to(DEV)
+
+    def run(force):
+        if force:
+            monkeypatch.setenv('W2S_FORCE_GENERIC', '1')
+        else:
+            monkeypatch.delenv('W2S_FORCE_GENERIC', raising=False)
+        torch.manual_seed(5)
+        m = W.Wav2Sleep(W.SignalEncoders(dict(cfg.signal_map), 128, 'gelu', norm='instance', chunk_causal=False), W.MultiModalAttentionEmbedder(128, layers=2, dropout=0.0, dim_ff=512, nhead=8),
+                        W.SequenceCNN(128, dropout=0.0, norm='layer', num_layers=2, kernel_size=7, num_dilations=6), 4).to(DEV).train()
+        assert m.fused_ok() != force
+        lg = m(xd)
+        loss = F.cross_entropy(lg.flatten(0, 1), yd.flatten().long(), ignore_index=-1)
+        loss.backward()
+        return lg.detach(), float(loss.detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    lf, lossf, gfu = run(False)
+    lgn, lossg, gge = run(True)
+    assert float((lf - lgn).abs().max()) <= 2e-4 * float(lf.abs().max())
+    assert abs(lossf - lossg) <= 1e-5 * abs(lossf)
+    worst = ('', 0.0)
+    for k in gfu:
+        e = float((gfu[k] - gge[k]).norm() / gfu[k].norm().clamp_min(1e-30))
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e <= 2e-3, (k, e)
+    print('fused vs generic: worst relative L2 gradient difference', worst)

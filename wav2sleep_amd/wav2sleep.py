@@ -12,6 +12,8 @@ There is no CPU path: CPU tensors raise (lib.W2SError).
 
 from __future__ import annotations
 
+import os
+
 import logging
 import math
 
@@ -484,6 +486,10 @@ class Wav2Sleep(_HandWritten, nn.Module):
         return list(self.signal_encoders.signal_map.keys())
 
     def fused_ok(self) -> bool:
+        """The production family runs on the fused kernels; W2S_FORCE_GENERIC=1 sends it down the generic path too (a cross-check of the two
+        independent forward / backward implementations against each other: tests/test_r6_generic_grad_gpu.py)."""
+        if os.environ.get('W2S_FORCE_GENERIC') == '1':
+            return False
         return self.signal_encoders.fused_ok() and self.epoch_mixer.fused_ok() and self.sequence_mixer.fused_ok() and self.num_classes <= 8
 
     def forward(self, x: dict[str, Tensor]) -> Tensor:
