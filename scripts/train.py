@@ -67,7 +67,7 @@ def main(argv=None) -> int:
             loss = mod.training_step(mod.on_after_batch_transfer(dev(batch), training=True))
         for batch in val:
             mod.validation_step(dev(batch), mode='val')
-        cm = mod.aux_outputs['val'][None]['all']
+        cm = mod.aux_outputs['val'][None if mod.unified else '_'.join(sig)]['all']   # (single-modality models log under the signal's name: trainer/main.py:165-170)
         if rank == 0:
             print(f'epoch {epoch}: train loss {float(loss):.4f}, val kappa {W.cohens_kappa(cm.cpu().numpy(), a.num_classes):.4f}, accuracy {W.confusion_accuracy(cm.cpu().numpy()):.4f}', flush=True)
             os.makedirs(a.out, exist_ok=True)

@@ -721,3 +721,20 @@ def test_train_script_synthetic_smoke(tmp_path, capsys):
     x = {'ECG': torch.randn(1, 24 * 1024, device=DEV), 'THX': torch.randn(1, 24 * 256, device=DEV)}
     with torch.no_grad():
         assert tuple(model(x).shape) == (1, 24, 4)
+
+
+def test_train_script_sleep_ppgnet_smoke(tmp_path, capsys):
+    """`scripts/train.py --model ppgnet` (scripts/config/model/ppgnet.yaml through the same Lightning module in the reference): SleepPPGNet on
+    synthetic 10-hour PPG, trained on the generic path's tape; the exported folder rebuilds through `load_model`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('w2s_train_cli2', os.path.join(ROOT, 'scripts', 'train.py'))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    rc = cli.main(['--model', 'ppgnet', '--signals', 'PPG', '--synthetic', '4', '--synthetic-epochs', '1200', '--batch-size', '2', '--epochs', '1',
+                   '--out', str(tmp_path / 'run')])
+    out = capsys.readouterr().out
+    assert rc == 0 and 'epoch 0: train loss' in out
+    model = W.load_model(str(tmp_path / 'run' / 'model'), device='cuda')
+    assert type(model).__name__ == 'SleepPPGNet'
+    with torch.no_grad():
+        assert tuple(model(torch.randn(1, 1228800, device=DEV)).shape) == (1, 1200, 4)

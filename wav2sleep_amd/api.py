@@ -14,6 +14,7 @@ from typing import Optional, Tuple
 import torch
 import yaml
 
+from . import ppgnet as _ppg
 from . import wav2sleep as _w
 
 _TARGETS = {
@@ -21,6 +22,7 @@ _TARGETS = {
     'wav2sleep.models.wav2sleep.SignalEncoders': _w.SignalEncoders,
     'wav2sleep.models.wav2sleep.MultiModalAttentionEmbedder': _w.MultiModalAttentionEmbedder,
     'wav2sleep.models.wav2sleep.SequenceCNN': _w.SequenceCNN,
+    'wav2sleep.models.ppgnet.SleepPPGNet': _ppg.SleepPPGNet,   # scripts/config/model/ppgnet.yaml
 }
 
 

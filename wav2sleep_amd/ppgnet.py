@@ -49,6 +49,11 @@ class SleepPPGNet(nn.Module):
             DilatedConvBlock(feature_dim=feature_dim, dropout=dropout, activation=activation, norm=norm),
         )
         self.classifier = nn.Linear(in_features=feature_dim, out_features=n_classes)
+        self._config = dict(n_classes=n_classes, norm=norm, feature_dim=feature_dim, activation=activation, dropout=dropout)
+
+    def config_dict(self) -> dict:
+        """The resolved `scripts/config/model/ppgnet.yaml` tree (Hydra `_target_` of the REFERENCE package) that rebuilds this model."""
+        return {'_target_': 'wav2sleep.models.ppgnet.SleepPPGNet', **self._config}
 
     def forward(self, x_BT: Tensor) -> Tensor:
         """[N, 1 228 800] -> logits [N, 1200, n_classes].  With gradients enabled the result is ONE autograd node whose backward is the
