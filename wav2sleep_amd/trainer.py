@@ -378,10 +378,14 @@ class GenericTrainStep:
             lib.zero_(self.cmat)
             lib.ce_fwd_bwd(logits, yv, rows, nc, part, self.loss_out, glogits, self.cmat, self.reducer.grad_scale / self.accumulate)
             pg = gf.backward(logits, glogits.view(B, S, nc))
+            # the tape's gradients into the flat buffer (plumbing: one multi-tensor copy / add instead of a launch per parameter)
+            dst, src = [self.views[p] for p in pg], list(pg.values())
             if first:
-                lib.zero_(self.flat_grad)
-            for p, g in pg.items():
-                lib.eltwise(lib.ELT_ADD, self.views[p], g, self.views[p], g.numel()) if g.numel() % 4 == 0 else self.views[p].add_(g)
+                if len(pg) < len(self.views):
+                    lib.zero_(self.flat_grad)
+                torch._foreach_copy_(dst, src)
+            else:
+                torch._foreach_add_(dst, src)
             if last and (self.reducer.world > 1 or self.reducer.force):
                 self.reducer.reduce_range(0, self.n)
                 self.reducer.wait()
