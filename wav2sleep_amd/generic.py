@@ -70,8 +70,12 @@ class GenericForward:
         lib.load()
 
     # ------------------------------------------------------------------ tape
-    def _rec(self, out, inputs, fn):
+    def _rec(self, out, inputs, fn, share=None, acc_ok=False):
         if self.grad:
+            if share is not None:
+                fn.share = share
+            if acc_ok:
+                fn.acc_ok = True
             self.tape.append((out, tuple(inputs), fn))
 
     def _add(self, a, b):
@@ -87,7 +91,7 @@ class GenericForward:
 
     def _view(self, t, *shape):
         v = t.view(*shape)
-        self._rec(v, (t,), lambda g: (g.reshape(t.shape),))
+        self._rec(v, (t,), lambda g: (g.reshape(t.shape),), share='view')
         return v
 
     def backward(self, out, g_out) -> dict:
@@ -95,15 +99,30 @@ class GenericForward:
         if not self.grad:
             raise RuntimeError('GenericForward(grad=False) keeps no tape')
         grads = {id(out): g_out.contiguous().float()}
+        owned = set()   # ids of gradient buffers that exactly one tape entry still refers to (fresh outputs of a closure): safe to add into
         for o, inputs, fn in reversed(self.tape):
             g = grads.pop(id(o), None)
             if g is None:
                 continue
+            g_owned = id(g) in owned
+            owned.discard(id(g))
+            k0 = id(inputs[0]) if len(inputs) == 1 else None
+            if getattr(fn, 'acc_ok', False) and k0 in grads and id(grads[k0]) in owned:
+                fn(g, acc=grads[k0])   # a convolution whose input already has a gradient (the residual branch ran first): y += in the data-gradient launch
+                continue
+            share = getattr(fn, 'share', None)   # 'all': the outputs ARE g (fan-out of an add); 'view': a view of g
             for t, gi in zip(inputs, fn(g)):
                 if gi is None:
                     continue
                 k = id(t)
-                grads[k] = self._add(grads[k], gi) if k in grads else gi
+                if k in grads:
+                    owned.discard(id(grads[k]))
+                    grads[k] = self._add(grads[k], gi)
+                    owned.add(id(grads[k]))
+                else:
+                    grads[k] = gi
+                    if share is None or (share == 'view' and g_owned):
+                        owned.add(id(gi))
         self.tape = []
         return self.pgrads
 
@@ -140,7 +159,7 @@ class GenericForward:
                 co0 += cp
         return dW
 
-    def _dgrad(self, gy, w, *, B, L_x, L_out, stride, pad, dil):
+    def _dgrad(self, gy, w, *, B, L_x, L_out, stride, pad, dil, acc=None):
         """gradient of the conv input: gy [B, L_out, cout], w [cout, cin, k] -> gx [B, L_x, cin] (w2s_conv_forward on the transposed weights:
         flipped taps for stride 1, W2S_MODE_UP2 for the k=3 / stride-2 conv, the even rows of gx for the 1x1 / stride-2 residual conv)."""
         cout, cin, k = w.shape
@@ -153,25 +172,25 @@ class GenericForward:
         if stride == 2 and k == 1:
             if pad != 0:
                 raise NotImplementedError('1x1 / stride-2 conv with padding')
-            gx = torch.zeros(B, L_x, cin, device=dev, dtype=torch.float32)
+            gx = acc if acc is not None else torch.zeros(B, L_x, cin, device=dev, dtype=torch.float32)
             samples = [(gy, gx, B)] if L_x == 2 * L_out else [(gy[b], gx[b], 1) for b in range(B)]
             for gs, xs, nb in samples:   # row t of the gradient lands on row 2t of gx: a GEMM whose output row stride is two rows of gx
                 for q, (c0, ck) in enumerate(chunks):
                     wq = wb if nchunk == 1 else wb[:, :, c0:c0 + ck].contiguous()
                     lib.conv_forward(lib.conv_args(x=gs if q == 0 else gs[..., c0:], w=wq, y=xs, B=1, L_in=nb * L_out, L_out=nb * L_out, cin=ck, cout=cin,
-                                                   taps=1, stride=1, pad=0, ldx=cout, ldy=2 * cin, accumulate=q > 0))
+                                                   taps=1, stride=1, pad=0, ldx=cout, ldy=2 * cin, accumulate=q > 0 or acc is not None))
             return gx
-        gx = torch.empty(B, L_x, cin, device=dev, dtype=torch.float32)
+        gx = acc if acc is not None else torch.empty(B, L_x, cin, device=dev, dtype=torch.float32)
         for q, (c0, ck) in enumerate(chunks):
             wq = wb if nchunk == 1 else wb[:, :, c0:c0 + ck].contiguous()
             xq = gy if q == 0 else gy[..., c0:]
             if stride == 1:
                 mode = lib.MODE_DILATED if k == 7 else lib.MODE_CONTIG
                 a = lib.conv_args(x=xq, w=wq, y=gx, B=B, L_in=L_out, L_out=L_x, cin=ck, cout=cin, taps=k, stride=1, pad=(k - 1) * dil - pad, dil=dil,
-                                  flip=1, mode=mode, ldx=cout, accumulate=q > 0)
+                                  flip=1, mode=mode, ldx=cout, accumulate=q > 0 or acc is not None)
             elif stride == 2 and k == 3 and dil == 1:
                 a = lib.conv_args(x=xq, w=wq, y=gx, B=B, L_in=L_out, L_out=L_x, cin=ck, cout=cin, taps=3, stride=2, pad=pad, mode=lib.MODE_UP2,
-                                  ldx=cout, accumulate=q > 0)
+                                  ldx=cout, accumulate=q > 0 or acc is not None)
             else:
                 raise NotImplementedError(f'data gradient of kernel_size={k}, stride={stride}, dilation={dil}')
             lib.conv_forward(a)
@@ -241,15 +260,15 @@ class GenericForward:
         if self.grad:
             xs = x   # the (padded) operand of the weight gradient
 
-            def bw(gy):
+            def bw(gy, acc=None):
                 if bp is not None:
                     self._pgrad(bp, self._rowsum(gy, B * L_out, cout, cout))
                 dW = self._wgrad(gy, xs, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=k, stride=stride, pad=pad, dil=dil)
                 self._pgrad(wp, dW[:, :cin_w] if cin_w != cin else dW)
                 if not x_needs_grad or cin_w == 1:
                     return (None,)
-                return (self._dgrad(gy, wp.detach(), B=B, L_x=L_in, L_out=L_out, stride=stride, pad=pad, dil=dil),)
-            self._rec(y, (x_in,), bw)
+                return (self._dgrad(gy, wp.detach(), B=B, L_x=L_in, L_out=L_out, stride=stride, pad=pad, dil=dil, acc=acc),)
+            self._rec(y, (x_in,), bw, acc_ok=x_needs_grad and cin_w != 1)
         return y, stats
 
     def _act(self, x, name: str, slope: float = 0.01):
@@ -399,7 +418,7 @@ class GenericForward:
         """a + b (in place into a unless a gradient is wanted)"""
         out = torch.empty_like(a) if self.grad else a
         lib.eltwise(lib.ELT_ADD, a, b, out, a.numel())
-        self._rec(out, (a, b), lambda g: (g, g))
+        self._rec(out, (a, b), lambda g: (g, g), share='all')
         return out
 
     def conv_layer(self, layer, x, x_needs_grad=True):
@@ -588,7 +607,7 @@ class GenericForward:
             def add(a_, b_):
                 o = torch.empty_like(a_)
                 lib.eltwise(lib.ELT_ADD, a_, b_, o, a_.numel())
-                self._rec(o, (a_, b_), lambda g: (g, g))
+                self._rec(o, (a_, b_), lambda g: (g, g), share='all')
                 return o
 
             if layer.norm_first:
