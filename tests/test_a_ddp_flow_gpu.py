@@ -22,14 +22,14 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run_ranks(out_dir, world, accumulate):
+def _run_ranks(out_dir, world, accumulate, mode='fused'):
     port = _free_port()
     procs = []
     try:
         for r in range(world):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                        W2S_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ddp_flow_worker.py'), str(out_dir), str(accumulate)], env=env,
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ddp_flow_worker.py'), str(out_dir), str(accumulate), mode], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     except PermissionError as e:   # exec refused (this process had already initialised the GPU)
         for p in procs:
@@ -111,3 +111,35 @@ def test_two_ranks_one_gpu_train_step_matches_oracle(tmp_path, accumulate):
     valid = sum(int((r['batches'][-1][1] >= 0).sum()) for r in res)
     assert int(r0['cm'].sum()) == valid
     assert r0['gmean'] == pytest.approx(r1['gmean'], rel=1e-12)
+
+
+def test_two_ranks_generic_train_step_is_mean_of_per_rank_gradients(tmp_path):
+    """GenericTrainStep (the generic path's tape: a GroupNorm / post-norm / RMS configuration) on two ranks with different batches, missing
+    modalities and label counts: both ranks start from rank 0's weights, end bit-identical, and the reduced gradient is the mean of the
+    per-rank mean-loss gradients -- recomputed here, one process, through the autograd node of the same model."""
+    import torch.nn.functional as F
+    res = _run_ranks(tmp_path, 2, 1, mode='generic')
+    r0, r1 = res
+    for k in r0['start']:
+        assert torch.equal(r0['start'][k], r1['start'][k]), k
+    assert torch.equal(r0['flat_grad'], r1['flat_grad'])
+    for k in r0['params']:
+        assert torch.equal(r0['params'][k], r1['params'][k]), k
+    assert r0['step_count'] == 1 and r0['loss'] != r1['loss']
+    import wav2sleep_amd as W
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import ddp_flow_worker as Wk
+    grads = []
+    for rank in range(2):
+        model = Wk.generic_model(W)
+        model.load_state_dict(r0['start'])
+        model.to('cuda').train()
+        x, y = Wk.generic_batch(rank, 0)
+        loss = F.cross_entropy(model({k: v.to('cuda') for k, v in x.items()}).flatten(0, 1), y.flatten().long().to('cuda'), ignore_index=-1)
+        assert abs(float(loss.detach()) - res[rank]['loss']) <= 1e-5 * abs(res[rank]['loss'])
+        loss.backward()
+        grads.append({n: p.grad.detach().cpu() for n, p in model.named_parameters()})
+    for (o, n, shape), name in zip(r0['layout'], r0['names']):
+        want = 0.5 * (grads[0][name] + grads[1][name])
+        got = r0['flat_grad'][o:o + n].view(shape)
+        assert float((got - want).norm()) <= 1e-5 * float(want.norm()) + 1e-9, name
