@@ -530,7 +530,7 @@ class GenericForward:
                     ge[idx] = self._rowsum(gm, Bq * Sq, Fq, Fq)
                     self._pgrad(mod.embedder.weight, ge)
                     return (g,)
-                self._rec(z_BSF, (z_in,), bw)
+                self._rec(z_BSF, (z_in,), bw, share='view')   # (the gradient passes through unchanged)
             z[name] = z_BSF
         return z
 
