@@ -232,3 +232,43 @@ def test_exported_scheduler_and_lr_state_is_what_torch_holds_after_k_steps():
     assert got['last_epoch'] == want['last_epoch'] == 7 and got['_step_count'] == want['_step_count']
     assert got['_last_lr'] == pytest.approx(want['_last_lr']) and got['_last_lr'][0] == pytest.approx(opt.param_groups[0]['lr'])
     assert got['_last_lr'][0] == pytest.approx(1e-3 * 8 / 2000)
+
+
+def test_generic_tape_chunks_and_gradient_accumulation():
+    """Host logic of the generic path's backward (wav2sleep_amd/generic.py), no kernels: how a contraction is cut into power-of-two blocks, and
+    how the tape sums gradients where a tensor fans out -- a fresh buffer is added into in place by a convolution's data gradient (`acc`),
+    a buffer that two inputs share (the fan-out of an add) or a view of one never is."""
+    from wav2sleep_amd.generic import GenericForward, _chunks
+    assert _chunks(16) == [(0, 16)] and _chunks(128) == [(0, 128)] and _chunks(256) == [(0, 128), (128, 128)]
+    assert _chunks(48) == [(0, 32), (32, 16)] and _chunks(1024)[-1] == (896, 128) and _chunks(208) == [(0, 128), (128, 64), (192, 16)]
+    with pytest.raises(NotImplementedError):
+        _chunks(24)
+    gf = GenericForward(grad=True)
+    gf._add = lambda a, b: a + b            # (the kernel behind it needs a GPU)
+    x = torch.zeros(4)
+    calls = []
+
+    def conv_like(scale):
+        def bw(g, acc=None):
+            calls.append(('acc' if acc is not None else 'new', scale))
+            if acc is not None:
+                acc += scale * g
+                return (acc,)
+            return (scale * g,)
+        return bw
+    # y1 = f1(x), y2 = f2(x) (both "convolutions" of the same input), s = y1 + y2, out = view(s)
+    y1, y2, s = torch.zeros(4), torch.zeros(4), torch.zeros(4)
+    root = torch.zeros(1)
+    gx = []
+    gf._rec(x, (root,), lambda g: (gx.append(g.clone()) or None,))   # (x is itself an output: its accumulated gradient arrives here)
+    gf._rec(y1, (x,), conv_like(2.0), acc_ok=True)
+    gf._rec(y2, (x,), conv_like(3.0), acc_ok=True)
+    gf._rec(s, (y1, y2), lambda g: (g, g), share='all')
+    out = s.view(2, 2)
+    gf._rec(out, (s,), lambda g: (g.reshape(4),), share='view')
+    g_out = torch.arange(4.0).view(2, 2)
+    gf.backward(out, g_out)
+    assert torch.equal(gx[0], 5.0 * torch.arange(4.0))
+    # the second convolution met a FRESH gradient of x (the first one's output) and added into it; the first one had nothing to add into
+    assert calls == [('new', 3.0), ('acc', 2.0)]
+    assert torch.equal(g_out, torch.arange(4.0).view(2, 2))   # the caller's gradient (shared by the add's fan-out through a view) was never written
