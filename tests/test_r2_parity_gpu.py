@@ -174,7 +174,7 @@ def test_ten_train_steps_match_reference_run():
             assert rel <= (0.03 if step == 0 else 0.15), (step, rel)
 
 
-@pytest.mark.parametrize('k', [2, 3])
+@pytest.mark.parametrize('k', [3])   # (k = 2 against the oracle: tests/test_a_ddp_flow_gpu.py::test_two_ranks_one_gpu_train_step_matches_oracle[2])
 def test_gradient_accumulation_matches_oracle(k):
     """FusedTrainStep(accumulate=k) = Lightning accumulate_grad_batches=k (scripts/train.py:59-76): k micro-batches, each loss / k,
     gradients summed, ONE clip + AdamW.  Oracle: mean of the k per-micro-batch mean-loss gradients."""
