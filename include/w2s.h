@@ -37,6 +37,10 @@ extern "C" {
 #define W2S_PRO_FIRST 6     /* x = the raw 1-channel signal [B][L_in], x2 = block 0's conv1 weight [16][3]: the 16-channel conv1 output is
                               * RE-COMPUTED on load (3 FMAs / element; inf -> 0 as W2S_PRO_SANITIZE) and then normalised + GELU'd as mode 3.
                               * The largest tensor of the model (16 x T per recording) is then never written or read.  cin must be 16. */
+#define W2S_PRO_AFFINE 7    /* act(x * scale + shift), act = pro - 7 in {0 linear, 1 ReLU, 2 LeakyReLU(0.01), 3 GELU, 4 SiLU} (W2S_PRO_AFFINE + act);
+                              * pro_stats / x_stats hold (scale, shift) per (b, c) instead of (mean, rstd): any per-channel norm + activation of
+                              * the generic path (BatchNorm, GroupNorm, instance, none) applied on load, so that its output is never written
+                              * (ConvLayer1D.forward, blocks.py:183-184, for the NEXT layer's conv and that conv's weight gradient; round 6) */
 
 /* ---- epilogue (applied to the accumulator tile before the store) ---- */
 #define W2S_EPI_PLAIN 0
@@ -437,9 +441,10 @@ int w2s_rownorm_bwd(const float* g, int ldg, const float* x, int ldx, const floa
  * (mean, rstd) per (b, c)), 1 BatchNorm1d training (stats = (E[y], E[y^2]) per (b, c); run_mean / run_var updated in place with `momentum`
  * and the unbiased variance over `count` = B L elements, or NULL), 2 BatchNorm1d eval (running statistics; stats unused), 3 GroupNorm (stats =
  * (E[y], E[y^2]); G groups of consecutive channels).  scale / shift [nset][C] feed w2s_affine_act, mr [nset][C][2] = (mean, rstd) feeds the
- * backward kernels as `stats`; nset = B for kinds 0 and 3, 1 for kinds 1 and 2. */
+ * backward kernels as `stats`; nset = B for kinds 0 and 3, 1 for kinds 1 and 2; ss (or NULL) [B][C][2] = (scale, shift) per sample, the
+ * (scale, shift) operand of W2S_PRO_AFFINE. */
 int w2s_norm_fold(int kind, const float* stats, int B, int C, int G, const float* gamma, const float* beta, float* run_mean, float* run_var,
-                  float eps, float momentum, double count, float* scale, float* shift, float* mr, void* stream);
+                  float eps, float momentum, double count, float* scale, float* shift, float* mr, float* ss, void* stream);
 /* means [B][C][2] = per-(sample, channel) means of ga and ga * xh -> coef [nset][3][C] for w2s_norm_act_bwd_apply, dgamma / dbeta [C] (or NULL) */
 int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, int B, int C, int G, const float* gamma, double L, float* coef,
                       float* dgamma, float* dbeta, void* stream);

@@ -401,11 +401,13 @@ extern "C" int w2s_attn_generic_bwd(const float* qkv, const unsigned char* keypa
 // kind: 0 InstanceNorm1d (stats = (mean, rstd) per (b, c), no affine), 1 BatchNorm1d in training (stats = (E[y], E[y^2]) per (b, c); the
 // running statistics are updated with the unbiased variance as nn.BatchNorm1d does), 2 BatchNorm1d in eval mode (running statistics),
 // 3 GroupNorm (stats = (E[y], E[y^2]); G groups of C / G consecutive channels).
-// out: scale / shift [nset][C] for w2s_affine_act and mr [nset][C][2] = (mean, rstd) for the backward; nset = B (kinds 0, 3) or 1 (1, 2).
+// out: scale / shift [nset][C] for w2s_affine_act and mr [nset][C][2] = (mean, rstd) for the backward; nset = B (kinds 0, 3) or 1 (1, 2);
+// ss (optional) [B][C][2] = (scale, shift) for every sample: the W2S_PRO_AFFINE operand of the next layer's conv / weight gradient.
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ void norm_fold_kernel(int kind, const float* __restrict__ stats, int B, int C, int G, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, float* __restrict__ run_mean, float* __restrict__ run_var, float eps, float momentum,
-                                 double count, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mr) {
+                                 double count, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mr,
+                                 float* __restrict__ ss) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double gm = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
@@ -430,6 +432,8 @@ __global__ void norm_fold_kernel(int kind, const float* __restrict__ stats, int 
     shift[c] = (float)(bt - m * gm * rstd);
     mr[2 * c] = (float)m;
     mr[2 * c + 1] = (float)rstd;
+    if (ss)
+      for (int b = 0; b < B; ++b) { ss[((size_t)b * C + c) * 2] = scale[c]; ss[((size_t)b * C + c) * 2 + 1] = shift[c]; }
     return;
   }
   const int cg = C / G, c0 = (c / cg) * cg;
@@ -451,16 +455,17 @@ __global__ void norm_fold_kernel(int kind, const float* __restrict__ stats, int 
     shift[(size_t)b * C + c] = (float)(bt - m * gm * rstd);
     mr[((size_t)b * C + c) * 2] = (float)m;
     mr[((size_t)b * C + c) * 2 + 1] = (float)rstd;
+    if (ss) { ss[((size_t)b * C + c) * 2] = scale[(size_t)b * C + c]; ss[((size_t)b * C + c) * 2 + 1] = shift[(size_t)b * C + c]; }
   }
 }
 
 extern "C" int w2s_norm_fold(int kind, const float* stats, int B, int C, int G, const float* gamma, const float* beta, float* run_mean, float* run_var,
-                             float eps, float momentum, double count, float* scale, float* shift, float* mr, void* stream) {
+                             float eps, float momentum, double count, float* scale, float* shift, float* mr, float* ss, void* stream) {
   if (kind < 0 || kind > 3 || B <= 0 || C <= 0 || !scale || !shift || !mr || (kind != 2 && !stats) || (kind == 2 && (!run_mean || !run_var)) ||
       (kind == 3 && (G <= 0 || C % G)) || (beta && !gamma))
     return W2S_EINVAL;
   hipLaunchKernelGGL(norm_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, stats, B, C, kind == 3 ? G : C,
-                     gamma, beta, run_mean, run_var, eps, momentum, count, scale, shift, mr);
+                     gamma, beta, run_mean, run_var, eps, momentum, count, scale, shift, mr, ss);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

@@ -238,6 +238,7 @@ __device__ __forceinline__ ProCoef pro_coef(int pro, f32x4 mean, f32x4 rstd, f32
   ProCoef k{rstd, -(mean * rstd), {0, 0, 0, 0}, {0, 0, 0, 0}};
   if (pro == W2S_PRO_INBWD) { k.b = -(rstd * rstd * s2); k.c = rstd * (rstd * s2 * mean - s1); }
   else if (pro == W2S_PRO_INBWD_GP) { k.c = -(rstd * s2); k.d = -(rstd * s1); }
+  else if (pro >= W2S_PRO_AFFINE) { k.a = mean; k.b = rstd; }   // the pair is (scale, shift) (generic path)
   return k;
 }
 __device__ __forceinline__ f32x4 pro_apply_k(int pro, f32x4 v, f32x4 v2, const ProCoef& k) {
@@ -255,6 +256,20 @@ __device__ __forceinline__ f32x4 pro_apply_k(int pro, f32x4 v, f32x4 v2, const P
     case W2S_PRO_INBWD_GP: {
       const f32x4 n = fma4(v2, k.a, k.b);
       return fma4(v * k.a, gelu_grad4(n), fma4(n, k.c, k.d));
+    }
+    case W2S_PRO_AFFINE:       // generic path: act(x * scale + shift), activation = pro - W2S_PRO_AFFINE (get_activation, models/utils.py:61-74)
+      return fma4(v, k.a, k.b);
+    case W2S_PRO_AFFINE + 1:
+      return __builtin_elementwise_max(fma4(v, k.a, k.b), splat4(0.f));
+    case W2S_PRO_AFFINE + 2: {
+      const f32x4 n = fma4(v, k.a, k.b);
+      return __builtin_elementwise_max(n, n * 0.01f);
+    }
+    case W2S_PRO_AFFINE + 3:
+      return gelu4(fma4(v, k.a, k.b));
+    case W2S_PRO_AFFINE + 4: {
+      const f32x4 n = fma4(v, k.a, k.b);
+      return (f32x4){n.x / (1.0f + __expf(-n.x)), n.y / (1.0f + __expf(-n.y)), n.z / (1.0f + __expf(-n.z)), n.w / (1.0f + __expf(-n.w))};
     }
     default:
       return v;

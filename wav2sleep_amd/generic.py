@@ -54,6 +54,20 @@ def _chunks(c: int):
     return out
 
 
+class _Lazy:
+    """act(y * scale + shift) NOT materialised: the output of a ConvLayer1D whose consumer is another convolution.  That convolution and its
+    weight gradient apply it on load (W2S_PRO_AFFINE + act, `ss` = (scale, shift) per (sample, channel)), so the tensor is never written.
+    `mat` caches the materialised form for any other consumer."""
+    __slots__ = ('y', 'ss', 'scale', 'shift', 'act', 'mat')
+
+    def __init__(self, y, ss, scale, shift, act):
+        self.y, self.ss, self.scale, self.shift, self.act, self.mat = y, ss, scale, shift, act, None
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+
 class GenericForward:
     """Stateless walker over the parameter containers of wav2sleep.py (same attribute names as the reference modules).
     grad=True: every launch group is recorded on a tape and nothing is overwritten in place; `backward(out, g)` then returns
@@ -93,6 +107,18 @@ class GenericForward:
         v = t.view(*shape)
         self._rec(v, (t,), lambda g: (g.reshape(t.shape),), share='view')
         return v
+
+    def _mat(self, t):
+        """the tensor behind t (a _Lazy output is written out now, once)"""
+        if not isinstance(t, _Lazy):
+            return t
+        if t.mat is None:
+            B, L, Cc = t.y.shape
+            out = torch.empty_like(t.y)
+            lib.affine_act(t.y, Cc, t.scale, t.shift, Cc if (t.scale is not None and t.scale.shape[0] > 1) else 0, out, Cc, L, B * L, Cc, t.act, 0.01)
+            t.mat = out
+            self._rec(out, (t,), lambda g: (g,), share='view')
+        return t.mat
 
     def backward(self, out, g_out) -> dict:
         """Replay the tape in reverse from d(loss)/d(out); returns {parameter: gradient} (a parameter used twice: the sum)."""
@@ -136,7 +162,7 @@ class GenericForward:
         return out
 
     # ------------------------------------------------------------------ weight / data gradients of a convolution
-    def _wgrad(self, g, x, *, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1):
+    def _wgrad(self, g, x, *, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, pro_h=0, x_stats=None):
         """dW [cout][cin][taps] = sum_{b,t} g[b,t,:] (x) x[b, t*stride + j*dil - pad, :]: w2s_wgrad per (<= 128 input channels) x
         (128 / 64 / 32 / 16 output channels) block -- the shapes its kernels are instantiated for -- then the deterministic slab sum."""
         dev = g.device
@@ -146,7 +172,7 @@ class GenericForward:
             while co0 < cout:
                 cp = next(c for c in (128, 64, 32, 16) if c <= cout - co0)
                 kw = dict(g=g if co0 == 0 else g[..., co0:], x=x if ci0 == 0 else x[..., ci0:], B=B, L_in=L_in, L_out=L_out, cin=ck, cout=cp,
-                          taps=taps, stride=stride, pad=pad, dil=dil, ldg=cout, ldx=cin, split_precision=True)
+                          taps=taps, stride=stride, pad=pad, dil=dil, ldg=cout, ldx=cin, split_precision=True, pro_h=pro_h, x_stats=x_stats)
                 gy = lib.wgrad_grid_y(ck, cp, taps, dil)
                 gx = max(1, min(_cdiv(B * L_out, 256), max(1, lib.wgrad_max_blocks(slab=None, nslab=0, **kw) // gy)))
                 nslab = gx * lib.wgrad_slabs_per_block_of(slab=None, nslab=0, **kw)
@@ -212,12 +238,18 @@ class GenericForward:
         wp / bp: the weight / bias PARAMETERS ([cout, cin, k] / [cout] or None).  want_stats: None | 0 (mean, rstd) | 1 (E[y], E[y^2]) -> [B, Cout, 2]."""
         w = wp.detach()
         bias = bp.detach() if bp is not None else None
+        pro, ss = lib.PRO_NONE, None
+        x_in = x
+        if isinstance(x, _Lazy):
+            if len(_chunks(x.shape[2])) == 1:   # the previous layer's norm + activation on load (its output was never written)
+                pro, ss, x = lib.PRO_AFFINE + x.act, x.ss, x.y
+            else:
+                x = x_in = self._mat(x)
         B, L_in, cin = x.shape
         cout, cin_w, k = w.shape
         if cout % 16:
             raise NotImplementedError(f'{cout} output channels: the generic kernels produce multiples of 16')
         dev = x.device
-        x_in = x
         if cin == 1:   # zero-pad the one-channel input to the narrowest tile the matrix path takes (once per input: conv1 and the residual conv share it)
             if self._x16 is None or self._x16[0] is not x:
                 x16 = torch.zeros(B, L_in, 16, device=dev, dtype=torch.float32)
@@ -245,7 +277,7 @@ class GenericForward:
             xq = x if q == 0 else x[..., c0:]                                   # pointer offset; row stride stays the full width
             a = lib.conv_args(x=xq, w=wq, y=y, B=B, L_in=L_in, L_out=L_out, cin=ck, cout=cout, taps=k, stride=stride, pad=pad, dil=dil, mode=mode,
                               ldx=cin, epi=lib.EPI_BIAS if (bias is not None and q == 0) else (lib.EPI_STATS if fused_stats else lib.EPI_PLAIN),
-                              bias=bias if q == 0 else None, accumulate=q > 0)
+                              bias=bias if q == 0 else None, accumulate=q > 0, pro=pro, pro_stats=ss)
             if fused_stats:
                 nt = _cdiv(L_out, lib.conv_tile_of(a))
                 part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32)
@@ -263,7 +295,7 @@ class GenericForward:
             def bw(gy, acc=None):
                 if bp is not None:
                     self._pgrad(bp, self._rowsum(gy, B * L_out, cout, cout))
-                dW = self._wgrad(gy, xs, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=k, stride=stride, pad=pad, dil=dil)
+                dW = self._wgrad(gy, xs, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=k, stride=stride, pad=pad, dil=dil, pro_h=pro, x_stats=ss)
                 self._pgrad(wp, dW[:, :cin_w] if cin_w != cin else dW)
                 if not x_needs_grad or cin_w == 1:
                     return (None,)
@@ -311,18 +343,26 @@ class GenericForward:
         lib.norm_act_bwd_apply(g, Cc, y, Cc, mr, 2 * Cc if per_sample else 0, gamma, beta, coef, 3 * Cc if per_sample else 0, gy, Cc, L, B * L, Cc, act, 0.01)
         return gy, dgam, dbet
 
-    def _norm_act(self, layer, y, stats, act_name):
-        """norm -> activation of one ConvLayer1D output y [B, L, C] (blocks.py:183-185); in place unless a gradient is wanted."""
+    def _norm_act(self, layer, y, stats, act_name, lazy=False):
+        """norm -> activation of one ConvLayer1D output y [B, L, C] (blocks.py:183-185); in place unless a gradient is wanted.
+        lazy (the consumer is a convolution over <= 128 channels): per-channel norms return a _Lazy instead of writing the result."""
         B, L, Cc = y.shape
+        lazy = lazy and len(_chunks(Cc)) == 1
         rows = B * L
         act = _act_code(act_name)
         norm = layer.norm
         kind = layer.norm_name
         dev = y.device
-        out = torch.empty_like(y) if self.grad else y
+        lazy = lazy and kind in (None, 'instance', 'batch', 'group')
+        out = None if lazy else (torch.empty_like(y) if self.grad else y)
         bw = None
         if kind is None or kind == 'weight':
-            lib.affine_act(y, Cc, None, None, 0, out, Cc, L, rows, Cc, act, 0.01)
+            if lazy:
+                ss = torch.zeros(B, Cc, 2, device=dev, dtype=torch.float32)
+                ss[..., 0] = 1.0
+                out = _Lazy(y, ss, None, None, act)
+            else:
+                lib.affine_act(y, Cc, None, None, 0, out, Cc, L, rows, Cc, act, 0.01)
 
             def bw(g):
                 gy = torch.empty_like(g)
@@ -355,8 +395,12 @@ class GenericForward:
             scale = torch.empty(nset, Cc, device=dev, dtype=torch.float32)
             shift = torch.empty(nset, Cc, device=dev, dtype=torch.float32)
             mr = torch.empty(nset, Cc, 2, device=dev, dtype=torch.float32)
-            lib.norm_fold(code, stats, B, Cc, G, gam, bet, rm, rv, eps, mom, float(B * L), scale, shift, mr)
-            lib.affine_act(y, Cc, scale, shift, Cc if nset > 1 else 0, out, Cc, L, rows, Cc, act, 0.01)
+            ss = torch.empty(B, Cc, 2, device=dev, dtype=torch.float32) if lazy else None
+            lib.norm_fold(code, stats, B, Cc, G, gam, bet, rm, rv, eps, mom, float(B * L), scale, shift, mr, ss)
+            if lazy:
+                out = _Lazy(y, ss, scale, shift, act)
+            else:
+                lib.affine_act(y, Cc, scale, shift, Cc if nset > 1 else 0, out, Cc, L, rows, Cc, act, 0.01)
 
             def bw(g):
                 gy, dgam, dbet = self._stat_norm_bwd(code, g, y, mr, gam, bet, act, B, L, Cc, G)
@@ -421,8 +465,9 @@ class GenericForward:
         self._rec(out, (a, b), lambda g: (g, g), share='all')
         return out
 
-    def conv_layer(self, layer, x, x_needs_grad=True):
-        """ConvLayer1D.forward on channels-last x [B, L, Cin] (blocks.py:173-186)."""
+    def conv_layer(self, layer, x, x_needs_grad=True, lazy_out=False):
+        """ConvLayer1D.forward on channels-last x [B, L, Cin] (blocks.py:173-186).  x may be the _Lazy output of the layer before;
+        lazy_out: the caller feeds the result to another conv_layer (and nothing else)."""
         conv = layer.conv
         k, stride, dil = conv.kernel_size[0], conv.stride[0], conv.dilation[0]
         if conv.groups != 1:
@@ -442,11 +487,13 @@ class GenericForward:
         if conv.bias is not None and want is not None:
             raise NotImplementedError('a convolution bias in front of a statistics-based norm')
         y, stats = self._conv(x, conv.weight, conv.bias, L_out, stride=stride, pad=pad, dil=dil, want_stats=want, eps=eps, x_needs_grad=x_needs_grad)
-        return self._dropout_(self._norm_act(layer, y, stats, layer.activation_name), layer.dropout_p)
+        drop = self.training and layer.dropout_p > 0.0
+        out = self._norm_act(layer, y, stats, layer.activation_name, lazy=lazy_out and not drop)
+        return self._dropout_(out, layer.dropout_p) if drop else out
 
     def conv_block(self, block, x, x_needs_grad=True):
         """ConvBlock1D.forward (blocks.py:57-71)."""
-        out = self.conv_layer(block.conv3, self.conv_layer(block.conv2, self.conv_layer(block.conv1, x, x_needs_grad)))
+        out = self.conv_layer(block.conv3, self.conv_layer(block.conv2, self.conv_layer(block.conv1, x, x_needs_grad, lazy_out=True), lazy_out=True))
         if block.use_residual:
             r, _ = self._conv(x, block.downsample.weight, None, out.shape[1], stride=2, pad=0, dil=1, x_needs_grad=x_needs_grad)
             out = self._sum(out, r)
@@ -455,8 +502,9 @@ class GenericForward:
     def dilated_block(self, block, x):
         """DilatedConvBlock.forward (blocks.py:115-126) on [B, S, F]."""
         out = x
-        for layer in block.conv_layers:
-            out = self.conv_layer(layer, out)
+        n = len(block.conv_layers)
+        for i, layer in enumerate(block.conv_layers):
+            out = self.conv_layer(layer, out, lazy_out=i + 1 < n)
         out = self._dropout_(out, block.dropout.p)
         if out is x:
             out = x.clone()

@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 
 # enums (include/w2s.h)
 PRO_NONE, PRO_SANITIZE, PRO_GELU, PRO_IN_GELU, PRO_INBWD, PRO_INBWD_GP, PRO_FIRST = range(7)
+PRO_AFFINE = 7   # + activation code (ACT): act(x * scale + shift) on load, statistics operand = (scale, shift) per (b, c)
 EPI_PLAIN, EPI_STATS, EPI_AUX_INGELU_ADD, EPI_BIAS, EPI_GP = range(5)
 MODE_CONTIG, MODE_DILATED, MODE_UP2 = range(3)
 ELT_GELU, ELT_GELU_BWD, ELT_ADD, ELT_ADD_DROP, ELT_DROP, ELT_GELU_DROP, ELT_GELU_DROP_BWD = range(7)
@@ -716,9 +717,9 @@ def norm_act_bwd_apply(g, ldg, y, ldy, stats, stats_stride, gamma, beta, coef, c
 NORM_KIND = {'instance': 0, 'batch_train': 1, 'batch_eval': 2, 'group': 3}
 
 
-def norm_fold(kind, stats, B, Cc, G, gamma, beta, run_mean, run_var, eps, momentum, count, scale, shift, mr):
+def norm_fold(kind, stats, B, Cc, G, gamma, beta, run_mean, run_var, eps, momentum, count, scale, shift, mr, ss=None):
     _chk(load().w2s_norm_fold(kind, _f(stats), B, Cc, G, _f(gamma), _f(beta), _f(run_mean), _f(run_var), C.c_float(eps), C.c_float(momentum),
-                              C.c_double(count), _f(scale), _f(shift), _f(mr), _stream()), 'w2s_norm_fold')
+                              C.c_double(count), _f(scale), _f(shift), _f(mr), _f(ss), _stream()), 'w2s_norm_fold')
 
 
 def norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, L, coef, dgamma, dbeta):
