@@ -326,3 +326,40 @@ def test_production_model_fused_and_generic_paths_agree(monkeypatch):
         worst = max(worst, (k, e), key=lambda t: t[1])
         assert e <= 2e-3, (k, e)
     print('fused vs generic: worst relative L2 gradient difference', worst)
+
+
+@pytest.mark.parametrize('act', ['linear', 'relu', 'leaky', 'gelu', 'silu'])
+def test_affine_activation_on_load_prologue_of_conv_and_weight_gradient(act):
+    """W2S_PRO_AFFINE + act: `w2s_conv_forward` and `w2s_wgrad` apply act(x * scale + shift) (per sample and channel) to their input operand
+    on load -- against torch CPU on the materialised tensor, zero padding of the TRANSFORMED operand included."""
+    torch.manual_seed(8)
+    B, L, cin, cout, k = 2, 777, 32, 48, 3
+    x = torch.randn(B, L, cin)
+    ss = torch.stack((1 + 0.3 * torch.randn(B, cin), 0.4 * torch.randn(B, cin)), dim=2).contiguous()   # [B, cin, 2] = (scale, shift)
+    w = torch.randn(cout, cin, k) / (cin * k) ** 0.5
+    g = torch.randn(B, L, cout)
+    xa = ACTS[act](x * ss[:, None, :, 0] + ss[:, None, :, 1])                     # [B, L, cin]
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv1d(xa.transpose(1, 2), wr, padding=1).transpose(1, 2)           # [B, L, cout]
+    y_ref.backward(g)
+    code = lib.PRO_AFFINE + lib.ACT[act]
+    xd, ssd, gd = x.to(DEV), ss.to(DEV), g.to(DEV)
+    y = torch.empty(B, L, cout, device=DEV)
+    lib.conv_forward(lib.conv_args(x=xd, w=w.permute(0, 2, 1).contiguous().to(DEV), y=y, B=B, L_in=L, L_out=L, cin=cin, cout=cout, taps=k, stride=1, pad=1,
+                                   pro=code, pro_stats=ssd))
+    assert rel(y, y_ref) < 2e-5
+    dW = torch.zeros(cout, cin, k, device=DEV)
+    for co0, cp in ((0, 32), (32, 16)):   # the channel blocks the weight-gradient kernels take (generic.py cuts them the same way)
+        kw = dict(g=gd[..., co0:], x=xd, B=B, L_in=L, L_out=L, cin=cin, cout=cp, taps=k, stride=1, pad=1, ldg=cout, ldx=cin, pro_h=code, x_stats=ssd)
+        gy = lib.wgrad_grid_y(cin, cp, k, 1)
+        gx = max(1, min(8, lib.wgrad_max_blocks(slab=None, nslab=0, **kw) // gy))
+        nslab = gx * lib.wgrad_slabs_per_block_of(slab=None, nslab=0, **kw)
+        slab = torch.empty(nslab * cp * cin * k, device=DEV)
+        lib.wgrad(slab=slab, nslab=nslab, **kw)
+        piece = torch.empty(cp, cin, k, device=DEV)
+        lib.wgrad_reduce(slab, nslab, piece, cp, cin, k, 1, False, 0)
+        dW[co0:co0 + cp] = piece
+    assert rel(dW, wr.grad) < 2e-5
+    with pytest.raises(lib.W2SError):   # an unknown prologue code is refused
+        lib.conv_forward(lib.conv_args(x=xd, w=w.permute(0, 2, 1).contiguous().to(DEV), y=y, B=B, L_in=L, L_out=L, cin=cin, cout=cout, taps=k, stride=1, pad=1,
+                                       pro=lib.PRO_AFFINE + 5, pro_stats=ssd))
