@@ -448,6 +448,14 @@ int w2s_norm_fold(int kind, const float* stats, int B, int C, int G, const float
 /* means [B][C][2] = per-(sample, channel) means of ga and ga * xh -> coef [nset][3][C] for w2s_norm_act_bwd_apply, dgamma / dbeta [C] (or NULL) */
 int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, int B, int C, int G, const float* gamma, double L, float* coef,
                       float* dgamma, float* dbeta, void* stream);
+/* the residual join of a ConvBlock1D (blocks.py:68-70) in one pass: y = act2(act(x * scale + shift) + add) -- x = conv3's raw output, (scale, shift)
+ * as for w2s_affine_act, add = downsample(x_in), act2 = the block's activation -- and its backward gs = g * act2'(act(x * scale + shift) + add),
+ * the gradient of both addends.  y / gs may alias add. */
+int w2s_affine_act_join(const float* x, int ldx, const float* scale, const float* shift, int sample_stride, const float* add, int ld_add, float* y,
+                        int ldy, int rows_per_sample, long rows, int C, int act, int act2, float slope, void* stream);
+int w2s_affine_act_join_bwd(const float* g, int ldg, const float* x, int ldx, const float* scale, const float* shift, int sample_stride,
+                            const float* add, int ld_add, float* gs, int ldgs, int rows_per_sample, long rows, int C, int act, int act2, float slope,
+                            void* stream);
 /* backward of w2s_attn_generic_fwd: gqkv [N][D][3*H*hd] (fully written) from gout [N][D][H*hd] */
 int w2s_attn_generic_bwd(const float* qkv, const unsigned char* keypad, const float* gout, float* gqkv, long N, int D, int H, int hd, float p_drop,
                          uint64_t seed, void* stream);

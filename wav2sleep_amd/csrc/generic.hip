@@ -521,3 +521,66 @@ extern "C" int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, 
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The residual join of a ConvBlock1D in one pass: out = act2(act(x * scale + shift) + add)  (blocks.py:68-70: conv3's norm + activation,
+// `+ downsample(x)`, the block's activation) and its backward gs = g * act2'(act(x * scale + shift) + add) -- the gradient of BOTH addends.
+// x = conv3's raw output; its activated form and the sum are never written (three passes forward instead of seven).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int BWD>
+__global__ __launch_bounds__(256) void affine_act_join_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift, int sample_stride,
+                                                              const float* __restrict__ add, int ld_add, float* __restrict__ y, int ldy,
+                                                              int rows_per_sample, long rows, int C, int act, int act2, float slope) {
+  const int c4n = C >> 2;
+  const long total = rows * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    f32x4 v = ld4(x + row * ldx + c);
+    if (scale) {
+      const long s = (row / rows_per_sample) * sample_stride + c;
+      v = v * ld4(scale + s) + ld4(shift + s);
+    }
+    const f32x4 a = ld4(add + row * ld_add + c);
+    f32x4 s = {act_f(v.x, act, slope) + a.x, act_f(v.y, act, slope) + a.y, act_f(v.z, act, slope) + a.z, act_f(v.w, act, slope) + a.w};
+    if (BWD) {
+      const f32x4 gv = ld4(g + row * ldg + c);
+      s = (f32x4){gv.x * act_grad_f(s.x, act2, slope), gv.y * act_grad_f(s.y, act2, slope), gv.z * act_grad_f(s.z, act2, slope),
+                  gv.w * act_grad_f(s.w, act2, slope)};
+    } else {
+      s = (f32x4){act_f(s.x, act2, slope), act_f(s.y, act2, slope), act_f(s.z, act2, slope), act_f(s.w, act2, slope)};
+    }
+    st4(y + row * ldy + c, s);
+  }
+}
+
+static int launch_join(int bwd, const float* g, int ldg, const float* x, int ldx, const float* scale, const float* shift, int sample_stride,
+                       const float* add, int ld_add, float* y, int ldy, int rows_per_sample, long rows, int C, int act, int act2, float slope,
+                       void* stream) {
+  if (!x || !add || !y || (bwd && !g) || rows <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3) || (ld_add & 3) || (ldg & 3) || rows_per_sample <= 0 ||
+      act < 0 || act > 4 || act2 < 0 || act2 > 4 || (scale == nullptr) != (shift == nullptr) || (sample_stride & 3))
+    return W2S_EINVAL;
+  const long total = rows * (C >> 2);
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (bwd)
+    hipLaunchKernelGGL(affine_act_join_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, ldg, x, ldx, scale, shift,
+                       sample_stride, add, ld_add, y, ldy, rows_per_sample, rows, C, act, act2, slope);
+  else
+    hipLaunchKernelGGL(affine_act_join_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, ldg, x, ldx, scale, shift,
+                       sample_stride, add, ld_add, y, ldy, rows_per_sample, rows, C, act, act2, slope);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+extern "C" int w2s_affine_act_join(const float* x, int ldx, const float* scale, const float* shift, int sample_stride, const float* add, int ld_add,
+                                   float* y, int ldy, int rows_per_sample, long rows, int C, int act, int act2, float slope, void* stream) {
+  return launch_join(0, nullptr, 0, x, ldx, scale, shift, sample_stride, add, ld_add, y, ldy, rows_per_sample, rows, C, act, act2, slope, stream);
+}
+
+extern "C" int w2s_affine_act_join_bwd(const float* g, int ldg, const float* x, int ldx, const float* scale, const float* shift, int sample_stride,
+                                       const float* add, int ld_add, float* gs, int ldgs, int rows_per_sample, long rows, int C, int act, int act2,
+                                       float slope, void* stream) {
+  return launch_join(1, g, ldg, x, ldx, scale, shift, sample_stride, add, ld_add, gs, ldgs, rows_per_sample, rows, C, act, act2, slope, stream);
+}

@@ -493,11 +493,30 @@ class GenericForward:
 
     def conv_block(self, block, x, x_needs_grad=True):
         """ConvBlock1D.forward (blocks.py:57-71)."""
-        out = self.conv_layer(block.conv3, self.conv_layer(block.conv2, self.conv_layer(block.conv1, x, x_needs_grad, lazy_out=True), lazy_out=True))
+        out = self.conv_layer(block.conv3, self.conv_layer(block.conv2, self.conv_layer(block.conv1, x, x_needs_grad, lazy_out=True), lazy_out=True),
+                              lazy_out=block.use_residual)
         if block.use_residual:
             r, _ = self._conv(x, block.downsample.weight, None, out.shape[1], stride=2, pad=0, dil=1, x_needs_grad=x_needs_grad)
+            if isinstance(out, _Lazy):
+                return self._join(out, r, block.activation_name)
             out = self._sum(out, r)
         return self._act(out, block.activation_name)
+
+    def _join(self, lz, r, act_name):
+        """act2(act3(y3 * scale + shift) + r) in one pass (w2s_affine_act_join): conv3's activated output and the sum are never written"""
+        B, L, Cc = lz.y.shape
+        rows = B * L
+        act2 = _act_code(act_name)
+        stride = Cc if (lz.scale is not None and lz.scale.shape[0] > 1) else 0
+        out = torch.empty_like(r) if self.grad else r
+        lib.affine_act_join(lz.y, Cc, lz.scale, lz.shift, stride, r, Cc, out, Cc, L, rows, Cc, lz.act, act2)
+
+        def bw(g):
+            gs = torch.empty_like(g)
+            lib.affine_act_join_bwd(g, Cc, lz.y, Cc, lz.scale, lz.shift, stride, r, Cc, gs, Cc, L, rows, Cc, lz.act, act2)
+            return (gs, gs)
+        self._rec(out, (lz, r), bw, share='all')
+        return out
 
     def dilated_block(self, block, x):
         """DilatedConvBlock.forward (blocks.py:115-126) on [B, S, F]."""
