@@ -328,11 +328,12 @@ def run_ema():
 def run_variants():
     """Eval (and one train-mode BatchNorm) forwards of the reference's modules in configurations outside the production family, default
     initialisation under a seed + tests.golden_util.perturb_state; and SleepPPGNet on one 10-h input."""
-    from tests.golden_util import VARIANTS, perturb_state, variant_inputs
+    from tests.golden_util import VARIANTS, VARIANT_SEEDS, perturb_state, variant_index, variant_inputs
     from wav2sleep.models.ppgnet import SleepPPGNet
     out = {}
-    for name, v in VARIANTS.items():
-        torch.manual_seed(4000 + sorted(VARIANTS).index(name))
+    for name in VARIANT_SEEDS:   # the round-2 set (round 6 added entries of its own: make_goldens_r6.py)
+        v = VARIANTS[name]
+        torch.manual_seed(4000 + variant_index(name))
         enc = SignalEncoders(**v['enc'])
         model = Wav2Sleep(enc, MultiModalAttentionEmbedder(**v['mix']), SequenceCNN(**v['seq']), num_classes=v['nc'])
         sd = perturb_state(model.state_dict(), seed=77)

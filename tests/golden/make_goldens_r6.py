@@ -23,7 +23,7 @@ sys.path.insert(0, HERE)
 
 import make_goldens as MG  # noqa: E402,F401  (sets up the stub parent packages and imports the reference model classes)
 from make_goldens import MultiModalAttentionEmbedder, SequenceCNN, SignalEncoders, Wav2Sleep  # noqa: E402
-from tests.golden_util import VARIANTS, grad_sample_index, perturb_state, variant_cfg, variant_inputs, variant_labels  # noqa: E402
+from tests.golden_util import VARIANTS, grad_sample_index, perturb_state, variant_cfg, variant_index, variant_inputs, variant_labels  # noqa: E402
 
 
 def store_grads(out, tag, model, model32):
@@ -42,7 +42,7 @@ def store_grads(out, tag, model, model32):
 
 def variant_run(name, train, dtype):
     v = variant_cfg(name, train)
-    torch.manual_seed(4000 + sorted(VARIANTS).index(name))
+    torch.manual_seed(4000 + variant_index(name))
     model = Wav2Sleep(SignalEncoders(**v['enc']), MultiModalAttentionEmbedder(**v['mix']), SequenceCNN(**v['seq']), num_classes=v['nc'])
     model.load_state_dict(perturb_state(model.state_dict(), seed=77), strict=True)
     model = model.to(dtype).train(train)

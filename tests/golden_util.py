@@ -126,7 +126,7 @@ def variant_inputs(name: str):
     """Seeded inputs of a variant: dict signal -> [B, S * spe] with the listed samples' rows set to -inf."""
     v = VARIANTS[name]
     spe = {'ABD': 256, 'THX': 256, 'ECG': 1024, 'PPG': 1024, 'EOG-L': 4096, 'EOG-R': 4096}
-    g = torch.Generator().manual_seed(900 + sorted(VARIANTS).index(name))
+    g = torch.Generator().manual_seed(900 + variant_index(name))
     x = {s: torch.randn(v['B'], v['S'] * spe[s], generator=g) for s in v['enc']['signal_map']}
     for s, rows in (v.get('missing') or {}).items():
         x[s][rows] = float('-inf')
@@ -137,10 +137,29 @@ def variant_inputs(name: str):
 GRAD_SAMPLE = 2048   # gradient tensors above this size are stored as an evenly strided sample of this many elements (+ their L2 norm)
 
 
+# round-6 additions (seeded on their own so that the round-2 entries keep theirs): per-epoch (chunk-causal) encoders with register tokens and
+# three classes; BatchNorm in train mode with an odd number of epochs and samples, a shared encoder and signal embeddings
+VARIANTS_R6 = {
+    'chunk_regs': dict(enc=dict(signal_map={'ECG': 'ECG', 'ABD': 'ABD'}, feature_dim=32, activation='gelu', norm='instance', causal=True, chunk_causal=True),
+                       mix=dict(feature_dim=32, layers=1, nhead=4, dim_ff=64, register_tokens=2),
+                       seq=dict(feature_dim=32, norm='layer', causal=True, num_layers=1, num_dilations=3, dropout=0.0), nc=3, B=3, S=5, missing={'ABD': [2]}, seed=4300),
+    'batch_shared_odd': dict(enc=dict(signal_map={'ABD': 'RESP', 'THX': 'RESP', 'PPG': 'PPG'}, feature_dim=16, activation='leaky', norm='batch', embed_signals=True),
+                             mix=dict(feature_dim=16, layers=2, nhead=2, dim_ff=32, activation='silu'),
+                             seq=dict(feature_dim=16, norm='batch', activation='relu', num_layers=2, num_dilations=2, dropout=0.0), nc=5, B=3, S=7, missing={'THX': [0]},
+                             seed=4301, train=True),
+}
+VARIANTS.update(VARIANTS_R6)   # (looked up by name everywhere; the seeds of the round-2 entries come from VARIANT_SEEDS below, not from this dict's order)
+VARIANT_SEEDS = {'causality': 0, 'causality_train': 1, 'leaky_auto_rms': 2, 'relu_nonorm': 3, 'silu_group': 4}   # = sorted() index of the round-2 set
+
+
+def variant_index(name: str) -> int:
+    return VARIANT_SEEDS[name] if name in VARIANT_SEEDS else VARIANTS[name]['seed'] - 4000
+
+
 def variant_labels(name: str):
     """Seeded stage labels [B, S] of a variant with ~15 % unscored (-1) epochs."""
     v = VARIANTS[name]
-    g = torch.Generator().manual_seed(1900 + sorted(VARIANTS).index(name))
+    g = torch.Generator().manual_seed(1900 + variant_index(name))
     y = torch.randint(0, v['nc'], (v['B'], v['S']), generator=g)
     y[torch.rand(v['B'], v['S'], generator=g) < 0.15] = -1
     return y

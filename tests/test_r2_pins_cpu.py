@@ -84,9 +84,9 @@ def test_parquet_dataset_matches_reference(name, labels, nc, mlh):
 
 # ---- generic-path variants: the parameter containers match the reference's modules (keys, order, default initialisation under a seed) ----
 def build_variant(name):
-    from tests.golden_util import VARIANTS, perturb_state
+    from tests.golden_util import VARIANTS, perturb_state, variant_index
     v = VARIANTS[name]
-    torch.manual_seed(4000 + sorted(VARIANTS).index(name))
+    torch.manual_seed(4000 + variant_index(name))
     model = W.Wav2Sleep(W.SignalEncoders(**v['enc']), W.MultiModalAttentionEmbedder(**v['mix']), W.SequenceCNN(**v['seq']), num_classes=v['nc'])
     model.load_state_dict(perturb_state(model.state_dict(), seed=77), strict=True)
     return model

@@ -14,14 +14,14 @@ pytestmark = pytest.mark.gpu
 
 import wav2sleep_amd as W  # noqa: E402
 from wav2sleep_amd import lib  # noqa: E402
-from tests.golden_util import VARIANTS, grad_sample_index, load, perturb_state, variant_cfg, variant_inputs, variant_labels  # noqa: E402
+from tests.golden_util import VARIANTS, grad_sample_index, load, perturb_state, variant_cfg, variant_index, variant_inputs, variant_labels  # noqa: E402
 
 DEV = 'cuda'
 
 
 def build(name, train):
     v = variant_cfg(name, train)
-    torch.manual_seed(4000 + sorted(VARIANTS).index(name))
+    torch.manual_seed(4000 + variant_index(name))
     model = W.Wav2Sleep(W.SignalEncoders(**v['enc']), W.MultiModalAttentionEmbedder(**v['mix']), W.SequenceCNN(**v['seq']), num_classes=v['nc'])
     model.load_state_dict(perturb_state(model.state_dict(), seed=77), strict=True)
     return model.to(DEV).train(train)
@@ -50,7 +50,8 @@ def check_grads(model, g, tag, floor=1e-3, k_ref=3.0):
     return worst
 
 
-@pytest.mark.parametrize('name,train', [('causality', False), ('causality', True), ('leaky_auto_rms', False), ('silu_group', False), ('relu_nonorm', False)])
+@pytest.mark.parametrize('name,train', [('causality', False), ('causality', True), ('leaky_auto_rms', False), ('silu_group', False), ('relu_nonorm', False),
+                                        ('chunk_regs', False), ('batch_shared_odd', False), ('batch_shared_odd', True)])
 def test_variant_gradients_match_reference_autograd(name, train):
     g = load('variants_grad')
     tag = f"{name}.{'train' if train else 'eval'}"
