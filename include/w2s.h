@@ -41,6 +41,10 @@ extern "C" {
                               * pro_stats / x_stats hold (scale, shift) per (b, c) instead of (mean, rstd): any per-channel norm + activation of
                               * the generic path (BatchNorm, GroupNorm, instance, none) applied on load, so that its output is never written
                               * (ConvLayer1D.forward, blocks.py:183-184, for the NEXT layer's conv and that conv's weight gradient; round 6) */
+#define W2S_PRO_AFFINE_BWD 12 /* + act: the BACKWARD of that norm + activation on load, two operands as the INBWD modes (x = g, x2 = y):
+                              * z = y * scale + shift, gy = (scale g) act'(z) + z c + d with (scale, shift) in pro_stats / g_stats and (c, d) in
+                              * pro_bstats / g_bstats per (b, c) (w2s_norm_bwd_coef writes them): the gradient of the conv output y is never
+                              * written; its data-gradient conv and weight gradient form it while staging */
 
 /* ---- epilogue (applied to the accumulator tile before the store) ---- */
 #define W2S_EPI_PLAIN 0
@@ -445,9 +449,10 @@ int w2s_rownorm_bwd(const float* g, int ldg, const float* x, int ldx, const floa
  * (scale, shift) operand of W2S_PRO_AFFINE. */
 int w2s_norm_fold(int kind, const float* stats, int B, int C, int G, const float* gamma, const float* beta, float* run_mean, float* run_var,
                   float eps, float momentum, double count, float* scale, float* shift, float* mr, float* ss, void* stream);
-/* means [B][C][2] = per-(sample, channel) means of ga and ga * xh -> coef [nset][3][C] for w2s_norm_act_bwd_apply, dgamma / dbeta [C] (or NULL) */
-int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, int B, int C, int G, const float* gamma, double L, float* coef,
-                      float* dgamma, float* dbeta, void* stream);
+/* means [B][C][2] = per-(sample, channel) means of ga and ga * xh -> coef [nset][3][C] for w2s_norm_act_bwd_apply, dgamma / dbeta [C] (or NULL),
+ * cd (or NULL) [B][C][2] = the (c, d) operand of W2S_PRO_AFFINE_BWD for every sample */
+int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, int B, int C, int G, const float* gamma, const float* beta, double L,
+                      float* coef, float* dgamma, float* dbeta, float* cd, void* stream);
 /* the residual join of a ConvBlock1D (blocks.py:68-70) in one pass: y = act2(act(x * scale + shift) + add) -- x = conv3's raw output, (scale, shift)
  * as for w2s_affine_act, add = downsample(x_in), act2 = the block's activation -- and its backward gs = g * act2'(act(x * scale + shift) + add),
  * the gradient of both addends.  y / gs may alias add. */

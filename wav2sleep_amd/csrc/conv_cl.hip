@@ -51,8 +51,8 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
     if (a.aux && (size_t)a.L_out * (size_t)(a.ld_aux ? a.ld_aux : a.cout) * 4 >= lim) return W2S_EINVAL;
   }
   if (a.pro >= W2S_PRO_IN_GELU && !a.pro_stats) return W2S_EINVAL;
-  if (a.pro < 0 || a.pro > W2S_PRO_AFFINE + 4) return W2S_EINVAL;
-  if ((a.pro == W2S_PRO_INBWD || a.pro == W2S_PRO_INBWD_GP) && (!a.pro_bstats || !a.x2)) return W2S_EINVAL;
+  if (a.pro < 0 || a.pro > W2S_PRO_AFFINE_BWD + 4) return W2S_EINVAL;
+  if ((a.pro == W2S_PRO_INBWD || a.pro == W2S_PRO_INBWD_GP || a.pro >= W2S_PRO_AFFINE_BWD) && (!a.pro_bstats || !a.x2)) return W2S_EINVAL;
   if (a.pro == W2S_PRO_FIRST && (!a.x2 || a.cin != 16 || a.taps != 3 || a.stride != 1 || a.pad != 1 || a.mode != W2S_MODE_CONTIG)) return W2S_EINVAL;
   if ((a.epi == W2S_EPI_AUX_INGELU_ADD && (!a.aux || !a.aux_stats)) || (a.epi == W2S_EPI_GP && !a.aux)) return W2S_EINVAL;
   // epilogue fusions of the transformer layer (`reserved` bits W2S_FUSE_*): only the bias epilogue implements them, and each reads the

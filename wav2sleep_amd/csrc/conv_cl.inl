@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
     f32x4 s01 = ld4(st), s23 = ld4(st + 4);
     pm = (f32x4){s01.x, s01.z, s23.x, s23.z};
     pr = (f32x4){s01.y, s01.w, s23.y, s23.w};
-    if (pro == W2S_PRO_INBWD || pro == W2S_PRO_INBWD_GP) {
+    if (pro == W2S_PRO_INBWD || pro == W2S_PRO_INBWD_GP || pro >= W2S_PRO_AFFINE_BWD) {
       const float* bs = a.pro_bstats + ((size_t)b * cin + myc4 * 4) * 2;
       f32x4 b01 = ld4(bs), b23 = ld4(bs + 4);
       ps1 = (f32x4){b01.x, b01.z, b23.x, b23.z};
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
   const ProCoef kc = pro_coef(pro, pm, pr, ps1, ps2);
   // wave-uniform per-sample bases + 32-bit lane offsets: scalar-base addressing (a sample's tensor is < 4 GB)
   const float* xb = ((PRO == W2S_PRO_FIRST)) ? a.x + (size_t)b * L_in : a.x + (size_t)b * L_in * a.ldx;
-  const float* x2b = (pro == W2S_PRO_INBWD || pro == W2S_PRO_INBWD_GP) ? a.x2 + (size_t)b * L_in * a.ldx : nullptr;
+  const float* x2b = (pro == W2S_PRO_INBWD || pro == W2S_PRO_INBWD_GP || pro >= W2S_PRO_AFFINE_BWD) ? a.x2 + (size_t)b * L_in * a.ldx : nullptr;
   float w1r[4][3];  // W2S_PRO_FIRST: this thread's 4 output channels of block 0's conv1 (a.x2 = its weight [16][3])
   if ((PRO == W2S_PRO_FIRST)) {
 #pragma unroll

@@ -474,8 +474,8 @@ extern "C" int w2s_norm_fold(int kind, const float* stats, int B, int C, int G, 
 // kind 1), mr as written by w2s_norm_fold -> coef [nset][3][C] = (A, B, Cx) of w2s_norm_act_bwd_apply and the affine parameters' gradients
 // dgamma[c] = L sum_b means[b][c][1], dbeta[c] = L sum_b means[b][c][0] (NULL for kind 0).
 __global__ void norm_bwd_coef_kernel(int kind, const float* __restrict__ means, const float* __restrict__ mr, int B, int C, int G,
-                                     const float* __restrict__ gamma, double L, float* __restrict__ coef, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta) {
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, double L, float* __restrict__ coef,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double gm = gamma ? (double)gamma[c] : 1.0;
@@ -485,9 +485,14 @@ __global__ void norm_bwd_coef_kernel(int kind, const float* __restrict__ means, 
   if (dbeta) dbeta[c] = (float)(s1 * L);
   if (kind == 1 || kind == 2) {
     const double rstd = mr[2 * c + 1];
+    const double cb = kind == 1 ? -rstd * gm * s1 / B : 0.0, cx = kind == 1 ? -rstd * gm * s2 / B : 0.0;
     coef[c] = (float)(rstd * gm);
-    coef[C + c] = kind == 1 ? (float)(-rstd * gm * s1 / B) : 0.f;
-    coef[2 * C + c] = kind == 1 ? (float)(-rstd * gm * s2 / B) : 0.f;
+    coef[C + c] = (float)cb;
+    coef[2 * C + c] = (float)cx;
+    if (cd) {   // W2S_PRO_AFFINE_BWD operand: gy = (scale g) act'(z) + z c + d,  c = Cx / gamma, d = B - c beta  (gamma = 0: Cx = 0 as well)
+      const double cc = gm != 0.0 ? cx / gm : 0.0, dd = cb - cc * (beta ? (double)beta[c] : 0.0);
+      for (int b = 0; b < B; ++b) { cd[((size_t)b * C + c) * 2] = (float)cc; cd[((size_t)b * C + c) * 2 + 1] = (float)dd; }
+    }
     return;
   }
   const int cg = C / G, c0 = (c / cg) * cg;
@@ -510,14 +515,19 @@ __global__ void norm_bwd_coef_kernel(int kind, const float* __restrict__ means, 
     cf[c] = (float)(rstd * gm);
     cf[C + c] = (float)(-rstd * m1);
     cf[2 * C + c] = (float)(-rstd * m2);
+    if (cd) {
+      const double cc = gm != 0.0 ? -rstd * m2 / gm : 0.0, dd = -rstd * m1 - cc * (beta ? (double)beta[c] : 0.0);
+      cd[((size_t)b * C + c) * 2] = (float)cc;
+      cd[((size_t)b * C + c) * 2 + 1] = (float)dd;
+    }
   }
 }
 
-extern "C" int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, int B, int C, int G, const float* gamma, double L, float* coef,
-                                 float* dgamma, float* dbeta, void* stream) {
+extern "C" int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, int B, int C, int G, const float* gamma, const float* beta, double L,
+                                 float* coef, float* dgamma, float* dbeta, float* cd, void* stream) {
   if (kind < 0 || kind > 3 || !means || !mr || !coef || B <= 0 || C <= 0 || (kind == 3 && (G <= 0 || C % G))) return W2S_EINVAL;
   hipLaunchKernelGGL(norm_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, means, mr, B, C,
-                     kind == 3 ? G : C, gamma, L, coef, dgamma, dbeta);
+                     kind == 3 ? G : C, gamma, beta, L, coef, dgamma, dbeta, cd);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

@@ -238,7 +238,7 @@ __device__ __forceinline__ ProCoef pro_coef(int pro, f32x4 mean, f32x4 rstd, f32
   ProCoef k{rstd, -(mean * rstd), {0, 0, 0, 0}, {0, 0, 0, 0}};
   if (pro == W2S_PRO_INBWD) { k.b = -(rstd * rstd * s2); k.c = rstd * (rstd * s2 * mean - s1); }
   else if (pro == W2S_PRO_INBWD_GP) { k.c = -(rstd * s2); k.d = -(rstd * s1); }
-  else if (pro >= W2S_PRO_AFFINE) { k.a = mean; k.b = rstd; }   // the pair is (scale, shift) (generic path)
+  else if (pro >= W2S_PRO_AFFINE) { k.a = mean; k.b = rstd; k.c = s1; k.d = s2; }   // (scale, shift) and, for the backward modes, (c, d) (generic path)
   return k;
 }
 __device__ __forceinline__ f32x4 pro_apply_k(int pro, f32x4 v, f32x4 v2, const ProCoef& k) {
@@ -270,6 +270,26 @@ __device__ __forceinline__ f32x4 pro_apply_k(int pro, f32x4 v, f32x4 v2, const P
     case W2S_PRO_AFFINE + 4: {
       const f32x4 n = fma4(v, k.a, k.b);
       return (f32x4){n.x / (1.0f + __expf(-n.x)), n.y / (1.0f + __expf(-n.y)), n.z / (1.0f + __expf(-n.z)), n.w / (1.0f + __expf(-n.w))};
+    }
+    case W2S_PRO_AFFINE_BWD:      // generic path, backward of the same: z = y scale + shift, gy = (scale g) act'(z) + z c + d
+    case W2S_PRO_AFFINE_BWD + 1:
+    case W2S_PRO_AFFINE_BWD + 2:
+    case W2S_PRO_AFFINE_BWD + 3:
+    case W2S_PRO_AFFINE_BWD + 4: {
+      const f32x4 n = fma4(v2, k.a, k.b);
+      f32x4 d;
+      switch (pro - W2S_PRO_AFFINE_BWD) {
+        case 1: d = (f32x4){n.x > 0.f ? 1.f : 0.f, n.y > 0.f ? 1.f : 0.f, n.z > 0.f ? 1.f : 0.f, n.w > 0.f ? 1.f : 0.f}; break;
+        case 2: d = (f32x4){n.x > 0.f ? 1.f : 0.01f, n.y > 0.f ? 1.f : 0.01f, n.z > 0.f ? 1.f : 0.01f, n.w > 0.f ? 1.f : 0.01f}; break;
+        case 3: d = gelu_grad4(n); break;
+        case 4: {
+          const f32x4 sg = {1.0f / (1.0f + __expf(-n.x)), 1.0f / (1.0f + __expf(-n.y)), 1.0f / (1.0f + __expf(-n.z)), 1.0f / (1.0f + __expf(-n.w))};
+          d = sg * (n * (splat4(1.f) - sg) + 1.0f);
+          break;
+        }
+        default: d = splat4(1.f);
+      }
+      return fma4(v * k.a, d, fma4(n, k.c, k.d));
     }
     default:
       return v;

@@ -750,7 +750,9 @@ extern "C" int w2s_wgrad(const w2s_wgrad_args* ap, void* stream) {
   if (a.pro_g >= W2S_PRO_IN_GELU && !a.g_stats) return W2S_EINVAL;
   if (a.pro_g >= W2S_PRO_INBWD && (!a.g_bstats || !a.g2)) return W2S_EINVAL;
   if (a.pro_h >= W2S_PRO_IN_GELU && !a.x_stats) return W2S_EINVAL;
-  if (a.pro_h < 0 || a.pro_h > W2S_PRO_AFFINE + 4 || a.pro_g < 0 || a.pro_g > W2S_PRO_INBWD_GP) return W2S_EINVAL;
+  if (a.pro_h < 0 || a.pro_h > W2S_PRO_AFFINE + 4 || a.pro_g < 0 || a.pro_g > W2S_PRO_AFFINE_BWD + 4 ||
+      (a.pro_g > W2S_PRO_INBWD_GP && a.pro_g < W2S_PRO_AFFINE_BWD))
+    return W2S_EINVAL;   // input side: the forward transforms; gradient side: the backward ones
   if (const int rc = w2s_wgrad_wide_try(a, s, 0); rc != 1) return rc;
   if (a.stride == 1) return dispatch_wgrad<1>(a, s);
   if (a.stride == 2) return dispatch_wgrad<2>(a, s);

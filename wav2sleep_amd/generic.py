@@ -68,6 +68,16 @@ class _Lazy:
         return self.y.shape
 
 
+class _LazyG:
+    """The gradient of a conv output y behind a per-channel norm + activation, NOT materialised: gy = (scale g) act'(y scale + shift) + z c + d.
+    The convolution's data-gradient launch and weight gradient form it on load (W2S_PRO_AFFINE_BWD + act; g = gradient of the activation's
+    output, ss = (scale, shift), cd = (c, d) per (sample, channel))."""
+    __slots__ = ('g', 'y', 'ss', 'cd', 'act')
+
+    def __init__(self, g, y, ss, cd, act):
+        self.g, self.y, self.ss, self.cd, self.act = g, y, ss, cd, act
+
+
 class GenericForward:
     """Stateless walker over the parameter containers of wav2sleep.py (same attribute names as the reference modules).
     grad=True: every launch group is recorded on a tape and nothing is overwritten in place; `backward(out, g)` then returns
@@ -162,7 +172,7 @@ class GenericForward:
         return out
 
     # ------------------------------------------------------------------ weight / data gradients of a convolution
-    def _wgrad(self, g, x, *, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, pro_h=0, x_stats=None):
+    def _wgrad(self, g, x, *, B, L_in, L_out, cin, cout, taps, stride, pad, dil=1, pro_h=0, x_stats=None, lg=None):
         """dW [cout][cin][taps] = sum_{b,t} g[b,t,:] (x) x[b, t*stride + j*dil - pad, :]: w2s_wgrad per (<= 128 input channels) x
         (128 / 64 / 32 / 16 output channels) block -- the shapes its kernels are instantiated for -- then the deterministic slab sum."""
         dev = g.device
@@ -173,6 +183,8 @@ class GenericForward:
                 cp = next(c for c in (128, 64, 32, 16) if c <= cout - co0)
                 kw = dict(g=g if co0 == 0 else g[..., co0:], x=x if ci0 == 0 else x[..., ci0:], B=B, L_in=L_in, L_out=L_out, cin=ck, cout=cp,
                           taps=taps, stride=stride, pad=pad, dil=dil, ldg=cout, ldx=cin, split_precision=True, pro_h=pro_h, x_stats=x_stats)
+                if lg is not None:   # (one output block: _norm_act allows the lazy gradient only then)
+                    kw.update(pro_g=lib.PRO_AFFINE_BWD + lg.act, g2=lg.y, g_stats=lg.ss, g_bstats=lg.cd)
                 gy = lib.wgrad_grid_y(ck, cp, taps, dil)
                 gx = max(1, min(_cdiv(B * L_out, 256), max(1, lib.wgrad_max_blocks(slab=None, nslab=0, **kw) // gy)))
                 nslab = gx * lib.wgrad_slabs_per_block_of(slab=None, nslab=0, **kw)
@@ -185,7 +197,7 @@ class GenericForward:
                 co0 += cp
         return dW
 
-    def _dgrad(self, gy, w, *, B, L_x, L_out, stride, pad, dil, acc=None):
+    def _dgrad(self, gy, w, *, B, L_x, L_out, stride, pad, dil, acc=None, lg=None):
         """gradient of the conv input: gy [B, L_out, cout], w [cout, cin, k] -> gx [B, L_x, cin] (w2s_conv_forward on the transposed weights:
         flipped taps for stride 1, W2S_MODE_UP2 for the k=3 / stride-2 conv, the even rows of gx for the 1x1 / stride-2 residual conv)."""
         cout, cin, k = w.shape
@@ -207,16 +219,17 @@ class GenericForward:
                                                    taps=1, stride=1, pad=0, ldx=cout, ldy=2 * cin, accumulate=q > 0 or acc is not None))
             return gx
         gx = acc if acc is not None else torch.empty(B, L_x, cin, device=dev, dtype=torch.float32)
+        pk = dict(pro=lib.PRO_AFFINE_BWD + lg.act, x2=lg.y, pro_stats=lg.ss, pro_bstats=lg.cd) if lg is not None else {}
         for q, (c0, ck) in enumerate(chunks):
             wq = wb if nchunk == 1 else wb[:, :, c0:c0 + ck].contiguous()
             xq = gy if q == 0 else gy[..., c0:]
             if stride == 1:
                 mode = lib.MODE_DILATED if k == 7 else lib.MODE_CONTIG
                 a = lib.conv_args(x=xq, w=wq, y=gx, B=B, L_in=L_out, L_out=L_x, cin=ck, cout=cin, taps=k, stride=1, pad=(k - 1) * dil - pad, dil=dil,
-                                  flip=1, mode=mode, ldx=cout, accumulate=q > 0 or acc is not None)
+                                  flip=1, mode=mode, ldx=cout, accumulate=q > 0 or acc is not None, **pk)
             elif stride == 2 and k == 3 and dil == 1:
                 a = lib.conv_args(x=xq, w=wq, y=gx, B=B, L_in=L_out, L_out=L_x, cin=ck, cout=cin, taps=3, stride=2, pad=pad, mode=lib.MODE_UP2,
-                                  ldx=cout, accumulate=q > 0 or acc is not None)
+                                  ldx=cout, accumulate=q > 0 or acc is not None, **pk)
             else:
                 raise NotImplementedError(f'data gradient of kernel_size={k}, stride={stride}, dilation={dil}')
             lib.conv_forward(a)
@@ -293,13 +306,16 @@ class GenericForward:
             xs = x   # the (padded) operand of the weight gradient
 
             def bw(gy, acc=None):
+                lg = gy if isinstance(gy, _LazyG) else None   # the norm + activation backward still to be applied (on load, below)
+                if lg is not None:
+                    gy = lg.g
                 if bp is not None:
                     self._pgrad(bp, self._rowsum(gy, B * L_out, cout, cout))
-                dW = self._wgrad(gy, xs, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=k, stride=stride, pad=pad, dil=dil, pro_h=pro, x_stats=ss)
+                dW = self._wgrad(gy, xs, B=B, L_in=L_in, L_out=L_out, cin=cin, cout=cout, taps=k, stride=stride, pad=pad, dil=dil, pro_h=pro, x_stats=ss, lg=lg)
                 self._pgrad(wp, dW[:, :cin_w] if cin_w != cin else dW)
                 if not x_needs_grad or cin_w == 1:
                     return (None,)
-                return (self._dgrad(gy, wp.detach(), B=B, L_x=L_in, L_out=L_out, stride=stride, pad=pad, dil=dil, acc=acc),)
+                return (self._dgrad(gy, wp.detach(), B=B, L_x=L_in, L_out=L_out, stride=stride, pad=pad, dil=dil, acc=acc, lg=lg),)
             self._rec(y, (x_in,), bw, acc_ok=x_needs_grad and cin_w != 1)
         return y, stats
 
@@ -323,7 +339,7 @@ class GenericForward:
         self._rec(out, (x,), bw)
         return out
 
-    def _stat_norm_bwd(self, kind, g, y, mr, gamma, beta, act, B, L, Cc, G):
+    def _stat_norm_bwd(self, kind, g, y, mr, gamma, beta, act, B, L, Cc, G, lazy_ss=None):
         """backward of (statistics-based norm -> affine -> activation) over y [B, L, C]: per-(sample, channel) means of ga and ga * xh
         (two launches), the norm's own averaging + (A, B, Cx) + the affine parameters' gradients (w2s_norm_bwd_coef), gy = A ga + B + Cx xh.
         Returns gy, dgamma, dbeta (None without affine parameters)."""
@@ -338,12 +354,15 @@ class GenericForward:
         coef = torch.empty(B if per_sample else 1, 3, Cc, device=dev, dtype=torch.float32)
         dgam = torch.empty(Cc, device=dev, dtype=torch.float32) if gamma is not None else None
         dbet = torch.empty(Cc, device=dev, dtype=torch.float32) if gamma is not None else None
-        lib.norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, float(L), coef, dgam, dbet)
+        cd = torch.empty(B, Cc, 2, device=dev, dtype=torch.float32) if lazy_ss is not None else None
+        lib.norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, beta, float(L), coef, dgam, dbet, cd)
+        if lazy_ss is not None:   # the convolution's data / weight gradient launches apply it on load: gy is never written
+            return _LazyG(g, y, lazy_ss, cd, act), dgam, dbet
         gy = torch.empty_like(y)
         lib.norm_act_bwd_apply(g, Cc, y, Cc, mr, 2 * Cc if per_sample else 0, gamma, beta, coef, 3 * Cc if per_sample else 0, gy, Cc, L, B * L, Cc, act, 0.01)
         return gy, dgam, dbet
 
-    def _norm_act(self, layer, y, stats, act_name, lazy=False):
+    def _norm_act(self, layer, y, stats, act_name, lazy=False, lazy_g=False):
         """norm -> activation of one ConvLayer1D output y [B, L, C] (blocks.py:183-185); in place unless a gradient is wanted.
         lazy (the consumer is a convolution over <= 128 channels): per-channel norms return a _Lazy instead of writing the result."""
         B, L, Cc = y.shape
@@ -354,6 +373,8 @@ class GenericForward:
         kind = layer.norm_name
         dev = y.device
         lazy = lazy and kind in (None, 'instance', 'batch', 'group')
+        # lazy_g (the producing conv has one <= 128-channel output block and no bias): the BACKWARD of norm + activation is applied on load too
+        lazy_g = lazy_g and self.grad and kind in ('instance', 'batch', 'group') and len(_chunks(Cc)) == 1
         out = None if lazy else (torch.empty_like(y) if self.grad else y)
         bw = None
         if kind is None or kind == 'weight':
@@ -395,7 +416,7 @@ class GenericForward:
             scale = torch.empty(nset, Cc, device=dev, dtype=torch.float32)
             shift = torch.empty(nset, Cc, device=dev, dtype=torch.float32)
             mr = torch.empty(nset, Cc, 2, device=dev, dtype=torch.float32)
-            ss = torch.empty(B, Cc, 2, device=dev, dtype=torch.float32) if lazy else None
+            ss = torch.empty(B, Cc, 2, device=dev, dtype=torch.float32) if (lazy or lazy_g) else None
             lib.norm_fold(code, stats, B, Cc, G, gam, bet, rm, rv, eps, mom, float(B * L), scale, shift, mr, ss)
             if lazy:
                 out = _Lazy(y, ss, scale, shift, act)
@@ -403,7 +424,7 @@ class GenericForward:
                 lib.affine_act(y, Cc, scale, shift, Cc if nset > 1 else 0, out, Cc, L, rows, Cc, act, 0.01)
 
             def bw(g):
-                gy, dgam, dbet = self._stat_norm_bwd(code, g, y, mr, gam, bet, act, B, L, Cc, G)
+                gy, dgam, dbet = self._stat_norm_bwd(code, g, y, mr, gam, bet, act, B, L, Cc, G, lazy_ss=ss if lazy_g else None)
                 if pnorm is not None:
                     self._pgrad(pnorm.weight, dgam)
                     self._pgrad(pnorm.bias, dbet)
@@ -488,7 +509,7 @@ class GenericForward:
             raise NotImplementedError('a convolution bias in front of a statistics-based norm')
         y, stats = self._conv(x, conv.weight, conv.bias, L_out, stride=stride, pad=pad, dil=dil, want_stats=want, eps=eps, x_needs_grad=x_needs_grad)
         drop = self.training and layer.dropout_p > 0.0
-        out = self._norm_act(layer, y, stats, layer.activation_name, lazy=lazy_out and not drop)
+        out = self._norm_act(layer, y, stats, layer.activation_name, lazy=lazy_out and not drop, lazy_g=conv.bias is None)
         return self._dropout_(out, layer.dropout_p) if drop else out
 
     def conv_block(self, block, x, x_needs_grad=True):

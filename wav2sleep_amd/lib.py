@@ -18,6 +18,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 # enums (include/w2s.h)
 PRO_NONE, PRO_SANITIZE, PRO_GELU, PRO_IN_GELU, PRO_INBWD, PRO_INBWD_GP, PRO_FIRST = range(7)
 PRO_AFFINE = 7   # + activation code (ACT): act(x * scale + shift) on load, statistics operand = (scale, shift) per (b, c)
+PRO_AFFINE_BWD = 12   # + activation code: its backward on load (x = g, x2 = y; statistics (scale, shift), backward statistics (c, d))
 EPI_PLAIN, EPI_STATS, EPI_AUX_INGELU_ADD, EPI_BIAS, EPI_GP = range(5)
 MODE_CONTIG, MODE_DILATED, MODE_UP2 = range(3)
 ELT_GELU, ELT_GELU_BWD, ELT_ADD, ELT_ADD_DROP, ELT_DROP, ELT_GELU_DROP, ELT_GELU_DROP_BWD = range(7)
@@ -732,9 +733,9 @@ def norm_fold(kind, stats, B, Cc, G, gamma, beta, run_mean, run_var, eps, moment
                               C.c_double(count), _f(scale), _f(shift), _f(mr), _f(ss), _stream()), 'w2s_norm_fold')
 
 
-def norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, L, coef, dgamma, dbeta):
-    _chk(load().w2s_norm_bwd_coef(kind, _f(means), _f(mr), B, Cc, G, _f(gamma), C.c_double(L), _f(coef), _f(dgamma), _f(dbeta), _stream()),
-         'w2s_norm_bwd_coef')
+def norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, beta, L, coef, dgamma, dbeta, cd=None):
+    _chk(load().w2s_norm_bwd_coef(kind, _f(means), _f(mr), B, Cc, G, _f(gamma), _f(beta), C.c_double(L), _f(coef), _f(dgamma), _f(dbeta), _f(cd),
+                                  _stream()), 'w2s_norm_bwd_coef')
 
 
 def rownorm_bwd_blocks(rows) -> int:
