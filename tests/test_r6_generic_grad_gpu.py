@@ -364,3 +364,44 @@ def test_affine_activation_on_load_prologue_of_conv_and_weight_gradient(act):
     with pytest.raises(lib.W2SError):   # an unknown prologue code is refused
         lib.conv_forward(lib.conv_args(x=xd, w=w.permute(0, 2, 1).contiguous().to(DEV), y=y, B=B, L_in=L, L_out=L, cin=cin, cout=cout, taps=k, stride=1, pad=1,
                                        pro=lib.PRO_AFFINE + 5, pro_stats=ssd))
+
+
+@pytest.mark.parametrize('act', ['linear', 'relu', 'leaky', 'gelu', 'silu'])
+def test_affine_activation_backward_on_load_prologue(act):
+    """W2S_PRO_AFFINE_BWD + act: gy = (scale g) act'(y scale + shift) + z c + d formed while staging, in the data-gradient conv (stride 1 flipped
+    taps and the stride-2 W2S_MODE_UP2 form) and on the gradient side of the weight gradient -- against the same launches on the materialised gy."""
+    torch.manual_seed(9)
+    B, L, Cc, cin, k = 2, 640, 32, 16, 3
+    g, y = torch.randn(B, L, Cc), torch.randn(B, L, Cc)
+    ss = torch.stack((1 + 0.3 * torch.randn(B, Cc), 0.4 * torch.randn(B, Cc)), dim=2).contiguous()
+    cd = torch.stack((0.2 * torch.randn(B, Cc), 0.1 * torch.randn(B, Cc)), dim=2).contiguous()
+    z = (y * ss[:, None, :, 0] + ss[:, None, :, 1]).requires_grad_(True)
+    ACTS[act](z).backward(torch.ones_like(z))                       # z.grad = act'(z)
+    gy = (ss[:, None, :, 0] * g) * z.grad + z.detach() * cd[:, None, :, 0] + cd[:, None, :, 1]
+    code = lib.PRO_AFFINE_BWD + lib.ACT[act]
+    gd, yd, ssd, cdd, gyd = g.to(DEV), y.to(DEV), ss.to(DEV), cd.to(DEV), gy.contiguous().to(DEV)
+    wb = (torch.randn(cin, k, Cc) / (Cc * k) ** 0.5).to(DEV)      # [cin][k][cout]: the transposed weights of a cin -> Cc conv
+    for stride, mode, Lx in ((1, lib.MODE_CONTIG, L), (2, lib.MODE_UP2, 2 * L)):
+        outs = []
+        for lazy in (False, True):
+            gx = torch.empty(B, Lx, cin, device=DEV)
+            kw = dict(pro=code, x2=yd, pro_stats=ssd, pro_bstats=cdd) if lazy else {}
+            lib.conv_forward(lib.conv_args(x=gd if lazy else gyd, w=wb, y=gx, B=B, L_in=L, L_out=Lx, cin=Cc, cout=cin, taps=k, stride=stride, pad=1,
+                                           flip=1 if stride == 1 else 0, mode=mode, **kw))
+            outs.append(gx)
+        assert rel(outs[1], outs[0].cpu()) < 1e-5, (stride, rel(outs[1], outs[0].cpu()))
+    x = torch.randn(B, L, cin, device=DEV)
+    dws = []
+    for lazy in (False, True):
+        kw = dict(g=gd if lazy else gyd, x=x, B=B, L_in=L, L_out=L, cin=cin, cout=Cc, taps=k, stride=1, pad=1)
+        if lazy:
+            kw.update(pro_g=code, g2=yd, g_stats=ssd, g_bstats=cdd)
+        gyb = lib.wgrad_grid_y(cin, Cc, k, 1)
+        gxb = max(1, min(8, lib.wgrad_max_blocks(slab=None, nslab=0, **kw) // gyb))
+        nslab = gxb * lib.wgrad_slabs_per_block_of(slab=None, nslab=0, **kw)
+        slab = torch.empty(nslab * Cc * cin * k, device=DEV)
+        lib.wgrad(slab=slab, nslab=nslab, **kw)
+        dW = torch.empty(Cc, cin, k, device=DEV)
+        lib.wgrad_reduce(slab, nslab, dW, Cc, cin, k, 1, False, 0)
+        dws.append(dW)
+    assert rel(dws[1], dws[0].cpu()) < 1e-5
