@@ -67,9 +67,14 @@ def test_variant_gradients_match_reference_autograd(name, train):
     loss.backward()
     worst = check_grads(model, g, tag)
     print(tag, 'worst gradient error / scale', worst)
-    # a second backward through the same node is refused (the tape is consumed), and no_grad keeps the old inference behaviour
+    # no_grad keeps the old inference behaviour; a second backward through the same node is refused (the tape is consumed)
     with torch.no_grad():
         assert not model(x).requires_grad
+    if name == 'relu_nonorm':
+        lg2 = model(x)
+        lg2.sum().backward(retain_graph=True)
+        with pytest.raises(RuntimeError, match='ONE backward per forward'):
+            lg2.sum().backward()
 
 
 def test_sleep_ppgnet_train_mode_gradients_match_reference_autograd():

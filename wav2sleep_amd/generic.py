@@ -780,6 +780,8 @@ class _GenericFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.gf is None:
+            raise RuntimeError('the generic path keeps ONE backward per forward (its tape is consumed): run the forward again')
         with torch.cuda.device(ctx.device):
             pg = ctx.gf.backward(ctx.out, g)
         ctx.gf = ctx.out = None
