@@ -461,6 +461,16 @@ int w2s_affine_act_join(const float* x, int ldx, const float* scale, const float
 int w2s_affine_act_join_bwd(const float* g, int ldg, const float* x, int ldx, const float* scale, const float* shift, int sample_stride,
                             const float* add, int ld_add, float* gs, int ldgs, int rows_per_sample, long rows, int C, int act, int act2, float slope,
                             void* stream);
+/* convolutions of the ONE-channel input (block 0's conv1 and 1x1 / stride-2 residual conv, blocks.py:44-55 with input_dim = 1) on the vector ALU:
+ * y[b,t,o] = bias[o] + sum_j w[o][j] x[b, t stride + j - pad], x [B][L_in], w [C][K] (K <= 3), y [B][L_out][C]; part (or NULL)
+ * [B][ceil(L_out / 1024)][2][C] = per-tile sums of y and y^2 (the statistics partials of the fused conv epilogue, for w2s_stats_finalize) */
+int w2s_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* part, int B, int L_in, int L_out, int C, int K, int stride,
+                  int pad, void* stream);
+/* its weight gradient: part [w2s_conv1_wgrad_parts(B, L_out)][C][K] per-(sample, tile) sums of gy[b,t,o] x[b, t stride + j - pad] (w2s_colsum
+ * finishes them); y2 != NULL: gy is formed on the fly as W2S_PRO_AFFINE_BWD + act does (g, y2, ss = (scale, shift), cd = (c, d) per (b, c)) */
+int w2s_conv1_wgrad_parts(int B, int L_out);
+int w2s_conv1_wgrad(const float* g, const float* y2, const float* ss, const float* cd, const float* x, float* part, int B, int L_in, int L_out, int C,
+                    int K, int stride, int pad, int act, void* stream);
 /* backward of w2s_attn_generic_fwd: gqkv [N][D][3*H*hd] (fully written) from gout [N][D][H*hd] */
 int w2s_attn_generic_bwd(const float* qkv, const unsigned char* keypad, const float* gout, float* gqkv, long N, int D, int H, int hd, float p_drop,
                          uint64_t seed, void* stream);

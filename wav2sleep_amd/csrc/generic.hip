@@ -594,3 +594,115 @@ extern "C" int w2s_affine_act_join_bwd(const float* g, int ldg, const float* x, 
                                        float slope, void* stream) {
   return launch_join(1, g, ldg, x, ldx, scale, shift, sample_stride, add, ld_add, gs, ldgs, rows_per_sample, rows, C, act, act2, slope, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Convolutions of the ONE-channel input (block 0's conv1 and its 1x1 / stride-2 residual conv; blocks.py:44-55 with input_dim = 1) on the
+// vector ALU: 3 (or 1) multiply-adds per output element, the signal read once from L1 / L2 instead of as a 16-channel zero-padded copy
+// (1.26 GB per pass at batch 16 x 10 h).  Forward with the per-(sample, tile) statistics partials of the fused conv epilogue (tile = 1024
+// positions); weight gradient with the norm + activation backward formed on the fly (the W2S_PRO_AFFINE_BWD formula) when y is given.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define W2S_C1_TILE 1024
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ y, float* __restrict__ part, int L_in, int L_out, int C, int K, int stride,
+                                                        int pad) {
+  __shared__ float sm[2048];
+  const int b = blockIdx.y, tl = blockIdx.x, nt = gridDim.x, tid = threadIdx.x;
+  const int c4n = C >> 2, rpb = 256 / c4n, q = tid % c4n, rr = tid / c4n, c = q * 4;
+  f32x4 a1 = splat4(0.f), a2 = splat4(0.f);
+  if (rr < rpb) {
+    f32x4 wk[3];
+    for (int j = 0; j < 3; ++j)
+      wk[j] = j < K ? (f32x4){w[(c + 0) * K + j], w[(c + 1) * K + j], w[(c + 2) * K + j], w[(c + 3) * K + j]} : splat4(0.f);
+    const f32x4 bv = bias ? ld4(bias + c) : splat4(0.f);
+    const float* xb = x + (size_t)b * L_in;
+    const int t1 = min(L_out, (tl + 1) * W2S_C1_TILE);
+    for (int t = tl * W2S_C1_TILE + rr; t < t1; t += rpb) {
+      f32x4 v = bv;
+      for (int j = 0; j < K; ++j) {
+        const int gi = t * stride + j - pad;
+        const float xv = (gi >= 0 && gi < L_in) ? xb[gi] : 0.f;
+        v += wk[j] * xv;
+      }
+      st4(y + ((size_t)b * L_out + t) * C + c, v);
+      a1 += v;
+      a2 += v * v;
+    }
+    st4(sm + (rr * 2 + 0) * C + c, a1);
+    st4(sm + (rr * 2 + 1) * C + c, a2);
+  }
+  if (!part) return;
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) {
+    float v = 0.f;
+    for (int r = 0; r < rpb; ++r) v += sm[r * 2 * C + i];
+    part[((size_t)b * nt + tl) * 2 * C + i] = v;
+  }
+}
+
+extern "C" int w2s_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* part, int B, int L_in, int L_out, int C, int K,
+                             int stride, int pad, void* stream) {
+  if (!x || !w || !y || B <= 0 || L_in <= 0 || L_out <= 0 || C < 4 || C > 256 || (C & 3) || K < 1 || K > 3 || stride < 1 || pad < 0) return W2S_EINVAL;
+  const int nt = (L_out + W2S_C1_TILE - 1) / W2S_C1_TILE;
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(nt, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, bias, y, part, L_in, L_out, C, K,
+                     stride, pad);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}
+
+// dW[o][j] = sum_{b,t} gy[b,t,o] x[b, t stride + j - pad]: part [B * ntiles][C][K] per-(sample, tile) sums (w2s_colsum finishes them).
+// y2 != NULL: gy = (scale g) act'(z) + z c + d, z = y2 scale + shift, with ss / cd [B][C][2] = (scale, shift) / (c, d).
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ y2, const float* __restrict__ ss,
+                                                          const float* __restrict__ cd, const float* __restrict__ x, float* __restrict__ part, int L_in,
+                                                          int L_out, int C, int K, int stride, int pad, int act, float slope) {
+  __shared__ float sm[3072];   // [rows in flight][K][C]
+  const int b = blockIdx.y, tl = blockIdx.x, nt = gridDim.x, tid = threadIdx.x;
+  const int c4n = C >> 2, rpb = 256 / c4n, q = tid % c4n, rr = tid / c4n, c = q * 4;
+  f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
+  if (rr < rpb) {
+    f32x4 sc = splat4(1.f), sh = splat4(0.f), cc = splat4(0.f), dd = splat4(0.f);
+    if (y2) {
+      const f32x4 s01 = ld4(ss + ((size_t)b * C + c) * 2), s23 = ld4(ss + ((size_t)b * C + c) * 2 + 4);
+      const f32x4 c01 = ld4(cd + ((size_t)b * C + c) * 2), c23 = ld4(cd + ((size_t)b * C + c) * 2 + 4);
+      sc = (f32x4){s01.x, s01.z, s23.x, s23.z}; sh = (f32x4){s01.y, s01.w, s23.y, s23.w};
+      cc = (f32x4){c01.x, c01.z, c23.x, c23.z}; dd = (f32x4){c01.y, c01.w, c23.y, c23.w};
+    }
+    const float* xb = x + (size_t)b * L_in;
+    const int t1 = min(L_out, (tl + 1) * W2S_C1_TILE);
+    for (int t = tl * W2S_C1_TILE + rr; t < t1; t += rpb) {
+      const size_t o = ((size_t)b * L_out + t) * C + c;
+      f32x4 gv = ld4(g + o);
+      if (y2) {
+        const f32x4 z = ld4(y2 + o) * sc + sh;
+        gv = (f32x4){sc.x * gv.x * act_grad_f(z.x, act, slope), sc.y * gv.y * act_grad_f(z.y, act, slope), sc.z * gv.z * act_grad_f(z.z, act, slope),
+                     sc.w * gv.w * act_grad_f(z.w, act, slope)} + z * cc + dd;
+      }
+      for (int j = 0; j < K; ++j) {
+        const int gi = t * stride + j - pad;
+        const float xv = (gi >= 0 && gi < L_in) ? xb[gi] : 0.f;
+        acc[j] += gv * xv;
+      }
+    }
+    for (int j = 0; j < K; ++j) st4(sm + (rr * K + j) * C + c, acc[j]);
+  }
+  __syncthreads();
+  for (int i = tid; i < K * C; i += 256) {   // i = j * C + channel
+    float v = 0.f;
+    for (int r = 0; r < rpb; ++r) v += sm[r * K * C + i];
+    const int j = i / C, ch = i % C;
+    part[((size_t)b * nt + tl) * C * K + ch * K + j] = v;
+  }
+}
+
+extern "C" int w2s_conv1_wgrad_parts(int B, int L_out) { return B * ((L_out + W2S_C1_TILE - 1) / W2S_C1_TILE); }
+
+extern "C" int w2s_conv1_wgrad(const float* g, const float* y2, const float* ss, const float* cd, const float* x, float* part, int B, int L_in, int L_out,
+                               int C, int K, int stride, int pad, int act, void* stream) {
+  if (!g || !x || !part || B <= 0 || L_in <= 0 || L_out <= 0 || C < 4 || C > 256 || (C & 3) || K < 1 || K > 3 || stride < 1 || pad < 0 || act < 0 ||
+      act > 4 || (y2 && (!ss || !cd)))
+    return W2S_EINVAL;
+  const int nt = (L_out + W2S_C1_TILE - 1) / W2S_C1_TILE;
+  hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(nt, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, y2, ss, cd, x, part, L_in, L_out, C, K,
+                     stride, pad, act, 0.01f);
+  W2S_CHECK_LAUNCH();
+  return W2S_OK;
+}

@@ -263,6 +263,8 @@ class GenericForward:
         if cout % 16:
             raise NotImplementedError(f'{cout} output channels: the generic kernels produce multiples of 16')
         dev = x.device
+        if cin == 1 and k <= 3 and dil == 1 and cout <= 256:
+            return self._conv1(x, wp, bp, L_out, stride=stride, pad=pad, want_stats=want_stats, eps=eps)
         if cin == 1:   # zero-pad the one-channel input to the narrowest tile the matrix path takes (once per input: conv1 and the residual conv share it)
             if self._x16 is None or self._x16[0] is not x:
                 x16 = torch.zeros(B, L_in, 16, device=dev, dtype=torch.float32)
@@ -317,6 +319,37 @@ class GenericForward:
                     return (None,)
                 return (self._dgrad(gy, wp.detach(), B=B, L_x=L_in, L_out=L_out, stride=stride, pad=pad, dil=dil, acc=acc, lg=lg),)
             self._rec(y, (x_in,), bw, acc_ok=x_needs_grad and cin_w != 1)
+        return y, stats
+
+    def _conv1(self, x, wp, bp, L_out, *, stride, pad, want_stats, eps):
+        """Convolution of the one-channel input [B, L_in, 1] (block 0's conv1 and residual conv) on the vector ALU: csrc/generic.hip conv1_*."""
+        B, L_in, _ = x.shape
+        cout, _, k = wp.shape
+        dev = x.device
+        x1 = x.reshape(B, L_in)
+        y = torch.empty(B, L_out, cout, device=dev, dtype=torch.float32)
+        nt = _cdiv(L_out, lib.C1_TILE)
+        part = torch.empty(B, nt, 2, cout, device=dev, dtype=torch.float32) if want_stats is not None else None
+        lib.conv1_fwd(x1, wp.detach().reshape(cout, k), bp.detach() if bp is not None else None, y, part, B, L_in, L_out, cout, k, stride, pad)
+        stats = None
+        if want_stats is not None:
+            stats = torch.empty(B, cout, 2, device=dev, dtype=torch.float32)
+            lib.stats_finalize(part, B, nt, cout, L_out, eps, want_stats, stats)
+
+        def bw(gy, acc=None):
+            lg = gy if isinstance(gy, _LazyG) else None
+            g = lg.g if lg is not None else gy
+            if bp is not None:
+                self._pgrad(bp, self._rowsum(g, B * L_out, cout, cout))   # (a conv bias means no norm behind it: the gradient is materialised)
+            nparts = lib.conv1_wgrad_parts(B, L_out)
+            wpart = torch.empty(nparts, cout * k, device=dev, dtype=torch.float32)
+            lib.conv1_wgrad(g, lg.y if lg is not None else None, lg.ss if lg is not None else None, lg.cd if lg is not None else None, x1, wpart,
+                            B, L_in, L_out, cout, k, stride, pad, lg.act if lg is not None else 0)
+            dW = torch.empty(cout * k, device=dev, dtype=torch.float32)
+            lib.colsum(wpart, nparts, cout * k, dW)
+            self._pgrad(wp, dW)
+            return (None,)
+        self._rec(y, (x,), bw)
         return y, stats
 
     def _act(self, x, name: str, slope: float = 0.01):

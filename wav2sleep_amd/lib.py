@@ -58,7 +58,7 @@ EXPORTS = ['w2s_conv_tile', 'w2s_conv_cfg', 'w2s_linear_pf_takes', 'w2s_seq_conv
            'w2s_conv_fwd_fused', 'w2s_conv_fwd_fused_tile', 'w2s_bwd_fused', 'w2s_bwd_wide', 'w2s_bwd_wide_tile', 'w2s_bwd_wide_groups', 'w2s_bwd_fused_h', 'w2s_gp_stats_h', 'w2s_enc_first_bwd_h', 'w2s_bwd_fused_w1', 'w2s_bwd_fused_wd', 'w2s_enc_first_wgrad', 'w2s_enc_first_dwd', 'w2s_enc_first_stats', 'w2s_bwd_fused_tile', 'w2s_bwd_fused_folds_residual', 'w2s_stats_finalize', 'w2s_enc_first_fwd', 'w2s_enc_first_join', 'w2s_enc_first_bwd', 'w2s_gp_stats',
            'w2s_layernorm_fwd', 'w2s_layernorm_bwd', 'w2s_bias_grad', 'w2s_colsum', 'w2s_colsum_batch', 'w2s_gelu_bwd_rows', 'w2s_fill_rows', 'w2s_add_rows', 'w2s_causal_normalize_host', 'w2s_eltwise',
            'w2s_attn_fwd', 'w2s_attn_bwd', 'w2s_head_fwd', 'w2s_ce_fwd_bwd', 'w2s_ce_count', 'w2s_ce_wave', 'w2s_ce_final', 'w2s_head_bwd', 'w2s_sumsq_partial',
-           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_token_masks', 'w2s_cls_scatter', 'w2s_copy_rows', 'w2s_zero', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_norm_act_bwd_part', 'w2s_norm_act_bwd_apply', 'w2s_rownorm_bwd_blocks', 'w2s_rownorm_bwd', 'w2s_attn_generic_bwd', 'w2s_norm_fold', 'w2s_norm_bwd_coef', 'w2s_affine_act_join', 'w2s_affine_act_join_bwd', 'w2s_version', 'w2s_abi_version']
+           'w2s_clip_coef', 'w2s_adamw', 'w2s_ema_update', 'w2s_swap', 'w2s_zscore', 'w2s_augment', 'w2s_map_labels', 'w2s_token_masks', 'w2s_cls_scatter', 'w2s_copy_rows', 'w2s_zero', 'w2s_affine_act', 'w2s_rownorm_fwd', 'w2s_attn_generic_fwd', 'w2s_norm_act_bwd_part', 'w2s_norm_act_bwd_apply', 'w2s_rownorm_bwd_blocks', 'w2s_rownorm_bwd', 'w2s_attn_generic_bwd', 'w2s_norm_fold', 'w2s_norm_bwd_coef', 'w2s_affine_act_join', 'w2s_affine_act_join_bwd', 'w2s_conv1_fwd', 'w2s_conv1_wgrad_parts', 'w2s_conv1_wgrad', 'w2s_version', 'w2s_abi_version']
 
 ABI_VERSION = 8   # include/w2s.h W2S_ABI_VERSION
 _lib = None
@@ -698,6 +698,21 @@ def affine_act_join(x, ldx, scale, shift, sample_stride, add, ld_add, y, ldy, ro
 def affine_act_join_bwd(g, ldg, x, ldx, scale, shift, sample_stride, add, ld_add, gs, ldgs, rows_per_sample, rows, Cc, act, act2, slope=0.01):
     _chk(load().w2s_affine_act_join_bwd(_f(g), ldg, _f(x), ldx, _f(scale), _f(shift), sample_stride, _f(add), ld_add, _f(gs), ldgs, rows_per_sample,
                                         C.c_long(rows), Cc, act, act2, C.c_float(slope), _stream()), 'w2s_affine_act_join_bwd')
+
+
+C1_TILE = 1024   # positions per statistics / weight-gradient partial of the one-channel convolutions (csrc/generic.hip W2S_C1_TILE)
+
+
+def conv1_fwd(x, w, bias, y, part, B, L_in, L_out, Cc, K, stride, pad):
+    _chk(load().w2s_conv1_fwd(_f(x), _f(w), _f(bias), _f(y), _f(part), B, L_in, L_out, Cc, K, stride, pad, _stream()), 'w2s_conv1_fwd')
+
+
+def conv1_wgrad_parts(B, L_out) -> int:
+    return load().w2s_conv1_wgrad_parts(B, L_out)
+
+
+def conv1_wgrad(g, y2, ss, cd, x, part, B, L_in, L_out, Cc, K, stride, pad, act=0):
+    _chk(load().w2s_conv1_wgrad(_f(g), _f(y2), _f(ss), _f(cd), _f(x), _f(part), B, L_in, L_out, Cc, K, stride, pad, act, _stream()), 'w2s_conv1_wgrad')
 
 
 def rownorm_fwd(x, ldx, gamma, beta, y, ldy, rows, Cc, eps, rms=False, act=0, slope=0.01):
