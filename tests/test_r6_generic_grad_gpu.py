@@ -410,3 +410,30 @@ def test_affine_activation_backward_on_load_prologue(act):
         lib.wgrad_reduce(slab, nslab, dW, Cc, cin, k, 1, False, 0)
         dws.append(dW)
     assert rel(dws[1], dws[0].cpu()) < 1e-5
+
+
+@pytest.mark.parametrize('k,stride,pad,bias', [(3, 1, 1, False), (3, 1, 2, True), (1, 2, 0, False)])
+def test_one_channel_convolution_kernels_against_torch(k, stride, pad, bias):
+    """w2s_conv1_fwd / w2s_conv1_wgrad (block 0's conv1, causal padding, and the 1x1 / stride-2 residual conv of a one-channel input): output,
+    statistics partials and weight gradient against torch CPU."""
+    torch.manual_seed(10)
+    B, L, Cc = 3, 2500, 16
+    x = torch.randn(B, L)
+    w = torch.randn(Cc, 1, k).requires_grad_(True)
+    bv = torch.randn(Cc) if bias else None
+    full = F.conv1d(x[:, None, :], w, bv, stride=stride, padding=pad)
+    L_out = full.shape[2] - (max(pad - (stride - 1), 0) if pad == 2 else 0)    # (causal layers trim the right side: blocks.py:178-182)
+    ref = full[:, :, :L_out].transpose(1, 2)
+    g = torch.randn(B, L_out, Cc)
+    ref.backward(g)
+    xd, gd = x.to(DEV), g.to(DEV)
+    y = torch.empty(B, L_out, Cc, device=DEV)
+    nt = -(-L_out // lib.C1_TILE)
+    part = torch.empty(B, nt, 2, Cc, device=DEV)
+    lib.conv1_fwd(xd, w.detach().reshape(Cc, k).to(DEV), bv.to(DEV) if bias else None, y, part, B, L, L_out, Cc, k, stride, pad)
+    assert rel(y, ref) < 1e-6
+    assert rel(part[:, :, 0].sum(1), ref.detach().sum(1)) < 1e-5 and rel(part[:, :, 1].sum(1), (ref.detach() ** 2).sum(1)) < 1e-5
+    nparts = lib.conv1_wgrad_parts(B, L_out)
+    wpart = torch.empty(nparts, Cc * k, device=DEV)
+    lib.conv1_wgrad(gd, None, None, None, xd, wpart, B, L, L_out, Cc, k, stride, pad)
+    assert rel(wpart.sum(0).view(Cc, 1, k), w.grad) < 1e-5
