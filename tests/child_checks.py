@@ -301,8 +301,8 @@ def argmax_sweep():
     cfg = O.ModelConfig(signal_map=SM4, num_classes=4)
     S, NSEED = 960, 16
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)
-    workers = max(1, min(4, cores // 8))
-    threads = max(1, min(16, cores // workers))
+    workers = max(1, min(16, cores // 8))   # (inference forwards of one recording: ~3 GB each; many narrow workers scale better than a few wide ones)
+    threads = max(1, min(8, cores // workers))
     pool = cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn'))
     # ---- CPU only so far: every seed's default initialisation and recording; their oracle forwards start now (this spawns all the workers)
     models, xs, futs = [], [], {}
