@@ -52,6 +52,9 @@ extern "C" {
 #define W2S_EPI_AUX_INGELU_ADD 2 /* v += GELU(IN(aux))    blocks.py:68-69 residual join, stored pre-activation */
 #define W2S_EPI_BIAS 3      /* v += bias[c]; optional y2 = GELU(v) */
 #define W2S_EPI_GP 4        /* v = (v [+ add_even[t/2] if t even]) * GELU'(n(aux)); partial sums of v and v*n */
+#define W2S_EPI_AFFINE_PART 5 /* + act (generic path): store v unchanged; partial sums of ga = v * act'(aux * scale + shift) and ga * aux per (b, tile, c),
+                              * aux = the raw conv output of the layer whose activated output this launch's result is the gradient of, aux_stats =
+                              * (scale, shift) per (b, c): the reduction pass of that layer's norm backward rides in this data-gradient launch */
 
 /* ---- geometry modes ---- */
 #define W2S_MODE_CONTIG 0   /* dilation 1: one staged window serves all taps */
@@ -452,7 +455,7 @@ int w2s_norm_fold(int kind, const float* stats, int B, int C, int G, const float
 /* means [B][C][2] = per-(sample, channel) means of ga and ga * xh -> coef [nset][3][C] for w2s_norm_act_bwd_apply, dgamma / dbeta [C] (or NULL),
  * cd (or NULL) [B][C][2] = the (c, d) operand of W2S_PRO_AFFINE_BWD for every sample */
 int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, int B, int C, int G, const float* gamma, const float* beta, double L,
-                      float* coef, float* dgamma, float* dbeta, float* cd, void* stream);
+                      float* coef, float* dgamma, float* dbeta, float* cd, int y_sums, void* stream);   /* y_sums: means[..][1] is of ga * y (W2S_EPI_AFFINE_PART) */
 /* the residual join of a ConvBlock1D (blocks.py:68-70) in one pass: y = act2(act(x * scale + shift) + add) -- x = conv3's raw output, (scale, shift)
  * as for w2s_affine_act, add = downsample(x_in), act2 = the block's activation -- and its backward gs = g * act2'(act(x * scale + shift) + add),
  * the gradient of both addends.  y / gs may alias add. */

@@ -55,6 +55,8 @@ extern "C" int w2s_conv_forward(const w2s_conv_args* ap, void* stream) {
   if ((a.pro == W2S_PRO_INBWD || a.pro == W2S_PRO_INBWD_GP || a.pro >= W2S_PRO_AFFINE_BWD) && (!a.pro_bstats || !a.x2)) return W2S_EINVAL;
   if (a.pro == W2S_PRO_FIRST && (!a.x2 || a.cin != 16 || a.taps != 3 || a.stride != 1 || a.pad != 1 || a.mode != W2S_MODE_CONTIG)) return W2S_EINVAL;
   if ((a.epi == W2S_EPI_AUX_INGELU_ADD && (!a.aux || !a.aux_stats)) || (a.epi == W2S_EPI_GP && !a.aux)) return W2S_EINVAL;
+  if (a.epi < 0 || a.epi > W2S_EPI_AFFINE_PART + 4) return W2S_EINVAL;
+  if (a.epi >= W2S_EPI_AFFINE_PART && (!a.aux || !a.aux_stats || !a.part || (a.reserved & 1))) return W2S_EINVAL;   // (sums of the COMPLETE result only)
   // epilogue fusions of the transformer layer (`reserved` bits W2S_FUSE_*): only the bias epilogue implements them, and each reads the
   // operand it names -- refuse instead of faulting on a NULL aux / y2 or silently ignoring a bit
   if (a.reserved & (W2S_FUSE_ADD_DROP | W2S_FUSE_Y2_GELU_DROP | W2S_FUSE_GELU_BWD_DROP)) {

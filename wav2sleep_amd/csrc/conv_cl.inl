@@ -412,6 +412,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
       } else if (epi == W2S_EPI_STATS) {
         sA[nt] += v;
         sB[nt] += v * v;
+      } else if (epi >= W2S_EPI_AFFINE_PART) {   // generic path: sums for the norm backward of the layer below (v is stored as it is)
+        const f32x4 ax = ld4o(a.aux + ob * a.ld_aux, (unsigned)pos * (unsigned)a.ld_aux + ch);
+        const float* st = a.aux_stats + ((size_t)b * cout + ch) * 2;
+        const f32x4 s01 = ld4(st), s23 = ld4(st + 4);
+        const ProCoef kz{(f32x4){s01.x, s01.z, s23.x, s23.z}, (f32x4){s01.y, s01.w, s23.y, s23.w}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        // ga = v act'(z): the backward prologue's formula with scale 1 on the gradient and no (c, d) terms, then undo its `* k.a`
+        const f32x4 z = fma4(ax, kz.a, kz.b);
+        f32x4 d;
+        switch (epi - W2S_EPI_AFFINE_PART) {
+          case 1: d = (f32x4){z.x > 0.f ? 1.f : 0.f, z.y > 0.f ? 1.f : 0.f, z.z > 0.f ? 1.f : 0.f, z.w > 0.f ? 1.f : 0.f}; break;
+          case 2: d = (f32x4){z.x > 0.f ? 1.f : 0.01f, z.y > 0.f ? 1.f : 0.01f, z.z > 0.f ? 1.f : 0.01f, z.w > 0.f ? 1.f : 0.01f}; break;
+          case 3: d = gelu_grad4(z); break;
+          case 4: {
+            const f32x4 sg = {1.0f / (1.0f + __expf(-z.x)), 1.0f / (1.0f + __expf(-z.y)), 1.0f / (1.0f + __expf(-z.z)), 1.0f / (1.0f + __expf(-z.w))};
+            d = sg * (z * (splat4(1.f) - sg) + 1.0f);
+            break;
+          }
+          default: d = splat4(1.f);
+        }
+        const f32x4 ga = v * d;
+        sA[nt] += ga;
+        sB[nt] += ga * ax;
       }
       v = v * keep;
       if (a.reserved & 1) v += ld4o(a.y + ob * a.ldy, (unsigned)pos * (unsigned)a.ldy + ch);   // accumulate: K split over several launches (generic path)
@@ -428,7 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 8 ? W
     }
   }
 
-  if ((epi == W2S_EPI_STATS || epi == W2S_EPI_GP) && a.part) {
+  if ((epi == W2S_EPI_STATS || epi == W2S_EPI_GP || epi >= W2S_EPI_AFFINE_PART) && a.part) {
     // deterministic two-level reduction: 16 positions (shuffle) -> 4 waves (LDS) -> one partial per tile
     __syncthreads();  // LDS window no longer needed
     float* red = smem;  // [wave][ntw][g][2][4]

@@ -475,12 +475,20 @@ extern "C" int w2s_norm_fold(int kind, const float* stats, int B, int C, int G, 
 // dgamma[c] = L sum_b means[b][c][1], dbeta[c] = L sum_b means[b][c][0] (NULL for kind 0).
 __global__ void norm_bwd_coef_kernel(int kind, const float* __restrict__ means, const float* __restrict__ mr, int B, int C, int G,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, double L, float* __restrict__ coef,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cd) {
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cd, int y_sums) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double gm = gamma ? (double)gamma[c] : 1.0;
+  const int per_sample = (kind == 0 || kind == 3);
+  // y_sums: the second mean is of ga * y (the conv epilogue's W2S_EPI_AFFINE_PART sums) instead of ga * xh: xh = (y - mean) rstd
+  auto M2 = [&](int b) -> double {
+    const double e1 = means[((size_t)b * C + c) * 2], e2 = means[((size_t)b * C + c) * 2 + 1];
+    if (!y_sums) return e2;
+    const size_t q = per_sample ? (size_t)b * C + c : (size_t)c;
+    return (double)mr[2 * q + 1] * (e2 - (double)mr[2 * q] * e1);
+  };
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < B; ++b) { s1 += (double)means[((size_t)b * C + c) * 2]; s2 += (double)means[((size_t)b * C + c) * 2 + 1]; }
+  for (int b = 0; b < B; ++b) { s1 += (double)means[((size_t)b * C + c) * 2]; s2 += M2(b); }
   if (dgamma) dgamma[c] = (float)(s2 * L);
   if (dbeta) dbeta[c] = (float)(s1 * L);
   if (kind == 1 || kind == 2) {
@@ -501,13 +509,15 @@ __global__ void norm_bwd_coef_kernel(int kind, const float* __restrict__ means, 
     double m1, m2;
     if (kind == 0) {
       m1 = means[((size_t)b * C + c) * 2];
-      m2 = means[((size_t)b * C + c) * 2 + 1];
+      m2 = M2(b);
     } else {
       m1 = 0.0; m2 = 0.0;
       for (int k = 0; k < cg; ++k) {
         const double gk = gamma ? (double)gamma[c0 + k] : 1.0;
-        m1 += gk * (double)means[((size_t)b * C + c0 + k) * 2];
-        m2 += gk * (double)means[((size_t)b * C + c0 + k) * 2 + 1];
+        const size_t q = (size_t)b * C + c0 + k;
+        const double e1 = means[q * 2], e2 = means[q * 2 + 1];
+        m1 += gk * e1;
+        m2 += gk * (y_sums ? (double)mr[2 * q + 1] * (e2 - (double)mr[2 * q] * e1) : e2);
       }
       m1 /= cg; m2 /= cg;
     }
@@ -524,10 +534,10 @@ __global__ void norm_bwd_coef_kernel(int kind, const float* __restrict__ means, 
 }
 
 extern "C" int w2s_norm_bwd_coef(int kind, const float* means, const float* mr, int B, int C, int G, const float* gamma, const float* beta, double L,
-                                 float* coef, float* dgamma, float* dbeta, float* cd, void* stream) {
+                                 float* coef, float* dgamma, float* dbeta, float* cd, int y_sums, void* stream) {
   if (kind < 0 || kind > 3 || !means || !mr || !coef || B <= 0 || C <= 0 || (kind == 3 && (G <= 0 || C % G))) return W2S_EINVAL;
   hipLaunchKernelGGL(norm_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, means, mr, B, C,
-                     kind == 3 ? G : C, gamma, beta, L, coef, dgamma, dbeta, cd);
+                     kind == 3 ? G : C, gamma, beta, L, coef, dgamma, dbeta, cd, y_sums);
   W2S_CHECK_LAUNCH();
   return W2S_OK;
 }

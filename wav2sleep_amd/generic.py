@@ -197,7 +197,7 @@ class GenericForward:
                 co0 += cp
         return dW
 
-    def _dgrad(self, gy, w, *, B, L_x, L_out, stride, pad, dil, acc=None, lg=None):
+    def _dgrad(self, gy, w, *, B, L_x, L_out, stride, pad, dil, acc=None, lg=None, part_for=None):
         """gradient of the conv input: gy [B, L_out, cout], w [cout, cin, k] -> gx [B, L_x, cin] (w2s_conv_forward on the transposed weights:
         flipped taps for stride 1, W2S_MODE_UP2 for the k=3 / stride-2 conv, the even rows of gx for the 1x1 / stride-2 residual conv)."""
         cout, cin, k = w.shape
@@ -232,6 +232,15 @@ class GenericForward:
                                   ldx=cout, accumulate=q > 0 or acc is not None, **pk)
             else:
                 raise NotImplementedError(f'data gradient of kernel_size={k}, stride={stride}, dilation={dil}')
+            if part_for is not None and nchunk == 1 and acc is None:
+                # gx is the gradient of a _Lazy tensor act(y' scale + shift): the reduction pass of THAT layer's norm backward (sums of
+                # ga = gx act'(z) and ga y') rides in this launch's epilogue (W2S_EPI_AFFINE_PART) instead of re-reading gx and y'
+                a.epi, a.ld_aux = lib.EPI_AFFINE_PART + part_for.act, cin
+                a.aux, a.aux_stats = lib._f(part_for.y), lib._f(part_for.ss)
+                nt = _cdiv(L_x, lib.conv_tile_of(a))
+                part = torch.empty(B, nt, 2, cin, device=dev, dtype=torch.float32)
+                lib.set_part(a, part)
+                gx._w2s_part = (part, nt)
             lib.conv_forward(a)
         return gx
 
@@ -317,7 +326,8 @@ class GenericForward:
                 self._pgrad(wp, dW[:, :cin_w] if cin_w != cin else dW)
                 if not x_needs_grad or cin_w == 1:
                     return (None,)
-                return (self._dgrad(gy, wp.detach(), B=B, L_x=L_in, L_out=L_out, stride=stride, pad=pad, dil=dil, acc=acc, lg=lg),)
+                return (self._dgrad(gy, wp.detach(), B=B, L_x=L_in, L_out=L_out, stride=stride, pad=pad, dil=dil, acc=acc, lg=lg,
+                                    part_for=x_in if (isinstance(x_in, _Lazy) and pro != lib.PRO_NONE and x_in.scale is not None) else None),)
             self._rec(y, (x_in,), bw, acc_ok=x_needs_grad and cin_w != 1)
         return y, stats
 
@@ -378,17 +388,21 @@ class GenericForward:
         Returns gy, dgamma, dbeta (None without affine parameters)."""
         dev = y.device
         per_sample = kind in (0, 3)
-        tile = 1024
-        nt = _cdiv(L, tile)
-        part = torch.empty(B, nt, 2, Cc, device=dev, dtype=torch.float32)
-        lib.norm_act_bwd_part(g, Cc, y, Cc, mr, 2 * Cc if per_sample else 0, gamma, beta, L, B, Cc, act, 0.01, tile, part)
+        pre = getattr(g, '_w2s_part', None)   # the sums came with g, out of the data-gradient launch that produced it (sums of ga and ga y)
+        if pre is not None:
+            part, nt = pre
+        else:
+            tile = 1024
+            nt = _cdiv(L, tile)
+            part = torch.empty(B, nt, 2, Cc, device=dev, dtype=torch.float32)
+            lib.norm_act_bwd_part(g, Cc, y, Cc, mr, 2 * Cc if per_sample else 0, gamma, beta, L, B, Cc, act, 0.01, tile, part)
         means = torch.empty(B, Cc, 2, device=dev, dtype=torch.float32)
         lib.stats_finalize(part, B, nt, Cc, L, 0.0, 1, means)
         coef = torch.empty(B if per_sample else 1, 3, Cc, device=dev, dtype=torch.float32)
         dgam = torch.empty(Cc, device=dev, dtype=torch.float32) if gamma is not None else None
         dbet = torch.empty(Cc, device=dev, dtype=torch.float32) if gamma is not None else None
         cd = torch.empty(B, Cc, 2, device=dev, dtype=torch.float32) if lazy_ss is not None else None
-        lib.norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, beta, float(L), coef, dgam, dbet, cd)
+        lib.norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, beta, float(L), coef, dgam, dbet, cd, y_sums=pre is not None)
         if lazy_ss is not None:   # the convolution's data / weight gradient launches apply it on load: gy is never written
             return _LazyG(g, y, lazy_ss, cd, act), dgam, dbet
         gy = torch.empty_like(y)

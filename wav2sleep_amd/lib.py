@@ -20,6 +20,7 @@ PRO_NONE, PRO_SANITIZE, PRO_GELU, PRO_IN_GELU, PRO_INBWD, PRO_INBWD_GP, PRO_FIRS
 PRO_AFFINE = 7   # + activation code (ACT): act(x * scale + shift) on load, statistics operand = (scale, shift) per (b, c)
 PRO_AFFINE_BWD = 12   # + activation code: its backward on load (x = g, x2 = y; statistics (scale, shift), backward statistics (c, d))
 EPI_PLAIN, EPI_STATS, EPI_AUX_INGELU_ADD, EPI_BIAS, EPI_GP = range(5)
+EPI_AFFINE_PART = 5   # + activation code: the reduction pass of the layer below's norm backward in this launch's epilogue (generic path)
 MODE_CONTIG, MODE_DILATED, MODE_UP2 = range(3)
 ELT_GELU, ELT_GELU_BWD, ELT_ADD, ELT_ADD_DROP, ELT_DROP, ELT_GELU_DROP, ELT_GELU_DROP_BWD = range(7)
 FUSE_ADD_DROP, FUSE_Y2_GELU_DROP, FUSE_GELU_BWD_DROP = 2, 4, 8
@@ -748,9 +749,9 @@ def norm_fold(kind, stats, B, Cc, G, gamma, beta, run_mean, run_var, eps, moment
                               C.c_double(count), _f(scale), _f(shift), _f(mr), _f(ss), _stream()), 'w2s_norm_fold')
 
 
-def norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, beta, L, coef, dgamma, dbeta, cd=None):
+def norm_bwd_coef(kind, means, mr, B, Cc, G, gamma, beta, L, coef, dgamma, dbeta, cd=None, y_sums=False):
     _chk(load().w2s_norm_bwd_coef(kind, _f(means), _f(mr), B, Cc, G, _f(gamma), _f(beta), C.c_double(L), _f(coef), _f(dgamma), _f(dbeta), _f(cd),
-                                  _stream()), 'w2s_norm_bwd_coef')
+                                  int(y_sums), _stream()), 'w2s_norm_bwd_coef')
 
 
 def rownorm_bwd_blocks(rows) -> int:
