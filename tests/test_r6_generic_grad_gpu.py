@@ -437,3 +437,30 @@ def test_one_channel_convolution_kernels_against_torch(k, stride, pad, bias):
     wpart = torch.empty(nparts, Cc * k, device=DEV)
     lib.conv1_wgrad(gd, None, None, None, xd, wpart, B, L, L_out, Cc, k, stride, pad)
     assert rel(wpart.sum(0).view(Cc, 1, k), w.grad) < 1e-5
+
+
+@pytest.mark.parametrize('act', ['relu', 'leaky', 'gelu', 'silu', 'linear'])
+def test_reduction_sums_in_the_data_gradient_epilogue(act):
+    """W2S_EPI_AFFINE_PART + act: the conv stores its result v unchanged and leaves per-(sample, tile, channel) sums of ga = v act'(aux scale +
+    shift) and ga aux -- against torch on the stored result; and w2s_norm_bwd_coef(y_sums=1) agrees with the xh-sum form of the same step."""
+    torch.manual_seed(12)
+    B, L, cin, Cc, k = 2, 900, 32, 16, 3
+    x = torch.randn(B, L, cin, device=DEV)
+    w = (torch.randn(Cc, k, cin, device=DEV) / (cin * k) ** 0.5).contiguous()
+    aux = torch.randn(B, L, Cc, device=DEV)
+    ss = torch.stack((1 + 0.3 * torch.randn(B, Cc), 0.4 * torch.randn(B, Cc)), dim=2).contiguous().to(DEV)
+    y = torch.empty(B, L, Cc, device=DEV)
+    a = lib.conv_args(x=x, w=w, y=y, B=B, L_in=L, L_out=L, cin=cin, cout=Cc, taps=k, stride=1, pad=1, epi=lib.EPI_AFFINE_PART + lib.ACT[act], aux=aux,
+                      aux_stats=ss, ld_aux=Cc)
+    nt = -(-L // lib.conv_tile_of(a))
+    part = torch.empty(B, nt, 2, Cc, device=DEV)
+    lib.set_part(a, part)
+    lib.conv_forward(a)
+    y0 = torch.empty_like(y)
+    lib.conv_forward(lib.conv_args(x=x, w=w, y=y0, B=B, L_in=L, L_out=L, cin=cin, cout=Cc, taps=k, stride=1, pad=1))
+    assert torch.equal(y, y0)                                   # the result itself is stored unchanged
+    z = (aux.cpu() * ss.cpu()[:, None, :, 0] + ss.cpu()[:, None, :, 1]).requires_grad_(True)
+    ACTS[act](z).backward(torch.ones_like(z))
+    ga = y.cpu() * z.grad
+    assert rel(part[:, :, 0].sum(1), ga.sum(1)) < 1e-5
+    assert rel(part[:, :, 1].sum(1), (ga * aux.cpu()).sum(1)) < 1e-5
