@@ -442,7 +442,8 @@ def test_one_channel_convolution_kernels_against_torch(k, stride, pad, bias):
 @pytest.mark.parametrize('act', ['relu', 'leaky', 'gelu', 'silu', 'linear'])
 def test_reduction_sums_in_the_data_gradient_epilogue(act):
     """W2S_EPI_AFFINE_PART + act: the conv stores its result v unchanged and leaves per-(sample, tile, channel) sums of ga = v act'(aux scale +
-    shift) and ga aux -- against torch on the stored result; and w2s_norm_bwd_coef(y_sums=1) agrees with the xh-sum form of the same step."""
+    shift) and ga aux -- against torch on the stored result (what w2s_norm_bwd_coef(y_sums=1) makes of them is covered by the model-level
+    gradient tests above: every BatchNorm / GroupNorm / instance layer between two convolutions goes through it)."""
     torch.manual_seed(12)
     B, L, cin, Cc, k = 2, 900, 32, 16, 3
     x = torch.randn(B, L, cin, device=DEV)
