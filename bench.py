@@ -296,6 +296,37 @@ def host_batches(trainer, x, y, dev, warmup=2, steps=8):
             'ms_per_step_prefetched_on_side_stream': round(1000 * pre, 3), 'recordings_per_s_prefetched': round(B / pre, 2), 'steps': steps, 'warmup': warmup}
 
 
+def ppgnet_leg(W, batch, dev, warmup=2, steps=6):
+    """The reference's second trainable model, SleepPPGNet (models/ppgnet.py; 10-hour PPG inputs, BatchNorm + LeakyReLU), one full train step
+    on the generic path (wav2sleep_amd/generic.py: walker + tape over HIP kernels, GenericTrainStep) -- reported under `extra`, never as
+    `value`; a failure here is reported in place and does not touch the headline line."""
+    try:
+        from wav2sleep_amd.trainer import GenericTrainStep
+        torch.manual_seed(42)
+        model = W.SleepPPGNet().to(dev).train()
+        step = GenericTrainStep(model, lr=1e-3, scheduler=False)
+        g = torch.Generator(device=dev).manual_seed(99)
+        x = torch.randn(batch, model.INPUT_LENGTH, device=dev, generator=g)
+        y = torch.randint(0, 4, (batch, 1200), device=dev, generator=g).float()
+        for _ in range(warmup):
+            step.step(x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step.step(x, y)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res = {'workload': f'SleepPPGNet, 10-hour PPG (1 228 800 samples), batch {batch}, full train step on the generic path', 'ms_per_step': round(1000 * dt, 3),
+               'value': round(batch / dt, 3), 'unit': 'recordings/s', 'steps': steps, 'warmup': warmup, 'final_loss': round(float(out['loss']), 5),
+               'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+        del model, step, x, y, out
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:   # noqa: BLE001  (an extra leg must not cost the headline record)
+        torch.cuda.empty_cache()
+        return {'error': f'{type(e).__name__}: {e}'}
+
+
 def extra_config(W, signal_map, spe, nc, causal, batch, epochs, dev, warmup=3, steps=8):
     """One more configuration of BASELINE.json, timed the same way as the headline (synthetic inputs resident in HBM, full train step),
     AFTER the headline's timed region and on a model of its own -- reported under `extra`, never as `value`."""
@@ -543,6 +574,7 @@ def main():
         del trainer, model, x, y, out
         torch.cuda.empty_cache()
         line['extra'] = {
+            'sleep_ppgnet_b16': ppgnet_leg(W, args.batch, dev),
             'host_batches_b16': host_leg,
             'inference_b16': inference,
             'configs3_eog_b16': extra_config(W, {'EOG-L': 'EOG-L', 'EOG-R': 'EOG-R'}, {'EOG-L': 4096, 'EOG-R': 4096}, 5, False, args.batch, args.epochs, dev, 2, 6),
